@@ -1,0 +1,65 @@
+"""Weight-only GEMM oracle in numpy (test infrastructure only).
+
+Math: tests/cpp/operator/cuda/operator_gemm_lowp_test.cpp:138-219
+  C[m,n] = FT(alpha * sum_k A[m,k] * ((q[k,n] - Z[k/G,n]) * S[k/G,n]))
+(CPU_SubC_Ref / CPU_PerC_Ref / CPU_FP16W4_PerC_Ref) plus the op-level epilogue of
+GemmA16W8GPU::Forward (csrc/core/operator/general/gemm_lowp/gemm_a16w8_gpu.cpp:169-248:
+bias add, UnaryType activation).
+
+``dequant`` reproduces the per-element f32 expression ``(float(q) - float(z)) * float(s)``
+bit-exactly; the k-sum here is done in float64 ("exact" mode) - the sequential-f32 sum
+of the reference lives in oracle/c (orc_gemm_a16wx) and in oracle/_ref (the reference's own
+loop).  ``x86_bf16`` mirrors GemmOpCPU under matmul_precision=medium_bf16
+(csrc/core/operator/general/gemm/gemm_op_cpu.cpp:75-126): bf16(x) . bf16(W_deq) -> f32.
+"""
+import numpy as np
+
+from .numerics import bf16_round, ft_round
+from .quant import unpack_u4
+
+
+def dequant(q, scales, zeros, group, wbits, N=None):
+    """q: int8 [K,N] (wbits 8) or packed u8 [K,ceil(N/2)] (wbits 4). Returns f32 [K,N]."""
+    scales = np.asarray(scales, np.float32)
+    zeros = np.asarray(zeros, np.float32)
+    N = scales.shape[-1] if N is None else N
+    if wbits == 4:
+        q = unpack_u4(q, N)
+    K = q.shape[0]
+    g = K if group in (-1, None, 0) else int(group)
+    idx = np.arange(K) // g
+    return ((q.astype(np.float32) - zeros[idx]).astype(np.float32) * scales[idx]).astype(np.float32)
+
+
+def activation(v, act):
+    if act in (None, "none"):
+        return v
+    if act == "relu":
+        return np.maximum(v, 0)
+    if act == "silu":  # oneDNN eltwise_swish alpha=1 on x86 / hie SiLU functor on GPU
+        return v / (1.0 + np.exp(-v))
+    if act == "gelu_erf":
+        from math import erf
+        return 0.5 * v * (1.0 + np.vectorize(erf)(v * 0.7071067811865476))
+    if act == "gelu_tanh":
+        return 0.5 * v * (1.0 + np.tanh(0.7978845608 * (v + 0.044715 * v ** 3)))
+    raise ValueError(act)
+
+
+def gemm_a16wx(x, q, scales, zeros, group, wbits, alpha=1.0, bias=None, act=None, ft="bf16",
+               mode="exact", round_out=True):
+    """x [M,K] FT-valued. mode: 'exact' (f64 k-sum) | 'x86_bf16'. Returns f32 [M,N]."""
+    x = np.asarray(x, np.float32)
+    w = dequant(q, scales, zeros, group, wbits)
+    if mode == "x86_bf16":
+        acc = bf16_round(x).astype(np.float64) @ bf16_round(w).astype(np.float64)
+    else:
+        acc = x.astype(np.float64) @ w.astype(np.float64)
+    v = alpha * acc
+    if bias is not None:
+        v = v + np.asarray(bias, np.float64)[None, :]
+    v = activation(v, act)
+    v = v.astype(np.float32)
+    if round_out and mode != "x86_bf16":
+        v = ft_round(v, ft)
+    return v
