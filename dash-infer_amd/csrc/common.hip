@@ -1,0 +1,58 @@
+// common.hip -- version, error text and device queries of libdashinfer_hip.so
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "device_utils.h"
+
+namespace dihip {
+
+static thread_local char g_last_error[512] = "";
+
+void set_last_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+  va_end(ap);
+}
+
+int cached_num_cus() {
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+      cus = n;
+    else {
+      (void)hipGetLastError();
+      cus = 0;
+    }
+  }
+  return cus;
+}
+
+}  // namespace dihip
+
+extern "C" {
+
+const char* dihip_version(void) { return "dashinfer-hip 0.1.0 (gfx950)"; }
+
+const char* dihip_last_error(void) { return dihip::g_last_error; }
+
+int dihip_device_info(int* num_cus, int* lds_bytes_per_cu, char* name, size_t name_len) {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    dihip::set_last_error("no HIP device available");
+    return DIHIP_RUNTIME_ERROR;
+  }
+  if (num_cus) *num_cus = prop.multiProcessorCount;
+  if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+  if (name && name_len) {
+    snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  return DIHIP_SUCCESS;
+}
+
+}  // extern "C"

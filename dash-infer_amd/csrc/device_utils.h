@@ -1,0 +1,144 @@
+// device_utils.h -- shared helpers for the gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dashinfer_hip.h"
+
+namespace dihip {
+
+// ---------------------------------------------------------------- host side ----------------
+void set_last_error(const char* fmt, ...);
+
+#define DIHIP_CHECK_HIP(expr, code)                                                   \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      dihip::set_last_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr,              \
+                            hipGetErrorString(_e));                                   \
+      return (code);                                                                  \
+    }                                                                                 \
+  } while (0)
+
+#define DIHIP_REQUIRE(cond, code, ...)                                                \
+  do {                                                                                \
+    if (!(cond)) {                                                                    \
+      dihip::set_last_error(__VA_ARGS__);                                             \
+      return (code);                                                                  \
+    }                                                                                 \
+  } while (0)
+
+inline int launch_status(int code = DIHIP_RUNTIME_ERROR) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_last_error("kernel launch failed: %s", hipGetErrorString(e));
+    return code;
+  }
+  return 0;
+}
+
+int cached_num_cus();
+
+// ---------------------------------------------------------------- device side --------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+// round-to-nearest-even, NaN quieted (same as torch / the reference's host bf16)
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint32_t b) {
+  _Float16 h = __builtin_bit_cast(_Float16, (uint16_t)b);
+  return (float)h;
+}
+__device__ __forceinline__ uint32_t f32_to_f16_bits(float f) {
+  _Float16 h = (_Float16)f;  // v_cvt_f16_f32: RNE
+  return (uint32_t)__builtin_bit_cast(uint16_t, h);
+}
+
+// FT codes: DIHIP_F32=0, DIHIP_F16=1, DIHIP_BF16=2
+template <int FT>
+__device__ __forceinline__ float ft_bits_to_f32(uint32_t b) {
+  if constexpr (FT == DIHIP_BF16) return bf16_bits_to_f32(b);
+  else return f16_bits_to_f32(b);
+}
+template <int FT>
+__device__ __forceinline__ uint32_t f32_to_ft_bits(float f) {
+  if constexpr (FT == DIHIP_BF16) return f32_to_bf16_bits(f);
+  else return f32_to_f16_bits(f);
+}
+template <int FT>
+__device__ __forceinline__ float ft_round(float f) {
+  return ft_bits_to_f32<FT>(f32_to_ft_bits<FT>(f));
+}
+template <int FT>
+__device__ __forceinline__ float load_ft(const void* p, size_t i) {
+  if constexpr (FT == DIHIP_F32) return ((const float*)p)[i];
+  else return ft_bits_to_f32<FT>(((const uint16_t*)p)[i]);
+}
+template <int FT>
+__device__ __forceinline__ void store_ft(void* p, size_t i, float v) {
+  if constexpr (FT == DIHIP_F32) ((float*)p)[i] = v;
+  else ((uint16_t*)p)[i] = (uint16_t)f32_to_ft_bits<FT>(v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {  // allspark UnaryType
+    case DIHIP_ACT_TANH: return tanhf(v);
+    case DIHIP_ACT_GELU_ERF: return 0.5f * v * (1.f + erff(v * 0.70710678f));
+    case DIHIP_ACT_GELU_TANH: return 0.5f * v * (1.f + tanhf(0.7978845608f * (v + 0.044715f * v * v * v)));
+    case DIHIP_ACT_RELU: return fmaxf(v, 0.f);
+    case DIHIP_ACT_SILU: return v / (1.f + expf(-v));
+    case DIHIP_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    default: return v;
+  }
+}
+
+// In-launch split hand-off (cdna_hip_programming.md G16, counter form): every wave of the
+// block has finished its plain slab stores; returns true in ALL threads of exactly one block
+// per counter -- the last to arrive -- after an agent-scope acquire, so that it may read the
+// other blocks' slabs with plain loads.  `flag_lds` is one word of the block's single LDS array.
+__device__ __forceinline__ bool arrive_and_check_last(unsigned* counter, unsigned expected,
+                                                      unsigned* flag_lds) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = (t == expected - 1);
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      // self-reset: the counter is zero again for the next launch (graph replay safe)
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    *flag_lds = last ? 1u : 0u;
+  }
+  __syncthreads();
+  return *flag_lds != 0u;
+}
+
+}  // namespace dihip

@@ -1,0 +1,624 @@
+// gemm_lowp.hip -- C-ABI entry points, weight re-layout and launch heuristics of the
+// weight-only GEMM (include/dashinfer_hip.h section 1).
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+
+#include "gemm_lowp_launch.hpp"
+
+namespace dihip {
+
+// ------------------------------------------------------------------------------------------
+// "dihip tile-major" weight layout
+//   W4: Kp = roundup(K,128), Np = roundup(N,16); 16-byte chunk index ((nt*KT + kt)*64 + lane),
+//       lane = kb*16 + n%16, kb = (k%32)/8; dword ks = (k%128)/32 of the chunk holds the 8
+//       nibbles j = k%8 at bit 4*(j/2) + 16*(j%2).
+//   W8: Kp = roundup(K,64); chunk byte ks*8 + j = u8(q + 128), ks = (k%64)/32.
+//   padding (k >= K or n >= N) is zero.
+// (scale, zero): uint32 [Gp][Np], lo16 = scale bits, hi16 = zero bits (FT), zero padded;
+//   Gp = max(G, ceil(Kp / group)).
+// ------------------------------------------------------------------------------------------
+static inline int roundup(int v, int m) { return (v + m - 1) / m * m; }
+
+struct LowpDims {
+  int KTILE, Kp, KT, Np, NTILES, G, Gp, group;
+};
+static LowpDims lowp_dims(int wbits, int N, int K, int group_size) {
+  LowpDims d;
+  d.KTILE = wbits == 4 ? 128 : wbits == 8 ? 64 : 32;
+  d.Kp = roundup(K, d.KTILE);
+  d.KT = d.Kp / d.KTILE;
+  d.Np = roundup(N, 16);
+  d.NTILES = d.Np / 16;
+  d.group = group_size > 0 ? group_size : 0;
+  d.G = d.group ? (K + d.group - 1) / d.group : 1;
+  d.Gp = d.group ? std::max(d.G, (d.Kp + d.group - 1) / d.group) : 1;
+  return d;
+}
+
+__global__ void pack_w4_kernel(const uint8_t* __restrict__ wq, uint32_t* __restrict__ out, int N,
+                               int K, int KT, int NTILES) {
+  const size_t total = (size_t)NTILES * KT * 64 * 4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int ks = idx & 3;
+    const int lane = (idx >> 2) & 63;
+    const size_t tk = idx >> 8;
+    const int kt = (int)(tk % KT), nt = (int)(tk / KT);
+    const int n = nt * 16 + (lane & 15), kb = lane >> 4;
+    const int NP = (N + 1) / 2;
+    uint32_t d = 0;
+    if (n < N) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = kt * 128 + ks * 32 + kb * 8 + j;
+        if (k < K) {
+          const uint8_t b = wq[(size_t)k * NP + (n >> 1)];
+          const uint32_t q = (n & 1) ? (b >> 4) : (b & 0xF);  // convert_4bit.h:9-16
+          d |= q << (4 * (j >> 1) + 16 * (j & 1));
+        }
+      }
+    }
+    out[idx] = d;
+  }
+}
+
+__global__ void pack_w8_kernel(const int8_t* __restrict__ wq, uint32_t* __restrict__ out, int N,
+                               int K, int KT, int NTILES) {
+  const size_t total = (size_t)NTILES * KT * 64 * 4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int dw = idx & 3;
+    const int lane = (idx >> 2) & 63;
+    const size_t tk = idx >> 8;
+    const int kt = (int)(tk % KT), nt = (int)(tk / KT);
+    const int n = nt * 16 + (lane & 15), kb = lane >> 4;
+    const int ks = dw >> 1, j0 = (dw & 1) * 4;
+    uint32_t d = 0;
+    if (n < N) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = kt * 64 + ks * 32 + kb * 8 + j0 + j;
+        if (k < K) d |= (uint32_t)(uint8_t)((int)wq[(size_t)k * N + n] + 128) << (8 * j);
+      }
+    }
+    out[idx] = d;
+  }
+}
+
+// W16: chunk = the 8 consecutive k (FT elements) of column n for k-step kt, lane = kb*16 + n%16
+__global__ void pack_w16_kernel(const uint16_t* __restrict__ w, uint32_t* __restrict__ out, int N, int K, int KT,
+                                int NTILES) {
+  const size_t total = (size_t)NTILES * KT * 64 * 4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int dw = idx & 3;
+    const int lane = (idx >> 2) & 63;
+    const size_t tk = idx >> 8;
+    const int kt = (int)(tk % KT), nt = (int)(tk / KT);
+    const int n = nt * 16 + (lane & 15), kb = lane >> 4;
+    const int k = kt * 32 + kb * 8 + dw * 2;
+    uint32_t d = 0;
+    if (n < N) {
+      if (k < K) d |= (uint32_t)w[(size_t)k * N + n];
+      if (k + 1 < K) d |= (uint32_t)w[(size_t)(k + 1) * N + n] << 16;
+    }
+    out[idx] = d;
+  }
+}
+
+__global__ void pack_sz_kernel(const uint16_t* __restrict__ s, const uint16_t* __restrict__ z,
+                               uint32_t* __restrict__ out, int N, int Np, int G, int Gp) {
+  const size_t total = (size_t)Gp * Np;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(idx % Np), g = (int)(idx / Np);
+    uint32_t v = 0;
+    if (n < N && g < G) v = (uint32_t)s[(size_t)g * N + n] | ((uint32_t)z[(size_t)g * N + n] << 16);
+    out[idx] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch plan
+// ------------------------------------------------------------------------------------------
+struct GemmPlan {
+  int MT, NT, NTW, col_blocks, m_blocks, splitk, ktiles_per_split, kslice_tiles;
+  size_t lds_bytes, slab_bytes;
+};
+
+static GemmPlan make_plan(int wbits, int M, int N, int K, int group_size, bool dual) {
+  const LowpDims d = lowp_dims(wbits, N, K, group_size);
+  GemmPlan p;
+  p.MT = M > 16 ? 2 : 1;
+  const int rows_per_block = 16 * p.MT;
+  p.m_blocks = (M + rows_per_block - 1) / rows_per_block;
+  const int num_cus = cached_num_cus();
+  const int target_blocks = num_cus > 0 ? (num_cus * 5) / 2 : 640;
+  // tiles per wave: 4 streams/wave normally; 2 when the matrix is too narrow to fill the chip
+  p.NT = 4;
+  if (!dual && wbits != 16) {
+    const int cb4 = (d.NTILES + GEMM_WAVES * 4 - 1) / (GEMM_WAVES * 4);
+    if ((long)cb4 * p.m_blocks * d.KT < target_blocks) p.NT = 2;
+  }
+  p.NTW = dual ? p.NT / 2 : p.NT;
+  p.col_blocks = (d.NTILES + GEMM_WAVES * p.NTW - 1) / (GEMM_WAVES * p.NTW);
+  // split-K granule: whole quantisation groups, whole k-tiles
+  int granule = 1;
+  if (d.group > d.KTILE) granule = (d.group + d.KTILE - 1) / d.KTILE;
+  const int units = (d.KT + granule - 1) / granule;
+  int want = (int)std::max<long>(1, target_blocks / std::max<long>(1, (long)p.col_blocks * p.m_blocks));
+  want = std::min(want, units);
+  int units_per_split = (units + want - 1) / want;
+  p.ktiles_per_split = units_per_split * granule;
+  p.splitk = (d.KT + p.ktiles_per_split - 1) / p.ktiles_per_split;
+  // the activation slice is staged in LDS in pieces of at most ~60 KiB:
+  // (rows+1) * (kslice*KTILE + 8) * 2 bytes
+  const int rows = std::min(M, rows_per_block);
+  const int max_tiles = std::max(1, (60 * 1024 / ((rows + 1) * 2) - 8) / d.KTILE);
+  p.kslice_tiles = std::min(p.ktiles_per_split, max_tiles);
+  p.lds_bytes = GEMM_LDS_HEADER + (size_t)(rows + 1) * (p.kslice_tiles * d.KTILE + 8) * 2;
+  p.slab_bytes = p.splitk > 1 ? (size_t)p.splitk * M * (dual ? 2 : 1) * d.Np * sizeof(float) : 0;
+  return p;
+}
+
+constexpr size_t GEMM_SYNC_BYTES = 64 * 1024;  // up to 16384 (column-block x m-block) counters
+
+template <int WBITS, int FT>
+static hipError_t dispatch(const GemmPlan& p, int pro, int epi, const GemmArgs& a, dim3 grid,
+                           hipStream_t s) {
+#define CASE(MT_, NT_, PRO_, EPI_)                                                 \
+  if (p.MT == MT_ && p.NT == NT_ && pro == PRO_ && epi == EPI_)                    \
+    return launch_gemm_lowp<WBITS, FT, MT_, NT_, PRO_, EPI_>(a, grid, p.lds_bytes, s);
+  CASE(1, 2, PRO_PLAIN, EPI_STD)
+  CASE(1, 4, PRO_PLAIN, EPI_STD)
+  CASE(2, 2, PRO_PLAIN, EPI_STD)
+  CASE(2, 4, PRO_PLAIN, EPI_STD)
+  if constexpr (FT == DIHIP_BF16) {
+    CASE(1, 2, PRO_RMSNORM, EPI_STD)
+    CASE(1, 4, PRO_RMSNORM, EPI_STD)
+    CASE(1, 4, PRO_RMSNORM, EPI_SWIGLU)
+    CASE(1, 4, PRO_PLAIN, EPI_SWIGLU)
+    CASE(2, 4, PRO_PLAIN, EPI_SWIGLU)
+    CASE(1, 2, PRO_PLAIN, EPI_ADDTO)
+    CASE(1, 4, PRO_PLAIN, EPI_ADDTO)
+    CASE(2, 2, PRO_PLAIN, EPI_ADDTO)
+    CASE(2, 4, PRO_PLAIN, EPI_ADDTO)
+  }
+#undef CASE
+  return hipErrorInvalidValue;
+}
+
+template <int FT>
+static hipError_t dispatch_dense(const GemmPlan& p, int pro, int epi, const GemmArgs& a, dim3 grid, hipStream_t s) {
+#define CASE(MT_, PRO_, EPI_)                                   \
+  if (p.MT == MT_ && p.NT == 4 && pro == PRO_ && epi == EPI_)   \
+    return launch_gemm_lowp<16, FT, MT_, 4, PRO_, EPI_>(a, grid, p.lds_bytes, s);
+  CASE(1, PRO_RMSNORM, EPI_ADDTO)
+  CASE(1, PRO_PLAIN, EPI_ADDTO)
+  CASE(2, PRO_PLAIN, EPI_ADDTO)
+  CASE(1, PRO_PLAIN, EPI_STD)
+  CASE(2, PRO_PLAIN, EPI_STD)
+#undef CASE
+  return hipErrorInvalidValue;
+}
+
+struct GemmCall {
+  int wbits, dtype, pro, epi;
+  const void* x;
+  int ldx;
+  const void* gamma;
+  float eps;
+  const void *w0, *sz0, *w1, *sz1;
+  const void *bias, *residual;
+  void* y;
+  const float* h_res;
+  float* h_out;
+  int M, N, K, group_size, act;
+  float alpha;
+  void* ws;
+  size_t ws_bytes;
+  void* sync;
+};
+
+static int run_gemm(hipStream_t stream, const GemmCall& c) {
+  DIHIP_REQUIRE(c.M >= 0 && c.N > 0 && c.K > 0, DIHIP_PARAM_ERROR, "gemm_lowp: bad shape M=%d N=%d K=%d",
+                c.M, c.N, c.K);
+  if (c.M == 0) return DIHIP_SUCCESS;  // empty batch
+  DIHIP_REQUIRE(c.dtype == DIHIP_BF16 || c.dtype == DIHIP_F16, DIHIP_PARAM_ERROR,
+                "gemm_lowp: activation type must be FLOAT16 or BFLOAT16 (gemm_a16w8.cpp:21-125)");
+  DIHIP_REQUIRE(c.group_size <= 0 || c.group_size % 32 == 0, DIHIP_PARAM_ERROR,
+                "gemm_lowp: GroupSize %d must be a multiple of 32", c.group_size);
+  DIHIP_REQUIRE(c.x && c.w0 && (c.sz0 || c.wbits == 16), DIHIP_PARAM_ERROR, "gemm_lowp: null input pointer");
+  const bool dual = c.epi == EPI_SWIGLU;
+  const LowpDims d = lowp_dims(c.wbits, c.N, c.K, c.group_size);
+  const GemmPlan p = make_plan(c.wbits, c.M, c.N, c.K, c.group_size, dual);
+  DIHIP_REQUIRE((size_t)p.col_blocks * p.m_blocks * sizeof(unsigned) <= GEMM_SYNC_BYTES, DIHIP_EXCEED_LIMIT_ERROR,
+                "gemm_lowp: too many tiles for the sync buffer");
+  unsigned* counters = reinterpret_cast<unsigned*>(c.sync);
+  float* slabs = reinterpret_cast<float*>(c.ws);
+  if (p.splitk > 1) {
+    size_t need = p.slab_bytes + (c.sync ? 0 : GEMM_SYNC_BYTES);
+    DIHIP_REQUIRE(c.ws && c.ws_bytes >= need, DIHIP_MEMORY_ERROR,
+                  "gemm_lowp: workspace too small (%zu < %zu)", c.ws_bytes, need);
+    if (!c.sync) {
+      counters = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(c.ws) + p.slab_bytes);
+      DIHIP_CHECK_HIP(hipMemsetAsync(counters, 0, (size_t)p.col_blocks * p.m_blocks * sizeof(unsigned), stream),
+                      DIHIP_RUNTIME_ERROR);
+    }
+  }
+  GemmArgs a{};
+  a.w0 = reinterpret_cast<const u32x4_t*>(c.w0);
+  a.w1 = reinterpret_cast<const u32x4_t*>(c.w1);
+  a.sz0 = reinterpret_cast<const uint32_t*>(c.sz0);
+  a.sz1 = reinterpret_cast<const uint32_t*>(c.sz1);
+  a.x = c.x;
+  a.ldx = c.ldx;
+  a.gamma = c.gamma;
+  a.eps = c.eps;
+  a.slabs = slabs;
+  a.counters = counters;
+  a.bias = c.bias;
+  a.residual = c.residual;
+  a.y = c.y;
+  a.ldy = c.N;
+  a.h_res = c.h_res;
+  a.h_out = c.h_out;
+  a.alpha = c.alpha;
+  a.act = c.act;
+  a.M = c.M;
+  a.N = c.N;
+  a.K = c.K;
+  a.Np = d.Np;
+  a.KT = d.KT;
+  a.NTILES = d.NTILES;
+  a.ksteps_per_group = d.group ? d.group / 32 : (1 << 30);
+  a.splitk = p.splitk;
+  a.ktiles_per_split = p.ktiles_per_split;
+  a.kslice_tiles = p.kslice_tiles;
+  const dim3 grid(p.col_blocks, p.splitk, p.m_blocks);
+  hipError_t e = hipErrorInvalidValue;
+  if (c.wbits == 4 && c.dtype == DIHIP_BF16) e = dispatch<4, DIHIP_BF16>(p, c.pro, c.epi, a, grid, stream);
+  else if (c.wbits == 4 && c.dtype == DIHIP_F16) e = dispatch<4, DIHIP_F16>(p, c.pro, c.epi, a, grid, stream);
+  else if (c.wbits == 8 && c.dtype == DIHIP_BF16) e = dispatch<8, DIHIP_BF16>(p, c.pro, c.epi, a, grid, stream);
+  else if (c.wbits == 8 && c.dtype == DIHIP_F16) e = dispatch<8, DIHIP_F16>(p, c.pro, c.epi, a, grid, stream);
+  else if (c.wbits == 16 && c.dtype == DIHIP_BF16) e = dispatch_dense<DIHIP_BF16>(p, c.pro, c.epi, a, grid, stream);
+  else if (c.wbits == 16 && c.dtype == DIHIP_F16) e = dispatch_dense<DIHIP_F16>(p, c.pro, c.epi, a, grid, stream);
+  DIHIP_REQUIRE(e == hipSuccess, e == hipErrorInvalidValue ? DIHIP_PARAM_ERROR : DIHIP_RUNTIME_ERROR,
+                "gemm_lowp: launch failed (wbits=%d dtype=%d MT=%d NT=%d pro=%d epi=%d): %s", c.wbits, c.dtype,
+                p.MT, p.NT, c.pro, c.epi, hipGetErrorString(e));
+  return DIHIP_SUCCESS;
+}
+
+// f32 hidden rows -> FT normalised rows (used by the fused entry points when M > 4)
+template <int FT>
+__global__ __launch_bounds__(256) void rmsnorm_f32_to_ft_kernel(uint16_t* __restrict__ y, const float* __restrict__ h,
+                                                                const void* __restrict__ gamma, float eps, int cols) {
+  __shared__ float red[4];
+  const float* hr = h + (size_t)blockIdx.x * cols;
+  float ss = 0.f;
+  for (int k = threadIdx.x; k < cols; k += 256) ss += hr[k] * hr[k];
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float rstd = 1.f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)cols + eps);
+  for (int k = threadIdx.x; k < cols; k += 256)
+    y[(size_t)blockIdx.x * cols + k] = (uint16_t)f32_to_ft_bits<FT>((load_ft<FT>(gamma, k) * hr[k]) * rstd);
+}
+
+}  // namespace dihip
+
+using namespace dihip;
+
+extern "C" {
+
+size_t dihip_gemm_lowp_packed_weight_bytes(int wbits, int N, int K) {
+  if ((wbits != 4 && wbits != 8) || N <= 0 || K <= 0) return 0;
+  const LowpDims d = lowp_dims(wbits, N, K, -1);
+  return (size_t)d.NTILES * d.KT * 64 * 16;
+}
+
+size_t dihip_gemm_lowp_packed_sz_bytes(int N, int K, int group_size) {
+  if (N <= 0 || K <= 0) return 0;
+  // Kp depends on wbits only through the tile (128 vs 64): size for the larger padding
+  const LowpDims d = lowp_dims(4, N, K, group_size);
+  return (size_t)d.Gp * d.Np * 4;
+}
+
+int dihip_gemm_lowp_pack(void* stream, int wbits, const void* wq, const void* scales, const void* zeros, int N,
+                         int K, int group_size, int dtype, void* w_packed, void* sz_packed) {
+  DIHIP_REQUIRE(wbits == 4 || wbits == 8, DIHIP_PARAM_ERROR, "gemm_lowp_pack: wbits must be 4 or 8");
+  DIHIP_REQUIRE(N > 0 && K > 0 && wq && scales && zeros && w_packed && sz_packed, DIHIP_PARAM_ERROR,
+                "gemm_lowp_pack: bad argument");
+  DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16, DIHIP_PARAM_ERROR, "gemm_lowp_pack: dtype");
+  DIHIP_REQUIRE(group_size <= 0 || group_size % 32 == 0, DIHIP_PARAM_ERROR,
+                "gemm_lowp_pack: GroupSize %d must be a multiple of 32", group_size);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const LowpDims d = lowp_dims(wbits, N, K, group_size);
+  const LowpDims d4 = lowp_dims(4, N, K, group_size);
+  const size_t total = (size_t)d.NTILES * d.KT * 64 * 4;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 65535);
+  if (wbits == 4)
+    hipLaunchKernelGGL(pack_w4_kernel, dim3(blocks), dim3(256), 0, s, (const uint8_t*)wq, (uint32_t*)w_packed, N, K,
+                       d.KT, d.NTILES);
+  else
+    hipLaunchKernelGGL(pack_w8_kernel, dim3(blocks), dim3(256), 0, s, (const int8_t*)wq, (uint32_t*)w_packed, N, K,
+                       d.KT, d.NTILES);
+  const size_t sztotal = (size_t)d4.Gp * d.Np;
+  hipLaunchKernelGGL(pack_sz_kernel, dim3((int)std::min<size_t>((sztotal + 255) / 256, 65535)), dim3(256), 0, s,
+                     (const uint16_t*)scales, (const uint16_t*)zeros, (uint32_t*)sz_packed, N, d.Np, d.G, d4.Gp);
+  return launch_status();
+}
+
+size_t dihip_gemm_lowp_sync_bytes(void) { return GEMM_SYNC_BYTES; }
+
+size_t dihip_gemm_lowp_workspace_bytes(int wbits, int M, int N, int K, int group_size) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  // sized for the dual (SwiGLU) form, the self-contained counter area and the M > 4 norm buffer
+  const GemmPlan p1 = make_plan(wbits, M, N, K, group_size, false);
+  const GemmPlan p2 = make_plan(wbits, M, N, K, group_size, true);
+  return std::max(p1.slab_bytes, p2.slab_bytes) + GEMM_SYNC_BYTES + (size_t)M * K * 2 + 256;
+}
+
+static int gemm_std(void* stream, int wbits, const void* x, const void* w, const void* sz, const void* bias,
+                    const void* residual, void* y, int M, int N, int K, int group_size, int act, float alpha,
+                    void* ws, size_t ws_bytes, void* sync, int dtype) {
+  GemmCall c{};
+  c.wbits = wbits;
+  c.dtype = dtype;
+  c.pro = PRO_PLAIN;
+  c.epi = EPI_STD;
+  c.x = x;
+  c.ldx = K;
+  c.w0 = w;
+  c.sz0 = sz;
+  c.bias = bias;
+  c.residual = residual;
+  c.y = y;
+  c.M = M;
+  c.N = N;
+  c.K = K;
+  c.group_size = group_size;
+  c.act = act;
+  c.alpha = alpha;
+  c.ws = ws;
+  c.ws_bytes = ws_bytes;
+  c.sync = sync;
+  DIHIP_REQUIRE(y != nullptr || M == 0, DIHIP_PARAM_ERROR, "gemm_lowp: null output");
+  return run_gemm(reinterpret_cast<hipStream_t>(stream), c);
+}
+
+int dihip_gemm_a16w8(void* stream, const void* x, const void* w_packed, const void* sz_packed, const void* bias,
+                     const void* residual, void* y, int M, int N, int K, int group_size, int act, float alpha,
+                     void* ws, size_t ws_bytes, void* sync, int dtype) {
+  return gemm_std(stream, 8, x, w_packed, sz_packed, bias, residual, y, M, N, K, group_size, act, alpha, ws,
+                  ws_bytes, sync, dtype);
+}
+
+int dihip_gemm_a16w4(void* stream, const void* x, const void* w_packed, const void* sz_packed, const void* bias,
+                     const void* residual, void* y, int M, int N, int K, int group_size, int act, float alpha,
+                     void* ws, size_t ws_bytes, void* sync, int dtype) {
+  return gemm_std(stream, 4, x, w_packed, sz_packed, bias, residual, y, M, N, K, group_size, act, alpha, ws,
+                  ws_bytes, sync, dtype);
+}
+
+// For M > 4 the norm runs as its own small kernel into the tail of `ws`.
+static int norm_to_ws(hipStream_t s, const float* h, const void* gamma, float eps, int M, int K, int dtype, void* ws,
+                      size_t ws_bytes, int wbits, int N, int group_size, bool dual, void** xnorm, size_t* ws_left) {
+  const GemmPlan p = make_plan(wbits, M, N, K, group_size, dual);
+  const size_t off = (p.slab_bytes + 255) & ~(size_t)255;
+  DIHIP_REQUIRE(ws && ws_bytes >= off + (size_t)M * K * 2, DIHIP_MEMORY_ERROR, "fused gemm: workspace too small");
+  *xnorm = reinterpret_cast<char*>(ws) + off;
+  *ws_left = off;
+  hipLaunchKernelGGL(rmsnorm_f32_to_ft_kernel<DIHIP_BF16>, dim3(M), dim3(256), 0, s, (uint16_t*)*xnorm, h, gamma, eps,
+                     K);
+  return launch_status();
+}
+
+int dihip_fused_norm_gemm(void* stream, int wbits, const float* h, const void* gamma, float eps, const void* w_packed,
+                          const void* sz_packed, const void* bias, void* y, int M, int N, int K, int group_size,
+                          int act, void* ws, size_t ws_bytes, void* sync, int dtype) {
+  DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "fused path is bf16 only");
+  DIHIP_REQUIRE(sync != nullptr, DIHIP_PARAM_ERROR, "fused path needs a sync buffer");
+  if (M == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  GemmCall c{};
+  c.wbits = wbits;
+  c.dtype = dtype;
+  c.epi = EPI_STD;
+  c.w0 = w_packed;
+  c.sz0 = sz_packed;
+  c.bias = bias;
+  c.y = y;
+  c.M = M;
+  c.N = N;
+  c.K = K;
+  c.group_size = group_size;
+  c.act = act;
+  c.alpha = 1.f;
+  c.sync = sync;
+  c.ldx = K;
+  if (M <= 4) {
+    c.pro = PRO_RMSNORM;
+    c.x = h;
+    c.gamma = gamma;
+    c.eps = eps;
+    c.ws = ws;
+    c.ws_bytes = ws_bytes;
+  } else {
+    void* xn;
+    size_t left;
+    int st = norm_to_ws(s, h, gamma, eps, M, K, dtype, ws, ws_bytes, wbits, N, group_size, false, &xn, &left);
+    if (st) return st;
+    c.pro = PRO_PLAIN;
+    c.x = xn;
+    c.ws = ws;
+    c.ws_bytes = left;
+  }
+  return run_gemm(s, c);
+}
+
+int dihip_fused_norm_swiglu(void* stream, int wbits, const float* h, const void* gamma, float eps,
+                            const void* wg_packed, const void* szg_packed, const void* wu_packed,
+                            const void* szu_packed, void* y, int M, int N, int K, int group_size, void* ws,
+                            size_t ws_bytes, void* sync, int dtype) {
+  DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "fused path is bf16 only");
+  DIHIP_REQUIRE(sync != nullptr, DIHIP_PARAM_ERROR, "fused path needs a sync buffer");
+  if (M == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  GemmCall c{};
+  c.wbits = wbits;
+  c.dtype = dtype;
+  c.epi = EPI_SWIGLU;
+  c.w0 = wg_packed;
+  c.sz0 = szg_packed;
+  c.w1 = wu_packed;
+  c.sz1 = szu_packed;
+  c.y = y;
+  c.M = M;
+  c.N = N;
+  c.K = K;
+  c.group_size = group_size;
+  c.alpha = 1.f;
+  c.sync = sync;
+  c.ldx = K;
+  if (M <= 4) {
+    c.pro = PRO_RMSNORM;
+    c.x = h;
+    c.gamma = gamma;
+    c.eps = eps;
+    c.ws = ws;
+    c.ws_bytes = ws_bytes;
+  } else {
+    void* xn;
+    size_t left;
+    int st = norm_to_ws(s, h, gamma, eps, M, K, dtype, ws, ws_bytes, wbits, N, group_size, true, &xn, &left);
+    if (st) return st;
+    c.pro = PRO_PLAIN;
+    c.x = xn;
+    c.ws = ws;
+    c.ws_bytes = left;
+  }
+  return run_gemm(s, c);
+}
+
+int dihip_fused_gemm_addto(void* stream, int wbits, const void* x, const void* w_packed, const void* sz_packed,
+                           const float* h_res, float* h_out, int M, int N, int K, int group_size, void* ws,
+                           size_t ws_bytes, void* sync, int dtype) {
+  DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "fused path is bf16 only");
+  DIHIP_REQUIRE(sync != nullptr && h_res && h_out, DIHIP_PARAM_ERROR, "fused addto: null pointer");
+  GemmCall c{};
+  c.wbits = wbits;
+  c.dtype = dtype;
+  c.pro = PRO_PLAIN;
+  c.epi = EPI_ADDTO;
+  c.x = x;
+  c.ldx = K;
+  c.w0 = w_packed;
+  c.sz0 = sz_packed;
+  c.h_res = h_res;
+  c.h_out = h_out;
+  c.M = M;
+  c.N = N;
+  c.K = K;
+  c.group_size = group_size;
+  c.alpha = 1.f;
+  c.ws = ws;
+  c.ws_bytes = ws_bytes;
+  c.sync = sync;
+  return run_gemm(reinterpret_cast<hipStream_t>(stream), c);
+}
+
+
+// ---- unquantised 16-bit weights (lm_head / dense Gemm), same kernel family ----------------------
+size_t dihip_dense_packed_weight_bytes(int N, int K) {
+  if (N <= 0 || K <= 0) return 0;
+  const LowpDims d = lowp_dims(16, N, K, -1);
+  return (size_t)d.NTILES * d.KT * 64 * 16;
+}
+
+int dihip_dense_pack(void* stream, const void* w_kn, int N, int K, int dtype, void* w_packed) {
+  DIHIP_REQUIRE(N > 0 && K > 0 && w_kn && w_packed, DIHIP_PARAM_ERROR, "dense_pack: bad argument");
+  DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16, DIHIP_PARAM_ERROR, "dense_pack: dtype");
+  const LowpDims d = lowp_dims(16, N, K, -1);
+  const size_t total = (size_t)d.NTILES * d.KT * 64 * 4;
+  hipLaunchKernelGGL(pack_w16_kernel, dim3((int)std::min<size_t>((total + 255) / 256, 65535)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), (const uint16_t*)w_kn, (uint32_t*)w_packed, N, K, d.KT,
+                     d.NTILES);
+  return launch_status();
+}
+
+size_t dihip_dense_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const GemmPlan p = make_plan(16, M, N, K, -1, false);
+  return p.slab_bytes + GEMM_SYNC_BYTES + (size_t)M * K * 2 + 512;
+}
+
+int dihip_gemm_a16w16(void* stream, const void* x, const void* w_packed, const void* bias, const void* residual,
+                      void* y, int M, int N, int K, int act, float alpha, void* ws, size_t ws_bytes, void* sync,
+                      int dtype) {
+  GemmCall c{};
+  c.wbits = 16;
+  c.dtype = dtype;
+  c.pro = PRO_PLAIN;
+  c.epi = EPI_STD;
+  c.x = x;
+  c.ldx = K;
+  c.w0 = w_packed;
+  c.bias = bias;
+  c.residual = residual;
+  c.y = y;
+  c.M = M;
+  c.N = N;
+  c.K = K;
+  c.group_size = -1;
+  c.act = act;
+  c.alpha = alpha;
+  c.ws = ws;
+  c.ws_bytes = ws_bytes;
+  c.sync = sync;
+  return run_gemm(reinterpret_cast<hipStream_t>(stream), c);
+}
+
+int dihip_lm_head(void* stream, float* logits, const float* h, const void* gamma, float eps, const void* w_packed,
+                  int M, int N, int K, void* ws, size_t ws_bytes, void* sync, int dtype) {
+  DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16, DIHIP_PARAM_ERROR, "lm_head: dtype");
+  DIHIP_REQUIRE(logits && h && w_packed && sync, DIHIP_PARAM_ERROR, "lm_head: null pointer");
+  if (M == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  GemmCall c{};
+  c.wbits = 16;
+  c.dtype = dtype;
+  c.epi = EPI_ADDTO;
+  c.w0 = w_packed;
+  c.h_res = nullptr;
+  c.h_out = logits;
+  c.M = M;
+  c.N = N;
+  c.K = K;
+  c.group_size = -1;
+  c.alpha = 1.f;
+  c.sync = sync;
+  c.ldx = K;
+  if (gamma != nullptr && M <= 4 && dtype == DIHIP_BF16) {
+    c.pro = PRO_RMSNORM;
+    c.x = h;
+    c.gamma = gamma;
+    c.eps = eps;
+    c.ws = ws;
+    c.ws_bytes = ws_bytes;
+  } else {
+    DIHIP_REQUIRE(gamma != nullptr && dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "lm_head: needs gamma, bf16");
+    void* xn;
+    size_t left;
+    int st = norm_to_ws(s, h, gamma, eps, M, K, dtype, ws, ws_bytes, 16, N, -1, false, &xn, &left);
+    if (st) return st;
+    c.pro = PRO_PLAIN;
+    c.x = xn;
+    c.ws = ws;
+    c.ws_bytes = left;
+  }
+  return run_gemm(s, c);
+}
+
+}  // extern "C"

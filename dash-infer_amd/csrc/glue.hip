@@ -1,0 +1,210 @@
+// glue.hip -- the bandwidth-trivial ops of a decode step (include/dashinfer_hip.h section 5):
+// LayerNormNoBeta (RMSNorm), Rotary, Binary ADD, SiLU*MUL, greedy argmax, embedding lookup,
+// device-side step counter.  All vectorised 16 B per lane where the layout allows.
+#include <algorithm>
+
+#include "device_utils.h"
+
+namespace dihip {
+
+// ---- LayerNormNoBeta: y = (gamma * x) * rsqrt(mean(x^2) + eps)  (layernorm.cpp:110-157) ------
+template <int FT>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(void* __restrict__ y, const void* __restrict__ x,
+                                                      const void* __restrict__ gamma, float eps, int cols) {
+  __shared__ float red[4];
+  const size_t row = (size_t)blockIdx.x * cols;
+  float ss = 0.f;
+  for (int k = threadIdx.x; k < cols; k += 256) {
+    const float v = load_ft<FT>(x, row + k);
+    ss += v * v;
+  }
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float rstd = 1.f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)cols + eps);
+  for (int k = threadIdx.x; k < cols; k += 256)
+    store_ft<FT>(y, row + k, (load_ft<FT>(gamma, k) * load_ft<FT>(x, row + k)) * rstd);
+}
+
+// ---- Rotary (rotate-half) on the q and k heads of fused qkv rows, in place ---------------------
+// grid (rows, n + g), 64 lanes = H/2 pairs (H = 128) ; lanes >= H/2 idle for smaller heads
+template <int FT>
+__global__ __launch_bounds__(64) void rope_qk_kernel(void* qkv, const uint32_t* __restrict__ positions,
+                                                     const float* __restrict__ inv_freq, int n, int g, int H) {
+  const int row = blockIdx.x, head = blockIdx.y, d = threadIdx.x;
+  const int half = H / 2;
+  if (d >= half) return;
+  const size_t base = (size_t)row * (n + 2 * g) * H + (size_t)head * H;  // q heads then k heads
+  const float ang = (float)positions[row] * inv_freq[d];
+  float sn, cs;
+  sincosf(ang, &sn, &cs);
+  const float x1 = load_ft<FT>(qkv, base + d), x2 = load_ft<FT>(qkv, base + d + half);
+  store_ft<FT>(qkv, base + d, x1 * cs - x2 * sn);
+  store_ft<FT>(qkv, base + d + half, x2 * cs + x1 * sn);
+}
+
+template <int FT, int OP>  // OP 0: a + b ; 1: silu(a) * b
+__global__ __launch_bounds__(256) void binary_kernel(void* __restrict__ y, const void* __restrict__ a,
+                                                     const void* __restrict__ b, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+    const float va = load_ft<FT>(a, i), vb = load_ft<FT>(b, i);
+    float r;
+    if constexpr (OP == 0) {
+      r = va + vb;
+    } else {
+      // Gemm(gate) with fused SiLU produces an FT tensor, then Binary MUL (qwen_v15.py:314-335)
+      float sa = va / (1.f + expf(-va));
+      if constexpr (FT != DIHIP_F32) sa = ft_round<FT>(sa);
+      r = sa * vb;
+    }
+    store_ft<FT>(y, i, r);
+  }
+}
+
+// ---- greedy argmax (GenerateOp top_k = 1): lowest index wins ties --------------------------------
+struct ArgPair {
+  float v;
+  int i;
+};
+__device__ __forceinline__ ArgPair arg_better(ArgPair a, ArgPair b) {
+  return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+__device__ __forceinline__ ArgPair wave_argmax(ArgPair p) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ArgPair q{__shfl_xor(p.v, o, 64), __shfl_xor(p.i, o, 64)};
+    p = arg_better(p, q);
+  }
+  return p;
+}
+// stage 1: grid (blocks, M) -> partial[m][block]; stage 2: one block per row
+__global__ __launch_bounds__(256) void argmax_stage1(ArgPair* __restrict__ partial, const float* __restrict__ logits,
+                                                     int N) {
+  __shared__ ArgPair red[4];
+  const int m = blockIdx.y;
+  ArgPair best{-INFINITY, 0x7fffffff};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+    const float v = logits[(size_t)m * N + i];
+    best = arg_better(best, ArgPair{v, i});
+  }
+  best = wave_argmax(best);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ArgPair r = arg_better(arg_better(red[0], red[1]), arg_better(red[2], red[3]));
+    partial[(size_t)m * gridDim.x + blockIdx.x] = r;
+  }
+}
+__global__ __launch_bounds__(256) void argmax_stage2(int64_t* __restrict__ ids, const ArgPair* __restrict__ partial,
+                                                     int nblocks) {
+  __shared__ ArgPair red[4];
+  const int m = blockIdx.x;
+  ArgPair best{-INFINITY, 0x7fffffff};
+  for (int i = threadIdx.x; i < nblocks; i += 256) best = arg_better(best, partial[(size_t)m * nblocks + i]);
+  best = wave_argmax(best);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ArgPair r = arg_better(arg_better(red[0], red[1]), arg_better(red[2], red[3]));
+    ids[m] = (int64_t)r.i;
+  }
+}
+
+template <int FT>
+__global__ __launch_bounds__(256) void embedding_kernel(float* __restrict__ h, const int64_t* __restrict__ ids,
+                                                        const void* __restrict__ table, int K) {
+  const int m = blockIdx.x;
+  const size_t row = (size_t)ids[m] * K;
+  for (int k = threadIdx.x; k < K; k += 256) h[(size_t)m * K + k] = load_ft<FT>(table, row + k);
+}
+
+__global__ void increment_u32_kernel(uint32_t* v, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) v[i] += 1u;
+}
+
+constexpr int ARGMAX_BLOCKS = 64;
+
+}  // namespace dihip
+
+using namespace dihip;
+
+#define FT_SWITCH(dtype, BODY)                                         \
+  switch (dtype) {                                                     \
+    case DIHIP_F32: { constexpr int FT = DIHIP_F32; BODY; } break;     \
+    case DIHIP_F16: { constexpr int FT = DIHIP_F16; BODY; } break;     \
+    case DIHIP_BF16: { constexpr int FT = DIHIP_BF16; BODY; } break;   \
+    default:                                                           \
+      set_last_error("unsupported dtype %d", dtype);                   \
+      return DIHIP_PARAM_ERROR;                                        \
+  }
+
+extern "C" {
+
+int dihip_rmsnorm(void* stream, void* y, const void* x, const void* gamma, float eps, int rows, int cols, int dtype) {
+  DIHIP_REQUIRE(rows >= 0 && cols > 0 && y && x && gamma, DIHIP_PARAM_ERROR, "rmsnorm: bad argument");
+  if (rows == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  FT_SWITCH(dtype, hipLaunchKernelGGL((rmsnorm_kernel<FT>), dim3(rows), dim3(256), 0, s, y, x, gamma, eps, cols));
+  return launch_status();
+}
+
+int dihip_rope_qk(void* stream, void* qkv, const uint32_t* positions, const float* inv_freq, int rows, int num_heads,
+                  int num_groups, int head_size, int dtype) {
+  DIHIP_REQUIRE(rows >= 0 && num_heads > 0 && num_groups > 0 && qkv && positions && inv_freq, DIHIP_PARAM_ERROR,
+                "rope: bad argument");
+  DIHIP_REQUIRE(head_size > 0 && head_size <= 128 && head_size % 2 == 0, DIHIP_PARAM_ERROR, "rope: head size %d",
+                head_size);
+  if (rows == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  FT_SWITCH(dtype, hipLaunchKernelGGL((rope_qk_kernel<FT>), dim3(rows, num_heads + num_groups), dim3(64), 0, s, qkv,
+                                      positions, inv_freq, num_heads, num_groups, head_size));
+  return launch_status();
+}
+
+int dihip_binary_add(void* stream, void* y, const void* a, const void* b, size_t count, int dtype) {
+  DIHIP_REQUIRE(y && a && b, DIHIP_PARAM_ERROR, "binary_add: null pointer");
+  if (count == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int blocks = (int)std::min<size_t>((count + 255) / 256, 2048);
+  FT_SWITCH(dtype, hipLaunchKernelGGL((binary_kernel<FT, 0>), dim3(blocks), dim3(256), 0, s, y, a, b, count));
+  return launch_status();
+}
+
+int dihip_silu_mul(void* stream, void* y, const void* gate, const void* up, size_t count, int dtype) {
+  DIHIP_REQUIRE(y && gate && up, DIHIP_PARAM_ERROR, "silu_mul: null pointer");
+  if (count == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int blocks = (int)std::min<size_t>((count + 255) / 256, 2048);
+  FT_SWITCH(dtype, hipLaunchKernelGGL((binary_kernel<FT, 1>), dim3(blocks), dim3(256), 0, s, y, gate, up, count));
+  return launch_status();
+}
+
+int dihip_argmax(void* stream, int64_t* ids, const float* logits, int M, int N, void* ws, size_t ws_bytes) {
+  DIHIP_REQUIRE(M >= 0 && N > 0 && ids && logits, DIHIP_PARAM_ERROR, "argmax: bad argument");
+  if (M == 0) return DIHIP_SUCCESS;
+  DIHIP_REQUIRE(ws && ws_bytes >= (size_t)M * ARGMAX_BLOCKS * sizeof(ArgPair), DIHIP_MEMORY_ERROR,
+                "argmax: workspace needs %zu bytes", (size_t)M * ARGMAX_BLOCKS * sizeof(ArgPair));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(argmax_stage1, dim3(ARGMAX_BLOCKS, M), dim3(256), 0, s, (ArgPair*)ws, logits, N);
+  hipLaunchKernelGGL(argmax_stage2, dim3(M), dim3(256), 0, s, ids, (const ArgPair*)ws, ARGMAX_BLOCKS);
+  return launch_status();
+}
+
+int dihip_embedding(void* stream, float* h, const int64_t* ids, const void* table, int M, int K, int dtype) {
+  DIHIP_REQUIRE(M >= 0 && K > 0 && h && ids && table, DIHIP_PARAM_ERROR, "embedding: bad argument");
+  if (M == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  FT_SWITCH(dtype, hipLaunchKernelGGL((embedding_kernel<FT>), dim3(M), dim3(256), 0, s, h, ids, table, K));
+  return launch_status();
+}
+
+int dihip_increment_u32(void* stream, uint32_t* v, int count) {
+  DIHIP_REQUIRE(count >= 0 && v, DIHIP_PARAM_ERROR, "increment: bad argument");
+  if (count == 0) return DIHIP_SUCCESS;
+  hipLaunchKernelGGL(increment_u32_kernel, dim3((count + 255) / 256), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), v, count);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,574 @@
+// span_attn.hip -- paged-KV decode attention for gfx950 (include/dashinfer_hip.h section 3).
+//
+// Replaces the span-attention library's 3-5 kernel pipeline (QKGemv -> softmax -> QKVGemv ->
+// reduce, span-attention/src/attn/span_attention.hpp:145-211, with FT scores between kernels and
+// per-step host-built tile maps) by ONE fused single-pass kernel:
+//   * grid = (kv-splits, kv-groups x head-chunks, requests); every workgroup streams a
+//     contiguous token range of one request's K and V spans exactly once (16 lanes x 16 B cover
+//     one token-head row, a wave-load is 4 consecutive tokens = 1 KiB for 16-bit KV);
+//   * each KV row is dequantised once into registers and reused by all query heads of the GQA
+//     group (hpg <= 8 per workgroup, larger groups use several head chunks);
+//   * scores, the online softmax (running max / sum) and the P.V accumulation stay in f32
+//     registers; QK rows are reduced across the 16 lanes of a token with DPP row rotations;
+//   * partial (m, l, o) of the splits are merged by the last-arriving workgroup of a
+//     (request, group) with the agent-scope ticket protocol (device_utils.h) - no extra launch,
+//     no host-side handle / tile-map rebuild per step, sequence lengths are read on the device.
+#include <algorithm>
+#include <new>
+#include <type_traits>
+#include <vector>
+
+#include "device_utils.h"
+
+namespace dihip {
+
+constexpr int ATTN_THREADS = 256;
+constexpr int ATTN_TOK_PER_ITER = 64;  // 4 waves x 4 token slots x 4 tokens
+constexpr int ATTN_PSTRIDE = 132;      // floats per partial record: o[128], m, l, pad
+
+struct AttnArgs {
+  void* out;
+  const void* q;
+  const void* const* kspans;
+  const void* const* vspans;
+  const uint32_t* seq_lens;  // including the new token
+  float* partials;           // [B*n][nsplits][ATTN_PSTRIDE]
+  unsigned* counters;        // [B][g*nchunks]
+  int B, n, g, hpg, S, span_stride, nsplits, nchunks;
+  float scale;
+};
+
+// sum over the 16 lanes of a DPP row (all 16 lanes receive the total)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, true));  // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, true));  // row_ror:1
+  return v;
+}
+
+// 8 consecutive head dims (d = dc*8 ..) of one token-head, dequantised to f32
+template <int FT, int MODE>
+struct KvChunk {
+  u32x4_t raw0, raw1;  // raw1 only for f32
+  float zero, scale;
+};
+
+template <int FT, int MODE>
+__device__ __forceinline__ void kv_issue(KvChunk<FT, MODE>& c, const void* span, int grp, int pos, int g, int S, int dc) {
+  constexpr int H = 128;
+  if constexpr (MODE == DIHIP_KV_NONE) {
+    if constexpr (FT == DIHIP_F32) {
+      const u32x4_t* p = reinterpret_cast<const u32x4_t*>(reinterpret_cast<const float*>(span) + ((size_t)grp * S + pos) * H + dc * 8);
+      c.raw0 = p[0];
+      c.raw1 = p[1];
+    } else {
+      c.raw0 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(span) + ((size_t)grp * S + pos) * H + dc * 8);
+    }
+  } else {
+    constexpr int HB = MODE == DIHIP_KV_I8 ? H : H / 2;
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(span);
+    const unsigned char* d = base + ((size_t)grp * S + pos) * HB;
+    if constexpr (MODE == DIHIP_KV_I8) {
+      const u32x2_t v = *reinterpret_cast<const u32x2_t*>(d + dc * 8);
+      c.raw0 = u32x4_t{v[0], v[1], 0, 0};
+    } else {
+      c.raw0 = u32x4_t{*reinterpret_cast<const uint32_t*>(d + dc * 4), 0, 0, 0};
+    }
+    const float* params = reinterpret_cast<const float*>(base + (size_t)g * S * HB) + ((size_t)grp * S + pos) * 2;
+    const u32x2_t pz = *reinterpret_cast<const u32x2_t*>(params);
+    c.zero = __uint_as_float(pz[0]);
+    c.scale = __uint_as_float(pz[1]);
+  }
+}
+
+template <int FT, int MODE>
+__device__ __forceinline__ void kv_decode(const KvChunk<FT, MODE>& c, float (&x)[8]) {
+  if constexpr (MODE == DIHIP_KV_NONE) {
+    if constexpr (FT == DIHIP_F32) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[j] = __uint_as_float(c.raw0[j]);
+        x[4 + j] = __uint_as_float(c.raw1[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[2 * j] = ft_bits_to_f32<FT == DIHIP_F32 ? DIHIP_BF16 : FT>(c.raw0[j] & 0xFFFFu);
+        x[2 * j + 1] = ft_bits_to_f32<FT == DIHIP_F32 ? DIHIP_BF16 : FT>(c.raw0[j] >> 16);
+      }
+    }
+  } else if constexpr (MODE == DIHIP_KV_I8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int q = (int)(signed char)((c.raw0[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+      x[j] = ((float)q - c.zero) * c.scale;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned q = (c.raw0[0] >> (4 * j)) & 0xFu;  // lo nibble = even d (impl_u4.cuh:27-36)
+      x[j] = ((float)q - c.zero) * c.scale;
+    }
+  }
+}
+
+__device__ __forceinline__ float safe_exp_diff(float a, float b) {  // exp(a - b), 0 when a == -inf
+  return a == -INFINITY ? 0.f : __expf(a - b);
+}
+
+template <int FT, int MODE, int HC>
+__global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const AttnArgs a) {
+  constexpr int H = 128;
+  __shared__ __attribute__((aligned(16))) float lds[4 * HC * ATTN_PSTRIDE + 4];
+  unsigned* flag_lds = reinterpret_cast<unsigned*>(lds + 4 * HC * ATTN_PSTRIDE);
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tl = lane >> 4, dc = lane & 15;
+  const int split = blockIdx.x;
+  const int grp = blockIdx.y / a.nchunks, hc = blockIdx.y % a.nchunks;
+  const int b = blockIdx.z;
+  const int h0 = grp * a.hpg + hc * HC;
+  const int nh = min(HC, a.hpg - hc * HC);
+
+  const int len = (int)a.seq_lens[b];
+  const int tps = ((len + a.nsplits - 1) / a.nsplits + 15) & ~15;
+  const int t0 = split * tps;
+  const int t1 = min(len, t0 + tps);
+
+  // q (pre-scaled) for this lane's 8 dims of every head of the chunk
+  float qr[HC][8];
+#pragma unroll
+  for (int h = 0; h < HC; ++h) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qr[h][j] = 0.f;
+    if (h < nh) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qr[h][j] = a.scale * load_ft<FT>(a.q, ((size_t)b * a.n + h0 + h) * H + dc * 8 + j);
+    }
+  }
+  float m[HC], l[HC], o[HC][8];
+#pragma unroll
+  for (int h = 0; h < HC; ++h) {
+    m[h] = -INFINITY;
+    l[h] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[h][j] = 0.f;
+  }
+
+  const void* const* ksp = a.kspans + (size_t)b * a.span_stride;
+  const void* const* vsp = a.vspans + (size_t)b * a.span_stride;
+
+  for (int tb = t0; tb < t1; tb += ATTN_TOK_PER_ITER) {
+    KvChunk<FT, MODE> kc[4], vc[4];
+    bool valid[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = tb + i * 16 + wave * 4 + tl;
+      valid[i] = t < t1;
+      const int tt = valid[i] ? t : t0;  // clamp: keeps the address legal, result discarded
+      const int sp = tt / a.S, pos = tt - sp * a.S;
+      kv_issue<FT, MODE>(kc[i], ksp[sp], grp, pos, a.g, a.S, dc);
+      kv_issue<FT, MODE>(vc[i], vsp[sp], grp, pos, a.g, a.S, dc);
+    }
+    float s[4][HC];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float kx[8];
+      kv_decode<FT, MODE>(kc[i], kx);
+#pragma unroll
+      for (int h = 0; h < HC; ++h) {
+        float p = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p = fmaf(qr[h][j], kx[j], p);
+        p = row16_sum(p);
+        s[i][h] = valid[i] ? p : -INFINITY;
+      }
+    }
+    float pw[4][HC];
+#pragma unroll
+    for (int h = 0; h < HC; ++h) {
+      float mn = fmaxf(fmaxf(s[0][h], s[1][h]), fmaxf(s[2][h], s[3][h]));
+      mn = fmaxf(mn, m[h]);
+      const float corr = safe_exp_diff(m[h], mn);
+      float ps = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        pw[i][h] = safe_exp_diff(s[i][h], mn);
+        ps += pw[i][h];
+      }
+      l[h] = l[h] * corr + ps;
+      m[h] = mn;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[h][j] *= corr;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float vx[8];
+      kv_decode<FT, MODE>(vc[i], vx);
+#pragma unroll
+      for (int h = 0; h < HC; ++h)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[h][j] = fmaf(pw[i][h], vx[j], o[h][j]);
+    }
+  }
+
+  // ---- merge the 4 token slots of the wave (lanes with equal dc) ---------------------------
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+#pragma unroll
+    for (int h = 0; h < HC; ++h) {
+      const float mo = __shfl_xor(m[h], off, 64), lo = __shfl_xor(l[h], off, 64);
+      const float mn = fmaxf(m[h], mo);
+      const float ca = safe_exp_diff(m[h], mn), cb = safe_exp_diff(mo, mn);
+      l[h] = l[h] * ca + lo * cb;
+      m[h] = mn;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[h][j] = o[h][j] * ca + __shfl_xor(o[h][j], off, 64) * cb;
+    }
+  }
+  // ---- merge the 4 waves through LDS ---------------------------------------------------------
+  if (tl == 0) {
+#pragma unroll
+    for (int h = 0; h < HC; ++h) {
+      float* rec = lds + (wave * HC + h) * ATTN_PSTRIDE;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rec[dc * 8 + j] = o[h][j];
+      if (dc == 0) {
+        rec[H] = m[h];
+        rec[H + 1] = l[h];
+      }
+    }
+  }
+  __syncthreads();
+  // thread -> (head, dim) pairs of the block result; kept in registers for the epilogue
+  constexpr int PER_THREAD = (HC * H + ATTN_THREADS - 1) / ATTN_THREADS;
+  float bo[PER_THREAD], bm[PER_THREAD], bl[PER_THREAD];
+#pragma unroll
+  for (int e = 0; e < PER_THREAD; ++e) {
+    const int idx = tid + e * ATTN_THREADS;
+    const int h = idx / H, d = idx - h * H;
+    bo[e] = 0.f;
+    bm[e] = -INFINITY;
+    bl[e] = 0.f;
+    if (h < nh) {
+      float mm = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) mm = fmaxf(mm, lds[(w * HC + h) * ATTN_PSTRIDE + H]);
+      float ll = 0.f, oo = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float* rec = lds + (w * HC + h) * ATTN_PSTRIDE;
+        const float c = safe_exp_diff(rec[H], mm);
+        ll += rec[H + 1] * c;
+        oo += rec[d] * c;
+      }
+      bo[e] = oo;
+      bm[e] = mm;
+      bl[e] = ll;
+    }
+  }
+
+  if (a.nsplits > 1) {
+#pragma unroll
+    for (int e = 0; e < PER_THREAD; ++e) {
+      const int idx = tid + e * ATTN_THREADS;
+      const int h = idx / H, d = idx - h * H;
+      if (h < nh) {
+        float* rec = a.partials + (((size_t)b * a.n + h0 + h) * a.nsplits + split) * ATTN_PSTRIDE;
+        rec[d] = bo[e];
+        if (d == 0) {
+          rec[H] = bm[e];
+          rec[H + 1] = bl[e];
+        }
+      }
+    }
+    unsigned* counter = a.counters + (size_t)b * gridDim.y + blockIdx.y;
+    if (!arrive_and_check_last(counter, (unsigned)a.nsplits, flag_lds)) return;
+#pragma unroll
+    for (int e = 0; e < PER_THREAD; ++e) {
+      const int idx = tid + e * ATTN_THREADS;
+      const int h = idx / H, d = idx - h * H;
+      if (h < nh) {
+        const float* base = a.partials + ((size_t)b * a.n + h0 + h) * a.nsplits * ATTN_PSTRIDE;
+        float mm = -INFINITY;
+        for (int sidx = 0; sidx < a.nsplits; ++sidx) mm = fmaxf(mm, base[(size_t)sidx * ATTN_PSTRIDE + H]);
+        float ll = 0.f, oo = 0.f;
+        for (int sidx = 0; sidx < a.nsplits; ++sidx) {
+          const float* rec = base + (size_t)sidx * ATTN_PSTRIDE;
+          const float c = safe_exp_diff(rec[H], mm);
+          ll += rec[H + 1] * c;
+          oo += rec[d] * c;
+        }
+        bo[e] = oo;
+        bl[e] = ll;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < PER_THREAD; ++e) {
+    const int idx = tid + e * ATTN_THREADS;
+    const int h = idx / H, d = idx - h * H;
+    if (h < nh) store_ft<FT>(a.out, ((size_t)b * a.n + h0 + h) * H + d, bl[e] > 0.f ? bo[e] / bl[e] : 0.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+struct AttnPlan {
+  int HC, nchunks, nsplits;
+  size_t partial_bytes;
+};
+
+static AttnPlan attn_plan(int batch, int n_heads, int n_groups, int max_seq_len, int num_cus) {
+  AttnPlan p;
+  const int hpg = n_heads / n_groups;
+  p.HC = hpg <= 1 ? 1 : hpg <= 2 ? 2 : hpg <= 4 ? 4 : 8;
+  p.nchunks = (hpg + p.HC - 1) / p.HC;
+  if (num_cus <= 0) num_cus = cached_num_cus();
+  if (num_cus <= 0) num_cus = 256;
+  const long base = (long)batch * n_groups * p.nchunks;
+  long want = (2L * num_cus + base - 1) / base;
+  const long max_splits = std::max(1, (max_seq_len + ATTN_TOK_PER_ITER - 1) / ATTN_TOK_PER_ITER);
+  p.nsplits = (int)std::max<long>(1, std::min<long>(std::min<long>(want, max_splits), 256));
+  p.partial_bytes = p.nsplits > 1 ? (size_t)batch * n_heads * p.nsplits * ATTN_PSTRIDE * sizeof(float) : 0;
+  return p;
+}
+
+template <int FT, int MODE>
+static void launch_attn(const AttnPlan& p, const AttnArgs& a, dim3 grid, hipStream_t s) {
+  switch (p.HC) {
+    case 1: hipLaunchKernelGGL((span_attn_decode_kernel<FT, MODE, 1>), grid, dim3(ATTN_THREADS), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((span_attn_decode_kernel<FT, MODE, 2>), grid, dim3(ATTN_THREADS), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((span_attn_decode_kernel<FT, MODE, 4>), grid, dim3(ATTN_THREADS), 0, s, a); break;
+    default: hipLaunchKernelGGL((span_attn_decode_kernel<FT, MODE, 8>), grid, dim3(ATTN_THREADS), 0, s, a); break;
+  }
+}
+
+static bool span_len_valid(int S) { return S == 16 || S == 32 || S == 64 || S == 128; }
+
+// returns 0 or an SaStatus-like code: 3 param, 1 hip
+static int run_decode(hipStream_t s, void* out, const void* q, const void* const* ks, const void* const* vs,
+                      const uint32_t* seq_lens_dev, int batch, int n, int g, int H, int S, int span_stride,
+                      int max_seq_len, int mode, int dtype, float scale, void* ws, size_t ws_bytes, unsigned* counters,
+                      int num_cus) {
+  if (H != 128) {
+    set_last_error("span_attn: unsupported head size %d (only 128, dispatch.hpp:45-57)", H);
+    return DIHIP_SA_PARAM_ERROR;
+  }
+  if (n % g != 0 || n / g > 32) {
+    set_last_error("span_attn: nHeads/nGroups must be an integer <= 32 (got %d/%d)", n, g);
+    return DIHIP_SA_PARAM_ERROR;
+  }
+  if (!span_len_valid(S)) {
+    set_last_error("span_attn: span length %d not in {16,32,64,128}", S);
+    return DIHIP_SA_PARAM_ERROR;
+  }
+  const AttnPlan p = attn_plan(batch, n, g, max_seq_len, num_cus);
+  if (p.nsplits > 1 && (ws == nullptr || ws_bytes < p.partial_bytes || counters == nullptr)) {
+    set_last_error("span_attn: workspace too small (%zu < %zu)", ws_bytes, p.partial_bytes);
+    return DIHIP_SA_PARAM_ERROR;
+  }
+  AttnArgs a{};
+  a.out = out;
+  a.q = q;
+  a.kspans = ks;
+  a.vspans = vs;
+  a.seq_lens = seq_lens_dev;
+  a.partials = reinterpret_cast<float*>(ws);
+  a.counters = counters;
+  a.B = batch;
+  a.n = n;
+  a.g = g;
+  a.hpg = n / g;
+  a.S = S;
+  a.span_stride = span_stride;
+  a.nsplits = p.nsplits;
+  a.nchunks = p.nchunks;
+  a.scale = scale;
+  const dim3 grid(p.nsplits, g * p.nchunks, batch);
+  bool ok = true;
+#define GO(FTV, MODEV)                                      \
+  if (dtype == FTV && mode == MODEV) {                      \
+    launch_attn<FTV, MODEV>(p, a, grid, s);                 \
+  } else
+  GO(DIHIP_BF16, DIHIP_KV_NONE)
+  GO(DIHIP_BF16, DIHIP_KV_I8)
+  GO(DIHIP_BF16, DIHIP_KV_U4)
+  GO(DIHIP_F16, DIHIP_KV_NONE)
+  GO(DIHIP_F16, DIHIP_KV_I8)
+  GO(DIHIP_F16, DIHIP_KV_U4)
+  GO(DIHIP_F32, DIHIP_KV_NONE)
+  GO(DIHIP_F32, DIHIP_KV_I8)
+  GO(DIHIP_F32, DIHIP_KV_U4) { ok = false; }
+#undef GO
+  if (!ok) {
+    set_last_error("span_attn: unsupported dtype %d / kv mode %d", dtype, mode);
+    return DIHIP_SA_PARAM_ERROR;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_last_error("span_attn: launch failed: %s", hipGetErrorString(e));
+    return DIHIP_SA_HIP_ERROR;
+  }
+  return DIHIP_SA_SUCCESS;
+}
+
+}  // namespace dihip
+
+using namespace dihip;
+
+// handle of the reference-shaped API (span::SpanAttnHandle, span-attention/src/attn/span_attn_handle.hpp)
+struct dihip_span_attn_handle {
+  int dtype, kv_mode, batch, n_heads, n_groups, head_size, span_len, n_spans, num_cus, max_len;
+  std::vector<uint32_t> seq_lens;
+  size_t lens_bytes, counter_bytes, partial_bytes;
+};
+
+extern "C" {
+
+size_t dihip_span_attn_sync_bytes(int batch, int n_heads) {
+  if (batch <= 0 || n_heads <= 0) return 0;
+  return ((size_t)batch * n_heads * sizeof(unsigned) + 255) & ~(size_t)255;
+}
+
+size_t dihip_span_attn_decode_workspace_bytes(int batch, int n_heads, int head_size, int max_seq_len, int num_cus) {
+  if (batch <= 0 || n_heads <= 0 || max_seq_len <= 0) return 0;
+  (void)head_size;
+  // worst case over the group count: g = 1 .. n gives at most 256 splits
+  size_t worst = 0;
+  for (int g = 1; g <= n_heads; ++g) {
+    if (n_heads % g) continue;
+    worst = std::max(worst, attn_plan(batch, n_heads, g, max_seq_len, num_cus).partial_bytes);
+  }
+  return worst + 256;
+}
+
+int dihip_span_attn_decode(void* stream, void* output, const void* query, const void* const* k_span_array,
+                           const void* const* v_span_array, const uint32_t* seq_lens_dev, int batch, int n_heads,
+                           int n_groups, int head_size, int span_len, int n_spans_per_request, int max_seq_len,
+                           int kv_mode, int dtype, float qk_scale, void* ws, size_t ws_bytes, void* sync) {
+  DIHIP_REQUIRE(batch >= 0 && n_heads > 0 && n_groups > 0 && head_size > 0 && n_spans_per_request > 0 &&
+                    max_seq_len > 0,
+                DIHIP_PARAM_ERROR, "span_attn_decode: invalid parameter");
+  DIHIP_REQUIRE(output && query && k_span_array && v_span_array && seq_lens_dev, DIHIP_PARAM_ERROR,
+                "span_attn_decode: null pointer");
+  if (batch == 0) return DIHIP_SUCCESS;
+  int st = run_decode(reinterpret_cast<hipStream_t>(stream), output, query, k_span_array, v_span_array, seq_lens_dev,
+                      batch, n_heads, n_groups, head_size, span_len, n_spans_per_request, max_seq_len, kv_mode, dtype,
+                      qk_scale, ws, ws_bytes, reinterpret_cast<unsigned*>(sync), 0);
+  if (st == DIHIP_SA_SUCCESS) return DIHIP_SUCCESS;
+  return st == DIHIP_SA_PARAM_ERROR ? DIHIP_PARAM_ERROR : DIHIP_RUNTIME_ERROR;
+}
+
+// ---- reference-shaped handle API (span_attn.h:108-175, api.cpp:41-177) --------------------------
+int dihip_span_attn_create_handle(dihip_span_attn_handle_t* handle, int dtype, int kv_mode, int batch, int n_heads,
+                                  int n_groups, int head_size, int span_len, int n_spans_per_request,
+                                  const int* seq_len_host, int num_cus) {
+  if (batch <= 0 || n_heads <= 0 || n_groups <= 0 || head_size <= 0 || span_len <= 0 || n_spans_per_request <= 0) {
+    set_last_error("CreateHandle: invalid parameter");
+    return DIHIP_SA_PARAM_ERROR;
+  }
+  if (n_heads % n_groups != 0) {
+    set_last_error("CreateHandle: nHeads should be a multiple of nGroups");
+    return DIHIP_SA_PARAM_ERROR;
+  }
+  if (seq_len_host == nullptr || handle == nullptr) {
+    set_last_error("CreateHandle: null pointer");
+    return DIHIP_SA_PARAM_ERROR;
+  }
+  if (dtype != DIHIP_F32 && dtype != DIHIP_F16 && dtype != DIHIP_BF16) return DIHIP_SA_PARAM_ERROR;
+  if (kv_mode != DIHIP_KV_NONE && kv_mode != DIHIP_KV_I8 && kv_mode != DIHIP_KV_U4) return DIHIP_SA_PARAM_ERROR;
+  if (head_size != 128) {  // span_attention.hpp:75-84
+    set_last_error("unsupported head size: %d", head_size);
+    return DIHIP_SA_PARAM_ERROR;
+  }
+  int max_len = 0;
+  for (int i = 0; i < batch; ++i) {
+    if (seq_len_host[i] < 0) return DIHIP_SA_PARAM_ERROR;
+    max_len = std::max(max_len, seq_len_host[i]);
+  }
+  // the reference caps a request at 65535 tiles of 64 tokens (tile_mapping.hpp:42-49)
+  if ((long)(max_len + 63) / 64 > 65535) {
+    set_last_error("CreateHandle: sequence length %d exceeds the tile limit", max_len);
+    return DIHIP_SA_EXCEED_LIMIT_ERROR;
+  }
+  dihip_span_attn_handle* h = new (std::nothrow) dihip_span_attn_handle();
+  if (!h) return DIHIP_SA_RUNTIME_ERROR;
+  h->dtype = dtype;
+  h->kv_mode = kv_mode;
+  h->batch = batch;
+  h->n_heads = n_heads;
+  h->n_groups = n_groups;
+  h->head_size = head_size;
+  h->span_len = span_len;
+  h->n_spans = n_spans_per_request;
+  h->num_cus = num_cus;
+  h->max_len = std::max(1, max_len);
+  h->seq_lens.assign(seq_len_host, seq_len_host + batch);
+  h->lens_bytes = ((size_t)batch * sizeof(uint32_t) + 255) & ~(size_t)255;
+  h->counter_bytes = dihip_span_attn_sync_bytes(batch, n_heads);
+  h->partial_bytes = attn_plan(batch, n_heads, n_groups, h->max_len, num_cus).partial_bytes;
+  *handle = h;
+  return DIHIP_SA_SUCCESS;
+}
+
+int dihip_span_attn_destroy_handle(dihip_span_attn_handle_t handle) {
+  if (handle == nullptr) return DIHIP_SA_PARAM_ERROR;
+  delete handle;
+  return DIHIP_SA_SUCCESS;
+}
+
+int dihip_span_attn_host_workspace_bytes(size_t* bytes, dihip_span_attn_handle_t handle) {
+  if (handle == nullptr || bytes == nullptr) return DIHIP_SA_PARAM_ERROR;
+  *bytes = handle->lens_bytes;  // staging of the sequence lengths for the async H2D copy
+  return DIHIP_SA_SUCCESS;
+}
+
+int dihip_span_attn_device_workspace_bytes(size_t* bytes, dihip_span_attn_handle_t handle) {
+  if (handle == nullptr || bytes == nullptr) return DIHIP_SA_PARAM_ERROR;
+  *bytes = handle->lens_bytes + handle->counter_bytes + handle->partial_bytes + 256;
+  return DIHIP_SA_SUCCESS;
+}
+
+int dihip_span_attn_run(void* output, const void* query, const void* const* k_span_array,
+                        const void* const* v_span_array, void* device_ws, size_t device_ws_bytes, void* host_ws,
+                        size_t host_ws_bytes, float qk_scale, dihip_span_attn_handle_t handle, void* stream) {
+  if (handle == nullptr) return DIHIP_SA_PARAM_ERROR;
+  if (output == nullptr || query == nullptr || k_span_array == nullptr || v_span_array == nullptr) {
+    set_last_error("Run: input and output pointers must not be null");
+    return DIHIP_SA_PARAM_ERROR;
+  }
+  if ((device_ws == nullptr && device_ws_bytes > 0) || (host_ws == nullptr && host_ws_bytes > 0)) {
+    set_last_error("Run: workspace pointer must not be null if its size is non-zero");
+    return DIHIP_SA_PARAM_ERROR;
+  }
+  // parameter checks that the reference defers to Run (dispatch.hpp:45-81)
+  if (handle->n_heads / handle->n_groups > 32 || !span_len_valid(handle->span_len)) {
+    set_last_error("Run: unsupported heads-per-group %d or span length %d", handle->n_heads / handle->n_groups,
+                   handle->span_len);
+    return DIHIP_SA_PARAM_ERROR;
+  }
+  size_t need = 0;
+  dihip_span_attn_device_workspace_bytes(&need, handle);
+  if (device_ws == nullptr || device_ws_bytes < need || host_ws == nullptr || host_ws_bytes < handle->lens_bytes) {
+    set_last_error("Run: workspace too small");
+    return DIHIP_SA_PARAM_ERROR;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  char* dws = reinterpret_cast<char*>(device_ws);
+  uint32_t* lens_dev = reinterpret_cast<uint32_t*>(dws);
+  unsigned* counters = reinterpret_cast<unsigned*>(dws + handle->lens_bytes);
+  void* partials = dws + handle->lens_bytes + handle->counter_bytes;
+  std::copy(handle->seq_lens.begin(), handle->seq_lens.end(), reinterpret_cast<uint32_t*>(host_ws));
+  if (hipMemcpyAsync(lens_dev, host_ws, (size_t)handle->batch * sizeof(uint32_t), hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemsetAsync(counters, 0, handle->counter_bytes, s) != hipSuccess) {
+    (void)hipGetLastError();
+    return DIHIP_SA_HIP_ERROR;
+  }
+  return run_decode(s, output, query, k_span_array, v_span_array, lens_dev, handle->batch, handle->n_heads,
+                    handle->n_groups, handle->head_size, handle->span_len, handle->n_spans, handle->max_len,
+                    handle->kv_mode, handle->dtype, qk_scale, partials, handle->partial_bytes, counters,
+                    handle->num_cus);
+}
+
+}  // extern "C"

@@ -1,0 +1,281 @@
+"""Tensor-level wrappers over the C-ABI (plumbing for tests, smoke and bench).
+
+torch is used for device memory and streams only; every computation is a call into
+lib/libdashinfer_hip.so through `capi`.  No CPU fallback exists here.
+"""
+import ctypes as C
+
+import torch
+
+from . import capi
+from .capi import check, lib
+
+_DT = {torch.float32: capi.F32, torch.float16: capi.F16, torch.bfloat16: capi.BF16}
+
+
+def dt_code(t):
+    return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+
+
+def cur_stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Scratch:
+    """Shared scratch ("workspace" tensor of the allspark tensor map) + the zero-initialised
+    arrival-counter buffer the split-K / split-KV kernels keep zero between launches."""
+
+    def __init__(self, ws_bytes, device="cuda", sync_bytes=None):
+        self.ws = torch.empty(max(int(ws_bytes), 256), dtype=torch.uint8, device=device)
+        nsync = int(sync_bytes if sync_bytes is not None else lib().dihip_gemm_lowp_sync_bytes())
+        self.sync = torch.zeros(nsync, dtype=torch.uint8, device=device)
+
+    @property
+    def ws_bytes(self):
+        return self.ws.numel()
+
+
+class PackedWeight:
+    """A weight in dihip tile-major order (+ interleaved (scale, zero) words for wbits 4/8)."""
+
+    def __init__(self, wbits, N, K, group, dtype, w, szp):
+        self.wbits, self.N, self.K, self.group, self.dtype, self.w, self.sz = wbits, N, K, group, dtype, w, szp
+
+    @property
+    def nbytes(self):
+        return self.w.numel() + (self.sz.numel() * 4 if self.sz is not None else 0)
+
+
+def pack_lowp(wq, scales, zeros, group, wbits):
+    """wq: int8 [K,N] (wbits 8) or uint8 [K,ceil(N/2)] (wbits 4) on the GPU; scales/zeros FT [G,N]."""
+    K = wq.shape[0]
+    N = scales.shape[-1]
+    group = -1 if group in (None, 0, -1) else int(group)
+    l = lib()
+    w = torch.empty(l.dihip_gemm_lowp_packed_weight_bytes(wbits, N, K), dtype=torch.uint8, device=wq.device)
+    szp = torch.empty(l.dihip_gemm_lowp_packed_sz_bytes(N, K, group) // 4, dtype=torch.int32, device=wq.device)
+    check(l.dihip_gemm_lowp_pack(cur_stream(), wbits, ptr(wq.contiguous()), ptr(scales.contiguous()),
+                                 ptr(zeros.contiguous()), N, K, group, dt_code(scales), ptr(w), ptr(szp)),
+          "dihip_gemm_lowp_pack")
+    return PackedWeight(wbits, N, K, group, scales.dtype, w, szp)
+
+
+def pack_dense(w_kn):
+    K, N = w_kn.shape
+    l = lib()
+    w = torch.empty(l.dihip_dense_packed_weight_bytes(N, K), dtype=torch.uint8, device=w_kn.device)
+    check(l.dihip_dense_pack(cur_stream(), ptr(w_kn.contiguous()), N, K, dt_code(w_kn), ptr(w)), "dihip_dense_pack")
+    return PackedWeight(16, N, K, -1, w_kn.dtype, w, None)
+
+
+def lowp_workspace_bytes(wbits, M, N, K, group):
+    return int(lib().dihip_gemm_lowp_workspace_bytes(wbits, M, N, K, -1 if group in (None, 0) else group))
+
+
+def gemm_lowp(x, pw, bias=None, residual=None, act=None, alpha=1.0, scratch=None, use_sync=True):
+    """op GemmA16W8 / GemmA16W4: x FT [..., K] -> FT [..., N]."""
+    M = x.numel() // pw.K
+    y = torch.empty(*x.shape[:-1], pw.N, dtype=x.dtype, device=x.device)
+    if scratch is None:
+        scratch = Scratch(lowp_workspace_bytes(pw.wbits, max(M, 1), pw.N, pw.K, pw.group), x.device)
+    fn = lib().dihip_gemm_a16w8 if pw.wbits == 8 else lib().dihip_gemm_a16w4
+    check(fn(cur_stream(), ptr(x), ptr(pw.w), ptr(pw.sz), ptr(bias), ptr(residual), ptr(y), M, pw.N, pw.K, pw.group,
+             capi.ACT[act], float(alpha), ptr(scratch.ws), scratch.ws_bytes, ptr(scratch.sync) if use_sync else None,
+             dt_code(x)), "dihip_gemm_a16wX")
+    return y
+
+
+def gemm_dense(x, pw, bias=None, residual=None, act=None, alpha=1.0, scratch=None):
+    M = x.numel() // pw.K
+    y = torch.empty(*x.shape[:-1], pw.N, dtype=x.dtype, device=x.device)
+    if scratch is None:
+        scratch = Scratch(lib().dihip_dense_workspace_bytes(max(M, 1), pw.N, pw.K), x.device)
+    check(lib().dihip_gemm_a16w16(cur_stream(), ptr(x), ptr(pw.w), ptr(bias), ptr(residual), ptr(y), M, pw.N, pw.K,
+                                  capi.ACT[act], float(alpha), ptr(scratch.ws), scratch.ws_bytes, ptr(scratch.sync),
+                                  dt_code(x)), "dihip_gemm_a16w16")
+    return y
+
+
+def fused_norm_gemm(h, gamma, eps, pw, bias, scratch, act=None, out=None):
+    M = h.shape[0]
+    y = out if out is not None else torch.empty(M, pw.N, dtype=pw.dtype, device=h.device)
+    check(lib().dihip_fused_norm_gemm(cur_stream(), pw.wbits, ptr(h), ptr(gamma), float(eps), ptr(pw.w), ptr(pw.sz),
+                                      ptr(bias), ptr(y), M, pw.N, pw.K, pw.group, capi.ACT[act], ptr(scratch.ws),
+                                      scratch.ws_bytes, ptr(scratch.sync), dt_code(pw.dtype)), "dihip_fused_norm_gemm")
+    return y
+
+
+def fused_norm_swiglu(h, gamma, eps, pg, pu, scratch, out=None):
+    M = h.shape[0]
+    y = out if out is not None else torch.empty(M, pg.N, dtype=pg.dtype, device=h.device)
+    check(lib().dihip_fused_norm_swiglu(cur_stream(), pg.wbits, ptr(h), ptr(gamma), float(eps), ptr(pg.w), ptr(pg.sz),
+                                        ptr(pu.w), ptr(pu.sz), ptr(y), M, pg.N, pg.K, pg.group, ptr(scratch.ws),
+                                        scratch.ws_bytes, ptr(scratch.sync), dt_code(pg.dtype)),
+          "dihip_fused_norm_swiglu")
+    return y
+
+
+def fused_gemm_addto(x, pw, h_res, scratch, out=None):
+    M = x.shape[0]
+    h_out = out if out is not None else torch.empty(M, pw.N, dtype=torch.float32, device=x.device)
+    check(lib().dihip_fused_gemm_addto(cur_stream(), pw.wbits, ptr(x), ptr(pw.w), ptr(pw.sz), ptr(h_res), ptr(h_out),
+                                       M, pw.N, pw.K, pw.group, ptr(scratch.ws), scratch.ws_bytes, ptr(scratch.sync),
+                                       dt_code(x)), "dihip_fused_gemm_addto")
+    return h_out
+
+
+def lm_head(h, gamma, eps, pw, scratch, out=None):
+    M = h.shape[0]
+    logits = out if out is not None else torch.empty(M, pw.N, dtype=torch.float32, device=h.device)
+    check(lib().dihip_lm_head(cur_stream(), ptr(logits), ptr(h), ptr(gamma), float(eps), ptr(pw.w), M, pw.N, pw.K,
+                              ptr(scratch.ws), scratch.ws_bytes, ptr(scratch.sync), dt_code(pw.dtype)), "dihip_lm_head")
+    return logits
+
+
+# ------------------------------------------------------------------------------ KV spans ----
+def span_bytes(g, S, H, mode, dtype):
+    return int(lib().dihip_span_bytes(g, S, H, capi.KV[mode], dt_code(dtype)))
+
+
+class SpanPool:
+    """Device pool of KV spans handed out in a strided (non-contiguous) order, like the
+    reference's span-attention test (test_quant_none.cpp:479-506).  Stands in for the
+    reference's CacheFrameManager / CacheSpanManager (out of scope, host code)."""
+
+    def __init__(self, num_spans, g, S, H, mode, dtype, device="cuda", stride=7):
+        self.nbytes = span_bytes(g, S, H, mode, dtype)
+        self.aligned = (self.nbytes + 255) // 256 * 256
+        self.pool = torch.zeros(num_spans * self.aligned, dtype=torch.uint8, device=device)
+        self.g, self.S, self.H, self.mode, self.dtype = g, S, H, mode, dtype
+        from math import gcd
+        while gcd(stride, num_spans) != 1:
+            stride += 1
+        order = [(i * stride) % num_spans for i in range(num_spans)]
+        self.free = order
+
+    def alloc(self):
+        idx = self.free.pop(0)
+        return self.pool.data_ptr() + idx * self.aligned, idx
+
+    def span_view(self, idx):
+        return self.pool[idx * self.aligned: idx * self.aligned + self.nbytes]
+
+
+class KVCacheSet:
+    """Per-batch span pointer tables for K and V ([B][span_stride] device int64) for one layer."""
+
+    def __init__(self, pool, batch, max_spans):
+        self.pool, self.batch, self.max_spans = pool, batch, max_spans
+        self.k_idx = [[] for _ in range(batch)]
+        self.v_idx = [[] for _ in range(batch)]
+        self.k_host = torch.zeros(batch, max_spans, dtype=torch.int64)
+        self.v_host = torch.zeros(batch, max_spans, dtype=torch.int64)
+        self.k_ptrs = torch.zeros(batch, max_spans, dtype=torch.int64, device=pool.pool.device)
+        self.v_ptrs = torch.zeros(batch, max_spans, dtype=torch.int64, device=pool.pool.device)
+
+    def ensure(self, b, ntokens):
+        S = self.pool.S
+        changed = False
+        while len(self.k_idx[b]) * S < ntokens:
+            kp, ki = self.pool.alloc()
+            vp, vi = self.pool.alloc()
+            self.k_host[b, len(self.k_idx[b])] = kp
+            self.v_host[b, len(self.v_idx[b])] = vp
+            self.k_idx[b].append(ki)
+            self.v_idx[b].append(vi)
+            changed = True
+        return changed
+
+    def sync(self):
+        self.k_ptrs.copy_(self.k_host)
+        self.v_ptrs.copy_(self.v_host)
+
+
+def kv_append(kv, q_out, qkv, old_lens, n, g, H):
+    pool = kv.pool
+    B = qkv.shape[0]
+    check(lib().dihip_kv_append(cur_stream(), ptr(kv.k_ptrs), ptr(kv.v_ptrs), ptr(q_out), ptr(qkv), ptr(old_lens), B, n,
+                                g, H, pool.S, kv.max_spans, capi.KV[pool.mode], dt_code(qkv)), "dihip_kv_append")
+
+
+def rope_kv_append(kv, q_out, qkv, old_lens, inv_freq, n, g, H):
+    pool = kv.pool
+    B = qkv.shape[0]
+    check(lib().dihip_rope_kv_append(cur_stream(), ptr(kv.k_ptrs), ptr(kv.v_ptrs), ptr(q_out), ptr(qkv), ptr(old_lens),
+                                     ptr(inv_freq), B, n, g, H, pool.S, kv.max_spans, capi.KV[pool.mode], dt_code(qkv)),
+          "dihip_rope_kv_append")
+
+
+def kv_context_copy(span_ptrs_row, src, src_stride, seq_len, start_pos, g, H, S, mode):
+    check(lib().dihip_kv_context_copy(cur_stream(), ptr(span_ptrs_row), ptr(src), src_stride, seq_len, start_pos, g, H,
+                                      S, capi.KV[mode], dt_code(src)), "dihip_kv_context_copy")
+
+
+def kv_prefix_gather(dst, span_ptrs_row, prefix_len, g, H, S, mode):
+    check(lib().dihip_kv_prefix_gather(cur_stream(), ptr(dst), ptr(span_ptrs_row), prefix_len, g, H, S, capi.KV[mode],
+                                       dt_code(dst)), "dihip_kv_prefix_gather")
+
+
+def span_attn_workspace(batch, n, H, max_len):
+    return int(lib().dihip_span_attn_decode_workspace_bytes(batch, n, H, max_len, 0))
+
+
+def span_attn_decode(q, kv, seq_lens_dev, n, g, H, max_len, scale, ws, sync, out=None):
+    B = q.shape[0]
+    out = out if out is not None else torch.empty(B, n * H, dtype=q.dtype, device=q.device)
+    pool = kv.pool
+    check(lib().dihip_span_attn_decode(cur_stream(), ptr(out), ptr(q), ptr(kv.k_ptrs), ptr(kv.v_ptrs), ptr(seq_lens_dev),
+                                       B, n, g, H, pool.S, kv.max_spans, max_len, capi.KV[pool.mode], dt_code(q),
+                                       float(scale), ptr(ws), ws.numel() if ws is not None else 0, ptr(sync)),
+          "dihip_span_attn_decode")
+    return out
+
+
+# ------------------------------------------------------------------------------ glue --------
+def rmsnorm(x, gamma, eps):
+    y = torch.empty_like(x)
+    check(lib().dihip_rmsnorm(cur_stream(), ptr(y), ptr(x), ptr(gamma), float(eps), x.numel() // x.shape[-1],
+                              x.shape[-1], dt_code(x)), "dihip_rmsnorm")
+    return y
+
+
+def rope_qk_(qkv, positions, inv_freq, n, g, H):
+    check(lib().dihip_rope_qk(cur_stream(), ptr(qkv), ptr(positions), ptr(inv_freq), qkv.shape[0], n, g, H,
+                              dt_code(qkv)), "dihip_rope_qk")
+    return qkv
+
+
+def binary_add(a, b):
+    y = torch.empty_like(a)
+    check(lib().dihip_binary_add(cur_stream(), ptr(y), ptr(a), ptr(b), a.numel(), dt_code(a)), "dihip_binary_add")
+    return y
+
+
+def silu_mul(gate, up):
+    y = torch.empty_like(gate)
+    check(lib().dihip_silu_mul(cur_stream(), ptr(y), ptr(gate), ptr(up), gate.numel(), dt_code(gate)), "dihip_silu_mul")
+    return y
+
+
+def argmax(logits, ws=None, out=None):
+    M, N = logits.shape
+    ids = out if out is not None else torch.empty(M, dtype=torch.int64, device=logits.device)
+    ws = ws if ws is not None else torch.empty(M * 64 * 8, dtype=torch.uint8, device=logits.device)
+    check(lib().dihip_argmax(cur_stream(), ptr(ids), ptr(logits), M, N, ptr(ws), ws.numel()), "dihip_argmax")
+    return ids
+
+
+def embedding(ids, table, out=None):
+    M, K = ids.shape[0], table.shape[1]
+    h = out if out is not None else torch.empty(M, K, dtype=torch.float32, device=table.device)
+    check(lib().dihip_embedding(cur_stream(), ptr(h), ptr(ids), ptr(table), M, K, dt_code(table)), "dihip_embedding")
+    return h
+
+
+def increment_u32_(v):
+    check(lib().dihip_increment_u32(cur_stream(), ptr(v), v.numel()), "dihip_increment_u32")
+    return v

@@ -1,0 +1,263 @@
+/* dashinfer_hip.h -- C-ABI of the MI355X (gfx950) device backend for DashInfer's quantized
+ * decode hot path.  This is the drop-in boundary: the host-side C++ operators
+ * (dash-infer_amd/host, mirroring allspark::AsOperator) and any foreign-language binding call
+ * ONLY these functions.  Plain pointers and sizes, no C++ / torch types, no exceptions.
+ *
+ * Conventions
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Every call only
+ *     ENQUEUES work on that stream (graph-capturable: no allocation, no synchronisation) unless
+ *     stated otherwise.
+ *   - all data pointers are DEVICE pointers unless the name ends in `_host`.
+ *   - return value: an allspark::AsStatus value (csrc/interface/allspark_check.h:62-80) for
+ *     dihip_* operator entry points; a span::SaStatus value
+ *     (span-attention/include/spanattn/span_attn.h:50-66) for dihip_span_attn_* (the reference's
+ *     inner library boundary keeps its own status enum).
+ *   - `dtype` is the activation type "FT": DIHIP_F32 / DIHIP_F16 / DIHIP_BF16, numbered like
+ *     span::DataType (span_attn.h:27-34).
+ */
+#ifndef DASHINFER_HIP_H_
+#define DASHINFER_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status: allspark::AsStatus (csrc/interface/allspark_check.h:62-80) ------------------- */
+#define DIHIP_SUCCESS 0
+#define DIHIP_UNKNOWN_ERROR 1
+#define DIHIP_PARAM_ERROR 2
+#define DIHIP_MEMORY_ERROR 4
+#define DIHIP_RUNTIME_ERROR 5
+#define DIHIP_EXCEED_LIMIT_ERROR 7
+#define DIHIP_INVALID_CALL_ERROR 8
+
+/* ---- status: span::SaStatus (span_attn.h:50-66) ------------------------------------------- */
+#define DIHIP_SA_SUCCESS 0
+#define DIHIP_SA_HIP_ERROR 1 /* CUDA_ERROR in the reference */
+#define DIHIP_SA_RUNTIME_ERROR 2
+#define DIHIP_SA_PARAM_ERROR 3
+#define DIHIP_SA_EXCEED_LIMIT_ERROR 4
+#define DIHIP_SA_INTERNAL_ERROR 5
+#define DIHIP_SA_UNKNOWN_ERROR 127
+
+/* ---- enums --------------------------------------------------------------------------------- */
+enum { DIHIP_F32 = 0, DIHIP_F16 = 1, DIHIP_BF16 = 2 };          /* span::DataType */
+enum { DIHIP_KV_NONE = 0, DIHIP_KV_I8 = 1, DIHIP_KV_U4 = 2 };   /* span::QuantMode */
+/* activation = allspark UnaryType (csrc/proto/allspark.proto:68-76) */
+enum {
+  DIHIP_ACT_NONE = 0, DIHIP_ACT_TANH = 1, DIHIP_ACT_GELU_ERF = 2, DIHIP_ACT_GELU_TANH = 3,
+  DIHIP_ACT_RELU = 4, DIHIP_ACT_SILU = 5, DIHIP_ACT_SIGMOID = 6
+};
+
+const char* dihip_version(void);
+/* last error text of the calling thread (never NULL) */
+const char* dihip_last_error(void);
+/* number of CUs / name of the current device; returns DIHIP_RUNTIME_ERROR without a GPU */
+int dihip_device_info(int* num_cus, int* lds_bytes_per_cu, char* name, size_t name_len);
+
+/* =============================================================================================
+ * 1. Weight-only GEMM / GEMV  (replaces GemmA16W8GPU / GemmA16W4GPU and their launchers:
+ *    csrc/core/operator/general/gemm_lowp/gemm_a16w8_gpu.cpp:30-267, gemm_a16w4_gpu.cpp:26-230,
+ *    csrc/core/kernel/cuda/gemm_lowp/gemm_a16w8_kernel.h:232-529, gemm_a16w4_kernel.h:53-273)
+ *
+ *    Y[M,N] = act(alpha * X[M,K] . ((Wq[K,N] - Z[G,N]) (.) S[G,N]) + bias[N]) (+ residual[M,N])
+ *
+ *    Like the reference (N32K16 reorder + u8 bias at InitV2, gemm_a16w8_gpu.cpp:421-473) the
+ *    weights are re-laid-out once at init into an MFMA-fragment-major tile order
+ *    ("dihip tile-major") by dihip_gemm_lowp_pack(); the GEMM entry points
+ *    take the packed buffers.
+ * ========================================================================================== */
+
+/* bytes of the packed weight / packed (scale,zero) buffers for a [K,N] weight */
+size_t dihip_gemm_lowp_packed_weight_bytes(int wbits, int N, int K);
+size_t dihip_gemm_lowp_packed_sz_bytes(int N, int K, int group_size);
+
+/* Re-layout on the device (InitV2-time; enqueued on `stream`).
+ *   wbits 8: wq = int8  [K, N]          row-major   (quantization_utils.py:158-217 output)
+ *   wbits 4: wq = uint8 [K, ceil(N/2)]  lo nibble = even n (gemm_a16w4.h:25-33)
+ *   scales/zeros: FT [G, N], G = 1 (group_size <= 0, per-channel) or ceil(K/group_size)
+ *   group_size: -1 or a multiple of 32 (the reference GPU kernels want %32 as well).
+ * w_packed / sz_packed: outputs of the sizes returned above.                                  */
+int dihip_gemm_lowp_pack(void* stream, int wbits, const void* wq, const void* scales,
+                         const void* zeros, int N, int K, int group_size, int dtype,
+                         void* w_packed, void* sz_packed);
+
+/* scratch (split-K slabs; contents need no initialisation) and sync (arrival counters; must be
+ * zero-filled ONCE by the owner, the kernels leave it zero) sizes */
+size_t dihip_gemm_lowp_workspace_bytes(int wbits, int M, int N, int K, int group_size);
+size_t dihip_gemm_lowp_sync_bytes(void);
+
+/* op type "GemmA16W8" / "GemmA16W4".  x: FT [M, K] (row stride K); y: FT [M, N].
+ * bias: FT [N] or NULL; residual: FT [M, N] added after the activation, or NULL (the Gemm op's
+ * fused binary ADD, python/pyhie/allspark/model/qwen_v15.py:296-300); act: DIHIP_ACT_*.
+ * sync: >= dihip_gemm_lowp_sync_bytes() zero-initialised device bytes owned by the op, or NULL
+ * (then the arrival counters live in `ws` and are cleared with a memset node per call).       */
+int dihip_gemm_a16w8(void* stream, const void* x, const void* w_packed, const void* sz_packed,
+                     const void* bias, const void* residual, void* y, int M, int N, int K,
+                     int group_size, int act, float alpha, void* ws, size_t ws_bytes, void* sync,
+                     int dtype);
+int dihip_gemm_a16w4(void* stream, const void* x, const void* w_packed, const void* sz_packed,
+                     const void* bias, const void* residual, void* y, int M, int N, int K,
+                     int group_size, int act, float alpha, void* ws, size_t ws_bytes, void* sync,
+                     int dtype);
+
+/* Fused decode-step variants (the glue the reference runs as separate
+ * LayerNormNoBeta / Binary / Unary ops, python/pyhie/allspark/model/qwen_v15.py:210-381).
+ * hidden stream `h` is f32 [M, K]; all use bf16 weights metadata; M <= 32.
+ *   norm_gemm   : y = act(rmsnorm(h; gamma, eps) . W + bias)                 y: FT [M,N]
+ *   norm_swiglu : y = FT(silu(rmsnorm(h).Wg)) * FT(rmsnorm(h).Wu)            y: FT [M,N]
+ *   gemm_addto  : h_out[M,N] (f32) = h_res + x . W   (f32, no rounding)           x: FT [M,K]   */
+int dihip_fused_norm_gemm(void* stream, int wbits, const float* h, const void* gamma, float eps,
+                          const void* w_packed, const void* sz_packed, const void* bias, void* y,
+                          int M, int N, int K, int group_size, int act, void* ws, size_t ws_bytes,
+                          void* sync, int dtype);
+int dihip_fused_norm_swiglu(void* stream, int wbits, const float* h, const void* gamma, float eps,
+                            const void* wg_packed, const void* szg_packed, const void* wu_packed,
+                            const void* szu_packed, void* y, int M, int N, int K, int group_size,
+                            void* ws, size_t ws_bytes, void* sync, int dtype);
+int dihip_fused_gemm_addto(void* stream, int wbits, const void* x, const void* w_packed,
+                           const void* sz_packed, const float* h_res, float* h_out, int M, int N,
+                           int K, int group_size, void* ws, size_t ws_bytes, void* sync, int dtype);
+
+/* =============================================================================================
+ * 2. KV span writers (replace csrc/core/kernel/cuda/cuda_kernel_span_cache.h:12-41)
+ *    span layout (bit-compatible with the reference, decoder_cache_append.cuh:33-87):
+ *      [g][S][H*bits/8] data, then (quantised modes) [g][S]{f32 zero, f32 scale}
+ * ========================================================================================== */
+size_t dihip_span_bytes(int num_groups, int span_len, int head_size, int kv_mode, int dtype);
+
+/* DecoderCacheAppendLauncher: split the fused qkv rows [B, (n+2g)*H] into q_out [B, n*H] and
+ * append this step's K/V head vectors at token position old_seq_lens[b] of request b.
+ * k_spans / v_spans: device arrays [B][span_stride] of span pointers.                         */
+int dihip_kv_append(void* stream, void* const* k_spans, void* const* v_spans, void* q_out,
+                    const void* qkv, const uint32_t* old_seq_lens, int batch, int num_heads,
+                    int num_groups, int head_size, int span_len, int span_stride, int kv_mode,
+                    int dtype);
+
+/* Rotary + DecoderCacheAppend in one launch (decode-step glue): identical
+ * results to dihip_rope_qk (positions = old_seq_lens) followed by dihip_kv_append.  H == 128.    */
+int dihip_rope_kv_append(void* stream, void* const* k_spans, void* const* v_spans, void* q_out,
+                         const void* qkv, const uint32_t* old_seq_lens, const float* inv_freq,
+                         int batch, int num_heads, int num_groups, int head_size, int span_len,
+                         int span_stride, int kv_mode, int dtype);
+
+/* ContextSpanCopyLauncher: contiguous prefill K or V [seq_len, g, H] (row stride `src_stride`
+ * elements) -> the request's spans, starting at token `start_pos` (a multiple of span_len).   */
+int dihip_kv_context_copy(void* stream, void* const* spans, const void* src, int src_stride,
+                          int seq_len, int start_pos, int num_groups, int head_size, int span_len,
+                          int kv_mode, int dtype);
+
+/* PrefixCacheCopyLauncher: spans -> contiguous dst [prefix_len, g, H] FT with dequantisation.  */
+int dihip_kv_prefix_gather(void* stream, void* dst, void* const* spans, int prefix_len,
+                           int num_groups, int head_size, int span_len, int kv_mode, int dtype);
+
+/* SpanToContCopyLauncher / ContToSpanCopyLauncher: raw byte gather/scatter of whole spans.     */
+int dihip_span_gather(void* stream, void* dst_cont, void* const* spans, int num_spans,
+                      size_t span_bytes);
+int dihip_span_scatter(void* stream, void* const* spans, const void* src_cont, int num_spans,
+                       size_t span_bytes);
+
+/* =============================================================================================
+ * 3. SpanAttention decode (replaces span::CreateHandle / Run / ..., span_attn.h:108-175)
+ *    Same argument meaning and SaStatus error behaviour as the reference library; the
+ *    cudaDeviceProp argument is replaced by the number of CUs (0 = query the current device).
+ *    Constraints as the reference: head_size == 128, nHeads % nGroups == 0,
+ *    nHeads/nGroups <= 32, span_len in {16,32,64,128}.
+ * ========================================================================================== */
+typedef struct dihip_span_attn_handle* dihip_span_attn_handle_t;
+
+int dihip_span_attn_create_handle(dihip_span_attn_handle_t* handle, int dtype, int kv_mode,
+                                  int batch, int n_heads, int n_groups, int head_size,
+                                  int span_len, int n_spans_per_request, const int* seq_len_host,
+                                  int num_cus);
+int dihip_span_attn_destroy_handle(dihip_span_attn_handle_t handle);
+int dihip_span_attn_host_workspace_bytes(size_t* bytes, dihip_span_attn_handle_t handle);
+int dihip_span_attn_device_workspace_bytes(size_t* bytes, dihip_span_attn_handle_t handle);
+/* output/query: FT [batch, n_heads, head_size]; k/v_span_array: device [batch][n_spans_per_request] */
+int dihip_span_attn_run(void* output, const void* query, const void* const* k_span_array,
+                        const void* const* v_span_array, void* device_ws, size_t device_ws_bytes,
+                        void* host_ws, size_t host_ws_bytes, float qk_scale,
+                        dihip_span_attn_handle_t handle, void* stream);
+
+/* Handle-free form for graph replay: sequence lengths (INCLUDING the new token) are read from
+ * device memory, so nothing on the host changes between decode steps.  max_seq_len bounds the
+ * split count (and the workspace).  Returns an AsStatus value.                                */
+size_t dihip_span_attn_decode_workspace_bytes(int batch, int n_heads, int head_size,
+                                              int max_seq_len, int num_cus);
+int dihip_span_attn_decode(void* stream, void* output, const void* query,
+                           const void* const* k_span_array, const void* const* v_span_array,
+                           const uint32_t* seq_lens_dev, int batch, int n_heads, int n_groups,
+                           int head_size, int span_len, int n_spans_per_request, int max_seq_len,
+                           int kv_mode, int dtype, float qk_scale, void* ws, size_t ws_bytes,
+                           void* sync);
+size_t dihip_span_attn_sync_bytes(int batch, int n_heads);
+
+/* =============================================================================================
+ * 4. Prefill attention (replaces xformer_prefill_attention,
+ *    csrc/core/kernel/cuda/xformer_mha/xformer_mha.h:26-41): causal softmax(alpha Q K^T) V, GQA.
+ *    q: [seq_q, n, H] with row stride q_stride elements; k/v: [seq_k, g, H] with row stride
+ *    kv_stride (INTERLEAVED qkv rows: q_stride = kv_stride = (n+2g)*H; MIX: k/v contiguous).
+ *    query i attends keys j <= i + (seq_k - seq_q).  out: FT [seq_q, n*H].
+ * ========================================================================================== */
+int dihip_prefill_attn(void* stream, void* out, const void* q, const void* k, const void* v,
+                       int seq_q, int seq_k, int q_stride, int kv_stride, int n_heads,
+                       int n_groups, int head_size, int causal, float alpha, int dtype);
+
+/* =============================================================================================
+ * 5. Glue ops for an end-to-end decode step
+ * ========================================================================================== */
+/* LayerNormNoBeta (csrc/core/kernel/cuda/layernorm.cu): y = (gamma*x) * rsqrt(mean(x^2)+eps)  */
+int dihip_rmsnorm(void* stream, void* y, const void* x, const void* gamma, float eps, int rows,
+                  int cols, int dtype);
+/* Rotary on the q and k heads of fused qkv rows [rows, (n+2g)*H] in place, rotate-half
+ * convention (csrc/core/kernel/cpu/rotary.cpp:22-106); positions[rows] on device; inv_freq[H/2] */
+int dihip_rope_qk(void* stream, void* qkv, const uint32_t* positions, const float* inv_freq,
+                  int rows, int num_heads, int num_groups, int head_size, int dtype);
+/* Binary ADD / MUL and SiLU*MUL on FT tensors */
+int dihip_binary_add(void* stream, void* y, const void* a, const void* b, size_t count, int dtype);
+int dihip_silu_mul(void* stream, void* y, const void* gate, const void* up, size_t count, int dtype);
+/* Unquantised 16-bit weights run through the same MFMA kernel family as the weight-only GEMM:
+ * the [K, N] weight is re-laid-out once into dihip tile-major order (dihip_dense_pack).
+ *   dihip_gemm_a16w16 : op type "Gemm" semantics, y = act(alpha x.W + bias) (+ residual)
+ *   dihip_lm_head     : logits f32 [M, N] = rmsnorm(h; gamma, eps) . W   (final LayerNormNoBeta +
+ *                       lm_head Gemm of python/pyhie/allspark/model/qwen_v15.py:383-388 fused)   */
+size_t dihip_dense_packed_weight_bytes(int N, int K);
+int dihip_dense_pack(void* stream, const void* w_kn, int N, int K, int dtype, void* w_packed);
+size_t dihip_dense_workspace_bytes(int M, int N, int K);
+int dihip_gemm_a16w16(void* stream, const void* x, const void* w_packed, const void* bias,
+                      const void* residual, void* y, int M, int N, int K, int act, float alpha,
+                      void* ws, size_t ws_bytes, void* sync, int dtype);
+int dihip_lm_head(void* stream, float* logits, const float* h, const void* gamma, float eps,
+                  const void* w_packed, int M, int N, int K, void* ws, size_t ws_bytes, void* sync,
+                  int dtype);
+/* greedy sampling (GenerateOp top_k = 1): ids[m] = argmax_n logits[m, n] (lowest index on ties) */
+int dihip_argmax(void* stream, int64_t* ids, const float* logits, int M, int N, void* ws,
+                 size_t ws_bytes);
+/* embedding lookup into the f32 hidden stream: h[m,:] = float(table[ids[m],:])                */
+int dihip_embedding(void* stream, float* h, const int64_t* ids, const void* table, int M, int K,
+                    int dtype);
+/* seq_lens[b] += 1 (device-side step counter for graph replay) */
+int dihip_increment_u32(void* stream, uint32_t* v, int count);
+
+/* =============================================================================================
+ * 6. Tensor-parallel all-reduce (replaces AllReduceOp's ncclAllReduce,
+ *    csrc/core/operator/nccl/allreduce/allreduce_op.cpp:84-92).  `comm` is an ncclComm_t (RCCL)
+ *    passed as void*.  In-place capable.  Unlike the reference it does NOT host-synchronise.
+ * ========================================================================================== */
+int dihip_rccl_unique_id(void* id128_host);
+int dihip_rccl_comm_init_rank(void** comm, int nranks, const void* id128_host, int rank);
+int dihip_rccl_comm_destroy(void* comm);
+int dihip_allreduce_sum(void* comm, void* stream, const void* in, void* out, size_t count,
+                        int dtype);
+/* AllGatherOp (csrc/core/operator/nccl/allgather/allgather_op.cpp:40-42): every rank contributes
+ * `bytes_per_rank` bytes; out holds nranks * bytes_per_rank in rank order.                     */
+int dihip_allgather_bytes(void* comm, void* stream, const void* in, void* out,
+                          size_t bytes_per_rank);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DASHINFER_HIP_H_ */

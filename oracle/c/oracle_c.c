@@ -86,11 +86,13 @@ static inline float wq_at(const void* B, int k, int n, int N, int wbits) {
 }
 
 static float apply_act(float v, int act) {
-  switch (act) { /* UnaryType, csrc/proto/allspark.proto */
-    case 1: return v > 0.f ? v : 0.f;
+  switch (act) { /* UnaryType values, csrc/proto/allspark.proto:68-76 */
+    case 1: return tanhf(v);
     case 2: return 0.5f * v * (1.f + erff(v * 0.70710678f));
     case 3: return 0.5f * v * (1.f + tanhf(0.7978845608f * (v + 0.044715f * v * v * v)));
-    case 4: return v / (1.f + expf(-v));
+    case 4: return v > 0.f ? v : 0.f;
+    case 5: return v / (1.f + expf(-v));
+    case 6: return 1.f / (1.f + expf(-v));
     default: return v;
   }
 }

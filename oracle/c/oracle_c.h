@@ -22,7 +22,8 @@ float orc_round_ft(float x, int ft);
  * accumulation over k exactly as CPU_SubC_Ref / CPU_PerC_Ref.  A,S,Z must already hold
  * FT-representable values; wbits 8: B is int8 [K,N]; wbits 4: B is packed u8 [K,ceil(N/2)].
  * group <= 0 -> per-channel.  Then (our op-level extension, gemm_a16w8_gpu.cpp:169-248):
- * + bias[n], activation (0 none, 1 relu, 2 gelu-erf, 3 gelu-tanh, 4 silu), rounded to FT. */
+ * + bias[n], activation = UnaryType value of csrc/proto/allspark.proto:68-76 (0 none, 1 tanh,
+ * 2 gelu-erf, 3 gelu-tanh, 4 relu, 5 silu, 6 sigmoid), rounded to FT. */
 int orc_gemm_a16wx(const float* A, const void* B, const float* S, const float* Z,
                    const float* bias, float* C, int M, int N, int K, int group, int wbits,
                    float alpha, int act, int ft);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _REFDIR = os.path.join(_HERE, "_ref")
 FT_CODE = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f16": 2, "fp16": 2, "float16": 2}
 KV_CODE = {"none": 0, "i8": 1, "u4": 2}
-ACT_CODE = {None: 0, "none": 0, "relu": 1, "gelu_erf": 2, "gelu_tanh": 3, "silu": 4}
+ACT_CODE = {None: 0, "none": 0, "tanh": 1, "gelu_erf": 2, "gelu_tanh": 3, "relu": 4, "silu": 5, "sigmoid": 6}
 
 _fp = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 

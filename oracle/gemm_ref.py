@@ -36,6 +36,10 @@ def activation(v, act):
         return v
     if act == "relu":
         return np.maximum(v, 0)
+    if act == "tanh":
+        return np.tanh(v)
+    if act == "sigmoid":
+        return 1.0 / (1.0 + np.exp(-v))
     if act == "silu":  # oneDNN eltwise_swish alpha=1 on x86 / hie SiLU functor on GPU
         return v / (1.0 + np.exp(-v))
     if act == "gelu_erf":

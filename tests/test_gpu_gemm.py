@@ -1,0 +1,294 @@
+"""GPU parity of the weight-only GEMM/GEMV (through the C-ABI) against the oracle.
+
+Cases follow the reference's operator tests (tests/cpp/operator/cuda/operator_gemm_lowp_test.cpp
+:1034-1115: M in {1,3,17,31,128,..}, ragged N/K, group 64/128/256, alpha != 1) at sizes the
+oracle finishes in seconds, the BASELINE.json layer shapes of Qwen2-7B at M=1 against the C
+oracle directly, and size-independent properties at full size (batch invariance, run-to-run
+determinism of the split-K reduction, linearity).
+
+Tolerance: the kernel accumulates exact products in f32 and rounds once to FT; the oracle sums in
+f64 and rounds once.  Allowed: one FT ulp (2^-7 relative for bf16, 2^-10 for f16) plus a small
+absolute term for cancellation -- far inside the reference's own 1e-1 (A16W8) bound
+(operator_gemm_lowp_test.cpp:470-471), which is also asserted with its check_equal metric.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cbind, gemm_ref, glue, quant
+from oracle.numerics import bf16_round, check_equal, f16_round
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+FT = {"bf16": torch.bfloat16, "f16": torch.float16}
+ULP = {"bf16": 2.0 ** -7, "f16": 2.0 ** -10}
+
+
+@pytest.fixture(scope="module")
+def ops(pkg):
+    from dash_infer_amd import ops as _ops
+    assert torch.cuda.is_available()
+    return _ops
+
+
+def rnd(ft):
+    return bf16_round if ft == "bf16" else f16_round
+
+
+def to_dev(a, ft=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if ft is not None:
+        t = t.to(FT[ft])
+    return t.cuda()
+
+
+def make_case(rng, M, N, K, G, wbits, ft, style="iq"):
+    r = rnd(ft)
+    x = r(rng.uniform(-1, 1, (M, K)).astype(np.float32))
+    if style == "iq":  # InstantQuant of a random weight (quantization_utils.py)
+        W = r(rng.normal(0, 0.02, (K, N)).astype(np.float32))
+        q, s, z = (quant.iq_quantize_a16w8 if wbits == 8 else quant.iq_quantize_a16w4)(W, G, ft)
+    else:  # the reference test's synthetic distribution (operator_gemm_lowp_test.cpp:486-489)
+        Gn = (K + G - 1) // G if G > 0 else 1
+        s = r(rng.uniform(0.9 * 2 / 256, 1.1 * 2 / 256, (Gn, N)).astype(np.float32))
+        z = r(rng.uniform(-10, 10, (Gn, N)).astype(np.float32))
+        if wbits == 8:
+            q = rng.integers(-128, 128, (K, N)).astype(np.int8)
+        else:
+            q = quant.pack_u4(rng.integers(0, 16, (K, N)).astype(np.uint8))
+    return x, q, s, z
+
+
+def assert_close(out, ref, ft, scale_hint=None, what=""):
+    out = np.asarray(out, np.float64)
+    ref = np.asarray(ref, np.float64)
+    mag = np.abs(ref).max() if scale_hint is None else scale_hint
+    tol = ULP[ft] * np.abs(ref) + ULP[ft] * 0.02 * max(mag, 1e-6) + 1e-6
+    bad = np.abs(out - ref) > tol
+    assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} elements off, max err {np.abs(out - ref).max():.3e} (ref max {mag:.3e})"
+
+
+# ------------------------------------------------------------------ layout (bit exact) -------
+@pytest.mark.parametrize("wbits,K,N,G", [(4, 256, 64, 128), (4, 200, 50, 64), (8, 192, 48, -1), (8, 130, 33, 32),
+                                         (4, 3584, 512, 128)])
+def test_pack_kernels_byte_exact(ops, wbits, K, N, G):
+    rng = np.random.default_rng(K + N)
+    x, q, s, z = make_case(rng, 1, N, K, G, wbits, "bf16", style="synthetic")
+    from oracle.numerics import bf16_bits
+    pw = ops.pack_lowp(to_dev(q), to_dev(s, "bf16"), to_dev(z, "bf16"), G, wbits)
+    torch.cuda.synchronize()
+    spec_w = helpers.pack_tile_major(q, N, wbits)
+    got_w = pw.w.cpu().numpy().view(np.uint32).reshape(spec_w.shape)
+    np.testing.assert_array_equal(got_w, spec_w)
+    spec_sz = helpers.pack_sz(bf16_bits(s), bf16_bits(z), N, K, G)
+    got_sz = pw.sz.cpu().numpy().view(np.uint32).reshape(spec_sz.shape)
+    np.testing.assert_array_equal(got_sz, spec_sz)
+
+
+def test_pack_dense_byte_exact(ops):
+    from oracle.numerics import bf16_bits
+    rng = np.random.default_rng(1)
+    K, N = 100, 40
+    w = bf16_round(rng.normal(0, 1, (K, N)).astype(np.float32))
+    pw = ops.pack_dense(to_dev(w, "bf16"))
+    torch.cuda.synchronize()
+    spec = helpers.pack_tile_major(bf16_bits(w), N, 16)
+    np.testing.assert_array_equal(pw.w.cpu().numpy().view(np.uint32).reshape(spec.shape), spec)
+
+
+# ------------------------------------------------------------------ operator-level parity ----
+SMALL = [  # (M, N, K, G)
+    (1, 256, 512, -1), (1, 256, 512, 128), (3, 320, 640, 64), (17, 261, 519, 128), (31, 512, 1024, 256),
+    (1, 2560, 5120, 128), (2, 48, 96, 32), (16, 64, 128, -1), (33, 80, 256, 64), (128, 320, 512, 128),
+]
+
+
+@pytest.mark.parametrize("ft", ["bf16", "f16"])
+@pytest.mark.parametrize("wbits", [8, 4])
+@pytest.mark.parametrize("M,N,K,G", SMALL)
+def test_gemm_a16wx_matches_oracle(ops, M, N, K, G, wbits, ft):
+    rng = np.random.default_rng(M * 7 + N + K + wbits)
+    x, q, s, z = make_case(rng, M, N, K, G, wbits, ft, style="iq")
+    alpha = 0.75 if (M % 2) else 1.0
+    ref = gemm_ref.gemm_a16wx(x, q, s, z, G, wbits, alpha=alpha, ft=ft)
+    pw = ops.pack_lowp(to_dev(q), to_dev(s, ft), to_dev(z, ft), G, wbits)
+    y = ops.gemm_lowp(to_dev(x, ft), pw, alpha=alpha)
+    torch.cuda.synchronize()
+    out = y.float().cpu().numpy()
+    assert_close(out, ref, ft, what=f"M{M} N{N} K{K} G{G} w{wbits} {ft}")
+    assert check_equal(ref, out) <= 1e-1  # the reference's own criterion
+
+
+@pytest.mark.parametrize("wbits", [8, 4])
+def test_reference_test_distribution(ops, wbits):
+    """operator_gemm_lowp_test.cpp:486-489: q small ints, scale ~ 2/256, zero ~ U(-10,10) (fractional)."""
+    rng = np.random.default_rng(42)
+    M, N, K, G = 3, 512, 1024, 128
+    x, q, s, z = make_case(rng, M, N, K, G, wbits, "bf16", style="synthetic")
+    ref = gemm_ref.gemm_a16wx(x, q, s, z, G, wbits, ft="bf16")
+    pw = ops.pack_lowp(to_dev(q), to_dev(s, "bf16"), to_dev(z, "bf16"), G, wbits)
+    y = ops.gemm_lowp(to_dev(x, "bf16"), pw)
+    out = y.float().cpu().numpy()
+    assert_close(out, ref, "bf16", what="synthetic")
+    if cbind.reflib() is not None and wbits == 8:
+        theirs = cbind.ref_gemm_a16w8(x, q, s, z, G, 1.0, "bf16")  # the reference's own host loop
+        assert check_equal(theirs, out) <= 1e-1
+
+
+@pytest.mark.parametrize("act", [None, "silu", "relu", "gelu_erf", "gelu_tanh", "tanh", "sigmoid"])
+def test_epilogue_bias_activation_residual(ops, act):
+    rng = np.random.default_rng(3)
+    M, N, K, G = 5, 384, 512, 128
+    x, q, s, z = make_case(rng, M, N, K, G, 4, "bf16")
+    bias = bf16_round(rng.normal(0, 0.5, N).astype(np.float32))
+    res = bf16_round(rng.normal(0, 1, (M, N)).astype(np.float32))
+    ref = gemm_ref.gemm_a16wx(x, q, s, z, G, 4, alpha=1.5, bias=bias, act=act, ft="bf16")
+    ref = bf16_round(ref + res)
+    pw = ops.pack_lowp(to_dev(q), to_dev(s, "bf16"), to_dev(z, "bf16"), G, 4)
+    y = ops.gemm_lowp(to_dev(x, "bf16"), pw, bias=to_dev(bias, "bf16"), residual=to_dev(res, "bf16"), act=act, alpha=1.5)
+    assert_close(y.float().cpu().numpy(), ref, "bf16", what=f"act={act}")
+
+
+def test_workspace_counters_path_without_sync_buffer(ops):
+    """sync == NULL: counters live in the workspace and are cleared per call (memset node)."""
+    rng = np.random.default_rng(4)
+    M, N, K, G = 1, 512, 4096, 128
+    x, q, s, z = make_case(rng, M, N, K, G, 4, "bf16")
+    ref = gemm_ref.gemm_a16wx(x, q, s, z, G, 4, ft="bf16")
+    pw = ops.pack_lowp(to_dev(q), to_dev(s, "bf16"), to_dev(z, "bf16"), G, 4)
+    sc = ops.Scratch(ops.lowp_workspace_bytes(4, M, N, K, G))
+    sc.ws.fill_(0xFF)  # poisoned scratch must not matter
+    y1 = ops.gemm_lowp(to_dev(x, "bf16"), pw, scratch=sc, use_sync=False)
+    y2 = ops.gemm_lowp(to_dev(x, "bf16"), pw, scratch=sc, use_sync=False)
+    assert_close(y1.float().cpu().numpy(), ref, "bf16")
+    assert torch.equal(y1, y2)
+
+
+def test_error_behaviour(ops):
+    from dash_infer_amd import capi
+    rng = np.random.default_rng(5)
+    x, q, s, z = make_case(rng, 1, 64, 128, 64, 8, "bf16")
+    pw = ops.pack_lowp(to_dev(q), to_dev(s, "bf16"), to_dev(z, "bf16"), 64, 8)
+    with pytest.raises(capi.DihipError) as e:  # fp32 activations are not an A16 type (gemm_a16w8.cpp)
+        ops.gemm_lowp(to_dev(x), pw)
+    assert e.value.code == capi.PARAM_ERROR
+    with pytest.raises(capi.DihipError) as e:
+        ops.pack_lowp(to_dev(q), to_dev(s, "bf16"), to_dev(z, "bf16"), 48, 8)  # GroupSize % 32
+    assert e.value.code == capi.PARAM_ERROR
+    empty = ops.gemm_lowp(torch.empty(0, 128, dtype=torch.bfloat16, device="cuda"), pw)  # empty batch
+    assert empty.shape == (0, 64)
+
+
+# ------------------------------------------------------------------ BASELINE shapes ----------
+QWEN7B = {"qkv": (3584, 4608), "o": (3584, 3584), "gate": (3584, 18944), "down": (18944, 3584)}
+
+
+@pytest.mark.parametrize("layer", list(QWEN7B))
+@pytest.mark.parametrize("wbits,G", [(8, -1), (4, 128)])
+def test_qwen2_7b_layer_shapes_m1_vs_c_oracle(ops, layer, wbits, G):
+    """configs[1] (int8 per-channel) and configs[2] (int4 g128) linear layers at batch 1, checked
+    directly against the plain-C oracle (sequential f32 CPU_SubC_Ref semantics)."""
+    K, N = QWEN7B[layer]
+    rng = np.random.default_rng(N + wbits)
+    x, q, s, z = make_case(rng, 1, N, K, G, wbits, "bf16")
+    ref = cbind.gemm_a16wx(x, q, s, z, G, wbits, ft="bf16")
+    pw = ops.pack_lowp(to_dev(q), to_dev(s, "bf16"), to_dev(z, "bf16"), G, wbits)
+    y = ops.gemm_lowp(to_dev(x, "bf16"), pw)
+    out = y.float().cpu().numpy()
+    # sequential-f32 oracle vs f32-MFMA kernel: both round once to bf16; allow 1 ulp + eps
+    assert_close(out, ref, "bf16", what=f"{layer} w{wbits}")
+
+
+@pytest.mark.parametrize("wbits,G", [(4, 128), (8, -1)])
+def test_batch_invariance_and_determinism_full_size(ops, wbits, G):
+    """Size-independent properties at BASELINE size (gate proj 3584 -> 18944, batch 32):
+    row m of a batched call is bit-identical to the M=1 call on that row, repeated launches are
+    bit-identical (deterministic split-K), and the op is linear in x within FT rounding."""
+    K, N = QWEN7B["gate"]
+    rng = np.random.default_rng(9)
+    x, q, s, z = make_case(rng, 32, N, K, G, wbits, "bf16")
+    pw = ops.pack_lowp(to_dev(q), to_dev(s, "bf16"), to_dev(z, "bf16"), G, wbits)
+    xd = to_dev(x, "bf16")
+    y32 = ops.gemm_lowp(xd, pw)
+    y32b = ops.gemm_lowp(xd, pw)
+    assert torch.equal(y32, y32b)
+    for m in (0, 13, 31):
+        y1 = ops.gemm_lowp(xd[m:m + 1].contiguous(), pw)
+        assert torch.equal(y1[0], y32[m]), f"row {m} differs between M=1 and M=32"
+    y16 = ops.gemm_lowp(xd[:16].contiguous(), pw)
+    assert torch.equal(y16, y32[:16])
+    # linearity: f(2x) == 2 f(x) exactly (power-of-two scaling commutes with every rounding)
+    y2 = ops.gemm_lowp((xd[:4] * 2).contiguous(), pw)
+    assert torch.equal(y2, y32[:4] * 2)
+    # spot-check 64 random columns of 2 rows against the f64 oracle
+    cols = rng.choice(N, 64, replace=False)
+    w = gemm_ref.dequant(q, s, z, G, wbits)[:, cols].astype(np.float64)
+    ref = bf16_round((x[[0, 31]].astype(np.float64) @ w).astype(np.float32))
+    assert_close(y32[[0, 31]][:, cols].float().cpu().numpy(), ref, "bf16", what="spot check")
+
+
+# ------------------------------------------------------------------ fused decode-step forms --
+@pytest.mark.parametrize("M", [1, 3, 8, 32])
+@pytest.mark.parametrize("wbits,G", [(4, 128), (8, -1)])
+def test_fused_norm_gemm_swiglu_addto(ops, M, wbits, G):
+    rng = np.random.default_rng(M + wbits)
+    K, I = 512, 1152
+    eps = 1e-6
+    h = rng.normal(0, 1.5, (M, K)).astype(np.float32)
+    gamma = bf16_round(rng.normal(1, 0.1, K).astype(np.float32))
+    xn = bf16_round(glue.rmsnorm(h, gamma, eps))
+    sc = ops.Scratch(max(ops.lowp_workspace_bytes(wbits, M, I, K, G), ops.lowp_workspace_bytes(wbits, M, K, I, G)))
+    hd, gd = to_dev(h), to_dev(gamma, "bf16")
+
+    # qkv-like: norm + gemm + bias
+    _, q1, s1, z1 = make_case(rng, 1, 768, K, G, wbits, "bf16")
+    bias = bf16_round(rng.normal(0, 0.3, 768).astype(np.float32))
+    p1 = ops.pack_lowp(to_dev(q1), to_dev(s1, "bf16"), to_dev(z1, "bf16"), G, wbits)
+    y = ops.fused_norm_gemm(hd, gd, eps, p1, to_dev(bias, "bf16"), sc)
+    ref = gemm_ref.gemm_a16wx(xn, q1, s1, z1, G, wbits, bias=bias, ft="bf16")
+    assert_close(y.float().cpu().numpy(), ref, "bf16", what="norm_gemm")
+
+    # gate/up SwiGLU
+    _, qg, sg, zg = make_case(rng, 1, I, K, G, wbits, "bf16")
+    _, qu, su, zu = make_case(rng, 1, I, K, G, wbits, "bf16")
+    pg = ops.pack_lowp(to_dev(qg), to_dev(sg, "bf16"), to_dev(zg, "bf16"), G, wbits)
+    pu = ops.pack_lowp(to_dev(qu), to_dev(su, "bf16"), to_dev(zu, "bf16"), G, wbits)
+    act = ops.fused_norm_swiglu(hd, gd, eps, pg, pu, sc)
+    g = gemm_ref.gemm_a16wx(xn, qg, sg, zg, G, wbits, round_out=False).astype(np.float64)
+    u = gemm_ref.gemm_a16wx(xn, qu, su, zu, G, wbits, round_out=False).astype(np.float64)
+    ref = bf16_round(((g / (1 + np.exp(-g))) * u).astype(np.float32))
+    assert_close(act.float().cpu().numpy(), ref, "bf16", what="swiglu")
+
+    # down proj + residual into the f32 hidden stream
+    _, qd, sd, zd = make_case(rng, 1, K, I, G, wbits, "bf16")
+    pd = ops.pack_lowp(to_dev(qd), to_dev(sd, "bf16"), to_dev(zd, "bf16"), G, wbits)
+    a_host = act.float().cpu().numpy()
+    h2 = ops.fused_gemm_addto(act, pd, hd, sc)
+    ref = h + gemm_ref.gemm_a16wx(a_host, qd, sd, zd, G, wbits, round_out=False)
+    np.testing.assert_allclose(h2.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+    torch.cuda.synchronize()
+    assert int(sc.sync.sum()) == 0  # arrival counters are left zero
+
+
+def test_lm_head_and_argmax(ops):
+    rng = np.random.default_rng(11)
+    K, V = 896, 5000 + 37
+    eps = 1e-6
+    W = bf16_round(rng.normal(0, 0.05, (K, V)).astype(np.float32))
+    gamma = bf16_round(rng.normal(1, 0.1, K).astype(np.float32))
+    pw = ops.pack_dense(to_dev(W, "bf16"))
+    sc = ops.Scratch(int(ops.lib().dihip_dense_workspace_bytes(32, V, K)))
+    for M in (1, 4, 9):
+        h = rng.normal(0, 1, (M, K)).astype(np.float32)
+        xn = bf16_round(glue.rmsnorm(h, gamma, eps))
+        ref = xn.astype(np.float64) @ W.astype(np.float64)
+        logits = ops.lm_head(to_dev(h), to_dev(gamma, "bf16"), eps, pw, sc)
+        np.testing.assert_allclose(logits.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+        ids = ops.argmax(logits)
+        np.testing.assert_array_equal(ids.cpu().numpy(), np.argmax(logits.cpu().numpy(), axis=-1))
+    # ties resolve to the lowest index
+    t = torch.zeros(2, 1000, device="cuda")
+    t[0, 400] = t[0, 7] = 5.0
+    t[1, 999] = 1.0
+    assert ops.argmax(t).tolist() == [7, 999]

@@ -1,0 +1,263 @@
+"""GPU parity of the KV span writers and the SpanAttention decode kernel (through the C-ABI)
+against the oracle.
+
+KV writers are integer/byte work: span images must be BYTE-EXACT against oracle/kv_codec.py
+(which restates span-attention/src/cache_quant/impl_{i8,u4}.cuh and the layout of
+decoder_cache_append.cuh).  Attention is floating point: tolerance 1e-2 for bf16/f32 and 1e-3 for
+f16 as in span-attention/test/test_lib/test_quant_none.cpp:253-258, tightened to what the f32
+single-pass kernel actually delivers.  Case list follows test_quant_none.cpp:665-940 (MHA/GQA,
+batch 1..many, ragged lengths, span 16/32/128) at oracle-friendly sizes plus the BASELINE shapes
+(Qwen2-7B: n=28, g=4, H=128, L=2048; batch 32 with uint4 KV).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import attention, cbind, kv_codec
+from oracle.numerics import bf16_round, f16_round
+
+pytestmark = pytest.mark.gpu
+
+TD = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+RND = {"bf16": bf16_round, "f16": f16_round, "f32": lambda a: np.asarray(a, np.float32)}
+
+
+@pytest.fixture(scope="module")
+def ops(pkg):
+    from dash_infer_amd import ops as _ops
+    assert torch.cuda.is_available()
+    return _ops
+
+
+def dev(a, ft):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(TD[ft]).cuda()
+
+
+def build_batch(ops, rng, lens, n, g, H, S, mode, ft, extra_tokens=0):
+    """Oracle caches + device span tables holding the same bytes."""
+    B = len(lens)
+    max_spans = (max(lens) + extra_tokens + S - 1) // S + 1
+    pool = ops.SpanPool(2 * B * max_spans + 3, g, S, H, mode, TD[ft])
+    kv = ops.KVCacheSet(pool, B, max_spans)
+    ok, ov = [], []
+    for b, L in enumerate(lens):
+        kc, vc = kv_codec.SpanCache(g, S, H, mode, ft), kv_codec.SpanCache(g, S, H, mode, ft)
+        for t in range(L):
+            kc.write(t, rng.normal(0, 1, (g, H)))
+            vc.write(t, rng.normal(0, 1, (g, H)))
+        kv.ensure(b, L + extra_tokens)
+        for i, sp in enumerate(kc.spans):
+            pool.span_view(kv.k_idx[b][i]).copy_(torch.from_numpy(sp))
+        for i, sp in enumerate(vc.spans):
+            pool.span_view(kv.v_idx[b][i]).copy_(torch.from_numpy(sp))
+        ok.append(kc)
+        ov.append(vc)
+    kv.sync()
+    return pool, kv, ok, ov
+
+
+# ----------------------------------------------------------------------- KV writers ---------
+@pytest.mark.parametrize("ft", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("mode", ["none", "i8", "u4"])
+def test_kv_append_byte_exact(ops, mode, ft):
+    rng = np.random.default_rng(sum(map(ord, mode + ft)))
+    n, g, H, S = 6, 2, 128, 16
+    lens = [0, 5, 15, 16, 37]  # empty cache, mid-span, last slot, first slot of a new span, ragged
+    B = len(lens)
+    pool, kv, ok, ov = build_batch(ops, rng, lens, n, g, H, S, mode, ft, extra_tokens=3)
+    old = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    for step in range(3):
+        qkv = RND[ft](rng.normal(0, 1, (B, (n + 2 * g) * H)).astype(np.float32))
+        if step == 1:
+            qkv[0, n * H: (n + 1) * H] = 0.5                 # constant K head -> scale clamps to EPS
+            qkv[1, n * H: (n + 1) * H] = np.abs(qkv[1, n * H: (n + 1) * H]) + 1  # all-positive head
+            qkv = RND[ft](qkv)
+        q_out = torch.empty(B, n * H, dtype=TD[ft], device="cuda")
+        ops.kv_append(kv, q_out, dev(qkv, ft), old, n, g, H)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(q_out.float().cpu().numpy(), qkv[:, : n * H])
+        for b in range(B):
+            pos = lens[b] + step
+            ok[b].write(pos, qkv[b, n * H: (n + g) * H].reshape(g, H))
+            ov[b].write(pos, qkv[b, (n + g) * H:].reshape(g, H))
+        old += 1
+    for b in range(B):
+        for i, sp in enumerate(ok[b].spans):
+            np.testing.assert_array_equal(pool.span_view(kv.k_idx[b][i]).cpu().numpy(), sp, err_msg=f"K b{b} span{i}")
+        for i, sp in enumerate(ov[b].spans):
+            np.testing.assert_array_equal(pool.span_view(kv.v_idx[b][i]).cpu().numpy(), sp, err_msg=f"V b{b} span{i}")
+
+
+@pytest.mark.parametrize("mode", ["none", "i8", "u4"])
+def test_context_copy_prefix_gather_roundtrip(ops, mode):
+    """ContextSpanCopy writes the prefill K into spans byte-exactly; PrefixCacheCopy reads them
+    back dequantised == oracle dequantisation; span gather/scatter is a byte round trip."""
+    rng = np.random.default_rng(7)
+    g, H, S, L, ft = 4, 128, 32, 77, "bf16"
+    pool = ops.SpanPool(16, g, S, H, mode, TD[ft])
+    kv = ops.KVCacheSet(pool, 1, 4)
+    kv.ensure(0, L)
+    kv.sync()
+    n = 8
+    stride = (n + 2 * g) * H
+    rows = RND[ft](rng.normal(0, 2, (L, stride)).astype(np.float32))
+    rows_d = dev(rows, ft)
+    ksrc = rows_d[:, n * H:]  # INTERLEAVED qkv rows: K starts after the n query heads
+    ops.kv_context_copy(kv.k_ptrs[0], ksrc, stride, L, 0, g, H, S, mode)
+    oc = kv_codec.SpanCache(g, S, H, mode, ft)
+    for t in range(L):
+        oc.write(t, rows[t, n * H: (n + g) * H].reshape(g, H))
+    torch.cuda.synchronize()
+    for i, sp in enumerate(oc.spans):
+        got = pool.span_view(kv.k_idx[0][i]).cpu().numpy()
+        valid = min(S, L - i * S)
+        if valid == S:
+            np.testing.assert_array_equal(got, sp)
+        else:  # the tail span: compare token by token (unwritten slots are unspecified)
+            hb = {"none": H * 2, "i8": H, "u4": H // 2}[mode]
+            np.testing.assert_array_equal(got[: g * S * hb].reshape(g, S, hb)[:, :valid], sp[: g * S * hb].reshape(g, S, hb)[:, :valid])
+    dst = torch.empty(L, g, H, dtype=TD[ft], device="cuda")
+    ops.kv_prefix_gather(dst, kv.k_ptrs[0], L, g, H, S, mode)
+    np.testing.assert_array_equal(dst.float().cpu().numpy(), RND[ft](oc.read_all(L)))
+    # mass span copy
+    from dash_infer_amd import capi
+    nsp = len(kv.k_idx[0])
+    cont = torch.empty(nsp * pool.nbytes, dtype=torch.uint8, device="cuda")
+    capi.check(ops.lib().dihip_span_gather(ops.cur_stream(), ops.ptr(cont), ops.ptr(kv.k_ptrs[0]), nsp, pool.nbytes))
+    for i in range(nsp):
+        assert torch.equal(cont[i * pool.nbytes:(i + 1) * pool.nbytes], pool.span_view(kv.k_idx[0][i]))
+    kv2 = ops.KVCacheSet(pool, 1, 4)
+    kv2.ensure(0, L)
+    kv2.sync()
+    capi.check(ops.lib().dihip_span_scatter(ops.cur_stream(), ops.ptr(kv2.k_ptrs[0]), ops.ptr(cont), nsp, pool.nbytes))
+    for i in range(nsp):
+        assert torch.equal(pool.span_view(kv2.k_idx[0][i]), pool.span_view(kv.k_idx[0][i]))
+
+
+# ----------------------------------------------------------------------- decode attention ---
+def run_attn(ops, kv, q, lens, n, g, H, ft, scale):
+    B = len(lens)
+    max_len = max(max(lens), 1)
+    ws = torch.empty(max(ops.span_attn_workspace(B, n, H, max_len), 256), dtype=torch.uint8, device="cuda")
+    ws.fill_(0x7F)
+    sync = torch.zeros(int(ops.lib().dihip_span_attn_sync_bytes(B, n)), dtype=torch.uint8, device="cuda")
+    lens_d = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    out = ops.span_attn_decode(dev(q, ft), kv, lens_d, n, g, H, max_len, scale, ws, sync)
+    torch.cuda.synchronize()
+    assert int(sync.sum()) == 0
+    return out.float().cpu().numpy().reshape(B, n, H)
+
+
+def oracle_attn(ok, ov, q, lens, scale):
+    return np.stack([attention.decode_attention(q[b], ok[b].read_all(L), ov[b].read_all(L), scale) for b, L in enumerate(lens)])
+
+
+CASES = [  # (n, g, S, lens)  -- test_quant_none.cpp:665-940 scaled
+    (2, 2, 16, [3]), (4, 4, 32, [31, 64]), (16, 2, 16, [999]), (14, 2, 32, [1, 17, 128, 129, 500]),
+    (28, 4, 128, [17, 2047]), (8, 8, 64, [333] * 3), (64, 2, 16, [70]),
+]
+
+
+@pytest.mark.parametrize("ft", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("n,g,S,lens", CASES)
+def test_span_attention_unquantised(ops, n, g, S, lens, ft):
+    rng = np.random.default_rng(n * 100 + S)
+    H = 128
+    pool, kv, ok, ov = build_batch(ops, rng, lens, n, g, H, S, "none", ft)
+    q = RND[ft](rng.normal(0, 1, (len(lens), n, H)).astype(np.float32))
+    scale = 1.0 / np.sqrt(H)
+    out = run_attn(ops, kv, q, lens, n, g, H, ft, scale)
+    ref = oracle_attn(ok, ov, q, lens, scale)
+    tol = {"bf16": 1e-2, "f16": 1e-3, "f32": 1e-4}[ft]
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol * 0.25)
+
+
+@pytest.mark.parametrize("mode", ["i8", "u4"])
+@pytest.mark.parametrize("n,g,S,lens", [(14, 2, 16, [999]), (28, 4, 128, [5, 700, 130]), (8, 1, 32, [257, 64])])
+def test_span_attention_quantised_kv(ops, n, g, S, lens, mode):
+    """uint4 / int8 KV: the reference pins no results; parity is against the codec
+    oracle: the kernel must reproduce attention over the DEQUANTISED cache to f32 accuracy."""
+    rng = np.random.default_rng(5 + S)
+    H, ft = 128, "bf16"
+    pool, kv, ok, ov = build_batch(ops, rng, lens, n, g, H, S, mode, ft)
+    q = bf16_round(rng.normal(0, 1, (len(lens), n, H)).astype(np.float32))
+    scale = 1.0 / np.sqrt(H)
+    out = run_attn(ops, kv, q, lens, n, g, H, ft, scale)
+    ref = oracle_attn(ok, ov, q, lens, scale)
+    np.testing.assert_allclose(out, ref, rtol=1e-2, atol=2.5e-3)
+
+
+def test_span_attention_softmax_spike(ops):
+    """One K row aligned with q so the running max jumps late in the sequence (forces the
+    online-softmax rescale path in a late tile), plus a huge-magnitude score."""
+    rng = np.random.default_rng(3)
+    n, g, H, S, L = 7, 1, 128, 32, 600
+    pool, kv, ok, ov = build_batch(ops, rng, [L], n, g, H, S, "none", "f32")
+    q = rng.normal(0, 1, (1, n, H)).astype(np.float32)
+    spike = 25.0 * q[0, 3] / np.linalg.norm(q[0, 3])
+    ok[0].write(571, spike[None, :])
+    pool.span_view(kv.k_idx[0][571 // S]).copy_(torch.from_numpy(ok[0].spans[571 // S]))
+    out = run_attn(ops, kv, q, [L], n, g, H, "f32", 1.0)
+    ref = oracle_attn(ok, ov, q, [L], 1.0)
+    np.testing.assert_allclose(out, ref, rtol=2e-4, atol=2e-5)
+
+
+def test_handle_api_matches_decode_api(ops):
+    """The reference-shaped entry points (CreateHandle / GetWorkspaceSize / Run / DestroyHandle,
+    span_attn.h:108-175) drive the same kernel."""
+    import ctypes as C
+    from dash_infer_amd import capi
+    rng = np.random.default_rng(8)
+    n, g, H, S, lens, ft = 14, 2, 128, 16, [100, 999, 1], "bf16"
+    pool, kv, ok, ov = build_batch(ops, rng, lens, n, g, H, S, "i8", ft)
+    q = bf16_round(rng.normal(0, 1, (3, n, H)).astype(np.float32))
+    l = ops.lib()
+    h = C.c_void_p()
+    lens_c = (C.c_int * 3)(*lens)
+    assert l.dihip_span_attn_create_handle(C.byref(h), capi.BF16, capi.KV_I8, 3, n, g, H, S, kv.max_spans, lens_c, 0) == 0
+    dws, hws = C.c_size_t(), C.c_size_t()
+    l.dihip_span_attn_device_workspace_bytes(C.byref(dws), h)
+    l.dihip_span_attn_host_workspace_bytes(C.byref(hws), h)
+    dbuf = torch.empty(dws.value, dtype=torch.uint8, device="cuda")
+    hbuf = torch.empty(max(hws.value, 8), dtype=torch.uint8).pin_memory()
+    out = torch.empty(3, n * H, dtype=torch.bfloat16, device="cuda")
+    st = l.dihip_span_attn_run(ops.ptr(out), ops.ptr(dev(q, ft)), ops.ptr(kv.k_ptrs), ops.ptr(kv.v_ptrs), ops.ptr(dbuf),
+                               dws.value, C.c_void_p(hbuf.data_ptr()), hws.value, 1.0 / np.sqrt(H), h, ops.cur_stream())
+    assert st == 0, l.dihip_last_error()
+    torch.cuda.synchronize()
+    assert l.dihip_span_attn_destroy_handle(h) == 0
+    ref = run_attn(ops, kv, q, lens, n, g, H, ft, 1.0 / np.sqrt(H))
+    np.testing.assert_array_equal(out.float().cpu().numpy().reshape(3, n, H), ref)
+
+
+@pytest.mark.parametrize("mode,B", [("none", 1), ("u4", 32)])
+def test_span_attention_baseline_shapes(ops, mode, B):
+    """BASELINE configs: Qwen2-7B attention (n=28, g=4, H=128, span 128) at L=2048; batch 1 with
+    bf16 KV (config #2) and batch 32 with uint4 KV (config #3).  Checked against the plain-C
+    oracle over the same span bytes."""
+    rng = np.random.default_rng(B)
+    n, g, H, S, L, ft = 28, 4, 128, 128, 2048, "bf16"
+    nsp = L // S
+    pool = ops.SpanPool(2 * B * nsp + 1, g, S, H, mode, TD[ft])
+    kv = ops.KVCacheSet(pool, B, nsp)
+    for b in range(B):
+        kv.ensure(b, L)
+    kv.sync()
+    if mode == "none":
+        pool.pool.view(torch.bfloat16).normal_(0, 1)
+    else:  # random bytes + sane (zero, scale) parameters
+        pool.pool.random_(0, 256)
+        hb = H // 2
+        for idx in range(2 * B * nsp):
+            params = pool.span_view(idx)[g * S * hb:].view(torch.float32).view(g, S, 2)
+            params[:, :, 0] = torch.randint(3, 12, (g, S), device="cuda").float()
+            params[:, :, 1] = torch.rand(g, S, device="cuda") * 0.2 + 0.05
+    q = bf16_round(rng.normal(0, 1, (B, n, H)).astype(np.float32))
+    scale = 1.0 / np.sqrt(H)
+    out = run_attn(ops, kv, q, [L] * B, n, g, H, ft, scale)
+    torch.cuda.synchronize()
+    for b in ([0] if B == 1 else [0, 17, 31]):
+        ks = [pool.span_view(i).cpu().numpy() for i in kv.k_idx[b]]
+        vs = [pool.span_view(i).cpu().numpy() for i in kv.v_idx[b]]
+        ref = cbind.span_attn_decode(q[b], ks, vs, L, n, g, H, S, mode, ft, scale)
+        np.testing.assert_allclose(out[b], ref, rtol=1e-2, atol=2.5e-3)
