@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- decode tokens/s (+ achieved HBM GB/s) of the quantized decode hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload int4_b1|int8_b1|int4_b32_u4kv]
+
+A "step" is one decode step of Qwen2-7B (synthetic InstantQuant weights, synthetic KV history of
+2048 tokens) over one batch; at N > 1 the model is tensor-parallel over N ranks (one process per
+GPU, RCCL all-reduce over xGMI) -- total work is fixed, so scaling is "strong".  W warm-up graph
+replays, then exactly K replays are timed between barrier + synchronize on both sides; the maximum
+over ranks is used; rank 0 prints ONE JSON line.
+
+Default workload: the configuration BASELINE.json's metric and target are quoted on -- Qwen2-7B int4
+(group 128) weight-only, bf16 KV, batch 1, seq 2048 (first row).
+`--workload int8_b1` is BASELINE.json configs[1]; `int4_b32_u4kv` is configs[2].
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    #                 wbits group kv     batch gptq
+    "int4_b1":       (4, 128, "none", 1, True),
+    "int8_b1":       (8, -1, "none", 1, False),
+    "int4_b32_u4kv": (4, 128, "u4", 32, True),
+}
+SEQ_LEN = 2048
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def load_pkg():
+    from __graft_entry__ import _load_pkg
+    return _load_pkg()
+
+
+def cpu_baseline(wbits, group, cores_hint=None):
+    """The oracle ("port": plain-C restatement of the reference's CPU_SubC_Ref loop, OpenMP over the
+    host cores) timed on a bounded sample: the five linear layers of ONE Qwen2-7B decoder layer at
+    batch 1; decode tokens/s is extrapolated over 28 layers (attention and lm_head excluded: the
+    sample bounds the CPU path from above)."""
+    import numpy as np
+    from oracle import cbind
+    rng = np.random.default_rng(0)
+    shapes = [(3584, 4608), (3584, 3584), (3584, 18944), (3584, 18944), (18944, 3584)]
+    cores = os.cpu_count() or 1
+    t_layer = 0.0
+    for K, N in shapes:
+        G = (K + group - 1) // group if group > 0 else 1
+        x = rng.uniform(-1, 1, (1, K)).astype(np.float32)
+        s = rng.uniform(0.001, 0.002, (G, N)).astype(np.float32)
+        z = rng.uniform(0, 15, (G, N)).astype(np.float32)
+        q = rng.integers(0, 256, (K, (N + 1) // 2 if wbits == 4 else N), dtype=np.uint8)
+        if wbits == 8:
+            q = q.view(np.int8)
+        cbind.gemm_a16wx(x, q, s, z, group, wbits, ft="bf16")  # warm
+        t0 = time.perf_counter()
+        cbind.gemm_a16wx(x, q, s, z, group, wbits, ft="bf16")
+        t_layer += time.perf_counter() - t0
+    return {"value": round(1.0 / (28 * t_layer), 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": "plain-C oracle (CPU_SubC_Ref loop, OpenMP) on the 5 linear layers of 1 of 28 Qwen2-7B decoder "
+                      f"layers at batch 1, extrapolated x28; {t_layer * 1e3:.1f} ms/layer"}
+
+
+def kernel_breakdown(sess, torch, ops, iters=3):
+    """Average launch duration of every hot-path kernel measured with HIP events on the launch
+    stream, eager mode, cycling through all layers' weights (1.9+ GB, far beyond the 256 MB
+    Infinity Cache)."""
+    m, cfg, sc = sess.model, sess.model.cfg, sess.scratch
+    B = sess.B
+    res = {}
+
+    def timed(name, nbytes, fn):
+        evs = []
+        for _ in range(iters):
+            for li, lw in enumerate(m.layers):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn(li, lw)
+                e1.record()
+                evs.append((e0, e1))
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in evs)
+        avg = sum(ts) / len(ts)
+        res[name] = {"avg_us": round(avg * 1e3, 2), "min_us": round(ts[0] * 1e3, 2), "bytes": int(nbytes),
+                     "GBps": round(nbytes / (avg * 1e-3) / 1e9, 1)}
+
+    l0 = m.layers[0]
+    act_b = lambda p: B * p.K * 2 + B * p.N * 2
+    timed("qkv_norm_gemv", l0.qkv.nbytes + act_b(l0.qkv),
+          lambda li, lw: ops.fused_norm_gemm(sess.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sc, out=sess.qkv))
+    timed("rope_kv_append", 0,
+          lambda li, lw: ops.rope_kv_append(sess.kv[li], sess.q, sess.qkv, sess.old_lens, sess.inv_freq, sess.n_loc, sess.g_loc, sess.H))
+    kvb = {"none": sess.H * 2, "i8": sess.H + 8, "u4": sess.H // 2 + 8}[sess.kv_mode]
+    timed("span_attention", B * 2 * sess.g_loc * SEQ_LEN * kvb,
+          lambda li, lw: ops.span_attn_decode(sess.q, sess.kv[li], sess.new_lens, sess.n_loc, sess.g_loc, sess.H, sess.max_len,
+                                              sess.scale, sess.attn_ws, sess.attn_sync, out=sess.attn))
+    timed("o_gemv_addto", l0.o.nbytes + act_b(l0.o),
+          lambda li, lw: ops.fused_gemm_addto(sess.attn, lw.o, sess.h, sc, out=sess.partial))
+    timed("gate_up_swiglu", l0.gate.nbytes + l0.up.nbytes + B * l0.gate.K * 4 + B * l0.gate.N * 2,
+          lambda li, lw: ops.fused_norm_swiglu(sess.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=sess.act))
+    timed("down_gemv_addto", l0.down.nbytes + act_b(l0.down),
+          lambda li, lw: ops.fused_gemm_addto(sess.act, lw.down, sess.h, sc, out=sess.partial))
+    evs = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.lm_head(sess.h, m.final_norm, cfg.eps, m.lm_head, sc, out=sess.logits)
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    ts = [a.elapsed_time(b) for a, b in evs][1:]
+    avg = sum(ts) / len(ts)
+    res["lm_head"] = {"avg_us": round(avg * 1e3, 2), "bytes": int(m.lm_head.nbytes),
+                      "GBps": round(m.lm_head.nbytes / (avg * 1e-3) / 1e9, 1)}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="int4_b1", choices=list(WORKLOADS))
+    ap.add_argument("--layers", type=int, default=None, help="debug: fewer decoder layers (result marked invalid)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="debug: eager launches instead of hipGraph replay")
+    args = ap.parse_args()
+
+    import torch
+    load_pkg()
+    from dash_infer_amd import decoder, ops
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus} (launch with torch.distributed.run)"
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        comm = decoder.RcclComm(rank, world, torch.device("cuda", local_rank))
+
+    wbits, group, kv_mode, batch, gptq = WORKLOADS[args.workload]
+    cfg = decoder.QWEN2_7B
+    spec = decoder.QuantSpec(wbits, group, gptq_like_zeros=gptq)
+    t_build = time.time()
+    model = decoder.build_random_model(cfg, spec, seed=1234, rank=rank, nranks=world, layers=args.layers)
+    max_len = SEQ_LEN + args.steps + args.warmup + 16
+    sess = decoder.DecodeSession(model, batch, max_len, span_len=128, kv_mode=kv_mode, comm=comm)
+    sess.fill_cache_random(SEQ_LEN)
+    gen = torch.Generator().manual_seed(7)
+    ids = torch.randint(0, cfg.vocab, (batch,), generator=gen)
+    sess.set_state(ids, [SEQ_LEN] * batch)
+    t_build = time.time() - t_build
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if not args.no_graph:
+        sess.capture(warmup=1)
+        run = sess.replay
+    else:
+        run = sess.step
+    for _ in range(args.warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    last_ids = sess.ids.tolist()
+
+    ms_per_step = elapsed / args.steps * 1e3
+    tokens_per_s = batch * args.steps / elapsed
+    # whole-step algorithmic bytes: this rank's packed weights + scales/zeros + lm_head + KV read
+    step_bytes = sess.algorithmic_bytes_per_step(SEQ_LEN + args.warmup + args.steps // 2)
+    step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
+
+    out = {
+        "metric": "decode tokens/sec (whole job) + achieved HBM GB/s, Qwen2-7B weight-only quantized decode",
+        "value": round(tokens_per_s, 2),
+        "unit": "tokens/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "bf16 activations, " + ("u4" if wbits == 4 else "i8") + " weights (f32 accumulate)",
+        "data": "synthetic (random-init InstantQuant weights of the Qwen2-7B architecture, random 2048-token KV history)",
+        "config": {"workload": f"Qwen2-7B {args.workload}: int{wbits} weight-only group {group}, KV {kv_mode}, batch {batch}, "
+                               f"seq {SEQ_LEN}, TP={world}, greedy, hipGraph={'off' if args.no_graph else 'on'}",
+                   "global_batch": batch, "seq_len": SEQ_LEN, "parallelism": f"tp{world}",
+                   "layers": len(model.layers)},
+        "step_hbm": {"algorithmic_bytes_per_rank": int(step_bytes), "achieved_GBps_per_gpu": round(step_gbs, 1),
+                     "frac_of_peak": round(step_gbs / HBM_PEAK_GBS, 4)},
+        "build_s": round(t_build, 1),
+        "last_ids": last_ids[:4],
+    }
+    if args.layers is not None:
+        out["invalid"] = "debug run with a truncated layer stack"
+
+    if rank == 0:
+        try:
+            kb = kernel_breakdown(sess, torch, ops)
+            dom = kb["gate_up_swiglu"]
+            out["roofline"] = {"bound": "hbm", "kernel": "gemm_lowp_kernel<EPI_SWIGLU> (gate/up GEMV + SwiGLU)",
+                               "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                               "avg_launch_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["bytes"]}
+            out["kernels"] = kb
+        except Exception as e:  # never lose the headline number to the breakdown
+            out["roofline_error"] = repr(e)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(wbits, group)
+            except Exception as e:
+                out["cpu_baseline_error"] = repr(e)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

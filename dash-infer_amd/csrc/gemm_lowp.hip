@@ -506,7 +506,8 @@ int dihip_fused_gemm_addto(void* stream, int wbits, const void* x, const void* w
                            const float* h_res, float* h_out, int M, int N, int K, int group_size, void* ws,
                            size_t ws_bytes, void* sync, int dtype) {
   DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "fused path is bf16 only");
-  DIHIP_REQUIRE(sync != nullptr && h_res && h_out, DIHIP_PARAM_ERROR, "fused addto: null pointer");
+  // h_res may be NULL: then h_out = x . W (row-parallel TP ranks other than 0, gemm_op.cpp:133-137)
+  DIHIP_REQUIRE(sync != nullptr && h_out, DIHIP_PARAM_ERROR, "fused addto: null pointer");
   GemmCall c{};
   c.wbits = wbits;
   c.dtype = dtype;

@@ -110,6 +110,20 @@ __global__ __launch_bounds__(256) void argmax_stage2(int64_t* __restrict__ ids, 
   }
 }
 
+// one wave per row: best of `count` pairs at in[m*row_stride + i*elem_stride]; writes the id and/or
+// the pair (index shifted by index_offset)
+__global__ __launch_bounds__(64) void argmax_merge_kernel(int64_t* ids, ArgPair* pairs_out, const ArgPair* in, int count,
+                                                          int row_stride, int elem_stride, int index_offset) {
+  const int m = blockIdx.x;
+  ArgPair best{-INFINITY, 0x7fffffff};
+  for (int i = threadIdx.x; i < count; i += 64) best = arg_better(best, in[(size_t)m * row_stride + (size_t)i * elem_stride]);
+  best = wave_argmax(best);
+  if (threadIdx.x == 0) {
+    if (ids) ids[m] = (int64_t)best.i;
+    if (pairs_out) pairs_out[m] = ArgPair{best.v, best.i + index_offset};
+  }
+}
+
 template <int FT>
 __global__ __launch_bounds__(256) void embedding_kernel(float* __restrict__ h, const int64_t* __restrict__ ids,
                                                         const void* __restrict__ table, int K) {
@@ -188,6 +202,30 @@ int dihip_argmax(void* stream, int64_t* ids, const float* logits, int M, int N, 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(argmax_stage1, dim3(ARGMAX_BLOCKS, M), dim3(256), 0, s, (ArgPair*)ws, logits, N);
   hipLaunchKernelGGL(argmax_stage2, dim3(M), dim3(256), 0, s, ids, (const ArgPair*)ws, ARGMAX_BLOCKS);
+  return launch_status();
+}
+
+// TP vocabulary-parallel greedy sampling: each rank reduces its logits slice to one (value, global
+// index) pair per row, the pairs are all-gathered, and every rank merges them identically.
+int dihip_argmax_partial(void* stream, void* pairs_out, const float* logits, int M, int N, int index_offset, void* ws,
+                         size_t ws_bytes) {
+  DIHIP_REQUIRE(M >= 0 && N > 0 && pairs_out && logits, DIHIP_PARAM_ERROR, "argmax_partial: bad argument");
+  if (M == 0) return DIHIP_SUCCESS;
+  DIHIP_REQUIRE(ws && ws_bytes >= (size_t)M * ARGMAX_BLOCKS * sizeof(ArgPair), DIHIP_MEMORY_ERROR,
+                "argmax_partial: workspace needs %zu bytes", (size_t)M * ARGMAX_BLOCKS * sizeof(ArgPair));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(argmax_stage1, dim3(ARGMAX_BLOCKS, M), dim3(256), 0, s, (ArgPair*)ws, logits, N);
+  hipLaunchKernelGGL(argmax_merge_kernel, dim3(M), dim3(64), 0, s, (int64_t*)nullptr, (ArgPair*)pairs_out,
+                     (const ArgPair*)ws, ARGMAX_BLOCKS, ARGMAX_BLOCKS, 1, index_offset);
+  return launch_status();
+}
+
+int dihip_argmax_merge(void* stream, int64_t* ids, const void* pairs, int nparts, int M) {
+  DIHIP_REQUIRE(M >= 0 && nparts > 0 && ids && pairs, DIHIP_PARAM_ERROR, "argmax_merge: bad argument");
+  if (M == 0) return DIHIP_SUCCESS;
+  // pairs laid out [nparts][M] (all-gather order)
+  hipLaunchKernelGGL(argmax_merge_kernel, dim3(M), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), ids,
+                     (ArgPair*)nullptr, (const ArgPair*)pairs, nparts, 1, M, 0);
   return launch_status();
 }
 

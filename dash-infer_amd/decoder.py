@@ -1,0 +1,350 @@
+"""Decode-step runner for a Qwen2-style decoder on the dihip C-ABI (bench / smoke / parity tests).
+
+This is NOT the reference's engine (AsEngine / AsModel are out of scope): it is the smallest
+graph executor that strings the hot-path ops of one decoder step together in the order of
+python/pyhie/allspark/model/qwen_v15.py:210-388, so that decode tokens/s can be measured and
+greedy token ids compared with the oracle:
+
+  embedding -> L x [ RMSNorm+qkv GEMV(+bias) -> RoPE+KV append -> SpanAttention
+                     -> o_proj GEMV (+residual, [all-reduce]) -> RMSNorm+gate/up GEMV+SwiGLU
+                     -> down GEMV (+residual, [all-reduce]) ]
+            -> final RMSNorm + lm_head -> greedy argmax -> step counters += 1
+
+Every arithmetic step is a call into libdashinfer_hip.so; torch provides device memory, streams,
+graph capture (hipGraph) and the process group used to bootstrap RCCL.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import capi, ops, quantize, tp
+from .capi import check, lib
+
+
+@dataclass
+class ModelConfig:
+    name: str
+    hidden: int
+    layers: int
+    n_heads: int
+    n_kv: int
+    head_dim: int
+    inter: int
+    vocab: int
+    eps: float = 1e-6
+    rope_theta: float = 1000000.0
+
+
+QWEN2_7B = ModelConfig("Qwen2-7B", 3584, 28, 28, 4, 128, 18944, 152064)
+QWEN2_72B = ModelConfig("Qwen2-72B", 8192, 80, 64, 8, 128, 29696, 152064)  # GPTQ-padded intermediate
+
+
+@dataclass
+class QuantSpec:
+    wbits: int            # 4 | 8
+    group: int            # -1 per-channel | 64/128/...
+    gptq_like_zeros: bool = False
+
+
+@dataclass
+class LayerWeights:
+    ln1: torch.Tensor
+    qkv: ops.PackedWeight
+    qkv_bias: torch.Tensor
+    o: ops.PackedWeight
+    ln2: torch.Tensor
+    gate: ops.PackedWeight
+    up: ops.PackedWeight
+    down: ops.PackedWeight
+
+
+@dataclass
+class ModelWeights:
+    cfg: ModelConfig
+    quant: QuantSpec
+    rank: int
+    nranks: int
+    heads: tp.HeadShard
+    embed: torch.Tensor           # FT [vocab, hidden] (replicated)
+    layers: List[LayerWeights]
+    final_norm: torch.Tensor
+    lm_head: ops.PackedWeight     # W16, this rank's vocabulary slice
+    vocab_offset: int
+    vocab_local: int
+    weight_bytes: int = 0         # packed weight + (scale, zero) bytes streamed per decode step
+
+
+def _pack(q, s, z, spec, rows=None, cols=None, n_full=None):
+    """Slice a quantised [K,N] weight (rows / cols = index lists or None) and pack it for the GPU."""
+    if rows is None and cols is None:
+        return ops.pack_lowp(q.contiguous(), s.contiguous(), z.contiguous(), spec.group, spec.wbits)
+    if spec.wbits == 4:
+        # work on unpacked nibbles for column slicing
+        K = q.shape[0]
+        un = torch.empty(K, q.shape[1] * 2, dtype=torch.uint8, device=q.device)
+        un[:, 0::2] = q & 0xF
+        un[:, 1::2] = q >> 4
+        un = un[:, :n_full]
+        if cols is not None:
+            un = un[:, cols]
+        if rows is not None:
+            un = un[rows, :]
+        if un.shape[1] % 2:
+            un = torch.nn.functional.pad(un, (0, 1))
+        qq = ((un[:, 1::2] << 4) | (un[:, 0::2] & 0xF)).contiguous()
+    else:
+        qq = q
+        if cols is not None:
+            qq = qq[:, cols]
+        if rows is not None:
+            qq = qq[rows, :]
+        qq = qq.contiguous()
+    ss, zz = s, z
+    if cols is not None:
+        ss, zz = ss[:, cols], zz[:, cols]
+    if rows is not None and spec.group > 0:
+        # sub-channel parameters follow the K split (whole groups per rank, qwen_v15.py:540-569)
+        g = spec.group
+        assert len(rows) % g == 0 and rows[0] % g == 0, "row split must be group aligned"
+        grp = torch.tensor([r // g for r in rows[::g]], device=s.device)
+        ss, zz = ss[grp, :], zz[grp, :]
+    return ops.pack_lowp(qq, ss.contiguous(), zz.contiguous(), spec.group, spec.wbits)
+
+
+def build_random_model(cfg: ModelConfig, spec: QuantSpec, seed=1234, device="cuda", rank=0, nranks=1,
+                       dtype=torch.bfloat16, layers: Optional[int] = None, keep_fp=False):
+    """Synthetic weights per SURVEY 8(d): W ~ N(0, 0.02^2) in FT with
+    Generator(seed + 1000*layer + idx), InstantQuant-quantised on the FULL matrix (as the reference
+    converter does before the TP split), then sliced for this rank and packed."""
+    H, n, g = cfg.head_dim, cfg.n_heads, cfg.n_kv
+    shards = tp.shard_heads(n, g, nranks)
+    me = shards[rank]
+    ffn = tp.shard_ffn(cfg.inter, nranks, max(spec.group, 128) if spec.group > 0 else 128)[rank]
+    ffn_cols = list(ffn)
+    gen = torch.Generator(device=device)
+    fp = {} if keep_fp else None
+
+    def rand(shape, s, std=0.02):
+        gen.manual_seed(s)
+        return (torch.randn(*shape, generator=gen, device=device, dtype=torch.float32) * std).to(dtype)
+
+    L = cfg.layers if layers is None else layers
+    out_layers, wbytes = [], 0
+    for li in range(L):
+        base = seed + 1000 * li
+        w_qkv = rand((cfg.hidden, (n + 2 * g) * H), base + 0)
+        b_qkv = rand(((n + 2 * g) * H,), base + 1)
+        w_o = rand((n * H, cfg.hidden), base + 2)
+        w_gate = rand((cfg.hidden, cfg.inter), base + 3)
+        w_up = rand((cfg.hidden, cfg.inter), base + 4)
+        w_down = rand((cfg.inter, cfg.hidden), base + 5)
+        ln1 = (1.0 + rand((cfg.hidden,), base + 6, 0.1).float()).to(dtype)
+        ln2 = (1.0 + rand((cfg.hidden,), base + 7, 0.1).float()).to(dtype)
+        qs = {}
+        for name, w in (("qkv", w_qkv), ("o", w_o), ("gate", w_gate), ("up", w_up), ("down", w_down)):
+            qs[name] = quantize.quantize(w, spec.wbits, spec.group, spec.gptq_like_zeros)
+        if fp is not None:
+            fp[li] = {"qkv": qs["qkv"], "o": qs["o"], "gate": qs["gate"], "up": qs["up"], "down": qs["down"],
+                      "qkv_bias": b_qkv, "ln1": ln1, "ln2": ln2}
+        cols = tp.qkv_columns(me, n, g, H) if nranks > 1 else None
+        rows_o = tp.o_rows(me, H) if nranks > 1 else None
+        lw = LayerWeights(
+            ln1=ln1,
+            qkv=_pack(*qs["qkv"], spec, cols=cols, n_full=(n + 2 * g) * H),
+            qkv_bias=(b_qkv[cols] if cols is not None else b_qkv).contiguous(),
+            o=_pack(*qs["o"], spec, rows=rows_o, n_full=cfg.hidden),
+            ln2=ln2,
+            gate=_pack(*qs["gate"], spec, cols=ffn_cols if nranks > 1 else None, n_full=cfg.inter),
+            up=_pack(*qs["up"], spec, cols=ffn_cols if nranks > 1 else None, n_full=cfg.inter),
+            down=_pack(*qs["down"], spec, rows=ffn_cols if nranks > 1 else None, n_full=cfg.hidden),
+        )
+        wbytes += sum(p.nbytes for p in (lw.qkv, lw.o, lw.gate, lw.up, lw.down))
+        out_layers.append(lw)
+        del w_qkv, w_o, w_gate, w_up, w_down, qs
+    embed = rand((cfg.vocab, cfg.hidden), seed + 900001)
+    final_norm = (1.0 + rand((cfg.hidden,), seed + 900002, 0.1).float()).to(dtype)
+    # lm_head stays unquantised FT (qwen_v15.py:153-164); vocabulary-parallel slice for TP
+    vloc = cfg.vocab // nranks
+    assert cfg.vocab % nranks == 0
+    w_lm = rand((cfg.hidden, cfg.vocab), seed + 900003)
+    if fp is not None:
+        fp["embed"], fp["final_norm"], fp["lm_head"] = embed, final_norm, w_lm
+    lm = ops.pack_dense(w_lm[:, rank * vloc:(rank + 1) * vloc].contiguous())
+    wbytes += lm.nbytes
+    del w_lm
+    torch.cuda.synchronize()
+    mw = ModelWeights(cfg, spec, rank, nranks, me, embed, out_layers, final_norm, lm, rank * vloc, vloc, wbytes)
+    mw.fp = fp
+    return mw
+
+
+class RcclComm:
+    """RCCL communicator created through the C-ABI; the 128-byte unique id travels over the
+    torch.distributed process group (plumbing)."""
+
+    def __init__(self, rank, nranks, device):
+        import torch.distributed as dist
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_ubyte * 128)()
+            check(lib().dihip_rccl_unique_id(buf), "dihip_rccl_unique_id")
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        ident = ident.to(device)
+        dist.broadcast(ident, 0)
+        raw = bytes(ident.cpu().tolist())
+        self.handle = C.c_void_p()
+        check(lib().dihip_rccl_comm_init_rank(C.byref(self.handle), nranks, raw, rank), "dihip_rccl_comm_init_rank")
+        self.rank, self.nranks = rank, nranks
+
+    def allreduce_(self, t):
+        check(lib().dihip_allreduce_sum(self.handle, ops.cur_stream(), ops.ptr(t), ops.ptr(t), t.numel(), ops.dt_code(t)),
+              "dihip_allreduce_sum")
+        return t
+
+    def allgather(self, src, dst):
+        check(lib().dihip_allgather_bytes(self.handle, ops.cur_stream(), ops.ptr(src), ops.ptr(dst),
+                                          src.numel() * src.element_size()), "dihip_allgather_bytes")
+        return dst
+
+
+class DecodeSession:
+    """Buffers + KV spans for a fixed batch; `step()` enqueues one decode step."""
+
+    def __init__(self, model: ModelWeights, batch, max_len, span_len=128, kv_mode="none", comm: Optional[RcclComm] = None,
+                 device="cuda"):
+        cfg = model.cfg
+        self.model, self.B, self.max_len, self.comm = model, batch, max_len, comm
+        self.kv_mode = kv_mode
+        H = cfg.head_dim
+        self.n_loc, self.g_loc, self.H = len(model.heads.q_heads), len(model.heads.kv_heads), H
+        dt = model.embed.dtype
+        L = len(model.layers)
+        spans_per_req = (max_len + span_len - 1) // span_len
+        self.pool = ops.SpanPool(2 * L * batch * spans_per_req + 1, self.g_loc, span_len, H, kv_mode, dt, device)
+        self.kv = [ops.KVCacheSet(self.pool, batch, spans_per_req) for _ in range(L)]
+        for kv in self.kv:  # all spans are claimed up front: the span tables are static under graph replay
+            for b in range(batch):
+                kv.ensure(b, max_len)
+            kv.sync()
+        self.inv_freq = (1.0 / (cfg.rope_theta ** (torch.arange(0, H, 2, dtype=torch.float64) / H))).float().to(device)
+        f32 = torch.float32
+        self.ids = torch.zeros(batch, dtype=torch.int64, device=device)
+        self.old_lens = torch.zeros(batch, dtype=torch.int32, device=device)
+        self.new_lens = torch.ones(batch, dtype=torch.int32, device=device)
+        self.h = torch.empty(batch, cfg.hidden, dtype=f32, device=device)
+        self.qkv = torch.empty(batch, (self.n_loc + 2 * self.g_loc) * H, dtype=dt, device=device)
+        self.q = torch.empty(batch, self.n_loc * H, dtype=dt, device=device)
+        self.attn = torch.empty(batch, self.n_loc * H, dtype=dt, device=device)
+        self.act = torch.empty(batch, model.layers[0].gate.N, dtype=dt, device=device)
+        self.logits = torch.empty(batch, model.vocab_local, dtype=f32, device=device)
+        self.partial = torch.zeros(batch, cfg.hidden, dtype=f32, device=device)
+        l0, wb, gsz = model.layers[0], model.quant.wbits, model.quant.group
+        need = max(ops.lowp_workspace_bytes(wb, batch, p.N, p.K, gsz) for p in (l0.qkv, l0.o, l0.gate, l0.down))
+        need = max(need, int(lib().dihip_dense_workspace_bytes(batch, model.lm_head.N, model.lm_head.K)))
+        self.scratch = ops.Scratch(need, device)
+        self.attn_ws = torch.empty(max(ops.span_attn_workspace(batch, self.n_loc, H, max_len), 256), dtype=torch.uint8, device=device)
+        self.attn_sync = torch.zeros(int(lib().dihip_span_attn_sync_bytes(batch, self.n_loc)), dtype=torch.uint8, device=device)
+        self.argmax_ws = torch.empty(batch * 64 * 8, dtype=torch.uint8, device=device)
+        nr = model.nranks
+        self.pair = torch.empty(batch * 8, dtype=torch.uint8, device=device)
+        self.pairs_all = torch.empty(nr * batch * 8, dtype=torch.uint8, device=device)
+        self.scale = 1.0 / (H ** 0.5)
+        self.graph = None
+
+    # -- state ---------------------------------------------------------------------------
+    def set_state(self, ids, lens):
+        """ids: next input token per request; lens: tokens already in the cache."""
+        self.ids.copy_(torch.as_tensor(ids, dtype=torch.int64))
+        lens = torch.as_tensor(lens, dtype=torch.int32)
+        self.old_lens.copy_(lens)
+        self.new_lens.copy_(lens + 1)
+
+    def fill_cache_random(self, length, seed=7):
+        """Synthetic KV history of `length` tokens (K,V ~ N(0,1))."""
+        gen = torch.Generator(device=self.pool.pool.device)
+        gen.manual_seed(seed)
+        if self.kv_mode == "none":
+            v = self.pool.pool.view(self.model.embed.dtype)
+            v.copy_(torch.randn(v.shape, generator=gen, device=v.device, dtype=torch.float32).to(v.dtype))
+        else:
+            self.pool.pool.random_(0, 256, generator=gen)
+            hb = self.H if self.kv_mode == "i8" else self.H // 2
+            g, S = self.g_loc, self.pool.S
+            per = self.pool.aligned
+            allp = self.pool.pool.view(-1, per)[:, g * S * hb: g * S * hb + g * S * 8].contiguous().view(torch.float32).view(-1, g, S, 2)
+            allp[..., 0] = 8.0 if self.kv_mode == "u4" else 0.0
+            allp[..., 1] = 0.25 if self.kv_mode == "u4" else 0.02
+            self.pool.pool.view(-1, per)[:, g * S * hb: g * S * hb + g * S * 8] = allp.view(torch.uint8).view(-1, g * S * 8)
+
+    # -- one decode step -------------------------------------------------------------------
+    def step(self):
+        m, cfg, sc = self.model, self.model.cfg, self.scratch
+        ops.embedding(self.ids, m.embed, out=self.h)
+        tp_on = self.comm is not None and m.nranks > 1
+        for li, lw in enumerate(m.layers):
+            ops.fused_norm_gemm(self.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sc, out=self.qkv)
+            ops.rope_kv_append(self.kv[li], self.q, self.qkv, self.old_lens, self.inv_freq, self.n_loc, self.g_loc, self.H)
+            ops.span_attn_decode(self.q, self.kv[li], self.new_lens, self.n_loc, self.g_loc, self.H, self.max_len,
+                                 self.scale, self.attn_ws, self.attn_sync, out=self.attn)
+            self._proj_residual(self.attn, lw.o, tp_on)
+            ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act)
+            self._proj_residual(self.act, lw.down, tp_on)
+        ops.lm_head(self.h, m.final_norm, cfg.eps, m.lm_head, sc, out=self.logits)
+        if tp_on:
+            check(lib().dihip_argmax_partial(ops.cur_stream(), ops.ptr(self.pair), ops.ptr(self.logits), self.B,
+                                             m.vocab_local, m.vocab_offset, ops.ptr(self.argmax_ws), self.argmax_ws.numel()),
+                  "dihip_argmax_partial")
+            self.comm.allgather(self.pair, self.pairs_all)
+            check(lib().dihip_argmax_merge(ops.cur_stream(), ops.ptr(self.ids), ops.ptr(self.pairs_all), m.nranks, self.B),
+                  "dihip_argmax_merge")
+        else:
+            ops.argmax(self.logits, ws=self.argmax_ws, out=self.ids)
+        ops.increment_u32_(self.old_lens)
+        ops.increment_u32_(self.new_lens)
+
+    def _proj_residual(self, x, pw, tp_on):
+        """h += x . W  (row-parallel under TP: rank 0 carries the residual, then all-reduce --
+        the reference applies the fused residual ADD on rank 0 only, gemm_op.cpp:133-137)."""
+        if not tp_on:
+            ops.fused_gemm_addto(x, pw, self.h, self.scratch, out=self.h)
+            return
+        if self.model.rank == 0:
+            ops.fused_gemm_addto(x, pw, self.h, self.scratch, out=self.h)
+        else:
+            check(lib().dihip_fused_gemm_addto(ops.cur_stream(), pw.wbits, ops.ptr(x), ops.ptr(pw.w), ops.ptr(pw.sz), None,
+                                               ops.ptr(self.h), x.shape[0], pw.N, pw.K, pw.group, ops.ptr(self.scratch.ws),
+                                               self.scratch.ws_bytes, ops.ptr(self.scratch.sync), ops.dt_code(x)),
+                  "dihip_fused_gemm_addto")
+        self.comm.allreduce_(self.h)
+
+    # -- hipGraph capture --------------------------------------------------------------------
+    def capture(self, warmup=2):
+        ids0, old0, new0 = self.ids.clone(), self.old_lens.clone(), self.new_lens.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.ids.copy_(ids0)
+        self.old_lens.copy_(old0)
+        self.new_lens.copy_(new0)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.step()
+        torch.cuda.synchronize()
+        # the capture pass itself does not execute; state is still (ids0, lens0)
+        return self.graph
+
+    def replay(self):
+        self.graph.replay()
+
+    # -- accounting --------------------------------------------------------------
+    def algorithmic_bytes_per_step(self, seq_len):
+        cfg = self.model.cfg
+        kvb = {"none": self.H * 2, "i8": self.H + 8, "u4": self.H // 2 + 8}[self.kv_mode]
+        kv = len(self.model.layers) * self.B * 2 * self.g_loc * seq_len * kvb
+        return self.model.weight_bytes + kv

@@ -236,6 +236,12 @@ int dihip_lm_head(void* stream, float* logits, const float* h, const void* gamma
 /* greedy sampling (GenerateOp top_k = 1): ids[m] = argmax_n logits[m, n] (lowest index on ties) */
 int dihip_argmax(void* stream, int64_t* ids, const float* logits, int M, int N, void* ws,
                  size_t ws_bytes);
+/* vocabulary-parallel greedy sampling for TP: one {f32 value, i32 global index} pair per row
+ * from this rank's logits slice [M, N] (global index = local + index_offset); after an
+ * all-gather of the pairs ([nparts][M]) every rank merges them to the same ids.                */
+int dihip_argmax_partial(void* stream, void* pairs_out, const float* logits, int M, int N,
+                         int index_offset, void* ws, size_t ws_bytes);
+int dihip_argmax_merge(void* stream, int64_t* ids, const void* pairs, int nparts, int M);
 /* embedding lookup into the f32 hidden stream: h[m,:] = float(table[ids[m],:])                */
 int dihip_embedding(void* stream, float* h, const int64_t* ids, const void* table, int M, int K,
                     int dtype);
