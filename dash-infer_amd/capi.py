@@ -86,6 +86,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `make -C dash-infer_amd/csrc -j8` "
                 "(or __graft_entry__.build()).  There is no CPU fallback.")
+        try:  # torch ships its own libamdhip64: it must be the HIP runtime of the process, so
+            import torch  # noqa: F401  load it BEFORE our library resolves libamdhip64.so
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)

@@ -117,6 +117,18 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
+// sin/cos of pos * inv_freq: the f32 product (as the reference computes it, rotary.cpp:22-106) is
+// range-reduced in f64 so that sincosf stays on its fast small-argument path (the large-argument
+// Payne-Hanek path of the device libm spills to scratch).
+__device__ __forceinline__ void rope_sincos(uint32_t pos, float inv_freq, float* sn, float* cs) {
+  const float ang = (float)pos * inv_freq;
+  const double two_pi = 6.283185307179586476925286766559;
+  double r = (double)ang;
+  r -= two_pi * floor(r / two_pi);
+  if (r > 3.14159265358979323846) r -= two_pi;
+  sincosf((float)r, sn, cs);
+}
+
 // In-launch split hand-off (cdna_hip_programming.md G16, counter form): every wave of the
 // block has finished its plain slab stores; returns true in ALL threads of exactly one block
 // per counter -- the last to arrive -- after an agent-scope acquire, so that it may read the

@@ -156,7 +156,8 @@ static GemmPlan make_plan(int wbits, int M, int N, int K, int group_size, bool d
   // (rows+1) * (kslice*KTILE + 8) * 2 bytes
   const int rows = std::min(M, rows_per_block);
   const int max_tiles = std::max(1, (60 * 1024 / ((rows + 1) * 2) - 8) / d.KTILE);
-  p.kslice_tiles = std::min(p.ktiles_per_split, max_tiles);
+  // several slices: each a multiple of the register ring depth (gemm_lowp_kernel.hpp)
+  p.kslice_tiles = p.ktiles_per_split <= max_tiles ? p.ktiles_per_split : std::max(GEMM_RING, max_tiles / GEMM_RING * GEMM_RING);
   p.lds_bytes = GEMM_LDS_HEADER + (size_t)(rows + 1) * (p.kslice_tiles * d.KTILE + 8) * 2;
   p.slab_bytes = p.splitk > 1 ? (size_t)p.splitk * M * (dual ? 2 : 1) * d.Np * sizeof(float) : 0;
   return p;

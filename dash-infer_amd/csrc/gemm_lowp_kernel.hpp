@@ -37,6 +37,7 @@ enum { EPI_STD = 0, EPI_SWIGLU = 1, EPI_ADDTO = 2 };
 constexpr int GEMM_THREADS = 256;
 constexpr int GEMM_WAVES = 4;
 constexpr int GEMM_LDS_HEADER = 1024;  // flag word + reduction scratch (bytes)
+constexpr int GEMM_RING = 4;           // k-tiles in flight per column tile per wave
 
 struct GemmArgs {
   const u32x4_t* w0;
@@ -78,21 +79,25 @@ struct WTraits {
 template <int WBITS, int FT>
 struct Expand;
 
-// W4: the dword holds nibble j at bit 4*(j/2) + 16*(j%2), so (d >> 4i) & 0x000F000F is the pair
-// (2i, 2i+1) already in the two 16-bit halves; OR-ing the exponent yields 128+q (bf16) or
-// 1024+q (f16) exactly.
+// W4: the dword holds nibble j at bit 4*(j/2) + 16*(j%2), so one shift brings the pair (2i, 2i+1)
+// to the TOP four mantissa bits of both 16-bit halves; OR-ing the exponent of 16.0 yields 16+q
+// exactly (bf16: mantissa bits 3..6 of [16,32) count units; f16: bits 6..9).  The small offset
+// (16, merged into the zero point) keeps the f32 accumulation noise two orders below one FT ulp.
 template <int FT>
 struct Expand<4, FT> {
-  static constexpr float OFFSET = FT == DIHIP_BF16 ? 128.f : 1024.f;
-  static constexpr uint32_t MAGIC = FT == DIHIP_BF16 ? 0x43004300u : 0x64006400u;
+  static constexpr float OFFSET = 16.f;
+  static constexpr int POS = FT == DIHIP_BF16 ? 3 : 6;  // bit position of the nibble LSB
+  static constexpr uint32_t MASK = 0x000F000Fu << POS;
+  static constexpr uint32_t MAGIC = FT == DIHIP_BF16 ? 0x41804180u : 0x4C004C00u;
+  template <int I>
+  __device__ __forceinline__ static uint32_t pair(uint32_t d) {
+    constexpr int sh = 4 * I - POS;  // > 0: shift right, < 0: shift left
+    const uint32_t v = sh >= 0 ? (d >> (sh >= 0 ? sh : 0)) : (d << (sh < 0 ? -sh : 0));
+    return (v & MASK) | MAGIC;
+  }
   __device__ __forceinline__ static u32x4_t frag(const u32x4_t& chunk, int ks) {
     const uint32_t d = chunk[ks];
-    u32x4_t r;
-    r[0] = (d & 0x000F000Fu) | MAGIC;
-    r[1] = ((d >> 4) & 0x000F000Fu) | MAGIC;
-    r[2] = ((d >> 8) & 0x000F000Fu) | MAGIC;
-    r[3] = ((d >> 12) & 0x000F000Fu) | MAGIC;
-    return r;
+    return u32x4_t{pair<0>(d), pair<1>(d), pair<2>(d), pair<3>(d)};
   }
 };
 // W8: bytes are u8 = q + 128 in natural k order.  f16: 0x6400|u8 = 1024+u8 exact.
@@ -148,6 +153,27 @@ __device__ __forceinline__ f32x4_t mfma16(const u32x4_t& a, const u32x4_t& b, co
   }
 }
 
+// One output element (m, n): v = k-sum of the first weight, v2 = of the second (EPI_SWIGLU).
+template <int FT, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, int m, int n, float v, float v2) {
+  if constexpr (EPI == EPI_STD) {
+    // reduce_sum order of the reference (gemm_a16w8_subc_kernel.cu:953-977):
+    // act(alpha * sum + bias); then the Gemm op's fused binary ADD.
+    v = a.alpha * v;
+    if (a.bias) v += load_ft<FT>(a.bias, n);
+    v = apply_act(v, a.act);
+    if (a.residual) v = ft_round<FT>(v) + load_ft<FT>(a.residual, (size_t)m * a.ldy + n);
+    store_ft<FT>(a.y, (size_t)m * a.ldy + n, v);
+  } else if constexpr (EPI == EPI_SWIGLU) {
+    // Gemm(gate, SiLU) x Gemm(up) -> Binary MUL (qwen_v15.py:314-335), one rounding
+    store_ft<FT>(a.y, (size_t)m * a.ldy + n, (v / (1.f + expf(-v))) * v2);
+  } else {
+    // f32 hidden-stream update; h_res == nullptr -> plain f32 output (lm_head logits, TP partials)
+    const float base = a.h_res ? a.h_res[(size_t)m * a.N + n] : 0.f;
+    a.h_out[(size_t)m * a.N + n] = base + a.alpha * v;
+  }
+}
+
 // MT : 16-row m-tiles per block (1: M<=16, 2: M<=32 per grid.z slice)
 // NT : 16-column n-tiles per wave (EPI_SWIGLU: NT/2 gate tiles + NT/2 up tiles, same columns)
 template <int WBITS, int FT, int MT, int NT, int PRO, int EPI>
@@ -159,6 +185,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_lowp_kernel(const GemmArgs 
   constexpr int NTW = EPI == EPI_SWIGLU ? NT / 2 : NT;  // distinct column tiles per wave
   constexpr int ROWS = 16 * MT;
   constexpr bool QUANT = WBITS != 16;
+  // k-tiles of every column tile kept in flight per wave (register ring).  Decode-sized
+  // launches are latency bound: the whole per-wave K range should be in flight at once.
+  constexpr int D = GEMM_RING;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* flag_lds = reinterpret_cast<unsigned*>(smem);
@@ -178,16 +207,33 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_lowp_kernel(const GemmArgs 
 
   const int tile0 = (cb * GEMM_WAVES + wave) * NTW;  // first column tile of this wave
   const bool wave_active = tile0 < a.NTILES;
+  const int last_grp = (a.KT * KSTEPS - 1) / a.ksteps_per_group;
+  const bool small_groups = QUANT && a.ksteps_per_group < KSTEPS;  // several groups per k-tile
 
-  // ---- issue the first weight chunk loads before touching x: they do not depend on it ------
-  u32x4_t wcur[NT];
-  const u32x4_t* wptr[NT];
+  // ---- weight / (scale, zero) register ring; first D k-tiles are issued before touching x ----
+  u32x4_t wbuf[D][NT];
+  uint32_t szbuf[D][NT];
+  const u32x4_t* wbase[NT];
+  const uint32_t* szbase[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int tile = min(tile0 + (t % NTW), a.NTILES - 1);
-    const u32x4_t* base = (EPI == EPI_SWIGLU && t >= NTW) ? a.w1 : a.w0;
-    wptr[t] = base + ((size_t)tile * a.KT + kt0) * 64 + lane;
-    wcur[t] = wave_active && kt0 < kt1 ? __builtin_nontemporal_load(wptr[t]) : u32x4_t{0, 0, 0, 0};
+    const bool second = EPI == EPI_SWIGLU && t >= NTW;
+    wbase[t] = (second ? a.w1 : a.w0) + (size_t)tile * a.KT * 64 + lane;
+    szbase[t] = (second ? a.sz1 : a.sz0) + tile * 16 + ni;
+  }
+#define DIHIP_ISSUE(SLOT, KT_)                                                                    \
+  do {                                                                                            \
+    _Pragma("unroll") for (int t_ = 0; t_ < NT; ++t_) {                                           \
+      wbuf[SLOT][t_] = __builtin_nontemporal_load(wbase[t_] + (size_t)(KT_) * 64);                \
+      if constexpr (QUANT)                                                                        \
+        szbuf[SLOT][t_] = szbase[t_][(size_t)min(((KT_) * KSTEPS) / a.ksteps_per_group, last_grp) * a.Np]; \
+    }                                                                                             \
+  } while (0)
+  if (wave_active) {
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+      if (kt0 + j < kt1) DIHIP_ISSUE(j, kt0 + j);
   }
 
   if constexpr (PRO == PRO_RMSNORM) {
@@ -233,21 +279,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_lowp_kernel(const GemmArgs 
   const u32x4_t ones = FT == DIHIP_BF16 ? u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}
                                         : u32x4_t{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
 
-  // (scale, zero) of the current group for this lane's column of each tile
   const int kstep0 = kt0 * KSTEPS;
   int grp = kstep0 / a.ksteps_per_group;
   int ksg = kstep0 - grp * a.ksteps_per_group;  // k-steps already consumed of the current group
-  const int last_grp = (a.KT * KSTEPS - 1) / a.ksteps_per_group;
-  uint32_t szv[NT];
-  auto load_sz = [&](int g) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int tile = min(tile0 + (t % NTW), a.NTILES - 1);
-      const uint32_t* sz = (EPI == EPI_SWIGLU && t >= NTW) ? a.sz1 : a.sz0;
-      szv[t] = sz[(size_t)g * a.Np + tile * 16 + ni];
-    }
-  };
-  auto fixup = [&]() {
+
+  // s * (acc - (z + OFFSET) * xsum) of the finished group into the running total
+  auto fixup = [&](const uint32_t (&szv)[NT]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const float s = ft_bits_to_f32<FT>(szv[t] & 0xFFFFu);
@@ -264,7 +301,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_lowp_kernel(const GemmArgs 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) xsum[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   };
-  if (QUANT && wave_active) load_sz(min(grp, last_grp));
+  uint32_t sz_last[NT];  // (scale, zero) of the group the most recent k-tile belongs to
+#pragma unroll
+  for (int t = 0; t < NT; ++t) sz_last[t] = 0;
 
   // ---- main loop over LDS-staged k-slices (one slice for decode shapes) ---------------------
   for (int s0 = kt0; s0 < kt1; s0 += a.kslice_tiles) {
@@ -311,123 +350,134 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_lowp_kernel(const GemmArgs 
     __syncthreads();
 
     if (wave_active) {
-      for (int kt = s0; kt < s1; ++kt) {
-        // prefetch the next chunk of every tile while this one is consumed
-        u32x4_t wnxt[NT];
-        const bool more = kt + 1 < kt1;
+      // (s0 - kt0) is a multiple of D (host plan), so ring slot j always holds k-tile base + j
+      for (int base = s0; base < s1; base += D) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          wptr[t] += 64;
-          wnxt[t] = more ? __builtin_nontemporal_load(wptr[t]) : u32x4_t{0, 0, 0, 0};
-        }
-        const int kl = (kt - s0) * KTILE;
+        for (int j = 0; j < D; ++j) {
+          const int kt = base + j;
+          if (kt < s1) {  // wave-uniform
+            const int kl = (kt - s0) * KTILE;
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-          u32x4_t af[MT];
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+              u32x4_t af[MT];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            af[mt] = *reinterpret_cast<const u32x4_t*>(xs + arow[mt] + kl + ks * 32);
-            if constexpr (QUANT) xsum[mt] = mfma16<FT>(af[mt], ones, xsum[mt]);
-          }
+              for (int mt = 0; mt < MT; ++mt) {
+                af[mt] = *reinterpret_cast<const u32x4_t*>(xs + arow[mt] + kl + ks * 32);
+                if constexpr (QUANT) xsum[mt] = mfma16<FT>(af[mt], ones, xsum[mt]);
+              }
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const u32x4_t bf = EX::frag(wcur[t], ks);
+              for (int t = 0; t < NT; ++t) {
+                const u32x4_t bf = EX::frag(wbuf[j][t], ks);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              if constexpr (QUANT) gacc[mt][t] = mfma16<FT>(af[mt], bf, gacc[mt][t]);
-              else tot[mt][t] = mfma16<FT>(af[mt], bf, tot[mt][t]);
+                for (int mt = 0; mt < MT; ++mt) {
+                  if constexpr (QUANT) gacc[mt][t] = mfma16<FT>(af[mt], bf, gacc[mt][t]);
+                  else tot[mt][t] = mfma16<FT>(af[mt], bf, tot[mt][t]);
+                }
+              }
+              if constexpr (QUANT) {
+                if (++ksg == a.ksteps_per_group) {  // wave-uniform
+                  if (small_groups) {  // rare: group < k-tile, fetch its parameters on demand
+                    uint32_t szv[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) szv[t] = szbase[t][(size_t)min(grp, last_grp) * a.Np];
+                    fixup(szv);
+                  } else {
+                    fixup(szbuf[j]);
+                  }
+                  ksg = 0;
+                  ++grp;
+                }
+              }
             }
-          }
-          if constexpr (QUANT) {
-            if (++ksg == a.ksteps_per_group) {  // wave-uniform
-              fixup();
-              ksg = 0;
-              ++grp;
-              load_sz(min(grp, last_grp));
+            if constexpr (QUANT) {
+#pragma unroll
+              for (int t = 0; t < NT; ++t) sz_last[t] = szbuf[j][t];
             }
+            if (kt + D < kt1) DIHIP_ISSUE(j, kt + D);
           }
         }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) wcur[t] = wnxt[t];
       }
     }
   }
-  if (QUANT && wave_active && ksg != 0) fixup();  // per-channel, or a K-range that ends inside a group
-
-  // ---- split-K hand-off ---------------------------------------------------------------------
-  // C layout of v_mfma_f32_16x16x32: lane holds column ni, rows kb*4 + r.
-  const int slab_cols = (EPI == EPI_SWIGLU ? 2 : 1) * a.Np;
-  if (a.splitk > 1) {
-    if (wave_active) {
+  if constexpr (QUANT) {
+    if (wave_active && ksg != 0) {  // per-channel, or a K range that ends inside a group
+      if (small_groups) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + mt * 16 + kb * 4 + r;
-          if (m < a.M) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-              const int col = ((EPI == EPI_SWIGLU && t >= NTW) ? a.Np : 0) + (tile0 + (t % NTW)) * 16 + ni;
-              if (tile0 + (t % NTW) < a.NTILES)
-                a.slabs[((size_t)split * a.M + m) * slab_cols + col] = tot[mt][t][r];
-            }
-          }
-        }
+        for (int t = 0; t < NT; ++t) sz_last[t] = szbase[t][(size_t)min(grp, last_grp) * a.Np];
+      }
+      fixup(sz_last);
     }
-    unsigned* counter = a.counters + (size_t)mz * gridDim.x + cb;
-    if (!arrive_and_check_last(counter, (unsigned)a.splitk, flag_lds)) return;
+  }
+#undef DIHIP_ISSUE
+
+  // ---- no split: epilogue straight from the accumulator registers ----------------------------
+  // C layout of v_mfma_f32_16x16x32: lane holds column ni, rows kb*4 + r.
+  if (a.splitk == 1) {
     if (!wave_active) return;
-    // last arriver: deterministic sum over the splits in split order
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + mt * 16 + kb * 4 + r;
+        if (m >= a.M) continue;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          float acc = 0.f;
-          const int col = ((EPI == EPI_SWIGLU && t >= NTW) ? a.Np : 0) + (tile0 + (t % NTW)) * 16 + ni;
-          if (m < a.M && tile0 + (t % NTW) < a.NTILES) {
-            for (int s = 0; s < a.splitk; ++s) acc += a.slabs[((size_t)s * a.M + m) * slab_cols + col];
-          }
-          tot[mt][t][r] = acc;
+        for (int t = 0; t < NTW; ++t) {
+          const int n = (tile0 + t) * 16 + ni;
+          if (n >= a.N) continue;
+          gemm_epilogue<FT, EPI>(a, m, n, tot[mt][t][r], EPI == EPI_SWIGLU ? tot[mt][(t + NTW) % NT][r] : 0.f);
         }
       }
-  } else if (!wave_active) {
     return;
   }
 
-  // ---- fused epilogue -----------------------------------------------------------------------
+  // ---- split-K hand-off: slabs [split][M][slab_cols] f32, last arriver reduces ----------------
+  const int slab_cols = (EPI == EPI_SWIGLU ? 2 : 1) * a.Np;
+  if (wave_active) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + mt * 16 + kb * 4 + r;
-      if (m >= a.M) continue;
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + mt * 16 + kb * 4 + r;
+        if (m < a.M) {
 #pragma unroll
-      for (int t = 0; t < NTW; ++t) {
-        const int n = (tile0 + t) * 16 + ni;
-        if (n >= a.N) continue;
-        if constexpr (EPI == EPI_STD) {
-          // reduce_sum order of the reference (gemm_a16w8_subc_kernel.cu:953-977):
-          // act(alpha * sum + bias); then the Gemm op's fused binary ADD.
-          float v = a.alpha * tot[mt][t][r];
-          if (a.bias) v += load_ft<FT>(a.bias, n);
-          v = apply_act(v, a.act);
-          if (a.residual) v = ft_round<FT>(v) + load_ft<FT>(a.residual, (size_t)m * a.ldy + n);
-          store_ft<FT>(a.y, (size_t)m * a.ldy + n, v);
-        } else if constexpr (EPI == EPI_SWIGLU) {
-          // Gemm(gate, SiLU) x Gemm(up) -> Binary MUL (qwen_v15.py:314-335), one rounding
-          const float g = tot[mt][t][r], u = tot[mt][t + NTW][r];
-          const float v = (g / (1.f + expf(-g))) * u;
-          store_ft<FT>(a.y, (size_t)m * a.ldy + n, v);
-        } else {
-          // f32 hidden-stream update; h_res == nullptr -> plain f32 output (lm_head logits)
-          const float base = a.h_res ? a.h_res[(size_t)m * a.N + n] : 0.f;
-          a.h_out[(size_t)m * a.N + n] = base + a.alpha * tot[mt][t][r];
+          for (int t = 0; t < NT; ++t) {
+            const int col = ((EPI == EPI_SWIGLU && t >= NTW) ? a.Np : 0) + (tile0 + (t % NTW)) * 16 + ni;
+            if (tile0 + (t % NTW) < a.NTILES) a.slabs[((size_t)split * a.M + m) * slab_cols + col] = tot[mt][t][r];
+          }
         }
       }
+  }
+  unsigned* counter = a.counters + (size_t)mz * gridDim.x + cb;
+  if (!arrive_and_check_last(counter, (unsigned)a.splitk, flag_lds)) return;
+
+  // Last arriver: every thread owns whole output elements; the split partials of an element are
+  // fetched in independent batches (all loads of a batch in flight together) and summed in split
+  // order, so the result does not depend on arrival order.
+  constexpr int BLOCK_COLS = GEMM_WAVES * NTW * 16;
+  const int ncols = min(BLOCK_COLS, a.Np - cb * BLOCK_COLS);
+  for (int e = tid; e < rows * ncols; e += GEMM_THREADS) {
+    const int mr = e / ncols, c = e - mr * ncols;
+    const int m = m0 + mr, n = cb * BLOCK_COLS + c;
+    if (n >= a.N) continue;
+    const float* p = a.slabs + (size_t)m * slab_cols + n;
+    const size_t sstride = (size_t)a.M * slab_cols;
+    float acc = 0.f, acc2 = 0.f;
+    for (int sb = 0; sb < a.splitk; sb += 16) {
+      float v[16], v2[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const bool in = sb + j < a.splitk;
+        v[j] = in ? p[(size_t)(sb + j) * sstride] : 0.f;
+        if constexpr (EPI == EPI_SWIGLU) v2[j] = in ? p[(size_t)(sb + j) * sstride + a.Np] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        acc += v[j];
+        if constexpr (EPI == EPI_SWIGLU) acc2 += v2[j];
+      }
     }
+    gemm_epilogue<FT, EPI>(a, m, n, acc, acc2);
+  }
 }
 
 }  // namespace dihip

@@ -35,9 +35,8 @@ __global__ __launch_bounds__(64) void rope_qk_kernel(void* qkv, const uint32_t* 
   const int half = H / 2;
   if (d >= half) return;
   const size_t base = (size_t)row * (n + 2 * g) * H + (size_t)head * H;  // q heads then k heads
-  const float ang = (float)positions[row] * inv_freq[d];
   float sn, cs;
-  sincosf(ang, &sn, &cs);
+  rope_sincos(positions[row], inv_freq[d], &sn, &cs);
   const float x1 = load_ft<FT>(qkv, base + d), x2 = load_ft<FT>(qkv, base + d + half);
   store_ft<FT>(qkv, base + d, x1 * cs - x2 * sn);
   store_ft<FT>(qkv, base + d + half, x2 * cs + x1 * sn);

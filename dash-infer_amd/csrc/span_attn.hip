@@ -23,7 +23,8 @@
 namespace dihip {
 
 constexpr int ATTN_THREADS = 256;
-constexpr int ATTN_TOK_PER_ITER = 64;  // 4 waves x 4 token slots x 4 tokens
+constexpr int ATTN_TB = 2;              // tokens per lane slot per iteration
+constexpr int ATTN_TOK_PER_ITER = 32;  // 4 waves x 4 token slots x ATTN_TB tokens
 constexpr int ATTN_PSTRIDE = 132;      // floats per partial record: o[128], m, l, pad
 
 struct AttnArgs {
@@ -120,6 +121,7 @@ __device__ __forceinline__ float safe_exp_diff(float a, float b) {  // exp(a - b
 template <int FT, int MODE, int HC>
 __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const AttnArgs a) {
   constexpr int H = 128;
+  constexpr int TB = ATTN_TB;  // tokens per lane-slot per iteration
   __shared__ __attribute__((aligned(16))) float lds[4 * HC * ATTN_PSTRIDE + 4];
   unsigned* flag_lds = reinterpret_cast<unsigned*>(lds + 4 * HC * ATTN_PSTRIDE);
 
@@ -136,6 +138,23 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const At
   const int t0 = split * tps;
   const int t1 = min(len, t0 + tps);
 
+  const void* const* ksp = a.kspans + (size_t)b * a.span_stride;
+  const void* const* vsp = a.vspans + (size_t)b * a.span_stride;
+
+  // token of (iteration base tb, slot i) for this lane: 16 consecutive tokens per wave-load group
+  auto issue = [&](KvChunk<FT, MODE> (&kc)[TB], KvChunk<FT, MODE> (&vc)[TB], int tb) {
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      const int t = tb + i * 16 + wave * 4 + tl;
+      const int tt = t < t1 ? t : t0;  // clamp: keeps the address legal, result discarded
+      const int sp = tt / a.S, pos = tt - sp * a.S;
+      kv_issue<FT, MODE>(kc[i], ksp[sp], grp, pos, a.g, a.S, dc);
+      kv_issue<FT, MODE>(vc[i], vsp[sp], grp, pos, a.g, a.S, dc);
+    }
+  };
+  KvChunk<FT, MODE> k0[TB], v0[TB], k1[TB], v1[TB];
+  if (t0 < t1) issue(k0, v0, t0);  // first tokens in flight before q is touched
+
   // q (pre-scaled) for this lane's 8 dims of every head of the chunk
   float qr[HC][8];
 #pragma unroll
@@ -143,8 +162,23 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const At
 #pragma unroll
     for (int j = 0; j < 8; ++j) qr[h][j] = 0.f;
     if (h < nh) {
+      const size_t off = ((size_t)b * a.n + h0 + h) * H + dc * 8;
+      if constexpr (FT == DIHIP_F32) {
+        const f32x4_t q0 = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(a.q) + off);
+        const f32x4_t q1 = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(a.q) + off + 4);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) qr[h][j] = a.scale * load_ft<FT>(a.q, ((size_t)b * a.n + h0 + h) * H + dc * 8 + j);
+        for (int j = 0; j < 4; ++j) {
+          qr[h][j] = a.scale * q0[j];
+          qr[h][4 + j] = a.scale * q1[j];
+        }
+      } else {
+        const u32x4_t qv = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(a.q) + off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          qr[h][2 * j] = a.scale * ft_bits_to_f32<FT == DIHIP_F32 ? DIHIP_BF16 : FT>(qv[j] & 0xFFFFu);
+          qr[h][2 * j + 1] = a.scale * ft_bits_to_f32<FT == DIHIP_F32 ? DIHIP_BF16 : FT>(qv[j] >> 16);
+        }
+      }
     }
   }
   float m[HC], l[HC], o[HC][8];
@@ -156,24 +190,11 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const At
     for (int j = 0; j < 8; ++j) o[h][j] = 0.f;
   }
 
-  const void* const* ksp = a.kspans + (size_t)b * a.span_stride;
-  const void* const* vsp = a.vspans + (size_t)b * a.span_stride;
-
-  for (int tb = t0; tb < t1; tb += ATTN_TOK_PER_ITER) {
-    KvChunk<FT, MODE> kc[4], vc[4];
-    bool valid[4];
+  auto process = [&](const KvChunk<FT, MODE> (&kc)[TB], const KvChunk<FT, MODE> (&vc)[TB], int tb) {
+    float s[TB][HC];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int t = tb + i * 16 + wave * 4 + tl;
-      valid[i] = t < t1;
-      const int tt = valid[i] ? t : t0;  // clamp: keeps the address legal, result discarded
-      const int sp = tt / a.S, pos = tt - sp * a.S;
-      kv_issue<FT, MODE>(kc[i], ksp[sp], grp, pos, a.g, a.S, dc);
-      kv_issue<FT, MODE>(vc[i], vsp[sp], grp, pos, a.g, a.S, dc);
-    }
-    float s[4][HC];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TB; ++i) {
+      const bool valid = tb + i * 16 + wave * 4 + tl < t1;
       float kx[8];
       kv_decode<FT, MODE>(kc[i], kx);
 #pragma unroll
@@ -182,20 +203,20 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const At
 #pragma unroll
         for (int j = 0; j < 8; ++j) p = fmaf(qr[h][j], kx[j], p);
         p = row16_sum(p);
-        s[i][h] = valid[i] ? p : -INFINITY;
+        s[i][h] = valid ? p : -INFINITY;
       }
     }
-    float pw[4][HC];
 #pragma unroll
     for (int h = 0; h < HC; ++h) {
-      float mn = fmaxf(fmaxf(s[0][h], s[1][h]), fmaxf(s[2][h], s[3][h]));
-      mn = fmaxf(mn, m[h]);
+      float mn = m[h];
+#pragma unroll
+      for (int i = 0; i < TB; ++i) mn = fmaxf(mn, s[i][h]);
       const float corr = safe_exp_diff(m[h], mn);
       float ps = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        pw[i][h] = safe_exp_diff(s[i][h], mn);
-        ps += pw[i][h];
+      for (int i = 0; i < TB; ++i) {
+        s[i][h] = safe_exp_diff(s[i][h], mn);  // now the softmax weight
+        ps += s[i][h];
       }
       l[h] = l[h] * corr + ps;
       m[h] = mn;
@@ -203,13 +224,26 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const At
       for (int j = 0; j < 8; ++j) o[h][j] *= corr;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TB; ++i) {
       float vx[8];
       kv_decode<FT, MODE>(vc[i], vx);
 #pragma unroll
       for (int h = 0; h < HC; ++h)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[h][j] = fmaf(pw[i][h], vx[j], o[h][j]);
+        for (int j = 0; j < 8; ++j) o[h][j] = fmaf(s[i][h], vx[j], o[h][j]);
+    }
+  };
+
+  // double-buffered token stream: the next iteration's K/V rows are in flight while this one
+  // is reduced
+  constexpr int STEP = ATTN_TOK_PER_ITER;
+  for (int tb = t0; tb < t1; tb += 2 * STEP) {
+    const bool more1 = tb + STEP < t1;
+    if (more1) issue(k1, v1, tb + STEP);
+    process(k0, v0, tb);
+    if (more1) {
+      if (tb + 2 * STEP < t1) issue(k0, v0, tb + 2 * STEP);
+      process(k1, v1, tb + STEP);
     }
   }
 
@@ -232,8 +266,8 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const At
 #pragma unroll
     for (int h = 0; h < HC; ++h) {
       float* rec = lds + (wave * HC + h) * ATTN_PSTRIDE;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) rec[dc * 8 + j] = o[h][j];
+      *reinterpret_cast<f32x4_t*>(rec + dc * 8) = f32x4_t{o[h][0], o[h][1], o[h][2], o[h][3]};
+      *reinterpret_cast<f32x4_t*>(rec + dc * 8 + 4) = f32x4_t{o[h][4], o[h][5], o[h][6], o[h][7]};
       if (dc == 0) {
         rec[H] = m[h];
         rec[H + 1] = l[h];
@@ -285,6 +319,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const At
     }
     unsigned* counter = a.counters + (size_t)b * gridDim.y + blockIdx.y;
     if (!arrive_and_check_last(counter, (unsigned)a.nsplits, flag_lds)) return;
+    // last arriver: merge the split partials; loads are issued in independent batches
 #pragma unroll
     for (int e = 0; e < PER_THREAD; ++e) {
       const int idx = tid + e * ATTN_THREADS;
@@ -292,13 +327,30 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const At
       if (h < nh) {
         const float* base = a.partials + ((size_t)b * a.n + h0 + h) * a.nsplits * ATTN_PSTRIDE;
         float mm = -INFINITY;
-        for (int sidx = 0; sidx < a.nsplits; ++sidx) mm = fmaxf(mm, base[(size_t)sidx * ATTN_PSTRIDE + H]);
+        for (int sb = 0; sb < a.nsplits; sb += 16) {
+          float mv[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) mv[j] = sb + j < a.nsplits ? base[(size_t)(sb + j) * ATTN_PSTRIDE + H] : -INFINITY;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) mm = fmaxf(mm, mv[j]);
+        }
         float ll = 0.f, oo = 0.f;
-        for (int sidx = 0; sidx < a.nsplits; ++sidx) {
-          const float* rec = base + (size_t)sidx * ATTN_PSTRIDE;
-          const float c = safe_exp_diff(rec[H], mm);
-          ll += rec[H + 1] * c;
-          oo += rec[d] * c;
+        for (int sb = 0; sb < a.nsplits; sb += 16) {
+          float mv[16], lv[16], ov[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const bool in = sb + j < a.nsplits;
+            const float* rec = base + (size_t)(sb + j) * ATTN_PSTRIDE;
+            mv[j] = in ? rec[H] : -INFINITY;
+            lv[j] = in ? rec[H + 1] : 0.f;
+            ov[j] = in ? rec[d] : 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const float c = safe_exp_diff(mv[j], mm);
+            ll += lv[j] * c;
+            oo += ov[j] * c;
+          }
         }
         bo[e] = oo;
         bl[e] = ll;
@@ -327,8 +379,8 @@ static AttnPlan attn_plan(int batch, int n_heads, int n_groups, int max_seq_len,
   if (num_cus <= 0) num_cus = cached_num_cus();
   if (num_cus <= 0) num_cus = 256;
   const long base = (long)batch * n_groups * p.nchunks;
-  long want = (2L * num_cus + base - 1) / base;
-  const long max_splits = std::max(1, (max_seq_len + ATTN_TOK_PER_ITER - 1) / ATTN_TOK_PER_ITER);
+  long want = (num_cus + base - 1) / base;  // about one workgroup per CU
+  const long max_splits = std::max(1, (max_seq_len + 127) / 128);  // >= 128 tokens per split
   p.nsplits = (int)std::max<long>(1, std::min<long>(std::min<long>(want, max_splits), 256));
   p.partial_bytes = p.nsplits > 1 ? (size_t)batch * n_heads * p.nsplits * ATTN_PSTRIDE * sizeof(float) : 0;
   return p;

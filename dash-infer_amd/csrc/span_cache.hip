@@ -153,11 +153,10 @@ __global__ __launch_bounds__(64) void rope_kv_append_kernel(void* const* k_spans
   const int b = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
   const size_t row = (size_t)b * (n + 2 * g) * H;
   const uint32_t old_len = old_seq_lens[b];
-  const float pos = (float)old_len;
   // lane holds d = 2*lane, 2*lane+1; the rotate-half partner (d +- 64) lives in lane ^ 32
   float cs[EPL], sn[EPL];
 #pragma unroll
-  for (int i = 0; i < EPL; ++i) sincosf(pos * inv_freq[(lane * EPL + i) & 63], &sn[i], &cs[i]);
+  for (int i = 0; i < EPL; ++i) rope_sincos(old_len, inv_freq[(lane * EPL + i) & 63], &sn[i], &cs[i]);
   auto rotate = [&](float (&x)[EPL]) {
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {

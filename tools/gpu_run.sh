@@ -18,7 +18,7 @@ timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke e
 timeout 600 python bench.py --steps 64 --warmup 8 > $OUT/bench_int4_b1.json 2> $OUT/bench_int4_b1.err; echo "bench exit $?" | tee -a $OUT/summary.log
 tail -c 3000 $OUT/bench_int4_b1.json; tail -5 $OUT/bench_int4_b1.err
 if [ "${PROFILE:-1}" = "1" ]; then
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 4 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof_bench.err)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 4 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof_bench.err)
   echo "rocprof exit $?" | tee -a $OUT/summary.log
   find $OUT/prof -name "*stats*" | head; find $OUT/prof -name "*kernel_stats*" -exec head -30 {} \;
   # keep only the small summaries
