@@ -60,11 +60,15 @@ def make_case(rng, M, N, K, G, wbits, ft, style="iq"):
     return x, q, s, z
 
 
-def assert_close(out, ref, ft, scale_hint=None, what=""):
+def assert_close(out, ref, ft, scale_hint=None, what="", pre=None):
+    """`pre`: an intermediate that was itself rounded to FT before the final op (residual add): a
+    one-ulp flip of it is legitimate (libm tanhf/expf differ in the last bit between host and device)."""
     out = np.asarray(out, np.float64)
     ref = np.asarray(ref, np.float64)
     mag = np.abs(ref).max() if scale_hint is None else scale_hint
     tol = ULP[ft] * np.abs(ref) + ULP[ft] * 0.02 * max(mag, 1e-6) + 1e-6
+    if pre is not None:
+        tol = tol + ULP[ft] * np.abs(np.asarray(pre, np.float64))
     bad = np.abs(out - ref) > tol
     assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} elements off, max err {np.abs(out - ref).max():.3e} (ref max {mag:.3e})"
 
@@ -143,11 +147,11 @@ def test_epilogue_bias_activation_residual(ops, act):
     x, q, s, z = make_case(rng, M, N, K, G, 4, "bf16")
     bias = bf16_round(rng.normal(0, 0.5, N).astype(np.float32))
     res = bf16_round(rng.normal(0, 1, (M, N)).astype(np.float32))
-    ref = gemm_ref.gemm_a16wx(x, q, s, z, G, 4, alpha=1.5, bias=bias, act=act, ft="bf16")
-    ref = bf16_round(ref + res)
+    pre = gemm_ref.gemm_a16wx(x, q, s, z, G, 4, alpha=1.5, bias=bias, act=act, ft="bf16")
+    ref = bf16_round(pre + res)
     pw = ops.pack_lowp(to_dev(q), to_dev(s, "bf16"), to_dev(z, "bf16"), G, 4)
     y = ops.gemm_lowp(to_dev(x, "bf16"), pw, bias=to_dev(bias, "bf16"), residual=to_dev(res, "bf16"), act=act, alpha=1.5)
-    assert_close(y.float().cpu().numpy(), ref, "bf16", what=f"act={act}")
+    assert_close(y.float().cpu().numpy(), ref, "bf16", what=f"act={act}", pre=pre)
 
 
 def test_workspace_counters_path_without_sync_buffer(ops):
