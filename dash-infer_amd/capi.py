@@ -67,6 +67,9 @@ _SIGS = {
     "dihip_rccl_comm_destroy": (i32, [vp]),
     "dihip_allreduce_sum": (i32, [vp, vp, vp, vp, sz, i32]),
     "dihip_allgather_bytes": (i32, [vp, vp, vp, vp, sz]),
+    "dihip_debug_set_trace": (i32, [vp, sz]),
+    "dihip_debug_gemv_plan": (i32, [i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32),
+                              C.POINTER(sz)]),
 }
 
 _lib = None

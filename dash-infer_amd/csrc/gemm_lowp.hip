@@ -3,8 +3,10 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "gemm_lowp_launch.hpp"
+#include "gemv_stream_kernel.hpp"
 
 namespace dihip {
 
@@ -15,8 +17,9 @@ namespace dihip {
 //       nibbles j = k%8 at bit 4*(j/2) + 16*(j%2).
 //   W8: Kp = roundup(K,64); chunk byte ks*8 + j = u8(q + 128), ks = (k%64)/32.
 //   padding (k >= K or n >= N) is zero.
-// (scale, zero): uint32 [Gp][Np], lo16 = scale bits, hi16 = zero bits (FT), zero padded;
-//   Gp = max(G, ceil(Kp / group)).
+// (scale, zero): uint32 [NTILES][Gp][16] (column-tile major: the parameters a wave needs next to
+//   a weight chunk are 64 contiguous bytes, consecutive groups of a tile are adjacent), lo16 =
+//   scale bits, hi16 = zero bits (FT), zero padded; Gp = max(G, ceil(Kp / group)).
 // ------------------------------------------------------------------------------------------
 static inline int roundup(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -112,7 +115,9 @@ __global__ void pack_sz_kernel(const uint16_t* __restrict__ s, const uint16_t* _
   const size_t total = (size_t)Gp * Np;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (size_t)gridDim.x * blockDim.x) {
-    const int n = (int)(idx % Np), g = (int)(idx / Np);
+    const int col = (int)(idx & 15);
+    const int g = (int)((idx >> 4) % Gp);
+    const int n = (int)((idx >> 4) / Gp) * 16 + col;
     uint32_t v = 0;
     if (n < N && g < G) v = (uint32_t)s[(size_t)g * N + n] | ((uint32_t)z[(size_t)g * N + n] << 16);
     out[idx] = v;
@@ -222,6 +227,92 @@ struct GemmCall {
   void* sync;
 };
 
+
+// ---- decode fast path (gemv_stream_kernel.hpp) ------------------------------------------------
+struct GemvPlan {
+  bool ok;
+  int MR, upb, blocks, WK, WN, ktpg, kgroups, RS;
+  size_t lds_bytes;
+};
+
+static GemvPlan make_gemv_plan(int wbits, int M, int N, int K, int group_size, bool dual) {
+  GemvPlan p{};
+  const LowpDims d = lowp_dims(wbits, N, K, group_size);
+  p.ok = false;
+  if (M < 1 || M > 16) return p;
+  if (d.group && d.group % d.KTILE != 0) return p;  // groups smaller than a k-tile: general kernel
+  p.ktpg = d.group ? d.group / d.KTILE : (1 << 28);
+  p.MR = M == 1 ? 1 : 4;
+  p.RS = d.Kp + 8;
+  int num_cus = cached_num_cus();
+  if (num_cus <= 0) num_cus = 256;
+  const int units = d.NTILES;
+  // one workgroup per CU when there are enough column tiles; below ~1.5 waves of CUs the launch
+  // is latency bound and one tile per workgroup spreads the loads widest
+  p.upb = units <= num_cus + num_cus / 2 ? 1 : (units + num_cus - 1) / num_cus;
+  p.blocks = (units + p.upb - 1) / p.upb;
+  const int nv = p.upb * (dual ? 2 : 1);
+  const int kgroups = d.group ? (d.KT + p.ktpg - 1) / p.ktpg : d.KT;
+  // wave grid WK x WN: minimise the longest per-wave chunk sequence (ties: fewer k-slices)
+  long best = -1;
+  p.kgroups = kgroups;
+  for (int wn = GEMV_WAVES; wn >= (dual ? 2 : 1); wn /= 2) {
+    const int wkk = GEMV_WAVES / wn;
+    if (wkk > kgroups) continue;
+    const long load = (long)((nv + wn - 1) / wn) * ((kgroups + wkk - 1) / wkk);
+    if (best < 0 || load < best) {
+      best = load;
+      p.WN = wn;
+      p.WK = wkk;
+    }
+  }
+  if (best < 0) {
+    p.WN = GEMV_WAVES;
+    p.WK = 1;
+  }
+  p.lds_bytes = gemv_lds_bytes(M, p.RS, d.KT, p.upb, dual, p.WK);
+  if (p.lds_bytes > 150 * 1024) return p;
+  p.ok = true;
+  return p;
+}
+
+template <int WBITS, int FT>
+static hipError_t dispatch_gemv(const GemvPlan& p, int pro, int epi, const GemvArgs& a, hipStream_t s) {
+  const bool gpt = WBITS != 16 && p.ktpg == 1;
+#define CASE(MR_, PRO_, EPI_)                                                              \
+  if (p.MR == MR_ && pro == PRO_ && epi == EPI_) {                                         \
+    if constexpr (WBITS != 16) {                                                           \
+      if (gpt) return launch_gemv_stream<WBITS, FT, MR_, PRO_, EPI_, 1>(a, p.blocks, p.lds_bytes, s); \
+    }                                                                                      \
+    return launch_gemv_stream<WBITS, FT, MR_, PRO_, EPI_, 0>(a, p.blocks, p.lds_bytes, s); \
+  }
+  CASE(1, PRO_PLAIN, EPI_STD)
+  CASE(4, PRO_PLAIN, EPI_STD)
+  CASE(1, PRO_RMSNORM, EPI_STD)
+  CASE(4, PRO_RMSNORM, EPI_STD)
+  CASE(1, PRO_RMSNORM, EPI_SWIGLU)
+  CASE(4, PRO_RMSNORM, EPI_SWIGLU)
+  CASE(1, PRO_PLAIN, EPI_SWIGLU)
+  CASE(4, PRO_PLAIN, EPI_SWIGLU)
+  CASE(1, PRO_PLAIN, EPI_ADDTO)
+  CASE(4, PRO_PLAIN, EPI_ADDTO)
+  CASE(1, PRO_RMSNORM, EPI_ADDTO)
+  CASE(4, PRO_RMSNORM, EPI_ADDTO)
+#undef CASE
+  return hipErrorInvalidValue;
+}
+
+static unsigned long long* g_gemv_trace = nullptr;
+static size_t g_gemv_trace_bytes = 0;
+static int g_force_general = -1;  // DIHIP_GEMV_STREAM=0 routes everything to the general kernel
+static bool gemv_stream_enabled() {
+  if (g_force_general < 0) {
+    const char* e = getenv("DIHIP_GEMV_STREAM");
+    g_force_general = (e && e[0] == '0') ? 1 : 0;
+  }
+  return g_force_general == 0;
+}
+
 static int run_gemm(hipStream_t stream, const GemmCall& c) {
   DIHIP_REQUIRE(c.M >= 0 && c.N > 0 && c.K > 0, DIHIP_PARAM_ERROR, "gemm_lowp: bad shape M=%d N=%d K=%d",
                 c.M, c.N, c.K);
@@ -233,6 +324,50 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
   DIHIP_REQUIRE(c.x && c.w0 && (c.sz0 || c.wbits == 16), DIHIP_PARAM_ERROR, "gemm_lowp: null input pointer");
   const bool dual = c.epi == EPI_SWIGLU;
   const LowpDims d = lowp_dims(c.wbits, c.N, c.K, c.group_size);
+  const bool gemv_aligned = (c.K == d.Kp) && (c.ldx % 8 == 0) && (reinterpret_cast<uintptr_t>(c.x) % 16 == 0) &&
+                            (c.pro == PRO_PLAIN || reinterpret_cast<uintptr_t>(c.gamma) % 16 == 0);
+  if (c.dtype == DIHIP_BF16 && gemv_stream_enabled() && gemv_aligned) {
+    const GemvPlan gp = make_gemv_plan(c.wbits, c.M, c.N, c.K, c.group_size, dual);
+    if (gp.ok) {
+      GemvArgs g{};
+      g.w0 = reinterpret_cast<const u32x4_t*>(c.w0);
+      g.w1 = reinterpret_cast<const u32x4_t*>(c.w1);
+      g.sz0 = reinterpret_cast<const uint32_t*>(c.sz0);
+      g.sz1 = reinterpret_cast<const uint32_t*>(c.sz1);
+      g.x = c.x;
+      g.ldx = c.ldx;
+      g.gamma = c.gamma;
+      g.eps = c.eps;
+      g.bias = c.bias;
+      g.residual = c.residual;
+      g.y = c.y;
+      g.ldy = c.N;
+      g.h_res = c.h_res;
+      g.h_out = c.h_out;
+      g.alpha = c.alpha;
+      g.act = c.act;
+      g.M = c.M;
+      g.N = c.N;
+      g.K = c.K;
+      g.KT = d.KT;
+      g.NTILES = d.NTILES;
+      g.Gp = lowp_dims(4, c.N, c.K, c.group_size).Gp;
+      g.ktpg = gp.ktpg;
+      g.kgroups = gp.kgroups;
+      g.upb = gp.upb;
+      g.WK = gp.WK;
+      g.WN = gp.WN;
+      g.RS = gp.RS;
+      g.trace = (g_gemv_trace && g_gemv_trace_bytes >= (size_t)gp.blocks * GEMV_WAVES * 64) ? g_gemv_trace : nullptr;
+      hipError_t e = hipErrorInvalidValue;
+      if (c.wbits == 4) e = dispatch_gemv<4, DIHIP_BF16>(gp, c.pro, c.epi, g, stream);
+      else if (c.wbits == 8) e = dispatch_gemv<8, DIHIP_BF16>(gp, c.pro, c.epi, g, stream);
+      else if (c.wbits == 16) e = dispatch_gemv<16, DIHIP_BF16>(gp, c.pro, c.epi, g, stream);
+      DIHIP_REQUIRE(e == hipSuccess, DIHIP_RUNTIME_ERROR, "gemv_stream: launch failed (wbits=%d MR=%d pro=%d epi=%d): %s",
+                    c.wbits, gp.MR, c.pro, c.epi, hipGetErrorString(e));
+      return DIHIP_SUCCESS;
+    }
+  }
   const GemmPlan p = make_plan(c.wbits, c.M, c.N, c.K, c.group_size, dual);
   DIHIP_REQUIRE((size_t)p.col_blocks * p.m_blocks * sizeof(unsigned) <= GEMM_SYNC_BYTES, DIHIP_EXCEED_LIMIT_ERROR,
                 "gemm_lowp: too many tiles for the sync buffer");
@@ -274,6 +409,7 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
   a.KT = d.KT;
   a.NTILES = d.NTILES;
   a.ksteps_per_group = d.group ? d.group / 32 : (1 << 30);
+  a.Gp = lowp_dims(4, c.N, c.K, c.group_size).Gp;  // the pack kernel sizes Gp for the W4 padding
   a.splitk = p.splitk;
   a.ktiles_per_split = p.ktiles_per_split;
   a.kslice_tiles = p.kslice_tiles;
@@ -312,6 +448,24 @@ __global__ __launch_bounds__(256) void rmsnorm_f32_to_ft_kernel(uint16_t* __rest
 using namespace dihip;
 
 extern "C" {
+
+int dihip_debug_set_trace(void* buf, size_t bytes) {
+  g_gemv_trace = reinterpret_cast<unsigned long long*>(buf);
+  g_gemv_trace_bytes = buf ? bytes : 0;
+  return DIHIP_SUCCESS;
+}
+
+int dihip_debug_gemv_plan(int wbits, int M, int N, int K, int group_size, int dual, int* blocks, int* upb, int* wk, int* wn,
+                          size_t* lds_bytes) {
+  const GemvPlan p = make_gemv_plan(wbits, M, N, K, group_size, dual != 0);
+  if (!p.ok) return DIHIP_PARAM_ERROR;
+  if (blocks) *blocks = p.blocks;
+  if (upb) *upb = p.upb;
+  if (wk) *wk = p.WK;
+  if (wn) *wn = p.WN;
+  if (lds_bytes) *lds_bytes = p.lds_bytes;
+  return DIHIP_SUCCESS;
+}
 
 size_t dihip_gemm_lowp_packed_weight_bytes(int wbits, int N, int K) {
   if ((wbits != 4 && wbits != 8) || N <= 0 || K <= 0) return 0;

@@ -63,6 +63,7 @@ struct GemmArgs {
   int KT;      // number of k-tiles (128 k for W4, 64 k for W8)
   int NTILES;  // Np / 16
   int ksteps_per_group;  // group_size / 32, or a huge number for per-channel
+  int Gp;      // (scale, zero) groups stored per column tile: sz layout [NTILES][Gp][16]
   int splitk;
   int ktiles_per_split;
   int kslice_tiles;  // k-tiles staged in LDS at a time (== ktiles_per_split for decode shapes)
@@ -220,14 +221,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_lowp_kernel(const GemmArgs 
     const int tile = min(tile0 + (t % NTW), a.NTILES - 1);
     const bool second = EPI == EPI_SWIGLU && t >= NTW;
     wbase[t] = (second ? a.w1 : a.w0) + (size_t)tile * a.KT * 64 + lane;
-    szbase[t] = (second ? a.sz1 : a.sz0) + tile * 16 + ni;
+    szbase[t] = (second ? a.sz1 : a.sz0) + (size_t)tile * a.Gp * 16 + ni;
   }
 #define DIHIP_ISSUE(SLOT, KT_)                                                                    \
   do {                                                                                            \
     _Pragma("unroll") for (int t_ = 0; t_ < NT; ++t_) {                                           \
       wbuf[SLOT][t_] = __builtin_nontemporal_load(wbase[t_] + (size_t)(KT_) * 64);                \
       if constexpr (QUANT)                                                                        \
-        szbuf[SLOT][t_] = szbase[t_][(size_t)min(((KT_) * KSTEPS) / a.ksteps_per_group, last_grp) * a.Np]; \
+        szbuf[SLOT][t_] = szbase[t_][(size_t)min(((KT_) * KSTEPS) / a.ksteps_per_group, last_grp) * 16]; \
     }                                                                                             \
   } while (0)
   if (wave_active) {
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_lowp_kernel(const GemmArgs 
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          tot[mt][t][r] += s * (gacc[mt][t][r] - zp * xsum[mt][r]);
+          tot[mt][t][r] = fmaf(s, fmaf(-zp, xsum[mt][r], gacc[mt][t][r]), tot[mt][t][r]);
           gacc[mt][t][r] = 0.f;
         }
       }
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_lowp_kernel(const GemmArgs 
                   if (small_groups) {  // rare: group < k-tile, fetch its parameters on demand
                     uint32_t szv[NT];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) szv[t] = szbase[t][(size_t)min(grp, last_grp) * a.Np];
+                    for (int t = 0; t < NT; ++t) szv[t] = szbase[t][(size_t)min(grp, last_grp) * 16];
                     fixup(szv);
                   } else {
                     fixup(szbuf[j]);
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_lowp_kernel(const GemmArgs 
     if (wave_active && ksg != 0) {  // per-channel, or a K range that ends inside a group
       if (small_groups) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) sz_last[t] = szbase[t][(size_t)min(grp, last_grp) * a.Np];
+        for (int t = 0; t < NT; ++t) sz_last[t] = szbase[t][(size_t)min(grp, last_grp) * 16];
       }
       fixup(sz_last);
     }

@@ -1,0 +1,5 @@
+// explicit instantiations: decode fast path (gemv_stream_kernel.hpp), W4, bf16 activations
+#include "gemv_stream_kernel.hpp"
+namespace dihip {
+DIHIP_DEFINE_GEMV_LAUNCH_SET(4, DIHIP_BF16, 0)
+}  // namespace dihip

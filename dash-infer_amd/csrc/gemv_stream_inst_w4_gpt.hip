@@ -1,0 +1,5 @@
+// explicit instantiations: decode fast path, W4, bf16, one quantisation group per k-tile
+#include "gemv_stream_kernel.hpp"
+namespace dihip {
+DIHIP_DEFINE_GEMV_LAUNCH_SET(4, DIHIP_BF16, 1)
+}  // namespace dihip

@@ -1,0 +1,568 @@
+// gemv_stream_kernel.hpp -- decode-shaped (M <= 16 rows) weight-only GEMV for gfx950.
+//
+// The batch-1 decode step is a chain of short weight-streaming launches (7-72 MB each).  At
+// that size the critical path of ONE launch -- not the sustained rate -- decides the achieved
+// HBM GB/s: every dependent global round trip (fence, counter, slab re-read) costs 1-3 us
+// against a 1-12 us transfer, and so does every microsecond of prologue during which no load
+// is in flight.  This kernel therefore
+//
+//   * has NO inter-workgroup communication: a workgroup (8 waves) owns whole 16-column tiles;
+//     its waves split K (and the tiles) among themselves and combine through LDS in a fixed
+//     order (bit-reproducible, no atomics, no fences, no slabs in HBM, no second launch);
+//   * streams each wave's flat sequence of 1 KiB weight chunks ("dihip tile-major": one 16-byte
+//     load per lane is one MFMA B fragment x KSTEPS) through a register ring of D chunks that is
+//     filled right after the activation loads have been issued, with hand-counted s_waitcnt so
+//     that D-1 chunks stay in flight while one is consumed;
+//   * keeps the code path short (one copy of the consume/refill body; the tail is handled by
+//     dummy refills that keep the vmcnt arithmetic uniform) -- six such kernels alternate every
+//     few microseconds and share the instruction cache;
+//   * expands integers with a one-op magic-number trick, feeds them to the MFMA as exact small
+//     numbers and applies scale / zero-point once per quantisation group on the f32
+//     accumulator, with sum_k x[k] taken from a per-k-tile table computed once per workgroup;
+//   * fuses the epilogues (bias, activation, residual | SwiGLU of a gate/up pair | f32
+//     hidden-stream update) and the RMSNorm prologue.
+//
+// Replaces, for decode shapes, gemv_a16w8_subc_splitk_m1_kernel + reduce_sum
+// (gemm_a16w8_subc_kernel.cu:953-1119), the Ampere per-channel split-K kernel
+// (gemm_a16w8_perc_kernel.cu:1573-1762) and hgemm_a16w4_subc_32x256x32 (gemm_a16w4_subc_kernel.cu:466-815).
+//
+// Host-side contract (gemm_lowp.hip: run_gemm / make_gemv_plan): M <= 16, K % KTILE == 0,
+// ldx % 8 == 0, x and gamma 16-byte aligned, group_size % KTILE == 0 or per-channel, LDS budget.
+#pragma once
+#include "gemm_lowp_kernel.hpp"
+
+namespace dihip {
+
+constexpr int GEMV_WAVES = 8;
+constexpr int GEMV_THREADS = GEMV_WAVES * 64;
+constexpr int GEMV_RING = 8;  // 1 KiB chunks in flight per wave
+
+// ---- hand-scheduled weight stream ------------------------------------------------------------
+// The ring loads are issued through inline asm so that hipcc's waitcnt pass does not see them:
+// with control flow in the loop it falls back to draining the ring every iteration (vmcnt(1)
+// at the loop head).  The loop places its own counted `s_waitcnt vmcnt(N)` instead
+// (cdna_hip_programming.md section 5.7 / T3+T4).  saddr form: wave-uniform 64-bit base in
+// SGPRs + a 32-bit per-lane byte offset.
+__device__ __forceinline__ void stream_load_b128(u32x4_t& dst, const void* sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=&v"(dst) : "v"(voff), "s"(sbase));
+}
+__device__ __forceinline__ void stream_load_b32(uint32_t& dst, const void* sbase, uint32_t voff) {
+  asm volatile("global_load_dword %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase));
+}
+__device__ __forceinline__ void stream_load_plain_b128(u32x4_t& dst, const void* sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {  // DPP move, all rows / banks enabled
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int N>
+__device__ __forceinline__ void stream_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));
+}
+// ties registers to the preceding wait: their uses cannot be scheduled above the s_waitcnt
+__device__ __forceinline__ void stream_landed(u32x4_t& w, uint32_t& s) { asm volatile("" : "+v"(w), "+v"(s)); }
+// Activation loads of the prologue are issued BEFORE the ring fill and waited for with a counted
+// vmcnt (loads return in order: a compiler-visible load issued after the ring would only be
+// usable once the whole ring has landed, serialising prologue and first HBM round trip).
+__device__ __forceinline__ void early_landed(u32x4_t& v) { asm volatile("" : "+v"(v)); }
+
+// W4 expansion for the GEMV: pair I of a dword is (d >> 4I) & 0x000F000F; OR-ing the exponent of
+// 128.0 (bf16) / 1024.0 (f16) gives OFFSET + q exactly in both halves.  mask / magic are passed as
+// (opaque) registers so that each pair is one v_lshrrev + one v_and_or_b32.
+template <int WBITS, int FT>
+struct ExpandV {
+  static constexpr float OFFSET = Expand<WBITS, FT>::OFFSET;
+  __device__ __forceinline__ static u32x4_t frag(const u32x4_t& chunk, int ks, uint32_t, uint32_t) {
+    return Expand<WBITS, FT>::frag(chunk, ks);
+  }
+};
+template <int FT>
+struct ExpandV<4, FT> {
+  static constexpr float OFFSET = FT == DIHIP_BF16 ? 128.f : 1024.f;
+  static constexpr uint32_t MASK = 0x000F000Fu;
+  static constexpr uint32_t MAGIC = FT == DIHIP_BF16 ? 0x43004300u : 0x64006400u;
+  __device__ __forceinline__ static u32x4_t frag(const u32x4_t& chunk, int ks, uint32_t mask, uint32_t magic) {
+    const uint32_t d = chunk[ks];
+    return u32x4_t{(d & mask) | magic, ((d >> 4) & mask) | magic, ((d >> 8) & mask) | magic, ((d >> 12) & mask) | magic};
+  }
+};
+
+struct GemvArgs {
+  const u32x4_t* w0;
+  const u32x4_t* w1;    // EPI_SWIGLU: "up" weight
+  const uint32_t* sz0;  // [NTILES][Gp][16] (scale | zero << 16)
+  const uint32_t* sz1;
+  const void* x;  // PRO_PLAIN: FT [M, ldx]; PRO_RMSNORM: f32 [M, ldx]
+  int ldx;
+  const void* gamma;
+  float eps;
+  const void* bias;
+  const void* residual;
+  void* y;
+  int ldy;
+  const float* h_res;
+  float* h_out;
+  float alpha;
+  int act;
+  int M, N, K;
+  int KT;      // k-tiles of the packed weight
+  int NTILES;  // 16-column tiles
+  int Gp;      // (scale, zero) groups stored per tile
+  int ktpg;    // k-tiles per quantisation group (per-channel: >= KT)
+  int kgroups; // K-split units: quantisation groups (sub-channel) or k-tiles (per-channel / W16)
+  int upb;     // units (column tiles; tile pairs for SwiGLU) per workgroup
+  int WK, WN;  // wave grid inside the workgroup, WK * WN == GEMV_WAVES, both powers of two (SwiGLU: WN >= 2)
+  int RS;      // LDS activation row stride in elements (KT * KTILE + 8)
+  unsigned long long* trace;  // diagnostics (dihip_debug_set_trace): [block][wave][8] wall-clock stamps, or null
+};
+
+// LDS carve-up (bytes): [zero block 256][xs : rows * RS * 2][xsum : KT * 16 * 4][red : upb*DUAL * WK * rows * 16 * 4]
+__host__ __device__ inline size_t gemv_xs_bytes(int rows, int RS) { return ((size_t)rows * RS * 2 + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t gemv_lds_bytes(int rows, int RS, int KT, int upb, int dual, int WK) {
+  size_t red = (size_t)upb * (dual ? 2 : 1) * WK * rows * 16 * 4;
+  if (red < 1024) red = 1024;  // also holds the RMSNorm partial sums
+  return 256 + gemv_xs_bytes(rows, RS) + (size_t)KT * 16 * 4 + red;
+}
+
+// GPT: every k-tile is one quantisation group (W4 g128, W8 g64): no accumulator carry between chunks
+template <int WBITS, int FT, int MR, int PRO, int EPI, int GPT>
+__global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArgs a) {
+  using WT = WTraits<WBITS>;
+  using EX = ExpandV<WBITS, FT>;
+  constexpr int KSTEPS = WT::KSTEPS;
+  constexpr int KTILE = WT::KTILE;
+  constexpr bool QUANT = WBITS != 16;
+  constexpr int DUAL = EPI == EPI_SWIGLU ? 2 : 1;
+  constexpr int D = GEMV_RING;
+  constexpr int LPC = QUANT ? 2 : 1;  // loads per chunk
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int rows = MR == 1 ? 1 : a.M;  // <= 16
+  uint16_t* xs = reinterpret_cast<uint16_t*>(smem + 256);
+  float* xsum_tab = reinterpret_cast<float*>(smem + 256 + gemv_xs_bytes(rows, a.RS));
+  float* red = xsum_tab + (size_t)a.KT * 16;
+
+  const int tid = threadIdx.x;
+  // wave-uniform bookkeeping lives in SGPRs
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int ni = lane & 15, kb = lane >> 4;
+  const int lgWK = __builtin_ctz(a.WK), lgWN = __builtin_ctz(a.WN);
+  const int wk = wave & (a.WK - 1), wn = wave >> lgWK;
+
+#define DIHIP_GEMV_STAMP(I)                                                                        \
+  do {                                                                                             \
+    if (a.trace && lane == 0) a.trace[((size_t)blockIdx.x * GEMV_WAVES + wave) * 8 + (I)] = wall_clock64(); \
+  } while (0)
+  DIHIP_GEMV_STAMP(0);
+
+  // ---- early activation loads -------------------------------------------------------------------
+  // Every thread owns 8-element vectors i = j*THREADS + tid of a row (k = 8i): PRO_PLAIN loads 16
+  // bytes of x, PRO_RMSNORM 2 x 16 bytes of the f32 hidden stream + 16 bytes of gamma.  Vector
+  // indices beyond the row are clamped (harmless reload) instead of predicated.
+  const int Kp = a.KT * KTILE;  // == K (host contract)
+  const int nvec = Kp >> 3;
+  constexpr int NE = PRO == PRO_RMSNORM ? 2 : 8;  // vectors per thread per batch
+  u32x4_t ev[PRO == PRO_RMSNORM ? 2 * NE : NE];
+  u32x4_t eg[PRO == PRO_RMSNORM ? NE : 1];
+  auto issue_batch = [&](int r, int v0) {
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const uint32_t i = (uint32_t)min(v0 + j * GEMV_THREADS + tid, nvec - 1);
+      if constexpr (PRO == PRO_RMSNORM) {
+        const float* hrow = reinterpret_cast<const float*>(a.x) + (size_t)r * a.ldx;
+        stream_load_plain_b128(ev[2 * j], hrow, i * 32u);
+        stream_load_plain_b128(ev[2 * j + 1], hrow, i * 32u + 16u);
+        stream_load_plain_b128(eg[j], a.gamma, i * 16u);
+      } else {
+        stream_load_plain_b128(ev[j], reinterpret_cast<const uint16_t*>(a.x) + (size_t)r * a.ldx, i * 16u);
+      }
+    }
+  };
+  constexpr int EARLY_LOADS = PRO == PRO_RMSNORM ? 3 * NE : NE;
+  issue_batch(0, 0);
+
+  // ---- this workgroup's units and this wave's share ---------------------------------------
+  const int u0 = blockIdx.x * a.upb;
+  const int nu = min(a.upb, a.NTILES - u0);  // units of this workgroup (SwiGLU: (gate, up) tile pairs)
+  const int nv = nu * DUAL;                  // half-units (one weight tile each)
+  // K split in whole quantisation groups (per-channel: any k-tile boundary)
+  const bool subc = QUANT && a.ktpg < a.KT;
+  const int gsz = subc ? a.ktpg : 1;
+  const int gcount = subc ? a.ktpg : (1 << 30);  // group countdown start (per-channel: never expires)
+  const int g_lo = (a.kgroups * wk) >> lgWK;
+  const int k_lo = min(a.KT, g_lo * gsz);
+  const int k_hi = min(a.KT, ((a.kgroups * (wk + 1)) >> lgWK) * gsz);
+  const int nk = k_hi - k_lo;
+  const int nvw = wn < nv ? (nv - wn + a.WN - 1) >> lgWN : 0;  // half-units v = wn, wn + WN, ...
+  const int total = nvw * nk;
+
+  // ---- register ring ----------------------------------------------------------------------
+  u32x4_t wb[D];
+  uint32_t sb[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) sb[j] = 0u;
+  // A wave walks tiles t0, t0 + tstep, ... of ONE matrix (SwiGLU: WN is even, so the parity of the
+  // half-unit index -- gate or up -- is fixed per wave); chunk pointers advance by constant strides.
+  // The refill is branch-free scalar code; once the sequence is exhausted the cursor parks on a
+  // dummy chunk (the head of the matrix), which keeps the vmcnt arithmetic uniform in the tail.
+  const bool second = DUAL == 2 && (wn & 1);
+  const int t0 = u0 + (DUAL == 2 ? wn >> 1 : wn);
+  const int tstep = DUAL == 2 ? a.WN >> 1 : a.WN;
+  const char* const dummy_w = reinterpret_cast<const char*>(a.w0);
+  const char* const dummy_s = dummy_w;
+  const char* wtile = reinterpret_cast<const char*>((second ? a.w1 : a.w0) + ((size_t)t0 * a.KT + k_lo) * 64);
+  const char* stile = QUANT ? reinterpret_cast<const char*>((second ? a.sz1 : a.sz0) + ((size_t)t0 * a.Gp + (subc ? g_lo : 0)) * 16)
+                            : dummy_s;
+  const size_t wstep = (size_t)tstep * a.KT * 1024, sstep = QUANT ? (size_t)tstep * a.Gp * 64 : 0;
+  int to_issue = total;  // real chunks not yet issued
+  const char* iwp = wtile;
+  const char* isp = stile;
+  int ikt = k_lo, igl = gcount;  // issue cursor: k-tile, group countdown
+  const uint32_t voff_w = (uint32_t)lane * 16u, voff_s = (uint32_t)ni * 4u;
+  // next real chunk into ring slot SLOT
+#define DIHIP_GEMV_ISSUE(SLOT)                                       \
+  do {                                                               \
+    stream_load_b128(wb[SLOT], iwp, voff_w);                         \
+    if constexpr (QUANT) stream_load_b32(sb[SLOT], isp, voff_s);     \
+    iwp += 1024;                                                     \
+    if constexpr (QUANT && GPT) {                                    \
+      isp += 64;                                                     \
+    } else if constexpr (QUANT) {                                    \
+      if (--igl == 0) {                                              \
+        igl = gcount;                                                \
+        isp += 64;                                                   \
+      }                                                              \
+    }                                                                \
+    if (++ikt == k_hi) {                                             \
+      ikt = k_lo;                                                    \
+      igl = gcount;                                                  \
+      wtile += wstep;                                                \
+      stile += sstep;                                                \
+      iwp = wtile;                                                   \
+      isp = stile;                                                   \
+    }                                                                \
+  } while (0)
+  // (tail) dummy loads that keep the vmcnt arithmetic uniform: one L2-resident line, never used
+#define DIHIP_GEMV_DUMMY(SLOT)                                       \
+  do {                                                               \
+    stream_load_b32(sb[SLOT], dummy_w, 0u);                          \
+    if constexpr (QUANT) stream_load_b32(sb[SLOT], dummy_w, 0u);     \
+  } while (0)
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    if (to_issue > 0) {
+      DIHIP_GEMV_ISSUE(j);
+      --to_issue;
+    } else {
+      DIHIP_GEMV_DUMMY(j);
+    }
+  }
+  DIHIP_GEMV_STAMP(1);
+
+  // ---- activation prologue ------------------------------------------------------------------
+  // x (normalised for PRO_RMSNORM) goes to LDS as FT rows; the per-k-tile sums
+  // xsum_tab[kt][row] = sum_{k in tile} x[row][k] are taken on the way: 8-element partials in a
+  // fixed pairwise order, combined over the KTILE/8 lanes of a tile by an xor butterfly (DPP).
+  if (tid < 16) reinterpret_cast<u32x4_t*>(smem)[tid] = u32x4_t{0u, 0u, 0u, 0u};  // zero block
+  auto stage_vector = [&](int r, int i, const u32x4_t& v) {  // i < nvec (wave-uniform validity handled by caller)
+    *reinterpret_cast<u32x4_t*>(xs + (size_t)r * a.RS + i * 8) = v;
+    if constexpr (QUANT) {
+      float e[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        e[2 * q] = ft_bits_to_f32<FT>(v[q] & 0xFFFFu);
+        e[2 * q + 1] = ft_bits_to_f32<FT>(v[q] >> 16);
+      }
+      float sum = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+      sum += dpp_f32<0xB1>(sum);                           // quad_perm [1,0,3,2]: xor 1
+      sum += dpp_f32<0x4E>(sum);                           // quad_perm [2,3,0,1]: xor 2
+      if constexpr (KTILE >= 64) sum += dpp_f32<0x141>(sum);   // row_half_mirror: other quad of the 8
+      if constexpr (KTILE >= 128) sum += dpp_f32<0x140>(sum);  // row_mirror: other half of the 16
+      if ((i & (KTILE / 8 - 1)) == 0) xsum_tab[(i / (KTILE / 8)) * 16 + r] = sum;
+    }
+  };
+  for (int r = 0; r < rows; ++r) {
+    if constexpr (PRO == PRO_RMSNORM) {
+      // LayerNormNoBeta of the f32 hidden stream (csrc/core/kernel/cpu/layernorm.cpp:110-157):
+      // rstd = 1/sqrt(mean(x^2)+eps); x_norm = FT((gamma*x)*rstd)
+      float ss = 0.f;
+      for (int v0 = 0; v0 < nvec; v0 += NE * GEMV_THREADS) {
+        if (r > 0 || v0 > 0) {
+          issue_batch(r, v0);
+          stream_wait<0>();
+        } else {
+          stream_wait<D * LPC>();  // everything older than the ring fill has landed
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * NE; ++j) early_landed(ev[j]);
+#pragma unroll
+        for (int j = 0; j < NE; ++j) early_landed(eg[j]);
+        if (r == 0 && v0 == 0) DIHIP_GEMV_STAMP(2);
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+          if (v0 + j * GEMV_THREADS + tid < nvec) {
+            const f32x4_t h0 = __builtin_bit_cast(f32x4_t, ev[2 * j]), h1 = __builtin_bit_cast(f32x4_t, ev[2 * j + 1]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ss = fmaf(h0[q], h0[q], ss);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ss = fmaf(h1[q], h1[q], ss);
+          }
+        }
+      }
+      ss = wave_sum(ss);
+      if (r > 0) __syncthreads();  // previous row's readers of `red` are done
+      if (lane == 0) red[wave] = ss;
+      __syncthreads();
+      float tot_ss = 0.f;
+#pragma unroll
+      for (int w = 0; w < GEMV_WAVES; ++w) tot_ss += red[w];
+      const float rstd = 1.f / sqrtf(tot_ss / (float)a.K + a.eps);
+      for (int v0 = 0; v0 < nvec; v0 += NE * GEMV_THREADS) {
+        if (nvec > NE * GEMV_THREADS) {  // multi-batch rows: fetch again (single-batch rows still hold their vectors)
+          issue_batch(r, v0);
+          stream_wait<0>();
+#pragma unroll
+          for (int j = 0; j < 2 * NE; ++j) early_landed(ev[j]);
+#pragma unroll
+          for (int j = 0; j < NE; ++j) early_landed(eg[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+          const int i = v0 + j * GEMV_THREADS + tid;
+          if (i < nvec) {
+            const f32x4_t h0 = __builtin_bit_cast(f32x4_t, ev[2 * j]), h1 = __builtin_bit_cast(f32x4_t, ev[2 * j + 1]);
+            u32x4_t o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float ga = ft_bits_to_f32<FT>(eg[j][q] & 0xFFFFu), gb = ft_bits_to_f32<FT>(eg[j][q] >> 16);
+              const float xa = q < 2 ? h0[2 * q] : h1[2 * q - 4], xb = q < 2 ? h0[2 * q + 1] : h1[2 * q - 3];
+              o[q] = f32_to_ft_bits<FT>((ga * xa) * rstd) | (f32_to_ft_bits<FT>((gb * xb) * rstd) << 16);
+            }
+            stage_vector(r, i, o);
+          }
+        }
+      }
+    } else {
+      for (int v0 = 0; v0 < nvec; v0 += NE * GEMV_THREADS) {
+        if (r > 0 || v0 > 0) {
+          issue_batch(r, v0);
+          stream_wait<0>();
+        } else {
+          stream_wait<D * LPC>();
+        }
+#pragma unroll
+        for (int j = 0; j < NE; ++j) early_landed(ev[j]);
+        if (r == 0 && v0 == 0) DIHIP_GEMV_STAMP(2);
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+          const int i = v0 + j * GEMV_THREADS + tid;
+          if (i < nvec) stage_vector(r, i, ev[j]);
+        }
+      }
+    }
+  }
+  (void)EARLY_LOADS;
+  __syncthreads();
+  DIHIP_GEMV_STAMP(3);
+
+  // ---- main loop ---------------------------------------------------------------------------------
+  float tot[MR], xacc[MR];
+#pragma unroll
+  for (int r = 0; r < MR; ++r) tot[r] = xacc[r] = 0.f;
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t g0 = zero4, g1 = zero4;
+  uint32_t ex_mask = 0x000F000Fu, ex_magic = FT == DIHIP_BF16 ? 0x43004300u : 0x64006400u;
+  asm volatile("" : "+v"(ex_mask), "+v"(ex_magic));  // opaque: keeps (x & mask) | magic a v_and_or_b32
+  // consume cursor: half-unit cv, k-tile ckt, group countdown cgl.  A rows >= M read the zero block
+  // (LDS byte address 0, no advance); the others walk their activation row.
+  int cv = wn, ckt = k_lo, cgl = gcount;
+  const bool arow_valid = ni < rows;
+  const uint32_t xk_reset = arow_valid ? 256u + (uint32_t)(ni * a.RS + kb * 8 + k_lo * KTILE) * 2u : 0u;
+  const uint32_t xk_step = arow_valid ? (uint32_t)KTILE * 2u : 0u;
+  uint32_t xk = xk_reset;
+  const float* xt = xsum_tab + k_lo * 16 + (MR == 1 ? 0 : kb * 4);
+
+#define DIHIP_GEMV_CONSUME(SLOT)                                                                  \
+  do {                                                                                            \
+    _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                       \
+      const u32x4_t af_ = *reinterpret_cast<const u32x4_t*>(smem + xk + ks * 64);                 \
+      const u32x4_t bf_ = EX::frag(wb[SLOT], ks, ex_mask, ex_magic);                              \
+      if constexpr (QUANT && GPT) {                                                               \
+        if (ks & 1) g1 = mfma16<FT>(af_, bf_, ks == 1 ? zero4 : g1);                              \
+        else g0 = mfma16<FT>(af_, bf_, ks == 0 ? zero4 : g0);                                     \
+      } else {                                                                                    \
+        if (ks & 1) g1 = mfma16<FT>(af_, bf_, g1);                                                \
+        else g0 = mfma16<FT>(af_, bf_, g0);                                                       \
+      }                                                                                           \
+    }                                                                                             \
+    xk += xk_step;                                                                                \
+    const bool tile_end_ = ++ckt == k_hi;                                                         \
+    if constexpr (QUANT) {                                                                        \
+      const float s_ = ft_bits_to_f32<FT>(sb[SLOT] & 0xFFFFu);                                    \
+      const float nzp_ = -(ft_bits_to_f32<FT>(sb[SLOT] >> 16) + EX::OFFSET);                      \
+      if constexpr (GPT) {                                                                        \
+        if constexpr (MR == 1) {                                                                  \
+          tot[0] = fmaf(s_, fmaf(nzp_, xt[0], KSTEPS > 1 ? g0[0] + g1[0] : g0[0]), tot[0]);       \
+        } else {                                                                                  \
+          const f32x4_t xv_ = *reinterpret_cast<const f32x4_t*>(xt);                              \
+          _Pragma("unroll") for (int r = 0; r < MR; ++r)                                          \
+            tot[r] = fmaf(s_, fmaf(nzp_, xv_[r], KSTEPS > 1 ? g0[r] + g1[r] : g0[r]), tot[r]);    \
+        }                                                                                         \
+        xt += 16;                                                                                 \
+      } else {                                                                                    \
+        if constexpr (MR == 1) {                                                                  \
+          xacc[0] += xt[0];                                                                       \
+        } else {                                                                                  \
+          const f32x4_t xv_ = *reinterpret_cast<const f32x4_t*>(xt);                              \
+          _Pragma("unroll") for (int r = 0; r < MR; ++r) xacc[r] += xv_[r];                       \
+        }                                                                                         \
+        xt += 16;                                                                                 \
+        if (--cgl == 0 || tile_end_) { /* group end (wave-uniform) */                             \
+          cgl = gcount;                                                                           \
+          _Pragma("unroll") for (int r = 0; r < MR; ++r) {                                        \
+            tot[r] = fmaf(s_, fmaf(nzp_, xacc[r], KSTEPS > 1 ? g0[r] + g1[r] : g0[r]), tot[r]);   \
+            xacc[r] = 0.f;                                                                        \
+          }                                                                                       \
+          g0 = zero4;                                                                             \
+          g1 = zero4;                                                                             \
+        }                                                                                         \
+      }                                                                                           \
+    }                                                                                             \
+    if (tile_end_) {                                                                              \
+      if constexpr (!QUANT) {                                                                     \
+        _Pragma("unroll") for (int r = 0; r < MR; ++r) tot[r] = g0[r] + g1[r];                    \
+        g0 = zero4;                                                                               \
+        g1 = zero4;                                                                               \
+      }                                                                                           \
+      /* partial of (half-unit cv, k-slice wk): rows kb*4 + r, column ni */                       \
+      float* dst_ = red + ((size_t)(cv * a.WK + wk) * rows) * 16 + ni;                            \
+      _Pragma("unroll") for (int r = 0; r < MR; ++r) {                                            \
+        const int m_ = kb * 4 + r;                                                                \
+        if (m_ < rows) dst_[m_ * 16] = tot[r];                                                    \
+        tot[r] = 0.f;                                                                             \
+      }                                                                                           \
+      ckt = k_lo;                                                                                 \
+      cv += a.WN;                                                                                 \
+      xk = xk_reset;                                                                              \
+      xt = xsum_tab + k_lo * 16 + (MR == 1 ? 0 : kb * 4);                                         \
+    }                                                                                             \
+  } while (0)
+
+  if (nk == 0) {
+    // a k-slice without work (fewer groups than WK): its partials must read as zero
+    for (int v = wn; v < nv; v += a.WN) {
+      float* dst = red + ((size_t)(v * a.WK + wk) * rows) * 16;
+      for (int i = lane; i < rows * 16; i += 64) dst[i] = 0.f;
+    }
+  }
+  // Consume slot j -- everything older than the D-1 refills issued after it has landed -- and
+  // refill it.  Steady state: every refill is a real chunk.
+  int c = 0;
+  while (to_issue >= D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      stream_wait<(D - 1) * LPC>();
+      stream_landed(wb[j], sb[j]);
+      DIHIP_GEMV_CONSUME(j);
+      DIHIP_GEMV_ISSUE(j);
+    }
+    to_issue -= D;
+    c += D;
+  }
+  // last real refills, then dummies
+  for (; c < total; c += D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      if (c + j < total) {
+        stream_wait<(D - 1) * LPC>();
+        stream_landed(wb[j], sb[j]);
+        DIHIP_GEMV_CONSUME(j);
+        if (to_issue > 0) {
+          DIHIP_GEMV_ISSUE(j);
+          --to_issue;
+        } else {
+          DIHIP_GEMV_DUMMY(j);
+        }
+      }
+    }
+  }
+  // the ring registers die here: no load may still be in flight into them
+  stream_wait<0>();
+#undef DIHIP_GEMV_ISSUE
+#undef DIHIP_GEMV_DUMMY
+#undef DIHIP_GEMV_CONSUME
+  DIHIP_GEMV_STAMP(4);
+  __syncthreads();
+  DIHIP_GEMV_STAMP(5);
+
+  // ---- combine the k-slices in fixed order + epilogue ----------------------------------------
+  for (int e = tid; e < nu * rows * 16; e += GEMV_THREADS) {
+    const int col = e & 15;
+    const int m = MR == 1 ? 0 : (e >> 4) % rows;
+    const int u = MR == 1 ? (e >> 4) : (e >> 4) / rows;
+    const int n = (u0 + u) * 16 + col;
+    if (n >= a.N) continue;
+    float v = 0.f, v2 = 0.f;
+    const float* p = red + ((size_t)(u * DUAL) * a.WK * rows + m) * 16 + col;
+    for (int s = 0; s < a.WK; ++s) v += p[(size_t)s * rows * 16];
+    if constexpr (DUAL == 2) {
+      const float* p2 = p + (size_t)a.WK * rows * 16;
+      for (int s = 0; s < a.WK; ++s) v2 += p2[(size_t)s * rows * 16];
+    }
+    if constexpr (EPI == EPI_STD) {
+      v = __fmul_rn(a.alpha, v);
+      if (a.bias) v = __fadd_rn(v, load_ft<FT>(a.bias, n));
+      v = apply_act(v, a.act);
+      if (a.residual) v = ft_round<FT>(v) + load_ft<FT>(a.residual, (size_t)m * a.ldy + n);
+      store_ft<FT>(a.y, (size_t)m * a.ldy + n, v);
+    } else if constexpr (EPI == EPI_SWIGLU) {
+      store_ft<FT>(a.y, (size_t)m * a.ldy + n, (v / (1.f + expf(-v))) * v2);
+    } else {
+      const float base = a.h_res ? a.h_res[(size_t)m * a.N + n] : 0.f;
+      a.h_out[(size_t)m * a.N + n] = __fadd_rn(base, __fmul_rn(a.alpha, v));
+    }
+  }
+  DIHIP_GEMV_STAMP(6);
+#undef DIHIP_GEMV_STAMP
+}
+
+template <int WBITS, int FT, int MR, int PRO, int EPI, int GPT>
+hipError_t launch_gemv_stream(const GemvArgs& a, int blocks, size_t lds_bytes, hipStream_t stream);
+
+#define DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, MR, PRO, EPI, GPT)                                    \
+  template <>                                                                                     \
+  hipError_t launch_gemv_stream<WBITS, FT, MR, PRO, EPI, GPT>(const GemvArgs& a, int blocks,      \
+                                                              size_t lds_bytes, hipStream_t s) {  \
+    auto kern = gemv_stream_kernel<WBITS, FT, MR, PRO, EPI, GPT>;                                 \
+    if (lds_bytes > 64 * 1024) {                                                                  \
+      static size_t granted = 0;                                                                  \
+      if (lds_bytes > granted) {                                                                  \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,            \
+                                           (int)lds_bytes);                                       \
+        if (e != hipSuccess) return e;                                                            \
+        granted = lds_bytes;                                                                      \
+      }                                                                                           \
+    }                                                                                             \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(GEMV_THREADS), lds_bytes, s, a);                  \
+    return hipGetLastError();                                                                     \
+  }
+
+// the forms the decode step uses, for one (WBITS, FT, GPT)
+#define DIHIP_DEFINE_GEMV_LAUNCH_SET(WBITS, FT, GPT)                  \
+  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 1, PRO_PLAIN, EPI_STD, GPT)     \
+  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 4, PRO_PLAIN, EPI_STD, GPT)     \
+  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 1, PRO_RMSNORM, EPI_STD, GPT)   \
+  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 4, PRO_RMSNORM, EPI_STD, GPT)   \
+  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 1, PRO_RMSNORM, EPI_SWIGLU, GPT) \
+  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 4, PRO_RMSNORM, EPI_SWIGLU, GPT) \
+  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 1, PRO_PLAIN, EPI_SWIGLU, GPT)  \
+  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 4, PRO_PLAIN, EPI_SWIGLU, GPT)  \
+  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 1, PRO_PLAIN, EPI_ADDTO, GPT)   \
+  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 4, PRO_PLAIN, EPI_ADDTO, GPT)   \
+  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 1, PRO_RMSNORM, EPI_ADDTO, GPT) \
+  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 4, PRO_RMSNORM, EPI_ADDTO, GPT)
+
+}  // namespace dihip

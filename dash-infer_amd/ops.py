@@ -76,6 +76,16 @@ def lowp_workspace_bytes(wbits, M, N, K, group):
     return int(lib().dihip_gemm_lowp_workspace_bytes(wbits, M, N, K, -1 if group in (None, 0) else group))
 
 
+def gemv_plan(wbits, M, N, K, group, dual=False):
+    """Launch plan of the decode GEMV for a shape, or None when the general kernel serves it."""
+    blocks, upb, wk, wn, lds = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_size_t()
+    st = lib().dihip_debug_gemv_plan(wbits, M, N, K, -1 if group in (None, 0) else group, int(dual), C.byref(blocks),
+                                     C.byref(upb), C.byref(wk), C.byref(wn), C.byref(lds))
+    if st != 0:
+        return None
+    return {"blocks": blocks.value, "upb": upb.value, "WK": wk.value, "WN": wn.value, "lds_bytes": lds.value}
+
+
 def gemm_lowp(x, pw, bias=None, residual=None, act=None, alpha=1.0, scratch=None, use_sync=True):
     """op GemmA16W8 / GemmA16W4: x FT [..., K] -> FT [..., N]."""
     M = x.numel() // pw.K

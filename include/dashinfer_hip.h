@@ -263,6 +263,16 @@ int dihip_allreduce_sum(void* comm, void* stream, const void* in, void* out, siz
 int dihip_allgather_bytes(void* comm, void* stream, const void* in, void* out,
                           size_t bytes_per_rank);
 
+/* =============================================================================================
+ * 7. Diagnostics (no reference counterpart)
+ * ========================================================================================== */
+/* Per-wave wall-clock stamps of the decode GEMV (gemv_stream_kernel.hpp): the next launches write
+ * [workgroup][8 waves][8 stamps] uint64 (100 MHz ticks) into `buf` while it is set; NULL disables. */
+int dihip_debug_set_trace(void* buf, size_t bytes);
+/* launch plan of the decode GEMV for a shape (DIHIP_PARAM_ERROR when the general kernel is used) */
+int dihip_debug_gemv_plan(int wbits, int M, int N, int K, int group_size, int dual, int* blocks,
+                          int* upb, int* wk, int* wn, size_t* lds_bytes);
+
 #ifdef __cplusplus
 }
 #endif

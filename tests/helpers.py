@@ -58,11 +58,11 @@ def pack_tile_major(wq, N, wbits):
 
 
 def pack_sz(scales_bits, zeros_bits, N, K, group):
-    """uint16 bit patterns [G,N] -> uint32 [Gp, Np] (lo = scale, hi = zero)."""
+    """uint16 bit patterns [G,N] -> uint32 [NTILES, Gp, 16] (column-tile major; lo = scale, hi = zero)."""
     Np = roundup(N, 16)
     Kp = roundup(K, 128)
     G = scales_bits.shape[0]
     Gp = max(G, (Kp + group - 1) // group) if group and group > 0 else 1
     out = np.zeros((Gp, Np), np.uint32)
     out[:G, :N] = scales_bits.astype(np.uint32) | (zeros_bits.astype(np.uint32) << 16)
-    return out
+    return np.ascontiguousarray(out.reshape(Gp, Np // 16, 16).transpose(1, 0, 2))

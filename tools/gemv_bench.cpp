@@ -1,0 +1,110 @@
+// gemv_bench.cpp -- stand-alone timing of the decode GEMV shapes through the C-ABI (no torch).
+//   hipcc -O2 tools/gemv_bench.cpp -Iinclude -Ldash-infer_amd/lib -ldashinfer_hip -o gpurun_out/gemv_bench
+// Cycles through NCOPY weight copies (> 256 MB Infinity Cache) and times LAUNCHES back-to-back
+// launches with HIP events on the launch stream.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include "dashinfer_hip.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+struct Shape { const char* name; int kind; int N, K; };  // kind 0 norm_gemm, 1 addto, 2 norm_swiglu, 3 lm_head
+
+int main(int argc, char** argv) {
+  setvbuf(stdout, NULL, _IONBF, 0);
+  int wbits = argc > 1 ? atoi(argv[1]) : 4;
+  int group = argc > 2 ? atoi(argv[2]) : (wbits == 4 ? 128 : -1);
+  int M = argc > 3 ? atoi(argv[3]) : 1;
+  int reps = argc > 4 ? atoi(argv[4]) : 5;
+  const Shape shapes[] = {{"qkv_norm_gemv", 0, 4608, 3584}, {"o_addto", 1, 3584, 3584},
+                          {"gate_up_swiglu", 2, 18944, 3584}, {"down_addto", 1, 3584, 18944},
+                          {"lm_head", 3, 152064, 3584}};
+  hipStream_t st; CK(hipStreamCreate(&st));
+  void *ws, *sync; size_t ws_bytes = 64 << 20;
+  CK(hipMalloc(&ws, ws_bytes)); CK(hipMalloc(&sync, dihip_gemm_lowp_sync_bytes())); CK(hipMemset(sync, 0, dihip_gemm_lowp_sync_bytes()));
+  const char* only = getenv("SHAPE");
+  for (const Shape& s : shapes) {
+    if (only && strcmp(only, s.name) != 0) continue;
+    const bool dense = s.kind == 3;
+    size_t wb = dense ? dihip_dense_packed_weight_bytes(s.N, s.K) : dihip_gemm_lowp_packed_weight_bytes(wbits, s.N, s.K);
+    size_t szb = dense ? 0 : dihip_gemm_lowp_packed_sz_bytes(s.N, s.K, group);
+    size_t per = (wb + szb) * (s.kind == 2 ? 2 : 1);
+    int ncopy = dense ? 2 : (int)((1200ull << 20) / per) + 1; if (ncopy > 28) ncopy = 28;
+    std::vector<void*> W(ncopy * 2), SZ(ncopy * 2);
+    // random weights; (scale, zero) words: scale ~ 2^-7 (bf16 0x3C00), zero ~ 8.0 (0x4100)
+    std::vector<uint32_t> hsz(szb / 4 + 1, 0x41003C00u);
+    std::vector<uint8_t> hw(wb);
+    for (size_t i = 0; i < wb; ++i) hw[i] = (uint8_t)(rand() >> 7);
+    if (dense) { uint16_t* p = (uint16_t*)hw.data(); for (size_t i = 0; i < wb / 2; ++i) p[i] = 0x3C00 | (rand() & 0x807F); }
+    for (int c = 0; c < ncopy * (s.kind == 2 ? 2 : 1); ++c) {
+      CK(hipMalloc(&W[c], wb)); CK(hipMemcpy(W[c], hw.data(), wb, hipMemcpyHostToDevice));
+      if (szb) { CK(hipMalloc(&SZ[c], szb)); CK(hipMemcpy(SZ[c], hsz.data(), szb, hipMemcpyHostToDevice)); }
+    }
+    float* h; CK(hipMalloc(&h, (size_t)M * 18944 * 4));
+    std::vector<float> hh((size_t)M * 18944); for (auto& v : hh) v = (rand() % 2001 - 1000) * 1e-3f;
+    CK(hipMemcpy(h, hh.data(), hh.size() * 4, hipMemcpyHostToDevice));
+    uint16_t *xb, *gamma, *y, *bias; CK(hipMalloc(&xb, (size_t)M * 18944 * 2)); CK(hipMalloc(&gamma, 18944 * 2)); CK(hipMalloc(&y, (size_t)M * 152064 * 4)); CK(hipMalloc(&bias, 18944 * 2));
+    CK(hipMemset(xb, 0x3c, (size_t)M * 18944 * 2)); CK(hipMemset(gamma, 0x3f, 18944 * 2)); CK(hipMemset(bias, 0, 18944 * 2));
+    float* hout; CK(hipMalloc(&hout, (size_t)M * 18944 * 4)); CK(hipMemset(hout, 0, (size_t)M * 18944 * 4));
+    auto launch = [&](int c) {
+      int rc = 0;
+      switch (s.kind) {
+        case 0: rc = dihip_fused_norm_gemm(st, wbits, h, gamma, 1e-6f, W[c], SZ[c], bias, y, M, s.N, s.K, group, 0, ws, ws_bytes, sync, DIHIP_BF16); break;
+        case 1: rc = dihip_fused_gemm_addto(st, wbits, xb, W[c], SZ[c], hout, hout, M, s.N, s.K, group, ws, ws_bytes, sync, DIHIP_BF16); break;
+        case 2: rc = dihip_fused_norm_swiglu(st, wbits, h, gamma, 1e-6f, W[2 * c], SZ[2 * c], W[2 * c + 1], SZ[2 * c + 1], y, M, s.N, s.K, group, ws, ws_bytes, sync, DIHIP_BF16); break;
+        case 3: rc = dihip_lm_head(st, (float*)y, h, gamma, 1e-6f, W[c], M, s.N, s.K, ws, ws_bytes, sync, DIHIP_BF16); break;
+      }
+      if (rc) { printf("%s: status %d: %s\n", s.name, rc, dihip_last_error()); exit(1); }
+    };
+    printf("[%s] warm-up...\n", s.name);
+    for (int c = 0; c < ncopy; ++c) launch(c);
+    CK(hipStreamSynchronize(st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9f, sum = 0;
+    for (int r = 0; r < reps; ++r) {
+      CK(hipEventRecord(e0, st));
+      for (int c = 0; c < ncopy; ++c) launch(c);
+      CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      float us = ms * 1e3f / ncopy; if (us < best) best = us; sum += us;
+    }
+    if (getenv("TRACE")) {
+      int blocks = 0, upb = 0, wk = 0, wn = 0; size_t lds = 0;
+      int ok = dihip_debug_gemv_plan(dense ? 16 : wbits, M, s.N, s.K, dense ? -1 : group, s.kind == 2, &blocks, &upb, &wk, &wn, &lds);
+      if (ok == 0) {
+        size_t tb = (size_t)blocks * 8 * 8 * 8;
+        unsigned long long* tr; CK(hipMalloc(&tr, tb)); CK(hipMemset(tr, 0, tb));
+        for (int c = 0; c < 3 && c < ncopy; ++c) launch(c);
+        CK(hipStreamSynchronize(st)); printf("  pre-trace launches ok; tr=%p tb=%zu\n", (void*)tr, tb);
+        dihip_debug_set_trace(tr, tb);
+        launch(ncopy - 1);
+        CK(hipStreamSynchronize(st)); printf("  trace launch ok\n");
+        dihip_debug_set_trace(nullptr, 0);
+        CK(hipStreamSynchronize(st));
+        std::vector<unsigned long long> ht(tb / 8);
+        CK(hipMemcpy(ht.data(), tr, tb, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < blocks * 8; ++b) if (ht[b * 8] && ht[b * 8] < t0) t0 = ht[b * 8];
+        printf("  plan: blocks %d upb %d WK %d WN %d lds %zu; stamps (us after first wave start) min / median / max over waves\n", blocks, upb, wk, wn, lds);
+        const char* names[7] = {"entry", "ring issued", "early landed", "prologue done", "main loop done", "block synced", "end"};
+        for (int st_ = 0; st_ < 7; ++st_) {
+          std::vector<double> v;
+          for (int b = 0; b < blocks * 8; ++b) if (ht[b * 8 + st_]) v.push_back((double)(ht[b * 8 + st_] - t0) * 0.01);
+          if (v.empty()) continue;
+          std::sort(v.begin(), v.end());
+          printf("    %-15s %7.2f %7.2f %7.2f\n", names[st_], v.front(), v[v.size() / 2], v.back());
+        }
+        CK(hipFree(tr));
+      }
+    }
+    printf("%-16s W%d g%d M=%d N=%d K=%d  bytes/launch %.2f MB  avg %.2f us  best %.2f us  -> %.0f GB/s (best %.0f)\n", s.name, dense ? 16 : wbits,
+           group, M, s.N, s.K, per / 1e6, sum / reps, best, per / (sum / reps) / 1e3, per / best / 1e3);
+    for (int c = 0; c < ncopy * (s.kind == 2 ? 2 : 1); ++c) { CK(hipFree(W[c])); if (szb) CK(hipFree(SZ[c])); }
+    CK(hipFree(h)); CK(hipFree(xb)); CK(hipFree(gamma)); CK(hipFree(y)); CK(hipFree(bias)); CK(hipFree(hout));
+  }
+  return 0;
+}
