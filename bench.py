@@ -92,12 +92,10 @@ def kernel_breakdown(sess, torch, ops, iters=3):
     act_b = lambda p: B * p.K * 2 + B * p.N * 2
     timed("qkv_norm_gemv", l0.qkv.nbytes + act_b(l0.qkv),
           lambda li, lw: ops.fused_norm_gemm(sess.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sc, out=sess.qkv))
-    timed("rope_kv_append", 0,
-          lambda li, lw: ops.rope_kv_append(sess.kv[li], sess.q, sess.qkv, sess.old_lens, sess.inv_freq, sess.n_loc, sess.g_loc, sess.H))
     kvb = {"none": sess.H * 2, "i8": sess.H + 8, "u4": sess.H // 2 + 8}[sess.kv_mode]
-    timed("span_attention", B * 2 * sess.g_loc * SEQ_LEN * kvb,
-          lambda li, lw: ops.span_attn_decode(sess.q, sess.kv[li], sess.new_lens, sess.n_loc, sess.g_loc, sess.H, sess.max_len,
-                                              sess.scale, sess.attn_ws, sess.attn_sync, out=sess.attn))
+    timed("rope_append_span_attention", B * 2 * sess.g_loc * SEQ_LEN * kvb,
+          lambda li, lw: ops.span_attn_decode_fused(sess.qkv, sess.kv[li], sess.old_lens, sess.rope_tab, sess.n_loc, sess.g_loc,
+                                                    sess.H, sess.max_len, sess.scale, sess.attn_ws, out=sess.attn))
     timed("o_gemv_addto", l0.o.nbytes + act_b(l0.o),
           lambda li, lw: ops.fused_gemm_addto(sess.attn, lw.o, sess.h, sc, out=sess.partial))
     timed("gate_up_swiglu", l0.gate.nbytes + l0.up.nbytes + B * l0.gate.K * 4 + B * l0.gate.N * 2,

@@ -47,6 +47,9 @@ _SIGS = {
     "dihip_span_attn_decode_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "dihip_span_attn_decode": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp]),
     "dihip_span_attn_sync_bytes": (sz, [i32, i32]),
+    "dihip_rope_table": (i32, [vp, vp, vp, i32, i32]),
+    "dihip_span_attn_fused_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "dihip_span_attn_decode_fused": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz]),
     "dihip_prefill_attn": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32]),
     "dihip_rmsnorm": (i32, [vp, vp, vp, vp, f32, i32, i32, i32]),
     "dihip_rope_qk": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32]),

@@ -31,9 +31,23 @@ int cached_num_cus() {
   return cus;
 }
 
+static unsigned long long* g_trace = nullptr;
+static size_t g_trace_bytes = 0;
+unsigned long long* debug_trace_buffer(size_t bytes) { return (g_trace && g_trace_bytes >= bytes) ? g_trace : nullptr; }
+void debug_set_trace(void* buf, size_t bytes) {
+  g_trace = reinterpret_cast<unsigned long long*>(buf);
+  g_trace_bytes = buf ? bytes : 0;
+}
+
 }  // namespace dihip
 
 extern "C" {
+
+int dihip_debug_set_trace(void* buf, size_t bytes) {
+  dihip::debug_set_trace(buf, bytes);
+  return DIHIP_SUCCESS;
+}
+
 
 const char* dihip_version(void) { return "dashinfer-hip 0.1.0 (gfx950)"; }
 

@@ -38,6 +38,9 @@ inline int launch_status(int code = DIHIP_RUNTIME_ERROR) {
 }
 
 int cached_num_cus();
+// diagnostics: the buffer set by dihip_debug_set_trace if it holds at least `bytes`, else null
+unsigned long long* debug_trace_buffer(size_t bytes);
+void debug_set_trace(void* buf, size_t bytes);
 
 // ---------------------------------------------------------------- device side --------------
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));

@@ -302,8 +302,6 @@ static hipError_t dispatch_gemv(const GemvPlan& p, int pro, int epi, const GemvA
   return hipErrorInvalidValue;
 }
 
-static unsigned long long* g_gemv_trace = nullptr;
-static size_t g_gemv_trace_bytes = 0;
 static int g_force_general = -1;  // DIHIP_GEMV_STREAM=0 routes everything to the general kernel
 static bool gemv_stream_enabled() {
   if (g_force_general < 0) {
@@ -358,7 +356,7 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
       g.WK = gp.WK;
       g.WN = gp.WN;
       g.RS = gp.RS;
-      g.trace = (g_gemv_trace && g_gemv_trace_bytes >= (size_t)gp.blocks * GEMV_WAVES * 64) ? g_gemv_trace : nullptr;
+      g.trace = debug_trace_buffer((size_t)gp.blocks * GEMV_WAVES * 64);
       hipError_t e = hipErrorInvalidValue;
       if (c.wbits == 4) e = dispatch_gemv<4, DIHIP_BF16>(gp, c.pro, c.epi, g, stream);
       else if (c.wbits == 8) e = dispatch_gemv<8, DIHIP_BF16>(gp, c.pro, c.epi, g, stream);
@@ -448,12 +446,6 @@ __global__ __launch_bounds__(256) void rmsnorm_f32_to_ft_kernel(uint16_t* __rest
 using namespace dihip;
 
 extern "C" {
-
-int dihip_debug_set_trace(void* buf, size_t bytes) {
-  g_gemv_trace = reinterpret_cast<unsigned long long*>(buf);
-  g_gemv_trace_bytes = buf ? bytes : 0;
-  return DIHIP_SUCCESS;
-}
 
 int dihip_debug_gemv_plan(int wbits, int M, int N, int K, int group_size, int dual, int* blocks, int* upb, int* wk, int* wn,
                           size_t* lds_bytes) {

@@ -18,105 +18,9 @@
 #include <type_traits>
 #include <vector>
 
-#include "device_utils.h"
+#include "span_attn_common.hpp"
 
 namespace dihip {
-
-constexpr int ATTN_THREADS = 256;
-constexpr int ATTN_TB = 2;              // tokens per lane slot per iteration
-constexpr int ATTN_TOK_PER_ITER = 32;  // 4 waves x 4 token slots x ATTN_TB tokens
-constexpr int ATTN_PSTRIDE = 132;      // floats per partial record: o[128], m, l, pad
-
-struct AttnArgs {
-  void* out;
-  const void* q;
-  const void* const* kspans;
-  const void* const* vspans;
-  const uint32_t* seq_lens;  // including the new token
-  float* partials;           // [B*n][nsplits][ATTN_PSTRIDE]
-  unsigned* counters;        // [B][g*nchunks]
-  int B, n, g, hpg, S, span_stride, nsplits, nchunks;
-  float scale;
-};
-
-// sum over the 16 lanes of a DPP row (all 16 lanes receive the total)
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));  // row_ror:4
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, true));  // row_ror:2
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, true));  // row_ror:1
-  return v;
-}
-
-// 8 consecutive head dims (d = dc*8 ..) of one token-head, dequantised to f32
-template <int FT, int MODE>
-struct KvChunk {
-  u32x4_t raw0, raw1;  // raw1 only for f32
-  float zero, scale;
-};
-
-template <int FT, int MODE>
-__device__ __forceinline__ void kv_issue(KvChunk<FT, MODE>& c, const void* span, int grp, int pos, int g, int S, int dc) {
-  constexpr int H = 128;
-  if constexpr (MODE == DIHIP_KV_NONE) {
-    if constexpr (FT == DIHIP_F32) {
-      const u32x4_t* p = reinterpret_cast<const u32x4_t*>(reinterpret_cast<const float*>(span) + ((size_t)grp * S + pos) * H + dc * 8);
-      c.raw0 = p[0];
-      c.raw1 = p[1];
-    } else {
-      c.raw0 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(span) + ((size_t)grp * S + pos) * H + dc * 8);
-    }
-  } else {
-    constexpr int HB = MODE == DIHIP_KV_I8 ? H : H / 2;
-    const unsigned char* base = reinterpret_cast<const unsigned char*>(span);
-    const unsigned char* d = base + ((size_t)grp * S + pos) * HB;
-    if constexpr (MODE == DIHIP_KV_I8) {
-      const u32x2_t v = *reinterpret_cast<const u32x2_t*>(d + dc * 8);
-      c.raw0 = u32x4_t{v[0], v[1], 0, 0};
-    } else {
-      c.raw0 = u32x4_t{*reinterpret_cast<const uint32_t*>(d + dc * 4), 0, 0, 0};
-    }
-    const float* params = reinterpret_cast<const float*>(base + (size_t)g * S * HB) + ((size_t)grp * S + pos) * 2;
-    const u32x2_t pz = *reinterpret_cast<const u32x2_t*>(params);
-    c.zero = __uint_as_float(pz[0]);
-    c.scale = __uint_as_float(pz[1]);
-  }
-}
-
-template <int FT, int MODE>
-__device__ __forceinline__ void kv_decode(const KvChunk<FT, MODE>& c, float (&x)[8]) {
-  if constexpr (MODE == DIHIP_KV_NONE) {
-    if constexpr (FT == DIHIP_F32) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        x[j] = __uint_as_float(c.raw0[j]);
-        x[4 + j] = __uint_as_float(c.raw1[j]);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        x[2 * j] = ft_bits_to_f32<FT == DIHIP_F32 ? DIHIP_BF16 : FT>(c.raw0[j] & 0xFFFFu);
-        x[2 * j + 1] = ft_bits_to_f32<FT == DIHIP_F32 ? DIHIP_BF16 : FT>(c.raw0[j] >> 16);
-      }
-    }
-  } else if constexpr (MODE == DIHIP_KV_I8) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int q = (int)(signed char)((c.raw0[j >> 2] >> (8 * (j & 3))) & 0xFFu);
-      x[j] = ((float)q - c.zero) * c.scale;
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const unsigned q = (c.raw0[0] >> (4 * j)) & 0xFu;  // lo nibble = even d (impl_u4.cuh:27-36)
-      x[j] = ((float)q - c.zero) * c.scale;
-    }
-  }
-}
-
-__device__ __forceinline__ float safe_exp_diff(float a, float b) {  // exp(a - b), 0 when a == -inf
-  return a == -INFINITY ? 0.f : __expf(a - b);
-}
 
 template <int FT, int MODE, int HC>
 __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const AttnArgs a) {

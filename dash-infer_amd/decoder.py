@@ -244,8 +244,15 @@ class DecodeSession:
         need = max(ops.lowp_workspace_bytes(wb, batch, p.N, p.K, gsz) for p in (l0.qkv, l0.o, l0.gate, l0.down))
         need = max(need, int(lib().dihip_dense_workspace_bytes(batch, model.lm_head.N, model.lm_head.K)))
         self.scratch = ops.Scratch(need, device)
-        self.attn_ws = torch.empty(max(ops.span_attn_workspace(batch, self.n_loc, H, max_len), 256), dtype=torch.uint8, device=device)
+        self.attn_ws = torch.empty(max(ops.span_attn_workspace(batch, self.n_loc, H, max_len),
+                                       ops.span_attn_fused_workspace(batch, self.n_loc, self.g_loc, H, max_len), 256),
+                                   dtype=torch.uint8, device=device)
         self.attn_sync = torch.zeros(int(lib().dihip_span_attn_sync_bytes(batch, self.n_loc)), dtype=torch.uint8, device=device)
+        self.rope_tab = ops.rope_table(self.inv_freq, max_len + 1, H)
+        # Rotary + cache append + attention in one launch pair: the latency-bound regime (few requests:
+        # one wave per query head, no cross-wave reductions).  Large batches stream thousands of tokens
+        # per workgroup and use the row-sharing op-boundary kernels instead.
+        self.fused_attention = batch * self.g_loc <= 64
         self.argmax_ws = torch.empty(batch * 64 * 8, dtype=torch.uint8, device=device)
         nr = model.nranks
         self.pair = torch.empty(batch * 8, dtype=torch.uint8, device=device)
@@ -285,9 +292,13 @@ class DecodeSession:
         tp_on = self.comm is not None and m.nranks > 1
         for li, lw in enumerate(m.layers):
             ops.fused_norm_gemm(self.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sc, out=self.qkv)
-            ops.rope_kv_append(self.kv[li], self.q, self.qkv, self.old_lens, self.inv_freq, self.n_loc, self.g_loc, self.H)
-            ops.span_attn_decode(self.q, self.kv[li], self.new_lens, self.n_loc, self.g_loc, self.H, self.max_len,
-                                 self.scale, self.attn_ws, self.attn_sync, out=self.attn)
+            if self.fused_attention:
+                ops.span_attn_decode_fused(self.qkv, self.kv[li], self.old_lens, self.rope_tab, self.n_loc, self.g_loc, self.H,
+                                           self.max_len, self.scale, self.attn_ws, out=self.attn)
+            else:
+                ops.rope_kv_append(self.kv[li], self.q, self.qkv, self.old_lens, self.inv_freq, self.n_loc, self.g_loc, self.H)
+                ops.span_attn_decode(self.q, self.kv[li], self.new_lens, self.n_loc, self.g_loc, self.H, self.max_len,
+                                     self.scale, self.attn_ws, self.attn_sync, out=self.attn)
             self._proj_residual(self.attn, lw.o, tp_on)
             ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act)
             self._proj_residual(self.act, lw.down, tp_on)

@@ -245,6 +245,27 @@ def span_attn_decode(q, kv, seq_lens_dev, n, g, H, max_len, scale, ws, sync, out
     return out
 
 
+def rope_table(inv_freq, max_pos, H):
+    tab = torch.empty(max_pos, H // 2, 2, dtype=torch.float32, device=inv_freq.device)
+    check(lib().dihip_rope_table(cur_stream(), ptr(tab), ptr(inv_freq), max_pos, H), "dihip_rope_table")
+    return tab
+
+
+def span_attn_fused_workspace(batch, n, g, H, max_len):
+    return int(lib().dihip_span_attn_fused_workspace_bytes(batch, n, g, H, max_len))
+
+
+def span_attn_decode_fused(qkv, kv, old_lens_dev, rope_tab, n, g, H, max_len, scale, ws, out=None):
+    """Rotary + cache append + paged decode attention of one step from the fused qkv rows."""
+    B = qkv.shape[0]
+    out = out if out is not None else torch.empty(B, n * H, dtype=qkv.dtype, device=qkv.device)
+    pool = kv.pool
+    check(lib().dihip_span_attn_decode_fused(cur_stream(), ptr(out), ptr(qkv), ptr(kv.k_ptrs), ptr(kv.v_ptrs), ptr(old_lens_dev),
+                                             ptr(rope_tab), B, n, g, H, pool.S, kv.max_spans, max_len, capi.KV[pool.mode],
+                                             dt_code(qkv), float(scale), ptr(ws), ws.numel()), "dihip_span_attn_decode_fused")
+    return out
+
+
 # ------------------------------------------------------------------------------ glue --------
 def rmsnorm(x, gamma, eps):
     y = torch.empty_like(x)

@@ -195,6 +195,24 @@ int dihip_span_attn_decode(void* stream, void* output, const void* query,
                            void* sync);
 size_t dihip_span_attn_sync_bytes(int batch, int n_heads);
 
+/* 3b. Decode-step form with Rotary and DecoderCacheAppend folded in: replaces the
+ * Rotary op (csrc/core/kernel/cpu/rotary.cpp:22-106 semantics, rotate-half, position = old_seq_lens[b])
+ * + SpanAttnOp::runDecoder (span_attn_op.cpp:90-169) for one decode step.  Results are identical to
+ * dihip_rope_qk + dihip_kv_append + dihip_span_attn_decode: q and k are rotated and rounded to FT, this
+ * step's K/V head vectors are written into the spans at token position old_seq_lens[b] (quantised per
+ * kv_mode), attention runs over old_seq_lens[b] + 1 tokens.
+ *   qkv        : FT [batch, (n + 2g) * H], pre-Rotary fused rows (16-byte aligned)
+ *   rope_table : f32 [max_pos][H/2]{cos, sin} built once by dihip_rope_table
+ *   ws         : >= dihip_span_attn_fused_workspace_bytes(...) (contents need no initialisation)  */
+int dihip_rope_table(void* stream, float* table, const float* inv_freq, int max_pos, int head_size);
+size_t dihip_span_attn_fused_workspace_bytes(int batch, int n_heads, int n_groups, int head_size,
+                                             int max_seq_len);
+int dihip_span_attn_decode_fused(void* stream, void* output, const void* qkv, void* const* k_span_array,
+                                 void* const* v_span_array, const uint32_t* old_seq_lens_dev,
+                                 const float* rope_table, int batch, int n_heads, int n_groups,
+                                 int head_size, int span_len, int n_spans_per_request, int max_seq_len,
+                                 int kv_mode, int dtype, float qk_scale, void* ws, size_t ws_bytes);
+
 /* =============================================================================================
  * 4. Prefill attention (replaces xformer_prefill_attention,
  *    csrc/core/kernel/cuda/xformer_mha/xformer_mha.h:26-41): causal softmax(alpha Q K^T) V, GQA.

@@ -261,3 +261,51 @@ def test_span_attention_baseline_shapes(ops, mode, B):
         vs = [pool.span_view(i).cpu().numpy() for i in kv.v_idx[b]]
         ref = cbind.span_attn_decode(q[b], ks, vs, L, n, g, H, S, mode, ft, scale)
         np.testing.assert_allclose(out[b], ref, rtol=1e-2, atol=2.5e-3)
+
+
+# ------------------------------------------------- fused Rotary + append + attention (3b) -----
+@pytest.mark.parametrize("mode", ["none", "i8", "u4"])
+@pytest.mark.parametrize("n,g,S,lens", [(28, 4, 128, [2048]), (14, 2, 32, [0, 1, 31, 32, 500]), (8, 8, 16, [77, 300]),
+                                        (32, 2, 64, [1000])])
+def test_fused_rope_append_attention_matches_separate_ops(ops, n, g, S, lens, mode):
+    """dihip_span_attn_decode_fused == dihip_rope_kv_append + dihip_span_attn_decode: the spans
+    must be BYTE-identical afterwards, the attention output equal to f32-accumulation accuracy;
+    and both agree with the oracle (rope -> codec -> attention)."""
+    from oracle import glue
+    rng = np.random.default_rng(n + S + len(mode))
+    H, ft = 128, "bf16"
+    B = len(lens)
+    pool, kv, ok, ov = build_batch(ops, rng, lens, n, g, H, S, mode, ft, extra_tokens=1)
+    pool2, kv2, _, _ = build_batch(ops, np.random.default_rng(n + S + len(mode)), lens, n, g, H, S, mode, ft, extra_tokens=1)
+    qkv = bf16_round(rng.normal(0, 1, (B, (n + 2 * g) * H)).astype(np.float32))
+    inv = glue.rope_inv_freq(H, 1000000.0)
+    inv_d = torch.from_numpy(inv).cuda()
+    old = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    scale = 1.0 / np.sqrt(H)
+    max_len = max(lens) + 1
+    # separate ops
+    q_out = torch.empty(B, n * H, dtype=torch.bfloat16, device="cuda")
+    ops.rope_kv_append(kv, q_out, dev(qkv, ft), old, inv_d, n, g, H)
+    ws = torch.empty(max(ops.span_attn_workspace(B, n, H, max_len), 256), dtype=torch.uint8, device="cuda")
+    sync = torch.zeros(int(ops.lib().dihip_span_attn_sync_bytes(B, n)), dtype=torch.uint8, device="cuda")
+    ref_out = ops.span_attn_decode(q_out, kv, old + 1, n, g, H, max_len, scale, ws, sync)
+    # fused
+    tab = ops.rope_table(inv_d, max_len + 3, H)
+    ws2 = torch.empty(ops.span_attn_fused_workspace(B, n, g, H, max_len), dtype=torch.uint8, device="cuda")
+    ws2.fill_(0x7F)
+    out = ops.span_attn_decode_fused(dev(qkv, ft), kv2, old, tab, n, g, H, max_len, scale, ws2)
+    torch.cuda.synchronize()
+    for b in range(B):
+        for i in range(len(kv.k_idx[b])):
+            assert torch.equal(pool.span_view(kv.k_idx[b][i]), pool2.span_view(kv2.k_idx[b][i])), f"K span {b}/{i}"
+            assert torch.equal(pool.span_view(kv.v_idx[b][i]), pool2.span_view(kv2.v_idx[b][i])), f"V span {b}/{i}"
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref_out.float().cpu().numpy(), rtol=1e-2, atol=2.5e-3)
+    # oracle: rotate q/k at position len, round to bf16, append through the codec, attend
+    heads = qkv[:, : (n + g) * H].reshape(B, n + g, H)
+    rot = bf16_round(glue.rope(heads, np.array(lens, np.int32), inv))
+    ref = []
+    for b, L in enumerate(lens):
+        ok[b].write(L, rot[b, n:])
+        ov[b].write(L, qkv[b, (n + g) * H:].reshape(g, H))
+        ref.append(attention.decode_attention(rot[b, :n], ok[b].read_all(L + 1), ov[b].read_all(L + 1), scale))
+    np.testing.assert_allclose(out.float().cpu().numpy().reshape(B, n, H), np.stack(ref), rtol=1e-2, atol=2.5e-3)
