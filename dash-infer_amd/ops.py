@@ -245,6 +245,17 @@ def span_attn_decode(q, kv, seq_lens_dev, n, g, H, max_len, scale, ws, sync, out
     return out
 
 
+def prefill_attn(q, k, v, n, g, H, alpha, causal=True, out=None):
+    """Causal GQA prefill attention.  q: FT [Lq, >= n*H] (row stride = q.stride(0)), k / v: FT
+    [Lk, >= g*H] views of contiguous (MIX) or fused-qkv (INTERLEAVED) rows -> FT [Lq, n*H]."""
+    Lq, Lk = q.shape[0], k.shape[0]
+    out = out if out is not None else torch.empty(Lq, n * H, dtype=q.dtype, device=q.device)
+    assert k.stride(0) == v.stride(0)
+    check(lib().dihip_prefill_attn(cur_stream(), ptr(out), ptr(q), ptr(k), ptr(v), Lq, Lk, q.stride(0), k.stride(0), n, g, H,
+                                   1 if causal else 0, float(alpha), dt_code(q)), "dihip_prefill_attn")
+    return out
+
+
 def rope_table(inv_freq, max_pos, H):
     tab = torch.empty(max_pos, H // 2, 2, dtype=torch.float32, device=inv_freq.device)
     check(lib().dihip_rope_table(cur_stream(), ptr(tab), ptr(inv_freq), max_pos, H), "dihip_rope_table")
