@@ -1,0 +1,44 @@
+// allreduce_op_hip.cpp -- op type "AllReduce" on DeviceType::HIP (AllReduceOp,
+// csrc/core/operator/nccl/allreduce/allreduce_op.cpp:23-95): in -> out sum all-reduce over the RCCL
+// communicator of the context.  Unlike the reference (which calls ctx->Synchronize() after the
+// collective, allreduce_op.cpp:90) the op only enqueues: ordering is the stream's.
+#include "dashinfer_hip.h"
+#include "operator.h"
+
+namespace allspark {
+
+class AllReduceOpHIP : public AsOperator {
+ public:
+  explicit AllReduceOpHIP(const std::string& op_type = "") : AsOperator(op_type) {}
+  AsStatus Init(const OperatorProto& op_proto, const DeviceContext& ctx, const TensorMap& weights_map,
+                TensorMap* tensor_map) override {
+    AS_CHECK_STATUS(AsOperator::Init(op_proto, ctx, weights_map, tensor_map));
+    tensor_map_->at(out_names_[0])->SetDataType(tensor_map_->at(in_names_[0])->GetDataType());
+    return AsStatus::ALLSPARK_SUCCESS;
+  }
+  AsStatus Reshape(RuntimeContext*) override {
+    AsTensor* x = tensor_map_->at(in_names_[0]).get();
+    count_ = x->Count();
+    return tensor_map_->at(out_names_[0])->SetShape(Shape(x->GetShape()));
+  }
+  AsStatus Forward(RuntimeContext*) override {
+    const HIPContext* h = static_cast<const HIPContext*>(ctx_);
+    AsTensor* x = tensor_map_->at(in_names_[0]).get();
+    AsTensor* y = tensor_map_->at(out_names_[0]).get();
+    if (h->GetNranks() == 1) {  // single rank: copy (allreduce_op.cpp:70-80 behaviour)
+      if (x->GetDataPtr() != y->GetDataPtr() &&
+          hipMemcpyAsync(y->GetDataPtr(), x->GetDataPtr(), x->GetSizeInByte(), hipMemcpyDeviceToDevice, h->GetStream()) != hipSuccess)
+        return AsStatus::ALLSPARK_RUNTIME_ERROR;
+      return AsStatus::ALLSPARK_SUCCESS;
+    }
+    if (!h->GetRCCLComm()) return AsStatus::ALLSPARK_PARAM_ERROR;
+    return FromDihip(dihip_allreduce_sum(h->GetRCCLComm(), h->GetStream(), x->GetDataPtr(), y->GetDataPtr(), (size_t)count_,
+                                         DihipDtype(x->GetDataType())));
+  }
+
+ private:
+  int64_t count_ = 0;
+};
+REGISTER_OP(AllReduce, HIP, AllReduceOpHIP)
+
+}  // namespace allspark

@@ -1,0 +1,188 @@
+// as_types.h -- the slice of the allspark core types the hot-path operators touch, restated so that
+// the HIP operator layer compiles stand-alone (the reference's operator.h pulls in <dnnl.hpp>,
+// protobuf and glog, none of which exist in this image -- SURVEY F4).  Names, member functions
+// and semantics follow the reference so that the operator sources below move into
+// csrc/core/operator/ unchanged once DeviceType::HIP exists there:
+//   AsStatus        csrc/interface/allspark_check.h:62-80
+//   DataType/Device csrc/interface/allspark.h, csrc/proto/allspark.proto
+//   AsTensor        csrc/core/tensor/tensor.h:54-160   (name, dtype, shape, data pointer, Free/SetShape)
+//   TensorMap       name -> shared_ptr<AsTensor>
+//   DeviceContext   csrc/device/device_context.h:17-209 (model dims, cache mode, span size, rank info)
+//   RuntimeContext / GenerateContext  csrc/core/model/generate_context.h:32-70,95+
+//   OperatorProto   csrc/proto/allspark.proto (op_type, op_name, inputs, outputs, weights, attr map of
+//                   raw little-endian bytes)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace allspark {
+
+enum class AsStatus : int {
+  ALLSPARK_SUCCESS = 0,
+  ALLSPARK_UNKNOWN_ERROR = 1,
+  ALLSPARK_PARAM_ERROR = 2,
+  ALLSPARK_IO_ERROR = 3,
+  ALLSPARK_MEMORY_ERROR = 4,
+  ALLSPARK_RUNTIME_ERROR = 5,
+  ALLSPARK_EXCEED_LIMIT_ERROR = 7,
+  ALLSPARK_INVALID_CALL_ERROR = 8,
+};
+#define AS_CHECK_STATUS(expr)                                     \
+  do {                                                            \
+    ::allspark::AsStatus s_ = (expr);                             \
+    if (s_ != ::allspark::AsStatus::ALLSPARK_SUCCESS) return s_;  \
+  } while (0)
+
+enum DataType { DATATYPE_UNDEFINED = 0, FLOAT32 = 1, FLOAT16 = 2, INT8 = 3, INT16 = 4, INT32 = 5, INT64 = 6,
+                STRING = 7, BOOL = 8, BFLOAT16 = 9, UINT8 = 10, POINTER = 20 };
+enum DeviceType { DEVICETYPE_UNDEFINED = 0, CPU = 1, CUDA = 2, COMPILE_TIME_MAX_DEVICE = 3, HIP = 4 };
+enum UnaryType { UNARYTYPE_UNDEFINED = 0, TANH = 1, GELU_ERF = 2, GELU_TANH = 3, RELU = 4, SILU = 5, SIGMOID = 6 };
+enum class AsCacheMode { AsCacheDefault = 0, AsCacheQuantI8 = 1, AsCacheQuantU4 = 2 };
+
+inline size_t SizeofType(DataType t) {
+  switch (t) {
+    case FLOAT32: case INT32: return 4;
+    case FLOAT16: case BFLOAT16: case INT16: return 2;
+    case INT64: case POINTER: return 8;
+    default: return 1;
+  }
+}
+
+using Shape = std::vector<int64_t>;
+
+// Device tensor: owns its storage unless constructed as a view.
+class AsTensor {
+ public:
+  AsTensor(const std::string& name, DeviceType dev, DataType dtype, const Shape& shape = {})
+      : name_(name), dev_(dev), dtype_(dtype) {
+    SetShape(Shape(shape));
+  }
+  AsTensor(const std::string& name, DeviceType dev, DataType dtype, const Shape& shape, void* view)
+      : name_(name), dev_(dev), dtype_(dtype), shape_(shape), data_(view), owner_(false) {}
+  ~AsTensor() { Free(); }
+  AsTensor(const AsTensor&) = delete;
+  AsTensor& operator=(const AsTensor&) = delete;
+
+  const std::string& GetName() const { return name_; }
+  DataType GetDataType() const { return dtype_; }
+  void SetDataType(DataType t) { dtype_ = t; }
+  DeviceType GetDeviceType() const { return dev_; }
+  const Shape& GetShape() const { return shape_; }
+  int64_t Count() const {
+    int64_t c = 1;
+    for (auto d : shape_) c *= d;
+    return shape_.empty() ? 0 : c;
+  }
+  size_t GetSizeInByte() const { return (size_t)Count() * SizeofType(dtype_); }
+  void* GetDataPtr() const { return data_; }
+  // grows only (like the reference's block allocator behind SetShape)
+  AsStatus SetShape(Shape&& shape) {
+    shape_ = std::move(shape);
+    const size_t need = GetSizeInByte();
+    if (!owner_) return need <= capacity_ || capacity_ == 0 ? AsStatus::ALLSPARK_SUCCESS : AsStatus::ALLSPARK_MEMORY_ERROR;
+    if (need > capacity_) {
+      Free();
+      if (dev_ == CPU) {
+        data_ = malloc(need);
+      } else if (hipMalloc(&data_, need) != hipSuccess) {
+        (void)hipGetLastError();
+        data_ = nullptr;
+        return AsStatus::ALLSPARK_MEMORY_ERROR;
+      }
+      capacity_ = need;
+    }
+    return AsStatus::ALLSPARK_SUCCESS;
+  }
+  void Free() {
+    if (owner_ && data_) {
+      if (dev_ == CPU) free(data_);
+      else (void)hipFree(data_);
+    }
+    data_ = nullptr;
+    capacity_ = 0;
+  }
+
+ private:
+  std::string name_;
+  DeviceType dev_;
+  DataType dtype_;
+  Shape shape_;
+  void* data_ = nullptr;
+  size_t capacity_ = 0;
+  bool owner_ = true;
+};
+using TensorMap = std::map<std::string, std::shared_ptr<AsTensor>>;
+
+struct OperatorProto {
+  std::string op_type, op_name;
+  std::vector<std::string> inputs, outputs, weights;
+  std::map<std::string, std::string> attr;  // raw bytes, read as *(T*)attr.at(k).c_str() like the reference
+};
+
+// csrc/device/device_context.h + the HIP specifics (stream, RCCL communicator)
+class DeviceContext {
+ public:
+  virtual ~DeviceContext() = default;
+  virtual DeviceType GetDeviceType() const = 0;
+  int GetNumberHeads() const { return num_heads_; }
+  int GetNumberGroups() const { return num_groups_; }
+  int GetSizePerHead() const { return size_per_head_; }
+  int GetCacheSpanSize() const { return span_size_; }
+  AsCacheMode GetCacheMode() const { return cache_mode_; }
+  int GetModelMaxBatch() const { return max_batch_; }
+  int GetModelMaxLength() const { return max_length_; }
+  int GetRank() const { return rank_; }
+  int GetNranks() const { return nranks_; }
+  void SetNumberHeads(int v) { num_heads_ = v; }
+  void SetNumberGroups(int v) { num_groups_ = v; }
+  void SetSizePerHead(int v) { size_per_head_ = v; }
+  void SetCacheSpanSize(int v) { span_size_ = v; }
+  void SetCacheMode(AsCacheMode m) { cache_mode_ = m; }
+  void SetModelMaxBatch(int v) { max_batch_ = v; }
+  void SetModelMaxLength(int v) { max_length_ = v; }
+  void SetRankInfo(int rank, int nranks) { rank_ = rank; nranks_ = nranks; }
+
+ protected:
+  int num_heads_ = 0, num_groups_ = 0, size_per_head_ = 0, span_size_ = 0, max_batch_ = 1, max_length_ = 0;
+  int rank_ = 0, nranks_ = 1;
+  AsCacheMode cache_mode_ = AsCacheMode::AsCacheDefault;
+};
+
+class HIPContext : public DeviceContext {
+ public:
+  DeviceType GetDeviceType() const override { return DeviceType::HIP; }
+  hipStream_t GetStream() const { return stream_; }
+  void SetStream(hipStream_t s) { stream_ = s; }
+  void* GetRCCLComm() const { return comm_; }
+  void SetRCCLComm(void* c) { comm_ = c; }
+
+ private:
+  hipStream_t stream_ = nullptr;
+  void* comm_ = nullptr;
+};
+
+// per-request generation state (generate_context.h:32-70): step = tokens already in the cache
+struct GenerateContext {
+  int step = 0;
+  int prefix_len = 0;
+  // VirtualCache::GetCache(layer, inc) of the reference returns the request's span pointer vector
+  // for a layer; here the vectors are handed over directly: [layer][span]
+  std::vector<std::vector<void*>> k_spans, v_spans;
+};
+
+struct RuntimeContext {
+  bool is_context = false;
+  int current_batch = 0;  // prefill: index of the request being prefilled
+  std::vector<std::shared_ptr<GenerateContext>> gen_ctx_list;
+  int GetGenCtxListSize() const { return (int)gen_ctx_list.size(); }
+  GenerateContext* GetGenCtx(int i) const { return gen_ctx_list.at(i).get(); }
+  GenerateContext* GetContextGenCtx() const { return gen_ctx_list.at(current_batch).get(); }
+};
+
+}  // namespace allspark

@@ -1,0 +1,170 @@
+// host_capi.cpp -- C test harness of the operator layer (include/dashinfer_hip_host.h).
+#include "dashinfer_hip_host.h"
+
+#include <sstream>
+
+#include "operator.h"
+
+using namespace allspark;
+
+struct dihost_model {
+  HIPContext ctx;
+  TensorMap tensors, weights, weights_buffer;
+  RuntimeContext rt;
+  std::vector<std::unique_ptr<AsOperator>> ops;
+};
+static thread_local std::string g_err;
+
+static std::vector<std::string> split(const char* s, char sep) {
+  std::vector<std::string> out;
+  if (!s) return out;
+  std::stringstream ss(s);
+  std::string item;
+  while (std::getline(ss, item, sep))
+    if (!item.empty()) out.push_back(item);
+  return out;
+}
+
+extern "C" {
+
+const char* dihost_last_error(void) { return g_err.c_str(); }
+
+const char* dihost_registered_ops(void) {
+  static std::string s;
+  s.clear();
+  for (const char* t : {"GemmA16W8", "GemmA16W4", "DecOptMHA", "DecOptMQA", "AllReduce", "Gemm", "Rotary"}) {
+    try {
+      (void)OpFactory::getInstance().GetOperator({t, DeviceType::HIP});
+      s += (s.empty() ? "" : ",");
+      s += t;
+    } catch (const AsException&) {
+    }
+  }
+  return s.c_str();
+}
+
+int dihost_model_create(dihost_model_t* m, void* stream, int num_heads, int num_groups, int size_per_head, int span_size,
+                        int cache_mode, int max_batch, int max_length, int rank, int nranks, void* rccl_comm) {
+  if (!m) return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  auto* p = new dihost_model();
+  p->ctx.SetStream(reinterpret_cast<hipStream_t>(stream));
+  p->ctx.SetNumberHeads(num_heads);
+  p->ctx.SetNumberGroups(num_groups);
+  p->ctx.SetSizePerHead(size_per_head);
+  p->ctx.SetCacheSpanSize(span_size);
+  p->ctx.SetCacheMode(static_cast<AsCacheMode>(cache_mode));
+  p->ctx.SetModelMaxBatch(max_batch);
+  p->ctx.SetModelMaxLength(max_length);
+  p->ctx.SetRankInfo(rank, nranks);
+  p->ctx.SetRCCLComm(rccl_comm);
+  p->tensors.emplace("workspace", std::make_shared<AsTensor>("workspace", DeviceType::HIP, INT8, Shape{256}));
+  *m = p;
+  return 0;
+}
+int dihost_model_destroy(dihost_model_t m) {
+  delete m;
+  return 0;
+}
+static int put(TensorMap& map, const char* name, int dtype, int ndim, const int64_t* shape, void* data) {
+  if (!name || ndim < 0 || ndim > 8) return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  Shape s(shape, shape + ndim);
+  map[name] = std::make_shared<AsTensor>(name, DeviceType::HIP, static_cast<DataType>(dtype), s, data);
+  return 0;
+}
+int dihost_set_tensor(dihost_model_t m, const char* name, int dtype, int ndim, const int64_t* shape, void* data) {
+  return put(m->tensors, name, dtype, ndim, shape, data);
+}
+int dihost_set_weight(dihost_model_t m, const char* name, int dtype, int ndim, const int64_t* shape, void* data) {
+  return put(m->weights, name, dtype, ndim, shape, data);
+}
+int dihost_get_tensor(dihost_model_t m, const char* name, int* dtype, int* ndim, int64_t* shape8, void** data) {
+  auto it = m->tensors.find(name);
+  if (it == m->tensors.end()) return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  const AsTensor& t = *it->second;
+  if (dtype) *dtype = t.GetDataType();
+  if (ndim) *ndim = (int)t.GetShape().size();
+  if (shape8)
+    for (size_t i = 0; i < t.GetShape().size() && i < 8; ++i) shape8[i] = t.GetShape()[i];
+  if (data) *data = t.GetDataPtr();
+  return 0;
+}
+
+int dihost_op_create(dihost_model_t m, int* op_id, const char* op_type, const char* op_name, const char* inputs,
+                     const char* outputs, const char* weights, const char* attrs) {
+  OperatorProto proto;
+  proto.op_type = op_type ? op_type : "";
+  proto.op_name = op_name ? op_name : "";
+  proto.inputs = split(inputs, ',');
+  proto.outputs = split(outputs, ',');
+  proto.weights = split(weights, ',');
+  for (const std::string& kv : split(attrs, ';')) {
+    const size_t eq = kv.find('=');
+    if (eq == std::string::npos || eq + 2 >= kv.size() || kv[eq + 2] != ':') {
+      g_err = "bad attribute: " + kv;
+      return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+    }
+    const std::string key = kv.substr(0, eq), val = kv.substr(eq + 3);
+    std::string bytes;
+    if (kv[eq + 1] == 'i') {
+      const int v = std::stoi(val);
+      bytes.assign(reinterpret_cast<const char*>(&v), sizeof(v));
+    } else if (kv[eq + 1] == 'f') {
+      const float v = std::stof(val);
+      bytes.assign(reinterpret_cast<const char*>(&v), sizeof(v));
+    } else {
+      const bool v = val != "0";
+      bytes.assign(reinterpret_cast<const char*>(&v), sizeof(v));
+    }
+    proto.attr[key] = bytes;
+  }
+  std::unique_ptr<AsOperator> op;
+  try {
+    op = OpFactory::getInstance().GetOperator({proto.op_type, DeviceType::HIP})();
+  } catch (const AsException& e) {
+    g_err = e.what();
+    return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  }
+  const AsStatus st = op->CallInit(proto, m->ctx, m->weights, m->weights_buffer, &m->tensors, &m->rt);
+  if (st != AsStatus::ALLSPARK_SUCCESS) {
+    g_err = "CallInit failed";
+    return (int)st;
+  }
+  m->ops.push_back(std::move(op));
+  if (op_id) *op_id = (int)m->ops.size() - 1;
+  return 0;
+}
+
+int dihost_set_runtime(dihost_model_t m, int is_context, int n_requests, const int* steps, int n_layers, int spans_per_req,
+                       void* const* k_spans, void* const* v_spans) {
+  m->rt.is_context = is_context != 0;
+  m->rt.current_batch = 0;
+  m->rt.gen_ctx_list.clear();
+  for (int r = 0; r < n_requests; ++r) {
+    auto gc = std::make_shared<GenerateContext>();
+    gc->step = steps ? steps[r] : 0;
+    gc->k_spans.resize(n_layers);
+    gc->v_spans.resize(n_layers);
+    for (int l = 0; l < n_layers; ++l)
+      for (int i = 0; i < spans_per_req; ++i) {
+        gc->k_spans[l].push_back(k_spans[((size_t)r * n_layers + l) * spans_per_req + i]);
+        gc->v_spans[l].push_back(v_spans[((size_t)r * n_layers + l) * spans_per_req + i]);
+      }
+    m->rt.gen_ctx_list.push_back(gc);
+  }
+  return 0;
+}
+static AsOperator* get_op(dihost_model_t m, int id) { return id >= 0 && id < (int)m->ops.size() ? m->ops[id].get() : nullptr; }
+int dihost_op_reshape(dihost_model_t m, int id) {
+  AsOperator* op = get_op(m, id);
+  return op ? (int)op->CallReshape(&m->rt) : (int)AsStatus::ALLSPARK_PARAM_ERROR;
+}
+int dihost_op_alloc(dihost_model_t m, int id) {
+  AsOperator* op = get_op(m, id);
+  return op ? (int)op->CallAlloc(&m->rt) : (int)AsStatus::ALLSPARK_PARAM_ERROR;
+}
+int dihost_op_forward(dihost_model_t m, int id) {
+  AsOperator* op = get_op(m, id);
+  return op ? (int)op->CallForward(&m->rt) : (int)AsStatus::ALLSPARK_PARAM_ERROR;
+}
+
+}  // extern "C"

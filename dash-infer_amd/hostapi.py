@@ -1,0 +1,113 @@
+"""ctypes binding of include/dashinfer_hip_host.h: the C test harness around the C++ operator
+layer (libdashinfer_hip_ops.so).  Plumbing for tests; fails loudly when the library is missing."""
+import ctypes as C
+import os
+import re
+
+from . import REPO_ROOT
+from .capi import lib as _devlib
+
+OPS_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdashinfer_hip_ops.so")
+DT = {"f32": 1, "f16": 2, "i8": 3, "i32": 5, "bf16": 9, "u8": 10}
+vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+_SIGS = {
+    "dihost_model_create": (i32, [C.POINTER(vp), vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "dihost_model_destroy": (i32, [vp]),
+    "dihost_set_tensor": (i32, [vp, C.c_char_p, i32, i32, C.POINTER(C.c_int64), vp]),
+    "dihost_set_weight": (i32, [vp, C.c_char_p, i32, i32, C.POINTER(C.c_int64), vp]),
+    "dihost_get_tensor": (i32, [vp, C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_int64), C.POINTER(vp)]),
+    "dihost_op_create": (i32, [vp, C.POINTER(i32), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+    "dihost_set_runtime": (i32, [vp, i32, i32, C.POINTER(i32), i32, i32, C.POINTER(vp), C.POINTER(vp)]),
+    "dihost_op_reshape": (i32, [vp, i32]),
+    "dihost_op_alloc": (i32, [vp, i32]),
+    "dihost_op_forward": (i32, [vp, i32]),
+    "dihost_last_error": (C.c_char_p, []),
+    "dihost_registered_ops": (C.c_char_p, []),
+}
+_lib = None
+
+
+def header_symbols():
+    text = open(os.path.join(REPO_ROOT, "include", "dashinfer_hip_host.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dihost_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(OPS_LIB_PATH):
+            raise RuntimeError(f"{OPS_LIB_PATH} is missing: build it with `make -C dash-infer_amd/host` (or __graft_entry__.build())")
+        _devlib()  # libdashinfer_hip.so (and torch's HIP runtime) first
+        l = C.CDLL(OPS_LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+class HostError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__(f"{what}: AsStatus {code}: {lib().dihost_last_error().decode()}")
+        self.code = code
+
+
+def _ck(code, what):
+    if code != 0:
+        raise HostError(code, what)
+
+
+class Model:
+    """HIPContext + TensorMap + RuntimeContext, driven the way AsModel drives its operators."""
+
+    def __init__(self, stream, n_heads, n_groups, head_size, span, cache_mode=0, max_batch=1, max_len=0, rank=0, nranks=1, comm=None):
+        self.h = vp()
+        _ck(lib().dihost_model_create(C.byref(self.h), stream, n_heads, n_groups, head_size, span, cache_mode, max_batch, max_len,
+                                      rank, nranks, comm), "dihost_model_create")
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            lib().dihost_model_destroy(self.h)
+            self.h = None
+
+    def _put(self, fn, name, t, dtype):
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        self._keep.append(t)
+        _ck(fn(self.h, name.encode(), DT[dtype], t.dim(), shape, vp(t.data_ptr())), "set " + name)
+
+    def set_tensor(self, name, t, dtype):
+        self._put(lib().dihost_set_tensor, name, t, dtype)
+
+    def set_weight(self, name, t, dtype):
+        self._put(lib().dihost_set_weight, name, t, dtype)
+
+    def get_tensor(self, name):
+        dt, nd, shp, p = i32(), i32(), (C.c_int64 * 8)(), vp()
+        _ck(lib().dihost_get_tensor(self.h, name.encode(), C.byref(dt), C.byref(nd), shp, C.byref(p)), "get " + name)
+        return dt.value, list(shp[: nd.value]), p.value
+
+    def create_op(self, op_type, op_name, inputs, outputs, weights=(), attrs=""):
+        oid = i32()
+        _ck(lib().dihost_op_create(self.h, C.byref(oid), op_type.encode(), op_name.encode(), ",".join(inputs).encode(),
+                                   ",".join(outputs).encode(), ",".join(weights).encode(), attrs.encode()), "create " + op_type)
+        return oid.value
+
+    def set_runtime(self, is_context, steps, k_spans, v_spans):
+        """k_spans / v_spans: [request][layer][span] lists of device pointers."""
+        nreq = len(steps)
+        nl = len(k_spans[0]) if nreq else 0
+        spr = len(k_spans[0][0]) if nl else 0
+        flat = lambda a: (vp * (nreq * nl * spr))(*[p for r in a for l in r for p in l])
+        _ck(lib().dihost_set_runtime(self.h, int(is_context), nreq, (i32 * max(nreq, 1))(*steps), nl, spr, flat(k_spans), flat(v_spans)),
+            "set_runtime")
+
+    def reshape(self, op):
+        _ck(lib().dihost_op_reshape(self.h, op), "CallReshape")
+
+    def alloc(self, op):
+        _ck(lib().dihost_op_alloc(self.h, op), "CallAlloc")
+
+    def forward(self, op):
+        _ck(lib().dihost_op_forward(self.h, op), "CallForward")

@@ -1,0 +1,45 @@
+/* dashinfer_hip_host.h -- C test harness around the C++ operator layer (dash-infer_amd/host).
+ *
+ * NOT part of the drop-in boundary (that is include/dashinfer_hip.h below the operators and the
+ * allspark::AsOperator interface above them): this header only lets tests, written in Python,
+ * build an OperatorProto / TensorMap / RuntimeContext, look an op up in the OpFactory and drive
+ * CallInit / CallReshape / CallAlloc / CallForward the way AsModel does
+ * (csrc/core/model/model.cpp:265-287,566-650,1305-1325).  Status codes are AsStatus values.     */
+#ifndef DASHINFER_HIP_HOST_H_
+#define DASHINFER_HIP_HOST_H_
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct dihost_model* dihost_model_t; /* HIPContext + tensor map + weights map + runtime context */
+
+/* dtype codes are allspark DataType values (FLOAT32 1, FLOAT16 2, INT8 3, INT32 5, BFLOAT16 9, UINT8 10) */
+int dihost_model_create(dihost_model_t* m, void* stream, int num_heads, int num_groups, int size_per_head, int span_size,
+                        int cache_mode, int max_batch, int max_length, int rank, int nranks, void* rccl_comm);
+int dihost_model_destroy(dihost_model_t m);
+/* tensors are views of caller-owned device memory (torch tensors in the tests) */
+int dihost_set_tensor(dihost_model_t m, const char* name, int dtype, int ndim, const int64_t* shape, void* data);
+int dihost_set_weight(dihost_model_t m, const char* name, int dtype, int ndim, const int64_t* shape, void* data);
+/* output tensors are owned by the model: shape / pointer after Reshape */
+int dihost_get_tensor(dihost_model_t m, const char* name, int* dtype, int* ndim, int64_t* shape8, void** data);
+
+/* names are comma-separated; attrs: "key=i:<int>" | "key=f:<float>" | "key=b:<0|1>", ';'-separated.
+ * Looks {op_type, HIP} up in the OpFactory; an unregistered type returns ALLSPARK_PARAM_ERROR with
+ * dihost_last_error() == "Unsupported op type." */
+int dihost_op_create(dihost_model_t m, int* op_id, const char* op_type, const char* op_name, const char* inputs,
+                     const char* outputs, const char* weights, const char* attrs);
+/* runtime context: is_context, one entry per request: step (tokens in cache); span pointer tables
+ * k_spans / v_spans: host arrays [n_requests][n_layers][spans_per_req] of device pointers */
+int dihost_set_runtime(dihost_model_t m, int is_context, int n_requests, const int* steps, int n_layers, int spans_per_req,
+                       void* const* k_spans, void* const* v_spans);
+int dihost_op_reshape(dihost_model_t m, int op_id);
+int dihost_op_alloc(dihost_model_t m, int op_id);
+int dihost_op_forward(dihost_model_t m, int op_id);
+const char* dihost_last_error(void);
+/* "GemmA16W8,GemmA16W4,DecOptMHA,DecOptMQA,AllReduce": op types registered for DeviceType::HIP */
+const char* dihost_registered_ops(void);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,158 @@
+"""GPU parity of the C++ operator layer (AsOperator subclasses on DeviceType::HIP), driven like
+AsModel drives ops: CallInit -> CallReshape -> [CallAlloc] -> CallForward, tensors bound by name,
+shared "workspace", RuntimeContext with per-request span vectors.  Reference: the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import attention, gemm_ref, glue, kv_codec, quant
+from oracle.numerics import bf16_round
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(pkg):
+    from dash_infer_amd import hostapi, ops
+    assert torch.cuda.is_available()
+    return hostapi, ops
+
+
+def dev(a, dt=torch.bfloat16):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dt).cuda()
+
+
+def view_of(ptr, shape, dtype):
+    """Copy of model-owned device memory as a torch tensor (torch has no from-pointer constructor)."""
+    import ctypes as C
+    n = int(np.prod(shape))
+    t = torch.empty(n, dtype=dtype, device="cuda")
+    torch.cuda.synchronize()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    assert hip.hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), n * t.element_size(), 3) == 0
+    return t.view(*shape)
+
+
+@pytest.mark.parametrize("wbits,G,act", [(4, 128, None), (8, -1, "silu"), (4, 64, "gelu_erf")])
+def test_gemm_lowp_operator(env, wbits, G, act):
+    hostapi, ops = env
+    rng = np.random.default_rng(wbits + abs(G))
+    K, N = 512, 384
+    W = bf16_round(rng.normal(0, 0.05, (K, N)).astype(np.float32))
+    q, s, z = (quant.iq_quantize_a16w4(W, G, "bf16") if wbits == 4 else quant.iq_quantize_a16w8(W, G, "bf16"))
+    bias = bf16_round(rng.normal(0, 0.2, N).astype(np.float32))
+    m = hostapi.Model(ops.cur_stream(), 4, 2, 128, 16)
+    qd = torch.from_numpy(q).cuda()
+    m.set_weight("w", qd, "u8" if wbits == 4 else "i8")
+    m.set_weight("w.scales", dev(s), "bf16")
+    m.set_weight("w.zeros", dev(z), "bf16")
+    m.set_weight("w.bias", dev(bias), "bf16")
+    actcode = {None: 0, "silu": 5, "gelu_erf": 2}[act]
+    attrs = f"alpha=f:1.0;activation=i:{actcode}" + (f";GroupSize=i:{G}" if G > 0 else "")
+    for M in (1, 5, 40):  # batch changes -> Reshape again, same op instance
+        x = bf16_round(rng.normal(0, 1, (M, 1, K)).astype(np.float32))
+        xd = dev(x)
+        m.set_tensor("x", xd, "bf16")
+        if M == 1:
+            op = m.create_op("GemmA16W4" if wbits == 4 else "GemmA16W8", "decoder.layer.0.ffn.gate", ["x"], ["y"],
+                             ["w", "w.scales", "w.zeros", "w.bias"], attrs)
+        m.reshape(op)
+        m.forward(op)
+        dt, shape, ptr = m.get_tensor("y")
+        assert dt == hostapi.DT["bf16"] and shape == [M, 1, N]
+        y = view_of(ptr, shape, torch.bfloat16).float().cpu().numpy().reshape(M, N)
+        ref = gemm_ref.gemm_a16wx(x.reshape(M, K), q, s, z, G, wbits, bias=bias, act=act, ft="bf16")
+        np.testing.assert_allclose(y, ref, rtol=2 ** -7, atol=2 ** -7 * 0.05 * np.abs(ref).max())
+    m.close()
+
+
+def test_gemm_operator_rejects_bad_attributes(env):
+    hostapi, ops = env
+    m = hostapi.Model(ops.cur_stream(), 4, 2, 128, 16)
+    z8 = torch.zeros(64, 32, dtype=torch.int8, device="cuda")
+    m.set_weight("w", z8, "i8")
+    m.set_weight("s", torch.zeros(1, 32, dtype=torch.bfloat16, device="cuda"), "bf16")
+    m.set_weight("z", torch.zeros(1, 32, dtype=torch.bfloat16, device="cuda"), "bf16")
+    m.set_tensor("x", torch.zeros(1, 1, 64, dtype=torch.bfloat16, device="cuda"), "bf16")
+    for bad in ("transB=b:1", "is_pooler=b:1", "GroupSize=i:48"):
+        with pytest.raises(hostapi.HostError) as e:
+            m.create_op("GemmA16W8", "g", ["x"], ["y"], ["w", "s", "z"], bad)
+        assert e.value.code == 2
+    m.close()
+
+
+@pytest.mark.parametrize("mode", ["none", "u4"])
+def test_span_attention_operator_prefill_then_decode(env, mode):
+    """DecOptMQA: a 70-token prefill (runContext: MFMA prefill attention + ContextSpanCopy), then two
+    decode steps of a batch of two requests (runDecoder: cache append + paged attention)."""
+    hostapi, ops = env
+    rng = np.random.default_rng(9)
+    n, g, H, S, L = 8, 2, 128, 32, 70
+    max_len = 128
+    spr = max_len // S
+    cache_mode = {"none": 0, "i8": 1, "u4": 2}[mode]
+    pool = ops.SpanPool(2 * 2 * spr + 1, g, S, H, mode, torch.bfloat16)
+    m = hostapi.Model(ops.cur_stream(), n, g, H, S, cache_mode, max_batch=2, max_len=max_len)
+    alpha = 1.0 / np.sqrt(H)
+    reqs = []
+    op = None
+    for r in range(2):
+        kp = [pool.alloc()[0] for _ in range(spr)]
+        vp_ = [pool.alloc()[0] for _ in range(spr)]
+        qkv = bf16_round(rng.normal(0, 1, (L, (n + 2 * g) * H)).astype(np.float32))
+        xd = dev(qkv.reshape(1, L, -1))
+        m.set_tensor("qkv", xd, "bf16")
+        if op is None:
+            op = m.create_op("DecOptMQA", "decoder.layer.0.attention", ["qkv"], ["attn_out"])
+        m.set_runtime(True, [0], [[kp]], [[vp_]])
+        m.reshape(op)
+        m.alloc(op)
+        m.forward(op)
+        _, shape, ptr = m.get_tensor("attn_out")
+        out = view_of(ptr, shape, torch.bfloat16).float().cpu().numpy().reshape(L, n, H)
+        q = qkv[:, : n * H].reshape(L, n, H)
+        k = qkv[:, n * H:(n + g) * H].reshape(L, g, H)
+        v = qkv[:, (n + g) * H:].reshape(L, g, H)
+        np.testing.assert_allclose(out, attention.prefill_attention(q, k, v, alpha), rtol=1e-2, atol=5e-3)  # P is bf16 on the matrix core
+        kc, vc = kv_codec.SpanCache(g, S, H, mode, "bf16"), kv_codec.SpanCache(g, S, H, mode, "bf16")
+        for t in range(L):
+            kc.write(t, k[t])
+            vc.write(t, v[t])
+        reqs.append((kp, vp_, kc, vc))
+    # the spans now hold exactly what the codec oracle holds
+    torch.cuda.synchronize()
+    for (kp, vp_, kc, vc) in reqs:
+        for i, sp in enumerate(kc.spans):
+            idx = (kp[i] - pool.pool.data_ptr()) // pool.aligned
+            assert np.array_equal(pool.span_view(idx).cpu().numpy(), sp)
+    # two decode steps of the batch of two
+    for step in range(2):
+        qkv = bf16_round(rng.normal(0, 1, (2, (n + 2 * g) * H)).astype(np.float32))
+        m.set_tensor("qkv", dev(qkv.reshape(2, 1, -1)), "bf16")
+        m.set_runtime(False, [L + step, L + step], [[r[0]] for r in reqs], [[r[1]] for r in reqs])
+        m.reshape(op)
+        m.alloc(op)
+        m.forward(op)
+        _, shape, ptr = m.get_tensor("attn_out")
+        out = view_of(ptr, shape, torch.bfloat16).float().cpu().numpy().reshape(2, n, H)
+        for b, (kp, vp_, kc, vc) in enumerate(reqs):
+            kc.write(L + step, qkv[b, n * H:(n + g) * H].reshape(g, H))
+            vc.write(L + step, qkv[b, (n + g) * H:].reshape(g, H))
+            ref = attention.decode_attention(qkv[b, : n * H].reshape(n, H), kc.read_all(L + step + 1), vc.read_all(L + step + 1), alpha)
+            np.testing.assert_allclose(out[b], ref, rtol=1e-2, atol=2.5e-3)
+    m.close()
+
+
+def test_allreduce_operator_single_rank(env):
+    hostapi, ops = env
+    m = hostapi.Model(ops.cur_stream(), 4, 2, 128, 16)
+    x = torch.randn(3, 1, 64, device="cuda").to(torch.bfloat16)
+    m.set_tensor("x", x, "bf16")
+    op = m.create_op("AllReduce", "decoder.layer.0.allreduce", ["x"], ["y"])
+    m.reshape(op)
+    m.forward(op)
+    _, shape, ptr = m.get_tensor("y")
+    assert torch.equal(view_of(ptr, shape, torch.bfloat16), x)
+    m.close()

@@ -45,7 +45,7 @@ def test_prefill_matches_oracle(ops, Lq, Lk, n, g, ft):
     alpha = 1.0 / np.sqrt(H)
     ref = attention.prefill_attention(q, k, v, alpha)
     out = ops.prefill_attn(dev(q.reshape(Lq, -1), ft), dev(k.reshape(Lk, -1), ft), dev(v.reshape(Lk, -1), ft), n, g, H, alpha)
-    np.testing.assert_allclose(out.float().cpu().numpy().reshape(Lq, n, H), ref, rtol=TOL[ft], atol=TOL[ft] * 0.25)
+    np.testing.assert_allclose(out.float().cpu().numpy().reshape(Lq, n, H), ref, rtol=TOL[ft], atol=TOL[ft] * 0.5)  # P is rounded to FT for the matrix core
 
 
 def test_prefill_interleaved_qkv_rows_and_non_causal(ops):
