@@ -65,27 +65,40 @@ def cpu_baseline(wbits, group, cores_hint=None):
                       f"layers at batch 1, extrapolated x28; {t_layer * 1e3:.1f} ms/layer"}
 
 
-def kernel_breakdown(sess, torch, ops, iters=3):
-    """Average launch duration of every hot-path kernel measured with HIP events on the launch
-    stream, eager mode, cycling through all layers' weights (1.9+ GB, far beyond the 256 MB
-    Infinity Cache)."""
+def kernel_breakdown(sess, torch, ops, iters=5):
+    """Average launch duration of every hot-path kernel: the launches of all layers (each layer its
+    own weights: 1.9+ GB per sweep, far beyond the 256 MB Infinity Cache) are captured into one
+    hipGraph per kernel kind and replayed; HIP events on the launch stream bracket the replays.  The
+    figure includes the ~1.6 us dependent-launch boundary of a graph node chain."""
     m, cfg, sc = sess.model, sess.model.cfg, sess.scratch
     B = sess.B
     res = {}
 
-    def timed(name, nbytes, fn):
-        evs = []
-        for _ in range(iters):
-            for li, lw in enumerate(m.layers):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+    def timed(name, nbytes, fn, layers=None):
+        layers = m.layers if layers is None else layers
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for li, lw in enumerate(layers):
                 fn(li, lw)
-                e1.record()
-                evs.append((e0, e1))
+        torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        ts = sorted(a.elapsed_time(b) for a, b in evs)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for li, lw in enumerate(layers):
+                fn(li, lw)
+        g.replay()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / len(layers))
         avg = sum(ts) / len(ts)
-        res[name] = {"avg_us": round(avg * 1e3, 2), "min_us": round(ts[0] * 1e3, 2), "bytes": int(nbytes),
+        res[name] = {"avg_us": round(avg * 1e3, 2), "min_us": round(min(ts) * 1e3, 2), "bytes": int(nbytes),
                      "GBps": round(nbytes / (avg * 1e-3) / 1e9, 1)}
 
     l0 = m.layers[0]
@@ -93,28 +106,39 @@ def kernel_breakdown(sess, torch, ops, iters=3):
     timed("qkv_norm_gemv", l0.qkv.nbytes + act_b(l0.qkv),
           lambda li, lw: ops.fused_norm_gemm(sess.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sc, out=sess.qkv))
     kvb = {"none": sess.H * 2, "i8": sess.H + 8, "u4": sess.H // 2 + 8}[sess.kv_mode]
-    timed("rope_append_span_attention", B * 2 * sess.g_loc * SEQ_LEN * kvb,
-          lambda li, lw: ops.span_attn_decode_fused(sess.qkv, sess.kv[li], sess.old_lens, sess.rope_tab, sess.n_loc, sess.g_loc,
-                                                    sess.H, sess.max_len, sess.scale, sess.attn_ws, out=sess.attn))
+    if sess.fused_attention:
+        timed("rope_append_span_attention", B * 2 * sess.g_loc * SEQ_LEN * kvb,
+              lambda li, lw: ops.span_attn_decode_fused(sess.qkv, sess.kv[li], sess.old_lens, sess.rope_tab, sess.n_loc, sess.g_loc,
+                                                        sess.H, sess.max_len, sess.scale, sess.attn_ws, out=sess.attn))
+    else:
+        def sep(li, lw):
+            ops.rope_kv_append(sess.kv[li], sess.q, sess.qkv, sess.old_lens, sess.inv_freq, sess.n_loc, sess.g_loc, sess.H)
+            ops.span_attn_decode(sess.q, sess.kv[li], sess.new_lens, sess.n_loc, sess.g_loc, sess.H, sess.max_len, sess.scale,
+                                 sess.attn_ws, sess.attn_sync, out=sess.attn)
+        timed("rope_append_span_attention", B * 2 * sess.g_loc * SEQ_LEN * kvb, sep)
     timed("o_gemv_addto", l0.o.nbytes + act_b(l0.o),
           lambda li, lw: ops.fused_gemm_addto(sess.attn, lw.o, sess.h, sc, out=sess.partial))
     timed("gate_up_swiglu", l0.gate.nbytes + l0.up.nbytes + B * l0.gate.K * 4 + B * l0.gate.N * 2,
           lambda li, lw: ops.fused_norm_swiglu(sess.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=sess.act))
     timed("down_gemv_addto", l0.down.nbytes + act_b(l0.down),
           lambda li, lw: ops.fused_gemm_addto(sess.act, lw.down, sess.h, sc, out=sess.partial))
-    evs = []
-    for _ in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        ops.lm_head(sess.h, m.final_norm, cfg.eps, m.lm_head, sc, out=sess.logits)
-        e1.record()
-        evs.append((e0, e1))
-    torch.cuda.synchronize()
-    ts = [a.elapsed_time(b) for a, b in evs][1:]
-    avg = sum(ts) / len(ts)
-    res["lm_head"] = {"avg_us": round(avg * 1e3, 2), "bytes": int(m.lm_head.nbytes),
-                      "GBps": round(m.lm_head.nbytes / (avg * 1e-3) / 1e9, 1)}
+    timed("lm_head", m.lm_head.nbytes,
+          lambda li, lw: ops.lm_head(sess.h, m.final_norm, cfg.eps, m.lm_head, sc, out=sess.logits), layers=[None] * 4)
     return res
+
+
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary
+    (profiles/r01_pmc_hbm_traffic.csv: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE)."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.csv")
+    if not os.path.exists(path):
+        return None
+    tot = 0
+    for r in csv.DictReader(open(path)):
+        if kernel_substr in r["kernel"]:
+            tot += int(r["avg_bytes_corrected"])
+    return tot or None
 
 
 def main():
@@ -201,7 +225,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "bf16 activations, " + ("u4" if wbits == 4 else "i8") + " weights (f32 accumulate)",
+        "dtype": "bf16",
         "data": "synthetic (random-init InstantQuant weights of the Qwen2-7B architecture, random 2048-token KV history)",
         "config": {"workload": f"Qwen2-7B {args.workload}: int{wbits} weight-only group {group}, KV {kv_mode}, batch {batch}, "
                                f"seq {SEQ_LEN}, TP={world}, greedy, hipGraph={'off' if args.no_graph else 'on'}",
@@ -219,9 +243,11 @@ def main():
         try:
             kb = kernel_breakdown(sess, torch, ops)
             dom = kb["gate_up_swiglu"]
-            out["roofline"] = {"bound": "hbm", "kernel": "gemm_lowp_kernel<EPI_SWIGLU> (gate/up GEMV + SwiGLU)",
+            kname = "gemv_stream_kernel<%d, 2, %d, 1, 1, %d>" % (wbits, 1 if batch == 1 else 4, 1 if group > 0 else 0)
+            out["roofline"] = {"bound": "hbm", "kernel": "dihip::" + kname + " (RMSNorm + gate/up GEMV + SwiGLU)",
                                "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                               "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4),
+                               "traffic": pmc_traffic(kname) if args.workload == "int4_b1" else None,
                                "avg_launch_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["bytes"]}
             out["kernels"] = kb
         except Exception as e:  # never lose the headline number to the breakdown
