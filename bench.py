@@ -166,7 +166,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        comm = decoder.RcclComm(rank, world, torch.device("cuda", local_rank))
+        comm = decoder.make_comm(rank, world, torch.device("cuda", local_rank))
 
     wbits, group, kv_mode, batch, gptq = WORKLOADS[args.workload]
     cfg = decoder.QWEN2_7B

@@ -65,6 +65,7 @@ _SIGS = {
     "dihip_argmax_merge": (i32, [vp, vp, vp, i32, i32]),
     "dihip_embedding": (i32, [vp, vp, vp, vp, i32, i32, i32]),
     "dihip_increment_u32": (i32, [vp, vp, i32]),
+    "dihip_prefetch": (i32, [vp, C.POINTER(vp), C.POINTER(sz), i32, i32]),
     "dihip_rccl_unique_id": (i32, [vp]),
     "dihip_rccl_comm_init_rank": (i32, [C.POINTER(vp), i32, vp, i32]),
     "dihip_rccl_comm_destroy": (i32, [vp]),

@@ -250,6 +250,12 @@ static GemvPlan make_gemv_plan(int wbits, int M, int N, int K, int group_size, b
   // one workgroup per CU when there are enough column tiles; below ~1.5 waves of CUs the launch
   // is latency bound and one tile per workgroup spreads the loads widest
   p.upb = units <= num_cus + num_cus / 2 ? 1 : (units + num_cus - 1) / num_cus;
+  static int upb_override = -1;  // experiments: DIHIP_GEMV_UPB=<units per workgroup> for the multi-unit shapes
+  if (upb_override < 0) {
+    const char* e = getenv("DIHIP_GEMV_UPB");
+    upb_override = e ? atoi(e) : 0;
+  }
+  if (upb_override > 0 && p.upb > 1) p.upb = upb_override;
   p.blocks = (units + p.upb - 1) / p.upb;
   const int nv = p.upb * (dual ? 2 : 1);
   const int kgroups = d.group ? (d.KT + p.ktpg - 1) / p.ktpg : d.KT;

@@ -152,6 +152,34 @@ using namespace dihip;
       return DIHIP_PARAM_ERROR;                                        \
   }
 
+// Weight prefetch into the 256 MB Infinity Cache (memory-side): streams up to 8 buffers through the
+// load path and discards them.  Launched on a SIDE stream next to a latency-bound phase of the decode
+// step (attention at batch 1 leaves HBM idle), so that the following weight-streaming GEMVs find their
+// weights on-die.  Reads only; the never-true store keeps the loads alive.
+struct PrefetchArgs {
+  const u32x4_t* p[8];
+  size_t n16[8];  // 16-byte vectors per buffer
+  unsigned* sink;
+};
+__global__ __launch_bounds__(256) void prefetch_kernel(const PrefetchArgs a) {
+  unsigned acc = 0;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (int b = 0; b < 8; ++b) {
+    const u32x4_t* p = a.p[b];
+    const size_t n = a.n16[b];
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 7 * stride < n; i += 8 * stride) {
+      u32x4_t v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = p[i + j * stride];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc ^= v[j][0] ^ v[j][3];
+    }
+    for (; i < n; i += stride) acc ^= p[i][0];
+  }
+  if (acc == 0x9E3779B9u && a.sink) a.sink[0] = acc;  // practically never
+}
+
 extern "C" {
 
 int dihip_rmsnorm(void* stream, void* y, const void* x, const void* gamma, float eps, int rows, int cols, int dtype) {
@@ -241,6 +269,21 @@ int dihip_increment_u32(void* stream, uint32_t* v, int count) {
   if (count == 0) return DIHIP_SUCCESS;
   hipLaunchKernelGGL(increment_u32_kernel, dim3((count + 255) / 256), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), v, count);
+  return launch_status();
+}
+
+int dihip_prefetch(void* stream, const void* const* bufs, const size_t* bytes, int count, int num_workgroups) {
+  DIHIP_REQUIRE(count >= 0 && count <= 8 && (count == 0 || (bufs && bytes)), DIHIP_PARAM_ERROR, "prefetch: bad argument");
+  if (count == 0) return DIHIP_SUCCESS;
+  PrefetchArgs a{};
+  for (int i = 0; i < count; ++i) {
+    DIHIP_REQUIRE((reinterpret_cast<uintptr_t>(bufs[i]) & 15) == 0, DIHIP_PARAM_ERROR, "prefetch: buffers must be 16-byte aligned");
+    a.p[i] = reinterpret_cast<const u32x4_t*>(bufs[i]);
+    a.n16[i] = bytes[i] / 16;
+  }
+  a.sink = nullptr;
+  if (num_workgroups <= 0) num_workgroups = 256;
+  hipLaunchKernelGGL(prefetch_kernel, dim3(num_workgroups), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
   return launch_status();
 }
 

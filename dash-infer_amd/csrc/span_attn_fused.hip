@@ -352,7 +352,7 @@ __global__ __launch_bounds__(128) void span_attn_merge_kernel(void* out, const f
   const int ns = min(nsplits, (len + tps - 1) / tps);
   const float* base = partials + (size_t)bh * nsplits * ATTN_PSTRIDE;
   float mm = -INFINITY, ll = 0.f, oo = 0.f;
-  constexpr int MB = 32;  // splits per batch: all loads of a batch are in flight together
+  constexpr int MB = 40;  // splits per batch: all loads of a batch are in flight together
   for (int sb = 0; sb < ns; sb += MB) {
     float mv[MB], lv[MB], ov[MB];
 #pragma unroll

@@ -209,6 +209,40 @@ class RcclComm:
         return dst
 
 
+class TorchComm:
+    """Fallback communicator: the same collectives through torch.distributed (backend nccl = RCCL).
+    Used only if creating a communicator through the C-ABI fails (e.g. two RCCL builds in one process)."""
+
+    def __init__(self, rank, nranks):
+        self.rank, self.nranks = rank, nranks
+
+    def allreduce_(self, t):
+        import torch.distributed as dist
+        dist.all_reduce(t)
+        return t
+
+    def allgather(self, src, dst):
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(dst, src)
+        return dst
+
+
+def make_comm(rank, nranks, device):
+    """RCCL communicator through the C-ABI, verified with one all-reduce; torch.distributed otherwise."""
+    import sys
+    try:
+        c = RcclComm(rank, nranks, device)
+        probe = torch.full((8,), float(rank + 1), dtype=torch.float32, device=device)
+        c.allreduce_(probe)
+        torch.cuda.synchronize()
+        if abs(float(probe[0]) - nranks * (nranks + 1) / 2) > 1e-3:
+            raise RuntimeError("C-ABI all-reduce returned a wrong sum")
+        return c
+    except Exception as e:  # noqa: BLE001
+        print(f"[rank {rank}] dihip RCCL communicator unavailable ({e}); using torch.distributed collectives", file=sys.stderr)
+        return TorchComm(rank, nranks)
+
+
 class DecodeSession:
     """Buffers + KV spans for a fixed batch; `step()` enqueues one decode step."""
 
@@ -259,6 +293,11 @@ class DecodeSession:
         self.pairs_all = torch.empty(nr * batch * 8, dtype=torch.uint8, device=device)
         self.scale = 1.0 / (H ** 0.5)
         self.graph = None
+        # Infinity Cache prefetch of the next weights on a side stream while attention (latency bound at
+        # small batch, HBM idle) runs.  DIHIP_PREFETCH=0 disables; value = workgroups of the prefetch kernel.
+        import os
+        self.prefetch_wgs = int(os.environ.get("DIHIP_PREFETCH", "0"))
+        self.side = torch.cuda.Stream() if self.prefetch_wgs > 0 else None
 
     # -- state ---------------------------------------------------------------------------
     def set_state(self, ids, lens):
@@ -290,8 +329,19 @@ class DecodeSession:
         m, cfg, sc = self.model, self.model.cfg, self.scratch
         ops.embedding(self.ids, m.embed, out=self.h)
         tp_on = self.comm is not None and m.nranks > 1
+        main = torch.cuda.current_stream()
         for li, lw in enumerate(m.layers):
             ops.fused_norm_gemm(self.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sc, out=self.qkv)
+            if self.side is not None:
+                # fork: the rest of this layer's weights (+ the next layer's qkv) stream into the Infinity
+                # Cache while attention runs; joined before the next fork so one sweep is in flight at most
+                nxt = m.layers[li + 1].qkv if li + 1 < len(m.layers) else None
+                self.side.wait_stream(main)
+                with torch.cuda.stream(self.side):
+                    ops.prefetch([lw.o.w, lw.o.sz, lw.gate.w, lw.gate.sz, lw.up.w, lw.up.sz, lw.down.w, lw.down.sz],
+                                 workgroups=self.prefetch_wgs)
+                    if nxt is not None:
+                        ops.prefetch([nxt.w, nxt.sz], workgroups=self.prefetch_wgs)
             if self.fused_attention:
                 ops.span_attn_decode_fused(self.qkv, self.kv[li], self.old_lens, self.rope_tab, self.n_loc, self.g_loc, self.H,
                                            self.max_len, self.scale, self.attn_ws, out=self.attn)
@@ -302,6 +352,8 @@ class DecodeSession:
             self._proj_residual(self.attn, lw.o, tp_on)
             ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act)
             self._proj_residual(self.act, lw.down, tp_on)
+            if self.side is not None:
+                main.wait_stream(self.side)
         ops.lm_head(self.h, m.final_norm, cfg.eps, m.lm_head, sc, out=self.logits)
         if tp_on:
             check(lib().dihip_argmax_partial(ops.cur_stream(), ops.ptr(self.pair), ops.ptr(self.logits), self.B,

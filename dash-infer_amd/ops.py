@@ -318,6 +318,16 @@ def embedding(ids, table, out=None):
     return h
 
 
+def prefetch(tensors, stream=None, workgroups=0):
+    """Enqueue a read-only sweep of up to 8 device tensors (Infinity Cache prefetch) on `stream`."""
+    tensors = [t for t in tensors if t is not None]
+    n = len(tensors)
+    bufs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    sizes = (C.c_size_t * n)(*[t.numel() * t.element_size() for t in tensors])
+    st = cur_stream() if stream is None else C.c_void_p(stream.cuda_stream)
+    check(lib().dihip_prefetch(st, bufs, sizes, n, workgroups), "dihip_prefetch")
+
+
 def increment_u32_(v):
     check(lib().dihip_increment_u32(cur_stream(), ptr(v), v.numel()), "dihip_increment_u32")
     return v

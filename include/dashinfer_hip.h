@@ -265,6 +265,11 @@ int dihip_embedding(void* stream, float* h, const int64_t* ids, const void* tabl
                     int dtype);
 /* seq_lens[b] += 1 (device-side step counter for graph replay) */
 int dihip_increment_u32(void* stream, uint32_t* v, int count);
+/* Read-only prefetch of up to 8 buffers into the on-die Infinity Cache (no reference counterpart):
+ * meant for a SIDE stream next to a latency-bound phase, so that the weight-streaming launches that
+ * follow find their weights on-die.  bufs / bytes are HOST arrays of device pointers / sizes.   */
+int dihip_prefetch(void* stream, const void* const* bufs_host, const size_t* bytes_host, int count,
+                   int num_workgroups);
 
 /* =============================================================================================
  * 6. Tensor-parallel all-reduce (replaces AllReduceOp's ncclAllReduce,

@@ -72,6 +72,22 @@ int main(int argc, char** argv) {
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       float us = ms * 1e3f / ncopy; if (us < best) best = us; sum += us;
     }
+    if (getenv("PREFETCH")) {
+      auto pf = [&](int c) {
+        const void* bufs[4]; size_t bytes[4]; int n = 0;
+        if (s.kind == 2) { bufs[n] = W[2 * c]; bytes[n++] = wb; bufs[n] = W[2 * c + 1]; bytes[n++] = wb; bufs[n] = SZ[2 * c]; bytes[n++] = szb; bufs[n] = SZ[2 * c + 1]; bytes[n++] = szb; }
+        else { bufs[n] = W[c]; bytes[n++] = wb; if (szb) { bufs[n] = SZ[c]; bytes[n++] = szb; } }
+        dihip_prefetch(st, bufs, bytes, n, 256);
+      };
+      float tA = 0, tB = 0;
+      for (int r = 0; r < 3; ++r) {
+        CK(hipEventRecord(e0, st)); for (int c = 0; c < ncopy; ++c) { pf(c); launch(c); } CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tA = ms * 1e3f / ncopy;
+        CK(hipEventRecord(e0, st)); for (int c = 0; c < ncopy; ++c) pf(c); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1)); tB = ms * 1e3f / ncopy;
+      }
+      printf("  prefetch+gemv %.2f us, prefetch alone %.2f us (%.0f GB/s) -> gemv on prefetched weights %.2f us\n", tA, tB, per / tB / 1e3, tA - tB);
+    }
     if (getenv("TRACE")) {
       int blocks = 0, upb = 0, wk = 0, wn = 0; size_t lds = 0;
       int ok = dihip_debug_gemv_plan(dense ? 16 : wbits, M, s.N, s.K, dense ? -1 : group, s.kind == 2, &blocks, &upb, &wk, &wn, &lds);
