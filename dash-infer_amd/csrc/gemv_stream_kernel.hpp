@@ -184,8 +184,11 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
   issue_batch(0, 0);
 
   // ---- this workgroup's units and this wave's share ---------------------------------------
-  const int u0 = blockIdx.x * a.upb;
-  const int nu = min(a.upb, a.NTILES - u0);  // units of this workgroup (SwiGLU: (gate, up) tile pairs)
+  // units are dealt round-robin: workgroup b owns units b, b + NB, b + 2*NB, ... (SwiGLU: (gate, up) tile
+  // pairs), which spreads every workgroup's address range over the whole matrix
+  const int NB = gridDim.x;
+  const int u0 = blockIdx.x;
+  const int nu = (a.NTILES - u0 + NB - 1) / NB;
   const int nv = nu * DUAL;                  // half-units (one weight tile each)
   // K split in whole quantisation groups (per-channel: any k-tile boundary)
   const bool subc = QUANT && a.ktpg < a.KT;
@@ -208,8 +211,8 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
   // The refill is branch-free scalar code; once the sequence is exhausted the cursor parks on a
   // dummy chunk (the head of the matrix), which keeps the vmcnt arithmetic uniform in the tail.
   const bool second = DUAL == 2 && (wn & 1);
-  const int t0 = u0 + (DUAL == 2 ? wn >> 1 : wn);
-  const int tstep = DUAL == 2 ? a.WN >> 1 : a.WN;
+  const int t0 = u0 + (DUAL == 2 ? wn >> 1 : wn) * NB;
+  const int tstep = (DUAL == 2 ? a.WN >> 1 : a.WN) * NB;
   const char* const dummy_w = reinterpret_cast<const char*>(a.w0);
   const char* const dummy_s = dummy_w;
   const char* wtile = reinterpret_cast<const char*>((second ? a.w1 : a.w0) + ((size_t)t0 * a.KT + k_lo) * 64);
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
     const int col = e & 15;
     const int m = MR == 1 ? 0 : (e >> 4) % rows;
     const int u = MR == 1 ? (e >> 4) : (e >> 4) / rows;
-    const int n = (u0 + u) * 16 + col;
+    const int n = (u0 + u * NB) * 16 + col;
     if (n >= a.N) continue;
     float v = 0.f, v2 = 0.f;
     const float* p = red + ((size_t)(u * DUAL) * a.WK * rows + m) * 16 + col;
