@@ -67,3 +67,38 @@ def quantize(fdata, wbits, group_size=-1, gptq_like_zeros=False):
         # mimic depack_gptq_zero (integer zero points, +1 convention => [1, 16])
         z = torch.clamp(torch.round(z.float()), 1, 16).to(z.dtype)
     return q, s, z
+
+
+# ---------------------------------------------------------------------- GPTQ checkpoints ----
+def depack_gptq_weight(qweight, bits=4):
+    """AutoGPTQ qweight int32 [K*bits/32, N] -> integers [K, N]: row r holds 32/bits consecutive k,
+    lowest bits first (quantization_utils.py:331-340)."""
+    per = 32 // bits
+    q = qweight.to(torch.int64) & 0xFFFFFFFF
+    shifts = (torch.arange(per, dtype=torch.int64, device=q.device) * bits)[None, :, None]
+    return ((q[:, None, :] >> shifts) & ((1 << bits) - 1)).reshape(-1, q.shape[-1])
+
+
+def depack_gptq_zero(qzeros, bits=4):
+    """AutoGPTQ qzeros int32 [G, N*bits/32] -> [G, N], stored minus one (quantization_utils.py:343-351)."""
+    per = 32 // bits
+    z = qzeros.to(torch.int64) & 0xFFFFFFFF
+    shifts = (torch.arange(per, dtype=torch.int64, device=z.device) * bits)[None, None, :]
+    return (((z[:, :, None] >> shifts) & ((1 << bits) - 1)) + 1).reshape(z.shape[0], -1)
+
+
+def repack_gptq(qweight, qzeros, scales, bits, dtype=torch.bfloat16):
+    """AutoGPTQ checkpoint tensors -> the (weight, scales, zeros) triple GemmA16W4 / GemmA16W8 take
+    (quantization_utils.py:391-437): bits 4 -> u8 [K, ceil(N/2)] with the low nibble = even n; bits 8 ->
+    int8 [K, N] (the reference's forced cast); zeros = stored zero + 1 in FT; scales in FT."""
+    q = depack_gptq_weight(qweight, bits)
+    if bits == 4:
+        if q.shape[1] % 2:
+            q = torch.nn.functional.pad(q, (0, 1))
+        w = ((q[:, 0::2] & 0xF) | ((q[:, 1::2] & 0xF) << 4)).to(torch.uint8)
+    elif bits == 8:
+        w = q.to(torch.uint8).view(torch.int8) if q.dtype != torch.int8 else q
+    else:
+        raise ValueError(f"not supported quant_bits: {bits}")
+    z = depack_gptq_zero(qzeros, bits).to(torch.float32).to(dtype) if qzeros is not None else torch.zeros_like(scales, dtype=dtype)
+    return w.contiguous(), scales.to(dtype).contiguous(), z.contiguous()
