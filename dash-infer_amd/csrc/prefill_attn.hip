@@ -4,9 +4,10 @@
 // Replaces xformer_prefill_attention (csrc/core/kernel/cuda/xformer_mha/xformer_mha.h:26-41; CUTLASS
 // fMHA with kBlockQuery = 32, kBlockKey = 128, xformer_mha.dispatch.cu:37-41) with a
 // flash-style single pass written for wave64 MFMA:
-//   * workgroup = 4 waves = 64 query rows of one head; each wave owns 16 rows and keeps its Q
-//     fragments (A operand of v_mfma_f32_16x16x32, 16 VGPRs for H = 128) and the 16 x 128 f32
-//     output accumulator (8 C tiles) in registers for the whole pass;
+//   * workgroup = 4 waves = 128 query rows of one head; each wave owns 32 rows (two 16-row MFMA
+//     tiles sharing every K / V fragment read) and keeps its Q fragments and the 32 x 128 f32 output
+//     accumulator in registers for the whole pass; under the causal mask a workgroup processes a
+//     query tile and its mirror, so all workgroups stream the same number of key tiles;
 //   * K and V tiles of 32 keys are staged once per workgroup in LDS: K row-major (its rows are
 //     the B fragments of Q.K^T as stored), V transposed on the way in (so that the B fragments
 //     of P.V are contiguous 16-byte reads);
@@ -24,7 +25,8 @@
 namespace dihip {
 
 constexpr int PF_THREADS = 256;
-constexpr int PF_QROWS = 64;   // query rows per workgroup (16 per wave)
+constexpr int PF_MT = 2;       // 16-row query tiles per wave
+constexpr int PF_QROWS = 64 * PF_MT;  // query rows per workgroup (4 waves x 16 x PF_MT)
 constexpr int PF_KEYS = 32;    // keys per tile
 constexpr int PF_KPITCH = 136; // K tile row pitch in elements (128 + 8: conflict-free b128 reads)
 constexpr int PF_VPITCH = 40;  // V^T tile row pitch in elements (32 + 8)
@@ -36,6 +38,7 @@ struct PrefillArgs {
   const void* v;
   int seq_q, seq_k, q_stride, kv_stride, n_heads, n_groups, causal;
   float alpha;
+  int pair;  // causal balance: a workgroup takes query tile x and its mirror
 };
 
 __device__ __forceinline__ float row16_max_pf(float v) {
@@ -56,128 +59,165 @@ __device__ __forceinline__ float row16_sum_pf(float v) {
 template <int FT>
 __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(const PrefillArgs a) {
   constexpr int H = 128;
-  __shared__ __attribute__((aligned(16))) uint16_t ks[PF_KEYS * PF_KPITCH];   // K tile [key][dim]
-  __shared__ __attribute__((aligned(16))) uint16_t vt[H * PF_VPITCH];         // V tile transposed [dim][key]
-  __shared__ __attribute__((aligned(16))) uint16_t ps[4 * 16 * PF_VPITCH];    // per-wave P patch [q row][key]
+  constexpr int MT = PF_MT;  // 16-row query tiles per wave
+  __shared__ __attribute__((aligned(16))) uint16_t ks[PF_KEYS * PF_KPITCH];          // K tile [key][dim]
+  __shared__ __attribute__((aligned(16))) uint16_t vt[H * PF_VPITCH];                // V tile transposed [dim][key]
+  __shared__ __attribute__((aligned(16))) uint16_t ps[4 * MT * 16 * PF_VPITCH];      // per-wave P patches [q row][key]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int ni = lane & 15, kb = lane >> 4;
   const int head = blockIdx.y, kvh = head / (a.n_heads / a.n_groups);
-  const int q0 = blockIdx.x * PF_QROWS + wave * 16;  // first query row of this wave
-  const int shift = a.seq_k - a.seq_q;               // query i sees keys j <= i + shift
+  const int shift = a.seq_k - a.seq_q;  // query i sees keys j <= i + shift
+  const int nqt = (a.seq_q + PF_QROWS - 1) / PF_QROWS;
+  uint16_t* pw = ps + wave * MT * 16 * PF_VPITCH;
 
-  // Q fragments: lane (kb, ni) holds Q[q0 + ni][ks*32 + kb*8 .. +8]
-  u32x4_t qf[4];
-  {
-    const int qr = min(q0 + ni, a.seq_q - 1);
-    const uint16_t* qp = reinterpret_cast<const uint16_t*>(a.q) + (size_t)qr * a.q_stride + (size_t)head * H + kb * 8;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const u32x4_t*>(qp + s * 32);
-  }
-  f32x4_t oacc[8];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) oacc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float mrow[4], lrow[4];  // running max / sum of query rows kb*4 + r (replicated over the 16 key lanes)
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    mrow[r] = -INFINITY;
-    lrow[r] = 0.f;
-  }
+  // Causal balance: workgroup x handles query tile x and then its mirror nqt-1-x, so every
+  // workgroup sees the same number of key tiles (a lone middle tile is done once).
+  const int npass = a.pair && (int)blockIdx.x != nqt - 1 - (int)blockIdx.x ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int qt = pass == 0 ? (int)blockIdx.x : nqt - 1 - (int)blockIdx.x;
+    const int q0 = qt * PF_QROWS + wave * (16 * MT);  // first query row of this wave
 
-  // keys needed by this workgroup: up to the diagonal of its last query row
-  const int wg_last_q = min(a.seq_q, (int)(blockIdx.x + 1) * PF_QROWS) - 1;
-  const int k_end = a.causal ? min(a.seq_k, wg_last_q + shift + 1) : a.seq_k;
-  uint16_t* pw = ps + wave * 16 * PF_VPITCH;
-
-  for (int k0 = 0; k0 < k_end; k0 += PF_KEYS) {
-    __syncthreads();  // previous tile fully consumed
-    // ---- stage K (row-major) and V (transposed): 32 keys x 128 dims each, 2 x 16 B per thread ----
+    // Q fragments: lane (kb, ni) holds Q[q0 + mt*16 + ni][s*32 + kb*8 .. +8]
+    u32x4_t qf[MT][4];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int c = tid + it * PF_THREADS;   // 0..511: key = c / 16, dim chunk = c % 16
-      const int key = c >> 4, dc = c & 15;
-      const int kr = min(k0 + key, a.seq_k - 1);
-      const size_t off = (size_t)kr * a.kv_stride + (size_t)kvh * H + dc * 8;
-      const u32x4_t kv4 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(a.k) + off);
-      const u32x4_t vv4 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(a.v) + off);
-      *reinterpret_cast<u32x4_t*>(ks + key * PF_KPITCH + dc * 8) = kv4;
+    for (int mt = 0; mt < MT; ++mt) {
+      const int qr = min(q0 + mt * 16 + ni, a.seq_q - 1);
+      const uint16_t* qp = reinterpret_cast<const uint16_t*>(a.q) + (size_t)qr * a.q_stride + (size_t)head * H + kb * 8;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        vt[(dc * 8 + 2 * j) * PF_VPITCH + key] = (uint16_t)(vv4[j] & 0xFFFFu);
-        vt[(dc * 8 + 2 * j + 1) * PF_VPITCH + key] = (uint16_t)(vv4[j] >> 16);
-      }
+      for (int s = 0; s < 4; ++s) qf[mt][s] = *reinterpret_cast<const u32x4_t*>(qp + s * 32);
     }
-    __syncthreads();
-    const bool wave_live = !a.causal || k0 <= q0 + 15 + shift;  // some key of the tile is visible to this wave
-    if (wave_live && q0 < a.seq_q) {
-      // ---- S = alpha * Q.K^T for 2 key tiles of 16 ----
-      f32x4_t sacc[2];
+    f32x4_t oacc[MT][8];
+    float mrow[MT][4], lrow[MT][4];  // running max / sum of query rows (replicated over the 16 key lanes)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        sacc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        const uint16_t* kp = ks + (nt * 16 + ni) * PF_KPITCH + kb * 8;
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const u32x4_t bf = *reinterpret_cast<const u32x4_t*>(kp + s * 32);
-          sacc[nt] = mfma16<FT>(qf[s], bf, sacc[nt]);
-        }
-      }
-      // ---- mask + online softmax: lane holds S[q = q0 + kb*4 + r][key = k0 + nt*16 + ni] ----
-      float p[2][4];
+      for (int t = 0; t < 8; ++t) oacc[mt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int qi = q0 + kb * 4 + r;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const int key = k0 + nt * 16 + ni;
-          const bool vis = key < a.seq_k && (!a.causal || key <= qi + shift);
-          const float sv = vis ? sacc[nt][r] * a.alpha : -INFINITY;
-          p[nt][r] = sv;
-          mx = fmaxf(mx, sv);
-        }
-        mx = row16_max_pf(mx);
-        const float mn = fmaxf(mrow[r], mx);
-        const float corr = mrow[r] == -INFINITY ? 0.f : __expf(mrow[r] - mn);
-        float psum = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const float e = p[nt][r] == -INFINITY ? 0.f : __expf(p[nt][r] - mn);
-          const float er = ft_round<FT>(e);  // P is fed to the matrix core in FT
-          p[nt][r] = er;
-          psum += er;
-        }
-        psum = row16_sum_pf(psum);
-        lrow[r] = lrow[r] * corr + psum;
-        mrow[r] = mn;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) oacc[t][r] *= corr;
-      }
-      // ---- P: C layout -> A layout through the wave's LDS patch [q row][32 keys] ----
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pw[(kb * 4 + r) * PF_VPITCH + nt * 16 + ni] = (uint16_t)f32_to_ft_bits<FT>(p[nt][r]);
-      // same wave writes and reads: LDS ops of one wave complete in order
-      const u32x4_t pf = *reinterpret_cast<const u32x4_t*>(pw + ni * PF_VPITCH + kb * 8);
-      // ---- O += P.V: B fragment of dim tile t = V^T[t*16 + ni][kb*8 .. +8] ----
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const u32x4_t vf = *reinterpret_cast<const u32x4_t*>(vt + (t * 16 + ni) * PF_VPITCH + kb * 8);
-        oacc[t] = mfma16<FT>(pf, vf, oacc[t]);
+        mrow[mt][r] = -INFINITY;
+        lrow[mt][r] = 0.f;
       }
     }
-  }
-  // ---- normalise and store: lane holds O[q0 + kb*4 + r][t*16 + ni] ----
+    // keys needed by this query tile: up to the diagonal of its last row
+    const int wg_last_q = min(a.seq_q, (qt + 1) * PF_QROWS) - 1;
+    const int k_end = a.causal ? min(a.seq_k, wg_last_q + shift + 1) : a.seq_k;
+
+    // global -> register prefetch of one K/V tile; written to LDS at the top of the next iteration
+    u32x4_t kreg[2], vreg[2];
+    auto load_tile = [&](int k0) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int qi = q0 + kb * 4 + r;
-    if (qi < a.seq_q) {
-      const float inv = lrow[r] > 0.f ? 1.f / lrow[r] : 0.f;
+      for (int it = 0; it < 2; ++it) {
+        // thread -> keys (2m, 2m + 1) of the tile, dim chunk dc: the pair packs into 32-bit V^T stores
+        const int key = (tid >> 4) * 2 + it, dc = tid & 15;
+        const int kr = min(k0 + key, a.seq_k - 1);
+        const size_t off = (size_t)kr * a.kv_stride + (size_t)kvh * H + dc * 8;
+        kreg[it] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(a.k) + off);
+        vreg[it] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(a.v) + off);
+      }
+    };
+    if (k_end > 0) load_tile(0);
+    for (int k0 = 0; k0 < k_end; k0 += PF_KEYS) {
+      __syncthreads();  // previous tile fully consumed
+      {
+        const int m = tid >> 4, dc = tid & 15;
+        *reinterpret_cast<u32x4_t*>(ks + (2 * m) * PF_KPITCH + dc * 8) = kreg[0];
+        *reinterpret_cast<u32x4_t*>(ks + (2 * m + 1) * PF_KPITCH + dc * 8) = kreg[1];
+        // V^T[d][2m, 2m+1] as one dword per dim; the dim order is rotated by the lane's chunk index so
+        // that the 16 lanes of a row hit different banks (rows 8 apart would otherwise share two banks)
+        uint32_t* vt32 = reinterpret_cast<uint32_t*>(vt);
 #pragma unroll
-      for (int t = 0; t < 8; ++t)
-        store_ft<FT>(a.out, (size_t)qi * a.n_heads * H + (size_t)head * H + t * 16 + ni, oacc[t][r] * inv);
+        for (int j = 0; j < 8; ++j) {
+          const int jj = (j + dc) & 7;
+          const uint32_t lo = (vreg[0][jj >> 1] >> ((jj & 1) * 16)) & 0xFFFFu;
+          const uint32_t hi = (vreg[1][jj >> 1] >> ((jj & 1) * 16)) & 0xFFFFu;
+          vt32[((dc * 8 + jj) * PF_VPITCH) / 2 + m] = lo | (hi << 16);
+        }
+      }
+      __syncthreads();
+      if (k0 + PF_KEYS < k_end) load_tile(k0 + PF_KEYS);
+      const bool wave_live = !a.causal || k0 <= q0 + 16 * MT - 1 + shift;  // some key of the tile is visible to this wave
+      if (wave_live && q0 < a.seq_q) {
+        // ---- S = alpha * Q.K^T: the B fragments of a key tile feed all MT query tiles ----
+        f32x4_t sacc[MT][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) sacc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          const uint16_t* kp = ks + (nt * 16 + ni) * PF_KPITCH + kb * 8;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const u32x4_t bf = *reinterpret_cast<const u32x4_t*>(kp + s * 32);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) sacc[mt][nt] = mfma16<FT>(qf[mt][s], bf, sacc[mt][nt]);
+          }
+        }
+        // ---- mask + online softmax: lane holds S[q = q0 + mt*16 + kb*4 + r][key = k0 + nt*16 + ni] ----
+        u32x4_t pf[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          float p[2][4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qi = q0 + mt * 16 + kb * 4 + r;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              const int key = k0 + nt * 16 + ni;
+              const bool vis = key < a.seq_k && (!a.causal || key <= qi + shift);
+              const float sv = vis ? sacc[mt][nt][r] * a.alpha : -INFINITY;
+              p[nt][r] = sv;
+              mx = fmaxf(mx, sv);
+            }
+            mx = row16_max_pf(mx);
+            const float mn = fmaxf(mrow[mt][r], mx);
+            const float corr = mrow[mt][r] == -INFINITY ? 0.f : __expf(mrow[mt][r] - mn);
+            float psum = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              const float e = p[nt][r] == -INFINITY ? 0.f : __expf(p[nt][r] - mn);
+              const float er = ft_round<FT>(e);  // P is fed to the matrix core in FT
+              p[nt][r] = er;
+              psum += er;
+            }
+            psum = row16_sum_pf(psum);
+            lrow[mt][r] = lrow[mt][r] * corr + psum;
+            mrow[mt][r] = mn;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) oacc[mt][t][r] *= corr;
+          }
+          // ---- P: C layout -> A layout through the wave's LDS patch [q row][32 keys] ----
+          uint16_t* pm = pw + mt * 16 * PF_VPITCH;
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pm[(kb * 4 + r) * PF_VPITCH + nt * 16 + ni] = (uint16_t)f32_to_ft_bits<FT>(p[nt][r]);
+          // same wave writes and reads: LDS ops of one wave complete in order
+          pf[mt] = *reinterpret_cast<const u32x4_t*>(pm + ni * PF_VPITCH + kb * 8);
+        }
+        // ---- O += P.V: B fragment of dim tile t = V^T[t*16 + ni][kb*8 .. +8], shared by the MT query tiles ----
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const u32x4_t vf = *reinterpret_cast<const u32x4_t*>(vt + (t * 16 + ni) * PF_VPITCH + kb * 8);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) oacc[mt][t] = mfma16<FT>(pf[mt], vf, oacc[mt][t]);
+        }
+      }
     }
+    // ---- normalise and store: lane holds O[q0 + mt*16 + kb*4 + r][t*16 + ni] ----
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = q0 + mt * 16 + kb * 4 + r;
+        if (qi < a.seq_q) {
+          const float inv = lrow[mt][r] > 0.f ? 1.f / lrow[mt][r] : 0.f;
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            store_ft<FT>(a.out, (size_t)qi * a.n_heads * H + (size_t)head * H + t * 16 + ni, oacc[mt][t][r] * inv);
+        }
+      }
+    __syncthreads();  // the next pass restages the LDS tiles
   }
 }
 
@@ -198,8 +238,10 @@ extern "C" int dihip_prefill_attn(void* stream, void* out, const void* q, const 
   DIHIP_REQUIRE(q_stride % 8 == 0 && kv_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(q) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(k) & 15) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0,
                 DIHIP_PARAM_ERROR, "prefill_attn: rows must be 16-byte aligned");
-  PrefillArgs a{out, q, k, v, seq_q, seq_k, q_stride, kv_stride, n_heads, n_groups, causal, alpha};
-  const dim3 grid((seq_q + PF_QROWS - 1) / PF_QROWS, n_heads);
+  const int nqt = (seq_q + PF_QROWS - 1) / PF_QROWS;
+  const int pair = causal && nqt >= 8;  // short sequences need every query tile as its own workgroup
+  PrefillArgs a{out, q, k, v, seq_q, seq_k, q_stride, kv_stride, n_heads, n_groups, causal, alpha, pair};
+  const dim3 grid(pair ? (nqt + 1) / 2 : nqt, n_heads);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == DIHIP_BF16) hipLaunchKernelGGL(prefill_attn_kernel<DIHIP_BF16>, grid, dim3(PF_THREADS), 0, s, a);
   else hipLaunchKernelGGL(prefill_attn_kernel<DIHIP_F16>, grid, dim3(PF_THREADS), 0, s, a);
