@@ -169,6 +169,15 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
   auto issue_batch = [&](int r, int v0) {
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
+      // sub-batches entirely beyond the row are skipped (wave-uniform); a partial one is clamped
+      if (j > 0 && v0 + j * GEMV_THREADS >= nvec) {
+        ev[PRO == PRO_RMSNORM ? 2 * j : j] = u32x4_t{0u, 0u, 0u, 0u};
+        if constexpr (PRO == PRO_RMSNORM) {
+          ev[2 * j + 1] = u32x4_t{0u, 0u, 0u, 0u};
+          eg[j] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+        continue;
+      }
       const uint32_t i = (uint32_t)min(v0 + j * GEMV_THREADS + tid, nvec - 1);
       if constexpr (PRO == PRO_RMSNORM) {
         const float* hrow = reinterpret_cast<const float*>(a.x) + (size_t)r * a.ldx;

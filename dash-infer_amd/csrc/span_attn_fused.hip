@@ -352,7 +352,7 @@ __global__ __launch_bounds__(128) void span_attn_merge_kernel(void* out, const f
   const int ns = min(nsplits, (len + tps - 1) / tps);
   const float* base = partials + (size_t)bh * nsplits * ATTN_PSTRIDE;
   float mm = -INFINITY, ll = 0.f, oo = 0.f;
-  constexpr int MB = 40;  // splits per batch: all loads of a batch are in flight together
+  constexpr int MB = 72;  // splits per batch: all loads of a batch are in flight together
   for (int sb = 0; sb < ns; sb += MB) {
     float mv[MB], lv[MB], ov[MB];
 #pragma unroll
@@ -412,7 +412,7 @@ static FusedPlan fused_plan(int batch, int n_heads, int n_groups, int max_seq_le
   static int min_tps = -1;  // at least this many tokens per split: every extra split costs merge work
   if (min_tps < 0) {
     const char* e = getenv("DIHIP_ATTN_MIN_TPS");
-    min_tps = e ? atoi(e) : 64;
+    min_tps = e ? atoi(e) : 32;
     if (min_tps < FUSED_TOK_PER_ITER) min_tps = FUSED_TOK_PER_ITER;
   }
   const long max_splits = std::max(1, (max_seq_len + min_tps - 1) / min_tps);

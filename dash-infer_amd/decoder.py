@@ -293,11 +293,6 @@ class DecodeSession:
         self.pairs_all = torch.empty(nr * batch * 8, dtype=torch.uint8, device=device)
         self.scale = 1.0 / (H ** 0.5)
         self.graph = None
-        # Infinity Cache prefetch of the next weights on a side stream while attention (latency bound at
-        # small batch, HBM idle) runs.  DIHIP_PREFETCH=0 disables; value = workgroups of the prefetch kernel.
-        import os
-        self.prefetch_wgs = int(os.environ.get("DIHIP_PREFETCH", "0"))
-        self.side = torch.cuda.Stream() if self.prefetch_wgs > 0 else None
 
     # -- state ---------------------------------------------------------------------------
     def set_state(self, ids, lens):
@@ -329,19 +324,8 @@ class DecodeSession:
         m, cfg, sc = self.model, self.model.cfg, self.scratch
         ops.embedding(self.ids, m.embed, out=self.h)
         tp_on = self.comm is not None and m.nranks > 1
-        main = torch.cuda.current_stream()
         for li, lw in enumerate(m.layers):
             ops.fused_norm_gemm(self.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sc, out=self.qkv)
-            if self.side is not None:
-                # fork: the rest of this layer's weights (+ the next layer's qkv) stream into the Infinity
-                # Cache while attention runs; joined before the next fork so one sweep is in flight at most
-                nxt = m.layers[li + 1].qkv if li + 1 < len(m.layers) else None
-                self.side.wait_stream(main)
-                with torch.cuda.stream(self.side):
-                    ops.prefetch([lw.o.w, lw.o.sz, lw.gate.w, lw.gate.sz, lw.up.w, lw.up.sz, lw.down.w, lw.down.sz],
-                                 workgroups=self.prefetch_wgs)
-                    if nxt is not None:
-                        ops.prefetch([nxt.w, nxt.sz], workgroups=self.prefetch_wgs)
             if self.fused_attention:
                 ops.span_attn_decode_fused(self.qkv, self.kv[li], self.old_lens, self.rope_tab, self.n_loc, self.g_loc, self.H,
                                            self.max_len, self.scale, self.attn_ws, out=self.attn)
@@ -352,8 +336,6 @@ class DecodeSession:
             self._proj_residual(self.attn, lw.o, tp_on)
             ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act)
             self._proj_residual(self.act, lw.down, tp_on)
-            if self.side is not None:
-                main.wait_stream(self.side)
         ops.lm_head(self.h, m.final_norm, cfg.eps, m.lm_head, sc, out=self.logits)
         if tp_on:
             check(lib().dihip_argmax_partial(ops.cur_stream(), ops.ptr(self.pair), ops.ptr(self.logits), self.B,
