@@ -153,6 +153,11 @@ int dihost_set_runtime(dihost_model_t m, int is_context, int n_requests, const i
   }
   return 0;
 }
+int dihost_set_prefix_len(dihost_model_t m, int request, int prefix_len) {
+  if (request < 0 || request >= (int)m->rt.gen_ctx_list.size()) return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  m->rt.gen_ctx_list[request]->prefix_len = prefix_len;
+  return 0;
+}
 static AsOperator* get_op(dihost_model_t m, int id) { return id >= 0 && id < (int)m->ops.size() ? m->ops[id].get() : nullptr; }
 int dihost_op_reshape(dihost_model_t m, int id) {
   AsOperator* op = get_op(m, id);

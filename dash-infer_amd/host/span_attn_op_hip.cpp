@@ -132,8 +132,8 @@ class SpanAttnOpHIP : public AsOperator {
 
   AsStatus runContext(RuntimeContext* rt) {
     const GenerateContext* gc = rt->GetContextGenCtx();
-    if (gc->prefix_len != 0) return AsStatus::ALLSPARK_INVALID_CALL_ERROR;  // prefix-cache path: SURVEY 8(f) rank 2
     const int stride = (n_ + 2 * g_) * h_;
+    if (gc->prefix_len != 0) return runContextWithPrefix(gc, stride);
     const char* qkv = reinterpret_cast<const char*>(tensor_map_->at(in_names_[0])->GetDataPtr());
     const size_t es = SizeofType(dtype_);
     const void* q = qkv;
@@ -151,6 +151,45 @@ class SpanAttnOpHIP : public AsOperator {
                                            h_, span_, kv_mode_, DihipDtype(dtype_)));
   }
 
+  // Prefill over a cached prefix (span_attn_op_cuda.cpp:205-241 copyPrefixSpanToCtxMem, :134-148 UpdateKV,
+  // :489-502 MIX format): the prefix is gathered (dequantised) from its spans into the contiguous
+  // context workspaces, this step's K/V rows are appended behind it, attention runs with
+  // seq_k = prefix + seq over contiguous K/V, and the new rows are written into the spans.
+  AsStatus runContextWithPrefix(const GenerateContext* gc, int stride) {
+    const int prefix = gc->prefix_len;
+    if (prefix % span_ != 0) return AsStatus::ALLSPARK_PARAM_ERROR;  // the prefix cache works in whole spans
+    const int total = prefix + seq_;
+    const size_t es = SizeofType(dtype_), row = (size_t)g_ * h_ * es;
+    auto grow = [&](std::unique_ptr<AsTensor>& t, const char* nm) {
+      if (!t) t = std::make_unique<AsTensor>(op_name_ + nm, DeviceType::HIP, dtype_, Shape{(int64_t)total, (int64_t)g_ * h_});
+      return t->SetShape(Shape{(int64_t)total, (int64_t)g_ * h_});
+    };
+    AS_CHECK_STATUS(grow(ctx_k_, ".context_k_workspace"));
+    AS_CHECK_STATUS(grow(ctx_v_, ".context_v_workspace"));
+    reinterpret_cast<int32_t*>(lens_host_->GetDataPtr())[0] = prefix;
+    reinterpret_cast<int32_t*>(lens_host_->GetDataPtr())[1] = total;
+    AS_CHECK_STATUS(stageSpans(gc, 0, total));
+    AS_CHECK_STATUS(uploadSpans(1));
+    void* const* kd = reinterpret_cast<void* const*>(k_arr_dev_->GetDataPtr());
+    void* const* vd = reinterpret_cast<void* const*>(v_arr_dev_->GetDataPtr());
+    AS_CHECK_STATUS(FromDihip(dihip_kv_prefix_gather(Stream(), ctx_k_->GetDataPtr(), kd, prefix, g_, h_, span_, kv_mode_, DihipDtype(dtype_))));
+    AS_CHECK_STATUS(FromDihip(dihip_kv_prefix_gather(Stream(), ctx_v_->GetDataPtr(), vd, prefix, g_, h_, span_, kv_mode_, DihipDtype(dtype_))));
+    const char* qkv = reinterpret_cast<const char*>(tensor_map_->at(in_names_[0])->GetDataPtr());
+    const void* k = qkv + (size_t)n_ * h_ * es;
+    const void* v = qkv + (size_t)(n_ + g_) * h_ * es;
+    char* kc = reinterpret_cast<char*>(ctx_k_->GetDataPtr()) + (size_t)prefix * row;
+    char* vc = reinterpret_cast<char*>(ctx_v_->GetDataPtr()) + (size_t)prefix * row;
+    if (hipMemcpy2DAsync(kc, row, k, (size_t)stride * es, row, seq_, hipMemcpyDeviceToDevice, Stream()) != hipSuccess ||
+        hipMemcpy2DAsync(vc, row, v, (size_t)stride * es, row, seq_, hipMemcpyDeviceToDevice, Stream()) != hipSuccess)
+      return AsStatus::ALLSPARK_RUNTIME_ERROR;
+    AS_CHECK_STATUS(FromDihip(dihip_prefill_attn(Stream(), tensor_map_->at(out_names_[0])->GetDataPtr(), qkv, ctx_k_->GetDataPtr(),
+                                                 ctx_v_->GetDataPtr(), seq_, total, stride, g_ * h_, n_, g_, h_, 1, alpha_,
+                                                 DihipDtype(dtype_))));
+    AS_CHECK_STATUS(FromDihip(dihip_kv_context_copy(Stream(), kd, k, stride, seq_, prefix, g_, h_, span_, kv_mode_, DihipDtype(dtype_))));
+    return FromDihip(dihip_kv_context_copy(Stream(), vd, v, stride, seq_, prefix, g_, h_, span_, kv_mode_, DihipDtype(dtype_)));
+  }
+
+  std::unique_ptr<AsTensor> ctx_k_, ctx_v_;
   int layer_num_ = -1, n_ = 0, g_ = 0, h_ = 0, span_ = 0, kv_mode_ = 0, batch_ = 0, seq_ = 0, max_spans_ = 0;
   float alpha_ = -1.f;
   DataType dtype_ = BFLOAT16;

@@ -18,6 +18,7 @@ _SIGS = {
     "dihost_get_tensor": (i32, [vp, C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_int64), C.POINTER(vp)]),
     "dihost_op_create": (i32, [vp, C.POINTER(i32), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
     "dihost_set_runtime": (i32, [vp, i32, i32, C.POINTER(i32), i32, i32, C.POINTER(vp), C.POINTER(vp)]),
+    "dihost_set_prefix_len": (i32, [vp, i32, i32]),
     "dihost_op_reshape": (i32, [vp, i32]),
     "dihost_op_alloc": (i32, [vp, i32]),
     "dihost_op_forward": (i32, [vp, i32]),
@@ -102,6 +103,9 @@ class Model:
         flat = lambda a: (vp * (nreq * nl * spr))(*[p for r in a for l in r for p in l])
         _ck(lib().dihost_set_runtime(self.h, int(is_context), nreq, (i32 * max(nreq, 1))(*steps), nl, spr, flat(k_spans), flat(v_spans)),
             "set_runtime")
+
+    def set_prefix_len(self, request, prefix_len):
+        _ck(lib().dihost_set_prefix_len(self.h, request, prefix_len), "set_prefix_len")
 
     def reshape(self, op):
         _ck(lib().dihost_op_reshape(self.h, op), "CallReshape")

@@ -33,6 +33,8 @@ int dihost_op_create(dihost_model_t m, int* op_id, const char* op_type, const ch
  * k_spans / v_spans: host arrays [n_requests][n_layers][spans_per_req] of device pointers */
 int dihost_set_runtime(dihost_model_t m, int is_context, int n_requests, const int* steps, int n_layers, int spans_per_req,
                        void* const* k_spans, void* const* v_spans);
+/* prefix-cache hit of the request being prefilled: tokens already present in its first spans */
+int dihost_set_prefix_len(dihost_model_t m, int request, int prefix_len);
 int dihost_op_reshape(dihost_model_t m, int op_id);
 int dihost_op_alloc(dihost_model_t m, int op_id);
 int dihost_op_forward(dihost_model_t m, int op_id);
