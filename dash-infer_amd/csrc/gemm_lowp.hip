@@ -7,6 +7,7 @@
 
 #include "gemm_lowp_launch.hpp"
 #include "gemv_stream_kernel.hpp"
+#include "gemv_batch_kernel.hpp"
 
 namespace dihip {
 
@@ -371,6 +372,46 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
                     c.wbits, gp.MR, c.pro, c.epi, hipGetErrorString(e));
       return DIHIP_SUCCESS;
     }
+  }
+  // small decode batches whose activations do not fit in LDS: register-resident A (gemv_batch_kernel.hpp)
+  if (c.dtype == DIHIP_BF16 && gemv_stream_enabled() && gemv_aligned && c.pro == PRO_PLAIN && c.M > 1 && c.M <= 32 &&
+      c.wbits != 16 && (d.group == 0 || d.group % d.KTILE == 0)) {
+    GembArgs g{};
+    g.w0 = reinterpret_cast<const u32x4_t*>(c.w0);
+    g.w1 = reinterpret_cast<const u32x4_t*>(c.w1);
+    g.sz0 = reinterpret_cast<const uint32_t*>(c.sz0);
+    g.sz1 = reinterpret_cast<const uint32_t*>(c.sz1);
+    g.x = c.x;
+    g.ldx = c.ldx;
+    g.bias = c.bias;
+    g.residual = c.residual;
+    g.y = c.y;
+    g.ldy = c.N;
+    g.h_res = c.h_res;
+    g.h_out = c.h_out;
+    g.alpha = c.alpha;
+    g.act = c.act;
+    g.M = c.M;
+    g.N = c.N;
+    g.K = c.K;
+    g.KT = d.KT;
+    g.NTILES = d.NTILES;
+    g.Gp = lowp_dims(4, c.N, c.K, c.group_size).Gp;
+    g.ktpg = d.group ? d.group / d.KTILE : (1 << 28);
+    g.kgroups = d.group ? (d.KT + g.ktpg - 1) / g.ktpg : d.KT;
+    const bool gpt = c.wbits != 16 && g.ktpg == 1;
+    const int mt = c.M > 16 ? 2 : 1;
+    hipError_t e = hipErrorInvalidValue;
+#define GEMB_GO(W_, MT_, EPI_, G_) \
+    if (c.wbits == W_ && mt == MT_ && c.epi == EPI_ && (int)gpt == G_) e = launch_gemv_batch<W_, DIHIP_BF16, MT_, EPI_, G_>(g, d.NTILES, stream);
+#define GEMB_ALL(W_, G_) GEMB_GO(W_, 1, EPI_STD, G_) GEMB_GO(W_, 2, EPI_STD, G_) GEMB_GO(W_, 1, EPI_SWIGLU, G_) GEMB_GO(W_, 2, EPI_SWIGLU, G_) \
+    GEMB_GO(W_, 1, EPI_ADDTO, G_) GEMB_GO(W_, 2, EPI_ADDTO, G_)
+    GEMB_ALL(4, 0) GEMB_ALL(4, 1) GEMB_ALL(8, 0) GEMB_ALL(8, 1)
+#undef GEMB_ALL
+#undef GEMB_GO
+    DIHIP_REQUIRE(e == hipSuccess, DIHIP_RUNTIME_ERROR, "gemv_batch: launch failed (wbits=%d M=%d epi=%d): %s", c.wbits, c.M, c.epi,
+                  hipGetErrorString(e));
+    return DIHIP_SUCCESS;
   }
   const GemmPlan p = make_plan(c.wbits, c.M, c.N, c.K, c.group_size, dual);
   DIHIP_REQUIRE((size_t)p.col_blocks * p.m_blocks * sizeof(unsigned) <= GEMM_SYNC_BYTES, DIHIP_EXCEED_LIMIT_ERROR,

@@ -303,3 +303,52 @@ def test_lm_head_and_argmax(ops):
     t[0, 400] = t[0, 7] = 5.0
     t[1, 999] = 1.0
     assert ops.argmax(t).tolist() == [7, 999]
+
+
+# ------------------------------------------------------------------ batched decode shapes ----
+CFG4_RANK = {"qkv": (8192, 1280), "o": (1024, 8192), "gate": (8192, 3712), "down": (3712, 8192)}  # Qwen2-72B, TP = 8
+
+
+@pytest.mark.parametrize("layer", list(CFG4_RANK))
+def test_config4_rank_shapes_m16_vs_c_oracle(ops, layer):
+    """BASELINE configs[3]: Qwen2-72B int4 g128, TP = 8, batch 16 -- per-rank linear layers (the activations
+    do not fit in LDS: small-batch register-resident kernel)."""
+    K, N = CFG4_RANK[layer]
+    rng = np.random.default_rng(N)
+    x, q, s, z = make_case(rng, 16, N, K, 128, 4, "bf16")
+    ref = cbind.gemm_a16wx(x, q, s, z, 128, 4, ft="bf16")
+    pw = ops.pack_lowp(to_dev(q), to_dev(s, "bf16"), to_dev(z, "bf16"), 128, 4)
+    y = ops.gemm_lowp(to_dev(x, "bf16"), pw)
+    assert_close(y.float().cpu().numpy(), ref, "bf16", what=f"cfg4 {layer}")
+
+
+@pytest.mark.parametrize("wbits,G", [(4, 128), (8, -1), (8, 128), (4, 256)])
+@pytest.mark.parametrize("M", [2, 17, 32])
+def test_small_batch_kernel_all_epilogues(ops, wbits, G, M):
+    """configs[2] regime (batch 32) and odd batch sizes through every fused form at a K that does not fit LDS."""
+    rng = np.random.default_rng(M * 10 + wbits)
+    K, N = 4096, 272
+    x, q, s, z = make_case(rng, M, N, K, G, wbits, "bf16")
+    _, q2, s2, z2 = make_case(rng, 1, N, K, G, wbits, "bf16")
+    pw = ops.pack_lowp(to_dev(q), to_dev(s, "bf16"), to_dev(z, "bf16"), G, wbits)
+    pw2 = ops.pack_lowp(to_dev(q2), to_dev(s2, "bf16"), to_dev(z2, "bf16"), G, wbits)
+    bias = bf16_round(rng.normal(0, 0.5, N).astype(np.float32))
+    xd = to_dev(x, "bf16")
+    y = ops.gemm_lowp(xd, pw, bias=to_dev(bias, "bf16"), act="silu", alpha=0.5)
+    ref = gemm_ref.gemm_a16wx(x, q, s, z, G, wbits, alpha=0.5, bias=bias, act="silu", ft="bf16")
+    assert_close(y.float().cpu().numpy(), ref, "bf16", what="std")
+    sc = ops.Scratch(ops.lowp_workspace_bytes(wbits, M, N, K, G))
+    h = rng.normal(0, 1, (M, N)).astype(np.float32)
+    hd = torch.from_numpy(h).cuda()
+    out = ops.fused_gemm_addto(xd, pw, hd, sc)
+    ref2 = h + gemm_ref.gemm_a16wx(x, q, s, z, G, wbits, ft="f32")
+    np.testing.assert_allclose(out.cpu().numpy(), ref2, rtol=2e-3, atol=2e-3 * np.abs(ref2).max())
+    # SwiGLU over a (gate, up) pair from the f32 hidden stream (M > 4: norm runs as its own launch)
+    hk = rng.normal(0, 1.5, (M, K)).astype(np.float32)
+    gamma = bf16_round(rng.normal(1, 0.1, K).astype(np.float32))
+    act = ops.fused_norm_swiglu(torch.from_numpy(hk).cuda(), to_dev(gamma, "bf16"), 1e-6, pw, pw2, sc)
+    xn = bf16_round(glue.rmsnorm(hk, gamma, 1e-6))
+    g_ = gemm_ref.gemm_a16wx(xn, q, s, z, G, wbits, ft="f32")
+    u_ = gemm_ref.gemm_a16wx(xn, q2, s2, z2, G, wbits, ft="f32")
+    ref3 = bf16_round(glue.silu(g_) * u_)
+    assert_close(act.float().cpu().numpy(), ref3, "bf16", what="swiglu", pre=ref3)
