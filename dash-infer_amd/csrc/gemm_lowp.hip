@@ -248,15 +248,21 @@ static GemvPlan make_gemv_plan(int wbits, int M, int N, int K, int group_size, b
   int num_cus = cached_num_cus();
   if (num_cus <= 0) num_cus = 256;
   const int units = d.NTILES;
-  // one workgroup per CU when there are enough column tiles; below ~1.5 waves of CUs the launch
-  // is latency bound and one tile per workgroup spreads the loads widest
-  p.upb = units <= num_cus + num_cus / 2 ? 1 : (units + num_cus - 1) / num_cus;
+  // never more workgroups than CUs (a second round starts ~2 us late, measured on the qkv shape):
+  // one tile per workgroup up to the CU count, ceil(tiles / CUs) beyond
+  p.upb = units <= num_cus ? 1 : (units + num_cus - 1) / num_cus;
   static int upb_override = -1;  // experiments: DIHIP_GEMV_UPB=<units per workgroup> for the multi-unit shapes
   if (upb_override < 0) {
     const char* e = getenv("DIHIP_GEMV_UPB");
     upb_override = e ? atoi(e) : 0;
   }
   if (upb_override > 0 && p.upb > 1) p.upb = upb_override;
+  static int upb_small = -1;  // experiments: DIHIP_GEMV_UPB_SMALL=<units per workgroup> for shapes with units in (CUs, 1.5 CUs]
+  if (upb_small < 0) {
+    const char* e = getenv("DIHIP_GEMV_UPB_SMALL");
+    upb_small = e ? atoi(e) : 0;
+  }
+  if (upb_small > 0 && p.upb == 1 && units > num_cus) p.upb = upb_small;
   p.blocks = (units + p.upb - 1) / p.upb;
   const int nv = p.upb * (dual ? 2 : 1);
   const int kgroups = d.group ? (d.KT + p.ktpg - 1) / p.ktpg : d.KT;
@@ -309,6 +315,16 @@ static hipError_t dispatch_gemv(const GemvPlan& p, int pro, int epi, const GemvA
   return hipErrorInvalidValue;
 }
 
+// f16 activations: the op-boundary form only (PRO_PLAIN / EPI_STD); the fused decode-step forms are bf16
+template <int WBITS>
+static hipError_t dispatch_gemv_f16(const GemvPlan& p, const GemvArgs& a, hipStream_t s) {
+  const bool gpt = p.ktpg == 1;
+  if (p.MR == 1) return gpt ? launch_gemv_stream<WBITS, DIHIP_F16, 1, PRO_PLAIN, EPI_STD, 1>(a, p.blocks, p.lds_bytes, s)
+                            : launch_gemv_stream<WBITS, DIHIP_F16, 1, PRO_PLAIN, EPI_STD, 0>(a, p.blocks, p.lds_bytes, s);
+  return gpt ? launch_gemv_stream<WBITS, DIHIP_F16, 4, PRO_PLAIN, EPI_STD, 1>(a, p.blocks, p.lds_bytes, s)
+             : launch_gemv_stream<WBITS, DIHIP_F16, 4, PRO_PLAIN, EPI_STD, 0>(a, p.blocks, p.lds_bytes, s);
+}
+
 static int g_force_general = -1;  // DIHIP_GEMV_STREAM=0 routes everything to the general kernel
 static bool gemv_stream_enabled() {
   if (g_force_general < 0) {
@@ -331,7 +347,8 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
   const LowpDims d = lowp_dims(c.wbits, c.N, c.K, c.group_size);
   const bool gemv_aligned = (c.K == d.Kp) && (c.ldx % 8 == 0) && (reinterpret_cast<uintptr_t>(c.x) % 16 == 0) &&
                             (c.pro == PRO_PLAIN || reinterpret_cast<uintptr_t>(c.gamma) % 16 == 0);
-  if (c.dtype == DIHIP_BF16 && gemv_stream_enabled() && gemv_aligned) {
+  const bool f16_std = c.dtype == DIHIP_F16 && c.pro == PRO_PLAIN && c.epi == EPI_STD && c.wbits != 16;
+  if ((c.dtype == DIHIP_BF16 || f16_std) && gemv_stream_enabled() && gemv_aligned) {
     const GemvPlan gp = make_gemv_plan(c.wbits, c.M, c.N, c.K, c.group_size, dual);
     if (gp.ok) {
       GemvArgs g{};
@@ -365,7 +382,8 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
       g.RS = gp.RS;
       g.trace = debug_trace_buffer((size_t)gp.blocks * GEMV_WAVES * 64);
       hipError_t e = hipErrorInvalidValue;
-      if (c.wbits == 4) e = dispatch_gemv<4, DIHIP_BF16>(gp, c.pro, c.epi, g, stream);
+      if (f16_std) e = c.wbits == 4 ? dispatch_gemv_f16<4>(gp, g, stream) : dispatch_gemv_f16<8>(gp, g, stream);
+      else if (c.wbits == 4) e = dispatch_gemv<4, DIHIP_BF16>(gp, c.pro, c.epi, g, stream);
       else if (c.wbits == 8) e = dispatch_gemv<8, DIHIP_BF16>(gp, c.pro, c.epi, g, stream);
       else if (c.wbits == 16) e = dispatch_gemv<16, DIHIP_BF16>(gp, c.pro, c.epi, g, stream);
       DIHIP_REQUIRE(e == hipSuccess, DIHIP_RUNTIME_ERROR, "gemv_stream: launch failed (wbits=%d MR=%d pro=%d epi=%d): %s",

@@ -173,7 +173,24 @@ __global__ __launch_bounds__(64 * FUSED_MAX_WAVES) void span_attn_fused_kernel(c
   const int len = newpos + 1;
   const int t0 = split * a.tps;
   const int t1 = min(len, t0 + a.tps);
-  if (t0 >= t1) return;  // the merge kernel derives the number of live splits from the length
+  if (t0 >= t1) {
+    // dead split (beyond the sequence): leave neutral partials so that the merge kernel needs no length
+    if (nh > 0 && tl == 0) {
+#pragma unroll
+      for (int h = 0; h < HC; ++h) {
+        if (h < nh) {
+          float* rec = a.partials + (((size_t)b * a.n + h0 + h) * a.nsplits + split) * ATTN_PSTRIDE;
+          *reinterpret_cast<f32x4_t*>(rec + dc * 8) = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4_t*>(rec + dc * 8 + 4) = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          if (dc == 0) {
+            rec[H] = -INFINITY;
+            rec[H + 1] = 0.f;
+          }
+        }
+      }
+    }
+    return;
+  }
   const bool has_new = newpos >= t0;  // newpos < t1 always; only the last live split holds it
 
   const void* const* ksp = a.kspans + (size_t)b * a.span_stride;
@@ -347,9 +364,11 @@ template <int FT>
 __global__ __launch_bounds__(128) void span_attn_merge_kernel(void* out, const float* partials, const uint32_t* old_lens,
                                                               int n, int nsplits, int tps) {
   constexpr int H = 128;
-  const int bh = blockIdx.x, b = bh / n, d = threadIdx.x;
-  const int len = (int)old_lens[b] + 1;
-  const int ns = min(nsplits, (len + tps - 1) / tps);
+  const int bh = blockIdx.x, d = threadIdx.x;
+  (void)old_lens;
+  (void)n;
+  (void)tps;
+  const int ns = nsplits;  // dead splits hold neutral records (max = -inf, sum = 0, o = 0)
   const float* base = partials + (size_t)bh * nsplits * ATTN_PSTRIDE;
   float mm = -INFINITY, ll = 0.f, oo = 0.f;
   constexpr int MB = 72;  // splits per batch: all loads of a batch are in flight together
@@ -496,7 +515,13 @@ int dihip_span_attn_decode_fused(void* stream, void* output, const void* qkv, vo
   a.scale = qk_scale;
   const dim3 grid(p.nsplits, n_groups, batch);
   a.trace = debug_trace_buffer((size_t)p.nsplits * n_groups * batch * FUSED_MAX_WAVES * 64);
+  static int dbg_phase = -1;  // diagnostics: DIHIP_ATTN_PHASE=1 main kernel only, =2 merge only
+  if (dbg_phase < 0) {
+    const char* e = getenv("DIHIP_ATTN_PHASE");
+    dbg_phase = e ? atoi(e) : 0;
+  }
   bool ok = true;
+  if (dbg_phase != 2) {
 #define GO(FTV, MODEV)                         \
   if (dtype == FTV && kv_mode == MODEV) {      \
     launch_fused<FTV, MODEV>(p, a, grid, s);   \
@@ -508,7 +533,9 @@ int dihip_span_attn_decode_fused(void* stream, void* output, const void* qkv, vo
   GO(DIHIP_F16, DIHIP_KV_I8)
   GO(DIHIP_F16, DIHIP_KV_U4) { ok = false; }
 #undef GO
+  }
   DIHIP_REQUIRE(ok, DIHIP_PARAM_ERROR, "span_attn_decode_fused: unsupported dtype %d / kv mode %d", dtype, kv_mode);
+  if (dbg_phase == 1) return launch_status();
   if (dtype == DIHIP_BF16)
     hipLaunchKernelGGL(span_attn_merge_kernel<DIHIP_BF16>, dim3(batch * n_heads), dim3(128), 0, s, output, a.partials,
                        old_seq_lens_dev, n_heads, p.nsplits, p.tps);
