@@ -119,9 +119,11 @@ def kernel_breakdown(sess, torch, ops, iters=5):
     timed("o_gemv_addto", l0.o.nbytes + act_b(l0.o),
           lambda li, lw: ops.fused_gemm_addto(sess.attn, lw.o, sess.h, sc, out=sess.partial))
     timed("gate_up_swiglu", l0.gate.nbytes + l0.up.nbytes + B * l0.gate.K * 4 + B * l0.gate.N * 2,
-          lambda li, lw: ops.fused_norm_swiglu(sess.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=sess.act))
+          lambda li, lw: ops.fused_norm_swiglu(sess.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=sess.act,
+                                               y_layout=ops.ACT_FRAG32 if sess.act_frag else ops.ACT_ROWMAJOR))
     timed("down_gemv_addto", l0.down.nbytes + act_b(l0.down),
-          lambda li, lw: ops.fused_gemm_addto(sess.act, lw.down, sess.h, sc, out=sess.partial))
+          lambda li, lw: ops.fused_gemm_addto(sess.act, lw.down, sess.h, sc, out=sess.partial, M=B,
+                                              x_layout=ops.ACT_FRAG32 if sess.act_frag else ops.ACT_ROWMAJOR))
     timed("lm_head", m.lm_head.nbytes,
           lambda li, lw: ops.lm_head(sess.h, m.final_norm, cfg.eps, m.lm_head, sc, out=sess.logits), layers=[None] * 4)
     return res

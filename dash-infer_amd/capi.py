@@ -32,6 +32,12 @@ _SIGS = {
     "dihip_fused_norm_gemm": (i32, [vp, i32, vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp, i32]),
     "dihip_fused_norm_swiglu": (i32, [vp, i32, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, i32]),
     "dihip_fused_gemm_addto": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, i32]),
+    "dihip_fused_norm_swiglu_ex": (i32, [vp, i32, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, i32, i32]),
+    "dihip_fused_gemm_addto_ex": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, i32, i32]),
+    "dihip_gemm_lowp_prefers_frag": (i32, [i32, i32, i32, i32, i32, i32]),
+    "dihip_act_frag_bytes": (sz, [i32, i32]),
+    "dihip_act_to_frag": (i32, [vp, vp, vp, i32, i32, i32]),
+    "dihip_act_from_frag": (i32, [vp, vp, vp, i32, i32, i32]),
     "dihip_span_bytes": (sz, [i32, i32, i32, i32, i32]),
     "dihip_kv_append": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32]),
     "dihip_rope_kv_append": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32]),

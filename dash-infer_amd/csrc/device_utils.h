@@ -92,6 +92,19 @@ __device__ __forceinline__ void store_ft(void* p, size_t i, float v) {
   else ((uint16_t*)p)[i] = (uint16_t)f32_to_ft_bits<FT>(v);
 }
 
+// Load through a pointer that was itself read from memory (span tables): hipcc cannot tell its address space
+// and emits FLAT loads, which count on vmcnt AND lgkmcnt and may return out of order -- every wait on one
+// becomes s_waitcnt vmcnt(0) lgkmcnt(0) and drains all prefetches.  The explicit global address space turns
+// them into global_load with exact in-order vmcnt accounting.
+template <typename T>
+__device__ __forceinline__ T gload(const void* p) {
+  return *(const __attribute__((address_space(1))) T*)(p);
+}
+template <typename T>
+__device__ __forceinline__ void gstore(void* p, const T& v) {
+  *(__attribute__((address_space(1))) T*)(p) = v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -226,6 +226,7 @@ struct GemmCall {
   void* ws;
   size_t ws_bytes;
   void* sync;
+  int x_layout, y_layout;  // DIHIP_ACT_ROWMAJOR / DIHIP_ACT_FRAG32 (small-batch kernel only)
 };
 
 
@@ -348,7 +349,8 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
   const bool gemv_aligned = (c.K == d.Kp) && (c.ldx % 8 == 0) && (reinterpret_cast<uintptr_t>(c.x) % 16 == 0) &&
                             (c.pro == PRO_PLAIN || reinterpret_cast<uintptr_t>(c.gamma) % 16 == 0);
   const bool f16_std = c.dtype == DIHIP_F16 && c.pro == PRO_PLAIN && c.epi == EPI_STD && c.wbits != 16;
-  if ((c.dtype == DIHIP_BF16 || f16_std) && gemv_stream_enabled() && gemv_aligned) {
+  const bool want_frag = c.x_layout == DIHIP_ACT_FRAG32 || c.y_layout == DIHIP_ACT_FRAG32;  // small-batch kernel only
+  if ((c.dtype == DIHIP_BF16 || f16_std) && gemv_stream_enabled() && gemv_aligned && !want_frag) {
     const GemvPlan gp = make_gemv_plan(c.wbits, c.M, c.N, c.K, c.group_size, dual);
     if (gp.ok) {
       GemvArgs g{};
@@ -419,18 +421,38 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
     g.kgroups = d.group ? (d.KT + g.ktpg - 1) / g.ktpg : d.KT;
     const bool gpt = c.wbits != 16 && g.ktpg == 1;
     const int mt = c.M > 16 ? 2 : 1;
+    g.xfrag = c.x_layout == DIHIP_ACT_FRAG32;
+    g.yfrag = c.y_layout == DIHIP_ACT_FRAG32;
+    // at most one workgroup per CU; a workgroup with several units walks them two at a time so that
+    // one pass over the activations (L2 -> registers) feeds two column tiles
+    static int env_upb = -1, env_nt = -1;  // diagnostics: DIHIP_GEMB_UPB / DIHIP_GEMB_NT
+    if (env_upb < 0) {
+      const char* e1 = getenv("DIHIP_GEMB_UPB");
+      const char* e2 = getenv("DIHIP_GEMB_NT");
+      env_upb = e1 ? atoi(e1) : 0;
+      env_nt = e2 ? atoi(e2) : 0;
+    }
+    int ncu = cached_num_cus();
+    if (ncu <= 0) ncu = 256;
+    g.upb = env_upb > 0 ? env_upb : (d.NTILES <= ncu ? 1 : (d.NTILES + ncu - 1) / ncu);
+    const int nt = env_nt > 0 ? std::min(env_nt, 2) : (g.upb >= 2 ? 2 : 1);
+    const int blocks = (d.NTILES + g.upb - 1) / g.upb;
     hipError_t e = hipErrorInvalidValue;
-#define GEMB_GO(W_, MT_, EPI_, G_) \
-    if (c.wbits == W_ && mt == MT_ && c.epi == EPI_ && (int)gpt == G_) e = launch_gemv_batch<W_, DIHIP_BF16, MT_, EPI_, G_>(g, d.NTILES, stream);
-#define GEMB_ALL(W_, G_) GEMB_GO(W_, 1, EPI_STD, G_) GEMB_GO(W_, 2, EPI_STD, G_) GEMB_GO(W_, 1, EPI_SWIGLU, G_) GEMB_GO(W_, 2, EPI_SWIGLU, G_) \
-    GEMB_GO(W_, 1, EPI_ADDTO, G_) GEMB_GO(W_, 2, EPI_ADDTO, G_)
+#define GEMB_GO(W_, MT_, NT_, EPI_, G_) \
+    if (c.wbits == W_ && mt == MT_ && nt == NT_ && c.epi == EPI_ && (int)gpt == G_) \
+      e = launch_gemv_batch<W_, DIHIP_BF16, MT_, NT_, EPI_, G_>(g, blocks, stream);
+#define GEMB_EPIS(W_, MT_, NT_, G_) GEMB_GO(W_, MT_, NT_, EPI_STD, G_) GEMB_GO(W_, MT_, NT_, EPI_SWIGLU, G_) GEMB_GO(W_, MT_, NT_, EPI_ADDTO, G_)
+#define GEMB_ALL(W_, G_) GEMB_EPIS(W_, 1, 1, G_) GEMB_EPIS(W_, 2, 1, G_) GEMB_EPIS(W_, 1, 2, G_) GEMB_EPIS(W_, 2, 2, G_)
     GEMB_ALL(4, 0) GEMB_ALL(4, 1) GEMB_ALL(8, 0) GEMB_ALL(8, 1)
 #undef GEMB_ALL
+#undef GEMB_EPIS
 #undef GEMB_GO
     DIHIP_REQUIRE(e == hipSuccess, DIHIP_RUNTIME_ERROR, "gemv_batch: launch failed (wbits=%d M=%d epi=%d): %s", c.wbits, c.M, c.epi,
                   hipGetErrorString(e));
     return DIHIP_SUCCESS;
   }
+  DIHIP_REQUIRE(!want_frag, DIHIP_PARAM_ERROR,
+                "gemm_lowp: the FRAG32 activation layout needs the small-batch kernel (see dihip_gemm_lowp_prefers_frag)");
   const GemmPlan p = make_plan(c.wbits, c.M, c.N, c.K, c.group_size, dual);
   DIHIP_REQUIRE((size_t)p.col_blocks * p.m_blocks * sizeof(unsigned) <= GEMM_SYNC_BYTES, DIHIP_EXCEED_LIMIT_ERROR,
                 "gemm_lowp: too many tiles for the sync buffer");
@@ -490,10 +512,22 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
   return DIHIP_SUCCESS;
 }
 
-// f32 hidden rows -> FT normalised rows (used by the fused entry points when M > 4)
+// true when a PRO_PLAIN bf16 call of this shape runs on the small-batch kernel (which reads FRAG32 faster)
+static bool batch_kernel_eligible(int wbits, int M, int N, int K, int group_size) {
+  if ((wbits != 4 && wbits != 8) || M <= 1 || M > 32 || N <= 0 || K <= 0) return false;
+  if (!gemv_stream_enabled()) return false;
+  const LowpDims d = lowp_dims(wbits, N, K, group_size);
+  return K == d.Kp && (d.group == 0 || d.group % d.KTILE == 0);
+}
+static bool batch_kernel_shape(int wbits, int M, int N, int K, int group_size, bool dual) {
+  return batch_kernel_eligible(wbits, M, N, K, group_size) && !make_gemv_plan(wbits, M, N, K, group_size, dual).ok;
+}
+
+// f32 hidden rows -> FT normalised rows (used by the fused entry points when M > 4); frag_mt > 0: FRAG32 output
 template <int FT>
 __global__ __launch_bounds__(256) void rmsnorm_f32_to_ft_kernel(uint16_t* __restrict__ y, const float* __restrict__ h,
-                                                                const void* __restrict__ gamma, float eps, int cols) {
+                                                                const void* __restrict__ gamma, float eps, int cols,
+                                                                int frag_mt) {
   __shared__ float red[4];
   const float* hr = h + (size_t)blockIdx.x * cols;
   float ss = 0.f;
@@ -502,8 +536,22 @@ __global__ __launch_bounds__(256) void rmsnorm_f32_to_ft_kernel(uint16_t* __rest
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
   __syncthreads();
   const float rstd = 1.f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)cols + eps);
-  for (int k = threadIdx.x; k < cols; k += 256)
-    y[(size_t)blockIdx.x * cols + k] = (uint16_t)f32_to_ft_bits<FT>((load_ft<FT>(gamma, k) * hr[k]) * rstd);
+  for (int k = threadIdx.x; k < cols; k += 256) {
+    const size_t idx = frag_mt ? act_frag_index((int)blockIdx.x, k, frag_mt) : (size_t)blockIdx.x * cols + k;
+    y[idx] = (uint16_t)f32_to_ft_bits<FT>((load_ft<FT>(gamma, k) * hr[k]) * rstd);
+  }
+}
+
+// row-major [M, K] 16-bit <-> FRAG32 (tests / callers that produce activations outside this library)
+__global__ void act_frag_convert_kernel(uint16_t* __restrict__ dst, const uint16_t* __restrict__ src, int M, int K, int mt,
+                                        int to_frag) {
+  const size_t total = (size_t)M * K;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / K), k = (int)(i - (size_t)m * K);
+    const size_t f = act_frag_index(m, k, mt);
+    if (to_frag) dst[f] = src[i];
+    else dst[i] = src[f];
+  }
 }
 
 }  // namespace dihip
@@ -569,7 +617,7 @@ size_t dihip_gemm_lowp_workspace_bytes(int wbits, int M, int N, int K, int group
   // sized for the dual (SwiGLU) form, the self-contained counter area and the M > 4 norm buffer
   const GemmPlan p1 = make_plan(wbits, M, N, K, group_size, false);
   const GemmPlan p2 = make_plan(wbits, M, N, K, group_size, true);
-  return std::max(p1.slab_bytes, p2.slab_bytes) + GEMM_SYNC_BYTES + (size_t)M * K * 2 + 256;
+  return std::max(p1.slab_bytes, p2.slab_bytes) + GEMM_SYNC_BYTES + (size_t)((M + 15) / 16 * 16) * K * 2 + 256;  // norm rows may be FRAG32
 }
 
 static int gemm_std(void* stream, int wbits, const void* x, const void* w, const void* sz, const void* bias,
@@ -615,15 +663,22 @@ int dihip_gemm_a16w4(void* stream, const void* x, const void* w_packed, const vo
 }
 
 // For M > 4 the norm runs as its own small kernel into the tail of `ws`.
+// The normalised rows are private to the call, so they are written in whatever layout the GEMM kernel that
+// follows reads fastest (*x_layout).
 static int norm_to_ws(hipStream_t s, const float* h, const void* gamma, float eps, int M, int K, int dtype, void* ws,
-                      size_t ws_bytes, int wbits, int N, int group_size, bool dual, void** xnorm, size_t* ws_left) {
+                      size_t ws_bytes, int wbits, int N, int group_size, bool dual, void** xnorm, size_t* ws_left,
+                      int* x_layout, bool force_frag = false) {
   const GemmPlan p = make_plan(wbits, M, N, K, group_size, dual);
   const size_t off = (p.slab_bytes + 255) & ~(size_t)255;
-  DIHIP_REQUIRE(ws && ws_bytes >= off + (size_t)M * K * 2, DIHIP_MEMORY_ERROR, "fused gemm: workspace too small");
+  const bool frag = force_frag || batch_kernel_shape(wbits, M, N, K, group_size, dual);
+  const int mt = M > 16 ? 2 : 1;
+  const size_t xbytes = frag ? (size_t)mt * 16 * K * 2 : (size_t)M * K * 2;
+  DIHIP_REQUIRE(ws && ws_bytes >= off + xbytes, DIHIP_MEMORY_ERROR, "fused gemm: workspace too small");
   *xnorm = reinterpret_cast<char*>(ws) + off;
   *ws_left = off;
+  *x_layout = frag ? DIHIP_ACT_FRAG32 : DIHIP_ACT_ROWMAJOR;
   hipLaunchKernelGGL(rmsnorm_f32_to_ft_kernel<DIHIP_BF16>, dim3(M), dim3(256), 0, s, (uint16_t*)*xnorm, h, gamma, eps,
-                     K);
+                     K, frag ? mt : 0);
   return launch_status();
 }
 
@@ -660,7 +715,7 @@ int dihip_fused_norm_gemm(void* stream, int wbits, const float* h, const void* g
   } else {
     void* xn;
     size_t left;
-    int st = norm_to_ws(s, h, gamma, eps, M, K, dtype, ws, ws_bytes, wbits, N, group_size, false, &xn, &left);
+    int st = norm_to_ws(s, h, gamma, eps, M, K, dtype, ws, ws_bytes, wbits, N, group_size, false, &xn, &left, &c.x_layout);
     if (st) return st;
     c.pro = PRO_PLAIN;
     c.x = xn;
@@ -674,7 +729,18 @@ int dihip_fused_norm_swiglu(void* stream, int wbits, const float* h, const void*
                             const void* wg_packed, const void* szg_packed, const void* wu_packed,
                             const void* szu_packed, void* y, int M, int N, int K, int group_size, void* ws,
                             size_t ws_bytes, void* sync, int dtype) {
+  return dihip_fused_norm_swiglu_ex(stream, wbits, h, gamma, eps, wg_packed, szg_packed, wu_packed, szu_packed, y, M, N, K,
+                                    group_size, ws, ws_bytes, sync, dtype, DIHIP_ACT_ROWMAJOR);
+}
+
+int dihip_fused_norm_swiglu_ex(void* stream, int wbits, const float* h, const void* gamma, float eps,
+                               const void* wg_packed, const void* szg_packed, const void* wu_packed,
+                               const void* szu_packed, void* y, int M, int N, int K, int group_size, void* ws,
+                               size_t ws_bytes, void* sync, int dtype, int y_layout) {
   DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "fused path is bf16 only");
+  DIHIP_REQUIRE(y_layout == DIHIP_ACT_ROWMAJOR || y_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "fused swiglu: bad y_layout");
+  DIHIP_REQUIRE(y_layout == DIHIP_ACT_ROWMAJOR || (M > 4 && batch_kernel_eligible(wbits, M, N, K, group_size)), DIHIP_PARAM_ERROR,
+                "fused swiglu: FRAG32 output needs the small-batch kernel (4 < M <= 32, K a multiple of the k-tile)");
   DIHIP_REQUIRE(sync != nullptr, DIHIP_PARAM_ERROR, "fused path needs a sync buffer");
   if (M == 0) return DIHIP_SUCCESS;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -694,6 +760,7 @@ int dihip_fused_norm_swiglu(void* stream, int wbits, const float* h, const void*
   c.alpha = 1.f;
   c.sync = sync;
   c.ldx = K;
+  c.y_layout = y_layout;
   if (M <= 4) {
     c.pro = PRO_RMSNORM;
     c.x = h;
@@ -704,7 +771,8 @@ int dihip_fused_norm_swiglu(void* stream, int wbits, const float* h, const void*
   } else {
     void* xn;
     size_t left;
-    int st = norm_to_ws(s, h, gamma, eps, M, K, dtype, ws, ws_bytes, wbits, N, group_size, true, &xn, &left);
+    int st = norm_to_ws(s, h, gamma, eps, M, K, dtype, ws, ws_bytes, wbits, N, group_size, true, &xn, &left, &c.x_layout,
+                        y_layout == DIHIP_ACT_FRAG32);
     if (st) return st;
     c.pro = PRO_PLAIN;
     c.x = xn;
@@ -717,7 +785,40 @@ int dihip_fused_norm_swiglu(void* stream, int wbits, const float* h, const void*
 int dihip_fused_gemm_addto(void* stream, int wbits, const void* x, const void* w_packed, const void* sz_packed,
                            const float* h_res, float* h_out, int M, int N, int K, int group_size, void* ws,
                            size_t ws_bytes, void* sync, int dtype) {
+  return dihip_fused_gemm_addto_ex(stream, wbits, x, w_packed, sz_packed, h_res, h_out, M, N, K, group_size, ws, ws_bytes,
+                                   sync, dtype, DIHIP_ACT_ROWMAJOR);
+}
+
+int dihip_gemm_lowp_prefers_frag(int wbits, int M, int N, int K, int group_size, int dual) {
+  return batch_kernel_shape(wbits, M, N, K, group_size, dual != 0) ? 1 : 0;
+}
+
+size_t dihip_act_frag_bytes(int M, int K) {
+  if (M <= 0 || M > 32 || K <= 0 || K % 32) return 0;
+  return (size_t)(M > 16 ? 32 : 16) * K * 2;
+}
+
+static int act_convert(void* stream, const void* src, void* dst, int M, int K, int dtype, int to_frag) {
+  DIHIP_REQUIRE(src && dst && M > 0 && M <= 32 && K > 0 && K % 32 == 0, DIHIP_PARAM_ERROR,
+                "act_frag: need 0 < M <= 32 and K a multiple of 32");
+  DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16, DIHIP_PARAM_ERROR, "act_frag: 16-bit activations only");
+  const size_t total = (size_t)M * K;
+  hipLaunchKernelGGL(act_frag_convert_kernel, dim3((int)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), (uint16_t*)dst, (const uint16_t*)src, M, K, M > 16 ? 2 : 1, to_frag);
+  return launch_status();
+}
+int dihip_act_to_frag(void* stream, const void* x_rowmajor, void* x_frag, int M, int K, int dtype) {
+  return act_convert(stream, x_rowmajor, x_frag, M, K, dtype, 1);
+}
+int dihip_act_from_frag(void* stream, const void* x_frag, void* x_rowmajor, int M, int K, int dtype) {
+  return act_convert(stream, x_frag, x_rowmajor, M, K, dtype, 0);
+}
+
+int dihip_fused_gemm_addto_ex(void* stream, int wbits, const void* x, const void* w_packed, const void* sz_packed,
+                              const float* h_res, float* h_out, int M, int N, int K, int group_size, void* ws,
+                              size_t ws_bytes, void* sync, int dtype, int x_layout) {
   DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "fused path is bf16 only");
+  DIHIP_REQUIRE(x_layout == DIHIP_ACT_ROWMAJOR || x_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "fused addto: bad x_layout");
   // h_res may be NULL: then h_out = x . W (row-parallel TP ranks other than 0, gemm_op.cpp:133-137)
   DIHIP_REQUIRE(sync != nullptr && h_out, DIHIP_PARAM_ERROR, "fused addto: null pointer");
   GemmCall c{};
@@ -727,6 +828,7 @@ int dihip_fused_gemm_addto(void* stream, int wbits, const void* x, const void* w
   c.epi = EPI_ADDTO;
   c.x = x;
   c.ldx = K;
+  c.x_layout = x_layout;
   c.w0 = w_packed;
   c.sz0 = sz_packed;
   c.h_res = h_res;
@@ -824,7 +926,7 @@ int dihip_lm_head(void* stream, float* logits, const float* h, const void* gamma
     DIHIP_REQUIRE(gamma != nullptr && dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "lm_head: needs gamma, bf16");
     void* xn;
     size_t left;
-    int st = norm_to_ws(s, h, gamma, eps, M, K, dtype, ws, ws_bytes, 16, N, -1, false, &xn, &left);
+    int st = norm_to_ws(s, h, gamma, eps, M, K, dtype, ws, ws_bytes, 16, N, -1, false, &xn, &left, &c.x_layout);
     if (st) return st;
     c.pro = PRO_PLAIN;
     c.x = xn;

@@ -191,6 +191,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
   };
   constexpr int EARLY_LOADS = PRO == PRO_RMSNORM ? 3 * NE : NE;
   issue_batch(0, 0);
+  DIHIP_GEMV_STAMP(7);
 
   // ---- this workgroup's units and this wave's share ---------------------------------------
   // units are dealt round-robin: workgroup b owns units b, b + NB, b + 2*NB, ... (SwiGLU: (gate, up) tile

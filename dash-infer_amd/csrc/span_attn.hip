@@ -14,6 +14,7 @@
 //     (request, group) with the agent-scope ticket protocol (device_utils.h) - no extra launch,
 //     no host-side handle / tile-map rebuild per step, sequence lengths are read on the device.
 #include <algorithm>
+#include <cstdlib>
 #include <new>
 #include <type_traits>
 #include <vector>
@@ -21,6 +22,105 @@
 #include "span_attn_common.hpp"
 
 namespace dihip {
+
+// Block epilogue shared by the decode kernels: the 4 waves have left one (o[128], m, l) record per head in
+// `lds` ([wave][HC] records of ATTN_PSTRIDE floats).  Combines them, and for split sequences hands the block
+// partial to the last-arriving workgroup of the (request, group chunk), which merges and writes the output.
+template <int FT, int HC>
+__device__ __forceinline__ void attn_block_epilogue(const AttnArgs& a, float* lds, unsigned* flag_lds, int b, int h0, int nh,
+                                                    int split) {
+  constexpr int H = 128;
+  const int tid = threadIdx.x;
+  __syncthreads();
+  // thread -> (head, dim) pairs of the block result; kept in registers for the epilogue
+  constexpr int PER_THREAD = (HC * H + ATTN_THREADS - 1) / ATTN_THREADS;
+  float bo[PER_THREAD], bm[PER_THREAD], bl[PER_THREAD];
+#pragma unroll
+  for (int e = 0; e < PER_THREAD; ++e) {
+    const int idx = tid + e * ATTN_THREADS;
+    const int h = idx / H, d = idx - h * H;
+    bo[e] = 0.f;
+    bm[e] = -INFINITY;
+    bl[e] = 0.f;
+    if (h < nh) {
+      float mm = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) mm = fmaxf(mm, lds[(w * HC + h) * ATTN_PSTRIDE + H]);
+      float ll = 0.f, oo = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float* rec = lds + (w * HC + h) * ATTN_PSTRIDE;
+        const float c = safe_exp_diff(rec[H], mm);
+        ll += rec[H + 1] * c;
+        oo += rec[d] * c;
+      }
+      bo[e] = oo;
+      bm[e] = mm;
+      bl[e] = ll;
+    }
+  }
+
+  if (a.nsplits > 1) {
+#pragma unroll
+    for (int e = 0; e < PER_THREAD; ++e) {
+      const int idx = tid + e * ATTN_THREADS;
+      const int h = idx / H, d = idx - h * H;
+      if (h < nh) {
+        float* rec = a.partials + (((size_t)b * a.n + h0 + h) * a.nsplits + split) * ATTN_PSTRIDE;
+        rec[d] = bo[e];
+        if (d == 0) {
+          rec[H] = bm[e];
+          rec[H + 1] = bl[e];
+        }
+      }
+    }
+    unsigned* counter = a.counters + (size_t)b * gridDim.y + blockIdx.y;
+    if (!arrive_and_check_last(counter, (unsigned)a.nsplits, flag_lds)) return;
+    // last arriver: merge the split partials; loads are issued in independent batches
+#pragma unroll
+    for (int e = 0; e < PER_THREAD; ++e) {
+      const int idx = tid + e * ATTN_THREADS;
+      const int h = idx / H, d = idx - h * H;
+      if (h < nh) {
+        const float* base = a.partials + ((size_t)b * a.n + h0 + h) * a.nsplits * ATTN_PSTRIDE;
+        float mm = -INFINITY;
+        for (int sb = 0; sb < a.nsplits; sb += 16) {
+          float mv[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) mv[j] = sb + j < a.nsplits ? base[(size_t)(sb + j) * ATTN_PSTRIDE + H] : -INFINITY;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) mm = fmaxf(mm, mv[j]);
+        }
+        float ll = 0.f, oo = 0.f;
+        for (int sb = 0; sb < a.nsplits; sb += 16) {
+          float mv[16], lv[16], ov[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const bool in = sb + j < a.nsplits;
+            const float* rec = base + (size_t)(sb + j) * ATTN_PSTRIDE;
+            mv[j] = in ? rec[H] : -INFINITY;
+            lv[j] = in ? rec[H + 1] : 0.f;
+            ov[j] = in ? rec[d] : 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const float c = safe_exp_diff(mv[j], mm);
+            ll += lv[j] * c;
+            oo += ov[j] * c;
+          }
+        }
+        bo[e] = oo;
+        bl[e] = ll;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < PER_THREAD; ++e) {
+    const int idx = tid + e * ATTN_THREADS;
+    const int h = idx / H, d = idx - h * H;
+    if (h < nh) store_ft<FT>(a.out, ((size_t)b * a.n + h0 + h) * H + d, bl[e] > 0.f ? bo[e] / bl[e] : 0.f);
+  }
+}
 
 template <int FT, int MODE, int HC>
 __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const AttnArgs a) {
@@ -142,13 +242,12 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const At
   // is reduced
   constexpr int STEP = ATTN_TOK_PER_ITER;
   for (int tb = t0; tb < t1; tb += 2 * STEP) {
-    const bool more1 = tb + STEP < t1;
-    if (more1) issue(k1, v1, tb + STEP);
+    // unconditional (rows past the range are clamped inside issue): a load behind a branch makes hipcc
+    // drain the whole queue at the join (s_waitcnt vmcnt(0)), which would serialise loads and arithmetic
+    issue(k1, v1, tb + STEP);
     process(k0, v0, tb);
-    if (more1) {
-      if (tb + 2 * STEP < t1) issue(k0, v0, tb + 2 * STEP);
-      process(k1, v1, tb + STEP);
-    }
+    issue(k0, v0, tb + 2 * STEP);
+    if (tb + STEP < t1) process(k1, v1, tb + STEP);
   }
 
   // ---- merge the 4 token slots of the wave (lanes with equal dc) ---------------------------
@@ -178,112 +277,280 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const At
       }
     }
   }
-  __syncthreads();
-  // thread -> (head, dim) pairs of the block result; kept in registers for the epilogue
-  constexpr int PER_THREAD = (HC * H + ATTN_THREADS - 1) / ATTN_THREADS;
-  float bo[PER_THREAD], bm[PER_THREAD], bl[PER_THREAD];
+  attn_block_epilogue<FT, HC>(a, lds, flag_lds, b, h0, nh, split);
+}
+
+// ---- uint4 KV cache, 16-bit bf16 activations: both contractions on the matrix cores ---------------------
+// The VALU kernel above spends ~45 instructions per (token, head group) on a u4 cache (4-byte loads, nibble
+// decode, 16-lane reductions) and keeps only a few KB per CU in flight.  Here a wave takes 32 tokens per
+// iteration:
+//   S^T[token, head] = K[token, :] . Q[head, :]   16x16x32 MFMA, A = K rows exactly as the span stores them
+//       (lane (kb, token) <- the 16 bytes = 32 dims kb*32.. of the token row: one 1 KiB wave-load per 16
+//       tokens; a dword expands to 8 exact bf16 integers 128+q with 7 VALU ops), B = Q (bf16, unscaled);
+//       zero-point and scales are applied to the f32 scores: s*alpha*(acc - (128+z)*sum_d q);
+//   transposed scores put a head in a lane (ni) and 4 tokens per 16-lane row (kb): the online softmax needs
+//       two cross-row shuffles per iteration and P is already in the B-operand layout of
+//   O^T[dim, head] += V^T[dim, token] . P'[token, head]   (P' = P * v_scale, rounded to bf16).  A = V^T comes
+//       from 8 dword loads per lane (dword `ni` of 8 token rows) and an in-register 8x8 nibble transpose
+//       (v_perm_b32); the k-slot <-> token and row <-> dim maps are free, so no LDS is involved.  The V
+//       zero-points leave through  sum_t P'_t (128 + z_t)  with the SAME rounded P'.
+// Everything else (split partials, last-arriver merge) is the epilogue shared with the VALU kernel.
+// two f32 -> packed bf16 (round to nearest even): v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  const f32x2_ v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
+}
+constexpr int MF_HC = 16;   // query heads per workgroup chunk (MFMA N)
+constexpr int MF_TOK = 32;  // tokens per wave iteration
+
+__global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const AttnArgs a) {
+  constexpr int H = 128;
+  constexpr int HC = MF_HC;
+  constexpr int HB = H / 2;  // bytes per token-head row
+  __shared__ __attribute__((aligned(16))) float lds[4 * HC * ATTN_PSTRIDE + 4];
+  unsigned* flag_lds = reinterpret_cast<unsigned*>(lds + 4 * HC * ATTN_PSTRIDE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kb = lane >> 4, ni = lane & 15;
+  const int split = blockIdx.x;
+  const int grp = blockIdx.y / a.nchunks, hc = blockIdx.y % a.nchunks;
+  const int b = blockIdx.z;
+  const int h0 = grp * a.hpg + hc * HC;
+  const int nh = min(HC, a.hpg - hc * HC);
+
+  const int len = (int)a.seq_lens[b];
+  const int tps = ((len + a.nsplits - 1) / a.nsplits + 31) & ~31;
+  const int t0 = split * tps;
+  const int t1 = min(len, t0 + tps);
+  const void* const* ksp = a.kspans + (size_t)b * a.span_stride;
+  const void* const* vsp = a.vspans + (size_t)b * a.span_stride;
+  const size_t par_off = (size_t)a.g * a.S * HB;  // (zero, scale) pairs follow the data of all groups
+
+  struct Buf {
+    u32x4_t k[2];      // K rows: tile c, token c*16 + ni, bytes kb*16..
+    uint32_t v[8];     // V: dword ni of token (j>>2)*16 + kb*4 + (j&3)
+    f32x4_t kp[2][2];  // K {zero, scale} of tokens c*16 + kb*4 + {0,1 | 2,3}
+    f32x4_t vp[2][2];
+  };
+  // tile bases are wave-uniform, so the span pointers are scalar loads (a vector load of the pointer would sit
+  // behind the prefetched rows in the in-order vmcnt queue and drain it)
+  auto issue = [&](Buf& r, int tb) {
 #pragma unroll
-  for (int e = 0; e < PER_THREAD; ++e) {
-    const int idx = tid + e * ATTN_THREADS;
-    const int h = idx / H, d = idx - h * H;
-    bo[e] = 0.f;
-    bm[e] = -INFINITY;
-    bl[e] = 0.f;
-    if (h < nh) {
-      float mm = -INFINITY;
+    for (int c = 0; c < 2; ++c) {
+      int base = tb + c * 16;
+      base = base < t1 ? base : ((t1 - 1) & ~15);  // a tile past the range re-reads the last valid one (masked later)
+      const int sp = __builtin_amdgcn_readfirstlane(base / a.S);
+      const int pos0 = base - sp * a.S;
+      const unsigned char* kp_ = reinterpret_cast<const unsigned char*>(ksp[sp]);
+      const unsigned char* vp_ = reinterpret_cast<const unsigned char*>(vsp[sp]);
+      const size_t row0 = (size_t)grp * a.S + pos0;
+      r.k[c] = gload<u32x4_t>(kp_ + (row0 + ni) * HB + kb * 16);
+      const float* kpar = reinterpret_cast<const float*>(kp_ + par_off) + (row0 + kb * 4) * 2;
+      const float* vpar = reinterpret_cast<const float*>(vp_ + par_off) + (row0 + kb * 4) * 2;
+      r.kp[c][0] = gload<f32x4_t>(kpar);
+      r.kp[c][1] = gload<f32x4_t>(kpar + 4);
+      r.vp[c][0] = gload<f32x4_t>(vpar);
+      r.vp[c][1] = gload<f32x4_t>(vpar + 4);
 #pragma unroll
-      for (int w = 0; w < 4; ++w) mm = fmaxf(mm, lds[(w * HC + h) * ATTN_PSTRIDE + H]);
-      float ll = 0.f, oo = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const float* rec = lds + (w * HC + h) * ATTN_PSTRIDE;
-        const float c = safe_exp_diff(rec[H], mm);
-        ll += rec[H + 1] * c;
-        oo += rec[d] * c;
-      }
-      bo[e] = oo;
-      bm[e] = mm;
-      bl[e] = ll;
+      for (int rr = 0; rr < 4; ++rr) r.v[c * 4 + rr] = gload<uint32_t>(vp_ + (row0 + kb * 4 + rr) * HB + ni * 4);
     }
+  };
+
+  const int tb0 = t0 + wave * MF_TOK;
+  const bool active = tb0 < t1;
+  Buf ba, bb;
+  if (active) issue(ba, tb0);
+
+  // ---- Q as the B operand: lane (kb, head ni) holds dims kb*32 + ks*8 + e in the order the nibble expansion
+  // produces them (pairs (e, e+4)); unscaled, so the bf16 values are exact
+  u32x4_t qf[4];
+  float qsum = 0.f;
+  {
+    const bool hv = ni < nh;
+    const uint16_t* qrow = reinterpret_cast<const uint16_t*>(a.q) + ((size_t)b * a.n + h0 + (hv ? ni : 0)) * H + kb * 32;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4_t raw = *reinterpret_cast<const u32x4_t*>(qrow + ks * 8);
+      if (!hv) raw = u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) qsum += ft_bits_to_f32<DIHIP_BF16>(raw[j] & 0xFFFFu) + ft_bits_to_f32<DIHIP_BF16>(raw[j] >> 16);
+      qf[ks] = u32x4_t{(raw[0] & 0xFFFFu) | (raw[2] << 16), (raw[0] >> 16) | (raw[2] & 0xFFFF0000u),
+                       (raw[1] & 0xFFFFu) | (raw[3] << 16), (raw[1] >> 16) | (raw[3] & 0xFFFF0000u)};
+    }
+    qsum += __shfl_xor(qsum, 16, 64);
+    qsum += __shfl_xor(qsum, 32, 64);
   }
 
-  if (a.nsplits > 1) {
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f, czero = 0.f;
+  f32x4_t o[8];  // O^T tile dt: rows (dims) kb*4 + r  <->  dim kb*32 + r*8 + dt, column = head ni
 #pragma unroll
-    for (int e = 0; e < PER_THREAD; ++e) {
-      const int idx = tid + e * ATTN_THREADS;
-      const int h = idx / H, d = idx - h * H;
-      if (h < nh) {
-        float* rec = a.partials + (((size_t)b * a.n + h0 + h) * a.nsplits + split) * ATTN_PSTRIDE;
-        rec[d] = bo[e];
-        if (d == 0) {
-          rec[H] = bm[e];
-          rec[H + 1] = bl[e];
-        }
+  for (int dt = 0; dt < 8; ++dt) o[dt] = zero4;
+
+  auto process = [&](const Buf& r, int tb) {
+    // ---- scores of the 32 tokens (transposed): sc[c][r] = token tb + c*16 + kb*4 + r, head ni
+    float sc[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      f32x4_t acc = zero4;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint32_t w = r.k[c][ks];
+        const u32x4_t kf = {(w & 0x000F000Fu) | 0x43004300u, ((w >> 4) & 0x000F000Fu) | 0x43004300u,
+                            ((w >> 8) & 0x000F000Fu) | 0x43004300u, ((w >> 12) & 0x000F000Fu) | 0x43004300u};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qf[ks]),
+                                                      acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float kz = r.kp[c][rr >> 1][(rr & 1) * 2], ksc = r.kp[c][rr >> 1][(rr & 1) * 2 + 1];
+        const float v = (ksc * a.scale) * fmaf(-(128.f + kz), qsum, acc[rr]);
+        sc[c][rr] = tb + c * 16 + kb * 4 + rr < t1 ? v : -INFINITY;
       }
     }
-    unsigned* counter = a.counters + (size_t)b * gridDim.y + blockIdx.y;
-    if (!arrive_and_check_last(counter, (unsigned)a.nsplits, flag_lds)) return;
-    // last arriver: merge the split partials; loads are issued in independent batches
+    // ---- online softmax: the head's tokens of this iteration live in the 4 lanes (kb) with this ni
+    float mn = m;
 #pragma unroll
-    for (int e = 0; e < PER_THREAD; ++e) {
-      const int idx = tid + e * ATTN_THREADS;
-      const int h = idx / H, d = idx - h * H;
-      if (h < nh) {
-        const float* base = a.partials + ((size_t)b * a.n + h0 + h) * a.nsplits * ATTN_PSTRIDE;
-        float mm = -INFINITY;
-        for (int sb = 0; sb < a.nsplits; sb += 16) {
-          float mv[16];
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int j = 0; j < 16; ++j) mv[j] = sb + j < a.nsplits ? base[(size_t)(sb + j) * ATTN_PSTRIDE + H] : -INFINITY;
+      for (int rr = 0; rr < 4; ++rr) mn = fmaxf(mn, sc[c][rr]);
+    mn = fmaxf(mn, __shfl_xor(mn, 16, 64));
+    mn = fmaxf(mn, __shfl_xor(mn, 32, 64));
+    const float corr = safe_exp_diff(m, mn);
+    m = mn;
+    float ps = 0.f;
+    uint32_t pk[4], pl[4];  // P' = hi + lo, both bf16: the second MFMA pass keeps P at f32 accuracy
+    float cz = 0.f;
 #pragma unroll
-          for (int j = 0; j < 16; ++j) mm = fmaxf(mm, mv[j]);
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        float pv[2], zz[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int rr = h2 * 2 + e;
+          const bool valid = tb + c * 16 + kb * 4 + rr < t1;
+          const float p = safe_exp_diff(sc[c][rr], mn);
+          ps += p;
+          const float vz = r.vp[c][rr >> 1][(rr & 1) * 2], vs = r.vp[c][rr >> 1][(rr & 1) * 2 + 1];
+          pv[e] = valid ? p * vs : 0.f;  // p == 0 there, but the parameters may be junk
+          zz[e] = valid ? 128.f + vz : 0.f;
         }
-        float ll = 0.f, oo = 0.f;
-        for (int sb = 0; sb < a.nsplits; sb += 16) {
-          float mv[16], lv[16], ov[16];
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const bool in = sb + j < a.nsplits;
-            const float* rec = base + (size_t)(sb + j) * ATTN_PSTRIDE;
-            mv[j] = in ? rec[H] : -INFINITY;
-            lv[j] = in ? rec[H + 1] : 0.f;
-            ov[j] = in ? rec[d] : 0.f;
-          }
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const float c = safe_exp_diff(mv[j], mm);
-            ll += lv[j] * c;
-            oo += ov[j] * c;
-          }
-        }
-        bo[e] = oo;
-        bl[e] = ll;
+        const uint32_t hi = pack_bf16x2(pv[0], pv[1]);
+        const float h0f = __uint_as_float(hi << 16), h1f = __uint_as_float(hi & 0xFFFF0000u);
+        const uint32_t lo = pack_bf16x2(pv[0] - h0f, pv[1] - h1f);
+        pk[c * 2 + h2] = hi;
+        pl[c * 2 + h2] = lo;
+        cz = fmaf(h0f + __uint_as_float(lo << 16), zz[0], cz);
+        cz = fmaf(h1f + __uint_as_float(lo & 0xFFFF0000u), zz[1], cz);
       }
+    l = l * corr + ps;
+    czero = czero * corr + cz;
+    // the running maxima settle after the first few iterations: rescale only when some head's maximum moved
+    // (wave-uniform branch), which also lets the accumulators live in the MFMA's own registers
+    if (__builtin_amdgcn_ballot_w64(corr != 1.f) != 0ull) {
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) o[dt][rr] *= corr;
+    }
+    // ---- O^T += V^T . P': k-slot j = token (j>>2)*16 + kb*4 + (j&3) on both operands
+    uint32_t le[4], lo_[4], he[4], ho[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t d0 = r.v[2 * i], d1 = r.v[2 * i + 1];
+      le[i] = d0 & 0x0F0F0F0Fu;
+      lo_[i] = (d0 >> 4) & 0x0F0F0F0Fu;
+      he[i] = d1 & 0x0F0F0F0Fu;
+      ho[i] = (d1 >> 4) & 0x0F0F0F0Fu;
+    }
+    const u32x4_t pkv = {pk[0], pk[1], pk[2], pk[3]};
+    const u32x4_t plv = {pl[0], pl[1], pl[2], pl[3]};
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      constexpr uint32_t SEL[4] = {0x0C040C00u, 0x0C050C01u, 0x0C060C02u, 0x0C070C03u};
+      u32x4_t vf;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        vf[i] = __builtin_amdgcn_perm((dt & 1) ? ho[i] : he[i], (dt & 1) ? lo_[i] : le[i], SEL[dt >> 1]) | 0x43004300u;
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pkv), o[dt], 0,
+                                                      0, 0);
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, plv), o[dt], 0,
+                                                      0, 0);
+    }
+  };
+
+  if (active) {
+    constexpr int STEP = 4 * MF_TOK;  // the 4 waves interleave 32-token blocks
+    for (int tb = tb0; tb < t1; tb += 2 * STEP) {
+      issue(bb, tb + STEP);  // unconditional (clamped inside): see the note in the VALU kernel
+      process(ba, tb);
+      issue(ba, tb + 2 * STEP);
+      if (tb + STEP < t1) process(bb, tb + STEP);
     }
   }
+  // ---- totals of the head over the 4 token rows (kb), then the record the shared epilogue expects
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  czero += __shfl_xor(czero, 16, 64);
+  czero += __shfl_xor(czero, 32, 64);
+  if (ni < nh) {
+    float* rec = lds + (wave * HC + ni) * ATTN_PSTRIDE;
 #pragma unroll
-  for (int e = 0; e < PER_THREAD; ++e) {
-    const int idx = tid + e * ATTN_THREADS;
-    const int h = idx / H, d = idx - h * H;
-    if (h < nh) store_ft<FT>(a.out, ((size_t)b * a.n + h0 + h) * H + d, bl[e] > 0.f ? bo[e] / bl[e] : 0.f);
+    for (int rr = 0; rr < 4; ++rr) {
+      f32x4_t x0, x1;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        x0[dt] = o[dt][rr] - czero;
+        x1[dt] = o[4 + dt][rr] - czero;
+      }
+      *reinterpret_cast<f32x4_t*>(rec + kb * 32 + rr * 8) = x0;
+      *reinterpret_cast<f32x4_t*>(rec + kb * 32 + rr * 8 + 4) = x1;
+    }
+    if (kb == 0) {
+      rec[H] = m;
+      rec[H + 1] = l;
+    }
   }
+  attn_block_epilogue<DIHIP_BF16, HC>(a, lds, flag_lds, b, h0, nh, split);
 }
 
 // ------------------------------------------------------------------------------------------
 struct AttnPlan {
   int HC, nchunks, nsplits;
+  bool mfma;
   size_t partial_bytes;
 };
 
-static AttnPlan attn_plan(int batch, int n_heads, int n_groups, int max_seq_len, int num_cus) {
+static bool attn_use_mfma(int mode, int dtype) {
+  static int enabled = -1;  // DIHIP_ATTN_MFMA=0: keep the VALU kernel for the u4 cache (diagnostics)
+  if (enabled < 0) {
+    const char* e = getenv("DIHIP_ATTN_MFMA");
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  return enabled && mode == DIHIP_KV_U4 && dtype == DIHIP_BF16;
+}
+
+static AttnPlan attn_plan(int batch, int n_heads, int n_groups, int max_seq_len, int num_cus, bool mfma = false) {
   AttnPlan p;
   const int hpg = n_heads / n_groups;
-  p.HC = hpg <= 1 ? 1 : hpg <= 2 ? 2 : hpg <= 4 ? 4 : 8;
+  p.mfma = mfma;
+  p.HC = mfma ? MF_HC : hpg <= 1 ? 1 : hpg <= 2 ? 2 : hpg <= 4 ? 4 : 8;
   p.nchunks = (hpg + p.HC - 1) / p.HC;
   if (num_cus <= 0) num_cus = cached_num_cus();
   if (num_cus <= 0) num_cus = 256;
   const long base = (long)batch * n_groups * p.nchunks;
-  long want = (num_cus + base - 1) / base;  // about one workgroup per CU
+  static int wgs_per_cu = -1;  // DIHIP_ATTN_WGS_PER_CU: workgroups (4 waves) the split count aims at per CU
+  if (wgs_per_cu < 0) {
+    const char* e = getenv("DIHIP_ATTN_WGS_PER_CU");
+    wgs_per_cu = e ? std::max(1, atoi(e)) : 0;
+  }
+  // the MFMA kernel hides latency with two co-resident workgroups per CU; the VALU kernel measured best with one
+  const int per_cu = wgs_per_cu > 0 ? wgs_per_cu : (mfma ? 2 : 1);
+  long want = ((long)num_cus * per_cu + base - 1) / base;
   const long max_splits = std::max(1, (max_seq_len + 127) / 128);  // >= 128 tokens per split
   p.nsplits = (int)std::max<long>(1, std::min<long>(std::min<long>(want, max_splits), 256));
   p.partial_bytes = p.nsplits > 1 ? (size_t)batch * n_heads * p.nsplits * ATTN_PSTRIDE * sizeof(float) : 0;
@@ -319,7 +586,7 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
     set_last_error("span_attn: span length %d not in {16,32,64,128}", S);
     return DIHIP_SA_PARAM_ERROR;
   }
-  const AttnPlan p = attn_plan(batch, n, g, max_seq_len, num_cus);
+  const AttnPlan p = attn_plan(batch, n, g, max_seq_len, num_cus, attn_use_mfma(mode, dtype));
   if (p.nsplits > 1 && (ws == nullptr || ws_bytes < p.partial_bytes || counters == nullptr)) {
     set_last_error("span_attn: workspace too small (%zu < %zu)", ws_bytes, p.partial_bytes);
     return DIHIP_SA_PARAM_ERROR;
@@ -343,6 +610,9 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
   a.scale = scale;
   const dim3 grid(p.nsplits, g * p.nchunks, batch);
   bool ok = true;
+  if (p.mfma) {
+    hipLaunchKernelGGL(span_attn_u4_mfma_kernel, grid, dim3(ATTN_THREADS), 0, s, a);
+  } else
 #define GO(FTV, MODEV)                                      \
   if (dtype == FTV && mode == MODEV) {                      \
     launch_attn<FTV, MODEV>(p, a, grid, s);                 \
@@ -394,7 +664,8 @@ size_t dihip_span_attn_decode_workspace_bytes(int batch, int n_heads, int head_s
   size_t worst = 0;
   for (int g = 1; g <= n_heads; ++g) {
     if (n_heads % g) continue;
-    worst = std::max(worst, attn_plan(batch, n_heads, g, max_seq_len, num_cus).partial_bytes);
+    worst = std::max(worst, attn_plan(batch, n_heads, g, max_seq_len, num_cus, false).partial_bytes);
+    worst = std::max(worst, attn_plan(batch, n_heads, g, max_seq_len, num_cus, true).partial_bytes);
   }
   return worst + 256;
 }
@@ -463,7 +734,7 @@ int dihip_span_attn_create_handle(dihip_span_attn_handle_t* handle, int dtype, i
   h->seq_lens.assign(seq_len_host, seq_len_host + batch);
   h->lens_bytes = ((size_t)batch * sizeof(uint32_t) + 255) & ~(size_t)255;
   h->counter_bytes = dihip_span_attn_sync_bytes(batch, n_heads);
-  h->partial_bytes = attn_plan(batch, n_heads, n_groups, h->max_len, num_cus).partial_bytes;
+  h->partial_bytes = attn_plan(batch, n_heads, n_groups, h->max_len, num_cus, attn_use_mfma(kv_mode, dtype)).partial_bytes;
   *handle = h;
   return DIHIP_SA_SUCCESS;
 }

@@ -31,6 +31,12 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+template <typename T, bool GL>
+__device__ __forceinline__ T kv_ld(const void* p) {
+  if constexpr (GL) return gload<T>(p);
+  else return *reinterpret_cast<const T*>(p);
+}
+
 // 8 consecutive head dims (d = dc*8 ..) of one token-head, dequantised to f32
 template <int FT, int MODE>
 struct KvChunk {
@@ -38,29 +44,30 @@ struct KvChunk {
   float zero, scale;
 };
 
-template <int FT, int MODE>
+// GL: load through the global address space (exact vmcnt accounting, see gload) or as plain (FLAT) loads
+template <int FT, int MODE, bool GL = true>
 __device__ __forceinline__ void kv_issue(KvChunk<FT, MODE>& c, const void* span, int grp, int pos, int g, int S, int dc) {
   constexpr int H = 128;
   if constexpr (MODE == DIHIP_KV_NONE) {
     if constexpr (FT == DIHIP_F32) {
-      const u32x4_t* p = reinterpret_cast<const u32x4_t*>(reinterpret_cast<const float*>(span) + ((size_t)grp * S + pos) * H + dc * 8);
-      c.raw0 = p[0];
-      c.raw1 = p[1];
+      const float* p = reinterpret_cast<const float*>(span) + ((size_t)grp * S + pos) * H + dc * 8;
+      c.raw0 = kv_ld<u32x4_t, GL>(p);
+      c.raw1 = kv_ld<u32x4_t, GL>(p + 4);
     } else {
-      c.raw0 = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(span) + ((size_t)grp * S + pos) * H + dc * 8);
+      c.raw0 = kv_ld<u32x4_t, GL>(reinterpret_cast<const uint16_t*>(span) + ((size_t)grp * S + pos) * H + dc * 8);
     }
   } else {
     constexpr int HB = MODE == DIHIP_KV_I8 ? H : H / 2;
     const unsigned char* base = reinterpret_cast<const unsigned char*>(span);
     const unsigned char* d = base + ((size_t)grp * S + pos) * HB;
     if constexpr (MODE == DIHIP_KV_I8) {
-      const u32x2_t v = *reinterpret_cast<const u32x2_t*>(d + dc * 8);
+      const u32x2_t v = kv_ld<u32x2_t, GL>(d + dc * 8);
       c.raw0 = u32x4_t{v[0], v[1], 0, 0};
     } else {
-      c.raw0 = u32x4_t{*reinterpret_cast<const uint32_t*>(d + dc * 4), 0, 0, 0};
+      c.raw0 = u32x4_t{kv_ld<uint32_t, GL>(d + dc * 4), 0, 0, 0};
     }
     const float* params = reinterpret_cast<const float*>(base + (size_t)g * S * HB) + ((size_t)grp * S + pos) * 2;
-    const u32x2_t pz = *reinterpret_cast<const u32x2_t*>(params);
+    const u32x2_t pz = kv_ld<u32x2_t, GL>(params);
     c.zero = __uint_as_float(pz[0]);
     c.scale = __uint_as_float(pz[1]);
   }

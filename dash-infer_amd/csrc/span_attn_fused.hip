@@ -141,6 +141,10 @@ __device__ __forceinline__ void append_row(float (&x)[8], void* span, int head, 
 // first), which costs a few redundant cache reads but removes every cross-wave reduction, keeps
 // the per-wave instruction stream short (one or two heads: rope, scores, online softmax, P.V,
 // slot merge) and needs no barrier except around the new token.
+#ifndef DIHIP_FUSED_GL
+#define DIHIP_FUSED_GL 1
+#endif
+constexpr bool FUSED_GLOBAL_LOADS = DIHIP_FUSED_GL != 0;
 constexpr int FUSED_TB = 8;             // tokens per lane slot per iteration (4 slots x 8 = 32 tokens)
 constexpr int FUSED_TOK_PER_ITER = 32;
 constexpr int FUSED_MAX_WAVES = 8;
@@ -169,9 +173,23 @@ __global__ __launch_bounds__(64 * FUSED_MAX_WAVES) void span_attn_fused_kernel(c
       a.trace[((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * FUSED_MAX_WAVES + wave) * 8 + (I)] = wall_clock64(); \
   } while (0)
   DIHIP_ATTN_STAMP(0);
-  const int newpos = (int)a.old_lens[b];
-  const int len = newpos + 1;
+  // The sequence length and the span pointers of the split's first 32-token block (one or, for 16-token spans,
+  // two spans) are independent scalar loads issued together: one scalar-cache round trip instead of a chain of
+  // three vector loads (length -> pointer -> rows), and nothing of it sits in the vmcnt queue.
+  const void* const* ksp = a.kspans + (size_t)b * a.span_stride;
+  const void* const* vsp = a.vspans + (size_t)b * a.span_stride;
   const int t0 = split * a.tps;
+  const int sp0 = t0 / a.S, sp1 = min((t0 + 16) / a.S, a.span_stride - 1);
+  uint32_t newpos_u;
+  const void *kp0, *kp1, *vp0, *vp1;
+  asm volatile(
+      "s_load_dword %0, %5, 0x0\n\ts_load_dwordx2 %1, %6, 0x0\n\ts_load_dwordx2 %2, %7, 0x0\n\t"
+      "s_load_dwordx2 %3, %8, 0x0\n\ts_load_dwordx2 %4, %9, 0x0\n\ts_waitcnt lgkmcnt(0)"
+      : "=&s"(newpos_u), "=&s"(kp0), "=&s"(kp1), "=&s"(vp0), "=&s"(vp1)
+      : "s"(a.old_lens + b), "s"(ksp + sp0), "s"(ksp + sp1), "s"(vsp + sp0), "s"(vsp + sp1)
+      : "memory");
+  const int newpos = (int)newpos_u;
+  const int len = newpos + 1;
   const int t1 = min(len, t0 + a.tps);
   if (t0 >= t1) {
     // dead split (beyond the sequence): leave neutral partials so that the merge kernel needs no length
@@ -193,22 +211,28 @@ __global__ __launch_bounds__(64 * FUSED_MAX_WAVES) void span_attn_fused_kernel(c
   }
   const bool has_new = newpos >= t0;  // newpos < t1 always; only the last live split holds it
 
-  const void* const* ksp = a.kspans + (size_t)b * a.span_stride;
-  const void* const* vsp = a.vspans + (size_t)b * a.span_stride;
-
   auto issue = [&](KvChunk<FT, MODE> (&kc)[TB], KvChunk<FT, MODE> (&vc)[TB], int tb) {
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
       const int t = tb + i * 4 + tl;
       const int tt = t < t1 ? t : t0;  // clamp: keeps the address legal, result discarded
       const int sp = tt / a.S, pos = tt - sp * a.S;
-      kv_issue<FT, MODE>(kc[i], ksp[sp], grp, pos, a.g, a.S, dc);
-      kv_issue<FT, MODE>(vc[i], vsp[sp], grp, pos, a.g, a.S, dc);
+      kv_issue<FT, MODE, FUSED_GLOBAL_LOADS>(kc[i], ksp[sp], grp, pos, a.g, a.S, dc);
+      kv_issue<FT, MODE, FUSED_GLOBAL_LOADS>(vc[i], vsp[sp], grp, pos, a.g, a.S, dc);
     }
   };
   KvChunk<FT, MODE> k0[TB], v0[TB], k1[TB], v1[TB];
-  issue(k0, v0, t0);  // first rows in flight before anything else (the slot of the new token reads
-                      // whatever the span holds; it is overridden below)
+  // first rows in flight before anything else (the slot of the new token reads whatever the span holds; it is
+  // overridden below); rows past the range re-read the split's first row
+#pragma unroll
+  for (int i = 0; i < TB; ++i) {
+    const int t = t0 + i * 4 + tl;
+    const bool live = t < t1;
+    const int pos = (live ? t : t0) & (a.S - 1);  // span lengths are powers of two
+    const bool second = live && i * 4 >= 16;
+    kv_issue<FT, MODE, FUSED_GLOBAL_LOADS>(k0[i], second ? kp1 : kp0, grp, pos, a.g, a.S, dc);
+    kv_issue<FT, MODE, FUSED_GLOBAL_LOADS>(v0[i], second ? vp1 : vp0, grp, pos, a.g, a.S, dc);
+  }
   DIHIP_ATTN_STAMP(1);
 
   const size_t row = (size_t)b * (a.n + 2 * a.g) * H;
@@ -313,6 +337,8 @@ __global__ __launch_bounds__(64 * FUSED_MAX_WAVES) void span_attn_fused_kernel(c
 
   if (nh > 0) {  // wave-uniform (idle waves of a ragged last head chunk only help with the new token)
     constexpr int STEP = FUSED_TOK_PER_ITER;
+    // (conditional prefetch: the unconditional form that keeps hipcc's vmcnt counting exact across iterations
+    // measured 2 us slower at the batch-1 plan of one iteration per split)
     for (int tb = t0; tb < t1; tb += 2 * STEP) {
       const bool more1 = tb + STEP < t1;
       if (more1) issue(k1, v1, tb + STEP);

@@ -271,7 +271,14 @@ class DecodeSession:
         self.qkv = torch.empty(batch, (self.n_loc + 2 * self.g_loc) * H, dtype=dt, device=device)
         self.q = torch.empty(batch, self.n_loc * H, dtype=dt, device=device)
         self.attn = torch.empty(batch, self.n_loc * H, dtype=dt, device=device)
-        self.act = torch.empty(batch, model.layers[0].gate.N, dtype=dt, device=device)
+        # the SwiGLU output only feeds the down projection: when both run on the small-batch kernel it is
+        # kept in the MFMA-fragment layout that kernel loads with contiguous 1 KiB wave-loads
+        l0_ = model.layers[0]
+        self.act_frag = ops.prefers_frag(l0_.gate, batch, dual=True) and ops.prefers_frag(l0_.down, batch)
+        if self.act_frag:
+            self.act = torch.zeros(ops.act_frag_numel(batch, l0_.gate.N), dtype=dt, device=device)
+        else:
+            self.act = torch.empty(batch, l0_.gate.N, dtype=dt, device=device)
         self.logits = torch.empty(batch, model.vocab_local, dtype=f32, device=device)
         self.partial = torch.zeros(batch, cfg.hidden, dtype=f32, device=device)
         l0, wb, gsz = model.layers[0], model.quant.wbits, model.quant.group
@@ -334,8 +341,9 @@ class DecodeSession:
                 ops.span_attn_decode(self.q, self.kv[li], self.new_lens, self.n_loc, self.g_loc, self.H, self.max_len,
                                      self.scale, self.attn_ws, self.attn_sync, out=self.attn)
             self._proj_residual(self.attn, lw.o, tp_on)
-            ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act)
-            self._proj_residual(self.act, lw.down, tp_on)
+            ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act,
+                                  y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
+            self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag)
         ops.lm_head(self.h, m.final_norm, cfg.eps, m.lm_head, sc, out=self.logits)
         if tp_on:
             check(lib().dihip_argmax_partial(ops.cur_stream(), ops.ptr(self.pair), ops.ptr(self.logits), self.B,
@@ -349,20 +357,14 @@ class DecodeSession:
         ops.increment_u32_(self.old_lens)
         ops.increment_u32_(self.new_lens)
 
-    def _proj_residual(self, x, pw, tp_on):
+    def _proj_residual(self, x, pw, tp_on, frag=False):
         """h += x . W  (row-parallel under TP: rank 0 carries the residual, then all-reduce --
         the reference applies the fused residual ADD on rank 0 only, gemm_op.cpp:133-137)."""
-        if not tp_on:
-            ops.fused_gemm_addto(x, pw, self.h, self.scratch, out=self.h)
-            return
-        if self.model.rank == 0:
-            ops.fused_gemm_addto(x, pw, self.h, self.scratch, out=self.h)
-        else:
-            check(lib().dihip_fused_gemm_addto(ops.cur_stream(), pw.wbits, ops.ptr(x), ops.ptr(pw.w), ops.ptr(pw.sz), None,
-                                               ops.ptr(self.h), x.shape[0], pw.N, pw.K, pw.group, ops.ptr(self.scratch.ws),
-                                               self.scratch.ws_bytes, ops.ptr(self.scratch.sync), ops.dt_code(x)),
-                  "dihip_fused_gemm_addto")
-        self.comm.allreduce_(self.h)
+        lay = ops.ACT_FRAG32 if frag else ops.ACT_ROWMAJOR
+        h_res = self.h if (not tp_on or self.model.rank == 0) else None
+        ops.fused_gemm_addto(x, pw, h_res, self.scratch, out=self.h, x_layout=lay, M=self.B)
+        if tp_on:
+            self.comm.allreduce_(self.h)
 
     # -- hipGraph capture --------------------------------------------------------------------
     def capture(self, warmup=2):

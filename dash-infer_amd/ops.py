@@ -119,22 +119,53 @@ def fused_norm_gemm(h, gamma, eps, pw, bias, scratch, act=None, out=None):
     return y
 
 
-def fused_norm_swiglu(h, gamma, eps, pg, pu, scratch, out=None):
+ACT_ROWMAJOR, ACT_FRAG32 = 0, 1
+
+
+def prefers_frag(pw, M, dual=False):
+    """True when a [M, pw.N, pw.K] call runs on the small-batch kernel, which reads / writes the FRAG32
+    activation layout (include/dashinfer_hip.h) faster than row-major."""
+    return bool(lib().dihip_gemm_lowp_prefers_frag(pw.wbits, int(M), pw.N, pw.K, pw.group, int(dual)))
+
+
+def act_frag_numel(M, K):
+    return int(lib().dihip_act_frag_bytes(int(M), int(K))) // 2
+
+
+def act_to_frag(x):
+    M, K = x.shape
+    out = torch.zeros(act_frag_numel(M, K), dtype=x.dtype, device=x.device)
+    check(lib().dihip_act_to_frag(cur_stream(), ptr(x), ptr(out), M, K, dt_code(x)), "dihip_act_to_frag")
+    return out
+
+
+def act_from_frag(xf, M, K):
+    out = torch.empty(M, K, dtype=xf.dtype, device=xf.device)
+    check(lib().dihip_act_from_frag(cur_stream(), ptr(xf), ptr(out), M, K, dt_code(xf)), "dihip_act_from_frag")
+    return out
+
+
+def fused_norm_swiglu(h, gamma, eps, pg, pu, scratch, out=None, y_layout=ACT_ROWMAJOR):
     M = h.shape[0]
-    y = out if out is not None else torch.empty(M, pg.N, dtype=pg.dtype, device=h.device)
-    check(lib().dihip_fused_norm_swiglu(cur_stream(), pg.wbits, ptr(h), ptr(gamma), float(eps), ptr(pg.w), ptr(pg.sz),
-                                        ptr(pu.w), ptr(pu.sz), ptr(y), M, pg.N, pg.K, pg.group, ptr(scratch.ws),
-                                        scratch.ws_bytes, ptr(scratch.sync), dt_code(pg.dtype)),
-          "dihip_fused_norm_swiglu")
+    if out is not None:
+        y = out
+    elif y_layout == ACT_FRAG32:
+        y = torch.zeros(act_frag_numel(M, pg.N), dtype=pg.dtype, device=h.device)
+    else:
+        y = torch.empty(M, pg.N, dtype=pg.dtype, device=h.device)
+    check(lib().dihip_fused_norm_swiglu_ex(cur_stream(), pg.wbits, ptr(h), ptr(gamma), float(eps), ptr(pg.w), ptr(pg.sz),
+                                           ptr(pu.w), ptr(pu.sz), ptr(y), M, pg.N, pg.K, pg.group, ptr(scratch.ws),
+                                           scratch.ws_bytes, ptr(scratch.sync), dt_code(pg.dtype), int(y_layout)),
+          "dihip_fused_norm_swiglu_ex")
     return y
 
 
-def fused_gemm_addto(x, pw, h_res, scratch, out=None):
-    M = x.shape[0]
+def fused_gemm_addto(x, pw, h_res, scratch, out=None, x_layout=ACT_ROWMAJOR, M=None):
+    M = x.shape[0] if M is None else M
     h_out = out if out is not None else torch.empty(M, pw.N, dtype=torch.float32, device=x.device)
-    check(lib().dihip_fused_gemm_addto(cur_stream(), pw.wbits, ptr(x), ptr(pw.w), ptr(pw.sz), ptr(h_res), ptr(h_out),
-                                       M, pw.N, pw.K, pw.group, ptr(scratch.ws), scratch.ws_bytes, ptr(scratch.sync),
-                                       dt_code(x)), "dihip_fused_gemm_addto")
+    check(lib().dihip_fused_gemm_addto_ex(cur_stream(), pw.wbits, ptr(x), ptr(pw.w), ptr(pw.sz), ptr(h_res), ptr(h_out),
+                                          M, pw.N, pw.K, pw.group, ptr(scratch.ws), scratch.ws_bytes, ptr(scratch.sync),
+                                          dt_code(x), int(x_layout)), "dihip_fused_gemm_addto_ex")
     return h_out
 
 

@@ -122,6 +122,27 @@ int dihip_fused_gemm_addto(void* stream, int wbits, const void* x, const void* w
                            const void* sz_packed, const float* h_res, float* h_out, int M, int N,
                            int K, int group_size, void* ws, size_t ws_bytes, void* sync, int dtype);
 
+/* Activation layouts between two calls of the decode-step section.  DIHIP_ACT_FRAG32 stores the
+ * 16-bit matrix x[M <= 32, K] as the MFMA A fragments the small-batch kernel (1 < M <= 32) consumes:
+ * element (m, k) at  ((((k/32)*MT + m/16)*64 + ((k%32)/8)*16 + m%16)*8 + k%8,  MT = 1 (M <= 16) or 2;
+ * a fragment is then one contiguous 1 KiB wave-load instead of 16 pieces of 64 B (1.2-1.7x faster
+ * kernels).  dihip_gemm_lowp_prefers_frag() tells whether a [M, N, K] call (dual = 1: the
+ * gate/up pair of dihip_fused_norm_swiglu) runs on that kernel; only then may FRAG32 be passed.   */
+#define DIHIP_ACT_ROWMAJOR 0
+#define DIHIP_ACT_FRAG32 1
+int dihip_gemm_lowp_prefers_frag(int wbits, int M, int N, int K, int group_size, int dual);
+size_t dihip_act_frag_bytes(int M, int K);
+int dihip_act_to_frag(void* stream, const void* x_rowmajor, void* x_frag, int M, int K, int dtype);
+int dihip_act_from_frag(void* stream, const void* x_frag, void* x_rowmajor, int M, int K, int dtype);
+int dihip_fused_norm_swiglu_ex(void* stream, int wbits, const float* h, const void* gamma, float eps,
+                               const void* wg_packed, const void* szg_packed, const void* wu_packed,
+                               const void* szu_packed, void* y, int M, int N, int K, int group_size,
+                               void* ws, size_t ws_bytes, void* sync, int dtype, int y_layout);
+int dihip_fused_gemm_addto_ex(void* stream, int wbits, const void* x, const void* w_packed,
+                              const void* sz_packed, const float* h_res, float* h_out, int M, int N,
+                              int K, int group_size, void* ws, size_t ws_bytes, void* sync, int dtype,
+                              int x_layout);
+
 /* =============================================================================================
  * 2. KV span writers (replace csrc/core/kernel/cuda/cuda_kernel_span_cache.h:12-41)
  *    span layout (bit-compatible with the reference, decoder_cache_append.cuh:33-87):

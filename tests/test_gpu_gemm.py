@@ -352,3 +352,56 @@ def test_small_batch_kernel_all_epilogues(ops, wbits, G, M):
     u_ = gemm_ref.gemm_a16wx(xn, q2, s2, z2, G, wbits, ft="f32")
     ref3 = bf16_round(glue.silu(g_) * u_)
     assert_close(act.float().cpu().numpy(), ref3, "bf16", what="swiglu", pre=ref3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wbits,G", [(4, 128), (8, -1)])
+@pytest.mark.parametrize("M", [7, 16, 17, 32])
+def test_frag32_activation_layout_chain(ops, wbits, G, M):
+    """FRAG32 (MFMA-fragment-major) activations between SwiGLU and the down projection: converters round-trip,
+    and the fused chain is bit-identical to the row-major chain (same kernels, same arithmetic, other addresses)."""
+    rng = np.random.default_rng(M * 7 + wbits)
+    K, N = 4096, 272          # K too large for the LDS-resident (batch <= 16) kernel: the small-batch kernel runs
+    K2, N2 = 4096, 304        # second projection: consumes the [M, K2] activations
+    x, q, s, z = make_case(rng, M, N, K, G, wbits, "bf16")
+    xd = to_dev(x, "bf16")
+    # converters
+    xf = ops.act_to_frag(xd)
+    assert xf.numel() == (32 if M > 16 else 16) * K
+    back = ops.act_from_frag(xf, M, K)
+    assert torch.equal(back.view(torch.int16), xd.view(torch.int16))
+    mt = 2 if M > 16 else 1
+    m_i, k_i = M - 1, 1234
+    idx = ((((k_i // 32) * mt + m_i // 16) * 64 + ((k_i % 32) // 8) * 16 + m_i % 16) * 8 + k_i % 8)
+    assert xf.view(torch.int16)[idx].item() == xd.view(torch.int16)[m_i, k_i].item()   # layout formula of the header
+    # gate/up -> down, row-major vs FRAG32
+    _, qg, sg, zg = make_case(rng, 1, K2, K, G, wbits, "bf16")
+    _, qu, su, zu = make_case(rng, 1, K2, K, G, wbits, "bf16")
+    _, qd, sd, zd = make_case(rng, 1, N2, K2, G, wbits, "bf16")
+    pg = ops.pack_lowp(to_dev(qg), to_dev(sg, "bf16"), to_dev(zg, "bf16"), G, wbits)
+    pu = ops.pack_lowp(to_dev(qu), to_dev(su, "bf16"), to_dev(zu, "bf16"), G, wbits)
+    pd = ops.pack_lowp(to_dev(qd), to_dev(sd, "bf16"), to_dev(zd, "bf16"), G, wbits)
+    frag_ok = ops.prefers_frag(pg, M, dual=True) and ops.prefers_frag(pd, M)
+    assert frag_ok == (M > 16)       # M <= 16 at this K is served by the LDS-resident kernel (row-major only)
+    assert not ops.prefers_frag(pd, 1) and not ops.prefers_frag(pd, 33)
+    sc = ops.Scratch(max(ops.lowp_workspace_bytes(wbits, M, K2, K, G), ops.lowp_workspace_bytes(wbits, M, N2, K2, G)))
+    hk = torch.from_numpy(rng.normal(0, 1.5, (M, K)).astype(np.float32)).cuda()
+    gamma = to_dev(bf16_round(rng.normal(1, 0.1, K).astype(np.float32)), "bf16")
+    h0 = torch.from_numpy(rng.normal(0, 1, (M, N2)).astype(np.float32)).cuda()
+    act_rm = ops.fused_norm_swiglu(hk, gamma, 1e-6, pg, pu, sc)
+    out_rm = ops.fused_gemm_addto(act_rm, pd, h0, sc)
+    if not frag_ok:
+        # an explicit FRAG32 request forces the small-batch kernel; the row-major chain ran on the LDS-resident
+        # kernel (another summation order), so the two agree to rounding only
+        act_fr = ops.fused_norm_swiglu(hk, gamma, 1e-6, pg, pu, sc, y_layout=ops.ACT_FRAG32)
+        a_rm, a_fr = act_rm.float().cpu().numpy(), ops.act_from_frag(act_fr, M, K2).float().cpu().numpy()
+        np.testing.assert_allclose(a_fr, a_rm, rtol=2e-2, atol=2e-2 * np.abs(a_rm).max())
+        out_fr = ops.fused_gemm_addto(act_fr, pd, h0, sc, x_layout=ops.ACT_FRAG32, M=M)
+        np.testing.assert_allclose(out_fr.cpu().numpy(), out_rm.cpu().numpy(), rtol=2e-2, atol=2e-2 * float(out_rm.abs().max()))
+        with pytest.raises(Exception):   # M <= 4 runs on the LDS-resident kernel only: refused loudly
+            ops.fused_gemm_addto(act_fr, pd, h0[:1], sc, x_layout=ops.ACT_FRAG32, M=1)
+        return
+    act_fr = ops.fused_norm_swiglu(hk, gamma, 1e-6, pg, pu, sc, y_layout=ops.ACT_FRAG32)
+    assert torch.equal(ops.act_from_frag(act_fr, M, K2).view(torch.int16), act_rm.view(torch.int16))
+    out_fr = ops.fused_gemm_addto(act_fr, pd, h0, sc, x_layout=ops.ACT_FRAG32, M=M)
+    assert torch.equal(out_fr, out_rm)

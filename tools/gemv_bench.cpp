@@ -106,8 +106,8 @@ int main(int argc, char** argv) {
         unsigned long long t0 = ~0ull;
         for (int b = 0; b < blocks * 8; ++b) if (ht[b * 8] && ht[b * 8] < t0) t0 = ht[b * 8];
         printf("  plan: blocks %d upb %d WK %d WN %d lds %zu; stamps (us after first wave start) min / median / max over waves\n", blocks, upb, wk, wn, lds);
-        const char* names[7] = {"entry", "ring issued", "early landed", "prologue done", "main loop done", "block synced", "end"};
-        for (int st_ = 0; st_ < 7; ++st_) {
+        const char* names[8] = {"entry", "ring issued", "early landed", "prologue done", "main loop done", "block synced", "end", "early issued"};
+        for (int st_ = 0; st_ < 8; ++st_) {
           std::vector<double> v;
           for (int b = 0; b < blocks * 8; ++b) if (ht[b * 8 + st_]) v.push_back((double)(ht[b * 8 + st_] - t0) * 0.01);
           if (v.empty()) continue;
