@@ -114,10 +114,12 @@ def kernel_breakdown(sess, torch, ops, iters=5):
         def sep(li, lw):
             ops.rope_kv_append(sess.kv[li], sess.q, sess.qkv, sess.old_lens, sess.inv_freq, sess.n_loc, sess.g_loc, sess.H)
             ops.span_attn_decode(sess.q, sess.kv[li], sess.new_lens, sess.n_loc, sess.g_loc, sess.H, sess.max_len, sess.scale,
-                                 sess.attn_ws, sess.attn_sync, out=sess.attn)
+                                 sess.attn_ws, sess.attn_sync, out=sess.attn,
+                                 out_layout=ops.ACT_FRAG32 if sess.attn_frag else ops.ACT_ROWMAJOR)
         timed("rope_append_span_attention", B * 2 * sess.g_loc * SEQ_LEN * kvb, sep)
     timed("o_gemv_addto", l0.o.nbytes + act_b(l0.o),
-          lambda li, lw: ops.fused_gemm_addto(sess.attn, lw.o, sess.h, sc, out=sess.partial))
+          lambda li, lw: ops.fused_gemm_addto(sess.attn, lw.o, sess.h, sc, out=sess.partial, M=B,
+                                              x_layout=ops.ACT_FRAG32 if sess.attn_frag else ops.ACT_ROWMAJOR))
     timed("gate_up_swiglu", l0.gate.nbytes + l0.up.nbytes + B * l0.gate.K * 4 + B * l0.gate.N * 2,
           lambda li, lw: ops.fused_norm_swiglu(sess.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=sess.act,
                                                y_layout=ops.ACT_FRAG32 if sess.act_frag else ops.ACT_ROWMAJOR))

@@ -92,6 +92,14 @@ __device__ __forceinline__ void store_ft(void* p, size_t i, float v) {
   else ((uint16_t*)p)[i] = (uint16_t)f32_to_ft_bits<FT>(v);
 }
 
+// FRAG32 activation layout (DIHIP_ACT_FRAG32): the 16-bit matrix x[M, K] stored as the MFMA A fragments the
+// small-batch kernel consumes -- [K/32 k-steps][MT 16-row tiles][lane = kb*16 + row][8 elements], so that one
+// fragment is ONE contiguous 1 KiB wave-load (row-major x makes it 16 pieces of 64 B from 16 rows: half-used
+// cache lines and 16 tag look-ups per load; measured 1.2-1.7x slower kernels).  MT = 1 for M <= 16, else 2.
+__host__ __device__ inline size_t act_frag_index(int m, int k, int mt) {
+  return ((((size_t)(k >> 5) * mt + (m >> 4)) * 64 + ((k & 31) >> 3) * 16 + (m & 15)) * 8 + (k & 7));
+}
+
 // Load through a pointer that was itself read from memory (span tables): hipcc cannot tell its address space
 // and emits FLAT loads, which count on vmcnt AND lgkmcnt and may return out of order -- every wait on one
 // becomes s_waitcnt vmcnt(0) lgkmcnt(0) and drains all prefetches.  The explicit global address space turns

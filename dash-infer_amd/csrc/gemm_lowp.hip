@@ -523,11 +523,52 @@ static bool batch_kernel_shape(int wbits, int M, int N, int K, int group_size, b
   return batch_kernel_eligible(wbits, M, N, K, group_size) && !make_gemv_plan(wbits, M, N, K, group_size, dual).ok;
 }
 
-// f32 hidden rows -> FT normalised rows (used by the fused entry points when M > 4); frag_mt > 0: FRAG32 output
-template <int FT>
+// f32 hidden rows -> FT normalised rows (used by the fused entry points when M > 4); frag_mt > 0: FRAG32 output.
+// One workgroup per row, the row stays in registers (one 16-byte load per 4 columns, all in flight together):
+// a single round trip instead of two dependent passes over h.  cols % 4 == 0, cols <= 256 * 4 * VPT.
+template <int FT, int VPT>
 __global__ __launch_bounds__(256) void rmsnorm_f32_to_ft_kernel(uint16_t* __restrict__ y, const float* __restrict__ h,
                                                                 const void* __restrict__ gamma, float eps, int cols,
                                                                 int frag_mt) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const f32x4_t* hr = reinterpret_cast<const f32x4_t*>(h + (size_t)row * cols);
+  const int nvec = cols >> 2;
+  f32x4_t v[VPT];
+  u32x2_t gm[VPT];
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = tid + i * 256;
+    v[i] = c < nvec ? hr[c] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    gm[i] = c < nvec ? reinterpret_cast<const u32x2_t*>(gamma)[c] : u32x2_t{0u, 0u};
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) ss += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  const float rstd = 1.f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)cols + eps);
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = tid + i * 256;
+    if (c < nvec) {
+      const float g0 = ft_bits_to_f32<FT>(gm[i][0] & 0xFFFFu), g1 = ft_bits_to_f32<FT>(gm[i][0] >> 16);
+      const float g2 = ft_bits_to_f32<FT>(gm[i][1] & 0xFFFFu), g3 = ft_bits_to_f32<FT>(gm[i][1] >> 16);
+      const uint32_t lo = f32_to_ft_bits<FT>((g0 * v[i][0]) * rstd) | (f32_to_ft_bits<FT>((g1 * v[i][1]) * rstd) << 16);
+      const uint32_t hi = f32_to_ft_bits<FT>((g2 * v[i][2]) * rstd) | (f32_to_ft_bits<FT>((g3 * v[i][3]) * rstd) << 16);
+      const int k = c * 4;  // 4 consecutive columns stay adjacent in both layouts
+      const size_t idx = frag_mt ? act_frag_index(row, k, frag_mt) : (size_t)row * cols + k;
+      *reinterpret_cast<u32x2_t*>(y + idx) = u32x2_t{lo, hi};
+    }
+  }
+}
+
+// any width (two passes over the row)
+template <int FT>
+__global__ __launch_bounds__(256) void rmsnorm_f32_to_ft_wide_kernel(uint16_t* __restrict__ y, const float* __restrict__ h,
+                                                                     const void* __restrict__ gamma, float eps, int cols,
+                                                                     int frag_mt) {
   __shared__ float red[4];
   const float* hr = h + (size_t)blockIdx.x * cols;
   float ss = 0.f;
@@ -677,8 +718,15 @@ static int norm_to_ws(hipStream_t s, const float* h, const void* gamma, float ep
   *xnorm = reinterpret_cast<char*>(ws) + off;
   *ws_left = off;
   *x_layout = frag ? DIHIP_ACT_FRAG32 : DIHIP_ACT_ROWMAJOR;
-  hipLaunchKernelGGL(rmsnorm_f32_to_ft_kernel<DIHIP_BF16>, dim3(M), dim3(256), 0, s, (uint16_t*)*xnorm, h, gamma, eps,
-                     K, frag ? mt : 0);
+  const int fm = frag ? mt : 0;
+  const bool vec = K % 4 == 0 && (reinterpret_cast<uintptr_t>(h) % 16 == 0) && (reinterpret_cast<uintptr_t>(gamma) % 8 == 0);
+  uint16_t* xo = reinterpret_cast<uint16_t*>(*xnorm);
+  if (vec && K <= 4096)
+    hipLaunchKernelGGL((rmsnorm_f32_to_ft_kernel<DIHIP_BF16, 4>), dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, fm);
+  else if (vec && K <= 8192)
+    hipLaunchKernelGGL((rmsnorm_f32_to_ft_kernel<DIHIP_BF16, 8>), dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, fm);
+  else
+    hipLaunchKernelGGL(rmsnorm_f32_to_ft_wide_kernel<DIHIP_BF16>, dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, fm);
   return launch_status();
 }
 

@@ -52,13 +52,6 @@ struct GembArgs {
   int yfrag;    // y (EPI_STD / EPI_SWIGLU) is written in the FRAG32 layout
 };
 
-// FRAG32 activation layout (DIHIP_ACT_FRAG32): the 16-bit matrix x[M, K] stored as the MFMA A fragments the
-// small-batch kernel consumes -- [K/32 k-steps][MT 16-row tiles][lane = kb*16 + row][8 elements], so that one
-// fragment is ONE contiguous 1 KiB wave-load (row-major x makes it 16 pieces of 64 B from 16 rows: half-used
-// cache lines and 16 tag look-ups per load; measured 1.2-1.7x slower kernels).  MT = 1 for M <= 16, else 2.
-__host__ __device__ inline size_t act_frag_index(int m, int k, int mt) {
-  return ((((size_t)(k >> 5) * mt + (m >> 4)) * 64 + ((k & 31) >> 3) * 16 + (m & 15)) * 8 + (k & 7));
-}
 
 
 // MT: 16-row tiles (1: M <= 16, 2: M <= 32); NT: column tiles (SwiGLU: gate/up tile pairs) that share

@@ -20,6 +20,7 @@ struct AttnArgs {
   unsigned* counters;        // [B][g*nchunks]
   int B, n, g, hpg, S, span_stride, nsplits, nchunks;
   float scale;
+  int out_frag_mt;  // 0: out is row-major [B, n*H]; 1 / 2: FRAG32 with that many 16-row tiles (act_frag_index)
 };
 
 // sum over the 16 lanes of a DPP row (all 16 lanes receive the total)

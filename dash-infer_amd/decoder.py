@@ -271,6 +271,7 @@ class DecodeSession:
         self.qkv = torch.empty(batch, (self.n_loc + 2 * self.g_loc) * H, dtype=dt, device=device)
         self.q = torch.empty(batch, self.n_loc * H, dtype=dt, device=device)
         self.attn = torch.empty(batch, self.n_loc * H, dtype=dt, device=device)
+        self.attn_frag = False  # set below: the op-boundary attention can write the o-projection's fragment layout
         # the SwiGLU output only feeds the down projection: when both run on the small-batch kernel it is
         # kept in the MFMA-fragment layout that kernel loads with contiguous 1 KiB wave-loads
         l0_ = model.layers[0]
@@ -294,6 +295,9 @@ class DecodeSession:
         # one wave per query head, no cross-wave reductions).  Large batches stream thousands of tokens
         # per workgroup and use the row-sharing op-boundary kernels instead.
         self.fused_attention = batch * self.g_loc <= 64
+        if not self.fused_attention and batch <= 32 and ops.prefers_frag(model.layers[0].o, batch):
+            self.attn_frag = True
+            self.attn = torch.zeros(ops.act_frag_numel(batch, self.n_loc * H), dtype=dt, device=device)
         self.argmax_ws = torch.empty(batch * 64 * 8, dtype=torch.uint8, device=device)
         nr = model.nranks
         self.pair = torch.empty(batch * 8, dtype=torch.uint8, device=device)
@@ -339,8 +343,9 @@ class DecodeSession:
             else:
                 ops.rope_kv_append(self.kv[li], self.q, self.qkv, self.old_lens, self.inv_freq, self.n_loc, self.g_loc, self.H)
                 ops.span_attn_decode(self.q, self.kv[li], self.new_lens, self.n_loc, self.g_loc, self.H, self.max_len,
-                                     self.scale, self.attn_ws, self.attn_sync, out=self.attn)
-            self._proj_residual(self.attn, lw.o, tp_on)
+                                     self.scale, self.attn_ws, self.attn_sync, out=self.attn,
+                                     out_layout=ops.ACT_FRAG32 if self.attn_frag else ops.ACT_ROWMAJOR)
+            self._proj_residual(self.attn, lw.o, tp_on, frag=self.attn_frag)
             ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act,
                                   y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
             self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag)

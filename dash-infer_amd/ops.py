@@ -265,14 +265,17 @@ def span_attn_workspace(batch, n, H, max_len):
     return int(lib().dihip_span_attn_decode_workspace_bytes(batch, n, H, max_len, 0))
 
 
-def span_attn_decode(q, kv, seq_lens_dev, n, g, H, max_len, scale, ws, sync, out=None):
+def span_attn_decode(q, kv, seq_lens_dev, n, g, H, max_len, scale, ws, sync, out=None, out_layout=0):
+    """out_layout = ACT_FRAG32: the [B, n*H] result in the MFMA-fragment layout the small-batch o-projection reads."""
     B = q.shape[0]
-    out = out if out is not None else torch.empty(B, n * H, dtype=q.dtype, device=q.device)
+    if out is None:
+        out = (torch.zeros(act_frag_numel(B, n * H), dtype=q.dtype, device=q.device) if out_layout
+               else torch.empty(B, n * H, dtype=q.dtype, device=q.device))
     pool = kv.pool
-    check(lib().dihip_span_attn_decode(cur_stream(), ptr(out), ptr(q), ptr(kv.k_ptrs), ptr(kv.v_ptrs), ptr(seq_lens_dev),
-                                       B, n, g, H, pool.S, kv.max_spans, max_len, capi.KV[pool.mode], dt_code(q),
-                                       float(scale), ptr(ws), ws.numel() if ws is not None else 0, ptr(sync)),
-          "dihip_span_attn_decode")
+    check(lib().dihip_span_attn_decode_ex(cur_stream(), ptr(out), ptr(q), ptr(kv.k_ptrs), ptr(kv.v_ptrs), ptr(seq_lens_dev),
+                                          B, n, g, H, pool.S, kv.max_spans, max_len, capi.KV[pool.mode], dt_code(q),
+                                          float(scale), ptr(ws), ws.numel() if ws is not None else 0, ptr(sync),
+                                          int(out_layout)), "dihip_span_attn_decode_ex")
     return out
 
 

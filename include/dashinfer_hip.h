@@ -214,6 +214,14 @@ int dihip_span_attn_decode(void* stream, void* output, const void* query,
                            int head_size, int span_len, int n_spans_per_request, int max_seq_len,
                            int kv_mode, int dtype, float qk_scale, void* ws, size_t ws_bytes,
                            void* sync);
+/* same, output optionally in the FRAG32 activation layout (section 1, batch <= 32) for the o-projection
+ * that follows (out_layout: DIHIP_ACT_ROWMAJOR / DIHIP_ACT_FRAG32; buffer of dihip_act_frag_bytes(batch, n*H)) */
+int dihip_span_attn_decode_ex(void* stream, void* output, const void* query,
+                              const void* const* k_span_array, const void* const* v_span_array,
+                              const uint32_t* seq_lens_dev, int batch, int n_heads, int n_groups,
+                              int head_size, int span_len, int n_spans_per_request, int max_seq_len,
+                              int kv_mode, int dtype, float qk_scale, void* ws, size_t ws_bytes,
+                              void* sync, int out_layout);
 size_t dihip_span_attn_sync_bytes(int batch, int n_heads);
 
 /* 3b. Decode-step form with Rotary and DecoderCacheAppend folded in: replaces the

@@ -309,3 +309,27 @@ def test_fused_rope_append_attention_matches_separate_ops(ops, n, g, S, lens, mo
         ov[b].write(L, qkv[b, (n + g) * H:].reshape(g, H))
         ref.append(attention.decode_attention(rot[b, :n], ok[b].read_all(L + 1), ov[b].read_all(L + 1), scale))
     np.testing.assert_allclose(out.float().cpu().numpy().reshape(B, n, H), np.stack(ref), rtol=1e-2, atol=2.5e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["none", "u4"])
+@pytest.mark.parametrize("B", [5, 24])
+def test_span_attention_frag32_output(ops, mode, B):
+    """The decode attention can leave its [B, n*H] result in the FRAG32 activation layout of the small-batch
+    o-projection: same values, other addresses."""
+    rng = np.random.default_rng(B)
+    n, g, H, S, ft = 8, 2, 128, 32, "bf16"
+    lens = [int(x) for x in rng.integers(1, 300, B)]
+    pool, kv, ok, ov = build_batch(ops, rng, lens, n, g, H, S, mode, ft)
+    q = bf16_round(rng.normal(0, 1, (B, n, H)).astype(np.float32))
+    scale = 1.0 / np.sqrt(H)
+    max_len = max(lens)
+    ws = torch.empty(max(ops.span_attn_workspace(B, n, H, max_len), 256), dtype=torch.uint8, device="cuda")
+    sync = torch.zeros(int(ops.lib().dihip_span_attn_sync_bytes(B, n)), dtype=torch.uint8, device="cuda")
+    lens_d = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    qd = dev(q, ft).reshape(B, n * H)
+    rm = ops.span_attn_decode(qd, kv, lens_d, n, g, H, max_len, scale, ws, sync)
+    fr = ops.span_attn_decode(qd, kv, lens_d, n, g, H, max_len, scale, ws, sync, out_layout=ops.ACT_FRAG32)
+    torch.cuda.synchronize()
+    assert fr.numel() == (32 if B > 16 else 16) * n * H
+    assert torch.equal(ops.act_from_frag(fr, B, n * H).view(torch.int16), rm.view(torch.int16))
