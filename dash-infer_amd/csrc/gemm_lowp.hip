@@ -241,7 +241,12 @@ static GemvPlan make_gemv_plan(int wbits, int M, int N, int K, int group_size, b
   GemvPlan p{};
   const LowpDims d = lowp_dims(wbits, N, K, group_size);
   p.ok = false;
-  if (M < 1 || M > 16) return p;
+  static int max_m = -1;  // DIHIP_GEMV_STREAM_MAXM: largest batch served by the LDS-resident kernel
+  if (max_m < 0) {
+    const char* e = getenv("DIHIP_GEMV_STREAM_MAXM");
+    max_m = e ? std::max(1, std::min(16, atoi(e))) : 4;  // beyond 4 rows the per-workgroup x staging (M x K into LDS) costs more than the small-batch kernel
+  }
+  if (M < 1 || M > max_m) return p;
   if (d.group && d.group % d.KTILE != 0) return p;  // groups smaller than a k-tile: general kernel
   p.ktpg = d.group ? d.group / d.KTILE : (1 << 28);
   p.MR = M == 1 ? 1 : 4;

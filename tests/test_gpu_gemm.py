@@ -207,8 +207,8 @@ def test_qwen2_7b_layer_shapes_m1_vs_c_oracle(ops, layer, wbits, G):
 @pytest.mark.parametrize("wbits,G", [(4, 128), (8, -1)])
 def test_batch_invariance_and_determinism_full_size(ops, wbits, G):
     """Size-independent properties at BASELINE size (gate proj 3584 -> 18944, batch 32):
-    within one kernel family (decode GEMV: small M while the activations fit in LDS; general split-K
-    GEMM otherwise) row m of a batched
+    within one kernel family (decode GEMV: M <= 4, activations resident in LDS; small-batch kernel:
+    4 < M <= 32) row m of a batched
     call is bit-identical to a smaller-batch call on that row; across the two families rows agree to
     one FT ulp; repeated launches are bit-identical (deterministic reductions), and the op is linear
     in x within FT rounding."""
@@ -220,18 +220,20 @@ def test_batch_invariance_and_determinism_full_size(ops, wbits, G):
     y32 = ops.gemm_lowp(xd, pw)
     y32b = ops.gemm_lowp(xd, pw)
     assert torch.equal(y32, y32b)
-    assert ops.gemv_plan(wbits, 8, N, K, G) is not None and ops.gemv_plan(wbits, 24, N, K, G) is None
-    y8 = ops.gemm_lowp(xd[:8].contiguous(), pw)            # decode GEMV family
-    assert torch.equal(y8, ops.gemm_lowp(xd[:8].contiguous(), pw))
-    for m in (0, 3, 7):
+    assert ops.gemv_plan(wbits, 4, N, K, G) is not None and ops.gemv_plan(wbits, 8, N, K, G) is None
+    y4 = ops.gemm_lowp(xd[:4].contiguous(), pw)            # decode GEMV family (activations resident in LDS)
+    assert torch.equal(y4, ops.gemm_lowp(xd[:4].contiguous(), pw))
+    for m in (0, 3):
         y1 = ops.gemm_lowp(xd[m:m + 1].contiguous(), pw)
-        assert torch.equal(y1[0], y8[m]), f"row {m} differs between M=1 and M=8"
-    y24 = ops.gemm_lowp(xd[:24].contiguous(), pw)          # general family
+        assert torch.equal(y1[0], y4[m]), f"row {m} differs between M=1 and M=4"
+    y24 = ops.gemm_lowp(xd[:24].contiguous(), pw)          # small-batch family
     assert torch.equal(y24, y32[:24])
-    assert_close(y8.float().cpu().numpy(), y32[:8].float().cpu().numpy(), "bf16", what="GEMV vs general family")
+    y8 = ops.gemm_lowp(xd[:8].contiguous(), pw)
+    assert torch.equal(y8, y32[:8])
+    assert_close(y4.float().cpu().numpy(), y32[:4].float().cpu().numpy(), "bf16", what="GEMV vs small-batch family")
     # linearity: f(2x) == 2 f(x) exactly (power-of-two scaling commutes with every rounding)
     y2 = ops.gemm_lowp((xd[:4] * 2).contiguous(), pw)
-    assert torch.equal(y2, y8[:4] * 2)
+    assert torch.equal(y2, y4 * 2)
     # spot-check 64 random columns of 2 rows against the f64 oracle
     cols = rng.choice(N, 64, replace=False)
     w = gemm_ref.dequant(q, s, z, G, wbits)[:, cols].astype(np.float64)
@@ -382,7 +384,7 @@ def test_frag32_activation_layout_chain(ops, wbits, G, M):
     pu = ops.pack_lowp(to_dev(qu), to_dev(su, "bf16"), to_dev(zu, "bf16"), G, wbits)
     pd = ops.pack_lowp(to_dev(qd), to_dev(sd, "bf16"), to_dev(zd, "bf16"), G, wbits)
     frag_ok = ops.prefers_frag(pg, M, dual=True) and ops.prefers_frag(pd, M)
-    assert frag_ok == (M > 16)       # M <= 16 at this K is served by the LDS-resident kernel (row-major only)
+    assert frag_ok                   # every 4 < M <= 32 is served by the small-batch kernel
     assert not ops.prefers_frag(pd, 1) and not ops.prefers_frag(pd, 33)
     sc = ops.Scratch(max(ops.lowp_workspace_bytes(wbits, M, K2, K, G), ops.lowp_workspace_bytes(wbits, M, N2, K2, G)))
     hk = torch.from_numpy(rng.normal(0, 1.5, (M, K)).astype(np.float32)).cuda()
@@ -405,3 +407,5 @@ def test_frag32_activation_layout_chain(ops, wbits, G, M):
     assert torch.equal(ops.act_from_frag(act_fr, M, K2).view(torch.int16), act_rm.view(torch.int16))
     out_fr = ops.fused_gemm_addto(act_fr, pd, h0, sc, x_layout=ops.ACT_FRAG32, M=M)
     assert torch.equal(out_fr, out_rm)
+    with pytest.raises(Exception):   # M <= 4 runs on the LDS-resident kernel only: the layout is refused loudly
+        ops.fused_gemm_addto(act_fr, pd, h0[:1], sc, x_layout=ops.ACT_FRAG32, M=1)

@@ -22,7 +22,10 @@ int main(int argc, char** argv) {
   int reps = argc > 4 ? atoi(argv[4]) : 5;
   const Shape shapes[] = {{"qkv_norm_gemv", 0, 4608, 3584}, {"o_addto", 1, 3584, 3584},
                           {"gate_up_swiglu", 2, 18944, 3584}, {"down_addto", 1, 3584, 18944},
-                          {"lm_head", 3, 152064, 3584}};
+                          {"lm_head", 3, 152064, 3584},
+                          // BASELINE configs[3]: Qwen2-72B, TP=8, per-rank shapes
+                          {"c4_qkv", 0, 1280, 8192}, {"c4_o_addto", 1, 8192, 1024},
+                          {"c4_gate_up", 2, 3712, 8192}, {"c4_down_addto", 1, 8192, 3712}};
   hipStream_t st; CK(hipStreamCreate(&st));
   void *ws, *sync; size_t ws_bytes = 64 << 20;
   CK(hipMalloc(&ws, ws_bytes)); CK(hipMalloc(&sync, dihip_gemm_lowp_sync_bytes())); CK(hipMemset(sync, 0, dihip_gemm_lowp_sync_bytes()));
