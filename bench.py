@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--layers", type=int, default=None, help="debug: fewer decoder layers (result marked invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="debug: eager launches instead of hipGraph replay")
+    ap.add_argument("--steps-per-graph", type=int, default=1,
+                    help="consecutive decode steps captured per hipGraph (measured: 1 is fastest, back-to-back replays already pipeline)")
     args = ap.parse_args()
 
     import torch
@@ -193,16 +195,16 @@ def main():
         torch.cuda.synchronize()
 
     if not args.no_graph:
-        sess.capture(warmup=1)
-        run = sess.replay
+        sess.capture(warmup=1, steps_per_graph=max(1, args.steps_per_graph))
+        run_n = sess.replay_steps
     else:
-        run = sess.step
-    for _ in range(args.warmup):
-        run()
+        def run_n(n):
+            for _ in range(n):
+                sess.step()
+    run_n(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
+    run_n(args.steps)  # exactly K decode steps (graphs of --steps-per-graph consecutive steps + single-step graphs)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -232,7 +234,8 @@ def main():
         "dtype": "bf16",
         "data": "synthetic (random-init InstantQuant weights of the Qwen2-7B architecture, random 2048-token KV history)",
         "config": {"workload": f"Qwen2-7B {args.workload}: int{wbits} weight-only group {group}, KV {kv_mode}, batch {batch}, "
-                               f"seq {SEQ_LEN}, TP={world}, greedy, hipGraph={'off' if args.no_graph else 'on'}",
+                               f"seq {SEQ_LEN}, TP={world}, greedy, hipGraph={'off' if args.no_graph else 'on'}, "
+                               f"{max(1, args.steps_per_graph)} steps per graph",
                    "global_batch": batch, "seq_len": SEQ_LEN, "parallelism": f"tp{world}",
                    "layers": len(model.layers)},
         "step_hbm": {"algorithmic_bytes_per_rank": int(step_bytes), "achieved_GBps_per_gpu": round(step_gbs, 1),

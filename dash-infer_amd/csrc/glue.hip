@@ -94,8 +94,9 @@ __global__ __launch_bounds__(256) void argmax_stage1(ArgPair* __restrict__ parti
     partial[(size_t)m * gridDim.x + blockIdx.x] = r;
   }
 }
+// adv_a / adv_b (optional): per-request u32 counters (sequence lengths) advanced by one with the sampled id
 __global__ __launch_bounds__(256) void argmax_stage2(int64_t* __restrict__ ids, const ArgPair* __restrict__ partial,
-                                                     int nblocks) {
+                                                     int nblocks, uint32_t* adv_a, uint32_t* adv_b) {
   __shared__ ArgPair red[4];
   const int m = blockIdx.x;
   ArgPair best{-INFINITY, 0x7fffffff};
@@ -106,6 +107,8 @@ __global__ __launch_bounds__(256) void argmax_stage2(int64_t* __restrict__ ids, 
   if (threadIdx.x == 0) {
     ArgPair r = arg_better(arg_better(red[0], red[1]), arg_better(red[2], red[3]));
     ids[m] = (int64_t)r.i;
+    if (adv_a) adv_a[m] += 1u;
+    if (adv_b) adv_b[m] += 1u;
   }
 }
 
@@ -228,7 +231,20 @@ int dihip_argmax(void* stream, int64_t* ids, const float* logits, int M, int N, 
                 "argmax: workspace needs %zu bytes", (size_t)M * ARGMAX_BLOCKS * sizeof(ArgPair));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(argmax_stage1, dim3(ARGMAX_BLOCKS, M), dim3(256), 0, s, (ArgPair*)ws, logits, N);
-  hipLaunchKernelGGL(argmax_stage2, dim3(M), dim3(256), 0, s, ids, (const ArgPair*)ws, ARGMAX_BLOCKS);
+  hipLaunchKernelGGL(argmax_stage2, dim3(M), dim3(256), 0, s, ids, (const ArgPair*)ws, ARGMAX_BLOCKS, (uint32_t*)nullptr,
+                     (uint32_t*)nullptr);
+  return launch_status();
+}
+
+int dihip_argmax_advance(void* stream, int64_t* ids, const float* logits, int M, int N, void* ws, size_t ws_bytes,
+                         uint32_t* counters_a, uint32_t* counters_b) {
+  DIHIP_REQUIRE(M >= 0 && N > 0 && ids && logits, DIHIP_PARAM_ERROR, "argmax_advance: bad argument");
+  if (M == 0) return DIHIP_SUCCESS;
+  DIHIP_REQUIRE(ws && ws_bytes >= (size_t)M * ARGMAX_BLOCKS * sizeof(ArgPair), DIHIP_MEMORY_ERROR,
+                "argmax_advance: workspace needs %zu bytes", (size_t)M * ARGMAX_BLOCKS * sizeof(ArgPair));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(argmax_stage1, dim3(ARGMAX_BLOCKS, M), dim3(256), 0, s, (ArgPair*)ws, logits, N);
+  hipLaunchKernelGGL(argmax_stage2, dim3(M), dim3(256), 0, s, ids, (const ArgPair*)ws, ARGMAX_BLOCKS, counters_a, counters_b);
   return launch_status();
 }
 

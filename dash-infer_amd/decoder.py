@@ -357,10 +357,10 @@ class DecodeSession:
             self.comm.allgather(self.pair, self.pairs_all)
             check(lib().dihip_argmax_merge(ops.cur_stream(), ops.ptr(self.ids), ops.ptr(self.pairs_all), m.nranks, self.B),
                   "dihip_argmax_merge")
+            ops.increment_u32_(self.old_lens)
+            ops.increment_u32_(self.new_lens)
         else:
-            ops.argmax(self.logits, ws=self.argmax_ws, out=self.ids)
-        ops.increment_u32_(self.old_lens)
-        ops.increment_u32_(self.new_lens)
+            ops.argmax(self.logits, ws=self.argmax_ws, out=self.ids, advance=(self.old_lens, self.new_lens))
 
     def _proj_residual(self, x, pw, tp_on, frag=False):
         """h += x . W  (row-parallel under TP: rank 0 carries the residual, then all-reduce --
@@ -372,7 +372,10 @@ class DecodeSession:
             self.comm.allreduce_(self.h)
 
     # -- hipGraph capture --------------------------------------------------------------------
-    def capture(self, warmup=2):
+    def capture(self, warmup=2, steps_per_graph=1):
+        """Capture one decode step as a hipGraph (self.graph) and, for steps_per_graph > 1, a second graph of that
+        many consecutive steps (self.graph_multi): greedy decoding needs no host decision between steps (ids and
+        lengths live on the device), so k steps replay with one graph launch instead of k."""
         ids0, old0, new0 = self.ids.clone(), self.old_lens.clone(), self.new_lens.clone()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -387,12 +390,28 @@ class DecodeSession:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.step()
+        self.graph_multi, self.steps_per_graph = None, 1
+        if steps_per_graph > 1:
+            self.graph_multi = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_multi):
+                for _ in range(steps_per_graph):
+                    self.step()
+            self.steps_per_graph = steps_per_graph
         torch.cuda.synchronize()
         # the capture pass itself does not execute; state is still (ids0, lens0)
         return self.graph
 
     def replay(self):
         self.graph.replay()
+
+    def replay_steps(self, n):
+        """n decode steps: whole multi-step graphs first, single-step graphs for the remainder."""
+        k = self.steps_per_graph
+        while self.graph_multi is not None and n >= k:
+            self.graph_multi.replay()
+            n -= k
+        for _ in range(n):
+            self.graph.replay()
 
     # -- accounting (SURVEY 8(d)) --------------------------------------------------------------
     def algorithmic_bytes_per_step(self, seq_len):

@@ -337,11 +337,18 @@ def silu_mul(gate, up):
     return y
 
 
-def argmax(logits, ws=None, out=None):
+def argmax(logits, ws=None, out=None, advance=()):
+    """Greedy sampling; `advance`: up to two per-request u32 counter tensors incremented in the same launch."""
     M, N = logits.shape
     ids = out if out is not None else torch.empty(M, dtype=torch.int64, device=logits.device)
     ws = ws if ws is not None else torch.empty(M * 64 * 8, dtype=torch.uint8, device=logits.device)
-    check(lib().dihip_argmax(cur_stream(), ptr(ids), ptr(logits), M, N, ptr(ws), ws.numel()), "dihip_argmax")
+    if advance:
+        a = advance[0]
+        b = advance[1] if len(advance) > 1 else None
+        check(lib().dihip_argmax_advance(cur_stream(), ptr(ids), ptr(logits), M, N, ptr(ws), ws.numel(), ptr(a), ptr(b)),
+              "dihip_argmax_advance")
+    else:
+        check(lib().dihip_argmax(cur_stream(), ptr(ids), ptr(logits), M, N, ptr(ws), ws.numel()), "dihip_argmax")
     return ids
 
 

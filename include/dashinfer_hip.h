@@ -283,6 +283,10 @@ int dihip_lm_head(void* stream, float* logits, const float* h, const void* gamma
 /* greedy sampling (GenerateOp top_k = 1): ids[m] = argmax_n logits[m, n] (lowest index on ties) */
 int dihip_argmax(void* stream, int64_t* ids, const float* logits, int M, int N, void* ws,
                  size_t ws_bytes);
+/* same, and the two per-request u32 counters (e.g. cached / total sequence length; either may be NULL)
+ * advance by one in the same launch: the decode step needs no separate length-update kernels */
+int dihip_argmax_advance(void* stream, int64_t* ids, const float* logits, int M, int N, void* ws,
+                         size_t ws_bytes, uint32_t* counters_a, uint32_t* counters_b);
 /* vocabulary-parallel greedy sampling for TP: one {f32 value, i32 global index} pair per row
  * from this rank's logits slice [M, N] (global index = local + index_offset); after an
  * all-gather of the pairs ([nparts][M]) every rank merges them to the same ids.                */
