@@ -8,25 +8,29 @@
 //     tiles sharing every K / V fragment read) and keeps its Q fragments and the 32 x 128 f32 output
 //     accumulator in registers for the whole pass; under the causal mask a workgroup processes a
 //     query tile and its mirror, so all workgroups stream the same number of key tiles;
-//   * K and V tiles of 32 keys are staged once per workgroup in LDS: K row-major (its rows are
-//     the B fragments of Q.K^T as stored), V transposed on the way in (so that the B fragments
-//     of P.V are contiguous 16-byte reads);
-//   * scores stay in f32: S = alpha * Q.K^T -> causal mask -> online softmax (row max / sum over
-//     the 16 key lanes with DPP row rotations) -> P rounded to FT -> through a 1 KiB per-wave LDS
-//     patch from the C layout into the A layout -> P.V;
+//   * K and V tiles of 32 keys are staged once per workgroup in LDS: K row-major (its rows are the A
+//     fragments of K.Q^T as stored), V transposed on the way in, keys in the k-slot order of the second
+//     MFMA (so that the A fragments of V^T.P^T are contiguous 16-byte reads);
+//   * TRANSPOSED formulation, S^T = K.Q^T and O^T = V^T.P^T: a lane owns one query per 16-query tile and
+//     its accumulator rows are keys / head dims.  The online softmax is lane-local (f32: alpha scale ->
+//     causal mask -> max over the lane's 8 scores + two cross-row shuffles -> exp -> P rounded to FT), P
+//     leaves the S^T accumulators already in the B-operand layout of the second MFMA (no LDS round
+//     trip, no 16-lane DPP reductions), the running rescale is skipped while no maximum moves, and the
+//     output is 4 consecutive dims per lane (8-byte stores);
 //   * key tiles entirely above the causal diagonal are skipped.
 // Numerics follow the reference's CPU check (tests/cpp/kernel/cuda/kernel_mhaprefill_test.cpp:
 // 119-320): f32 softmax, FT inputs/outputs; P is rounded to FT before P.V as the tensor-core
 // kernels of the reference do.
 #include <algorithm>
+#include <cstdlib>
 
 #include "gemm_lowp_kernel.hpp"  // mfma16<FT>
 
 namespace dihip {
 
 constexpr int PF_THREADS = 256;
-constexpr int PF_MT = 2;       // 16-row query tiles per wave
-constexpr int PF_QROWS = 64 * PF_MT;  // query rows per workgroup (4 waves x 16 x PF_MT)
+// MT = 16-row query tiles per wave (template): 2 -> 128 query rows per workgroup, every K / V fragment read from
+// LDS feeds two MFMAs; 1 -> 64 rows per workgroup, used while the larger tile would leave CUs without work
 constexpr int PF_KEYS = 32;    // keys per tile
 constexpr int PF_KPITCH = 136; // K tile row pitch in elements (128 + 8: conflict-free b128 reads)
 constexpr int PF_VPITCH = 40;  // V^T tile row pitch in elements (32 + 8)
@@ -41,35 +45,18 @@ struct PrefillArgs {
   int pair;  // causal balance: a workgroup takes query tile x and its mirror
 };
 
-__device__ __forceinline__ float row16_max_pf(float v) {
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true)));
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true)));
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, true)));
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, true)));
-  return v;
-}
-__device__ __forceinline__ float row16_sum_pf(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, true));
-  return v;
-}
-
-template <int FT>
-__global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(const PrefillArgs a) {
+template <int FT, int MT>
+__global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const PrefillArgs a) {
   constexpr int H = 128;
-  constexpr int MT = PF_MT;  // 16-row query tiles per wave
+  constexpr int PF_QROWS = 64 * MT;  // query rows per workgroup (4 waves x 16 x MT)
   __shared__ __attribute__((aligned(16))) uint16_t ks[PF_KEYS * PF_KPITCH];          // K tile [key][dim]
   __shared__ __attribute__((aligned(16))) uint16_t vt[H * PF_VPITCH];                // V tile transposed [dim][key]
-  __shared__ __attribute__((aligned(16))) uint16_t ps[4 * MT * 16 * PF_VPITCH];      // per-wave P patches [q row][key]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int ni = lane & 15, kb = lane >> 4;
   const int head = blockIdx.y, kvh = head / (a.n_heads / a.n_groups);
   const int shift = a.seq_k - a.seq_q;  // query i sees keys j <= i + shift
   const int nqt = (a.seq_q + PF_QROWS - 1) / PF_QROWS;
-  uint16_t* pw = ps + wave * MT * 16 * PF_VPITCH;
 
   // Causal balance: workgroup x handles query tile x and then its mirror nqt-1-x, so every
   // workgroup sees the same number of key tiles (a lone middle tile is done once).
@@ -87,17 +74,18 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(const PrefillA
 #pragma unroll
       for (int s = 0; s < 4; ++s) qf[mt][s] = *reinterpret_cast<const u32x4_t*>(qp + s * 32);
     }
-    f32x4_t oacc[MT][8];
-    float mrow[MT][4], lrow[MT][4];  // running max / sum of query rows (replicated over the 16 key lanes)
+    // Transposed formulation (S^T = K.Q^T, O^T = V^T.P^T): a lane owns ONE query (column ni) per 16-query tile,
+    // its accumulator rows are keys / head dims.  The online softmax is then lane-local (8 scores per tile in
+    // registers, two cross-row shuffles for the max), P leaves the S^T accumulators already in the B-operand
+    // layout of the P.V MFMA (no LDS round trip), and the output is 4 consecutive dims per lane.
+    f32x4_t oacc[MT][8];       // O^T tile t: rows (dims) t*16 + kb*4 + r, column = query ni
+    float mrow[MT], lrow[MT];  // running max (uniform over kb) / partial sum (this lane's keys) of query ni
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) oacc[mt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        mrow[mt][r] = -INFINITY;
-        lrow[mt][r] = 0.f;
-      }
+      mrow[mt] = -INFINITY;
+      lrow[mt] = 0.f;
     }
     // keys needed by this query tile: up to the diagonal of its last row
     const int wg_last_q = min(a.seq_q, (qt + 1) * PF_QROWS) - 1;
@@ -126,19 +114,24 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(const PrefillA
         // V^T[d][2m, 2m+1] as one dword per dim; the dim order is rotated by the lane's chunk index so
         // that the 16 lanes of a row hit different banks (rows 8 apart would otherwise share two banks)
         uint32_t* vt32 = reinterpret_cast<uint32_t*>(vt);
+        // column of key pair (2m, 2m+1): keys are stored in the k-slot order of the P.V MFMA -- lane group kb
+        // owns keys {kb*4..+4} and {16 + kb*4..+4} of the tile (the rows its S^T accumulators hold), so its 8
+        // slots are one contiguous 16-byte read: pos(key) = ((key>>2)&3)*8 + (key>>4)*4 + (key&3)
+        const int key0 = 2 * m;
+        const int vcol = ((((key0 >> 2) & 3) * 8 + (key0 >> 4) * 4 + (key0 & 3))) >> 1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int jj = (j + dc) & 7;
           const uint32_t lo = (vreg[0][jj >> 1] >> ((jj & 1) * 16)) & 0xFFFFu;
           const uint32_t hi = (vreg[1][jj >> 1] >> ((jj & 1) * 16)) & 0xFFFFu;
-          vt32[((dc * 8 + jj) * PF_VPITCH) / 2 + m] = lo | (hi << 16);
+          vt32[((dc * 8 + jj) * PF_VPITCH) / 2 + vcol] = lo | (hi << 16);
         }
       }
       __syncthreads();
       if (k0 + PF_KEYS < k_end) load_tile(k0 + PF_KEYS);
       const bool wave_live = !a.causal || k0 <= q0 + 16 * MT - 1 + shift;  // some key of the tile is visible to this wave
       if (wave_live && q0 < a.seq_q) {
-        // ---- S = alpha * Q.K^T: the B fragments of a key tile feed all MT query tiles ----
+        // ---- S^T = K.Q^T: the K fragments (A) of a key tile feed all MT query tiles (B) ----
         f32x4_t sacc[MT][2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -147,76 +140,82 @@ __global__ __launch_bounds__(PF_THREADS) void prefill_attn_kernel(const PrefillA
           const uint16_t* kp = ks + (nt * 16 + ni) * PF_KPITCH + kb * 8;
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const u32x4_t bf = *reinterpret_cast<const u32x4_t*>(kp + s * 32);
+            const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(kp + s * 32);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) sacc[mt][nt] = mfma16<FT>(qf[mt][s], bf, sacc[mt][nt]);
+            for (int mt = 0; mt < MT; ++mt) sacc[mt][nt] = mfma16<FT>(kf, qf[mt][s], sacc[mt][nt]);
           }
         }
-        // ---- mask + online softmax: lane holds S[q = q0 + mt*16 + kb*4 + r][key = k0 + nt*16 + ni] ----
+        // ---- mask + online softmax: lane holds S[q = q0 + mt*16 + ni][key = k0 + nt*16 + kb*4 + r] ----
         u32x4_t pf[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+          const int qi = q0 + mt * 16 + ni;
           float p[2][4];
+          float mx = -INFINITY;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int qi = q0 + mt * 16 + kb * 4 + r;
-            float mx = -INFINITY;
+          for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-              const int key = k0 + nt * 16 + ni;
+            for (int r = 0; r < 4; ++r) {
+              const int key = k0 + nt * 16 + kb * 4 + r;
               const bool vis = key < a.seq_k && (!a.causal || key <= qi + shift);
               const float sv = vis ? sacc[mt][nt][r] * a.alpha : -INFINITY;
               p[nt][r] = sv;
               mx = fmaxf(mx, sv);
             }
-            mx = row16_max_pf(mx);
-            const float mn = fmaxf(mrow[mt][r], mx);
-            const float corr = mrow[mt][r] == -INFINITY ? 0.f : __expf(mrow[mt][r] - mn);
-            float psum = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-              const float e = p[nt][r] == -INFINITY ? 0.f : __expf(p[nt][r] - mn);
-              const float er = ft_round<FT>(e);  // P is fed to the matrix core in FT
-              p[nt][r] = er;
-              psum += er;
-            }
-            psum = row16_sum_pf(psum);
-            lrow[mt][r] = lrow[mt][r] * corr + psum;
-            mrow[mt][r] = mn;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) oacc[mt][t][r] *= corr;
-          }
-          // ---- P: C layout -> A layout through the wave's LDS patch [q row][32 keys] ----
-          uint16_t* pm = pw + mt * 16 * PF_VPITCH;
+          mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          const float mn = fmaxf(mrow[mt], mx);
+          const float corr = mrow[mt] == -INFINITY ? 0.f : __expf(mrow[mt] - mn);
+          mrow[mt] = mn;
+          float psum = 0.f;
+          uint32_t pk[4];
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pm[(kb * 4 + r) * PF_VPITCH + nt * 16 + ni] = (uint16_t)f32_to_ft_bits<FT>(p[nt][r]);
-          // same wave writes and reads: LDS ops of one wave complete in order
-          pf[mt] = *reinterpret_cast<const u32x4_t*>(pm + ni * PF_VPITCH + kb * 8);
+            for (int h2 = 0; h2 < 2; ++h2) {
+              const float e0 = p[nt][2 * h2] == -INFINITY ? 0.f : __expf(p[nt][2 * h2] - mn);
+              const float e1 = p[nt][2 * h2 + 1] == -INFINITY ? 0.f : __expf(p[nt][2 * h2 + 1] - mn);
+              const uint32_t b0 = f32_to_ft_bits<FT>(e0), b1 = f32_to_ft_bits<FT>(e1);  // P is fed to the matrix core in FT
+              psum += ft_bits_to_f32<FT>(b0) + ft_bits_to_f32<FT>(b1);
+              pk[nt * 2 + h2] = b0 | (b1 << 16);  // k-slot j <-> key (j>>2)*16 + kb*4 + (j&3): the V^T column order
+            }
+          lrow[mt] = lrow[mt] * corr + psum;
+          pf[mt] = u32x4_t{pk[0], pk[1], pk[2], pk[3]};
+          // rescale only when some query's maximum moved (wave-uniform): rare after the first tiles
+          if (__builtin_amdgcn_ballot_w64(corr != 1.f) != 0ull) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) oacc[mt][t][r] *= corr;
+          }
         }
-        // ---- O += P.V: B fragment of dim tile t = V^T[t*16 + ni][kb*8 .. +8], shared by the MT query tiles ----
+        // ---- O^T += V^T.P^T: A fragment of dim tile t = V^T[t*16 + ni][slots kb*8 .. +8], shared by the MT query tiles ----
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           const u32x4_t vf = *reinterpret_cast<const u32x4_t*>(vt + (t * 16 + ni) * PF_VPITCH + kb * 8);
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) oacc[mt][t] = mfma16<FT>(pf[mt], vf, oacc[mt][t]);
+          for (int mt = 0; mt < MT; ++mt) oacc[mt][t] = mfma16<FT>(vf, pf[mt], oacc[mt][t]);
         }
       }
     }
-    // ---- normalise and store: lane holds O[q0 + mt*16 + kb*4 + r][t*16 + ni] ----
+    // ---- normalise and store: lane holds O[q0 + mt*16 + ni][t*16 + kb*4 .. +4] ----
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
+      float l = lrow[mt];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      const int qi = q0 + mt * 16 + ni;
+      if (qi < a.seq_q) {
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        uint16_t* orow = reinterpret_cast<uint16_t*>(a.out) + (size_t)qi * a.n_heads * H + (size_t)head * H + kb * 4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qi = q0 + mt * 16 + kb * 4 + r;
-        if (qi < a.seq_q) {
-          const float inv = lrow[mt][r] > 0.f ? 1.f / lrow[mt][r] : 0.f;
-#pragma unroll
-          for (int t = 0; t < 8; ++t)
-            store_ft<FT>(a.out, (size_t)qi * a.n_heads * H + (size_t)head * H + t * 16 + ni, oacc[mt][t][r] * inv);
+        for (int t = 0; t < 8; ++t) {
+          const uint32_t lo = f32_to_ft_bits<FT>(oacc[mt][t][0] * inv) | (f32_to_ft_bits<FT>(oacc[mt][t][1] * inv) << 16);
+          const uint32_t hi = f32_to_ft_bits<FT>(oacc[mt][t][2] * inv) | (f32_to_ft_bits<FT>(oacc[mt][t][3] * inv) << 16);
+          *reinterpret_cast<u32x2_t*>(orow + t * 16) = u32x2_t{lo, hi};
         }
       }
+    }
     __syncthreads();  // the next pass restages the LDS tiles
   }
 }
@@ -238,12 +237,30 @@ extern "C" int dihip_prefill_attn(void* stream, void* out, const void* q, const 
   DIHIP_REQUIRE(q_stride % 8 == 0 && kv_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(q) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(k) & 15) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0,
                 DIHIP_PARAM_ERROR, "prefill_attn: rows must be 16-byte aligned");
-  const int nqt = (seq_q + PF_QROWS - 1) / PF_QROWS;
-  const int pair = causal && nqt >= 8;  // short sequences need every query tile as its own workgroup
+  static int force_mt = -1;  // DIHIP_PREFILL_MT: diagnostics
+  if (force_mt < 0) {
+    const char* e = getenv("DIHIP_PREFILL_MT");
+    force_mt = e ? atoi(e) : 0;
+  }
+  int ncu = cached_num_cus();
+  if (ncu <= 0) ncu = 256;
+  // 128-row query tiles read every K / V fragment once per two MFMAs; 64-row tiles double the workgroup count.
+  // Two workgroups fit a CU: take the small tile while the large one would fill less than 1.5 slots (measured).
+  auto wgs = [&](int rows) {
+    const int t = (seq_q + rows - 1) / rows;
+    return (long)((causal && t >= 8) ? (t + 1) / 2 : t) * n_heads;
+  };
+  const int mt = force_mt > 0 ? std::min(force_mt, 2) : (2 * wgs(128) >= 3L * ncu ? 2 : 1);
+  const int rows = 64 * mt;
+  const int nqt = (seq_q + rows - 1) / rows;
+  const int pair = causal && nqt >= 8;  // short sequences need every query tile as its own workgroup (measured: unpaired
+                                         // grids lose 40 % to the causal imbalance from 16 query tiles on)
   PrefillArgs a{out, q, k, v, seq_q, seq_k, q_stride, kv_stride, n_heads, n_groups, causal, alpha, pair};
   const dim3 grid(pair ? (nqt + 1) / 2 : nqt, n_heads);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == DIHIP_BF16) hipLaunchKernelGGL(prefill_attn_kernel<DIHIP_BF16>, grid, dim3(PF_THREADS), 0, s, a);
-  else hipLaunchKernelGGL(prefill_attn_kernel<DIHIP_F16>, grid, dim3(PF_THREADS), 0, s, a);
+  if (dtype == DIHIP_BF16 && mt == 2) hipLaunchKernelGGL((prefill_attn_kernel<DIHIP_BF16, 2>), grid, dim3(PF_THREADS), 0, s, a);
+  else if (dtype == DIHIP_BF16) hipLaunchKernelGGL((prefill_attn_kernel<DIHIP_BF16, 1>), grid, dim3(PF_THREADS), 0, s, a);
+  else if (mt == 2) hipLaunchKernelGGL((prefill_attn_kernel<DIHIP_F16, 2>), grid, dim3(PF_THREADS), 0, s, a);
+  else hipLaunchKernelGGL((prefill_attn_kernel<DIHIP_F16, 1>), grid, dim3(PF_THREADS), 0, s, a);
   return launch_status();
 }
