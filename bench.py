@@ -250,8 +250,14 @@ def main():
         try:
             kb = kernel_breakdown(sess, torch, ops)
             dom = kb["gate_up_swiglu"]
-            kname = "gemv_stream_kernel<%d, 2, %d, 1, 1, %d>" % (wbits, 1 if batch == 1 else 4, 1 if group > 0 else 0)
-            out["roofline"] = {"bound": "hbm", "kernel": "dihip::" + kname + " (RMSNorm + gate/up GEMV + SwiGLU)",
+            gpt = 1 if (group > 0 and group == (128 if wbits == 4 else 64)) else 0
+            if batch <= 4:
+                kname = "gemv_stream_kernel<%d, 2, %d, 1, 1, %d>" % (wbits, 1 if batch == 1 else 4, gpt)
+                kdesc = " (RMSNorm + gate/up GEMV + SwiGLU)"
+            else:
+                kname = "gemv_batch_kernel<%d, 2, %d, 2, 1, %d>" % (wbits, 2 if batch > 16 else 1, gpt)
+                kdesc = " (gate/up small-batch GEMM + SwiGLU; the timed launch pair includes the RMSNorm kernel)"
+            out["roofline"] = {"bound": "hbm", "kernel": "dihip::" + kname + kdesc,
                                "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4),
                                "traffic": pmc_traffic(kname) if args.workload == "int4_b1" else None,
