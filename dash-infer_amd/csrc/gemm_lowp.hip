@@ -8,6 +8,7 @@
 #include "gemm_lowp_launch.hpp"
 #include "gemv_stream_kernel.hpp"
 #include "gemv_batch_kernel.hpp"
+#include "gemm_panel_kernel.hpp"
 
 namespace dihip {
 
@@ -340,6 +341,51 @@ static bool gemv_stream_enabled() {
   return g_force_general == 0;
 }
 
+// ---- batched decode, FRAG32 activations (gemm_panel_kernel.hpp) ----------------------------------------
+struct PanelPlan {
+  bool ok;
+  int panels, nslices, ktps;
+  size_t slab_bytes;
+};
+
+static PanelPlan make_panel_plan(int wbits, int M, int N, int K, int group_size, bool dual) {
+  PanelPlan p{};
+  static int enabled = -1;  // DIHIP_GEMM_PANEL=0: keep the whole-column kernel (diagnostics)
+  if (enabled < 0) {
+    const char* e = getenv("DIHIP_GEMM_PANEL");
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!enabled) return p;
+  const LowpDims d = lowp_dims(wbits, N, K, group_size);
+  int ncu = cached_num_cus();
+  if (ncu <= 0) ncu = 256;
+  p.panels = (d.NTILES + PANEL_WAVES - 1) / PANEL_WAVES;
+  const int ktpg = d.group ? std::max(1, d.group / d.KTILE) : 1;  // slices hold whole quantisation groups
+  static int target = -1, one_frac = -1;  // diagnostics: DIHIP_PANEL_TARGET_WGS, DIHIP_PANEL_ONE_SLICE_PCT
+  if (target < 0) {
+    const char* e1 = getenv("DIHIP_PANEL_TARGET_WGS");
+    const char* e2 = getenv("DIHIP_PANEL_ONE_SLICE_PCT");
+    target = e1 ? atoi(e1) : 0;
+    one_frac = e2 ? atoi(e2) : 50;
+  }
+  const int tgt = target > 0 ? target : ncu;
+  if (100 * p.panels >= one_frac * ncu) {
+    p.nslices = 1;  // enough panels to keep the HBM queue full from every second CU on
+    p.ktps = d.KT;
+  } else {
+    // few columns: split K so that about one workgroup lands on every CU, but keep >= 8 k-tiles per slice
+    int s = std::max(1, tgt / p.panels);
+    int ktps = (d.KT + s - 1) / s;
+    ktps = (ktps + ktpg - 1) / ktpg * ktpg;
+    if (ktps < 8) return p;  // the ring would never fill: the whole-column kernel handles these
+    p.ktps = ktps;
+    p.nslices = (d.KT + ktps - 1) / ktps;
+  }
+  p.slab_bytes = p.nslices > 1 ? (size_t)p.nslices * (dual ? 2 : 1) * M * N * sizeof(float) : 0;
+  p.ok = true;
+  return p;
+}
+
 static int run_gemm(hipStream_t stream, const GemmCall& c) {
   DIHIP_REQUIRE(c.M >= 0 && c.N > 0 && c.K > 0, DIHIP_PARAM_ERROR, "gemm_lowp: bad shape M=%d N=%d K=%d",
                 c.M, c.N, c.K);
@@ -395,6 +441,53 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
       else if (c.wbits == 16) e = dispatch_gemv<16, DIHIP_BF16>(gp, c.pro, c.epi, g, stream);
       DIHIP_REQUIRE(e == hipSuccess, DIHIP_RUNTIME_ERROR, "gemv_stream: launch failed (wbits=%d MR=%d pro=%d epi=%d): %s",
                     c.wbits, gp.MR, c.pro, c.epi, hipGetErrorString(e));
+      return DIHIP_SUCCESS;
+    }
+  }
+  // batched decode with FRAG32 activations: panels of 8 column tiles sharing x through LDS (gemm_panel_kernel.hpp)
+  if (c.dtype == DIHIP_BF16 && gemv_stream_enabled() && c.x_layout == DIHIP_ACT_FRAG32 && c.pro == PRO_PLAIN && c.M > 4 &&
+      c.M <= 32 && c.wbits != 16 && c.K == d.Kp && (d.group == 0 || d.group % d.KTILE == 0)) {
+    const PanelPlan pp = make_panel_plan(c.wbits, c.M, c.N, c.K, c.group_size, dual);
+    if (pp.ok) {
+      DIHIP_REQUIRE(pp.nslices == 1 || (c.ws && c.ws_bytes >= pp.slab_bytes), DIHIP_MEMORY_ERROR,
+                    "gemm_panel: workspace too small for the split-K slab (%zu < %zu)", c.ws_bytes, pp.slab_bytes);
+      PanelArgs g{};
+      g.w0 = reinterpret_cast<const u32x4_t*>(c.w0);
+      g.w1 = reinterpret_cast<const u32x4_t*>(c.w1);
+      g.sz0 = reinterpret_cast<const uint32_t*>(c.sz0);
+      g.sz1 = reinterpret_cast<const uint32_t*>(c.sz1);
+      g.x = c.x;
+      g.bias = c.bias;
+      g.residual = c.residual;
+      g.y = c.y;
+      g.ldy = c.N;
+      g.h_res = c.h_res;
+      g.h_out = c.h_out;
+      g.alpha = c.alpha;
+      g.act = c.act;
+      g.M = c.M;
+      g.N = c.N;
+      g.K = c.K;
+      g.KT = d.KT;
+      g.NTILES = d.NTILES;
+      g.Gp = lowp_dims(4, c.N, c.K, c.group_size).Gp;
+      g.ktpg = d.group ? d.group / d.KTILE : (1 << 28);
+      g.ktps = pp.ktps;
+      g.nslices = pp.nslices;
+      g.slab = reinterpret_cast<float*>(c.ws);
+      g.yfrag = c.y_layout == DIHIP_ACT_FRAG32;
+      const bool gpt = g.ktpg == 1;
+      const int mt = c.M > 16 ? 2 : 1;
+      hipError_t e = hipErrorInvalidValue;
+#define PANEL_GO(W_, MT_, EPI_, G_) \
+      if (c.wbits == W_ && mt == MT_ && c.epi == EPI_ && (int)gpt == G_) e = launch_gemm_panel<W_, DIHIP_BF16, MT_, EPI_, G_>(g, pp.panels, stream);
+#define PANEL_ALL(W_, G_) PANEL_GO(W_, 1, EPI_STD, G_) PANEL_GO(W_, 2, EPI_STD, G_) PANEL_GO(W_, 1, EPI_SWIGLU, G_) \
+      PANEL_GO(W_, 2, EPI_SWIGLU, G_) PANEL_GO(W_, 1, EPI_ADDTO, G_) PANEL_GO(W_, 2, EPI_ADDTO, G_)
+      PANEL_ALL(4, 0) PANEL_ALL(4, 1) PANEL_ALL(8, 0) PANEL_ALL(8, 1)
+#undef PANEL_ALL
+#undef PANEL_GO
+      DIHIP_REQUIRE(e == hipSuccess, DIHIP_RUNTIME_ERROR, "gemm_panel: launch failed (wbits=%d M=%d epi=%d): %s", c.wbits, c.M,
+                    c.epi, hipGetErrorString(e));
       return DIHIP_SUCCESS;
     }
   }
@@ -663,7 +756,12 @@ size_t dihip_gemm_lowp_workspace_bytes(int wbits, int M, int N, int K, int group
   // sized for the dual (SwiGLU) form, the self-contained counter area and the M > 4 norm buffer
   const GemmPlan p1 = make_plan(wbits, M, N, K, group_size, false);
   const GemmPlan p2 = make_plan(wbits, M, N, K, group_size, true);
-  return std::max(p1.slab_bytes, p2.slab_bytes) + GEMM_SYNC_BYTES + (size_t)((M + 15) / 16 * 16) * K * 2 + 256;  // norm rows may be FRAG32
+  size_t slab = std::max(p1.slab_bytes, p2.slab_bytes);
+  if (wbits != 16 && M > 4 && M <= 32) {
+    slab = std::max(slab, make_panel_plan(wbits, M, N, K, group_size, false).slab_bytes);
+    slab = std::max(slab, make_panel_plan(wbits, M, N, K, group_size, true).slab_bytes);
+  }
+  return slab + GEMM_SYNC_BYTES + (size_t)((M + 15) / 16 * 16) * K * 2 + 512;  // norm rows may be FRAG32
 }
 
 static int gemm_std(void* stream, int wbits, const void* x, const void* w, const void* sz, const void* bias,
@@ -715,7 +813,9 @@ static int norm_to_ws(hipStream_t s, const float* h, const void* gamma, float ep
                       size_t ws_bytes, int wbits, int N, int group_size, bool dual, void** xnorm, size_t* ws_left,
                       int* x_layout, bool force_frag = false) {
   const GemmPlan p = make_plan(wbits, M, N, K, group_size, dual);
-  const size_t off = (p.slab_bytes + 255) & ~(size_t)255;
+  size_t slab = p.slab_bytes;
+  if (wbits != 16 && M > 4 && M <= 32) slab = std::max(slab, make_panel_plan(wbits, M, N, K, group_size, dual).slab_bytes);
+  const size_t off = (slab + 255) & ~(size_t)255;
   const bool frag = force_frag || batch_kernel_shape(wbits, M, N, K, group_size, dual);
   const int mt = M > 16 ? 2 : 1;
   const size_t xbytes = frag ? (size_t)mt * 16 * K * 2 : (size_t)M * K * 2;

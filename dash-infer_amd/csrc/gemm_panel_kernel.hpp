@@ -1,0 +1,299 @@
+// gemm_panel_kernel.hpp -- weight-only GEMM for batched decode (4 < M <= 32) with the activations in the
+// FRAG32 layout: a workgroup owns a PANEL of 8 column tiles (one per wave; SwiGLU: gate/up tile pairs) and a
+// K-slice, and shares every activation k-tile through LDS.
+//
+// gemv_batch_kernel.hpp keeps whole columns in one workgroup (no inter-workgroup reduction): its 8 waves
+// split K, so every workgroup re-reads the full M x K activations -- 163 MB (gate/up) / 271 MB (down) of
+// L2 -> CU traffic per launch at batch 32 next to 72 / 36 MB of weights -- and, because loads return in
+// order, the weight stream of a wave cannot run further ahead than its (8x larger) activation stream.
+// Here the roles are swapped:
+//   * the 8 waves split N; an activation k-tile (FRAG32: KSTEPS*MT contiguous 1 KiB fragments) is copied
+//     into LDS ONCE per workgroup, one 16-byte load per lane per wave, and every wave reads its A
+//     fragments from there (ds_read_b128, lane-linear, conflict free).  L2 -> CU activation traffic drops
+//     8x and a wave's global-load queue holds 1 KiB of x per (1 or 2) KiB of weights;
+//   * both streams are prefetched the same P k-tiles ahead in a register ring (plain unconditional loads in
+//     a fully unrolled body: hipcc counts them exactly), so waiting for step t leaves P steps in flight;
+//   * one workgroup barrier per k-tile (two LDS slots alternate);
+//   * no cross-wave reduction: a wave accumulates its tile over the whole K-slice in registers;
+//   * layers with few columns (N = 3584: 28 panels) split K across workgroups: f32 partial tiles go to a
+//     slab and gemm_panel_reduce_kernel applies the epilogue (fixed summation order, deterministic).
+// The arithmetic per element is the one of the other decode kernels (exact integer MFMA, scale / zero-point
+// per quantisation group on the f32 accumulator); only the f32 summation order over K differs.
+#pragma once
+#include <type_traits>
+
+#include "gemv_stream_kernel.hpp"
+
+namespace dihip {
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int PANEL_WAVES = 8;
+constexpr int PANEL_THREADS = PANEL_WAVES * 64;
+// prefetch distance in k-tiles: 6 (one weight chunk per step) / 4 (SwiGLU: two chunks per step); 8 measured slower
+
+struct PanelArgs {
+  const u32x4_t* w0;
+  const u32x4_t* w1;
+  const uint32_t* sz0;
+  const uint32_t* sz1;
+  const void* x;  // FT, FRAG32 [K/32][MT][64][8]
+  const void* bias;
+  const void* residual;  // row-major [M, N]
+  void* y;
+  int ldy;
+  const float* h_res;
+  float* h_out;
+  float alpha;
+  int act;
+  int M, N, K;
+  int KT, NTILES, Gp;
+  int ktpg;     // k-tiles per quantisation group (per-channel: >= KT)
+  int ktps;     // k-tiles per K-slice (multiple of ktpg when groups span several k-tiles)
+  int nslices;  // gridDim.y; > 1: partial tiles go to `slab`
+  float* slab;  // [nslices][DUAL][M][N] f32
+  int yfrag;    // y (EPI_STD / EPI_SWIGLU) in FRAG32
+};
+
+template <int FT, int EPI>
+__device__ __forceinline__ void panel_epilogue(const PanelArgs& a, int m, int n, float v, float v2, int mt_tiles) {
+  if constexpr (EPI == EPI_STD) {
+    v = __fmul_rn(a.alpha, v);
+    if (a.bias) v = __fadd_rn(v, load_ft<FT>(a.bias, n));
+    v = apply_act(v, a.act);
+    if (a.residual) v = ft_round<FT>(v) + load_ft<FT>(a.residual, (size_t)m * a.ldy + n);
+    store_ft<FT>(a.y, a.yfrag ? act_frag_index(m, n, mt_tiles) : (size_t)m * a.ldy + n, v);
+  } else if constexpr (EPI == EPI_SWIGLU) {
+    store_ft<FT>(a.y, a.yfrag ? act_frag_index(m, n, mt_tiles) : (size_t)m * a.ldy + n, (v / (1.f + expf(-v))) * v2);
+  } else {
+    const float base = a.h_res ? a.h_res[(size_t)m * a.N + n] : 0.f;
+    a.h_out[(size_t)m * a.N + n] = __fadd_rn(base, __fmul_rn(a.alpha, v));
+  }
+}
+
+template <int WBITS, int FT, int MT, int EPI, int GPT>
+__global__ __launch_bounds__(PANEL_THREADS) void gemm_panel_kernel(const PanelArgs a) {
+  using WT = WTraits<WBITS>;
+  using EX = ExpandV<WBITS, FT>;
+  constexpr int KSTEPS = WT::KSTEPS;
+  constexpr int DUAL = EPI == EPI_SWIGLU ? 2 : 1;
+  constexpr int NF = KSTEPS * MT;  // activation fragments (1 KiB each) per k-tile: 2, 4 or 8
+  constexpr int P = DUAL == 2 ? 4 : 6;
+  static_assert(NF <= PANEL_WAVES, "one fragment per wave");
+
+  __shared__ __attribute__((aligned(16))) u32x4_t xlds[2][NF][64];
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int ni = lane & 15, kb = lane >> 4;
+  const int unit = blockIdx.x * PANEL_WAVES + wave;
+  const int tile = min(unit, a.NTILES - 1);  // clamped: a panel's spare waves redo the last tile, never store
+  const int kt0 = blockIdx.y * a.ktps;
+  const int nk = min(a.KT, kt0 + a.ktps) - kt0;  // the same for all waves: they walk the slice in lock-step
+
+  const bool subc = a.ktpg < a.KT;
+  const int gcount = subc ? a.ktpg : (1 << 30);
+
+  // ---- streams: this wave's weight chunks + its share (fragment wave % NF) of the activation k-tile ----------
+  struct Slot {
+    u32x4_t w[DUAL];
+    uint32_t s[DUAL];
+    u32x4_t x;
+  };
+  const u32x4_t* wp[DUAL];
+  const uint32_t* sp[DUAL];
+#pragma unroll
+  for (int v = 0; v < DUAL; ++v) {
+    wp[v] = (v ? a.w1 : a.w0) + ((size_t)tile * a.KT + kt0) * 64 + lane;
+    sp[v] = (v ? a.sz1 : a.sz0) + (size_t)tile * a.Gp * 16 + ni;
+  }
+  const u32x4_t* xp = reinterpret_cast<const u32x4_t*>(a.x) + ((size_t)kt0 * NF + (wave % NF)) * 64 + lane;
+  auto load_slot = [&](Slot& r, int t) {
+    const int tt = min(t, nk - 1);  // past the slice: a valid re-load (unconditional loads keep hipcc's vmcnt counting exact)
+#pragma unroll
+    for (int v = 0; v < DUAL; ++v) {
+      r.w[v] = __builtin_nontemporal_load(wp[v] + (size_t)tt * 64);
+      const int kt = kt0 + tt;
+      // (nontemporal builtin: a plain load of read-only memory is rematerialisable -- hipcc then re-loads the word
+      // right before its use instead of keeping it in the ring, and waits vmcnt(0) for it)
+      r.s[v] = __builtin_nontemporal_load(sp[v] + (size_t)(GPT ? kt : (subc ? kt / a.ktpg : 0)) * 16);
+    }
+    r.x = __builtin_nontemporal_load(xp + (size_t)tt * NF * 64);
+  };
+
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t tot[DUAL][MT], gacc[DUAL][MT], xacc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    xacc[mt] = zero4;
+#pragma unroll
+    for (int v = 0; v < DUAL; ++v) {
+      tot[v][mt] = zero4;
+      gacc[v][mt] = zero4;
+    }
+  }
+  int cgl = gcount;
+  uint32_t ex_mask = 0x000F000Fu, ex_magic = FT == DIHIP_BF16 ? 0x43004300u : 0x64006400u;
+  asm volatile("" : "+v"(ex_mask), "+v"(ex_magic));
+  const u32x4_t ones = FT == DIHIP_BF16 ? u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}
+                                        : u32x4_t{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+
+  Slot ring[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) load_slot(ring[j], j);
+
+  // one k-tile step of the workgroup (ring slot j); REFILL: request k-tile t + P into the freed slot
+  auto step = [&](Slot& slot, int t, auto refill) {
+    constexpr bool REFILL = decltype(refill)::value;
+    // publish this wave's share of activation k-tile t.  The ring slot is refilled (k-tile t + P) only AFTER its
+    // last use below: a refill before the use makes hipcc rename the registers and rotate the whole ring with
+    // v_mov at the loop head -- which has to wait for every load in flight.
+    xlds[t & 1][wave % NF][lane] = slot.x;
+    __syncthreads();  // slot t & 1 complete; the other slot (k-tile t - 1) is free for the next step's writes
+    u32x4_t af[KSTEPS][MT];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) af[ks][mt] = xlds[t & 1][ks * MT + mt][lane];
+    f32x4_t xs[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {  // Sum_k x[m][k] of the k-tile: one MFMA against ones per k-step
+      f32x4_t sx = zero4;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) sx = mfma16<FT>(af[ks][mt], ones, sx);
+      xs[mt] = sx;
+      if constexpr (!GPT)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) xacc[mt][rr] += sx[rr];
+    }
+    bool gend = t + 1 == nk;
+    if constexpr (!GPT) gend = --cgl == 0 || gend;
+#pragma unroll
+    for (int v = 0; v < DUAL; ++v) {
+      f32x4_t g[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) g[mt] = zero4;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const u32x4_t bf = EX::frag(slot.w[v], ks, ex_mask, ex_magic);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) g[mt] = mfma16<FT>(af[ks][mt], bf, g[mt]);
+      }
+      const float s_ = ft_bits_to_f32<FT>(slot.s[v] & 0xFFFFu);
+      const float nzp_ = -(ft_bits_to_f32<FT>(slot.s[v] >> 16) + EX::OFFSET);
+      if constexpr (GPT) {
+        // explicit {v, v} pairs for the packed FMAs: hipcc otherwise broadcasts ONE register with op_sel and names a
+        // 64-bit pair whose other half is whatever sits next to it -- here a ring register with a load in flight,
+        // i.e. a false dependency that drains the prefetch queue once per ring revolution
+        f32x2_t s2 = {s_, s_}, nz2 = {nzp_, nzp_};
+        asm volatile("" : "+v"(s2), "+v"(nz2));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const f32x2_t x0 = {xs[mt][0], xs[mt][1]}, x1 = {xs[mt][2], xs[mt][3]};
+          const f32x2_t g0 = {g[mt][0], g[mt][1]}, g1 = {g[mt][2], g[mt][3]};
+          const f32x2_t t0v = {tot[v][mt][0], tot[v][mt][1]}, t1v = {tot[v][mt][2], tot[v][mt][3]};
+          const f32x2_t r0 = __builtin_elementwise_fma(s2, __builtin_elementwise_fma(nz2, x0, g0), t0v);
+          const f32x2_t r1 = __builtin_elementwise_fma(s2, __builtin_elementwise_fma(nz2, x1, g1), t1v);
+          tot[v][mt] = f32x4_t{r0[0], r0[1], r1[0], r1[1]};
+        }
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) gacc[v][mt][rr] += g[mt][rr];
+        if (gend) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              tot[v][mt][rr] = fmaf(s_, fmaf(nzp_, xacc[mt][rr], gacc[v][mt][rr]), tot[v][mt][rr]);
+              gacc[v][mt][rr] = 0.f;
+            }
+        }
+      }
+    }
+    if constexpr (!GPT) {
+      if (gend) {
+        cgl = gcount;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xacc[mt] = zero4;
+      }
+    }
+    if constexpr (REFILL) {
+      // pin the refill between the slot's last use and the next step: hoisted above the use it is renamed and
+      // copied back at the loop edge (a copy waits for the load), sunk below it shortens the prefetch distance
+      __builtin_amdgcn_sched_barrier(0);
+      load_slot(slot, t + P);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // full ring revolutions: straight-line, unconditional loads (a load behind a branch makes hipcc drain the
+  // queue at the join); the last nk % P steps run guarded and request nothing
+  int t0 = 0;
+  for (; t0 + P <= nk; t0 += P) {
+#pragma unroll
+    for (int j = 0; j < P; ++j) step(ring[j], t0 + j, std::true_type{});
+  }
+#pragma unroll
+  for (int j = 0; j < P; ++j)
+    if (t0 + j < nk) step(ring[j], t0 + j, std::false_type{});  // workgroup-uniform
+
+  // ---- rows kb*4 + r, column ni of this wave's tile ----------------------------------------------------------
+  if (unit >= a.NTILES) return;
+  const int n = tile * 16 + ni;
+  if (n >= a.N) return;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int m = mt * 16 + kb * 4 + rr;
+      if (m >= a.M) continue;
+      if (a.nslices > 1) {
+#pragma unroll
+        for (int v = 0; v < DUAL; ++v)
+          a.slab[(((size_t)blockIdx.y * DUAL + v) * a.M + m) * a.N + n] = tot[v][mt][rr];
+      } else {
+        panel_epilogue<FT, EPI>(a, m, n, tot[0][mt][rr], DUAL == 2 ? tot[DUAL - 1][mt][rr] : 0.f, MT);
+      }
+    }
+}
+
+// split-K: sum the slices in fixed order and apply the epilogue
+template <int FT, int EPI>
+__global__ __launch_bounds__(256) void gemm_panel_reduce_kernel(const PanelArgs a, int mt_tiles) {
+  constexpr int DUAL = EPI == EPI_SWIGLU ? 2 : 1;
+  const size_t total = (size_t)a.M * a.N;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int m = (int)(e / a.N), n = (int)(e - (size_t)m * a.N);
+    float v = 0.f, v2 = 0.f;
+    for (int s = 0; s < a.nslices; ++s) {
+      v += a.slab[((size_t)s * DUAL) * total + e];
+      if constexpr (DUAL == 2) v2 += a.slab[((size_t)s * DUAL + 1) * total + e];
+    }
+    panel_epilogue<FT, EPI>(a, m, n, v, v2, mt_tiles);
+  }
+}
+
+template <int WBITS, int FT, int MT, int EPI, int GPT>
+hipError_t launch_gemm_panel(const PanelArgs& a, int panels, hipStream_t stream);
+
+#define DIHIP_DEFINE_PANEL_LAUNCH(WBITS, FT, MT, EPI, GPT)                                                   \
+  template <>                                                                                                \
+  hipError_t launch_gemm_panel<WBITS, FT, MT, EPI, GPT>(const PanelArgs& a, int panels, hipStream_t s) {     \
+    hipLaunchKernelGGL((gemm_panel_kernel<WBITS, FT, MT, EPI, GPT>), dim3(panels, a.nslices), dim3(PANEL_THREADS), 0, s, a); \
+    if (a.nslices > 1) {                                                                                     \
+      const int blocks = (int)std::min<size_t>(((size_t)a.M * a.N + 255) / 256, 1024);                       \
+      hipLaunchKernelGGL((gemm_panel_reduce_kernel<FT, EPI>), dim3(blocks), dim3(256), 0, s, a, MT);         \
+    }                                                                                                        \
+    return hipGetLastError();                                                                                \
+  }
+#define DIHIP_DEFINE_PANEL_LAUNCH_SET(WBITS, FT, GPT)      \
+  DIHIP_DEFINE_PANEL_LAUNCH(WBITS, FT, 1, EPI_STD, GPT)    \
+  DIHIP_DEFINE_PANEL_LAUNCH(WBITS, FT, 2, EPI_STD, GPT)    \
+  DIHIP_DEFINE_PANEL_LAUNCH(WBITS, FT, 1, EPI_SWIGLU, GPT) \
+  DIHIP_DEFINE_PANEL_LAUNCH(WBITS, FT, 2, EPI_SWIGLU, GPT) \
+  DIHIP_DEFINE_PANEL_LAUNCH(WBITS, FT, 1, EPI_ADDTO, GPT)  \
+  DIHIP_DEFINE_PANEL_LAUNCH(WBITS, FT, 2, EPI_ADDTO, GPT)
+
+}  // namespace dihip

@@ -409,3 +409,38 @@ def test_frag32_activation_layout_chain(ops, wbits, G, M):
     assert torch.equal(out_fr, out_rm)
     with pytest.raises(Exception):   # M <= 4 runs on the LDS-resident kernel only: the layout is refused loudly
         ops.fused_gemm_addto(act_fr, pd, h0[:1], sc, x_layout=ops.ACT_FRAG32, M=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wbits,G", [(4, 128), (8, -1), (8, 128)])
+@pytest.mark.parametrize("M", [17, 32])
+def test_panel_kernel_full_size_mlp(ops, wbits, G, M):
+    """BASELINE configs[2] MLP at full size through the FRAG32 / panel path (gate/up: one K-slice, 148 panels;
+    down: split-K over 9 slices + reduce) against the row-major whole-column kernels and the f64 oracle."""
+    rng = np.random.default_rng(M + wbits)
+    K, I = QWEN7B["gate"]                # 3584 -> 18944
+    hk = torch.from_numpy(rng.normal(0, 1.0, (M, K)).astype(np.float32)).cuda()
+    gamma = to_dev(bf16_round(rng.normal(1, 0.1, K).astype(np.float32)), "bf16")
+    _, qg, sg, zg = make_case(rng, 1, I, K, G, wbits, "bf16")
+    _, qu, su, zu = make_case(rng, 1, I, K, G, wbits, "bf16")
+    _, qd, sd, zd = make_case(rng, 1, K, I, G, wbits, "bf16")
+    pg = ops.pack_lowp(to_dev(qg), to_dev(sg, "bf16"), to_dev(zg, "bf16"), G, wbits)
+    pu = ops.pack_lowp(to_dev(qu), to_dev(su, "bf16"), to_dev(zu, "bf16"), G, wbits)
+    pd = ops.pack_lowp(to_dev(qd), to_dev(sd, "bf16"), to_dev(zd, "bf16"), G, wbits)
+    sc = ops.Scratch(max(ops.lowp_workspace_bytes(wbits, M, I, K, G), ops.lowp_workspace_bytes(wbits, M, K, I, G)))
+    h0 = torch.from_numpy(rng.normal(0, 1, (M, K)).astype(np.float32)).cuda()
+    act_rm = ops.fused_norm_swiglu(hk, gamma, 1e-6, pg, pu, sc)                                   # row-major out
+    act_fr = ops.fused_norm_swiglu(hk, gamma, 1e-6, pg, pu, sc, y_layout=ops.ACT_FRAG32)
+    a_rm = act_rm.float().cpu().numpy()
+    a_fr = ops.act_from_frag(act_fr, M, I).float().cpu().numpy()
+    assert_close(a_fr, a_rm, "bf16", what="swiglu FRAG32 vs row-major output", pre=a_rm)
+    out_rm = ops.fused_gemm_addto(act_rm, pd, h0, sc)                                              # whole-column kernel
+    out_fr = ops.fused_gemm_addto(ops.act_to_frag(act_rm), pd, h0, sc, x_layout=ops.ACT_FRAG32, M=M)  # panel, split-K
+    o_rm, o_fr = out_rm.cpu().numpy(), out_fr.cpu().numpy()
+    np.testing.assert_allclose(o_fr, o_rm, rtol=2e-3, atol=2e-3 * np.abs(o_rm - h0.cpu().numpy()).max())
+    assert torch.equal(out_fr, ops.fused_gemm_addto(ops.act_to_frag(act_rm), pd, h0, sc, x_layout=ops.ACT_FRAG32, M=M))
+    # f64 oracle on 48 random columns of the down projection (input = the kernel's own bf16 activations)
+    cols = rng.choice(K, 48, replace=False)
+    wd = gemm_ref.dequant(qd, sd, zd, G, wbits)[:, cols].astype(np.float64)
+    ref = h0.cpu().numpy()[:, cols] + (a_rm.astype(np.float64) @ wd)
+    np.testing.assert_allclose(o_fr[:, cols], ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
