@@ -194,13 +194,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if not args.no_graph:
-        sess.capture(warmup=1, steps_per_graph=max(1, args.steps_per_graph))
-        run_n = sess.replay_steps
+    def run_eager(n):
+        for _ in range(n):
+            sess.step()
+
+    graph_on = not args.no_graph
+    if graph_on:
+        try:
+            sess.capture(warmup=1, steps_per_graph=max(1, args.steps_per_graph))
+            run_n = sess.replay_steps
+        except Exception as e:  # noqa: BLE001 -- e.g. a collective that refuses stream capture: measure eager launches
+            print(f"[rank {rank}] hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
+            graph_on = False
+            torch.cuda.synchronize()
+            sess.set_state(ids, [SEQ_LEN] * batch)
+            run_n = run_eager
     else:
-        def run_n(n):
-            for _ in range(n):
-                sess.step()
+        run_n = run_eager
     run_n(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -234,7 +244,7 @@ def main():
         "dtype": "bf16",
         "data": "synthetic (random-init InstantQuant weights of the Qwen2-7B architecture, random 2048-token KV history)",
         "config": {"workload": f"Qwen2-7B {args.workload}: int{wbits} weight-only group {group}, KV {kv_mode}, batch {batch}, "
-                               f"seq {SEQ_LEN}, TP={world}, greedy, hipGraph={'off' if args.no_graph else 'on'}, "
+                               f"seq {SEQ_LEN}, TP={world}, greedy, hipGraph={'on' if graph_on else 'off'}, "
                                f"{max(1, args.steps_per_graph)} steps per graph",
                    "global_batch": batch, "seq_len": SEQ_LEN, "parallelism": f"tp{world}",
                    "layers": len(model.layers)},

@@ -173,7 +173,8 @@ def test_span_attention_unquantised(ops, n, g, S, lens, ft):
 
 
 @pytest.mark.parametrize("mode", ["i8", "u4"])
-@pytest.mark.parametrize("n,g,S,lens", [(14, 2, 16, [999]), (28, 4, 128, [5, 700, 130]), (8, 1, 32, [257, 64])])
+@pytest.mark.parametrize("n,g,S,lens", [(14, 2, 16, [999]), (28, 4, 128, [5, 700, 130]), (8, 1, 32, [257, 64]),
+                                        (32, 1, 64, [200, 1]), (4, 4, 32, [33, 96, 31]), (64, 2, 16, [70])])
 def test_span_attention_quantised_kv(ops, n, g, S, lens, mode):
     """uint4 / int8 KV: the reference pins no results; parity is against the codec
     oracle: the kernel must reproduce attention over the DEQUANTISED cache to f32 accuracy."""
