@@ -162,9 +162,14 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const At
   auto issue = [&](KvChunk<FT, MODE> (&kc)[TB], KvChunk<FT, MODE> (&vc)[TB], int tb) {
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
-      const int t = tb + i * 16 + wave * 4 + tl;
-      const int tt = t < t1 ? t : t0;  // clamp: keeps the address legal, result discarded
-      const int sp = tt / a.S, pos = tt - sp * a.S;
+      // a wave-load row = 4 consecutive tokens starting at a multiple of 4: one span (span lengths are
+      // multiples of 16), so the span pointers are wave-uniform scalar loads -- a per-lane vector load of the
+      // pointer would queue behind the prefetched rows (in-order vmcnt) and drain them
+      int rb = tb + i * 16 + wave * 4;
+      rb = rb < t1 ? rb : t0;  // a row past the range re-reads the first row (legal address, result discarded)
+      const int sp = __builtin_amdgcn_readfirstlane(rb / a.S);
+      const int tt = min(rb + tl, t1 - 1);  // stays inside the row: same span
+      const int pos = tt - sp * a.S;
       kv_issue<FT, MODE>(kc[i], ksp[sp], grp, pos, a.g, a.S, dc);
       kv_issue<FT, MODE>(vc[i], vsp[sp], grp, pos, a.g, a.S, dc);
     }
@@ -350,6 +355,12 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
   };
   // tile bases are wave-uniform, so the span pointers are scalar loads (a vector load of the pointer would sit
   // behind the prefetched rows in the in-order vmcnt queue and drain it)
+  // per-lane byte offsets inside a 16-token tile (constant over the kernel): every load below is then
+  // wave-uniform 64-bit base (SGPR pair) + 32-bit lane offset (+ immediate) -- the saddr form, no per-lane
+  // 64-bit address arithmetic in the loop
+  const uint32_t lo_k = (uint32_t)(ni * HB + kb * 16);      // K row of token ni, bytes kb*16..
+  const uint32_t lo_p = (uint32_t)(kb * 32);                // {zero, scale} x 4 tokens kb*4..
+  const uint32_t lo_v = (uint32_t)(kb * 4 * HB + ni * 4);   // V dword ni of token kb*4 (+ rr*HB)
   auto issue = [&](Buf& r, int tb) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -357,18 +368,18 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
       base = base < t1 ? base : ((t1 - 1) & ~15);  // a tile past the range re-reads the last valid one (masked later)
       const int sp = __builtin_amdgcn_readfirstlane(base / a.S);
       const int pos0 = base - sp * a.S;
-      const unsigned char* kp_ = reinterpret_cast<const unsigned char*>(ksp[sp]);
-      const unsigned char* vp_ = reinterpret_cast<const unsigned char*>(vsp[sp]);
-      const size_t row0 = (size_t)grp * a.S + pos0;
-      r.k[c] = gload<u32x4_t>(kp_ + (row0 + ni) * HB + kb * 16);
-      const float* kpar = reinterpret_cast<const float*>(kp_ + par_off) + (row0 + kb * 4) * 2;
-      const float* vpar = reinterpret_cast<const float*>(vp_ + par_off) + (row0 + kb * 4) * 2;
-      r.kp[c][0] = gload<f32x4_t>(kpar);
-      r.kp[c][1] = gload<f32x4_t>(kpar + 4);
-      r.vp[c][0] = gload<f32x4_t>(vpar);
-      r.vp[c][1] = gload<f32x4_t>(vpar + 4);
+      const size_t row0 = (size_t)grp * a.S + pos0;  // wave-uniform
+      const unsigned char* kd = reinterpret_cast<const unsigned char*>(ksp[sp]) + row0 * HB;
+      const unsigned char* vd = reinterpret_cast<const unsigned char*>(vsp[sp]) + row0 * HB;
+      const unsigned char* kq = reinterpret_cast<const unsigned char*>(ksp[sp]) + par_off + row0 * 8;
+      const unsigned char* vq = reinterpret_cast<const unsigned char*>(vsp[sp]) + par_off + row0 * 8;
+      r.k[c] = gload<u32x4_t>(kd + lo_k);
+      r.kp[c][0] = gload<f32x4_t>(kq + lo_p);
+      r.kp[c][1] = gload<f32x4_t>(kq + lo_p + 16);
+      r.vp[c][0] = gload<f32x4_t>(vq + lo_p);
+      r.vp[c][1] = gload<f32x4_t>(vq + lo_p + 16);
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) r.v[c * 4 + rr] = gload<uint32_t>(vp_ + (row0 + kb * 4 + rr) * HB + ni * 4);
+      for (int rr = 0; rr < 4; ++rr) r.v[c * 4 + rr] = gload<uint32_t>(vd + lo_v + rr * HB);
     }
   };
 
@@ -531,6 +542,310 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
   attn_block_epilogue<DIHIP_BF16, HC>(a, lds, flag_lds, b, h0, nh, split);
 }
 
+// ---- 16-bit KV cache (bf16 / f16, the default cache mode) on the matrix cores -----------------------------
+// Same transposed formulation as the u4 kernel (S^T = K.Q^T, lane-local softmax, O^T = V^T.P^T with P as
+// bf16/f16 hi + lo).  K rows are A fragments as stored (lane (kb, token) <- 16 bytes = dims ks*32 + kb*8..).
+// V^T needs 8 tokens of one dim per lane: the 32-token V tile goes through a per-wave LDS tile (coalesced
+// 16-byte loads, ds_write_b128, row pitch 288 B) and comes back with ds_read_b64_tr_b16, the gfx950 transpose
+// read (tools/trread_test.cpp pins its lane mapping): two reads give the 8 k-slots of one dim tile, pitch 288
+// makes the 16 lanes of a read hit 32 distinct banks.  Registers hold ONE K tile pair and ONE V tile: V(t+1) is
+// requested as soon as V(t) sits in LDS, K(t+1) as soon as the scores of t are done -- the loads are in
+// flight during softmax and P.V without a second register set.
+constexpr int MF_VPITCH = 288;  // bytes per token row of the LDS V tile (256 + 32)
+
+__device__ __forceinline__ u32x2_t lds_read_tr16(const unsigned char* p) {
+  typedef short v4i16_ __attribute__((ext_vector_type(4)));
+  const v4i16_ r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16_*)(p));
+  return __builtin_bit_cast(u32x2_t, r);
+}
+
+template <int FT>
+__device__ __forceinline__ f32x4_t mfma_ft(const u32x4_t& a_, const u32x4_t& b_, const f32x4_t& c_) {
+  if constexpr (FT == DIHIP_BF16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a_), __builtin_bit_cast(bf16x8_t, b_), c_, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a_), __builtin_bit_cast(f16x8_t, b_), c_, 0, 0, 0);
+}
+
+template <int FT>
+__device__ __forceinline__ uint32_t pack_ft2(float a_, float b_) {
+  if constexpr (FT == DIHIP_BF16) return pack_bf16x2(a_, b_);
+  else return f32_to_ft_bits<FT>(a_) | (f32_to_ft_bits<FT>(b_) << 16);
+}
+
+// MODE = DIHIP_KV_NONE: rows are FT.  MODE = DIHIP_KV_I8: rows are int8 with per-token {zero, scale}; bytes become
+// exact FT integers 128 + q (byte ^ 0x80 -> v_cvt_f32_ubyte -> packed convert) on the way to the K fragments / the LDS
+// V tile, and zero-points and scales are applied to the f32 scores and to P exactly as in the u4 kernel.
+template <int FT, int MODE>
+__global__ __launch_bounds__(ATTN_THREADS, 2) void span_attn_ft_mfma_kernel(const AttnArgs a) {
+  constexpr int H = 128;
+  constexpr int HC = MF_HC;
+  constexpr bool Q8 = MODE == DIHIP_KV_I8;
+  constexpr int ROWB = Q8 ? H : H * 2;  // bytes per token-head row in the span
+  constexpr int EPI_BYTES = (4 * HC * ATTN_PSTRIDE + 4) * 4;
+  constexpr int VT_BYTES = 4 * MF_TOK * MF_VPITCH;
+  // the per-wave V tiles and the epilogue records share one buffer (a barrier separates the two uses)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[EPI_BYTES > VT_BYTES ? EPI_BYTES : VT_BYTES];
+  float* lds = reinterpret_cast<float*>(smem);
+  unsigned* flag_lds = reinterpret_cast<unsigned*>(lds + 4 * HC * ATTN_PSTRIDE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kb = lane >> 4, ni = lane & 15;
+  const int split = blockIdx.x;
+  const int grp = blockIdx.y / a.nchunks, hc = blockIdx.y % a.nchunks;
+  const int b = blockIdx.z;
+  const int h0 = grp * a.hpg + hc * HC;
+  const int nh = min(HC, a.hpg - hc * HC);
+  unsigned char* vt = smem + wave * (MF_TOK * MF_VPITCH);
+
+  const int len = (int)a.seq_lens[b];
+  const int tps = ((len + a.nsplits - 1) / a.nsplits + 31) & ~31;
+  const int t0 = split * tps;
+  const int t1 = min(len, t0 + tps);
+  const void* const* ksp = a.kspans + (size_t)b * a.span_stride;
+  const void* const* vsp = a.vspans + (size_t)b * a.span_stride;
+  const size_t par_off = (size_t)a.g * a.S * ROWB;  // int8: (zero, scale) pairs follow the data of all groups
+
+  // K: tile c.  FT rows: k-step ks = dims ks*32 + kb*8.. (4 x 16 B per token);  int8 rows: dims kb*32.. (2 x 16 B)
+  u32x4_t kreg[2][Q8 ? 2 : 4];
+  // V: FT rows: load i = tokens i*4 + (lane>>4), bytes (lane&15)*16..;  int8: tokens i*8 + (lane>>3), bytes (lane&7)*16..
+  u32x4_t vreg[Q8 ? 4 : 8];
+  f32x4_t kpar[Q8 ? 2 : 1][2], vpar[Q8 ? 2 : 1][2];  // int8: {zero, scale} of tokens c*16 + kb*4 + {0,1 | 2,3}
+  // tile bases are wave-uniform (scalar span pointer loads); tokens past the range re-read the last valid
+  // token of the tile (finite data: an uninitialised row could hold NaN bit patterns, and 0 * NaN = NaN)
+  auto tile_base = [&](int tb, int c, int& row0, int& last) {
+    int base = tb + c * 16;
+    base = base < t1 ? base : ((t1 - 1) & ~15);
+    const int sp = __builtin_amdgcn_readfirstlane(base / a.S);
+    row0 = grp * a.S + (base - sp * a.S);
+    last = min(15, t1 - 1 - base);  // last valid token of the tile, relative
+    return sp;
+  };
+  auto load_k = [&](int tb) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      int row0, last;
+      const int sp = tile_base(tb, c, row0, last);
+      const unsigned char* kbase = reinterpret_cast<const unsigned char*>(ksp[sp]);
+      const unsigned char* kd = kbase + (size_t)row0 * ROWB;
+      if constexpr (Q8) {
+        const uint32_t off = (uint32_t)(min(ni, last) * ROWB + kb * 32);
+        kreg[c][0] = gload<u32x4_t>(kd + off);
+        kreg[c][1] = gload<u32x4_t>(kd + off + 16);
+        const unsigned char* kq = kbase + par_off + (size_t)row0 * 8 + kb * 32;
+        kpar[c][0] = gload<f32x4_t>(kq);
+        kpar[c][1] = gload<f32x4_t>(kq + 16);
+      } else {
+        const uint32_t off = (uint32_t)(min(ni, last) * ROWB + kb * 16);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kreg[c][ks] = gload<u32x4_t>(kd + off + ks * 64);
+      }
+    }
+  };
+  auto load_v = [&](int tb) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      int row0, last;
+      const int sp = tile_base(tb, c, row0, last);
+      const unsigned char* vbase = reinterpret_cast<const unsigned char*>(vsp[sp]);
+      const unsigned char* vd = vbase + (size_t)row0 * ROWB;
+      if constexpr (Q8) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const uint32_t off = (uint32_t)(min(i * 8 + (lane >> 3), last) * ROWB + (lane & 7) * 16);
+          vreg[c * 2 + i] = gload<u32x4_t>(vd + off);
+        }
+        const unsigned char* vq = vbase + par_off + (size_t)row0 * 8 + kb * 32;
+        vpar[c][0] = gload<f32x4_t>(vq);
+        vpar[c][1] = gload<f32x4_t>(vq + 16);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t off = (uint32_t)(min(i * 4 + (lane >> 4), last) * ROWB + (lane & 15) * 16);
+          vreg[c * 4 + i] = gload<u32x4_t>(vd + off);
+        }
+      }
+    }
+  };
+  // 4 int8 bytes of a dword -> 4 exact FT values 128 + q (two packed dwords)
+  auto expand8 = [&](uint32_t d0, uint32_t d1) {  // 8 bytes -> one MFMA operand register quad
+    const uint32_t u0 = d0 ^ 0x80808080u, u1 = d1 ^ 0x80808080u;
+    return u32x4_t{pack_ft2<FT>((float)(u0 & 0xFFu), (float)((u0 >> 8) & 0xFFu)),
+                   pack_ft2<FT>((float)((u0 >> 16) & 0xFFu), (float)(u0 >> 24)),
+                   pack_ft2<FT>((float)(u1 & 0xFFu), (float)((u1 >> 8) & 0xFFu)),
+                   pack_ft2<FT>((float)((u1 >> 16) & 0xFFu), (float)(u1 >> 24))};
+  };
+
+  const int tb0 = t0 + wave * MF_TOK;
+  const bool active = tb0 < t1;
+  if (active) {
+    load_v(tb0);
+    load_k(tb0);
+  }
+
+  // Q as the B operand, unscaled (exact FT values): lane (kb, head ni) holds the 8 dims of k-step ks in the order
+  // of the K fragments (FT rows: ks*32 + kb*8..; int8 rows: kb*32 + ks*8..)
+  u32x4_t qf[4];
+  float qsum = 0.f;
+  {
+    const bool hv = ni < nh;
+    const uint16_t* qrow = reinterpret_cast<const uint16_t*>(a.q) + ((size_t)b * a.n + h0 + (hv ? ni : 0)) * H;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = *reinterpret_cast<const u32x4_t*>(qrow + (Q8 ? kb * 32 + ks * 8 : ks * 32 + kb * 8));
+      if (!hv) qf[ks] = u32x4_t{0u, 0u, 0u, 0u};
+      if constexpr (Q8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) qsum += ft_bits_to_f32<FT>(qf[ks][j] & 0xFFFFu) + ft_bits_to_f32<FT>(qf[ks][j] >> 16);
+      }
+    }
+    if constexpr (Q8) {
+      qsum += __shfl_xor(qsum, 16, 64);
+      qsum += __shfl_xor(qsum, 32, 64);
+    }
+  }
+
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f, czero = 0.f;
+  f32x4_t o[8];  // O^T tile dt: rows (dims) dt*16 + kb*4 + r, column = head ni
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) o[dt] = zero4;
+  // transpose-read addresses: lane p of a 16-lane group supplies row p/4 (token), columns (p%4)*4.. of a 4 x 16 block
+  const unsigned char* tr0 = vt + (kb * 4 + (ni >> 2)) * MF_VPITCH + (ni & 3) * 8;
+
+  if (active) {
+    constexpr int STEP = 4 * MF_TOK;
+    for (int tb = tb0; tb < t1; tb += STEP) {
+      // ---- V(t) into this wave's LDS tile (FT elements, [token][dim]), then request V(t + 1) into the same registers
+      float vzp[2][4], vsc[2][4];  // int8: parameters of this lane's tokens (c, kb*4 + rr), read before the refill
+      if constexpr (Q8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          unsigned char* dst = vt + (i * 8 + (lane >> 3)) * MF_VPITCH + (lane & 7) * 32;
+          *reinterpret_cast<u32x4_t*>(dst) = expand8(vreg[i][0], vreg[i][1]);
+          *reinterpret_cast<u32x4_t*>(dst + 16) = expand8(vreg[i][2], vreg[i][3]);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            vzp[c][rr] = vpar[c][rr >> 1][(rr & 1) * 2];
+            vsc[c][rr] = vpar[c][rr >> 1][(rr & 1) * 2 + 1];
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          *reinterpret_cast<u32x4_t*>(vt + (i * 4 + (lane >> 4)) * MF_VPITCH + (lane & 15) * 16) = vreg[i];
+      }
+      load_v(tb + STEP);
+      // ---- scores of the 32 tokens (transposed): sc[c][r] = token tb + c*16 + kb*4 + r, head ni
+      float sc[2][4];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        f32x4_t acc = zero4;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if constexpr (Q8) {
+            acc = mfma_ft<FT>(expand8(kreg[c][ks >> 1][(ks & 1) * 2], kreg[c][ks >> 1][(ks & 1) * 2 + 1]), qf[ks], acc);
+          } else {
+            acc = mfma_ft<FT>(kreg[c][ks], qf[ks], acc);
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          float v = acc[rr] * a.scale;
+          if constexpr (Q8) {
+            const float kz = kpar[c][rr >> 1][(rr & 1) * 2], ksc = kpar[c][rr >> 1][(rr & 1) * 2 + 1];
+            v = (ksc * a.scale) * fmaf(-(128.f + kz), qsum, acc[rr]);
+          }
+          sc[c][rr] = tb + c * 16 + kb * 4 + rr < t1 ? v : -INFINITY;
+        }
+      }
+      load_k(tb + STEP);
+      // ---- online softmax (lane-local + two cross-row shuffles)
+      float mn = m;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) mn = fmaxf(mn, sc[c][rr]);
+      mn = fmaxf(mn, __shfl_xor(mn, 16, 64));
+      mn = fmaxf(mn, __shfl_xor(mn, 32, 64));
+      const float corr = safe_exp_diff(m, mn);
+      m = mn;
+      float ps = 0.f, cz = 0.f;
+      uint32_t pk[4], pl[4];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          float pv[2], zz[2] = {0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int rr = 2 * h2 + e;
+            const float p_ = safe_exp_diff(sc[c][rr], mn);
+            ps += p_;
+            pv[e] = p_;
+            if constexpr (Q8) {
+              const bool valid = tb + c * 16 + kb * 4 + rr < t1;  // p == 0 there, but the parameters may be junk
+              pv[e] = valid ? p_ * vsc[c][rr] : 0.f;
+              zz[e] = valid ? 128.f + vzp[c][rr] : 0.f;
+            }
+          }
+          const uint32_t hi = pack_ft2<FT>(pv[0], pv[1]);
+          const float h0f = ft_bits_to_f32<FT>(hi & 0xFFFFu), h1f = ft_bits_to_f32<FT>(hi >> 16);
+          const uint32_t lo = pack_ft2<FT>(pv[0] - h0f, pv[1] - h1f);
+          pk[c * 2 + h2] = hi;
+          pl[c * 2 + h2] = lo;
+          if constexpr (Q8) {
+            cz = fmaf(h0f + ft_bits_to_f32<FT>(lo & 0xFFFFu), zz[0], cz);
+            cz = fmaf(h1f + ft_bits_to_f32<FT>(lo >> 16), zz[1], cz);
+          }
+        }
+      l = l * corr + ps;
+      czero = czero * corr + cz;
+      if (__builtin_amdgcn_ballot_w64(corr != 1.f) != 0ull) {
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) o[dt][rr] *= corr;
+      }
+      // ---- O^T += V^T . P: A = V^T from the LDS tile by transpose reads; k-slot j = token (j>>2)*16 + kb*4 + (j&3)
+      const u32x4_t pkv = {pk[0], pk[1], pk[2], pk[3]};
+      const u32x4_t plv = {pl[0], pl[1], pl[2], pl[3]};
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        const u32x2_t lo2 = lds_read_tr16(tr0 + dt * 32);
+        const u32x2_t hi2 = lds_read_tr16(tr0 + dt * 32 + 16 * MF_VPITCH);
+        const u32x4_t vf = {lo2[0], lo2[1], hi2[0], hi2[1]};
+        o[dt] = mfma_ft<FT>(vf, pkv, o[dt]);
+        o[dt] = mfma_ft<FT>(vf, plv, o[dt]);
+      }
+    }
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if constexpr (Q8) {
+    czero += __shfl_xor(czero, 16, 64);
+    czero += __shfl_xor(czero, 32, 64);
+  }
+  __syncthreads();  // every wave is done with its V tile: the buffer now holds the epilogue records
+  if (ni < nh) {
+    float* rec = lds + (wave * HC + ni) * ATTN_PSTRIDE;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      f32x4_t x = o[dt];
+      if constexpr (Q8) x = f32x4_t{x[0] - czero, x[1] - czero, x[2] - czero, x[3] - czero};
+      *reinterpret_cast<f32x4_t*>(rec + dt * 16 + kb * 4) = x;
+    }
+    if (kb == 0) {
+      rec[H] = m;
+      rec[H + 1] = l;
+    }
+  }
+  attn_block_epilogue<FT, HC>(a, lds, flag_lds, b, h0, nh, split);
+}
+
 // ------------------------------------------------------------------------------------------
 struct AttnPlan {
   int HC, nchunks, nsplits;
@@ -544,7 +859,8 @@ static bool attn_use_mfma(int mode, int dtype) {
     const char* e = getenv("DIHIP_ATTN_MFMA");
     enabled = (e && e[0] == '0') ? 0 : 1;
   }
-  return enabled && mode == DIHIP_KV_U4 && dtype == DIHIP_BF16;
+  if (!enabled || dtype == DIHIP_F32) return false;
+  return mode == DIHIP_KV_U4 ? dtype == DIHIP_BF16 : (mode == DIHIP_KV_NONE || mode == DIHIP_KV_I8);
 }
 
 static AttnPlan attn_plan(int batch, int n_heads, int n_groups, int max_seq_len, int num_cus, bool mfma = false) {
@@ -637,8 +953,16 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
   }
   const dim3 grid(p.nsplits, g * p.nchunks, batch);
   bool ok = true;
-  if (p.mfma) {
+  if (p.mfma && mode == DIHIP_KV_U4) {
     hipLaunchKernelGGL(span_attn_u4_mfma_kernel, grid, dim3(ATTN_THREADS), 0, s, a);
+  } else if (p.mfma && dtype == DIHIP_BF16 && mode == DIHIP_KV_NONE) {
+    hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_NONE>), grid, dim3(ATTN_THREADS), 0, s, a);
+  } else if (p.mfma && dtype == DIHIP_F16 && mode == DIHIP_KV_NONE) {
+    hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_F16, DIHIP_KV_NONE>), grid, dim3(ATTN_THREADS), 0, s, a);
+  } else if (p.mfma && dtype == DIHIP_BF16) {
+    hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_I8>), grid, dim3(ATTN_THREADS), 0, s, a);
+  } else if (p.mfma) {
+    hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_F16, DIHIP_KV_I8>), grid, dim3(ATTN_THREADS), 0, s, a);
   } else
 #define GO(FTV, MODEV)                                      \
   if (dtype == FTV && mode == MODEV) {                      \

@@ -205,7 +205,9 @@ int dihip_span_attn_run(void* output, const void* query, const void* const* k_sp
 
 /* Handle-free form for graph replay: sequence lengths (INCLUDING the new token) are read from
  * device memory, so nothing on the host changes between decode steps.  max_seq_len bounds the
- * split count (and the workspace).  Returns an AsStatus value.                                */
+ * split count (and the workspace).  Returns an AsStatus value.  Split sequences are combined by a
+ * second small launch; `sync` (dihip_span_attn_sync_bytes) is no longer touched and may be NULL -- it
+ * stays in the signature for callers written against the earlier in-kernel merge.              */
 size_t dihip_span_attn_decode_workspace_bytes(int batch, int n_heads, int head_size,
                                               int max_seq_len, int num_cus);
 int dihip_span_attn_decode(void* stream, void* output, const void* query,

@@ -117,6 +117,22 @@ int main(int argc, char** argv) {
           std::sort(v.begin(), v.end());
           printf("    %-15s %7.2f %7.2f %7.2f\n", names[st_], v.front(), v[v.size() / 2], v.back());
         }
+        // workgroup entry / main-loop-done / end by block index (16 bins): is the skew tied to the dispatch order?
+        if (getenv("TRACE_BINS")) {
+          const int nb = 16;
+          printf("    block bin:      entry   loop done   end   (median us of wave 0 per bin of %d blocks)\n", (blocks + nb - 1) / nb);
+          for (int bi = 0; bi < nb; ++bi) {
+            std::vector<double> e, m, z;
+            for (int b = bi * blocks / nb; b < (bi + 1) * blocks / nb; ++b) {
+              const unsigned long long* r = &ht[(size_t)b * 64];
+              if (!r[0]) continue;
+              e.push_back((double)(r[0] - t0) * 0.01); m.push_back((double)(r[4] - t0) * 0.01); z.push_back((double)(r[6] - t0) * 0.01);
+            }
+            if (e.empty()) continue;
+            std::sort(e.begin(), e.end()); std::sort(m.begin(), m.end()); std::sort(z.begin(), z.end());
+            printf("    %3d..%3d       %6.2f   %6.2f   %6.2f\n", bi * blocks / nb, (bi + 1) * blocks / nb - 1, e[e.size() / 2], m[m.size() / 2], z[z.size() / 2]);
+          }
+        }
         CK(hipFree(tr));
       }
     }
