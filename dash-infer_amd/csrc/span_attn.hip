@@ -576,11 +576,17 @@ __device__ __forceinline__ uint32_t pack_ft2(float a_, float b_) {
 // MODE = DIHIP_KV_NONE: rows are FT.  MODE = DIHIP_KV_I8: rows are int8 with per-token {zero, scale}; bytes become
 // exact FT integers 128 + q (byte ^ 0x80 -> v_cvt_f32_ubyte -> packed convert) on the way to the K fragments / the LDS
 // V tile, and zero-points and scales are applied to the f32 scores and to P exactly as in the u4 kernel.
-template <int FT, int MODE>
+// FUSED (16-bit cache only): the decode-step form.  a.q is the fused pre-Rotary qkv row, a.seq_lens the tokens already
+// cached.  Query heads are rotated in the prologue (the rotate-half partner d +- 64 of a lane's dims is k-step ks +- 2 of
+// the SAME lane); the workgroup whose range holds the new token rotates / rounds this step's K head and takes its V
+// head, one wave writes both into the span (byte-identical to DecoderCacheAppend), and every lane whose (clamped)
+// token is the new one uses the register copy -- the span row itself may not be written yet.
+template <int FT, int MODE, bool FUSED>
 __global__ __launch_bounds__(ATTN_THREADS, 2) void span_attn_ft_mfma_kernel(const AttnArgs a) {
   constexpr int H = 128;
   constexpr int HC = MF_HC;
   constexpr bool Q8 = MODE == DIHIP_KV_I8;
+  static_assert(!FUSED || MODE == DIHIP_KV_NONE, "the decode-step form covers the 16-bit cache");
   constexpr int ROWB = Q8 ? H : H * 2;  // bytes per token-head row in the span
   constexpr int EPI_BYTES = (4 * HC * ATTN_PSTRIDE + 4) * 4;
   constexpr int VT_BYTES = 4 * MF_TOK * MF_VPITCH;
@@ -599,7 +605,8 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void span_attn_ft_mfma_kernel(cons
   const int nh = min(HC, a.hpg - hc * HC);
   unsigned char* vt = smem + wave * (MF_TOK * MF_VPITCH);
 
-  const int len = (int)a.seq_lens[b];
+  const int len = (int)a.seq_lens[b] + (FUSED ? 1 : 0);
+  const int newpos = len - 1;  // FUSED: position of this step's token
   const int tps = ((len + a.nsplits - 1) / a.nsplits + 31) & ~31;
   const int t0 = split * tps;
   const int t1 = min(len, t0 + tps);
@@ -684,25 +691,82 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void span_attn_ft_mfma_kernel(cons
     load_k(tb0);
   }
 
+  // rotate-half on a lane's fragments: dims ks*32 + kb*8 + e (ks = 0, 1) pair with ks + 2; table row = position.
+  // Same arithmetic and rounding as dihip_rope_qk / the Rotary op: two products, one add, rounded to FT.
+  auto rotate = [&](u32x4_t (&f)[4], const float* cs_row) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const f32x4_t* t = reinterpret_cast<const f32x4_t*>(cs_row + (ks * 32 + kb * 8) * 2);
+      const f32x4_t c0 = t[0], c1 = t[1], c2 = t[2], c3 = t[3];  // {cos, sin} x 8 dims
+      const float cosv[8] = {c0[0], c0[2], c1[0], c1[2], c2[0], c2[2], c3[0], c3[2]};
+      const float sinv[8] = {c0[1], c0[3], c1[1], c1[3], c2[1], c2[3], c3[1], c3[3]};
+      u32x4_t lo_, hi_;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x0[2], x1[2], r0[2], r1[2];
+        x0[0] = ft_bits_to_f32<FT>(f[ks][j] & 0xFFFFu);
+        x0[1] = ft_bits_to_f32<FT>(f[ks][j] >> 16);
+        x1[0] = ft_bits_to_f32<FT>(f[ks + 2][j] & 0xFFFFu);
+        x1[1] = ft_bits_to_f32<FT>(f[ks + 2][j] >> 16);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          r0[e] = x0[e] * cosv[2 * j + e] - x1[e] * sinv[2 * j + e];
+          r1[e] = x1[e] * cosv[2 * j + e] + x0[e] * sinv[2 * j + e];
+        }
+        lo_[j] = f32_to_ft_bits<FT>(r0[0]) | (f32_to_ft_bits<FT>(r0[1]) << 16);
+        hi_[j] = f32_to_ft_bits<FT>(r1[0]) | (f32_to_ft_bits<FT>(r1[1]) << 16);
+      }
+      f[ks] = lo_;
+      f[ks + 2] = hi_;
+    }
+  };
   // Q as the B operand, unscaled (exact FT values): lane (kb, head ni) holds the 8 dims of k-step ks in the order
   // of the K fragments (FT rows: ks*32 + kb*8..; int8 rows: kb*32 + ks*8..)
   u32x4_t qf[4];
   float qsum = 0.f;
+  const size_t qrow_stride = FUSED ? (size_t)(a.n + 2 * a.g) * H : (size_t)a.n * H;
+  const float* cs_row = FUSED ? a.rope_tab + (size_t)newpos * 128 : nullptr;
   {
     const bool hv = ni < nh;
-    const uint16_t* qrow = reinterpret_cast<const uint16_t*>(a.q) + ((size_t)b * a.n + h0 + (hv ? ni : 0)) * H;
+    const uint16_t* qrow = reinterpret_cast<const uint16_t*>(a.q) + (size_t)b * qrow_stride + (size_t)(h0 + (hv ? ni : 0)) * H;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       qf[ks] = *reinterpret_cast<const u32x4_t*>(qrow + (Q8 ? kb * 32 + ks * 8 : ks * 32 + kb * 8));
-      if (!hv) qf[ks] = u32x4_t{0u, 0u, 0u, 0u};
       if constexpr (Q8) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) qsum += ft_bits_to_f32<FT>(qf[ks][j] & 0xFFFFu) + ft_bits_to_f32<FT>(qf[ks][j] >> 16);
+        for (int j = 0; j < 4; ++j) qsum += hv ? ft_bits_to_f32<FT>(qf[ks][j] & 0xFFFFu) + ft_bits_to_f32<FT>(qf[ks][j] >> 16) : 0.f;
       }
     }
+    if constexpr (FUSED) rotate(qf, cs_row);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      if (!hv) qf[ks] = u32x4_t{0u, 0u, 0u, 0u};
     if constexpr (Q8) {
       qsum += __shfl_xor(qsum, 16, 64);
       qsum += __shfl_xor(qsum, 32, 64);
+    }
+  }
+  // FUSED: this step's K (rotated, rounded) and V head of the group, as the cache will hold them
+  const bool has_new = FUSED && newpos >= t0 && newpos < t0 + tps;  // workgroup-uniform (all head chunks of the group)
+  u32x4_t knew[4] = {}, vnew = {};
+  if constexpr (FUSED) {
+    if (has_new) {
+      const uint16_t* krow = reinterpret_cast<const uint16_t*>(a.q) + (size_t)b * qrow_stride + (size_t)(a.n + grp) * H;
+      const uint16_t* vrow = krow + (size_t)a.g * H;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) knew[ks] = *reinterpret_cast<const u32x4_t*>(krow + ks * 32 + kb * 8);
+      rotate(knew, cs_row);
+      vnew = *reinterpret_cast<const u32x4_t*>(vrow + (lane & 15) * 8);
+      if (hc == 0 && wave == 0) {  // one writer per (request, group): DecoderCacheAppend
+        const int sp = newpos / a.S, pos = newpos - sp * a.S;
+        unsigned char* kd = reinterpret_cast<unsigned char*>(const_cast<void*>(ksp[sp])) + ((size_t)grp * a.S + pos) * ROWB;
+        unsigned char* vd = reinterpret_cast<unsigned char*>(const_cast<void*>(vsp[sp])) + ((size_t)grp * a.S + pos) * ROWB;
+        if (ni == 0) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) gstore<u32x4_t>(kd + ks * 64 + kb * 16, knew[ks]);
+        }
+        if (lane < 16) gstore<u32x4_t>(vd + lane * 16, vnew);
+      }
     }
   }
 
@@ -717,6 +781,24 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void span_attn_ft_mfma_kernel(cons
   if (active) {
     constexpr int STEP = 4 * MF_TOK;
     for (int tb = tb0; tb < t1; tb += STEP) {
+      // FUSED: lanes whose (clamped) token is this step's token take the register copy (see above)
+      if constexpr (FUSED) {
+        if (has_new) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            int base = tb + c * 16;
+            base = base < t1 ? base : ((t1 - 1) & ~15);
+            const int last = min(15, t1 - 1 - base);
+            if (base + min(ni, last) == newpos) {
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) kreg[c][ks] = knew[ks];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (base + min(i * 4 + (lane >> 4), last) == newpos) vreg[c * 4 + i] = vnew;
+          }
+        }
+      }
       // ---- V(t) into this wave's LDS tile (FT elements, [token][dim]), then request V(t + 1) into the same registers
       float vzp[2][4], vsc[2][4];  // int8: parameters of this lane's tokens (c, kb*4 + rr), read before the refill
       if constexpr (Q8) {
@@ -880,7 +962,12 @@ static AttnPlan attn_plan(int batch, int n_heads, int n_groups, int max_seq_len,
   // the MFMA kernel hides latency with two co-resident workgroups per CU; the VALU kernel measured best with one
   const int per_cu = wgs_per_cu > 0 ? wgs_per_cu : (mfma ? 2 : 1);
   long want = ((long)num_cus * per_cu + base - 1) / base;
-  const long max_splits = std::max(1, (max_seq_len + 127) / 128);  // >= 128 tokens per split
+  static int min_tps = -1;  // DIHIP_ATTN_SPLIT_TOKENS: fewest tokens per split (diagnostics)
+  if (min_tps < 0) {
+    const char* e = getenv("DIHIP_ATTN_SPLIT_TOKENS");
+    min_tps = e ? std::max(32, atoi(e)) : 128;
+  }
+  const long max_splits = std::max(1, (max_seq_len + min_tps - 1) / min_tps);  // >= 128 tokens per split
   p.nsplits = (int)std::max<long>(1, std::min<long>(std::min<long>(want, max_splits), 256));
   static int force_splits = -1;  // DIHIP_ATTN_NSPLITS: diagnostics
   if (force_splits < 0) {
@@ -956,13 +1043,13 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
   if (p.mfma && mode == DIHIP_KV_U4) {
     hipLaunchKernelGGL(span_attn_u4_mfma_kernel, grid, dim3(ATTN_THREADS), 0, s, a);
   } else if (p.mfma && dtype == DIHIP_BF16 && mode == DIHIP_KV_NONE) {
-    hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_NONE>), grid, dim3(ATTN_THREADS), 0, s, a);
+    hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_NONE, false>), grid, dim3(ATTN_THREADS), 0, s, a);
   } else if (p.mfma && dtype == DIHIP_F16 && mode == DIHIP_KV_NONE) {
-    hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_F16, DIHIP_KV_NONE>), grid, dim3(ATTN_THREADS), 0, s, a);
+    hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_F16, DIHIP_KV_NONE, false>), grid, dim3(ATTN_THREADS), 0, s, a);
   } else if (p.mfma && dtype == DIHIP_BF16) {
-    hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_I8>), grid, dim3(ATTN_THREADS), 0, s, a);
+    hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_I8, false>), grid, dim3(ATTN_THREADS), 0, s, a);
   } else if (p.mfma) {
-    hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_F16, DIHIP_KV_I8>), grid, dim3(ATTN_THREADS), 0, s, a);
+    hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_F16, DIHIP_KV_I8, false>), grid, dim3(ATTN_THREADS), 0, s, a);
   } else
 #define GO(FTV, MODEV)                                      \
   if (dtype == FTV && mode == MODEV) {                      \
@@ -997,6 +1084,58 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
     return DIHIP_SA_HIP_ERROR;
   }
   return DIHIP_SA_SUCCESS;
+}
+
+// decode-step form (Rotary + cache append folded in) for the 16-bit cache: span_attn_ft_mfma_kernel<FT, NONE, true>
+size_t span_attn_fused_mfma_workspace_bytes(int batch, int n_heads, int n_groups, int max_seq_len) {
+  return attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true).partial_bytes;
+}
+
+int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* const* k_span_array, void* const* v_span_array,
+                         const uint32_t* old_seq_lens_dev, const float* rope_table, int batch, int n_heads, int n_groups,
+                         int span_len, int n_spans_per_request, int max_seq_len, int kv_mode, int dtype, float qk_scale, void* ws,
+                         size_t ws_bytes, bool* handled) {
+  *handled = false;
+  static int enabled = -1;  // DIHIP_ATTN_FUSED_MFMA=0: keep the one-wave-per-head kernel (diagnostics)
+  if (enabled < 0) {
+    const char* e = getenv("DIHIP_ATTN_FUSED_MFMA");
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!enabled || kv_mode != DIHIP_KV_NONE || !attn_use_mfma(kv_mode, dtype)) return DIHIP_SUCCESS;
+  const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true);
+  if (p.nsplits > 1 && (ws == nullptr || ws_bytes < p.partial_bytes)) return DIHIP_SUCCESS;  // caller's kernels size their own
+  *handled = true;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  AttnArgs a{};
+  a.out = output;
+  a.q = qkv;
+  a.kspans = k_span_array;
+  a.vspans = v_span_array;
+  a.seq_lens = old_seq_lens_dev;
+  a.partials = reinterpret_cast<float*>(ws);
+  a.B = batch;
+  a.n = n_heads;
+  a.g = n_groups;
+  a.hpg = n_heads / n_groups;
+  a.S = span_len;
+  a.span_stride = n_spans_per_request;
+  a.nsplits = p.nsplits;
+  a.nchunks = p.nchunks;
+  a.scale = qk_scale;
+  a.rope_tab = rope_table;
+  const dim3 grid(p.nsplits, n_groups * p.nchunks, batch);
+  if (dtype == DIHIP_BF16)
+    hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_NONE, true>), grid, dim3(ATTN_THREADS), 0, s, a);
+  else
+    hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_F16, DIHIP_KV_NONE, true>), grid, dim3(ATTN_THREADS), 0, s, a);
+  if (p.nsplits > 1) {
+    const dim3 mg(batch * n_heads), mb(128);
+    if (dtype == DIHIP_BF16)
+      hipLaunchKernelGGL(span_attn_split_merge_kernel<DIHIP_BF16>, mg, mb, 0, s, output, a.partials, n_heads, p.nsplits, 0);
+    else
+      hipLaunchKernelGGL(span_attn_split_merge_kernel<DIHIP_F16>, mg, mb, 0, s, output, a.partials, n_heads, p.nsplits, 0);
+  }
+  return launch_status();
 }
 
 }  // namespace dihip

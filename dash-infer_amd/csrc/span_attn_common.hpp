@@ -21,7 +21,18 @@ struct AttnArgs {
   int B, n, g, hpg, S, span_stride, nsplits, nchunks;
   float scale;
   int out_frag_mt;  // 0: out is row-major [B, n*H]; 1 / 2: FRAG32 with that many 16-row tiles (act_frag_index)
+  // decode-step form (Rotary + DecoderCacheAppend folded in): q points at the fused pre-Rotary qkv rows
+  // [B, (n + 2g) * H], seq_lens holds the tokens ALREADY cached (position of the new token)
+  const float* rope_tab;  // [max_pos][64] {cos, sin}; non-null selects the decode-step form
 };
+
+// decode-step form on the matrix cores (span_attn.hip); returns a DIHIP status, DIHIP_PARAM_ERROR with
+// *handled = false when the configuration is not covered (caller falls back to its own kernels)
+int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* const* k_span_array, void* const* v_span_array,
+                         const uint32_t* old_seq_lens_dev, const float* rope_table, int batch, int n_heads, int n_groups,
+                         int span_len, int n_spans_per_request, int max_seq_len, int kv_mode, int dtype, float qk_scale, void* ws,
+                         size_t ws_bytes, bool* handled);
+size_t span_attn_fused_mfma_workspace_bytes(int batch, int n_heads, int n_groups, int max_seq_len);
 
 // sum over the 16 lanes of a DPP row (all 16 lanes receive the total)
 __device__ __forceinline__ float row16_sum(float v) {

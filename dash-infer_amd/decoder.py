@@ -294,7 +294,9 @@ class DecodeSession:
         # Rotary + cache append + attention in one launch pair: the latency-bound regime (few requests:
         # one wave per query head, no cross-wave reductions).  Large batches stream thousands of tokens
         # per workgroup and use the row-sharing op-boundary kernels instead.
-        self.fused_attention = batch * self.g_loc <= 64
+        # (16-bit cache: the decode-step form runs on the matrix cores at every batch size; quantised caches have the
+        # MFMA kernels only at the op boundary, their decode-step form is the one-wave-per-head kernel)
+        self.fused_attention = kv_mode == "none" or batch * self.g_loc <= 64
         if not self.fused_attention and batch <= 32 and ops.prefers_frag(model.layers[0].o, batch):
             self.attn_frag = True
             self.attn = torch.zeros(ops.act_frag_numel(batch, self.n_loc * H), dtype=dt, device=device)

@@ -44,6 +44,10 @@ def run(B, n, g, L, mode, S=128, H=128, layers=8):
     byts = B * 2 * g * L * kvb
     print(f"B={B} n={n} g={g} L={L} kv={mode}: {us:.1f} us/layer, {byts/1e6:.1f} MB -> {byts/us/1e3:.0f} GB/s")
 
-for mode in ("none", "i8", "u4"):
-    run(32, 28, 4, 2048, mode)
-    run(16, 8, 1, 4096, mode)
+if len(sys.argv) > 1:   # e.g. "1,4,8,16": batch sweep of the 7B shape with the 16-bit cache
+    for B in [int(x) for x in sys.argv[1].split(",")]:
+        run(B, 28, 4, 2048, "none")
+else:
+    for mode in ("none", "i8", "u4"):
+        run(32, 28, 4, 2048, mode)
+        run(16, 8, 1, 4096, mode)
