@@ -133,6 +133,20 @@ int main(int argc, char** argv) {
             printf("    %3d..%3d       %6.2f   %6.2f   %6.2f\n", bi * blocks / nb, (bi + 1) * blocks / nb - 1, e[e.size() / 2], m[m.size() / 2], z[z.size() / 2]);
           }
         }
+        if (getenv("TRACE_BINS")) {
+          printf("    wave index:   ring issued  prologue done  loop done   (median us over blocks)\n");
+          for (int w = 0; w < 8; ++w) {
+            std::vector<double> a1, a3, a4;
+            for (int b = 0; b < blocks; ++b) {
+              const unsigned long long* r = &ht[((size_t)b * 8 + w) * 8];
+              if (!r[0]) continue;
+              a1.push_back((double)(r[1] - t0) * 0.01); a3.push_back((double)(r[3] - t0) * 0.01); a4.push_back((double)(r[4] - t0) * 0.01);
+            }
+            if (a4.empty()) continue;
+            std::sort(a1.begin(), a1.end()); std::sort(a3.begin(), a3.end()); std::sort(a4.begin(), a4.end());
+            printf("    wave %d          %6.2f        %6.2f       %6.2f  (min %.2f max %.2f)\n", w, a1[a1.size() / 2], a3[a3.size() / 2], a4[a4.size() / 2], a4.front(), a4.back());
+          }
+        }
         CK(hipFree(tr));
       }
     }
