@@ -1,10 +1,10 @@
-// gemv_batch_kernel.hpp -- weight-only GEMM for small decode batches (1 < M <= 32) on gfx950.
+// gemv_batch_kernel.hpp -- weight-only GEMM for small decode batches (4 < M <= 32) on gfx950: whole columns per
+// workgroup (row-major or FRAG32 activations; the panel kernel, gemm_panel_kernel.hpp, takes the large FRAG32 shapes).
 //
 // Batched decode (BASELINE configs #3 / #4: M = 32 / 16 rows) streams the same weight bytes as
 // batch 1, so it is just as launch-latency sensitive -- but M x K activations (up to 1.2 MB) no
 // longer fit in LDS, which the batch-1 kernel (gemv_stream_kernel.hpp) relies on.  This kernel keeps
-// the no-inter-workgroup-communication structure and the hand-counted weight ring of that kernel
-// and changes where the A operand lives:
+// the no-inter-workgroup-communication structure of that kernel and changes where the A operand lives:
 //
 //   * a workgroup (8 waves) owns a.upb consecutive units (a unit = one 16-column tile; SwiGLU: the gate
 //     and the up tile of the same columns) and walks them NT at a time; the 8 waves split K and combine

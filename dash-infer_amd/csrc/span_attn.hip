@@ -2,17 +2,20 @@
 //
 // Replaces the span-attention library's 3-5 kernel pipeline (QKGemv -> softmax -> QKVGemv ->
 // reduce, span-attention/src/attn/span_attention.hpp:145-211, with FT scores between kernels and
-// per-step host-built tile maps) by ONE fused single-pass kernel:
-//   * grid = (kv-splits, kv-groups x head-chunks, requests); every workgroup streams a
-//     contiguous token range of one request's K and V spans exactly once (16 lanes x 16 B cover
-//     one token-head row, a wave-load is 4 consecutive tokens = 1 KiB for 16-bit KV);
-//   * each KV row is dequantised once into registers and reused by all query heads of the GQA
-//     group (hpg <= 8 per workgroup, larger groups use several head chunks);
-//   * scores, the online softmax (running max / sum) and the P.V accumulation stay in f32
-//     registers; QK rows are reduced across the 16 lanes of a token with DPP row rotations;
-//   * partial (m, l, o) of the splits are merged by a second small launch (cheaper than an in-kernel
-//     last-arriver hand-off, whose agent-scope fences cost ~20 us per layer at batch 32);
-//     no host-side handle / tile-map rebuild per step, sequence lengths are read on the device.
+// per-step host-built tile maps) by one single-pass kernel + a small split-merge launch.  Common to all
+// kernels here: grid = (kv-splits, kv-groups x head-chunks, requests); every workgroup streams a contiguous
+// token range of one request's K and V spans exactly once, every KV row is reused by all query heads of its
+// GQA group, scores / online softmax / P.V accumulation stay in f32, split partials (m, l, o) are merged by
+// span_attn_split_merge_kernel (cheaper than an in-kernel last-arriver hand-off, whose agent-scope fences
+// cost ~20 us per layer at batch 32), and sequence lengths are read on the device: no host-side handle /
+// tile-map rebuild per step.
+//   span_attn_decode_kernel        VALU, every dtype x cache mode (16 lanes x 16 B cover a token-head row; QK
+//                                  rows reduced over the 16 lanes with DPP rotations; 8 heads per workgroup).
+//                                  Still used for f32 activations and f16 + uint4.
+//   span_attn_u4_mfma_kernel       uint4 cache, bf16 activations: S^T = K.Q^T and O^T = V^T.P^T on MFMA with an
+//                                  in-register nibble transpose for V^T.
+//   span_attn_ft_mfma_kernel       16-bit and int8 caches on MFMA (V^T through an LDS tile + transpose reads);
+//                                  FUSED = the decode-step form with Rotary and the cache append folded in.
 #include <algorithm>
 #include <cstdlib>
 #include <new>
