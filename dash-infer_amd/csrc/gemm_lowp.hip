@@ -238,7 +238,8 @@ struct GemvPlan {
   size_t lds_bytes;
 };
 
-static GemvPlan make_gemv_plan(int wbits, int M, int N, int K, int group_size, bool dual) {
+// want_blocks > 0 (expert slots: gridDim.y multiplies the grid): aim at that many workgroups instead of one per CU
+static GemvPlan make_gemv_plan(int wbits, int M, int N, int K, int group_size, bool dual, int want_blocks = 0) {
   GemvPlan p{};
   const LowpDims d = lowp_dims(wbits, N, K, group_size);
   p.ok = false;
@@ -270,6 +271,7 @@ static GemvPlan make_gemv_plan(int wbits, int M, int N, int K, int group_size, b
     upb_small = e ? atoi(e) : 0;
   }
   if (upb_small > 0 && p.upb == 1 && units > num_cus) p.upb = upb_small;
+  if (want_blocks > 0) p.upb = std::max(1, (units + want_blocks - 1) / want_blocks);
   p.blocks = (units + p.upb - 1) / p.upb;
   const int nv = p.upb * (dual ? 2 : 1);
   const int kgroups = d.group ? (d.KT + p.ktpg - 1) / p.ktpg : d.KT;
@@ -386,6 +388,61 @@ static PanelPlan make_panel_plan(int wbits, int M, int N, int K, int group_size,
   return p;
 }
 
+// One launch of M = 1 GEMVs over (token, expert-rank) slots (mixture-of-experts, moe.hip): slot s streams expert
+// slot_expert[s] of a stack of equally shaped packed weights, reads activation row s / x_div, writes row s.
+int run_gemv_slots(hipStream_t stream, int wbits, int epi, const void* x, int ldx, int x_div, const void* w0, const void* sz0,
+                   const void* w1, const void* sz1, void* y, int N, int K, int group_size, const int* slot_expert, int nslots) {
+  const bool dual = epi == EPI_SWIGLU;
+  const LowpDims d = lowp_dims(wbits, N, K, group_size);
+  DIHIP_REQUIRE(K == d.Kp && (d.group == 0 || d.group % d.KTILE == 0), DIHIP_PARAM_ERROR,
+                "moe: K = %d must be a multiple of the k-tile (%d) and groups whole k-tiles", K, d.KTILE);
+  // slots multiply the grid: about one workgroup per CU over the whole launch, at most 8 units per workgroup
+  int ncu = cached_num_cus();
+  if (ncu <= 0) ncu = 256;
+  const int want = std::max((d.NTILES + 7) / 8, (ncu + nslots - 1) / nslots);
+  const GemvPlan gp = make_gemv_plan(wbits, 1, N, K, group_size, dual, want);
+  DIHIP_REQUIRE(gp.ok && gp.lds_bytes <= 64 * 1024, DIHIP_PARAM_ERROR, "moe: unsupported expert shape N=%d K=%d", N, K);
+  GemvArgs g{};
+  g.w0 = reinterpret_cast<const u32x4_t*>(w0);
+  g.w1 = reinterpret_cast<const u32x4_t*>(w1);
+  g.sz0 = reinterpret_cast<const uint32_t*>(sz0);
+  g.sz1 = reinterpret_cast<const uint32_t*>(sz1);
+  g.x = x;
+  g.ldx = ldx;
+  g.y = y;
+  g.ldy = N;
+  g.alpha = 1.f;
+  g.act = DIHIP_ACT_NONE;
+  g.M = 1;
+  g.N = N;
+  g.K = K;
+  g.KT = d.KT;
+  g.NTILES = d.NTILES;
+  g.Gp = lowp_dims(4, N, K, group_size).Gp;
+  g.ktpg = gp.ktpg;
+  g.kgroups = gp.kgroups;
+  g.upb = gp.upb;
+  g.nu_q = d.NTILES / gp.blocks;
+  g.nu_r = d.NTILES % gp.blocks;
+  g.WK = gp.WK;
+  g.WN = gp.WN;
+  g.RS = gp.RS;
+  g.slot_expert = slot_expert;
+  g.w_estride = (size_t)d.NTILES * d.KT * 64;       // u32x4 per expert
+  g.sz_estride = (size_t)d.NTILES * g.Gp * 16;      // u32 per expert
+  g.x_div = x_div;
+  g.nslots = nslots;
+  const bool gpt = gp.ktpg == 1;
+  hipError_t e = hipErrorInvalidValue;
+#define SLOT_GO(W_, EPI_, G_) \
+  if (wbits == W_ && epi == EPI_ && (int)gpt == G_) e = launch_gemv_slots<W_, DIHIP_BF16, EPI_, G_>(g, gp.blocks, gp.lds_bytes, stream);
+  SLOT_GO(8, EPI_SWIGLU, 0) SLOT_GO(8, EPI_STD, 0) SLOT_GO(8, EPI_SWIGLU, 1) SLOT_GO(8, EPI_STD, 1)
+  SLOT_GO(4, EPI_SWIGLU, 0) SLOT_GO(4, EPI_STD, 0) SLOT_GO(4, EPI_SWIGLU, 1) SLOT_GO(4, EPI_STD, 1)
+#undef SLOT_GO
+  DIHIP_REQUIRE(e == hipSuccess, DIHIP_RUNTIME_ERROR, "moe: expert GEMV launch failed: %s", hipGetErrorString(e));
+  return DIHIP_SUCCESS;
+}
+
 static int run_gemm(hipStream_t stream, const GemmCall& c) {
   DIHIP_REQUIRE(c.M >= 0 && c.N > 0 && c.K > 0, DIHIP_PARAM_ERROR, "gemm_lowp: bad shape M=%d N=%d K=%d",
                 c.M, c.N, c.K);
@@ -430,6 +487,8 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
       g.ktpg = gp.ktpg;
       g.kgroups = gp.kgroups;
       g.upb = gp.upb;
+      g.nu_q = d.NTILES / gp.blocks;
+      g.nu_r = d.NTILES % gp.blocks;
       g.WK = gp.WK;
       g.WN = gp.WN;
       g.RS = gp.RS;

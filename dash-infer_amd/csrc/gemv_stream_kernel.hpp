@@ -112,6 +112,12 @@ struct GemvArgs {
   int ktpg;    // k-tiles per quantisation group (per-channel: >= KT)
   int kgroups; // K-split units: quantisation groups (sub-channel) or k-tiles (per-channel / W16)
   int upb;     // units (column tiles; tile pairs for SwiGLU) per workgroup
+  int nu_q, nu_r;  // NTILES / blocks, NTILES % blocks (host): block b owns nu_q + (b < nu_r) units
+  // SLOT variant only (mixture-of-experts, M = 1 per slot)
+  const int* slot_expert;        // [gridDim.y] expert of the slot, < 0: skip
+  size_t w_estride, sz_estride;  // u32x4 / u32 elements between consecutive experts' packed tensors
+  int x_div;                     // activation row of slot s = s / x_div
+  int nslots;
   int WK, WN;  // wave grid inside the workgroup, WK * WN == GEMV_WAVES, both powers of two (SwiGLU: WN >= 2)
   int RS;      // LDS activation row stride in elements (KT * KTILE + 8)
   unsigned long long* trace;  // diagnostics (dihip_debug_set_trace): [block][wave][8] wall-clock stamps, or null
@@ -126,8 +132,24 @@ __host__ __device__ inline size_t gemv_lds_bytes(int rows, int RS, int KT, int u
 }
 
 // GPT: every k-tile is one quantisation group (W4 g128, W8 g64): no accumulator carry between chunks
-template <int WBITS, int FT, int MR, int PRO, int EPI, int GPT>
-__global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArgs a) {
+// SLOT (mixture-of-experts): gridDim.y enumerates (token, expert-rank) slots; slot s streams the weights of expert
+// slot_expert[s] (all experts have one shape: base + expert * stride), reads activation row s / x_div and writes row s.
+template <int WBITS, int FT, int MR, int PRO, int EPI, int GPT, bool SLOT = false>
+__global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArgs a_in) {
+  GemvArgs a_slot;
+  if constexpr (SLOT) {
+    a_slot = a_in;
+    const int s_ = blockIdx.y;
+    const int e_ = a_in.slot_expert[s_];
+    if (e_ < 0) return;  // expert not on this rank (expert parallelism): the slot contributes nothing
+    a_slot.w0 = a_in.w0 + (size_t)e_ * a_in.w_estride;
+    a_slot.sz0 = a_in.sz0 + (size_t)e_ * a_in.sz_estride;
+    if (a_in.w1) a_slot.w1 = a_in.w1 + (size_t)e_ * a_in.w_estride;
+    if (a_in.sz1) a_slot.sz1 = a_in.sz1 + (size_t)e_ * a_in.sz_estride;
+    a_slot.x = reinterpret_cast<const uint16_t*>(a_in.x) + (size_t)(s_ / a_in.x_div) * a_in.ldx;
+    a_slot.y = reinterpret_cast<uint16_t*>(a_in.y) + (size_t)s_ * a_in.ldy;
+  }
+  const GemvArgs& a = SLOT ? a_slot : a_in;
   using WT = WTraits<WBITS>;
   using EX = ExpandV<WBITS, FT>;
   constexpr int KSTEPS = WT::KSTEPS;
@@ -198,7 +220,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
   // pairs), which spreads every workgroup's address range over the whole matrix
   const int NB = gridDim.x;
   const int u0 = blockIdx.x;
-  const int nu = (a.NTILES - u0 + NB - 1) / NB;
+  const int nu = a.nu_q + (u0 < a.nu_r ? 1 : 0);  // (NTILES - u0 + NB - 1) / NB without a device-side division
   const int nv = nu * DUAL;                  // half-units (one weight tile each)
   // K split in whole quantisation groups (per-channel: any k-tile boundary)
   const bool subc = QUANT && a.ktpg < a.KT;
@@ -543,6 +565,16 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
 
 template <int WBITS, int FT, int MR, int PRO, int EPI, int GPT>
 hipError_t launch_gemv_stream(const GemvArgs& a, int blocks, size_t lds_bytes, hipStream_t stream);
+template <int WBITS, int FT, int EPI, int GPT>
+hipError_t launch_gemv_slots(const GemvArgs& a, int blocks, size_t lds_bytes, hipStream_t stream);
+
+#define DIHIP_DEFINE_GEMV_SLOT_LAUNCH(WBITS, FT, EPI, GPT)                                                       \
+  template <>                                                                                                    \
+  hipError_t launch_gemv_slots<WBITS, FT, EPI, GPT>(const GemvArgs& a, int blocks, size_t lds_bytes, hipStream_t s) { \
+    auto kern = gemv_stream_kernel<WBITS, FT, 1, PRO_PLAIN, EPI, GPT, true>;                                     \
+    hipLaunchKernelGGL(kern, dim3(blocks, a.nslots), dim3(GEMV_THREADS), lds_bytes, s, a);                       \
+    return hipGetLastError();                                                                                    \
+  }
 
 #define DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, MR, PRO, EPI, GPT)                                    \
   template <>                                                                                     \

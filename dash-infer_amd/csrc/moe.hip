@@ -1,0 +1,147 @@
+// moe.hip -- mixture-of-experts decode path with weight-only quantised experts (BASELINE
+// configs[4]: Qwen2-57B-A14B).  Semantics of the reference's MOE operator (csrc/core/operator/general/moe/moe_op.cpp:
+// 338-460, inputs = hidden rows + router logits, weights = stacked gate_up / down projections, attributes num_experts,
+// num_experts_per_tok):
+//   float softmax over the experts (sum + 1e-12, csrc/core/kernel/cuda/softmax_low_reduce.cu:11-41), top-k of the
+//   probabilities WITHOUT renormalisation (TopKKernelLauncher, moe_op.cpp:359-365), per (token, expert):
+//   SiLU(x.Wgate) * (x.Wup) -> . Wdown  (UnaryGLU, csrc/core/kernel/cuda/unary.cu:122-132), and
+//   out[t] = sum_k score[t,k] * y[t,k] accumulated in float in rank order (finalize_new_kernel, moe.cu:386-418).
+// The reference has bf16 (MOE) and A8W8 experts only; here the experts are A16W8 / A16W4 weight-only (the quantised
+// linear of section 1), which is what "MoE int8, expert GEMM" needs on a bandwidth-bound decode step.
+//
+// MI355X shape of the problem: a decode step touches top_k experts per token, each an M = 1 GEMV over weights nobody
+// else reads -- the reference's reorder / pad / batched-GEMM machinery (moe_op.cpp:395-452) buys nothing.  One launch
+// of the decode GEMV kernel per projection covers all (token, expert-rank) slots: gridDim.y = slots, the slot's
+// expert index offsets the weight base (gemv_stream_kernel<..., SLOT = true>), SwiGLU is fused into the gate/up
+// launch, and a small kernel applies the routing weights.  No host work per step: routing results stay on the device.
+#include <algorithm>
+
+#include "device_utils.h"
+
+namespace dihip {
+
+int run_gemv_slots(hipStream_t stream, int wbits, int epi, const void* x, int ldx, int x_div, const void* w0, const void* sz0,
+                   const void* w1, const void* sz1, void* y, int N, int K, int group_size, const int* slot_expert, int nslots);
+constexpr int MOE_EPI_STD = 0, MOE_EPI_SWIGLU = 1;  // EPI_STD / EPI_SWIGLU of gemm_lowp_kernel.hpp
+
+struct ScoreIdx {
+  float v;
+  int i;
+};
+__device__ __forceinline__ ScoreIdx better(ScoreIdx a, ScoreIdx b) {  // larger value, lower index on ties
+  return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+
+// one wave per token: softmax over E <= 256 router logits, then top_k picks in descending order
+template <int FT>
+__global__ __launch_bounds__(64) void moe_route_kernel(float* __restrict__ scores, int* __restrict__ experts,
+                                                        const void* __restrict__ logits, int E, int top_k) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  float v[4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = lane + j * 64;
+    v[j] = e < E ? load_ft<FT>(logits, (size_t)t * E + e) : -INFINITY;
+    mx = fmaxf(mx, v[j]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] = lane + j * 64 < E ? expf(v[j] - mx) : 0.f;
+    sum += v[j];
+  }
+  sum = wave_sum(sum) + 1e-12f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = lane + j * 64 < E ? v[j] / sum : -1.f;  // probabilities; -1 = not an expert
+  for (int k = 0; k < top_k; ++k) {
+    ScoreIdx best{-2.f, 0x7fffffff};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) best = better(best, ScoreIdx{v[j], lane + j * 64});
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = better(best, ScoreIdx{__shfl_xor(best.v, o, 64), __shfl_xor(best.i, o, 64)});
+    if (lane == 0) {
+      scores[(size_t)t * top_k + k] = best.v;
+      experts[(size_t)t * top_k + k] = best.i;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (lane + j * 64 == best.i) v[j] = -1.f;  // taken
+  }
+}
+
+// out[t, :] = sum_k score[t, k] * y[t * top_k + k, :]  (float accumulation in rank order; skipped experts add nothing)
+template <int FT>
+__global__ __launch_bounds__(256) void moe_finalize_kernel(void* __restrict__ out, const void* __restrict__ y,
+                                                           const float* __restrict__ scores, const int* __restrict__ experts,
+                                                           int top_k, int cols) {
+  const int t = blockIdx.x;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    float acc = 0.f;
+    for (int k = 0; k < top_k; ++k) {
+      const size_t s = (size_t)t * top_k + k;
+      if (experts[s] >= 0) acc = acc + scores[s] * load_ft<FT>(y, s * cols + c);
+    }
+    store_ft<FT>(out, (size_t)t * cols + c, acc);
+  }
+}
+
+}  // namespace dihip
+
+using namespace dihip;
+
+extern "C" {
+
+int dihip_moe_route(void* stream, const void* router_logits, int num_tokens, int num_experts, int top_k, float* scores,
+                    int32_t* experts, int dtype) {
+  DIHIP_REQUIRE(num_tokens >= 0 && num_experts > 0 && num_experts <= 256 && top_k > 0 && top_k <= num_experts, DIHIP_PARAM_ERROR,
+                "moe_route: need 0 < top_k <= num_experts <= 256 (moe_op.cpp:69-73)");
+  DIHIP_REQUIRE(router_logits && scores && experts, DIHIP_PARAM_ERROR, "moe_route: null pointer");
+  if (num_tokens == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == DIHIP_BF16)
+    hipLaunchKernelGGL(moe_route_kernel<DIHIP_BF16>, dim3(num_tokens), dim3(64), 0, s, scores, experts, router_logits, num_experts, top_k);
+  else if (dtype == DIHIP_F16)
+    hipLaunchKernelGGL(moe_route_kernel<DIHIP_F16>, dim3(num_tokens), dim3(64), 0, s, scores, experts, router_logits, num_experts, top_k);
+  else if (dtype == DIHIP_F32)
+    hipLaunchKernelGGL(moe_route_kernel<DIHIP_F32>, dim3(num_tokens), dim3(64), 0, s, scores, experts, router_logits, num_experts, top_k);
+  else
+    DIHIP_REQUIRE(false, DIHIP_PARAM_ERROR, "moe_route: unsupported dtype %d", dtype);
+  return launch_status();
+}
+
+size_t dihip_moe_workspace_bytes(int num_tokens, int top_k, int hidden, int proj) {
+  if (num_tokens <= 0 || top_k <= 0 || hidden <= 0 || proj <= 0) return 0;
+  const size_t slots = (size_t)num_tokens * top_k;
+  return (slots * proj * 2 + 255) / 256 * 256 + slots * hidden * 2 + 256;
+}
+
+int dihip_moe_experts(void* stream, int wbits, const void* x, const int32_t* experts, const float* scores,
+                      const void* gate_packed, const void* gate_sz, const void* up_packed, const void* up_sz,
+                      const void* down_packed, const void* down_sz, int num_tokens, int top_k, int hidden, int proj,
+                      int group_size, void* out, void* ws, size_t ws_bytes, int dtype) {
+  DIHIP_REQUIRE(wbits == 4 || wbits == 8, DIHIP_PARAM_ERROR, "moe_experts: wbits must be 4 or 8");
+  DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "moe_experts: bf16 activations only");
+  DIHIP_REQUIRE(num_tokens >= 0 && top_k > 0 && hidden > 0 && proj > 0, DIHIP_PARAM_ERROR, "moe_experts: bad shape");
+  DIHIP_REQUIRE(x && experts && scores && gate_packed && gate_sz && up_packed && up_sz && down_packed && down_sz && out,
+                DIHIP_PARAM_ERROR, "moe_experts: null pointer");
+  if (num_tokens == 0) return DIHIP_SUCCESS;
+  const size_t slots = (size_t)num_tokens * top_k;
+  DIHIP_REQUIRE(slots <= 65535, DIHIP_EXCEED_LIMIT_ERROR, "moe_experts: %zu (token, expert) slots exceed one launch (65535)", slots);
+  DIHIP_REQUIRE(ws && ws_bytes >= dihip_moe_workspace_bytes(num_tokens, top_k, hidden, proj), DIHIP_MEMORY_ERROR,
+                "moe_experts: workspace too small (%zu < %zu)", ws_bytes, dihip_moe_workspace_bytes(num_tokens, top_k, hidden, proj));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  char* act = reinterpret_cast<char*>(ws);                                   // [slots, proj]  SiLU(gate) * up
+  char* ys = act + (slots * proj * 2 + 255) / 256 * 256;                     // [slots, hidden] expert outputs
+  int st = run_gemv_slots(s, wbits, MOE_EPI_SWIGLU, x, hidden, top_k, gate_packed, gate_sz, up_packed, up_sz, act, proj, hidden,
+                          group_size, experts, (int)slots);
+  if (st) return st;
+  st = run_gemv_slots(s, wbits, MOE_EPI_STD, act, proj, 1, down_packed, down_sz, nullptr, nullptr, ys, hidden, proj, group_size,
+                      experts, (int)slots);
+  if (st) return st;
+  hipLaunchKernelGGL(moe_finalize_kernel<DIHIP_BF16>, dim3(num_tokens), dim3(256), 0, s, out, ys, scores, experts, top_k, hidden);
+  return launch_status();
+}
+
+}  // extern "C"

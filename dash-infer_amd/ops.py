@@ -119,6 +119,48 @@ def fused_norm_gemm(h, gamma, eps, pw, bias, scratch, act=None, out=None):
     return y
 
 
+# ---------------------------------------------------------------------------- mixture of experts
+class PackedExperts:
+    """num_experts equally shaped quantised matrices [K, N], each packed like PackedWeight, stacked back to back."""
+
+    def __init__(self, w, sz, wbits, N, K, group, num_experts):
+        self.w, self.sz, self.wbits, self.N, self.K, self.group, self.num_experts = w, sz, wbits, N, K, group, num_experts
+
+
+def pack_experts(qs, scales, zeros, group, wbits):
+    """qs / scales / zeros: lists (one entry per expert) in the layout pack_lowp takes."""
+    E = len(qs)
+    packed = [pack_lowp(q.contiguous(), s_.contiguous(), z.contiguous(), group, wbits) for q, s_, z in zip(qs, scales, zeros)]
+    p0 = packed[0]
+    wb = int(lib().dihip_gemm_lowp_packed_weight_bytes(wbits, p0.N, p0.K))
+    sb = int(lib().dihip_gemm_lowp_packed_sz_bytes(p0.N, p0.K, p0.group))
+    assert p0.w.numel() * p0.w.element_size() == wb and p0.sz.numel() * p0.sz.element_size() == sb
+    w = torch.cat([p.w.view(torch.uint8).reshape(-1) for p in packed])
+    sz = torch.cat([p.sz.view(torch.uint8).reshape(-1) for p in packed])
+    return PackedExperts(w, sz, wbits, p0.N, p0.K, p0.group, E)
+
+
+def moe_route(logits, top_k):
+    T, E = logits.shape
+    scores = torch.empty(T, top_k, dtype=torch.float32, device=logits.device)
+    experts = torch.empty(T, top_k, dtype=torch.int32, device=logits.device)
+    check(lib().dihip_moe_route(cur_stream(), ptr(logits), T, E, top_k, ptr(scores), ptr(experts), dt_code(logits)), "dihip_moe_route")
+    return scores, experts
+
+
+def moe_experts(x, experts, scores, gate, up, down, ws=None, out=None):
+    T, hidden = x.shape
+    top_k = experts.shape[1]
+    proj = gate.N
+    need = int(lib().dihip_moe_workspace_bytes(T, top_k, hidden, proj))
+    ws = ws if ws is not None else torch.empty(need, dtype=torch.uint8, device=x.device)
+    out = out if out is not None else torch.empty(T, hidden, dtype=x.dtype, device=x.device)
+    check(lib().dihip_moe_experts(cur_stream(), gate.wbits, ptr(x), ptr(experts), ptr(scores), ptr(gate.w), ptr(gate.sz), ptr(up.w),
+                                  ptr(up.sz), ptr(down.w), ptr(down.sz), T, top_k, hidden, proj, gate.group, ptr(out), ptr(ws),
+                                  ws.numel(), dt_code(x)), "dihip_moe_experts")
+    return out
+
+
 ACT_ROWMAJOR, ACT_FRAG32 = 0, 1
 
 

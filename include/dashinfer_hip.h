@@ -143,6 +143,27 @@ int dihip_fused_gemm_addto_ex(void* stream, int wbits, const void* x, const void
                               int K, int group_size, void* ws, size_t ws_bytes, void* sync, int dtype,
                               int x_layout);
 
+/* ---------------------------------------------------------------------------------------------
+ * 1b. Mixture-of-experts decode path with weight-only experts (BASELINE configs[4]).
+ *     Semantics of the reference's MOE operator (csrc/core/operator/general/moe/moe_op.cpp:338-460): float
+ *     softmax of the router logits, top-k WITHOUT renormalisation, per (token, expert) SiLU(x.Wgate) * (x.Wup)
+ *     -> .Wdown, out[t] = sum_k score[t,k] * y[t,k] in float.  The reference's experts are bf16 / A8W8; these
+ *     are A16W8 / A16W4 (section 1 quantiser and packing), one packed tensor per expert, experts stacked back
+ *     to back: expert e of a projection lives at  base + e * dihip_gemm_lowp_packed_weight_bytes(wbits, N, K)
+ *     (scales/zeros: + e * dihip_gemm_lowp_packed_sz_bytes(N, K, group)); gate/up: N = proj, K = hidden;
+ *     down: N = hidden, K = proj.  An expert index < 0 in `experts` skips the slot (expert parallelism).
+ *   dihip_moe_route  : scores f32 [T, top_k], experts i32 [T, top_k] (descending probability, lower index
+ *                      first on ties) from router logits FT/f32 [T, num_experts <= 256]
+ *   dihip_moe_experts: out FT [T, hidden]; ws >= dihip_moe_workspace_bytes (no initialisation needed)      */
+int dihip_moe_route(void* stream, const void* router_logits, int num_tokens, int num_experts, int top_k,
+                    float* scores, int32_t* experts, int dtype);
+size_t dihip_moe_workspace_bytes(int num_tokens, int top_k, int hidden, int proj);
+int dihip_moe_experts(void* stream, int wbits, const void* x, const int32_t* experts, const float* scores,
+                      const void* gate_packed, const void* gate_sz, const void* up_packed,
+                      const void* up_sz, const void* down_packed, const void* down_sz, int num_tokens,
+                      int top_k, int hidden, int proj, int group_size, void* out, void* ws,
+                      size_t ws_bytes, int dtype);
+
 /* =============================================================================================
  * 2. KV span writers (replace csrc/core/kernel/cuda/cuda_kernel_span_cache.h:12-41)
  *    span layout (bit-compatible with the reference, decoder_cache_append.cuh:33-87):

@@ -1,0 +1,114 @@
+"""GPU parity of the mixture-of-experts decode path (dihip_moe_route / dihip_moe_experts, C-ABI) against oracle/moe.py.
+
+Cases: a small expert stack for every weight format, ragged routing (ties, an expert hit by several tokens, an
+expert nobody picks), skipped slots (expert parallelism: index -1), and the Qwen2-57B-A14B shape of
+BASELINE configs[4] (64 experts, top-8, hidden 3584, expert width 2560) with oracle spot checks plus size-independent
+properties: run-to-run determinism and linearity of the combine in the routing weights.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import moe, quant
+from oracle.numerics import bf16_round
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops(pkg):
+    from dash_infer_amd import ops as _ops
+    assert torch.cuda.is_available()
+    return _ops
+
+
+def dev(a, dt=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t.to(dt) if dt is not None else t).cuda()
+
+
+def make_experts(rng, E, N, K, G, wbits):
+    qs, ss, zs = [], [], []
+    for _ in range(E):
+        W = bf16_round(rng.normal(0, 0.05, (K, N)).astype(np.float32))
+        q, s, z = (quant.iq_quantize_a16w8 if wbits == 8 else quant.iq_quantize_a16w4)(W, G, "bf16")
+        qs.append(q)
+        ss.append(s)
+        zs.append(z)
+    return qs, ss, zs
+
+
+def pack(ops, qs, ss, zs, G, wbits):
+    return ops.pack_experts([dev(q) for q in qs], [dev(s, torch.bfloat16) for s in ss], [dev(z, torch.bfloat16) for z in zs], G, wbits)
+
+
+@pytest.mark.parametrize("T,E,k", [(1, 8, 2), (5, 60, 4), (3, 64, 8), (2, 200, 6)])
+def test_route_matches_oracle(ops, T, E, k):
+    rng = np.random.default_rng(E + k)
+    logits = bf16_round(rng.normal(0, 2, (T, E)).astype(np.float32))
+    logits[0, 1] = logits[0, 3] = logits[0].max() + 1.0   # an exact tie at the top: lower index first
+    s_ref, e_ref = moe.route(logits, k)
+    for dt in (torch.bfloat16, torch.float32):
+        s, e = ops.moe_route(dev(logits, dt), k)
+        np.testing.assert_array_equal(e.cpu().numpy(), e_ref)
+        np.testing.assert_allclose(s.cpu().numpy(), s_ref, rtol=2e-6, atol=1e-9)
+    assert e_ref[0, 0] == 1 and e_ref[0, 1] == 3
+
+
+@pytest.mark.parametrize("wbits,G", [(8, -1), (8, 128), (4, 128)])
+def test_experts_small_matches_oracle(ops, wbits, G):
+    rng = np.random.default_rng(wbits * 10 + (G > 0))
+    T, E, k, hidden, proj = 4, 6, 3, 256, 384
+    x = bf16_round(rng.normal(0, 1, (T, hidden)).astype(np.float32))
+    gate, up, down = (make_experts(rng, E, proj, hidden, G, wbits), make_experts(rng, E, proj, hidden, G, wbits),
+                      make_experts(rng, E, hidden, proj, G, wbits))
+    pg, pu, pd = pack(ops, *gate, G, wbits), pack(ops, *up, G, wbits), pack(ops, *down, G, wbits)
+    logits = bf16_round(rng.normal(0, 1.5, (T, E)).astype(np.float32))
+    logits[:, 5] = -30.0            # expert 5 is never picked; expert 0 by everyone
+    logits[:, 0] = 4.0
+    scores, experts = ops.moe_route(dev(logits, torch.bfloat16), k)
+    s_ref, e_ref = moe.route(logits, k)
+    np.testing.assert_array_equal(experts.cpu().numpy(), e_ref)
+    out = ops.moe_experts(dev(x, torch.bfloat16), experts, scores, pg, pu, pd)
+    ref = moe.experts_ffn(x, e_ref, s_ref, list(zip(*gate)), list(zip(*up)), list(zip(*down)), G, wbits)
+    o = out.float().cpu().numpy()
+    np.testing.assert_allclose(o, ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max())   # bf16 intermediates (two roundings)
+    # expert parallelism: slots whose expert lives on another rank (-1) contribute nothing
+    ex2 = experts.clone()
+    ex2[:, 1] = -1
+    out2 = ops.moe_experts(dev(x, torch.bfloat16), ex2, scores, pg, pu, pd)
+    e2 = e_ref.copy()
+    e2[:, 1] = -1
+    ref2 = moe.experts_ffn(x, e2, s_ref, list(zip(*gate)), list(zip(*up)), list(zip(*down)), G, wbits)
+    np.testing.assert_allclose(out2.float().cpu().numpy(), ref2, rtol=2e-2, atol=2e-2 * np.abs(ref2).max())
+
+
+def test_experts_qwen2_57b_a14b_shape(ops):
+    """configs[4] expert shapes at int8 per-channel: 64 experts x (3584 -> 2560 gate/up, 2560 -> 3584 down), top-8."""
+    rng = np.random.default_rng(57)
+    T, E, k, hidden, proj, wbits, G = 2, 64, 8, 3584, 2560, 8, -1
+    # one random expert triple replicated with per-expert scale tweaks keeps host-side quantisation time small
+    base = make_experts(rng, 3, proj, hidden, G, wbits), make_experts(rng, 3, proj, hidden, G, wbits), make_experts(rng, 3, hidden, proj, G, wbits)
+    def stack(trip):
+        qs, ss, zs = trip
+        return ([qs[e % 3] for e in range(E)], [bf16_round(ss[e % 3] * (1.0 + 0.01 * (e // 3))) for e in range(E)],
+                [zs[e % 3] for e in range(E)])
+    gate, up, down = stack(base[0]), stack(base[1]), stack(base[2])
+    pg, pu, pd = pack(ops, *gate, G, wbits), pack(ops, *up, G, wbits), pack(ops, *down, G, wbits)
+    x = bf16_round(rng.normal(0, 1, (T, hidden)).astype(np.float32))
+    logits = bf16_round(rng.normal(0, 1, (T, E)).astype(np.float32))
+    scores, experts = ops.moe_route(dev(logits, torch.bfloat16), k)
+    xd = dev(x, torch.bfloat16)
+    out = ops.moe_experts(xd, experts, scores, pg, pu, pd)
+    assert torch.equal(out, ops.moe_experts(xd, experts, scores, pg, pu, pd))            # deterministic
+    # combine is linear in the routing weights: doubling them doubles the (pre-rounding) result exactly
+    out2 = ops.moe_experts(xd, experts, scores * 2, pg, pu, pd)
+    assert torch.equal(out2, out * 2)
+    # oracle on token 0 restricted to its first 2 experts (the oracle's python loops are slow at this size)
+    e_np, s_np = experts.cpu().numpy(), scores.cpu().numpy()
+    e1 = np.full_like(e_np, -1)
+    e1[0, :2] = e_np[0, :2]
+    part = ops.moe_experts(xd, dev(e1), scores, pg, pu, pd).float().cpu().numpy()
+    ref = moe.experts_ffn(x, e1, s_np, list(zip(*gate)), list(zip(*up)), list(zip(*down)), G, wbits)
+    np.testing.assert_allclose(part, ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max())
+    assert np.all(part[1] == 0)
