@@ -216,3 +216,50 @@ def test_span_attention_operator_prefill_over_cached_prefix(env, mode):
             continue
         assert np.array_equal(got, exp), f"K span {i}"
     m.close()
+
+
+def test_moe_a16w8_operator(env):
+    """Op type MOEA16W8 through the AsOperator interface (host/moe_op_hip.cpp): stacked int8 experts with [gate | up]
+    columns, routing from the second input, shared workspace; against oracle/moe.py; batch change -> Reshape again."""
+    from oracle import moe
+    hostapi, ops = env
+    rng = np.random.default_rng(8)
+    E, k, hidden, proj, G = 6, 2, 256, 384, -1
+    def experts(K, N):
+        qs, ss, zs = [], [], []
+        for _ in range(E):
+            W = bf16_round(rng.normal(0, 0.05, (K, N)).astype(np.float32))
+            q, s, z = quant.iq_quantize_a16w8(W, G, "bf16")
+            qs.append(q); ss.append(s); zs.append(z)
+        return np.stack(qs), np.stack(ss), np.stack(zs)
+    gq, gs, gz = experts(hidden, proj)
+    uq, us, uz = experts(hidden, proj)
+    dq, ds, dz = experts(proj, hidden)
+    m = hostapi.Model(ops.cur_stream(), 4, 2, 128, 16)
+    m.set_weight("gu", torch.from_numpy(np.concatenate([gq, uq], axis=2)).cuda(), "i8")       # [E, hidden, 2*proj]
+    m.set_weight("gu.scales", dev(np.concatenate([gs, us], axis=2)), "bf16")
+    m.set_weight("gu.zeros", dev(np.concatenate([gz, uz], axis=2)), "bf16")
+    m.set_weight("dn", torch.from_numpy(dq).cuda(), "i8")
+    m.set_weight("dn.scales", dev(ds), "bf16")
+    m.set_weight("dn.zeros", dev(dz), "bf16")
+    op = None
+    for T in (1, 5):
+        x = bf16_round(rng.normal(0, 1, (T, 1, hidden)).astype(np.float32))
+        logits = bf16_round(rng.normal(0, 1.5, (T, 1, E)).astype(np.float32))
+        m.set_tensor("x", dev(x), "bf16")
+        m.set_tensor("router", dev(logits), "bf16")
+        if op is None:
+            op = m.create_op("MOEA16W8", "decoder.layer.0.mlp.moe", ["x", "router"], ["y"],
+                             ["gu", "gu.scales", "gu.zeros", "dn", "dn.scales", "dn.zeros"], f"num_experts=i:{E};num_experts_per_tok=i:{k}")
+        m.reshape(op)
+        m.forward(op)
+        dt, shape, ptr = m.get_tensor("y")
+        assert dt == hostapi.DT["bf16"] and shape == [T, 1, hidden]
+        y = view_of(ptr, shape, torch.bfloat16).float().cpu().numpy().reshape(T, hidden)
+        s_ref, e_ref = moe.route(logits.reshape(T, E), k)
+        ref = moe.experts_ffn(x.reshape(T, hidden), e_ref, s_ref, list(zip(gq, gs, gz)), list(zip(uq, us, uz)), list(zip(dq, ds, dz)), G, 8)
+        np.testing.assert_allclose(y, ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max())
+    with pytest.raises(hostapi.HostError):   # attribute checks of MoeOp::Init (moe_op.cpp:65-80)
+        m.create_op("MOEA16W8", "bad", ["x", "router"], ["y2"], ["gu", "gu.scales", "gu.zeros", "dn", "dn.scales", "dn.zeros"],
+                    f"num_experts=i:{E}")
+    m.close()
