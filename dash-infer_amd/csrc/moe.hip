@@ -71,20 +71,36 @@ __global__ __launch_bounds__(64) void moe_route_kernel(float* __restrict__ score
   }
 }
 
-// out[t, :] = sum_k score[t, k] * y[t * top_k + k, :]  (float accumulation in rank order; skipped experts add nothing)
+// out[t, :] = sum_k score[t, k] * y[t * top_k + k, :]  (float accumulation in rank order; skipped experts add nothing).
+// grid (column chunks of 512, tokens): a thread owns two adjacent columns and issues the loads of up to 8 ranks together.
 template <int FT>
 __global__ __launch_bounds__(256) void moe_finalize_kernel(void* __restrict__ out, const void* __restrict__ y,
                                                            const float* __restrict__ scores, const int* __restrict__ experts,
                                                            int top_k, int cols) {
-  const int t = blockIdx.x;
-  for (int c = threadIdx.x; c < cols; c += 256) {
-    float acc = 0.f;
-    for (int k = 0; k < top_k; ++k) {
+  const int t = blockIdx.y;
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (c >= cols) return;
+  const bool pair = c + 1 < cols;
+  float a0 = 0.f, a1 = 0.f;
+  for (int k0 = 0; k0 < top_k; k0 += 8) {
+    float v0[8], v1[8], sc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = min(k0 + j, top_k - 1);
       const size_t s = (size_t)t * top_k + k;
-      if (experts[s] >= 0) acc = acc + scores[s] * load_ft<FT>(y, s * cols + c);
+      const bool live = k0 + j < top_k && experts[s] >= 0;
+      sc[j] = live ? scores[s] : 0.f;
+      v0[j] = live ? load_ft<FT>(y, s * cols + c) : 0.f;
+      v1[j] = live && pair ? load_ft<FT>(y, s * cols + c + 1) : 0.f;
     }
-    store_ft<FT>(out, (size_t)t * cols + c, acc);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a0 = a0 + sc[j] * v0[j];
+      a1 = a1 + sc[j] * v1[j];
+    }
   }
+  store_ft<FT>(out, (size_t)t * cols + c, a0);
+  if (pair) store_ft<FT>(out, (size_t)t * cols + c + 1, a1);
 }
 
 }  // namespace dihip
@@ -140,7 +156,8 @@ int dihip_moe_experts(void* stream, int wbits, const void* x, const int32_t* exp
   st = run_gemv_slots(s, wbits, MOE_EPI_STD, act, proj, 1, down_packed, down_sz, nullptr, nullptr, ys, hidden, proj, group_size,
                       experts, (int)slots);
   if (st) return st;
-  hipLaunchKernelGGL(moe_finalize_kernel<DIHIP_BF16>, dim3(num_tokens), dim3(256), 0, s, out, ys, scores, experts, top_k, hidden);
+  hipLaunchKernelGGL(moe_finalize_kernel<DIHIP_BF16>, dim3((hidden + 511) / 512, num_tokens), dim3(256), 0, s, out, ys, scores, experts,
+                     top_k, hidden);
   return launch_status();
 }
 
