@@ -34,7 +34,6 @@ __device__ __forceinline__ void attn_block_epilogue(const AttnArgs& a, float* ld
                                                     int split) {
   constexpr int H = 128;
   const int tid = threadIdx.x;
-  (void)flag_lds;
   __syncthreads();
   // thread -> (head, dim) pairs of the block result; kept in registers for the epilogue
   constexpr int PER_THREAD = (HC * H + ATTN_THREADS - 1) / ATTN_THREADS;
@@ -78,10 +77,48 @@ __device__ __forceinline__ void attn_block_epilogue(const AttnArgs& a, float* ld
         }
       }
     }
-    // The split partials are merged by span_attn_split_merge_kernel (next launch).  An in-kernel hand-off to
-    // the last-arriving workgroup needs an agent-scope release/acquire per workgroup (L2 write-back +
-    // invalidate): measured ~20 us per layer at batch 32 against ~3 us for the extra launch.
-    return;
+    // The split partials are normally merged by span_attn_split_merge_kernel (next launch).  An in-kernel hand-off
+    // to the last-arriving workgroup needs an agent-scope release/acquire per workgroup (L2 write-back +
+    // invalidate): measured ~20 us per layer at batch 32 against ~3 us for the extra launch.  a.counters != null
+    // selects the hand-off (small grids only, see run_decode).
+    if (a.counters == nullptr) return;
+    unsigned* counter = a.counters + (size_t)b * gridDim.y + blockIdx.y;
+    if (!arrive_and_check_last(counter, (unsigned)a.nsplits, flag_lds)) return;
+#pragma unroll
+    for (int e = 0; e < PER_THREAD; ++e) {
+      const int idx = tid + e * ATTN_THREADS;
+      const int h = idx / H, d = idx - h * H;
+      if (h < nh) {
+        const float* base = a.partials + ((size_t)b * a.n + h0 + h) * a.nsplits * ATTN_PSTRIDE;
+        float mm = -INFINITY, ll = 0.f, oo = 0.f;
+        for (int sb = 0; sb < a.nsplits; sb += 16) {
+          float mv[16], lv[16], ov[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const bool in = sb + j < a.nsplits;
+            const float* rec = base + (size_t)(in ? sb + j : 0) * ATTN_PSTRIDE;
+            mv[j] = in ? rec[H] : -INFINITY;
+            lv[j] = in ? rec[H + 1] : 0.f;
+            ov[j] = in ? rec[d] : 0.f;
+          }
+          float bmx = mm;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) bmx = fmaxf(bmx, mv[j]);
+          const float carry = safe_exp_diff(mm, bmx);
+          ll *= carry;
+          oo *= carry;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const float c = safe_exp_diff(mv[j], bmx);
+            ll = fmaf(lv[j], c, ll);
+            oo = fmaf(ov[j], c, oo);
+          }
+          mm = bmx;
+        }
+        bo[e] = oo;
+        bl[e] = ll;
+      }
+    }
   }
 #pragma unroll
   for (int e = 0; e < PER_THREAD; ++e) {
@@ -1024,7 +1061,13 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
   a.vspans = vs;
   a.seq_lens = seq_lens_dev;
   a.partials = reinterpret_cast<float*>(ws);
-  a.counters = counters;
+  static int ticket_max = -1;  // DIHIP_ATTN_TICKET_MAX_WGS: in-kernel last-arriver merge up to this many workgroups (0 = never)
+  if (ticket_max < 0) {
+    const char* e = getenv("DIHIP_ATTN_TICKET_MAX_WGS");
+    ticket_max = e ? atoi(e) : 0;
+  }
+  const bool ticket = counters != nullptr && p.nsplits > 1 && (long)p.nsplits * g * p.nchunks * batch <= ticket_max;
+  a.counters = ticket ? counters : nullptr;
   a.B = batch;
   a.n = n;
   a.g = g;
@@ -1072,7 +1115,7 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
     set_last_error("span_attn: unsupported dtype %d / kv mode %d", dtype, mode);
     return DIHIP_SA_PARAM_ERROR;
   }
-  if (p.nsplits > 1) {
+  if (p.nsplits > 1 && !ticket) {
     const dim3 mg(batch * n), mb(128);
     if (dtype == DIHIP_BF16)
       hipLaunchKernelGGL(span_attn_split_merge_kernel<DIHIP_BF16>, mg, mb, 0, s, out, a.partials, n, p.nsplits, a.out_frag_mt);
