@@ -77,6 +77,20 @@ __device__ __forceinline__ uint32_t f32_to_ft_bits(float f) {
   if constexpr (FT == DIHIP_BF16) return f32_to_bf16_bits(f);
   else return f32_to_f16_bits(f);
 }
+// two f32 -> two packed FT (round to nearest even): ONE v_cvt_pk_bf16_f32 on gfx950 for bf16
+template <int FT>
+__device__ __forceinline__ uint32_t pack_ft2(float a, float b) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  const f32x2_ v = {a, b};
+  if constexpr (FT == DIHIP_BF16) {
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
+  } else {
+    typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_));
+  }
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) { return pack_ft2<DIHIP_BF16>(a, b); }
 template <int FT>
 __device__ __forceinline__ float ft_round(float f) {
   return ft_bits_to_f32<FT>(f32_to_ft_bits<FT>(f));

@@ -49,8 +49,9 @@ template <int FT, int MT>
 __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const PrefillArgs a) {
   constexpr int H = 128;
   constexpr int PF_QROWS = 64 * MT;  // query rows per workgroup (4 waves x 16 x MT)
-  __shared__ __attribute__((aligned(16))) uint16_t ks[PF_KEYS * PF_KPITCH];          // K tile [key][dim]
-  __shared__ __attribute__((aligned(16))) uint16_t vt[H * PF_VPITCH];                // V tile transposed [dim][key]
+  // two copies of each tile: the next tile is written while the current one is read, one barrier per tile
+  __shared__ __attribute__((aligned(16))) uint16_t ks_buf[2][PF_KEYS * PF_KPITCH];   // K tile [key][dim]
+  __shared__ __attribute__((aligned(16))) uint16_t vt_buf[2][H * PF_VPITCH];         // V tile transposed [dim][key]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int ni = lane & 15, kb = lane >> 4;
@@ -90,8 +91,11 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
     // keys needed by this query tile: up to the diagonal of its last row
     const int wg_last_q = min(a.seq_q, (qt + 1) * PF_QROWS) - 1;
     const int k_end = a.causal ? min(a.seq_k, wg_last_q + shift + 1) : a.seq_k;
+    const float sl2 = a.alpha * 1.44269504088896341f;  // exp(alpha * s) = exp2(sl2 * s)
 
-    // global -> register prefetch of one K/V tile; written to LDS at the top of the next iteration
+    // global -> register prefetch of one K/V tile, two tiles ahead of the MFMAs: registers hold tile i + 1 while
+    // tile i is consumed from LDS.  Rows are clamped, so the loads (and the LDS writes) need no guard -- a load
+    // behind a branch would cost a full vmcnt(0) at the join.
     u32x4_t kreg[2], vreg[2];
     auto load_tile = [&](int k0) {
 #pragma unroll
@@ -104,31 +108,38 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
         vreg[it] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(a.v) + off);
       }
     };
-    if (k_end > 0) load_tile(0);
-    for (int k0 = 0; k0 < k_end; k0 += PF_KEYS) {
-      __syncthreads();  // previous tile fully consumed
-      {
-        const int m = tid >> 4, dc = tid & 15;
-        *reinterpret_cast<u32x4_t*>(ks + (2 * m) * PF_KPITCH + dc * 8) = kreg[0];
-        *reinterpret_cast<u32x4_t*>(ks + (2 * m + 1) * PF_KPITCH + dc * 8) = kreg[1];
-        // V^T[d][2m, 2m+1] as one dword per dim; the dim order is rotated by the lane's chunk index so
-        // that the 16 lanes of a row hit different banks (rows 8 apart would otherwise share two banks)
-        uint32_t* vt32 = reinterpret_cast<uint32_t*>(vt);
-        // column of key pair (2m, 2m+1): keys are stored in the k-slot order of the P.V MFMA -- lane group kb
-        // owns keys {kb*4..+4} and {16 + kb*4..+4} of the tile (the rows its S^T accumulators hold), so its 8
-        // slots are one contiguous 16-byte read: pos(key) = ((key>>2)&3)*8 + (key>>4)*4 + (key&3)
-        const int key0 = 2 * m;
-        const int vcol = ((((key0 >> 2) & 3) * 8 + (key0 >> 4) * 4 + (key0 & 3))) >> 1;
+    auto stage_tile = [&](int buf) {
+      uint16_t* ksw = ks_buf[buf];
+      const int m = tid >> 4, dc = tid & 15;
+      *reinterpret_cast<u32x4_t*>(ksw + (2 * m) * PF_KPITCH + dc * 8) = kreg[0];
+      *reinterpret_cast<u32x4_t*>(ksw + (2 * m + 1) * PF_KPITCH + dc * 8) = kreg[1];
+      // V^T[d][2m, 2m+1] as one dword per dim; the dim order is rotated by the lane's chunk index so
+      // that the 16 lanes of a row hit different banks (rows 8 apart would otherwise share two banks)
+      uint32_t* vt32 = reinterpret_cast<uint32_t*>(vt_buf[buf]);
+      // column of key pair (2m, 2m+1): keys are stored in the k-slot order of the P.V MFMA -- lane group kb
+      // owns keys {kb*4..+4} and {16 + kb*4..+4} of the tile (the rows its S^T accumulators hold), so its 8
+      // slots are one contiguous 16-byte read: pos(key) = ((key>>2)&3)*8 + (key>>4)*4 + (key&3)
+      const int key0 = 2 * m;
+      const int vcol = ((((key0 >> 2) & 3) * 8 + (key0 >> 4) * 4 + (key0 & 3))) >> 1;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int jj = (j + dc) & 7;
-          const uint32_t lo = (vreg[0][jj >> 1] >> ((jj & 1) * 16)) & 0xFFFFu;
-          const uint32_t hi = (vreg[1][jj >> 1] >> ((jj & 1) * 16)) & 0xFFFFu;
-          vt32[((dc * 8 + jj) * PF_VPITCH) / 2 + vcol] = lo | (hi << 16);
-        }
+      for (int j = 0; j < 8; ++j) {
+        const int jj = (j + dc) & 7;
+        const uint32_t lo = (vreg[0][jj >> 1] >> ((jj & 1) * 16)) & 0xFFFFu;
+        const uint32_t hi = (vreg[1][jj >> 1] >> ((jj & 1) * 16)) & 0xFFFFu;
+        vt32[((dc * 8 + jj) * PF_VPITCH) / 2 + vcol] = lo | (hi << 16);
       }
-      __syncthreads();
-      if (k0 + PF_KEYS < k_end) load_tile(k0 + PF_KEYS);
+    };
+    load_tile(0);
+    stage_tile(0);
+    load_tile(PF_KEYS);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < k_end; k0 += PF_KEYS, buf ^= 1) {
+      // the other copy was last read one iteration ago and every wave has passed that iteration's barrier
+      stage_tile(buf ^ 1);
+      load_tile(k0 + 2 * PF_KEYS);
+      const uint16_t* ks = ks_buf[buf];
+      const uint16_t* vt = vt_buf[buf];
       const bool wave_live = !a.causal || k0 <= q0 + 16 * MT - 1 + shift;  // some key of the tile is visible to this wave
       if (wave_live && q0 < a.seq_q) {
         // ---- S^T = K.Q^T: the K fragments (A) of a key tile feed all MT query tiles (B) ----
@@ -146,47 +157,64 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
           }
         }
         // ---- mask + online softmax: lane holds S[q = q0 + mt*16 + ni][key = k0 + nt*16 + kb*4 + r] ----
+        // Scores stay raw; alpha * log2(e) is folded into the exponent (one fma + v_exp_f32 per score, alpha > 0),
+        // and the visibility test is compiled out for tiles below the diagonal (wave-uniform).
         u32x4_t pf[MT];
+        const bool tile_full = k0 + PF_KEYS <= a.seq_k && (!a.causal || k0 + PF_KEYS - 1 <= q0 + shift);
+        if (!tile_full) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int qi = q0 + mt * 16 + ni;
-          float p[2][4];
-          float mx = -INFINITY;
+          for (int mt = 0; mt < MT; ++mt) {
+            const int qi = q0 + mt * 16 + ni;
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int key = k0 + nt * 16 + kb * 4 + r;
-              const bool vis = key < a.seq_k && (!a.causal || key <= qi + shift);
-              const float sv = vis ? sacc[mt][nt][r] * a.alpha : -INFINITY;
-              p[nt][r] = sv;
-              mx = fmaxf(mx, sv);
+              for (int r = 0; r < 4; ++r) {
+                const int key = k0 + nt * 16 + kb * 4 + r;
+                const bool vis = key < a.seq_k && (!a.causal || key <= qi + shift);
+                sacc[mt][nt][r] = vis ? sacc[mt][nt][r] : -INFINITY;
+              }
+          }
+        }
+        {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            float p[2][4];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float sv = sacc[mt][nt][r];
+                p[nt][r] = sv;
+                mx = fmaxf(mx, sv);
+              }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(mrow[mt], mx * sl2);                          // log2 units
+            const float nmn = mn == -INFINITY ? 0.f : -mn;                       // a row with nothing visible yet
+            const float corr = __builtin_amdgcn_exp2f(mrow[mt] + nmn);           // exp2(-inf) = 0 on the first tile
+            mrow[mt] = mn;
+            float psum = 0.f;
+            uint32_t pk[4];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+              for (int h2 = 0; h2 < 2; ++h2) {
+                const float e0 = __builtin_amdgcn_exp2f(fmaf(p[nt][2 * h2], sl2, nmn));      // masked: exp2(-inf) = 0
+                const float e1 = __builtin_amdgcn_exp2f(fmaf(p[nt][2 * h2 + 1], sl2, nmn));
+                const uint32_t pb = pack_ft2<FT>(e0, e1);  // P is fed to the matrix core in FT; the row sum uses the same rounded values
+                psum += ft_bits_to_f32<FT>(pb & 0xFFFFu) + ft_bits_to_f32<FT>(pb >> 16);
+                pk[nt * 2 + h2] = pb;  // k-slot j <-> key (j>>2)*16 + kb*4 + (j&3): the V^T column order
+              }
+            lrow[mt] = lrow[mt] * corr + psum;
+            pf[mt] = u32x4_t{pk[0], pk[1], pk[2], pk[3]};
+            // rescale only when some query's maximum moved (wave-uniform): rare after the first tiles
+            if (__builtin_amdgcn_ballot_w64(corr != 1.f) != 0ull) {
+#pragma unroll
+              for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oacc[mt][t][r] *= corr;
             }
-          mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-          const float mn = fmaxf(mrow[mt], mx);
-          const float corr = mrow[mt] == -INFINITY ? 0.f : __expf(mrow[mt] - mn);
-          mrow[mt] = mn;
-          float psum = 0.f;
-          uint32_t pk[4];
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-              const float e0 = p[nt][2 * h2] == -INFINITY ? 0.f : __expf(p[nt][2 * h2] - mn);
-              const float e1 = p[nt][2 * h2 + 1] == -INFINITY ? 0.f : __expf(p[nt][2 * h2 + 1] - mn);
-              const uint32_t b0 = f32_to_ft_bits<FT>(e0), b1 = f32_to_ft_bits<FT>(e1);  // P is fed to the matrix core in FT
-              psum += ft_bits_to_f32<FT>(b0) + ft_bits_to_f32<FT>(b1);
-              pk[nt * 2 + h2] = b0 | (b1 << 16);  // k-slot j <-> key (j>>2)*16 + kb*4 + (j&3): the V^T column order
-            }
-          lrow[mt] = lrow[mt] * corr + psum;
-          pf[mt] = u32x4_t{pk[0], pk[1], pk[2], pk[3]};
-          // rescale only when some query's maximum moved (wave-uniform): rare after the first tiles
-          if (__builtin_amdgcn_ballot_w64(corr != 1.f) != 0ull) {
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) oacc[mt][t][r] *= corr;
           }
         }
         // ---- O^T += V^T.P^T: A fragment of dim tile t = V^T[t*16 + ni][slots kb*8 .. +8], shared by the MT query tiles ----
@@ -197,6 +225,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
           for (int mt = 0; mt < MT; ++mt) oacc[mt][t] = mfma16<FT>(vf, pf[mt], oacc[mt][t]);
         }
       }
+      __syncthreads();  // tile consumed by every wave; the copy written above becomes visible
     }
     // ---- normalise and store: lane holds O[q0 + mt*16 + ni][t*16 + kb*4 .. +4] ----
 #pragma unroll
@@ -216,7 +245,6 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
         }
       }
     }
-    __syncthreads();  // the next pass restages the LDS tiles
   }
 }
 
@@ -232,6 +260,7 @@ extern "C" int dihip_prefill_attn(void* stream, void* out, const void* q, const 
   DIHIP_REQUIRE(n_heads % n_groups == 0, DIHIP_PARAM_ERROR, "prefill_attn: nHeads must be a multiple of nGroups");
   DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16, DIHIP_PARAM_ERROR, "prefill_attn: FLOAT16 / BFLOAT16 only");
   DIHIP_REQUIRE(seq_k >= seq_q || !causal, DIHIP_PARAM_ERROR, "prefill_attn: causal attention needs seq_k >= seq_q");
+  DIHIP_REQUIRE(alpha > 0.f, DIHIP_PARAM_ERROR, "prefill_attn: the softmax scale must be positive");
   if (seq_q == 0) return DIHIP_SUCCESS;
   DIHIP_REQUIRE(out && q && k && v && seq_k > 0, DIHIP_PARAM_ERROR, "prefill_attn: null pointer / empty keys");
   DIHIP_REQUIRE(q_stride % 8 == 0 && kv_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(q) & 15) == 0 &&

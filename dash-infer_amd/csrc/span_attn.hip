@@ -353,13 +353,6 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const At
 //       (v_perm_b32); the k-slot <-> token and row <-> dim maps are free, so no LDS is involved.  The V
 //       zero-points leave through  sum_t P'_t (128 + z_t)  with the SAME rounded P'.
 // Everything else (split partials, last-arriver merge) is the epilogue shared with the VALU kernel.
-// two f32 -> packed bf16 (round to nearest even): v_cvt_pk_bf16_f32 on gfx950
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-  typedef float f32x2_ __attribute__((ext_vector_type(2)));
-  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
-  const f32x2_ v = {a, b};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
-}
 constexpr int MF_HC = 16;   // query heads per workgroup chunk (MFMA N)
 constexpr int MF_TOK = 32;  // tokens per wave iteration
 
@@ -607,11 +600,6 @@ __device__ __forceinline__ f32x4_t mfma_ft(const u32x4_t& a_, const u32x4_t& b_,
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a_), __builtin_bit_cast(f16x8_t, b_), c_, 0, 0, 0);
 }
 
-template <int FT>
-__device__ __forceinline__ uint32_t pack_ft2(float a_, float b_) {
-  if constexpr (FT == DIHIP_BF16) return pack_bf16x2(a_, b_);
-  else return f32_to_ft_bits<FT>(a_) | (f32_to_ft_bits<FT>(b_) << 16);
-}
 
 // MODE = DIHIP_KV_NONE: rows are FT.  MODE = DIHIP_KV_I8: rows are int8 with per-token {zero, scale}; bytes become
 // exact FT integers 128 + q (byte ^ 0x80 -> v_cvt_f32_ubyte -> packed convert) on the way to the K fragments / the LDS
