@@ -106,6 +106,14 @@ __device__ __forceinline__ void store_ft(void* p, size_t i, float v) {
   else ((uint16_t*)p)[i] = (uint16_t)f32_to_ft_bits<FT>(v);
 }
 
+// ds_read_b64_tr_b16: a 16-lane group reads a 4 x 16 block of 16-bit elements TRANSPOSED -- lane p supplies the address
+// of row p/4, columns (p%4)*4 .. +4, and receives column p of the block (4 rows).  Pinned by tools/trread_test.cpp.
+__device__ __forceinline__ u32x2_t lds_read_tr16(const unsigned char* p) {
+  typedef short v4i16_ __attribute__((ext_vector_type(4)));
+  const v4i16_ r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16_*)(p));
+  return __builtin_bit_cast(u32x2_t, r);
+}
+
 // FRAG32 activation layout (DIHIP_ACT_FRAG32): the 16-bit matrix x[M, K] stored as the MFMA A fragments the
 // small-batch kernel consumes -- [K/32 k-steps][MT 16-row tiles][lane = kb*16 + row][8 elements], so that one
 // fragment is ONE contiguous 1 KiB wave-load (row-major x makes it 16 pieces of 64 B from 16 rows: half-used

@@ -8,9 +8,9 @@
 //     tiles sharing every K / V fragment read) and keeps its Q fragments and the 32 x 128 f32 output
 //     accumulator in registers for the whole pass; under the causal mask a workgroup processes a
 //     query tile and its mirror, so all workgroups stream the same number of key tiles;
-//   * K and V tiles of 32 keys are staged once per workgroup in LDS: K row-major (its rows are the A
-//     fragments of K.Q^T as stored), V transposed on the way in, keys in the k-slot order of the second
-//     MFMA (so that the A fragments of V^T.P^T are contiguous 16-byte reads);
+//   * K and V tiles of 32 keys are staged once per workgroup in LDS, both row-major as they come (16-byte stores, two
+//     copies so that one barrier per tile suffices): K rows are the A fragments of K.Q^T as stored; the A fragments
+//     of V^T.P^T are read with the transposing LDS load (ds_read_b64_tr_b16) in the k-slot order P leaves the first MFMA;
 //   * TRANSPOSED formulation, S^T = K.Q^T and O^T = V^T.P^T: a lane owns one query per 16-query tile and
 //     its accumulator rows are keys / head dims.  The online softmax is lane-local (f32: alpha scale ->
 //     causal mask -> max over the lane's 8 scores + two cross-row shuffles -> exp -> P rounded to FT), P
@@ -33,7 +33,7 @@ constexpr int PF_THREADS = 256;
 // LDS feeds two MFMAs; 1 -> 64 rows per workgroup, used while the larger tile would leave CUs without work
 constexpr int PF_KEYS = 32;    // keys per tile
 constexpr int PF_KPITCH = 136; // K tile row pitch in elements (128 + 8: conflict-free b128 reads)
-constexpr int PF_VPITCH = 40;  // V^T tile row pitch in elements (32 + 8)
+constexpr int PF_VPITCH = 144; // V tile row pitch in elements (128 + 16: conflict-free transposing reads)
 
 struct PrefillArgs {
   void* out;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
   constexpr int PF_QROWS = 64 * MT;  // query rows per workgroup (4 waves x 16 x MT)
   // two copies of each tile: the next tile is written while the current one is read, one barrier per tile
   __shared__ __attribute__((aligned(16))) uint16_t ks_buf[2][PF_KEYS * PF_KPITCH];   // K tile [key][dim]
-  __shared__ __attribute__((aligned(16))) uint16_t vt_buf[2][H * PF_VPITCH];         // V tile transposed [dim][key]
+  __shared__ __attribute__((aligned(16))) uint16_t vs_buf[2][PF_KEYS * PF_VPITCH];   // V tile [key][dim]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int ni = lane & 15, kb = lane >> 4;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
     auto load_tile = [&](int k0) {
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
-        // thread -> keys (2m, 2m + 1) of the tile, dim chunk dc: the pair packs into 32-bit V^T stores
+        // thread -> keys (2m, 2m + 1) of the tile, dim chunk dc
         const int key = (tid >> 4) * 2 + it, dc = tid & 15;
         const int kr = min(k0 + key, a.seq_k - 1);
         const size_t off = (size_t)kr * a.kv_stride + (size_t)kvh * H + dc * 8;
@@ -113,21 +113,9 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
       const int m = tid >> 4, dc = tid & 15;
       *reinterpret_cast<u32x4_t*>(ksw + (2 * m) * PF_KPITCH + dc * 8) = kreg[0];
       *reinterpret_cast<u32x4_t*>(ksw + (2 * m + 1) * PF_KPITCH + dc * 8) = kreg[1];
-      // V^T[d][2m, 2m+1] as one dword per dim; the dim order is rotated by the lane's chunk index so
-      // that the 16 lanes of a row hit different banks (rows 8 apart would otherwise share two banks)
-      uint32_t* vt32 = reinterpret_cast<uint32_t*>(vt_buf[buf]);
-      // column of key pair (2m, 2m+1): keys are stored in the k-slot order of the P.V MFMA -- lane group kb
-      // owns keys {kb*4..+4} and {16 + kb*4..+4} of the tile (the rows its S^T accumulators hold), so its 8
-      // slots are one contiguous 16-byte read: pos(key) = ((key>>2)&3)*8 + (key>>4)*4 + (key&3)
-      const int key0 = 2 * m;
-      const int vcol = ((((key0 >> 2) & 3) * 8 + (key0 >> 4) * 4 + (key0 & 3))) >> 1;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int jj = (j + dc) & 7;
-        const uint32_t lo = (vreg[0][jj >> 1] >> ((jj & 1) * 16)) & 0xFFFFu;
-        const uint32_t hi = (vreg[1][jj >> 1] >> ((jj & 1) * 16)) & 0xFFFFu;
-        vt32[((dc * 8 + jj) * PF_VPITCH) / 2 + vcol] = lo | (hi << 16);
-      }
+      uint16_t* vsw = vs_buf[buf];
+      *reinterpret_cast<u32x4_t*>(vsw + (2 * m) * PF_VPITCH + dc * 8) = vreg[0];
+      *reinterpret_cast<u32x4_t*>(vsw + (2 * m + 1) * PF_VPITCH + dc * 8) = vreg[1];
     };
     load_tile(0);
     stage_tile(0);
@@ -139,7 +127,9 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
       stage_tile(buf ^ 1);
       load_tile(k0 + 2 * PF_KEYS);
       const uint16_t* ks = ks_buf[buf];
-      const uint16_t* vt = vt_buf[buf];
+      // transposing reads of the V tile (ds_read_b64_tr_b16): lane p of a 16-lane group supplies row p/4 (key kb*4 + p/4),
+      // columns (p%4)*4.. of a 4 x 16 block and receives column p%16 of it, i.e. 4 keys of ONE head dim
+      const unsigned char* tr0 = reinterpret_cast<const unsigned char*>(vs_buf[buf]) + (kb * 4 + (ni >> 2)) * (PF_VPITCH * 2) + (ni & 3) * 8;
       const bool wave_live = !a.causal || k0 <= q0 + 16 * MT - 1 + shift;  // some key of the tile is visible to this wave
       if (wave_live && q0 < a.seq_q) {
         // ---- S^T = K.Q^T: the K fragments (A) of a key tile feed all MT query tiles (B) ----
@@ -217,10 +207,13 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
             }
           }
         }
-        // ---- O^T += V^T.P^T: A fragment of dim tile t = V^T[t*16 + ni][slots kb*8 .. +8], shared by the MT query tiles ----
+        // ---- O^T += V^T.P^T: A fragment of dim tile t = V[keys kb*4.. and 16 + kb*4..][t*16 + ni], read transposed from the
+        //      row-major tile in the k-slot order of P (slot j <-> key (j>>2)*16 + kb*4 + (j&3)); shared by the MT query tiles ----
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          const u32x4_t vf = *reinterpret_cast<const u32x4_t*>(vt + (t * 16 + ni) * PF_VPITCH + kb * 8);
+          const u32x2_t lo2 = lds_read_tr16(tr0 + t * 32);
+          const u32x2_t hi2 = lds_read_tr16(tr0 + t * 32 + 16 * PF_VPITCH * 2);
+          const u32x4_t vf = {lo2[0], lo2[1], hi2[0], hi2[1]};
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) oacc[mt][t] = mfma16<FT>(vf, pf[mt], oacc[mt][t]);
         }

@@ -586,11 +586,6 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
 // flight during softmax and P.V without a second register set.
 constexpr int MF_VPITCH = 288;  // bytes per token row of the LDS V tile (256 + 32)
 
-__device__ __forceinline__ u32x2_t lds_read_tr16(const unsigned char* p) {
-  typedef short v4i16_ __attribute__((ext_vector_type(4)));
-  const v4i16_ r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16_*)(p));
-  return __builtin_bit_cast(u32x2_t, r);
-}
 
 template <int FT>
 __device__ __forceinline__ f32x4_t mfma_ft(const u32x4_t& a_, const u32x4_t& b_, const f32x4_t& c_) {
