@@ -135,6 +135,24 @@ __device__ __forceinline__ void gstore(void* p, const T& v) {
   *(__attribute__((address_space(1))) T*)(p) = v;
 }
 
+// Reductions over the 4 rows of 16 lanes (lane bits 4 and 5), result in every lane: v_permlane32_swap / v_permlane16_swap
+// (gfx950) exchange half-waves / odd-even rows between two registers -- VALU only, no LDS round trip as ds_bpermute.
+__device__ __forceinline__ float rows_max(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const float m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  const unsigned um = __float_as_uint(m);
+  const auto r2 = __builtin_amdgcn_permlane16_swap(um, um, false, false);
+  return fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+}
+__device__ __forceinline__ float rows_sum(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const float m = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  const unsigned um = __float_as_uint(m);
+  const auto r2 = __builtin_amdgcn_permlane16_swap(um, um, false, false);
+  return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

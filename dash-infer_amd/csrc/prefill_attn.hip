@@ -53,7 +53,8 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
   __shared__ __attribute__((aligned(16))) uint16_t ks_buf[2][PF_KEYS * PF_KPITCH];   // K tile [key][dim]
   __shared__ __attribute__((aligned(16))) uint16_t vs_buf[2][PF_KEYS * PF_VPITCH];   // V tile [key][dim]
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: the per-wave tile tests become scalar branches
   const int ni = lane & 15, kb = lane >> 4;
   const int head = blockIdx.y, kvh = head / (a.n_heads / a.n_groups);
   const int shift = a.seq_k - a.seq_q;  // query i sees keys j <= i + shift
@@ -132,20 +133,35 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
       const unsigned char* tr0 = reinterpret_cast<const unsigned char*>(vs_buf[buf]) + (kb * 4 + (ni >> 2)) * (PF_VPITCH * 2) + (ni & 3) * 8;
       const bool wave_live = !a.causal || k0 <= q0 + 16 * MT - 1 + shift;  // some key of the tile is visible to this wave
       if (wave_live && q0 < a.seq_q) {
-        // ---- S^T = K.Q^T: the K fragments (A) of a key tile feed all MT query tiles (B) ----
+        // ---- S^T = K.Q^T: the K fragments (A) of a key tile feed all MT query tiles (B).  All 8 fragment reads are issued
+        //      before the first MFMA (one LDS latency per tile, not four) and the 2 x MT accumulators form independent chains ----
+        u32x4_t kf[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            kf[nt][s] = *reinterpret_cast<const u32x4_t*>(ks + (nt * 16 + ni) * PF_KPITCH + kb * 8 + s * 32);
+        __builtin_amdgcn_sched_barrier(0);
         f32x4_t sacc[MT][2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) sacc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-          const uint16_t* kp = ks + (nt * 16 + ni) * PF_KPITCH + kb * 8;
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(kp + s * 32);
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) sacc[mt][nt] = mfma16<FT>(kf, qf[mt][s], sacc[mt][nt]);
-          }
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) sacc[mt][nt] = mfma16<FT>(kf[nt][s], qf[mt][s], sacc[mt][nt]);
+        // V fragments: the transposing reads fly while the softmax runs on the VALU (which has no LDS traffic of its own)
+        u32x4_t vf[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const u32x2_t lo2 = lds_read_tr16(tr0 + t * 32);
+          const u32x2_t hi2 = lds_read_tr16(tr0 + t * 32 + 16 * PF_VPITCH * 2);
+          vf[t] = u32x4_t{lo2[0], lo2[1], hi2[0], hi2[1]};
         }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- mask + online softmax: lane holds S[q = q0 + mt*16 + ni][key = k0 + nt*16 + kb*4 + r] ----
         // Scores stay raw; alpha * log2(e) is folded into the exponent (one fma + v_exp_f32 per score, alpha > 0),
         // and the visibility test is compiled out for tiles below the diagonal (wave-uniform).
@@ -178,8 +194,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
                 p[nt][r] = sv;
                 mx = fmaxf(mx, sv);
               }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = rows_max(mx);
             const float mn = fmaxf(mrow[mt], mx * sl2);                          // log2 units
             const float nmn = mn == -INFINITY ? 0.f : -mn;                       // a row with nothing visible yet
             const float corr = __builtin_amdgcn_exp2f(mrow[mt] + nmn);           // exp2(-inf) = 0 on the first tile
@@ -211,11 +226,8 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
         //      row-major tile in the k-slot order of P (slot j <-> key (j>>2)*16 + kb*4 + (j&3)); shared by the MT query tiles ----
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          const u32x2_t lo2 = lds_read_tr16(tr0 + t * 32);
-          const u32x2_t hi2 = lds_read_tr16(tr0 + t * 32 + 16 * PF_VPITCH * 2);
-          const u32x4_t vf = {lo2[0], lo2[1], hi2[0], hi2[1]};
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) oacc[mt][t] = mfma16<FT>(vf, pf[mt], oacc[mt][t]);
+          for (int mt = 0; mt < MT; ++mt) oacc[mt][t] = mfma16<FT>(vf[t], pf[mt], oacc[mt][t]);
         }
       }
       __syncthreads();  // tile consumed by every wave; the copy written above becomes visible
@@ -223,9 +235,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
     // ---- normalise and store: lane holds O[q0 + mt*16 + ni][t*16 + kb*4 .. +4] ----
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      float l = lrow[mt];
-      l += __shfl_xor(l, 16, 64);
-      l += __shfl_xor(l, 32, 64);
+      const float l = rows_sum(lrow[mt]);
       const int qi = q0 + mt * 16 + ni;
       if (qi < a.seq_q) {
         const float inv = l > 0.f ? 1.f / l : 0.f;
