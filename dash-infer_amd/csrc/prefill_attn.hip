@@ -31,8 +31,10 @@ namespace dihip {
 constexpr int PF_THREADS = 256;
 // MT = 16-row query tiles per wave (template): 2 -> 128 query rows per workgroup, every K / V fragment read from
 // LDS feeds two MFMAs; 1 -> 64 rows per workgroup, used while the larger tile would leave CUs without work
-constexpr int PF_KEYS = 32;    // keys per tile
-constexpr int PF_KPITCH = 136; // K tile row pitch in elements (128 + 8: conflict-free b128 reads)
+constexpr int PF_KEYS = 64;    // keys per tile (4 MFMA key sub-tiles: the per-tile softmax bookkeeping is paid per 64 keys)
+constexpr int PF_KPITCH = 128; // K tile row pitch in elements; the 16-byte chunk c of row r sits at chunk c ^ (r & 15):
+                               // ds_read_b128 serves lanes in groups {0-3,12-15,20-27}.. (two k-chunks x 8 rows each), which
+                               // row padding cannot spread over the 64 banks but the XOR does (0 conflicts)
 constexpr int PF_VPITCH = 144; // V tile row pitch in elements (128 + 16: conflict-free transposing reads)
 
 struct PrefillArgs {
@@ -59,6 +61,10 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
   const int head = blockIdx.y, kvh = head / (a.n_heads / a.n_groups);
   const int shift = a.seq_k - a.seq_q;  // query i sees keys j <= i + shift
   const int nqt = (a.seq_q + PF_QROWS - 1) / PF_QROWS;
+  constexpr int NT = PF_KEYS / 16;  // 16-key MFMA sub-tiles per key tile
+  const int row_bytes = a.kv_stride * 2;
+  const int kv_bytes = (a.seq_k - 1) * row_bytes + H * 2;  // the kv head's rows, from its first element
+  const int voff = (tid >> 4) * row_bytes + (tid & 15) * 16;
 
   // Causal balance: workgroup x handles query tile x and then its mirror nqt-1-x, so every
   // workgroup sees the same number of key tiles (a lone middle tile is done once).
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) oacc[mt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      mrow[mt] = -INFINITY;
+      mrow[mt] = -1e30f;
       lrow[mt] = 0.f;
     }
     // keys needed by this query tile: up to the diagonal of its last row
@@ -94,29 +100,31 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
     const int k_end = a.causal ? min(a.seq_k, wg_last_q + shift + 1) : a.seq_k;
     const float sl2 = a.alpha * 1.44269504088896341f;  // exp(alpha * s) = exp2(sl2 * s)
 
-    // global -> register prefetch of one K/V tile, two tiles ahead of the MFMAs: registers hold tile i + 1 while
-    // tile i is consumed from LDS.  Rows are clamped, so the loads (and the LDS writes) need no guard -- a load
-    // behind a branch would cost a full vmcnt(0) at the join.
-    u32x4_t kreg[2], vreg[2];
+    // global -> register prefetch of one K/V tile (T + 2 while tile T is consumed): buffer loads with a per-thread
+    // byte offset fixed for the whole pass and the tile's row offset in an SGPR -- no address arithmetic in the loop --
+    // and rows past seq_k read as zeros (hardware range check), so neither loads nor LDS writes need a guard.
+    const auto rsrc_k = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(reinterpret_cast<const uint16_t*>(a.k) + (size_t)kvh * H), 0, kv_bytes, 0x00020000);
+    const auto rsrc_v = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(reinterpret_cast<const uint16_t*>(a.v) + (size_t)kvh * H), 0, kv_bytes, 0x00020000);
+    u32x4_t kreg[4], vreg[4];  // thread -> keys (tid >> 4) + 16 * it of the tile, 16-byte dim chunk tid & 15
     auto load_tile = [&](int k0) {
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        // thread -> keys (2m, 2m + 1) of the tile, dim chunk dc
-        const int key = (tid >> 4) * 2 + it, dc = tid & 15;
-        const int kr = min(k0 + key, a.seq_k - 1);
-        const size_t off = (size_t)kr * a.kv_stride + (size_t)kvh * H + dc * 8;
-        kreg[it] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(a.k) + off);
-        vreg[it] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(a.v) + off);
+      for (int it = 0; it < 4; ++it) {
+        const int soff = (k0 + 16 * it) * row_bytes;
+        kreg[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_k, voff, soff, 0);
+        vreg[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, voff, soff, 0);
       }
     };
     auto stage_tile = [&](int buf) {
-      uint16_t* ksw = ks_buf[buf];
-      const int m = tid >> 4, dc = tid & 15;
-      *reinterpret_cast<u32x4_t*>(ksw + (2 * m) * PF_KPITCH + dc * 8) = kreg[0];
-      *reinterpret_cast<u32x4_t*>(ksw + (2 * m + 1) * PF_KPITCH + dc * 8) = kreg[1];
-      uint16_t* vsw = vs_buf[buf];
-      *reinterpret_cast<u32x4_t*>(vsw + (2 * m) * PF_VPITCH + dc * 8) = vreg[0];
-      *reinterpret_cast<u32x4_t*>(vsw + (2 * m + 1) * PF_VPITCH + dc * 8) = vreg[1];
+      const int r = tid >> 4, dc = tid & 15;  // row r + 16 * it: the XOR key r & 15 is the same for the four rows
+      uint16_t* ksw = ks_buf[buf] + r * PF_KPITCH + (dc ^ r) * 8;
+      uint16_t* vsw = vs_buf[buf] + r * PF_VPITCH + dc * 8;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        *reinterpret_cast<u32x4_t*>(ksw + it * 16 * PF_KPITCH) = kreg[it];
+        *reinterpret_cast<u32x4_t*>(vsw + it * 16 * PF_VPITCH) = vreg[it];
+      }
     };
     load_tile(0);
     stage_tile(0);
@@ -126,53 +134,61 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
     for (int k0 = 0; k0 < k_end; k0 += PF_KEYS, buf ^= 1) {
       // the other copy was last read one iteration ago and every wave has passed that iteration's barrier
       stage_tile(buf ^ 1);
-      load_tile(k0 + 2 * PF_KEYS);
       const uint16_t* ks = ks_buf[buf];
       // transposing reads of the V tile (ds_read_b64_tr_b16): lane p of a 16-lane group supplies row p/4 (key kb*4 + p/4),
       // columns (p%4)*4.. of a 4 x 16 block and receives column p%16 of it, i.e. 4 keys of ONE head dim
       const unsigned char* tr0 = reinterpret_cast<const unsigned char*>(vs_buf[buf]) + (kb * 4 + (ni >> 2)) * (PF_VPITCH * 2) + (ni & 3) * 8;
       const bool wave_live = !a.causal || k0 <= q0 + 16 * MT - 1 + shift;  // some key of the tile is visible to this wave
       if (wave_live && q0 < a.seq_q) {
-        // ---- S^T = K.Q^T: the K fragments (A) of a key tile feed all MT query tiles (B).  All 8 fragment reads are issued
-        //      before the first MFMA (one LDS latency per tile, not four) and the 2 x MT accumulators form independent chains ----
-        u32x4_t kf[2][4];
+        // ---- S^T = K.Q^T: the K fragments (A) of a key sub-tile feed all MT query tiles (B).  All 16 fragment reads are
+        //      issued before the first MFMA (one LDS latency per tile) and the NT x MT accumulators are independent chains ----
+        u32x4_t kf[NT][4];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int s = 0; s < 4; ++s)
-            kf[nt][s] = *reinterpret_cast<const u32x4_t*>(ks + (nt * 16 + ni) * PF_KPITCH + kb * 8 + s * 32);
+            kf[nt][s] = *reinterpret_cast<const u32x4_t*>(ks + (nt * 16 + ni) * PF_KPITCH + ((kb + 4 * s) ^ ni) * 8);
         __builtin_amdgcn_sched_barrier(0);
-        f32x4_t sacc[MT][2];
+        f32x4_t sacc[MT][NT];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) sacc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
+          for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) sacc[mt][nt] = mfma16<FT>(kf[nt][s], qf[mt][s], sacc[mt][nt]);
-        // V fragments: the transposing reads fly while the softmax runs on the VALU (which has no LDS traffic of its own)
-        u32x4_t vf[8];
+        __builtin_amdgcn_sched_barrier(0);
+        // the K fragment registers are free again: tile T + 2 leaves for the prefetch registers now and has the softmax,
+        // the second MFMA phase and the barrier to land
+        load_tile(k0 + 2 * PF_KEYS);
+        // V fragments of the first four dim tiles: the transposing reads fly while the softmax runs on the VALU
+        // (which has no LDS traffic of its own).  Fragment hh covers keys hh*32 ..+32 in the k-slot order of P.
+        u32x4_t vf[8][2];
+        auto read_v = [&](int t) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const u32x2_t lo2 = lds_read_tr16(tr0 + t * 32);
-          const u32x2_t hi2 = lds_read_tr16(tr0 + t * 32 + 16 * PF_VPITCH * 2);
-          vf[t] = u32x4_t{lo2[0], lo2[1], hi2[0], hi2[1]};
-        }
+          for (int hh = 0; hh < 2; ++hh) {
+            const u32x2_t lo2 = lds_read_tr16(tr0 + t * 32 + (hh * 32) * PF_VPITCH * 2);
+            const u32x2_t hi2 = lds_read_tr16(tr0 + t * 32 + (hh * 32 + 16) * PF_VPITCH * 2);
+            vf[t][hh] = u32x4_t{lo2[0], lo2[1], hi2[0], hi2[1]};
+          }
+        };
+#pragma unroll
+        for (int t = 0; t < 4; ++t) read_v(t);
         __builtin_amdgcn_sched_barrier(0);
         // ---- mask + online softmax: lane holds S[q = q0 + mt*16 + ni][key = k0 + nt*16 + kb*4 + r] ----
         // Scores stay raw; alpha * log2(e) is folded into the exponent (one fma + v_exp_f32 per score, alpha > 0),
         // and the visibility test is compiled out for tiles below the diagonal (wave-uniform).
-        u32x4_t pf[MT];
+        u32x4_t pf[MT][2];
         const bool tile_full = k0 + PF_KEYS <= a.seq_k && (!a.causal || k0 + PF_KEYS - 1 <= q0 + shift);
         if (!tile_full) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const int qi = q0 + mt * 16 + ni;
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int key = k0 + nt * 16 + kb * 4 + r;
@@ -181,54 +197,53 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
               }
           }
         }
-        {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            float p[2][4];
-            float mx = -INFINITY;
+        for (int mt = 0; mt < MT; ++mt) {
+          float mx = sacc[mt][0][0];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+          for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float sv = sacc[mt][nt][r];
-                p[nt][r] = sv;
-                mx = fmaxf(mx, sv);
-              }
-            mx = rows_max(mx);
-            const float mn = fmaxf(mrow[mt], mx * sl2);                          // log2 units
-            const float nmn = mn == -INFINITY ? 0.f : -mn;                       // a row with nothing visible yet
-            const float corr = __builtin_amdgcn_exp2f(mrow[mt] + nmn);           // exp2(-inf) = 0 on the first tile
-            mrow[mt] = mn;
-            float psum = 0.f;
-            uint32_t pk[4];
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[mt][nt][r]);
+          mx = rows_max(mx);
+          // log2 units; the running maximum starts at -1e30 (finite), so mn is finite, exp2(-inf) = 0 for masked scores
+          // and corr = 0 on the first tile without any special case
+          const float mn = fmaxf(mrow[mt], mx * sl2);
+          const float corr = __builtin_amdgcn_exp2f(mrow[mt] - mn);
+          mrow[mt] = mn;
+          float psum = 0.f;
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+          for (int nt = 0; nt < NT; ++nt) {
+            float e[4];
 #pragma unroll
-              for (int h2 = 0; h2 < 2; ++h2) {
-                const float e0 = __builtin_amdgcn_exp2f(fmaf(p[nt][2 * h2], sl2, nmn));      // masked: exp2(-inf) = 0
-                const float e1 = __builtin_amdgcn_exp2f(fmaf(p[nt][2 * h2 + 1], sl2, nmn));
-                const uint32_t pb = pack_ft2<FT>(e0, e1);  // P is fed to the matrix core in FT; the row sum uses the same rounded values
-                psum += ft_bits_to_f32<FT>(pb & 0xFFFFu) + ft_bits_to_f32<FT>(pb >> 16);
-                pk[nt * 2 + h2] = pb;  // k-slot j <-> key (j>>2)*16 + kb*4 + (j&3): the V^T column order
-              }
-            lrow[mt] = lrow[mt] * corr + psum;
-            pf[mt] = u32x4_t{pk[0], pk[1], pk[2], pk[3]};
-            // rescale only when some query's maximum moved (wave-uniform): rare after the first tiles
-            if (__builtin_amdgcn_ballot_w64(corr != 1.f) != 0ull) {
-#pragma unroll
-              for (int t = 0; t < 8; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) oacc[mt][t][r] *= corr;
+            for (int r = 0; r < 4; ++r) {
+              e[r] = __builtin_amdgcn_exp2f(fmaf(sacc[mt][nt][r], sl2, -mn));
+              psum += e[r];  // row sum in f32 (P itself is rounded to FT for the matrix core)
             }
+            // k-slot j of fragment hh <-> key hh*32 + (j>>2)*16 + kb*4 + (j&3): the order the V fragments are read in
+            pf[mt][nt >> 1][(nt & 1) * 2] = pack_ft2<FT>(e[0], e[1]);
+            pf[mt][nt >> 1][(nt & 1) * 2 + 1] = pack_ft2<FT>(e[2], e[3]);
+          }
+          lrow[mt] = lrow[mt] * corr + psum;
+          // rescale only when some query's maximum moved (wave-uniform): rare after the first tiles
+          if (__builtin_amdgcn_ballot_w64(corr != 1.f) != 0ull) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) oacc[mt][t][r] *= corr;
           }
         }
-        // ---- O^T += V^T.P^T: A fragment of dim tile t = V[keys kb*4.. and 16 + kb*4..][t*16 + ni], read transposed from the
-        //      row-major tile in the k-slot order of P (slot j <-> key (j>>2)*16 + kb*4 + (j&3)); shared by the MT query tiles ----
+        // ---- O^T += V^T.P^T: A fragment of dim tile t = V[the 32 keys of fragment hh][t*16 + ni], read transposed from the
+        //      row-major tile; shared by the MT query tiles.  Dim tiles 4..7 are read while tiles 0..3 multiply. ----
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
+        for (int t = 4; t < 8; ++t) read_v(t);
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) oacc[mt][t] = mfma16<FT>(vf[t], pf[mt], oacc[mt][t]);
-        }
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) oacc[mt][t] = mfma16<FT>(vf[t][hh], pf[mt][hh], oacc[mt][t]);
+      } else {
+        load_tile(k0 + 2 * PF_KEYS);
       }
       __syncthreads();  // tile consumed by every wave; the copy written above becomes visible
     }
@@ -264,6 +279,8 @@ extern "C" int dihip_prefill_attn(void* stream, void* out, const void* q, const 
   DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16, DIHIP_PARAM_ERROR, "prefill_attn: FLOAT16 / BFLOAT16 only");
   DIHIP_REQUIRE(seq_k >= seq_q || !causal, DIHIP_PARAM_ERROR, "prefill_attn: causal attention needs seq_k >= seq_q");
   DIHIP_REQUIRE(alpha > 0.f, DIHIP_PARAM_ERROR, "prefill_attn: the softmax scale must be positive");
+  DIHIP_REQUIRE((size_t)(seq_k + 2 * PF_KEYS + 64) * (size_t)(kv_stride > 0 ? kv_stride : 0) * 2 < (1ull << 31), DIHIP_EXCEED_LIMIT_ERROR,
+                "prefill_attn: K / V of one call must stay below 2 GiB (32-bit buffer offsets)");
   if (seq_q == 0) return DIHIP_SUCCESS;
   DIHIP_REQUIRE(out && q && k && v && seq_k > 0, DIHIP_PARAM_ERROR, "prefill_attn: null pointer / empty keys");
   DIHIP_REQUIRE(q_stride % 8 == 0 && kv_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(q) & 15) == 0 &&

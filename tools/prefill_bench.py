@@ -7,7 +7,8 @@ from __graft_entry__ import _load_pkg
 _load_pkg()
 from dash_infer_amd import ops
 n, g, H = 28, 4, 128
-for L in (512, 2048, 4096, 8192):
+Ls = [int(x) for x in sys.argv[1:]] or [512, 2048, 4096, 8192]
+for L in Ls:
     qkv = torch.randn(L, (n + 2 * g) * H, device="cuda").to(torch.bfloat16)
     q, k, v = qkv[:, : n * H], qkv[:, n * H:(n + g) * H], qkv[:, (n + g) * H:]
     out = torch.empty(L, n * H, dtype=torch.bfloat16, device="cuda")
