@@ -6,17 +6,21 @@
 // flash-style single pass written for wave64 MFMA:
 //   * workgroup = 4 waves = 128 query rows of one head; each wave owns 32 rows (two 16-row MFMA
 //     tiles sharing every K / V fragment read) and keeps its Q fragments and the 32 x 128 f32 output
-//     accumulator in registers for the whole pass; under the causal mask a workgroup processes a
-//     query tile and its mirror, so all workgroups stream the same number of key tiles;
-//   * K and V tiles of 32 keys are staged once per workgroup in LDS, both row-major as they come (16-byte stores, two
-//     copies so that one barrier per tile suffices): K rows are the A fragments of K.Q^T as stored; the A fragments
-//     of V^T.P^T are read with the transposing LDS load (ds_read_b64_tr_b16) in the k-slot order P leaves the first MFMA;
+//     accumulator in registers for the whole pass.  One-dimensional grid, longest query tiles first: in-order
+//     dispatch then balances the causal triangle greedily;
+//   * K and V tiles of 64 keys are staged once per workgroup in LDS, both row-major as they come (buffer loads with the
+//     hardware range check -> registers -> 16-byte LDS stores; two copies, so one barrier per tile; the loads of tile
+//     T + 2 leave right after the first MFMA phase of tile T).  K rows are the A fragments of K.Q^T as stored, 16-byte
+//     chunks XOR-swizzled by the row (conflict-free ds_read_b128); the A fragments of V^T.P^T are read with the
+//     transposing LDS load (ds_read_b64_tr_b16) in the k-slot order P leaves the first MFMA;
 //   * TRANSPOSED formulation, S^T = K.Q^T and O^T = V^T.P^T: a lane owns one query per 16-query tile and
-//     its accumulator rows are keys / head dims.  The online softmax is lane-local (f32: alpha scale ->
-//     causal mask -> max over the lane's 8 scores + two cross-row shuffles -> exp -> P rounded to FT), P
-//     leaves the S^T accumulators already in the B-operand layout of the second MFMA (no LDS round
-//     trip, no 16-lane DPP reductions), the running rescale is skipped while no maximum moves, and the
+//     its accumulator rows are keys / head dims.  The online softmax is lane-local (f32: causal mask on diagonal tiles
+//     only -> max over the lane's 16 scores + two v_permlane swaps -> exp2 with alpha * log2(e) folded into one fma ->
+//     P rounded to FT by the packed hardware convert), P leaves the S^T accumulators already in the B-operand layout
+//     of the second MFMA (no LDS round trip), the running rescale is skipped while no maximum moves, and the
 //     output is 4 consecutive dims per lane (8-byte stores);
+//   * per 64 MFMAs a wave issues ~180 VALU instructions (2.8 per MFMA; the first version had 4.4 on top of a VALU
+//     transpose in the staging) -- the VALU issue port, not the matrix pipe, is what bounds this kernel;
 //   * key tiles entirely above the causal diagonal are skipped.
 // Numerics follow the reference's CPU check (tests/cpp/kernel/cuda/kernel_mhaprefill_test.cpp:
 // 119-320): f32 softmax, FT inputs/outputs; P is rounded to FT before P.V as the tensor-core
@@ -44,7 +48,6 @@ struct PrefillArgs {
   const void* v;
   int seq_q, seq_k, q_stride, kv_stride, n_heads, n_groups, causal;
   float alpha;
-  int pair;  // causal balance: a workgroup takes query tile x and its mirror
 };
 
 template <int FT, int MT>
@@ -58,7 +61,11 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: the per-wave tile tests become scalar branches
   const int ni = lane & 15, kb = lane >> 4;
-  const int head = blockIdx.y, kvh = head / (a.n_heads / a.n_groups);
+  // The grid is one-dimensional, heads fastest, and under the causal mask the LONGEST query tiles come first: workgroups
+  // are dispatched in index order to whichever CU frees up, i.e. greedy longest-job-first balancing of the triangle
+  // (measured against pairing each query tile with its mirror: +9 % at 8192, +2..4 % elsewhere)
+  const int head = (int)blockIdx.x % a.n_heads;
+  const int kvh = head / (a.n_heads / a.n_groups);
   const int shift = a.seq_k - a.seq_q;  // query i sees keys j <= i + shift
   const int nqt = (a.seq_q + PF_QROWS - 1) / PF_QROWS;
   constexpr int NT = PF_KEYS / 16;  // 16-key MFMA sub-tiles per key tile
@@ -66,11 +73,9 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
   const int kv_bytes = (a.seq_k - 1) * row_bytes + H * 2;  // the kv head's rows, from its first element
   const int voff = (tid >> 4) * row_bytes + (tid & 15) * 16;
 
-  // Causal balance: workgroup x handles query tile x and then its mirror nqt-1-x, so every
-  // workgroup sees the same number of key tiles (a lone middle tile is done once).
-  const int npass = a.pair && (int)blockIdx.x != nqt - 1 - (int)blockIdx.x ? 2 : 1;
-  for (int pass = 0; pass < npass; ++pass) {
-    const int qt = pass == 0 ? (int)blockIdx.x : nqt - 1 - (int)blockIdx.x;
+  {
+    const int qt_lin = (int)blockIdx.x / a.n_heads;
+    const int qt = a.causal ? nqt - 1 - qt_lin : qt_lin;
     const int q0 = qt * PF_QROWS + wave * (16 * MT);  // first query row of this wave
 
     // Q fragments: lane (kb, ni) holds Q[q0 + mt*16 + ni][s*32 + kb*8 .. +8]
@@ -295,17 +300,12 @@ extern "C" int dihip_prefill_attn(void* stream, void* out, const void* q, const 
   if (ncu <= 0) ncu = 256;
   // 128-row query tiles read every K / V fragment once per two MFMAs; 64-row tiles double the workgroup count.
   // Two workgroups fit a CU: take the small tile while the large one would fill less than 1.5 slots (measured).
-  auto wgs = [&](int rows) {
-    const int t = (seq_q + rows - 1) / rows;
-    return (long)((causal && t >= 8) ? (t + 1) / 2 : t) * n_heads;
-  };
+  auto wgs = [&](int rows) { return (long)((seq_q + rows - 1) / rows) * n_heads; };
   const int mt = force_mt > 0 ? std::min(force_mt, 2) : (2 * wgs(128) >= 3L * ncu ? 2 : 1);
   const int rows = 64 * mt;
   const int nqt = (seq_q + rows - 1) / rows;
-  const int pair = causal && nqt >= 8;  // short sequences need every query tile as its own workgroup (measured: unpaired
-                                         // grids lose 40 % to the causal imbalance from 16 query tiles on)
-  PrefillArgs a{out, q, k, v, seq_q, seq_k, q_stride, kv_stride, n_heads, n_groups, causal, alpha, pair};
-  const dim3 grid(pair ? (nqt + 1) / 2 : nqt, n_heads);
+  PrefillArgs a{out, q, k, v, seq_q, seq_k, q_stride, kv_stride, n_heads, n_groups, causal, alpha};
+  const dim3 grid(nqt * n_heads);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == DIHIP_BF16 && mt == 2) hipLaunchKernelGGL((prefill_attn_kernel<DIHIP_BF16, 2>), grid, dim3(PF_THREADS), 0, s, a);
   else if (dtype == DIHIP_BF16) hipLaunchKernelGGL((prefill_attn_kernel<DIHIP_BF16, 1>), grid, dim3(PF_THREADS), 0, s, a);
