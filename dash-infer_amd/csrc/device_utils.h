@@ -145,12 +145,12 @@ __device__ __forceinline__ float rows_max(float v) {
   const auto r2 = __builtin_amdgcn_permlane16_swap(um, um, false, false);
   return fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
 }
-__device__ __forceinline__ float rows_sum(float v) {
+__device__ __forceinline__ float rows_sum(float v) {  // (r0 + r1) + (r2 + r3): the order of two xor-16 / xor-32 shuffles
   const unsigned u = __float_as_uint(v);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
   const float m = __uint_as_float(r[0]) + __uint_as_float(r[1]);
   const unsigned um = __float_as_uint(m);
-  const auto r2 = __builtin_amdgcn_permlane16_swap(um, um, false, false);
+  const auto r2 = __builtin_amdgcn_permlane32_swap(um, um, false, false);
   return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
 }
 __device__ __forceinline__ float wave_sum(float v) {

@@ -48,6 +48,7 @@ struct PrefillArgs {
   const void* v;
   int seq_q, seq_k, q_stride, kv_stride, n_heads, n_groups, causal;
   float alpha;
+  int prio;
 };
 
 template <int FT, int MT>
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
           for (int s = 0; s < 4; ++s)
             kf[nt][s] = *reinterpret_cast<const u32x4_t*>(ks + (nt * 16 + ni) * PF_KPITCH + ((kb + 4 * s) ^ ni) * 8);
         __builtin_amdgcn_sched_barrier(0);
+        if (a.prio) __builtin_amdgcn_s_setprio(1);  // the matrix phases win the issue arbitration against the other workgroup's softmax
         f32x4_t sacc[MT][NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -165,6 +167,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) sacc[mt][nt] = mfma16<FT>(kf[nt][s], qf[mt][s], sacc[mt][nt]);
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         // the K fragment registers are free again: tile T + 2 leaves for the prefetch registers now and has the softmax,
         // the second MFMA phase and the barrier to land
@@ -241,12 +244,14 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
         //      row-major tile; shared by the MT query tiles.  Dim tiles 4..7 are read while tiles 0..3 multiply. ----
 #pragma unroll
         for (int t = 4; t < 8; ++t) read_v(t);
+        if (a.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) oacc[mt][t] = mfma16<FT>(vf[t][hh], pf[mt][hh], oacc[mt][t]);
+        __builtin_amdgcn_s_setprio(0);
       } else {
         load_tile(k0 + 2 * PF_KEYS);
       }
@@ -304,7 +309,15 @@ extern "C" int dihip_prefill_attn(void* stream, void* out, const void* q, const 
   const int mt = force_mt > 0 ? std::min(force_mt, 2) : (2 * wgs(128) >= 3L * ncu ? 2 : 1);
   const int rows = 64 * mt;
   const int nqt = (seq_q + rows - 1) / rows;
-  PrefillArgs a{out, q, k, v, seq_q, seq_k, q_stride, kv_stride, n_heads, n_groups, causal, alpha};
+  static int force_prio = -2;  // DIHIP_PREFILL_PRIO: diagnostics
+  if (force_prio == -2) {
+    const char* e = getenv("DIHIP_PREFILL_PRIO");
+    force_prio = e ? atoi(e) : -1;
+  }
+  // raised issue priority for the MFMA phases: +9..11 % once the grid exceeds the resident workgroups (2 per CU), +2 % at
+  // 16384, but -4 % while every workgroup is resident from the start (measured, A/B in one process)
+  const int prio = force_prio >= 0 ? force_prio : ((long)nqt * n_heads > 2L * ncu ? 1 : 0);
+  PrefillArgs a{out, q, k, v, seq_q, seq_k, q_stride, kv_stride, n_heads, n_groups, causal, alpha, prio};
   const dim3 grid(nqt * n_heads);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == DIHIP_BF16 && mt == 2) hipLaunchKernelGGL((prefill_attn_kernel<DIHIP_BF16, 2>), grid, dim3(PF_THREADS), 0, s, a);

@@ -437,8 +437,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
       qf[ks] = u32x4_t{(raw[0] & 0xFFFFu) | (raw[2] << 16), (raw[0] >> 16) | (raw[2] & 0xFFFF0000u),
                        (raw[1] & 0xFFFFu) | (raw[3] << 16), (raw[1] >> 16) | (raw[3] & 0xFFFF0000u)};
     }
-    qsum += __shfl_xor(qsum, 16, 64);
-    qsum += __shfl_xor(qsum, 32, 64);
+    qsum = rows_sum(qsum);
   }
 
   const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -474,8 +473,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) mn = fmaxf(mn, sc[c][rr]);
-    mn = fmaxf(mn, __shfl_xor(mn, 16, 64));
-    mn = fmaxf(mn, __shfl_xor(mn, 32, 64));
+    mn = rows_max(mn);
     const float corr = safe_exp_diff(m, mn);
     m = mn;
     float ps = 0.f;
@@ -550,10 +548,8 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
     }
   }
   // ---- totals of the head over the 4 token rows (kb), then the record the shared epilogue expects
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
-  czero += __shfl_xor(czero, 16, 64);
-  czero += __shfl_xor(czero, 32, 64);
+  l = rows_sum(l);
+  czero = rows_sum(czero);
   if (ni < nh) {
     float* rec = lds + (wave * HC + ni) * ATTN_PSTRIDE;
 #pragma unroll
@@ -765,8 +761,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void span_attn_ft_mfma_kernel(cons
     for (int ks = 0; ks < 4; ++ks)
       if (!hv) qf[ks] = u32x4_t{0u, 0u, 0u, 0u};
     if constexpr (Q8) {
-      qsum += __shfl_xor(qsum, 16, 64);
-      qsum += __shfl_xor(qsum, 32, 64);
+      qsum = rows_sum(qsum);
     }
   }
   // FUSED: this step's K (rotated, rounded) and V head of the group, as the cache will hold them
@@ -874,8 +869,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void span_attn_ft_mfma_kernel(cons
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) mn = fmaxf(mn, sc[c][rr]);
-      mn = fmaxf(mn, __shfl_xor(mn, 16, 64));
-      mn = fmaxf(mn, __shfl_xor(mn, 32, 64));
+      mn = rows_max(mn);
       const float corr = safe_exp_diff(m, mn);
       m = mn;
       float ps = 0.f, cz = 0.f;
@@ -928,11 +922,9 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void span_attn_ft_mfma_kernel(cons
       }
     }
   }
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
+  l = rows_sum(l);
   if constexpr (Q8) {
-    czero += __shfl_xor(czero, 16, 64);
-    czero += __shfl_xor(czero, 32, 64);
+    czero = rows_sum(czero);
   }
   __syncthreads();  // every wave is done with its V tile: the buffer now holds the epilogue records
   if (ni < nh) {
