@@ -1,0 +1,231 @@
+// gemm_kslice_kernel.hpp -- weight-only GEMM for batched decode (4 < M <= 32), activations in the FRAG32 layout,
+// with the activations REGISTER-RESIDENT: the waves of a workgroup split K, a wave loads the A fragments of its
+// K-slice (16 k-steps: 16 KiB of x at M = 32) once, keeps them for the whole kernel, and streams the weight
+// chunks of that slice for every column tile the workgroup owns.
+//
+// Why a third small-batch kernel: gemm_panel_kernel.hpp shares an activation k-tile through LDS and pays one
+// workgroup barrier per k-tile (1-2 KiB of weights per wave), and its weight ring shares the in-order load queue
+// with the activation stream; gemv_batch_kernel.hpp re-reads the activations for every column tile.  Here the
+// main loop issues nothing but weight loads (the structure of the M <= 4 kernel, which streams at 4.8 TB/s):
+//   * a half-unit is the wave's CH chunks of one column tile; half-units come in PAIRS (SwiGLU: the gate and the
+//     up tile of one unit, otherwise two tiles).  The ring holds 8 KiB per wave (W4: a pair, W8: one half-unit);
+//     the fully unrolled body indexes ring slots and activation registers statically, and every slot is refilled
+//     with the same chunk position one ring revolution ahead right after its last use;
+//   * the K-slices of a pair meet in LDS (4 KiB per wave, two buffers, ONE barrier per pair = per 8 KiB of weights
+//     per wave); 2 * MT waves sum the slices in fixed order and apply the epilogue while the others stream on;
+//   * K beyond 8 slices (down projection) is split across workgroups: f32 partial tiles go to the slab of the
+//     panel kernel and gemm_panel_reduce_kernel finishes (same layout, same deterministic order).
+// Sum_k x[m][k] per quantisation group (the zero-point term) is recomputed per chunk with MFMAs against ones:
+// the matrix pipe is idle most of the time here and the alternative costs 32 registers or 64 KiB of LDS.
+// Arithmetic per element as in the other decode kernels (exact integer MFMA, scale / zero-point per group on
+// the f32 accumulator); a group that straddles two K-slices is closed in both with the same (scale, zero).
+#pragma once
+#include "gemm_panel_kernel.hpp"
+
+namespace dihip {
+
+constexpr int KSL_WAVES = 8;
+
+template <int WBITS, int FT, int MT, int EPI, int GPT>
+__global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const PanelArgs a) {
+  using WT = WTraits<WBITS>;
+  using EX = ExpandV<WBITS, FT>;
+  constexpr int KSTEPS = WT::KSTEPS;
+  constexpr int CH = 16 / KSTEPS;  // chunks (k-tiles) per K-slice: 16 k-steps of 32
+  constexpr int XS = CH * KSTEPS;
+  constexpr int DUAL = EPI == EPI_SWIGLU ? 2 : 1;
+  constexpr int RH = WBITS == 4 && MT == 1 ? 2 : 1;  // half-units per ring revolution: 8 KiB in flight per wave, 4 KiB for
+                                                      // W4 at MT = 2 (128 activation registers leave room for 4 slots)
+  constexpr int P = RH * CH;
+
+  __shared__ __attribute__((aligned(16))) f32x4_t xch[2][KSL_WAVES][2][MT][64];
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int ni = lane & 15, kb = lane >> 4;
+  const int nsl_total = a.KT / CH;
+  const int slice0 = blockIdx.y * KSL_WAVES;
+  const int nw = min(KSL_WAVES, nsl_total - slice0);  // K-slices (= working waves) of this workgroup
+  const bool active = wave < nw;
+  const int kt0 = min(slice0 + wave, nsl_total - 1) * CH;
+
+  // units of this workgroup: blockIdx.x, + gridDim.x, ...; a unit is a column tile (SwiGLU: the gate / up tile pair)
+  const int NB = gridDim.x;
+  const int nu = (a.nunits - (int)blockIdx.x + NB - 1) / NB;
+  const int NH = nu * DUAL;                                // half-units
+  const int NP = (NH + 1) >> 1;                            // pairs
+  auto tile_of = [&](int h) {                              // column tile of half-unit h (clamped: dummies re-load the last)
+    const int hc = min(h, NH - 1);
+    return (int)blockIdx.x + (DUAL == 2 ? hc >> 1 : hc) * NB;
+  };
+
+  // ---- this wave's activations: XS k-steps x MT row tiles, 1 KiB contiguous per fragment ----
+  u32x4_t xf[XS][MT];
+  {
+    const u32x4_t* xp = reinterpret_cast<const u32x4_t*>(a.x) + (size_t)kt0 * KSTEPS * MT * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < XS; ++i)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        xf[i][mt] = xp[(size_t)(i * MT + mt) * 64];
+        asm volatile("" : "+v"(xf[i][mt]));  // opaque: never re-loaded next to its use
+      }
+  }
+
+  struct Slot {
+    u32x4_t w;
+    uint32_t s;
+  };
+  const bool subc = a.ktpg < a.KT;
+  // bases of the half-unit the refills request (wave-uniform tile arithmetic, lane offsets folded in)
+  const u32x4_t* wbn;
+  const uint32_t* sbn;
+  auto set_half = [&](int h) {
+    const int tile = tile_of(h);
+    const bool up = DUAL == 2 && (min(h, NH - 1) & 1);
+    wbn = (up ? a.w1 : a.w0) + ((size_t)tile * a.KT + kt0) * 64 + lane;
+    sbn = (up ? a.sz1 : a.sz0) + (size_t)tile * a.Gp * 16 + ni;
+  };
+  auto load_slot = [&](Slot& r, int c) {  // chunk c of the half-unit set_half() named
+    r.w = __builtin_nontemporal_load(wbn + (size_t)c * 64);
+    const int kt = kt0 + c;
+    r.s = __builtin_nontemporal_load(sbn + (size_t)(GPT ? kt : (subc ? kt / a.ktpg : 0)) * 16);
+  };
+
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  uint32_t ex_mask = 0x000F000Fu, ex_magic = FT == DIHIP_BF16 ? 0x43004300u : 0x64006400u;
+  asm volatile("" : "+v"(ex_mask), "+v"(ex_magic));
+  u32x4_t ones = FT == DIHIP_BF16 ? u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}
+                                  : u32x4_t{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+
+  Slot ring[P];
+  if (active) {
+#pragma unroll
+    for (int r = 0; r < RH; ++r) {
+      set_half(r);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) load_slot(ring[r * CH + c], c);
+    }
+  }
+
+  for (int p = 0; p < NP; ++p) {
+    if (active) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        set_half(2 * p + hh + RH);  // the refills below request the half-unit RH ahead (past the end: a valid re-load)
+        f32x4_t tot[MT], gacc[MT], xacc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) tot[mt] = gacc[mt] = xacc[mt] = zero4;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          Slot& slot = ring[(RH == 2 ? hh * CH : 0) + c];
+          f32x4_t g[MT], xs[MT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) g[mt] = xs[mt] = zero4;
+          // the chunk's Sum_k x is loop-invariant: left alone, hipcc hoists all CH x MT of them out of the unit loop
+          // (32 more live registers -> 140 spilled); the opaque redefinition keeps the recomputation where it is
+          asm volatile("" : "+v"(ones));
+#pragma unroll
+          for (int ks = 0; ks < KSTEPS; ++ks) {
+            const u32x4_t bf = EX::frag(slot.w, ks, ex_mask, ex_magic);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              g[mt] = mfma16<FT>(xf[c * KSTEPS + ks][mt], bf, g[mt]);
+              xs[mt] = mfma16<FT>(xf[c * KSTEPS + ks][mt], ones, xs[mt]);  // Sum_k x[m][k] of the chunk
+            }
+          }
+          const float s_ = ft_bits_to_f32<FT>(slot.s & 0xFFFFu);
+          const float nzp_ = -(ft_bits_to_f32<FT>(slot.s >> 16) + EX::OFFSET);
+          if constexpr (GPT) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) tot[mt][rr] = fmaf(s_, fmaf(nzp_, xs[mt][rr], g[mt][rr]), tot[mt][rr]);
+          } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) {
+                gacc[mt][rr] += g[mt][rr];
+                xacc[mt][rr] += xs[mt][rr];
+              }
+            // the group ends with this chunk, or the slice does (the next slice closes its part with the same scale)
+            if (c == CH - 1 || (kt0 + c + 1) % a.ktpg == 0) {
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                  tot[mt][rr] = fmaf(s_, fmaf(nzp_, xacc[mt][rr], gacc[mt][rr]), tot[mt][rr]);
+                  gacc[mt][rr] = 0.f;
+                  xacc[mt][rr] = 0.f;
+                }
+            }
+          }
+          // refill pinned between the slot's last use and the next chunk (see gemm_panel_kernel.hpp)
+          __builtin_amdgcn_sched_barrier(0);
+          load_slot(slot, c);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xch[p & 1][wave][hh][mt][lane] = tot[mt];
+      }
+    }
+    __syncthreads();  // the pair's slices are in xch[p & 1]; its previous use (pair p - 2) was reduced before barrier p - 1
+    // ---- reduce over the K-slices in fixed order + epilogue: fragment f = (half, row tile) per wave ----
+    constexpr int NFR = DUAL == 2 ? MT : 2 * MT;
+    for (int f = wave; f < NFR; f += (int)(blockDim.x >> 6)) {
+      const int mt = DUAL == 2 ? f : f % MT;
+      const int hh = DUAL == 2 ? 0 : f / MT;
+      const int h = 2 * p + hh;
+      if (h >= NH) continue;  // the odd last pair's dummy half
+      f32x4_t v = zero4, v2 = zero4;
+      for (int w = 0; w < nw; ++w) {
+        const f32x4_t t = xch[p & 1][w][hh][mt][lane];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) v[rr] += t[rr];
+        if constexpr (DUAL == 2) {
+          const f32x4_t t2 = xch[p & 1][w][1][mt][lane];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) v2[rr] += t2[rr];
+        }
+      }
+      const int n = tile_of(h) * 16 + ni;
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int m = mt * 16 + kb * 4 + rr;
+        if (m >= a.M) continue;
+        if (a.nslices > 1) {
+          a.slab[(((size_t)blockIdx.y * DUAL) * a.M + m) * a.N + n] = v[rr];
+          if constexpr (DUAL == 2) a.slab[(((size_t)blockIdx.y * DUAL + 1) * a.M + m) * a.N + n] = v2[rr];
+        } else {
+          panel_epilogue<FT, EPI>(a, m, n, v[rr], v2[rr], MT);
+        }
+      }
+    }
+  }
+}
+
+template <int WBITS, int FT, int MT, int EPI, int GPT>
+hipError_t launch_gemm_kslice(const PanelArgs& a, int groups, int waves, hipStream_t stream);
+
+#define DIHIP_DEFINE_KSLICE_LAUNCH(WBITS, FT, MT, EPI, GPT)                                                   \
+  template <>                                                                                                 \
+  hipError_t launch_gemm_kslice<WBITS, FT, MT, EPI, GPT>(const PanelArgs& a, int groups, int waves, hipStream_t s) { \
+    hipLaunchKernelGGL((gemm_kslice_kernel<WBITS, FT, MT, EPI, GPT>), dim3(groups, a.nslices), dim3(waves * 64), 0, s, a); \
+    if (a.nslices > 1) {                                                                                      \
+      const int blocks = (int)std::min<size_t>(((size_t)a.M * a.N + 255) / 256, 1024);                        \
+      hipLaunchKernelGGL((gemm_panel_reduce_kernel<FT, EPI>), dim3(blocks), dim3(256), 0, s, a, MT);          \
+    }                                                                                                         \
+    return hipGetLastError();                                                                                 \
+  }
+#define DIHIP_DEFINE_KSLICE_LAUNCH_SET(WBITS, FT, GPT)      \
+  DIHIP_DEFINE_KSLICE_LAUNCH(WBITS, FT, 1, EPI_STD, GPT)    \
+  DIHIP_DEFINE_KSLICE_LAUNCH(WBITS, FT, 2, EPI_STD, GPT)    \
+  DIHIP_DEFINE_KSLICE_LAUNCH(WBITS, FT, 1, EPI_SWIGLU, GPT) \
+  DIHIP_DEFINE_KSLICE_LAUNCH(WBITS, FT, 2, EPI_SWIGLU, GPT) \
+  DIHIP_DEFINE_KSLICE_LAUNCH(WBITS, FT, 1, EPI_ADDTO, GPT)  \
+  DIHIP_DEFINE_KSLICE_LAUNCH(WBITS, FT, 2, EPI_ADDTO, GPT)
+
+}  // namespace dihip

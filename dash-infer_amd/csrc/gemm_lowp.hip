@@ -8,6 +8,7 @@
 #include "gemm_lowp_launch.hpp"
 #include "gemv_stream_kernel.hpp"
 #include "gemv_batch_kernel.hpp"
+#include "gemm_kslice_kernel.hpp"
 #include "gemm_panel_kernel.hpp"
 
 namespace dihip {
@@ -388,6 +389,45 @@ static PanelPlan make_panel_plan(int wbits, int M, int N, int K, int group_size,
   return p;
 }
 
+// ---- batched decode, FRAG32 activations, register-resident K-slices (gemm_kslice_kernel.hpp) ---------------------
+struct KslicePlan {
+  bool ok;
+  int groups, nslices, waves, nunits;
+  size_t slab_bytes;
+};
+static KslicePlan make_kslice_plan(int wbits, int M, int N, int K, int group_size, bool dual, bool sizing = false) {
+  KslicePlan p{};
+  // DIHIP_GEMM_KSLICE: 0 = never, 2 = every eligible shape (tests / diagnostics); read per call so that one process can
+  // exercise both kernels
+  const char* e = getenv("DIHIP_GEMM_KSLICE");
+  const int mode = sizing ? 2 : e ? atoi(e) : 1;  // workspace sizing covers the forced mode as well
+  if (mode == 0 || (wbits != 4 && wbits != 8)) return p;
+  const LowpDims d = lowp_dims(wbits, N, K, group_size);
+  const int ch = wbits == 4 ? 4 : 8;  // k-tiles per K-slice (16 k-steps of 32)
+  if (d.KT % ch) return p;            // slices hold whole k-tiles of equal count
+  if (wbits == 8 && d.group == d.KTILE && M > 16) return p;  // W8 g64 at two row tiles does not fit the register file
+  // Measured against the panel kernel (tools/gemv_bench, 7B and 72B/TP8 shapes): +7..8 % on the SwiGLU pair at M <= 16
+  // (8 KiB in flight per wave), equal at M = 32 (the 128 activation registers leave room for 4 KiB), 30-40 % slower on
+  // matrices of a few MB (one or two half-units per workgroup: the ring never reaches steady state)
+  if (mode != 2 && !(M <= 16 && dual && (size_t)N * K * wbits / 8 * 2 >= ((size_t)24 << 20))) return p;
+  int ncu = cached_num_cus();
+  if (ncu <= 0) ncu = 256;
+  const int nsl = d.KT / ch;
+  p.waves = std::min(KSL_WAVES, nsl);
+  p.nslices = (nsl + KSL_WAVES - 1) / KSL_WAVES;
+  p.nunits = d.NTILES;
+  static int target = -1;  // DIHIP_KSLICE_TARGET_WGS: diagnostics
+  if (target < 0) {
+    const char* e = getenv("DIHIP_KSLICE_TARGET_WGS");
+    target = e ? atoi(e) : 0;
+  }
+  const int tgt = target > 0 ? target : ncu;  // one 8-wave workgroup per CU (64 KB LDS, ~250 registers)
+  p.groups = std::max(1, std::min(p.nunits, tgt / p.nslices));
+  p.slab_bytes = p.nslices > 1 ? (size_t)p.nslices * (dual ? 2 : 1) * M * N * sizeof(float) : 0;
+  p.ok = true;
+  return p;
+}
+
 // One launch of M = 1 GEMVs over (token, expert-rank) slots (mixture-of-experts, moe.hip): slot s streams expert
 // slot_expert[s] of a stack of equally shaped packed weights, reads activation row s / x_div, writes row s.
 int run_gemv_slots(hipStream_t stream, int wbits, int epi, const void* x, int ldx, int x_div, const void* w0, const void* sz0,
@@ -506,6 +546,49 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
   // batched decode with FRAG32 activations: panels of 8 column tiles sharing x through LDS (gemm_panel_kernel.hpp)
   if (c.dtype == DIHIP_BF16 && gemv_stream_enabled() && c.x_layout == DIHIP_ACT_FRAG32 && c.pro == PRO_PLAIN && c.M > 4 &&
       c.M <= 32 && c.wbits != 16 && c.K == d.Kp && (d.group == 0 || d.group % d.KTILE == 0)) {
+    const KslicePlan kp = make_kslice_plan(c.wbits, c.M, c.N, c.K, c.group_size, dual);
+    if (kp.ok) {
+      DIHIP_REQUIRE(kp.nslices == 1 || (c.ws && c.ws_bytes >= kp.slab_bytes), DIHIP_MEMORY_ERROR,
+                    "gemm_kslice: workspace too small for the split-K slab (%zu < %zu)", c.ws_bytes, kp.slab_bytes);
+      PanelArgs g{};
+      g.w0 = reinterpret_cast<const u32x4_t*>(c.w0);
+      g.w1 = reinterpret_cast<const u32x4_t*>(c.w1);
+      g.sz0 = reinterpret_cast<const uint32_t*>(c.sz0);
+      g.sz1 = reinterpret_cast<const uint32_t*>(c.sz1);
+      g.x = c.x;
+      g.bias = c.bias;
+      g.residual = c.residual;
+      g.y = c.y;
+      g.ldy = c.N;
+      g.h_res = c.h_res;
+      g.h_out = c.h_out;
+      g.alpha = c.alpha;
+      g.act = c.act;
+      g.M = c.M;
+      g.N = c.N;
+      g.K = c.K;
+      g.KT = d.KT;
+      g.NTILES = d.NTILES;
+      g.Gp = lowp_dims(4, c.N, c.K, c.group_size).Gp;
+      g.ktpg = d.group ? d.group / d.KTILE : (1 << 28);
+      g.nslices = kp.nslices;
+      g.slab = reinterpret_cast<float*>(c.ws);
+      g.yfrag = c.y_layout == DIHIP_ACT_FRAG32;
+      g.nunits = kp.nunits;
+      const bool gpt = g.ktpg == 1;
+      const int mt = c.M > 16 ? 2 : 1;
+      hipError_t e = hipErrorInvalidValue;
+#define KSLICE_GO(W_, MT_, EPI_, G_) \
+      if (c.wbits == W_ && mt == MT_ && c.epi == EPI_ && (int)gpt == G_) e = launch_gemm_kslice<W_, DIHIP_BF16, MT_, EPI_, G_>(g, kp.groups, kp.waves, stream);
+#define KSLICE_ALL(W_, G_) KSLICE_GO(W_, 1, EPI_STD, G_) KSLICE_GO(W_, 2, EPI_STD, G_) KSLICE_GO(W_, 1, EPI_SWIGLU, G_) \
+      KSLICE_GO(W_, 2, EPI_SWIGLU, G_) KSLICE_GO(W_, 1, EPI_ADDTO, G_) KSLICE_GO(W_, 2, EPI_ADDTO, G_)
+      KSLICE_ALL(4, 0) KSLICE_ALL(4, 1) KSLICE_ALL(8, 0) KSLICE_ALL(8, 1)
+#undef KSLICE_ALL
+#undef KSLICE_GO
+      DIHIP_REQUIRE(e == hipSuccess, DIHIP_RUNTIME_ERROR, "gemm_kslice: launch failed (wbits=%d M=%d epi=%d): %s", c.wbits, c.M,
+                    c.epi, hipGetErrorString(e));
+      return DIHIP_SUCCESS;
+    }
     const PanelPlan pp = make_panel_plan(c.wbits, c.M, c.N, c.K, c.group_size, dual);
     if (pp.ok) {
       DIHIP_REQUIRE(pp.nslices == 1 || (c.ws && c.ws_bytes >= pp.slab_bytes), DIHIP_MEMORY_ERROR,
@@ -819,6 +902,7 @@ size_t dihip_gemm_lowp_workspace_bytes(int wbits, int M, int N, int K, int group
   if (wbits != 16 && M > 4 && M <= 32) {
     slab = std::max(slab, make_panel_plan(wbits, M, N, K, group_size, false).slab_bytes);
     slab = std::max(slab, make_panel_plan(wbits, M, N, K, group_size, true).slab_bytes);
+    slab = std::max(slab, make_kslice_plan(wbits, M, N, K, group_size, true, true).slab_bytes);
   }
   return slab + GEMM_SYNC_BYTES + (size_t)((M + 15) / 16 * 16) * K * 2 + 512;  // norm rows may be FRAG32
 }
@@ -873,7 +957,10 @@ static int norm_to_ws(hipStream_t s, const float* h, const void* gamma, float ep
                       int* x_layout, bool force_frag = false) {
   const GemmPlan p = make_plan(wbits, M, N, K, group_size, dual);
   size_t slab = p.slab_bytes;
-  if (wbits != 16 && M > 4 && M <= 32) slab = std::max(slab, make_panel_plan(wbits, M, N, K, group_size, dual).slab_bytes);
+  if (wbits != 16 && M > 4 && M <= 32) {
+    slab = std::max(slab, make_panel_plan(wbits, M, N, K, group_size, dual).slab_bytes);
+    slab = std::max(slab, make_kslice_plan(wbits, M, N, K, group_size, dual, true).slab_bytes);
+  }
   const size_t off = (slab + 255) & ~(size_t)255;
   const bool frag = force_frag || batch_kernel_shape(wbits, M, N, K, group_size, dual);
   const int mt = M > 16 ? 2 : 1;

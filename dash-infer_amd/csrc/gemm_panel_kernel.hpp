@@ -53,6 +53,7 @@ struct PanelArgs {
   int nslices;  // gridDim.y; > 1: partial tiles go to `slab`
   float* slab;  // [nslices][DUAL][M][N] f32
   int yfrag;    // y (EPI_STD / EPI_SWIGLU) in FRAG32
+  int nunits;   // gemm_kslice_kernel.hpp: column tiles (SwiGLU: tile pairs) of the whole launch
 };
 
 template <int FT, int EPI>

@@ -444,3 +444,68 @@ def test_panel_kernel_full_size_mlp(ops, wbits, G, M):
     wd = gemm_ref.dequant(qd, sd, zd, G, wbits)[:, cols].astype(np.float64)
     ref = h0.cpu().numpy()[:, cols] + (a_rm.astype(np.float64) @ wd)
     np.testing.assert_allclose(o_fr[:, cols], ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wbits,G,M", [(4, 128, 5), (4, 128, 16), (4, 128, 32), (4, 256, 16), (8, -1, 16), (8, -1, 32), (8, 128, 9)])
+def test_kslice_kernel_full_size_mlp(ops, wbits, G, M):
+    """Register-resident K-slice kernel (gemm_kslice_kernel.hpp) on the BASELINE configs[2] MLP at full size:
+    SwiGLU epilogue with one workgroup-level K-slice (gate/up, 7 waves), residual epilogue through the split-K slab
+    (down: 37 slices = 5 workgroup slices), plain epilogue with bias.  DIHIP_GEMM_KSLICE=2 forces it for every
+    eligible shape (by default it serves M <= 16 SwiGLU pairs of >= 24 MB); checked against the panel kernel
+    (DIHIP_GEMM_KSLICE=0; other summation order over K) and the f64 oracle."""
+    import os
+    rng = np.random.default_rng(3 * M + wbits + G)
+    K, I = QWEN7B["gate"]                # 3584 -> 18944
+    hk = torch.from_numpy(rng.normal(0, 1.0, (M, K)).astype(np.float32)).cuda()
+    gamma = to_dev(bf16_round(rng.normal(1, 0.1, K).astype(np.float32)), "bf16")
+    _, qg, sg, zg = make_case(rng, 1, I, K, G, wbits, "bf16")
+    _, qu, su, zu = make_case(rng, 1, I, K, G, wbits, "bf16")
+    _, qd, sd, zd = make_case(rng, 1, K, I, G, wbits, "bf16")
+    pg = ops.pack_lowp(to_dev(qg), to_dev(sg, "bf16"), to_dev(zg, "bf16"), G, wbits)
+    pu = ops.pack_lowp(to_dev(qu), to_dev(su, "bf16"), to_dev(zu, "bf16"), G, wbits)
+    pd = ops.pack_lowp(to_dev(qd), to_dev(sd, "bf16"), to_dev(zd, "bf16"), G, wbits)
+    sc = ops.Scratch(max(ops.lowp_workspace_bytes(wbits, M, I, K, G), ops.lowp_workspace_bytes(wbits, M, K, I, G)))
+    h0 = torch.from_numpy(rng.normal(0, 1, (M, K)).astype(np.float32)).cuda()
+    NQ = 4608
+    _, qq, sq, zq = make_case(rng, 1, NQ, K, G, wbits, "bf16")
+    pq = ops.pack_lowp(to_dev(qq), to_dev(sq, "bf16"), to_dev(zq, "bf16"), G, wbits)
+    bias = to_dev(bf16_round(rng.normal(0, 0.5, NQ).astype(np.float32)), "bf16")
+    old = os.environ.get("DIHIP_GEMM_KSLICE")
+
+    def run(mode):
+        os.environ["DIHIP_GEMM_KSLICE"] = mode
+        act = ops.fused_norm_swiglu(hk, gamma, 1e-6, pg, pu, sc, y_layout=ops.ACT_FRAG32)
+        out = ops.fused_gemm_addto(act, pd, h0, sc, x_layout=ops.ACT_FRAG32, M=M)
+        y = ops.fused_norm_gemm(hk, gamma, 1e-6, pq, bias, sc)
+        return ops.act_from_frag(act, M, I), out, y
+
+    try:
+        a_pan, o_pan, y_pan = run("0")
+        a_ksl, o_ksl, y_ksl = run("2")
+        a_ks2, o_ks2, y_ks2 = run("2")
+    finally:
+        if old is None:
+            os.environ.pop("DIHIP_GEMM_KSLICE", None)
+        else:
+            os.environ["DIHIP_GEMM_KSLICE"] = old
+    assert torch.equal(a_ksl.view(torch.int16), a_ks2.view(torch.int16)) and torch.equal(o_ksl, o_ks2)   # deterministic
+    assert torch.equal(y_ksl.view(torch.int16), y_ks2.view(torch.int16))
+    yp, yk = y_pan.float().cpu().numpy(), y_ksl.float().cpu().numpy()
+    assert_close(yk, yp, "bf16", what="qkv (bias epilogue): K-slice vs panel kernel", pre=yp)
+    ap, ak = a_pan.float().cpu().numpy(), a_ksl.float().cpu().numpy()
+    assert_close(ak, ap, "bf16", what="swiglu: K-slice vs panel kernel", pre=ap)
+    op_, ok_ = o_pan.cpu().numpy(), o_ksl.cpu().numpy()
+    h0n = h0.cpu().numpy()
+    # the two down projections start from activations that may differ in the last bf16 bit
+    np.testing.assert_allclose(ok_, op_, rtol=1e-2, atol=1e-2 * np.abs(op_ - h0n).max())
+    # f64 oracle: 48 random columns of both projections (down: input = the kernel's own bf16 activations)
+    cols = rng.choice(I, 48, replace=False)
+    xn = bf16_round(glue.rmsnorm(hk.cpu().numpy(), gamma.float().cpu().numpy(), 1e-6)).astype(np.float64)
+    g_ = xn @ gemm_ref.dequant(qg, sg, zg, G, wbits)[:, cols].astype(np.float64)
+    u_ = xn @ gemm_ref.dequant(qu, su, zu, G, wbits)[:, cols].astype(np.float64)
+    ref_a = glue.silu(g_) * u_
+    np.testing.assert_allclose(ak[:, cols], ref_a, rtol=1e-2, atol=1e-2 * np.abs(ref_a).max())
+    cols = rng.choice(K, 48, replace=False)
+    ref_o = h0n[:, cols] + ak.astype(np.float64) @ gemm_ref.dequant(qd, sd, zd, G, wbits)[:, cols].astype(np.float64)
+    np.testing.assert_allclose(ok_[:, cols], ref_o, rtol=2e-3, atol=2e-3 * np.abs(ref_o).max())
