@@ -34,8 +34,11 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
   constexpr int CH = 16 / KSTEPS;  // chunks (k-tiles) per K-slice: 16 k-steps of 32
   constexpr int XS = CH * KSTEPS;
   constexpr int DUAL = EPI == EPI_SWIGLU ? 2 : 1;
-  constexpr int RH = WBITS == 4 && MT == 1 ? 2 : 1;  // half-units per ring revolution: 8 KiB in flight per wave, 4 KiB for
-                                                      // W4 at MT = 2 (128 activation registers leave room for 4 slots)
+  // half-units per ring revolution: a pair at MT = 1 (W4: 8 KiB in flight per wave, W8: 16 KiB); at MT = 2 the 128
+  // activation registers leave room for one half-unit (W4: 4 KiB, W8: 8 KiB).  Two pairs (16 KiB, W4) measured 15 %
+  // SLOWER than one: the work per workgroup is only ~5 pairs, and whole bodies round it up.
+  constexpr int RH = MT == 1 ? 2 : 1;
+  constexpr int PU = RH >= 2 ? RH / 2 : 1;  // pairs per unrolled body (static ring slots)
   constexpr int P = RH * CH;
 
   __shared__ __attribute__((aligned(16))) f32x4_t xch[2][KSL_WAVES][2][MT][64];
@@ -109,7 +112,12 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
     }
   }
 
-  for (int p = 0; p < NP; ++p) {
+  // NP is rounded up to whole bodies: a dummy pair re-loads the last tiles and stores nothing (a guarded pair would put
+  // its loads behind a branch, and hipcc drains the queue at such a join)
+  for (int p0 = 0; p0 < NP; p0 += PU)
+#pragma unroll
+  for (int pu = 0; pu < PU; ++pu) {
+    const int p = p0 + pu;
     if (active) {
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
         for (int mt = 0; mt < MT; ++mt) tot[mt] = gacc[mt] = xacc[mt] = zero4;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-          Slot& slot = ring[(RH == 2 ? hh * CH : 0) + c];
+          Slot& slot = ring[((2 * pu + hh) % RH) * CH + c];
           f32x4_t g[MT], xs[MT];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) g[mt] = xs[mt] = zero4;

@@ -405,7 +405,7 @@ static KslicePlan make_kslice_plan(int wbits, int M, int N, int K, int group_siz
   const LowpDims d = lowp_dims(wbits, N, K, group_size);
   const int ch = wbits == 4 ? 4 : 8;  // k-tiles per K-slice (16 k-steps of 32)
   if (d.KT % ch) return p;            // slices hold whole k-tiles of equal count
-  if (wbits == 8 && d.group == d.KTILE && M > 16) return p;  // W8 g64 at two row tiles does not fit the register file
+  if (wbits == 8 && d.group == d.KTILE) return p;  // W8 g64 (a scale per k-tile in a 16-slot ring) does not fit the register file
   // Measured against the panel kernel (tools/gemv_bench, 7B and 72B/TP8 shapes): +7..8 % on the SwiGLU pair at M <= 16
   // (8 KiB in flight per wave), equal at M = 32 (the 128 activation registers leave room for 4 KiB), 30-40 % slower on
   // matrices of a few MB (one or two half-units per workgroup: the ring never reaches steady state)

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 python -c "import torch; print(torch.__version__, torch.cuda.is_available(), torch.cuda.get_device_name(0))" > $OUT/env.log 2>&1
 nproc >> $OUT/env.log; rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -8 >> $OUT/env.log
-for f in test_gpu_gemm test_gpu_kv_attn test_gpu_glue test_gpu_prefill test_gpu_host_ops; do
+for f in test_gpu_gemm test_gpu_kv_attn test_gpu_glue test_gpu_prefill test_gpu_host_ops test_gpu_moe; do
   timeout 900 python -m pytest tests/$f.py -q -m gpu -x --timeout 600 > $OUT/$f.log 2>&1
   echo "$f exit $?" | tee -a $OUT/summary.log
   tail -5 $OUT/$f.log
@@ -28,4 +28,6 @@ for w in ${EXTRA_WORKLOADS:-}; do
   timeout 900 python bench.py --steps 32 --warmup 4 --workload $w --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err; echo "bench $w exit $?" | tee -a $OUT/summary.log
   tail -c 2500 $OUT/bench_$w.json
 done
+timeout 200 python tools/prefill_bench.py 512 1024 2048 4096 8192 16384 > $OUT/prefill.txt 2>&1; tail -6 $OUT/prefill.txt
+timeout 200 python tools/attn_batch_bench.py > $OUT/attn_batch.txt 2>&1; tail -6 $OUT/attn_batch.txt
 cat $OUT/summary.log
