@@ -51,16 +51,25 @@ struct PrefillArgs {
   int prio;
 };
 
-template <int FT, int MT>
-__global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const PrefillArgs a) {
+// NG = key groups per workgroup: 1 -> 4 waves, two workgroups per CU; 2 -> 8 waves, one workgroup per CU whose two
+// 4-wave groups take alternate key tiles of the SAME query tile and merge (O, m, l) through LDS at the end.  The CU
+// holds the same 8 waves either way, but the chain of dependent key tiles per query tile is half as long: that is what
+// bounds short prompts, where every workgroup is resident from the start and the longest one sets the time.
+template <int FT, int MT, int NG>
+__global__ __launch_bounds__(PF_THREADS * NG, NG == 1 ? 2 : 1) void prefill_attn_kernel(const PrefillArgs a) {
   constexpr int H = 128;
   constexpr int PF_QROWS = 64 * MT;  // query rows per workgroup (4 waves x 16 x MT)
   // two copies of each tile: the next tile is written while the current one is read, one barrier per tile
-  __shared__ __attribute__((aligned(16))) uint16_t ks_buf[2][PF_KEYS * PF_KPITCH];   // K tile [key][dim]
-  __shared__ __attribute__((aligned(16))) uint16_t vs_buf[2][PF_KEYS * PF_VPITCH];   // V tile [key][dim]
+  __shared__ __attribute__((aligned(16))) uint16_t ks_all[NG][2][PF_KEYS * PF_KPITCH];   // K tile [key][dim]
+  __shared__ __attribute__((aligned(16))) uint16_t vs_all[NG][2][PF_KEYS * PF_VPITCH];   // V tile [key][dim]
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: the per-wave tile tests become scalar branches
+  const int lane = threadIdx.x & 63;
+  const int wave_wg = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);  // uniform: per-wave tile tests become scalar branches
+  const int grp = NG == 1 ? 0 : wave_wg >> 2;  // key group of this wave
+  const int wave = wave_wg & 3;                // its 16 * MT query rows inside the workgroup's tile
+  const int tid = threadIdx.x & (PF_THREADS - 1);  // thread index inside the group (staging)
+  uint16_t (*ks_buf)[PF_KEYS * PF_KPITCH] = ks_all[grp];
+  uint16_t (*vs_buf)[PF_KEYS * PF_VPITCH] = vs_all[grp];
   const int ni = lane & 15, kb = lane >> 4;
   // The grid is one-dimensional, heads fastest, and under the causal mask the LONGEST query tiles come first: workgroups
   // are dispatched in index order to whichever CU frees up, i.e. greedy longest-job-first balancing of the triangle
@@ -132,19 +141,24 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
         *reinterpret_cast<u32x4_t*>(vsw + it * 16 * PF_VPITCH) = vreg[it];
       }
     };
-    load_tile(0);
+    // group g walks key tiles g, g + NG, ...: tile T of the group starts at key kstep * T + koff
+    constexpr int kstep = NG * PF_KEYS;
+    const int koff = grp * PF_KEYS;
+    load_tile(koff);
     stage_tile(0);
-    load_tile(PF_KEYS);
+    load_tile(koff + kstep);
     __syncthreads();
     int buf = 0;
-    for (int k0 = 0; k0 < k_end; k0 += PF_KEYS, buf ^= 1) {
+    for (int kbase = 0; kbase < k_end; kbase += kstep, buf ^= 1) {
+      const int k0 = kbase + koff;
       // the other copy was last read one iteration ago and every wave has passed that iteration's barrier
       stage_tile(buf ^ 1);
       const uint16_t* ks = ks_buf[buf];
       // transposing reads of the V tile (ds_read_b64_tr_b16): lane p of a 16-lane group supplies row p/4 (key kb*4 + p/4),
       // columns (p%4)*4.. of a 4 x 16 block and receives column p%16 of it, i.e. 4 keys of ONE head dim
       const unsigned char* tr0 = reinterpret_cast<const unsigned char*>(vs_buf[buf]) + (kb * 4 + (ni >> 2)) * (PF_VPITCH * 2) + (ni & 3) * 8;
-      const bool wave_live = !a.causal || k0 <= q0 + 16 * MT - 1 + shift;  // some key of the tile is visible to this wave
+      // some key of the tile is visible to this wave (NG = 2: the other group's last tile may lie past k_end)
+      const bool wave_live = k0 < k_end && (!a.causal || k0 <= q0 + 16 * MT - 1 + shift);
       if (wave_live && q0 < a.seq_q) {
         // ---- S^T = K.Q^T: the K fragments (A) of a key sub-tile feed all MT query tiles (B).  All 16 fragment reads are
         //      issued before the first MFMA (one LDS latency per tile) and the NT x MT accumulators are independent chains ----
@@ -171,7 +185,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
         __builtin_amdgcn_sched_barrier(0);
         // the K fragment registers are free again: tile T + 2 leaves for the prefetch registers now and has the softmax,
         // the second MFMA phase and the barrier to land
-        load_tile(k0 + 2 * PF_KEYS);
+        load_tile(k0 + 2 * kstep);
         // V fragments of the first four dim tiles: the transposing reads fly while the softmax runs on the VALU
         // (which has no LDS traffic of its own).  Fragment hh covers keys hh*32 ..+32 in the k-slot order of P.
         u32x4_t vf[8][2];
@@ -253,9 +267,38 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(const Prefi
             for (int mt = 0; mt < MT; ++mt) oacc[mt][t] = mfma16<FT>(vf[t][hh], pf[mt][hh], oacc[mt][t]);
         __builtin_amdgcn_s_setprio(0);
       } else {
-        load_tile(k0 + 2 * PF_KEYS);
+        load_tile(k0 + 2 * kstep);
       }
       __syncthreads();  // tile consumed by every wave; the copy written above becomes visible
+    }
+    if constexpr (NG == 2) {
+      // ---- merge the two key groups: group 1 -> LDS (the K tiles are dead after the loop's last barrier), group 0 adds ----
+      f32x4_t* ox = reinterpret_cast<f32x4_t*>(&ks_all[0][0][0]);   // [wave][mt][t][lane]: 4 x MT x 8 KiB <= 64 KiB
+      float* mx = reinterpret_cast<float*>(&vs_all[0][0][0]);       // [wave][mt][m, l][lane]
+      if (grp == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) ox[((wave * MT + mt) * 8 + t) * 64 + lane] = oacc[mt][t];
+          mx[((wave * MT + mt) * 2 + 0) * 64 + lane] = mrow[mt];
+          mx[((wave * MT + mt) * 2 + 1) * 64 + lane] = lrow[mt];
+        }
+      }
+      __syncthreads();
+      if (grp == 1) return;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float m1 = mx[((wave * MT + mt) * 2 + 0) * 64 + lane], l1 = mx[((wave * MT + mt) * 2 + 1) * 64 + lane];
+        const float mn = fmaxf(mrow[mt], m1);
+        const float c0 = __builtin_amdgcn_exp2f(mrow[mt] - mn), c1 = __builtin_amdgcn_exp2f(m1 - mn);  // a group without tiles: m = -1e30, c = 0 or 1
+        lrow[mt] = lrow[mt] * c0 + l1 * c1;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const f32x4_t o1 = ox[((wave * MT + mt) * 8 + t) * 64 + lane];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) oacc[mt][t][r] = oacc[mt][t][r] * c0 + o1[r] * c1;
+        }
+      }
     }
     // ---- normalise and store: lane holds O[q0 + mt*16 + ni][t*16 + kb*4 .. +4] ----
 #pragma unroll
@@ -306,7 +349,17 @@ extern "C" int dihip_prefill_attn(void* stream, void* out, const void* q, const 
   // 128-row query tiles read every K / V fragment once per two MFMAs; 64-row tiles double the workgroup count.
   // Two workgroups fit a CU: take the small tile while the large one would fill less than 1.5 slots (measured).
   auto wgs = [&](int rows) { return (long)((seq_q + rows - 1) / rows) * n_heads; };
-  const int mt = force_mt > 0 ? std::min(force_mt, 2) : (2 * wgs(128) >= 3L * ncu ? 2 : 1);
+  static int force_ng = -1;  // DIHIP_PREFILL_NG: diagnostics
+  if (force_ng < 0) {
+    const char* e = getenv("DIHIP_PREFILL_NG");
+    force_ng = e ? atoi(e) : 0;
+  }
+  // While all 128-row workgroups are resident at once (2 per CU) the longest one sets the time: two key groups per
+  // workgroup halve its chain of key tiles (same 8 waves per CU).  Measured: +12 % at 2048 tokens (448 workgroups);
+  // below one workgroup per CU the 64-row tiles are faster still, above two per CU the greedy dispatch balances already
+  // (-10..14 % with two groups at 4096 / 8192).
+  const int ng = force_ng > 0 ? std::min(force_ng, 2) : (force_mt == 0 && wgs(128) > (long)ncu && wgs(128) <= 2L * ncu ? 2 : 1);
+  const int mt = ng == 2 ? 2 : force_mt > 0 ? std::min(force_mt, 2) : (2 * wgs(128) >= 3L * ncu ? 2 : 1);
   const int rows = 64 * mt;
   const int nqt = (seq_q + rows - 1) / rows;
   static int force_prio = -2;  // DIHIP_PREFILL_PRIO: diagnostics
@@ -316,13 +369,14 @@ extern "C" int dihip_prefill_attn(void* stream, void* out, const void* q, const 
   }
   // raised issue priority for the MFMA phases: +9..11 % once the grid exceeds the resident workgroups (2 per CU), +2 % at
   // 16384, but -4 % while every workgroup is resident from the start (measured, A/B in one process)
-  const int prio = force_prio >= 0 ? force_prio : ((long)nqt * n_heads > 2L * ncu ? 1 : 0);
+  const int prio = force_prio >= 0 ? force_prio : ((long)nqt * n_heads > (ng == 2 ? 1L : 2L) * ncu ? 1 : 0);
   PrefillArgs a{out, q, k, v, seq_q, seq_k, q_stride, kv_stride, n_heads, n_groups, causal, alpha, prio};
   const dim3 grid(nqt * n_heads);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == DIHIP_BF16 && mt == 2) hipLaunchKernelGGL((prefill_attn_kernel<DIHIP_BF16, 2>), grid, dim3(PF_THREADS), 0, s, a);
-  else if (dtype == DIHIP_BF16) hipLaunchKernelGGL((prefill_attn_kernel<DIHIP_BF16, 1>), grid, dim3(PF_THREADS), 0, s, a);
-  else if (mt == 2) hipLaunchKernelGGL((prefill_attn_kernel<DIHIP_F16, 2>), grid, dim3(PF_THREADS), 0, s, a);
-  else hipLaunchKernelGGL((prefill_attn_kernel<DIHIP_F16, 1>), grid, dim3(PF_THREADS), 0, s, a);
+#define PF_GO(FT_, MT_, NG_) \
+  if (dtype == FT_ && mt == MT_ && ng == NG_) hipLaunchKernelGGL((prefill_attn_kernel<FT_, MT_, NG_>), grid, dim3(PF_THREADS * NG_), 0, s, a);
+  PF_GO(DIHIP_BF16, 2, 1) PF_GO(DIHIP_BF16, 1, 1) PF_GO(DIHIP_BF16, 2, 2)
+  PF_GO(DIHIP_F16, 2, 1) PF_GO(DIHIP_F16, 1, 1) PF_GO(DIHIP_F16, 2, 2)
+#undef PF_GO
   return launch_status();
 }
