@@ -115,3 +115,39 @@ def test_prefill_error_behaviour(ops):
     rc = ops.lib().dihip_prefill_attn(ops.cur_stream(), ops.ptr(t), ops.ptr(t), ops.ptr(t), ops.ptr(t), 0, 0, 256, 256, 2, 2, 128, 1,
                                       1.0, capi.BF16)
     assert rc == capi.SUCCESS  # empty prefill
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("causal", [True, False])
+def test_prefill_two_key_groups(ops, causal):
+    """Grids between one and two workgroups per CU run the 8-wave form: two 4-wave groups take alternate key tiles of a
+    query tile and merge (O, m, l) through LDS.  5 x 64 = 320 workgroups, ragged lengths, seq_k > seq_q."""
+    rng = np.random.default_rng(11)
+    Lq, Lk, n, g, H, ft = 600, 700, 64, 8, 128, "bf16"
+    q = bf16_round(rng.normal(0, 1, (Lq, n, H)).astype(np.float32))
+    k = bf16_round(rng.normal(0, 1, (Lk, g, H)).astype(np.float32))
+    v = bf16_round(rng.normal(0, 1, (Lk, g, H)).astype(np.float32))
+    alpha = 1.0 / np.sqrt(H)
+    ref = attention.prefill_attention(q, k, v, alpha, causal)
+    out = ops.prefill_attn(dev(q.reshape(Lq, -1), ft), dev(k.reshape(Lk, -1), ft), dev(v.reshape(Lk, -1), ft), n, g, H, alpha, causal)
+    np.testing.assert_allclose(out.float().cpu().numpy().reshape(Lq, n, H), ref, rtol=1e-2, atol=5e-3)
+
+
+@pytest.mark.gpu
+def test_prefill_full_size_2048_properties(ops):
+    """BASELINE sequence length at the Qwen2-7B head counts (448 workgroups: the two-key-group form): the first row
+    attends to key 0 only, and the first 128 rows agree with a 128-token call (another tile shape)."""
+    rng = np.random.default_rng(12)
+    L, n, g, H = 2048, 28, 4, 128
+    qkv = torch.from_numpy(rng.normal(0, 1, (L, (n + 2 * g) * H)).astype(np.float32)).to(torch.bfloat16).cuda()
+    q, k, v = qkv[:, : n * H], qkv[:, n * H:(n + g) * H], qkv[:, (n + g) * H:]
+    full = ops.prefill_attn(q, k, v, n, g, H, 0.088)
+    assert torch.isfinite(full.float()).all()
+    v0 = v[0].float().cpu().numpy().reshape(g, H)
+    np.testing.assert_array_equal(full[0].float().cpu().numpy().reshape(n, H), np.repeat(v0, n // g, axis=0))
+    short = ops.prefill_attn(q[:128], k[:128], v[:128], n, g, H, 0.088)
+    np.testing.assert_allclose(full[:128].float().cpu().numpy(), short.float().cpu().numpy(), rtol=1e-2, atol=2.5e-3)
+    # last row against the f64 oracle (one query over all 2048 keys)
+    qn = q[-1:].float().cpu().numpy().reshape(1, n, H)
+    ref = attention.prefill_attention(qn, k.float().cpu().numpy().reshape(L, g, H), v.float().cpu().numpy().reshape(L, g, H), 0.088)
+    np.testing.assert_allclose(full[-1].float().cpu().numpy().reshape(1, n, H), ref, rtol=1e-2, atol=2.5e-3)
