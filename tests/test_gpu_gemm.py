@@ -509,3 +509,45 @@ def test_kslice_kernel_full_size_mlp(ops, wbits, G, M):
     cols = rng.choice(K, 48, replace=False)
     ref_o = h0n[:, cols] + ak.astype(np.float64) @ gemm_ref.dequant(qd, sd, zd, G, wbits)[:, cols].astype(np.float64)
     np.testing.assert_allclose(ok_[:, cols], ref_o, rtol=2e-3, atol=2e-3 * np.abs(ref_o).max())
+
+
+# Qwen2-7B under TP = 8 (tp.py: every KV head on two ranks, its 7 query heads split 4 + 3; 148 FFN groups split 19 / 18):
+# the per-rank linear layers of the ranks with the larger and the smaller share
+TP8_7B = [("qkv_r0", 3584, 768), ("qkv_r1", 3584, 640), ("o_r0", 512, 3584), ("o_r1", 384, 3584),
+          ("gate_r0", 3584, 2432), ("gate_r7", 3584, 2304), ("down_r0", 2432, 3584), ("down_r7", 2304, 3584)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,K,N", TP8_7B)
+@pytest.mark.parametrize("M", [1, 32])
+def test_qwen7b_tp8_rank_shapes(ops, name, K, N, M):
+    """The scale bench runs the decode step at TP = 2 / 4 / 8: every per-rank shape must be served (int4 g128 and
+    int8 per-channel, batch 1 and 32, fused forms as the decoder calls them) and match the oracle."""
+    rng = np.random.default_rng(K + N + M)
+    for wbits, G in ((4, 128), (8, -1)):
+        x, q, s, z = make_case(rng, M, N, K, G, wbits, "bf16")
+        pw = ops.pack_lowp(to_dev(q), to_dev(s, "bf16"), to_dev(z, "bf16"), G, wbits)
+        sc = ops.Scratch(ops.lowp_workspace_bytes(wbits, M, N, K, G))
+        if name.startswith(("o_", "down_")):        # residual form from bf16 activations
+            h = rng.normal(0, 1, (M, N)).astype(np.float32)
+            out = ops.fused_gemm_addto(to_dev(x, "bf16"), pw, torch.from_numpy(h).cuda(), sc)
+            ref = h + gemm_ref.gemm_a16wx(x, q, s, z, G, wbits, ft="f32")
+            np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+            continue
+        hk = rng.normal(0, 1.5, (M, K)).astype(np.float32)
+        gamma = bf16_round(rng.normal(1, 0.1, K).astype(np.float32))
+        xn = bf16_round(glue.rmsnorm(hk, gamma, 1e-6))
+        hd, gd = torch.from_numpy(hk).cuda(), to_dev(gamma, "bf16")
+        if name.startswith("qkv"):
+            bias = bf16_round(rng.normal(0, 0.5, N).astype(np.float32))
+            y = ops.fused_norm_gemm(hd, gd, 1e-6, pw, to_dev(bias, "bf16"), sc)
+            ref = gemm_ref.gemm_a16wx(xn, q, s, z, G, wbits, bias=bias, ft="bf16")
+            assert_close(y.float().cpu().numpy(), ref, "bf16", what=f"{name} W{wbits}")
+        else:
+            _, q2, s2, z2 = make_case(rng, 1, N, K, G, wbits, "bf16")
+            pw2 = ops.pack_lowp(to_dev(q2), to_dev(s2, "bf16"), to_dev(z2, "bf16"), G, wbits)
+            act = ops.fused_norm_swiglu(hd, gd, 1e-6, pw, pw2, sc)
+            g_ = gemm_ref.gemm_a16wx(xn, q, s, z, G, wbits, ft="f32")
+            u_ = gemm_ref.gemm_a16wx(xn, q2, s2, z2, G, wbits, ft="f32")
+            ref = bf16_round(glue.silu(g_) * u_)
+            assert_close(act.float().cpu().numpy(), ref, "bf16", what=f"{name} W{wbits} swiglu", pre=ref)
