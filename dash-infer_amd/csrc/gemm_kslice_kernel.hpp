@@ -15,8 +15,8 @@
 //     per wave); 2 * MT waves sum the slices in fixed order and apply the epilogue while the others stream on;
 //   * K beyond 8 slices (down projection) is split across workgroups: f32 partial tiles go to the slab of the
 //     panel kernel and gemm_panel_reduce_kernel finishes (same layout, same deterministic order).
-// Sum_k x[m][k] per quantisation group (the zero-point term) is recomputed per chunk with MFMAs against ones:
-// the matrix pipe is idle most of the time here and the alternative costs 32 registers or 64 KiB of LDS.
+// Sum_k x[m][k] per chunk (the zero-point term) is computed once per wave with MFMAs against ones and kept in
+// wave-private LDS (W4; W8 slices have twice the chunks and recompute it).
 // Arithmetic per element as in the other decode kernels (exact integer MFMA, scale / zero-point per group on
 // the f32 accumulator); a group that straddles two K-slices is closed in both with the same (scale, zero).
 #pragma once
@@ -42,6 +42,11 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
   constexpr int P = RH * CH;
 
   __shared__ __attribute__((aligned(16))) f32x4_t xch[2][KSL_WAVES][2][MT][64];
+  // W4: Sum_k x[m][k] of every chunk of the wave's slice, computed once (wave-private LDS, no barrier): at M = 32 the
+  // 8 extra MFMAs per chunk were half of the matrix-pipe time of a kernel that is instruction-bound, not load-bound.
+  // W8 slices have 8 chunks (2 x the LDS); their sums are recomputed per chunk.
+  constexpr bool XS_LDS = WBITS == 4;
+  __shared__ __attribute__((aligned(16))) f32x4_t xsl[XS_LDS ? KSL_WAVES : 1][XS_LDS ? CH : 1][MT][64];
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -104,6 +109,17 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
 
   Slot ring[P];
   if (active) {
+    if constexpr (XS_LDS) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          f32x4_t sx = zero4;
+#pragma unroll
+          for (int ks = 0; ks < KSTEPS; ++ks) sx = mfma16<FT>(xf[c * KSTEPS + ks][mt], ones, sx);
+          xsl[wave][c][mt][lane] = sx;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < RH; ++r) {
       set_half(r);
@@ -140,9 +156,12 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               g[mt] = mfma16<FT>(xf[c * KSTEPS + ks][mt], bf, g[mt]);
-              xs[mt] = mfma16<FT>(xf[c * KSTEPS + ks][mt], ones, xs[mt]);  // Sum_k x[m][k] of the chunk
+              if constexpr (!XS_LDS) xs[mt] = mfma16<FT>(xf[c * KSTEPS + ks][mt], ones, xs[mt]);  // Sum_k x[m][k] of the chunk
             }
           }
+          if constexpr (XS_LDS)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xs[mt] = xsl[wave][c][mt][lane];
           const float s_ = ft_bits_to_f32<FT>(slot.s & 0xFFFFu);
           const float nzp_ = -(ft_bits_to_f32<FT>(slot.s >> 16) + EX::OFFSET);
           if constexpr (GPT) {

@@ -406,10 +406,10 @@ static KslicePlan make_kslice_plan(int wbits, int M, int N, int K, int group_siz
   const int ch = wbits == 4 ? 4 : 8;  // k-tiles per K-slice (16 k-steps of 32)
   if (d.KT % ch) return p;            // slices hold whole k-tiles of equal count
   if (wbits == 8 && d.group == d.KTILE) return p;  // W8 g64 (a scale per k-tile in a 16-slot ring) does not fit the register file
-  // Measured against the panel kernel (tools/gemv_bench, 7B and 72B/TP8 shapes): +7..8 % on the SwiGLU pair at M <= 16
-  // (8 KiB in flight per wave), equal at M = 32 (the 128 activation registers leave room for 4 KiB), 30-40 % slower on
+  // Measured against the panel kernel (tools/gemv_bench and bench.py, 7B and 72B/TP8 shapes): +13 % on the SwiGLU pair
+  // at M = 16 (8 KiB in flight per wave), +4 % (gate/up) and +8 % (down, split-K slab) at M = 32, but 30-40 % slower on
   // matrices of a few MB (one or two half-units per workgroup: the ring never reaches steady state)
-  if (mode != 2 && !(M <= 16 && dual && (size_t)N * K * wbits / 8 * 2 >= ((size_t)24 << 20))) return p;
+  if (mode != 2 && (size_t)N * K * wbits / 8 * (dual ? 2 : 1) < ((size_t)24 << 20)) return p;
   int ncu = cached_num_cus();
   if (ncu <= 0) ncu = 256;
   const int nsl = d.KT / ch;

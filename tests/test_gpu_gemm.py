@@ -452,7 +452,7 @@ def test_kslice_kernel_full_size_mlp(ops, wbits, G, M):
     """Register-resident K-slice kernel (gemm_kslice_kernel.hpp) on the BASELINE configs[2] MLP at full size:
     SwiGLU epilogue with one workgroup-level K-slice (gate/up, 7 waves), residual epilogue through the split-K slab
     (down: 37 slices = 5 workgroup slices), plain epilogue with bias.  DIHIP_GEMM_KSLICE=2 forces it for every
-    eligible shape (by default it serves M <= 16 SwiGLU pairs of >= 24 MB); checked against the panel kernel
+    eligible shape (by default it serves weight matrices / SwiGLU pairs of >= 24 MB); checked against the panel kernel
     (DIHIP_GEMM_KSLICE=0; other summation order over K) and the f64 oracle."""
     import os
     rng = np.random.default_rng(3 * M + wbits + G)
