@@ -294,8 +294,10 @@ def main():
                 kname = "gemv_stream_kernel<%d, 2, %d, 1, 1, %d>" % (wbits, 1 if batch == 1 else 4, gpt)
                 kdesc = " (RMSNorm + gate/up GEMV + SwiGLU)"
             else:
-                kname = "gemm_panel_kernel<%d, 2, %d, 1, %d>" % (wbits, 2 if batch > 16 else 1, gpt)
-                kdesc = " (gate/up panel GEMM + SwiGLU; the timed launch pair includes the RMSNorm kernel)"
+                # the 7B gate/up pair (>= 24 MB) runs on the K-slice kernel unless DIHIP_GEMM_KSLICE=0 selects the panel kernel
+                fam = "gemm_panel_kernel" if os.environ.get("DIHIP_GEMM_KSLICE", "1") == "0" else "gemm_kslice_kernel"
+                kname = "%s<%d, 2, %d, 1, %d>" % (fam, wbits, 2 if batch > 16 else 1, gpt)
+                kdesc = " (gate/up small-batch GEMM + SwiGLU; the timed launch pair includes the RMSNorm kernel)"
             out["roofline"] = {"bound": "hbm", "kernel": "dihip::" + kname + kdesc,
                                "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4),
