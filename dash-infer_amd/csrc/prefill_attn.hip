@@ -332,7 +332,7 @@ extern "C" int dihip_prefill_attn(void* stream, void* out, const void* q, const 
   DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16, DIHIP_PARAM_ERROR, "prefill_attn: FLOAT16 / BFLOAT16 only");
   DIHIP_REQUIRE(seq_k >= seq_q || !causal, DIHIP_PARAM_ERROR, "prefill_attn: causal attention needs seq_k >= seq_q");
   DIHIP_REQUIRE(alpha > 0.f, DIHIP_PARAM_ERROR, "prefill_attn: the softmax scale must be positive");
-  DIHIP_REQUIRE((size_t)(seq_k + 2 * PF_KEYS + 64) * (size_t)(kv_stride > 0 ? kv_stride : 0) * 2 < (1ull << 31), DIHIP_EXCEED_LIMIT_ERROR,
+  DIHIP_REQUIRE((size_t)(seq_k + 6 * PF_KEYS + 64) * (size_t)(kv_stride > 0 ? kv_stride : 0) * 2 < (1ull << 31), DIHIP_EXCEED_LIMIT_ERROR,
                 "prefill_attn: K / V of one call must stay below 2 GiB (32-bit buffer offsets)");
   if (seq_q == 0) return DIHIP_SUCCESS;
   DIHIP_REQUIRE(out && q && k && v && seq_k > 0, DIHIP_PARAM_ERROR, "prefill_attn: null pointer / empty keys");

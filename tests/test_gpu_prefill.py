@@ -115,6 +115,12 @@ def test_prefill_error_behaviour(ops):
     rc = ops.lib().dihip_prefill_attn(ops.cur_stream(), ops.ptr(t), ops.ptr(t), ops.ptr(t), ops.ptr(t), 0, 0, 256, 256, 2, 2, 128, 1,
                                       1.0, capi.BF16)
     assert rc == capi.SUCCESS  # empty prefill
+    rc = ops.lib().dihip_prefill_attn(ops.cur_stream(), ops.ptr(t), ops.ptr(t), ops.ptr(t), ops.ptr(t), 2, 2, 256, 256, 2, 2, 128, 1,
+                                      0.0, capi.BF16)
+    assert rc == capi.PARAM_ERROR and b"scale" in ops.lib().dihip_last_error()       # exp2 folding needs alpha > 0
+    rc = ops.lib().dihip_prefill_attn(ops.cur_stream(), ops.ptr(t), ops.ptr(t), ops.ptr(t), ops.ptr(t), 2, 1 << 20, 256, 4096, 2, 2,
+                                      128, 1, 1.0, capi.BF16)
+    assert rc == capi.EXCEED_LIMIT_ERROR and b"2 GiB" in ops.lib().dihip_last_error()   # 32-bit buffer offsets
 
 
 @pytest.mark.gpu
