@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 python -c "import torch; print(torch.__version__, torch.cuda.is_available(), torch.cuda.get_device_name(0))" > $OUT/env.log 2>&1
 nproc >> $OUT/env.log; rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -8 >> $OUT/env.log
-for f in test_gpu_gemm test_gpu_kv_attn test_gpu_glue test_gpu_prefill test_gpu_host_ops test_gpu_moe test_gpu_decoder; do
+for f in test_gpu_gemm test_gpu_kv_attn test_gpu_glue test_gpu_prefill test_gpu_host_ops test_gpu_moe test_gpu_decoder test_gpu_tp_loopback; do
   timeout 900 python -m pytest tests/$f.py -q -m gpu -x --timeout 600 > $OUT/$f.log 2>&1
   echo "$f exit $?" | tee -a $OUT/summary.log
   tail -5 $OUT/$f.log
