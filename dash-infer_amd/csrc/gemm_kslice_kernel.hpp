@@ -104,7 +104,7 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
   const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
   uint32_t ex_mask = 0x000F000Fu, ex_magic = FT == DIHIP_BF16 ? 0x43004300u : 0x64006400u;
   asm volatile("" : "+v"(ex_mask), "+v"(ex_magic));
-  u32x4_t ones = FT == DIHIP_BF16 ? u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}
+  const u32x4_t ones = FT == DIHIP_BF16 ? u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}
                                   : u32x4_t{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
 
   Slot ring[P];
@@ -147,9 +147,6 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
           f32x4_t g[MT], xs[MT];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) g[mt] = xs[mt] = zero4;
-          // the chunk's Sum_k x is loop-invariant: left alone, hipcc hoists all CH x MT of them out of the unit loop
-          // (32 more live registers -> 140 spilled); the opaque redefinition keeps the recomputation where it is
-          asm volatile("" : "+v"(ones));
 #pragma unroll
           for (int ks = 0; ks < KSTEPS; ++ks) {
             const u32x4_t bf = EX::frag(slot.w, ks, ex_mask, ex_magic);
