@@ -112,3 +112,47 @@ def test_experts_qwen2_57b_a14b_shape(ops):
     ref = moe.experts_ffn(x, e1, s_np, list(zip(*gate)), list(zip(*up)), list(zip(*down)), G, wbits)
     np.testing.assert_allclose(part, ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max())
     assert np.all(part[1] == 0)
+
+
+@pytest.mark.parametrize("wbits,G,nranks", [(8, -1, 8), (4, 128, 4)])
+def test_experts_tensor_parallel_split(ops, wbits, G, nranks):
+    """configs[4] runs the experts under TP: every rank holds a column slice of each expert's gate / up and the matching
+    row slice of its down projection (the FFN split of SURVEY 8(e): whole quantisation groups per rank, per-channel
+    scales of the row-split matrix not split), calls the SAME entry point with its local width, and the outputs are
+    summed by the all-reduce.  SwiGLU is column-wise and the down projection linear, so the sum over ranks must equal
+    the unsplit call (to the rounding of the per-rank bf16 outputs)."""
+    rng = np.random.default_rng(7 * nranks + wbits)
+    T, E, k, hidden = 3, 8, 3, 256
+    proj = 64 * nranks if wbits == 8 else 128 * nranks
+    x = bf16_round(rng.normal(0, 1, (T, hidden)).astype(np.float32))
+    gate, up, down = (make_experts(rng, E, proj, hidden, G, wbits), make_experts(rng, E, proj, hidden, G, wbits),
+                      make_experts(rng, E, hidden, proj, G, wbits))
+    logits = bf16_round(rng.normal(0, 1.5, (T, E)).astype(np.float32))
+    scores, experts = ops.moe_route(dev(logits, torch.bfloat16), k)
+    xd = dev(x, torch.bfloat16)
+    full = ops.moe_experts(xd, experts, scores, pack(ops, *gate, G, wbits), pack(ops, *up, G, wbits), pack(ops, *down, G, wbits))
+
+    def cols(trip, lo, hi):   # column slice of [K, N] weights (uint4: two columns per byte) and of their [G, N] parameters
+        qs, ss, zs = trip
+        if wbits == 4:
+            qs = [quant.pack_u4(quant.unpack_u4(q, proj)[:, lo:hi]) for q in qs]
+        else:
+            qs = [q[:, lo:hi] for q in qs]
+        return qs, [s_[:, lo:hi] for s_ in ss], [z[:, lo:hi] for z in zs]
+
+    def rows(trip, lo, hi):   # row (K) slice: whole groups; per-channel parameters stay whole
+        qs, ss, zs = trip
+        qs = [q[lo:hi] for q in qs]
+        if G > 0:
+            ss, zs = [s_[lo // G:hi // G] for s_ in ss], [z[lo // G:hi // G] for z in zs]
+        return qs, ss, zs
+
+    per = proj // nranks
+    acc = np.zeros((T, hidden), np.float64)
+    for r in range(nranks):
+        lo, hi = r * per, (r + 1) * per
+        out_r = ops.moe_experts(xd, experts, scores, pack(ops, *cols(gate, lo, hi), G, wbits), pack(ops, *cols(up, lo, hi), G, wbits),
+                                pack(ops, *rows(down, lo, hi), G, wbits))
+        acc += out_r.float().cpu().numpy()
+    ref = full.float().cpu().numpy()
+    np.testing.assert_allclose(acc, ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max())
