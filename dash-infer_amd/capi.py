@@ -34,6 +34,9 @@ _SIGS = {
     "dihip_fused_gemm_addto": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, i32]),
     "dihip_fused_norm_swiglu_ex": (i32, [vp, i32, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, i32, i32]),
     "dihip_fused_gemm_addto_ex": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, i32, i32]),
+    "dihip_fused_gemm_addto_norm": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, i32, i32, vp, f32, vp, i32]),
+    "dihip_prenorm_gemm": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp, i32]),
+    "dihip_prenorm_swiglu": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, i32, i32]),
     "dihip_gemm_lowp_prefers_frag": (i32, [i32, i32, i32, i32, i32, i32]),
     "dihip_moe_route": (i32, [vp, vp, i32, i32, i32, vp, vp, i32]),
     "dihip_moe_workspace_bytes": (sz, [i32, i32, i32, i32]),

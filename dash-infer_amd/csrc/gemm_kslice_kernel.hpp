@@ -238,10 +238,7 @@ hipError_t launch_gemm_kslice(const PanelArgs& a, int groups, int waves, hipStre
   template <>                                                                                                 \
   hipError_t launch_gemm_kslice<WBITS, FT, MT, EPI, GPT>(const PanelArgs& a, int groups, int waves, hipStream_t s) { \
     hipLaunchKernelGGL((gemm_kslice_kernel<WBITS, FT, MT, EPI, GPT>), dim3(groups, a.nslices), dim3(waves * 64), 0, s, a); \
-    if (a.nslices > 1) {                                                                                      \
-      const int blocks = (int)std::min<size_t>(((size_t)a.M * a.N + 255) / 256, 1024);                        \
-      hipLaunchKernelGGL((gemm_panel_reduce_kernel<FT, EPI>), dim3(blocks), dim3(256), 0, s, a, MT);          \
-    }                                                                                                         \
+    if (a.nslices > 1) launch_slab_reduce<FT, EPI>(a, MT, s);                                                 \
     return hipGetLastError();                                                                                 \
   }
 #define DIHIP_DEFINE_KSLICE_LAUNCH_SET(WBITS, FT, GPT)      \

@@ -229,6 +229,13 @@ struct GemmCall {
   size_t ws_bytes;
   void* sync;
   int x_layout, y_layout;  // DIHIP_ACT_ROWMAJOR / DIHIP_ACT_FRAG32 (small-batch kernel only)
+  // EPI_ADDTO: RMSNorm of the finished rows wanted in n_out (dihip_fused_gemm_addto_norm); *n_done is set when the kernel
+  // family that served the call has produced it (split-K slab reduction), otherwise the caller runs the norm kernel
+  const void* n_gamma;
+  float n_eps;
+  void* n_out;
+  int n_frag_mt;
+  bool* n_done;
 };
 
 
@@ -575,6 +582,13 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
       g.slab = reinterpret_cast<float*>(c.ws);
       g.yfrag = c.y_layout == DIHIP_ACT_FRAG32;
       g.nunits = kp.nunits;
+      if (c.epi == EPI_ADDTO && c.n_gamma && c.n_out && g.nslices > 1 && c.N % 4 == 0 && c.N <= 8192) {
+        g.n_gamma = c.n_gamma;
+        g.n_eps = c.n_eps;
+        g.n_out = c.n_out;
+        g.n_frag_mt = c.n_frag_mt;
+        if (c.n_done) *c.n_done = true;
+      }
       const bool gpt = g.ktpg == 1;
       const int mt = c.M > 16 ? 2 : 1;
       hipError_t e = hipErrorInvalidValue;
@@ -618,6 +632,13 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
       g.nslices = pp.nslices;
       g.slab = reinterpret_cast<float*>(c.ws);
       g.yfrag = c.y_layout == DIHIP_ACT_FRAG32;
+      if (c.epi == EPI_ADDTO && c.n_gamma && c.n_out && g.nslices > 1 && c.N % 4 == 0 && c.N <= 8192) {
+        g.n_gamma = c.n_gamma;
+        g.n_eps = c.n_eps;
+        g.n_out = c.n_out;
+        g.n_frag_mt = c.n_frag_mt;
+        if (c.n_done) *c.n_done = true;
+      }
       const bool gpt = g.ktpg == 1;
       const int mt = c.M > 16 ? 2 : 1;
       hipError_t e = hipErrorInvalidValue;
@@ -1132,6 +1153,124 @@ int dihip_fused_gemm_addto_ex(void* stream, int wbits, const void* x, const void
   c.sz0 = sz_packed;
   c.h_res = h_res;
   c.h_out = h_out;
+  c.M = M;
+  c.N = N;
+  c.K = K;
+  c.group_size = group_size;
+  c.alpha = 1.f;
+  c.ws = ws;
+  c.ws_bytes = ws_bytes;
+  c.sync = sync;
+  return run_gemm(reinterpret_cast<hipStream_t>(stream), c);
+}
+
+static int launch_rmsnorm_rows(hipStream_t s, const float* h, const void* gamma, float eps, int M, int K, void* out, int frag_mt) {
+  const bool vec = K % 4 == 0 && (reinterpret_cast<uintptr_t>(h) % 16 == 0) && (reinterpret_cast<uintptr_t>(gamma) % 8 == 0);
+  uint16_t* xo = reinterpret_cast<uint16_t*>(out);
+  if (vec && K <= 4096)
+    hipLaunchKernelGGL((rmsnorm_f32_to_ft_kernel<DIHIP_BF16, 4>), dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, frag_mt);
+  else if (vec && K <= 8192)
+    hipLaunchKernelGGL((rmsnorm_f32_to_ft_kernel<DIHIP_BF16, 8>), dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, frag_mt);
+  else
+    hipLaunchKernelGGL(rmsnorm_f32_to_ft_wide_kernel<DIHIP_BF16>, dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, frag_mt);
+  return launch_status();
+}
+
+int dihip_fused_gemm_addto_norm(void* stream, int wbits, const void* x, const void* w_packed, const void* sz_packed,
+                                const float* h_res, float* h_out, int M, int N, int K, int group_size, void* ws,
+                                size_t ws_bytes, void* sync, int dtype, int x_layout, const void* gamma, float eps,
+                                void* xnorm, int xnorm_layout) {
+  DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "fused path is bf16 only");
+  DIHIP_REQUIRE(x_layout == DIHIP_ACT_ROWMAJOR || x_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "fused addto: bad x_layout");
+  DIHIP_REQUIRE(xnorm_layout == DIHIP_ACT_ROWMAJOR || (xnorm_layout == DIHIP_ACT_FRAG32 && M <= 32 && N % 32 == 0),
+                DIHIP_PARAM_ERROR, "fused addto + norm: FRAG32 output needs M <= 32 and N %% 32 == 0");
+  DIHIP_REQUIRE(sync != nullptr && h_out && gamma && xnorm, DIHIP_PARAM_ERROR, "fused addto + norm: null pointer");
+  if (M == 0) return DIHIP_SUCCESS;
+  bool done = false;
+  GemmCall c{};
+  c.wbits = wbits;
+  c.dtype = dtype;
+  c.pro = PRO_PLAIN;
+  c.epi = EPI_ADDTO;
+  c.x = x;
+  c.ldx = K;
+  c.x_layout = x_layout;
+  c.w0 = w_packed;
+  c.sz0 = sz_packed;
+  c.h_res = h_res;
+  c.h_out = h_out;
+  c.M = M;
+  c.N = N;
+  c.K = K;
+  c.group_size = group_size;
+  c.alpha = 1.f;
+  c.ws = ws;
+  c.ws_bytes = ws_bytes;
+  c.sync = sync;
+  c.n_gamma = gamma;
+  c.n_eps = eps;
+  c.n_out = xnorm;
+  c.n_frag_mt = xnorm_layout == DIHIP_ACT_FRAG32 ? (M > 16 ? 2 : 1) : 0;
+  c.n_done = &done;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int st = run_gemm(s, c);
+  if (st || done) return st;
+  return launch_rmsnorm_rows(s, h_out, gamma, eps, M, N, xnorm, c.n_frag_mt);  // this plan has no slab reduction to ride on
+}
+
+int dihip_prenorm_gemm(void* stream, int wbits, const void* xnorm, int x_layout, const void* w_packed, const void* sz_packed,
+                       const void* bias, void* y, int M, int N, int K, int group_size, int act, void* ws, size_t ws_bytes,
+                       void* sync, int dtype) {
+  DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "fused path is bf16 only");
+  DIHIP_REQUIRE(x_layout == DIHIP_ACT_ROWMAJOR || x_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "prenorm gemm: bad x_layout");
+  DIHIP_REQUIRE(sync != nullptr && xnorm && y, DIHIP_PARAM_ERROR, "prenorm gemm: null pointer");
+  GemmCall c{};
+  c.wbits = wbits;
+  c.dtype = dtype;
+  c.pro = PRO_PLAIN;
+  c.epi = EPI_STD;
+  c.x = xnorm;
+  c.ldx = K;
+  c.x_layout = x_layout;
+  c.w0 = w_packed;
+  c.sz0 = sz_packed;
+  c.bias = bias;
+  c.y = y;
+  c.M = M;
+  c.N = N;
+  c.K = K;
+  c.group_size = group_size;
+  c.act = act;
+  c.alpha = 1.f;
+  c.ws = ws;
+  c.ws_bytes = ws_bytes;
+  c.sync = sync;
+  return run_gemm(reinterpret_cast<hipStream_t>(stream), c);
+}
+
+int dihip_prenorm_swiglu(void* stream, int wbits, const void* xnorm, int x_layout, const void* wg_packed,
+                         const void* szg_packed, const void* wu_packed, const void* szu_packed, void* y, int M, int N, int K,
+                         int group_size, void* ws, size_t ws_bytes, void* sync, int dtype, int y_layout) {
+  DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "fused path is bf16 only");
+  DIHIP_REQUIRE(x_layout == DIHIP_ACT_ROWMAJOR || x_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "prenorm swiglu: bad x_layout");
+  DIHIP_REQUIRE(y_layout == DIHIP_ACT_ROWMAJOR || y_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "prenorm swiglu: bad y_layout");
+  DIHIP_REQUIRE(sync != nullptr && xnorm && y, DIHIP_PARAM_ERROR, "prenorm swiglu: null pointer");
+  DIHIP_REQUIRE(y_layout == DIHIP_ACT_ROWMAJOR || (M > 4 && batch_kernel_eligible(wbits, M, N, K, group_size)), DIHIP_PARAM_ERROR,
+                "prenorm swiglu: FRAG32 output needs the small-batch kernel (4 < M <= 32, K a multiple of the k-tile)");
+  GemmCall c{};
+  c.wbits = wbits;
+  c.dtype = dtype;
+  c.pro = PRO_PLAIN;
+  c.epi = EPI_SWIGLU;
+  c.x = xnorm;
+  c.ldx = K;
+  c.x_layout = x_layout;
+  c.y_layout = y_layout;
+  c.w0 = wg_packed;
+  c.sz0 = szg_packed;
+  c.w1 = wu_packed;
+  c.sz1 = szu_packed;
+  c.y = y;
   c.M = M;
   c.N = N;
   c.K = K;

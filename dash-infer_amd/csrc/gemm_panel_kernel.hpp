@@ -54,6 +54,11 @@ struct PanelArgs {
   float* slab;  // [nslices][DUAL][M][N] f32
   int yfrag;    // y (EPI_STD / EPI_SWIGLU) in FRAG32
   int nunits;   // gemm_kslice_kernel.hpp: column tiles (SwiGLU: tile pairs) of the whole launch
+  // EPI_ADDTO with a split-K slab only: RMSNorm of the finished rows rides on the reduction (gemm_reduce_addto_norm_kernel)
+  const void* n_gamma;  // FT [N]; null: plain reduction
+  float n_eps;
+  void* n_out;          // FT, row-major [M, N] or FRAG32 (n_frag_mt = 1 / 2)
+  int n_frag_mt;
 };
 
 template <int FT, int EPI>
@@ -276,6 +281,96 @@ __global__ __launch_bounds__(256) void gemm_panel_reduce_kernel(const PanelArgs 
   }
 }
 
+// split-K reduction of an EPI_ADDTO GEMM fused with the RMSNorm that follows it in the decoder graph: one workgroup per
+// row keeps the finished f32 row in registers (slices summed in the fixed order of gemm_panel_reduce_kernel, residual
+// added as in panel_epilogue), writes h_out, and normalises straight into the next GEMM's activation layout -- the
+// arithmetic of rmsnorm_f32_to_ft_kernel (gemm_lowp.hip), one launch and one pass over the row less.
+// N % 4 == 0, N <= 1024 * VPT.
+template <int FT, int VPT>
+__global__ __launch_bounds__(256) void gemm_reduce_addto_norm_kernel(const PanelArgs a) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const int nvec = a.N >> 2;
+  const size_t total = (size_t)a.M * a.N;
+  f32x4_t v[VPT];
+  u32x2_t gm[VPT];
+  // loads of SB slices x VPT column vectors are in flight together (a loop over the runtime slice count with one
+  // dependent accumulation per load would serialise ~40 memory round trips per thread -- the slab comes from other XCDs'
+  // L2s, i.e. from memory); slices are still added in order
+  f32x4_t base[VPT];
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = min(tid + i * 256, nvec - 1);  // clamped: lanes past the row re-load its last vector and store nothing
+    const size_t e = (size_t)row * a.N + (size_t)c * 4;
+    v[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    gm[i] = reinterpret_cast<const u32x2_t*>(a.n_gamma)[c];
+    base[i] = a.h_res ? *reinterpret_cast<const f32x4_t*>(a.h_res + e) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  constexpr int SB = VPT <= 4 ? 8 : 4;
+  for (int s0 = 0; s0 < a.nslices; s0 += SB) {
+    f32x4_t t[SB][VPT];
+#pragma unroll
+    for (int j = 0; j < SB; ++j) {
+      const int sj = min(s0 + j, a.nslices - 1);
+#pragma unroll
+      for (int i = 0; i < VPT; ++i) {
+        const int c = min(tid + i * 256, nvec - 1);
+        t[j][i] = *reinterpret_cast<const f32x4_t*>(a.slab + (size_t)sj * total + (size_t)row * a.N + (size_t)c * 4);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < SB; ++j)
+      if (s0 + j < a.nslices) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[i][r] += t[j][i][r];
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = tid + i * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[i][r] = c < nvec ? __fadd_rn(base[i][r], __fmul_rn(a.alpha, v[i][r])) : 0.f;
+    if (c < nvec) *reinterpret_cast<f32x4_t*>(a.h_out + (size_t)row * a.N + (size_t)c * 4) = v[i];
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) ss += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  const float rstd = 1.f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)a.N + a.n_eps);
+  uint16_t* y = reinterpret_cast<uint16_t*>(a.n_out);
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = tid + i * 256;
+    if (c < nvec) {
+      const float g0 = ft_bits_to_f32<FT>(gm[i][0] & 0xFFFFu), g1 = ft_bits_to_f32<FT>(gm[i][0] >> 16);
+      const float g2 = ft_bits_to_f32<FT>(gm[i][1] & 0xFFFFu), g3 = ft_bits_to_f32<FT>(gm[i][1] >> 16);
+      const uint32_t lo = f32_to_ft_bits<FT>((g0 * v[i][0]) * rstd) | (f32_to_ft_bits<FT>((g1 * v[i][1]) * rstd) << 16);
+      const uint32_t hi = f32_to_ft_bits<FT>((g2 * v[i][2]) * rstd) | (f32_to_ft_bits<FT>((g3 * v[i][3]) * rstd) << 16);
+      const int k = c * 4;
+      const size_t idx = a.n_frag_mt ? act_frag_index(row, k, a.n_frag_mt) : (size_t)row * a.N + k;
+      *reinterpret_cast<u32x2_t*>(y + idx) = u32x2_t{lo, hi};
+    }
+  }
+}
+
+// the reduction launch shared by the panel and the K-slice kernels
+template <int FT, int EPI>
+inline void launch_slab_reduce(const PanelArgs& a, int mt_tiles, hipStream_t s) {
+  if constexpr (EPI == EPI_ADDTO) {
+    if (a.n_gamma) {  // host contract (run_gemm): N % 4 == 0, N <= 8192, 16-byte aligned rows
+      if (a.N <= 4096) hipLaunchKernelGGL((gemm_reduce_addto_norm_kernel<FT, 4>), dim3(a.M), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gemm_reduce_addto_norm_kernel<FT, 8>), dim3(a.M), dim3(256), 0, s, a);
+      return;
+    }
+  }
+  const int blocks = (int)std::min<size_t>(((size_t)a.M * a.N + 255) / 256, 1024);
+  hipLaunchKernelGGL((gemm_panel_reduce_kernel<FT, EPI>), dim3(blocks), dim3(256), 0, s, a, mt_tiles);
+}
+
 template <int WBITS, int FT, int MT, int EPI, int GPT>
 hipError_t launch_gemm_panel(const PanelArgs& a, int panels, hipStream_t stream);
 
@@ -283,10 +378,7 @@ hipError_t launch_gemm_panel(const PanelArgs& a, int panels, hipStream_t stream)
   template <>                                                                                                \
   hipError_t launch_gemm_panel<WBITS, FT, MT, EPI, GPT>(const PanelArgs& a, int panels, hipStream_t s) {     \
     hipLaunchKernelGGL((gemm_panel_kernel<WBITS, FT, MT, EPI, GPT>), dim3(panels, a.nslices), dim3(PANEL_THREADS), 0, s, a); \
-    if (a.nslices > 1) {                                                                                     \
-      const int blocks = (int)std::min<size_t>(((size_t)a.M * a.N + 255) / 256, 1024);                       \
-      hipLaunchKernelGGL((gemm_panel_reduce_kernel<FT, EPI>), dim3(blocks), dim3(256), 0, s, a, MT);         \
-    }                                                                                                        \
+    if (a.nslices > 1) launch_slab_reduce<FT, EPI>(a, MT, s);                                                \
     return hipGetLastError();                                                                                \
   }
 #define DIHIP_DEFINE_PANEL_LAUNCH_SET(WBITS, FT, GPT)      \

@@ -17,6 +17,8 @@ import ctypes as C
 from dataclasses import dataclass, field
 from typing import List, Optional
 
+import os
+
 import torch
 
 from . import capi, ops, quantize, tp
@@ -300,6 +302,18 @@ class DecodeSession:
         if not self.fused_attention and batch <= 32 and ops.prefers_frag(model.layers[0].o, batch):
             self.attn_frag = True
             self.attn = torch.zeros(ops.act_frag_numel(batch, self.n_loc * H), dtype=dt, device=device)
+        # Batched decode (4 < batch <= 32, one rank): the RMSNorm after each residual GEMM is produced by that GEMM call
+        # (riding on its split-K reduction) and handed to the next GEMM in its preferred layout -- two launches less
+        # per layer.  Under TP the all-reduce sits between the GEMM and the norm, so the separate norm stays.
+        self.norm_fuse = (4 < batch <= 32 and (comm is None or model.nranks == 1)
+                          and os.environ.get("DIHIP_DECODER_NORM_FUSE", "1") != "0")  # =0: diagnostics
+        if self.norm_fuse:
+            def norm_buf(pw, dual):
+                frag = ops.prefers_frag(pw, batch, dual=dual)
+                n = ops.act_frag_numel(batch, pw.K) if frag else batch * pw.K
+                return torch.zeros(n, dtype=dt, device=device), (ops.ACT_FRAG32 if frag else ops.ACT_ROWMAJOR)
+            self.xn1, self.xn1_layout = norm_buf(l0_.qkv, False)
+            self.xn2, self.xn2_layout = norm_buf(l0_.gate, True)
         self.argmax_ws = torch.empty(batch * 64 * 8, dtype=torch.uint8, device=device)
         nr = model.nranks
         self.pair = torch.empty(batch * 8, dtype=torch.uint8, device=device)
@@ -337,8 +351,12 @@ class DecodeSession:
         m, cfg, sc = self.model, self.model.cfg, self.scratch
         ops.embedding(self.ids, m.embed, out=self.h)
         tp_on = self.comm is not None and m.nranks > 1
+        nf = self.norm_fuse and not tp_on
         for li, lw in enumerate(m.layers):
-            ops.fused_norm_gemm(self.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sc, out=self.qkv)
+            if nf and li > 0:
+                ops.prenorm_gemm(self.xn1, lw.qkv, lw.qkv_bias, sc, self.B, x_layout=self.xn1_layout, out=self.qkv)
+            else:
+                ops.fused_norm_gemm(self.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sc, out=self.qkv)
             if self.fused_attention:
                 ops.span_attn_decode_fused(self.qkv, self.kv[li], self.old_lens, self.rope_tab, self.n_loc, self.g_loc, self.H,
                                            self.max_len, self.scale, self.attn_ws, out=self.attn)
@@ -347,6 +365,19 @@ class DecodeSession:
                 ops.span_attn_decode(self.q, self.kv[li], self.new_lens, self.n_loc, self.g_loc, self.H, self.max_len,
                                      self.scale, self.attn_ws, self.attn_sync, out=self.attn,
                                      out_layout=ops.ACT_FRAG32 if self.attn_frag else ops.ACT_ROWMAJOR)
+            if nf:
+                ops.fused_gemm_addto_norm(self.attn, lw.o, self.h, sc, lw.ln2, cfg.eps, self.xn2, out=self.h,
+                                          x_layout=ops.ACT_FRAG32 if self.attn_frag else ops.ACT_ROWMAJOR,
+                                          xnorm_layout=self.xn2_layout, M=self.B)
+                ops.prenorm_swiglu(self.xn2, lw.gate, lw.up, sc, self.B, x_layout=self.xn2_layout, out=self.act,
+                                   y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
+                if li + 1 < len(m.layers):
+                    ops.fused_gemm_addto_norm(self.act, lw.down, self.h, sc, m.layers[li + 1].ln1, cfg.eps, self.xn1, out=self.h,
+                                              x_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR,
+                                              xnorm_layout=self.xn1_layout, M=self.B)
+                else:
+                    self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag)  # lm_head applies the final norm itself
+                continue
             self._proj_residual(self.attn, lw.o, tp_on, frag=self.attn_frag)
             ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act,
                                   y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)

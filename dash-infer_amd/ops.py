@@ -211,6 +211,36 @@ def fused_gemm_addto(x, pw, h_res, scratch, out=None, x_layout=ACT_ROWMAJOR, M=N
     return h_out
 
 
+def fused_gemm_addto_norm(x, pw, h_res, scratch, gamma, eps, xnorm, out=None, x_layout=ACT_ROWMAJOR, xnorm_layout=ACT_ROWMAJOR, M=None):
+    """h_out = h_res + x.W and xnorm = RMSNorm(h_out) (FT; row-major or FRAG32) in one call: the norm rides on the split-K
+    reduction when the plan has one."""
+    M = x.shape[0] if M is None else M
+    h_out = out if out is not None else torch.empty(M, pw.N, dtype=torch.float32, device=x.device)
+    check(lib().dihip_fused_gemm_addto_norm(cur_stream(), pw.wbits, ptr(x), ptr(pw.w), ptr(pw.sz), ptr(h_res), ptr(h_out),
+                                            M, pw.N, pw.K, pw.group, ptr(scratch.ws), scratch.ws_bytes, ptr(scratch.sync),
+                                            dt_code(x), int(x_layout), ptr(gamma), float(eps), ptr(xnorm), int(xnorm_layout)),
+          "dihip_fused_gemm_addto_norm")
+    return h_out
+
+
+def prenorm_gemm(xnorm, pw, bias, scratch, M, x_layout=ACT_ROWMAJOR, act=None, out=None):
+    y = out if out is not None else torch.empty(M, pw.N, dtype=pw.dtype, device=xnorm.device)
+    check(lib().dihip_prenorm_gemm(cur_stream(), pw.wbits, ptr(xnorm), int(x_layout), ptr(pw.w), ptr(pw.sz), ptr(bias), ptr(y),
+                                   M, pw.N, pw.K, pw.group, capi.ACT[act], ptr(scratch.ws), scratch.ws_bytes, ptr(scratch.sync),
+                                   dt_code(pw.dtype)), "dihip_prenorm_gemm")
+    return y
+
+
+def prenorm_swiglu(xnorm, pg, pu, scratch, M, x_layout=ACT_ROWMAJOR, out=None, y_layout=ACT_ROWMAJOR):
+    if out is None:
+        out = (torch.zeros(act_frag_numel(M, pg.N), dtype=pg.dtype, device=xnorm.device) if y_layout == ACT_FRAG32
+               else torch.empty(M, pg.N, dtype=pg.dtype, device=xnorm.device))
+    check(lib().dihip_prenorm_swiglu(cur_stream(), pg.wbits, ptr(xnorm), int(x_layout), ptr(pg.w), ptr(pg.sz), ptr(pu.w), ptr(pu.sz),
+                                     ptr(out), M, pg.N, pg.K, pg.group, ptr(scratch.ws), scratch.ws_bytes, ptr(scratch.sync),
+                                     dt_code(pg.dtype), int(y_layout)), "dihip_prenorm_swiglu")
+    return out
+
+
 def lm_head(h, gamma, eps, pw, scratch, out=None):
     M = h.shape[0]
     logits = out if out is not None else torch.empty(M, pw.N, dtype=torch.float32, device=h.device)

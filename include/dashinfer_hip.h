@@ -142,6 +142,25 @@ int dihip_fused_gemm_addto_ex(void* stream, int wbits, const void* x, const void
                               const void* sz_packed, const float* h_res, float* h_out, int M, int N,
                               int K, int group_size, void* ws, size_t ws_bytes, void* sync, int dtype,
                               int x_layout);
+/* Batched decode (M > 4), fewer launches: the RMSNorm that FOLLOWS a residual GEMM in the decoder graph
+ * (LayerNormNoBeta after o_proj / down_proj, qwen_v15.py:296-361) is produced by the GEMM call itself --
+ *   h_out = h_res + x.W;   xnorm = RMSNorm(h_out; gamma, eps)  in FT, row-major [M, N] or FRAG32
+ * -- riding on the split-K slab reduction when the plan has one (one workgroup per row sums the slices,
+ * adds the residual and normalises: the separate norm launch and one pass over the row disappear), as a
+ * separate launch otherwise; the result is the same either way and equal to dihip_fused_gemm_addto_ex followed
+ * by the norm of dihip_fused_norm_gemm / _swiglu.  The next GEMMs then take the normalised rows directly:
+ * dihip_prenorm_gemm (qkv: + bias) and dihip_prenorm_swiglu (gate / up).  x_layout / xnorm_layout as above. */
+int dihip_fused_gemm_addto_norm(void* stream, int wbits, const void* x, const void* w_packed,
+                                const void* sz_packed, const float* h_res, float* h_out, int M, int N,
+                                int K, int group_size, void* ws, size_t ws_bytes, void* sync, int dtype,
+                                int x_layout, const void* gamma, float eps, void* xnorm, int xnorm_layout);
+int dihip_prenorm_gemm(void* stream, int wbits, const void* xnorm, int x_layout, const void* w_packed,
+                       const void* sz_packed, const void* bias, void* y, int M, int N, int K,
+                       int group_size, int act, void* ws, size_t ws_bytes, void* sync, int dtype);
+int dihip_prenorm_swiglu(void* stream, int wbits, const void* xnorm, int x_layout, const void* wg_packed,
+                         const void* szg_packed, const void* wu_packed, const void* szu_packed, void* y,
+                         int M, int N, int K, int group_size, void* ws, size_t ws_bytes, void* sync,
+                         int dtype, int y_layout);
 
 /* ---------------------------------------------------------------------------------------------
  * 1b. Mixture-of-experts decode path with weight-only experts (BASELINE configs[4]).

@@ -551,3 +551,46 @@ def test_qwen7b_tp8_rank_shapes(ops, name, K, N, M):
             u_ = gemm_ref.gemm_a16wx(xn, q2, s2, z2, G, wbits, ft="f32")
             ref = bf16_round(glue.silu(g_) * u_)
             assert_close(act.float().cpu().numpy(), ref, "bf16", what=f"{name} W{wbits} swiglu", pre=ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wbits,G,M", [(4, 128, 32), (4, 128, 8), (8, -1, 17)])
+def test_residual_gemm_with_fused_norm(ops, wbits, G, M):
+    """dihip_fused_gemm_addto_norm / dihip_prenorm_gemm / dihip_prenorm_swiglu (batched decode, one launch pair less per
+    residual GEMM): h_out must be bit-identical to dihip_fused_gemm_addto, and the GEMMs fed with the normalised rows
+    bit-identical to the forms that normalise h_out themselves -- on a split-K plan (down projection: the norm rides on the
+    slab reduction) and on a plan without one (wide N: separate norm launch)."""
+    rng = np.random.default_rng(5 * M + wbits)
+    hidden, inter = 3584, 18944
+    for K, N in ((inter, hidden), (hidden, 8192)):     # split-K slab / no slab
+        x, q, s, z = make_case(rng, M, N, K, G, wbits, "bf16")
+        pw = ops.pack_lowp(to_dev(q), to_dev(s, "bf16"), to_dev(z, "bf16"), G, wbits)
+        _, q1, s1, z1 = make_case(rng, 1, 1024, N, G, wbits, "bf16")        # consumers of the normalised rows
+        _, q2, s2, z2 = make_case(rng, 1, 1024, N, G, wbits, "bf16")
+        p1 = ops.pack_lowp(to_dev(q1), to_dev(s1, "bf16"), to_dev(z1, "bf16"), G, wbits)
+        p2 = ops.pack_lowp(to_dev(q2), to_dev(s2, "bf16"), to_dev(z2, "bf16"), G, wbits)
+        sc = ops.Scratch(max(ops.lowp_workspace_bytes(wbits, M, N, K, G), ops.lowp_workspace_bytes(wbits, M, 1024, N, G)))
+        h = torch.from_numpy(rng.normal(0, 1, (M, N)).astype(np.float32)).cuda()
+        gamma = to_dev(bf16_round(rng.normal(1, 0.1, N).astype(np.float32)), "bf16")
+        bias = to_dev(bf16_round(rng.normal(0, 0.5, 1024).astype(np.float32)), "bf16")
+        xd = to_dev(x, "bf16")
+        frag = ops.prefers_frag(pw, M)
+        xin = ops.act_to_frag(xd) if frag else xd
+        lay = ops.ACT_FRAG32 if frag else ops.ACT_ROWMAJOR
+        ref_h = ops.fused_gemm_addto(xin, pw, h, sc, x_layout=lay, M=M)
+        for consumer_dual in (False, True):
+            cfrag = ops.prefers_frag(p1, M, dual=consumer_dual)
+            clay = ops.ACT_FRAG32 if cfrag else ops.ACT_ROWMAJOR
+            xn = torch.zeros(ops.act_frag_numel(M, N) if cfrag else M * N, dtype=torch.bfloat16, device="cuda")
+            out_h = ops.fused_gemm_addto_norm(xin, pw, h, sc, gamma, 1e-6, xn, x_layout=lay, xnorm_layout=clay, M=M)
+            assert torch.equal(out_h, ref_h)
+            xn_rm = ops.act_from_frag(xn, M, N) if cfrag else xn.view(M, N)
+            ref_n = bf16_round(glue.rmsnorm(ref_h.cpu().numpy(), gamma.float().cpu().numpy(), 1e-6))
+            assert_close(xn_rm.float().cpu().numpy(), ref_n, "bf16", what="fused norm rows", pre=ref_n)
+            if consumer_dual:
+                y0 = ops.fused_norm_swiglu(ref_h, gamma, 1e-6, p1, p2, sc)
+                y1 = ops.prenorm_swiglu(xn, p1, p2, sc, M, x_layout=clay)
+            else:
+                y0 = ops.fused_norm_gemm(ref_h, gamma, 1e-6, p1, bias, sc)
+                y1 = ops.prenorm_gemm(xn, p1, bias, sc, M, x_layout=clay)
+            assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
