@@ -290,6 +290,9 @@ int dihip_span_attn_decode_fused(void* stream, void* output, const void* qkv, vo
  *    q: [seq_q, n, H] with row stride q_stride elements; k/v: [seq_k, g, H] with row stride
  *    kv_stride (INTERLEAVED qkv rows: q_stride = kv_stride = (n+2g)*H; MIX: k/v contiguous).
  *    query i attends keys j <= i + (seq_k - seq_q).  out: FT [seq_q, n*H].
+ *    head_size 128, FT = bf16 / f16, rows 16-byte aligned; alpha > 0 (the scale is folded into an exp2 argument);
+ *    K / V of one call below 2 GiB ((seq_k + 448) * kv_stride * 2 bytes: 32-bit buffer offsets) -> DIHIP_PARAM_ERROR /
+ *    DIHIP_EXCEED_LIMIT_ERROR otherwise.  No workspace; seq_q = 0 is a no-op.
  * ========================================================================================== */
 int dihip_prefill_attn(void* stream, void* out, const void* q, const void* k, const void* v,
                        int seq_q, int seq_k, int q_stride, int kv_stride, int n_heads,
