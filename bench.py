@@ -301,7 +301,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": "dihip::" + kname + kdesc,
                                "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4),
-                               "traffic": pmc_traffic(kname) if args.workload == "int4_b1" else None,
+                               "traffic": pmc_traffic(kname) if (args.workload == "int4_b1" and world == 1) else None,  # PMC pass: TP=1 shapes
                                "avg_launch_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["bytes"]}
             out["kernels"] = kb
         except Exception as e:  # never lose the headline number to the breakdown
