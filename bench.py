@@ -161,15 +161,17 @@ def kernel_breakdown(sess, torch, ops, iters=5):
 
 
 def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary
-    (profiles/r01_pmc_hbm_traffic.csv: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE)."""
+    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary
+    (profiles/*_pmc_hbm_traffic.csv, written by tools/gpu_pmc.sh: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE)."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.csv")
-    if not os.path.exists(path):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.csv")))
+    if not files:
         return None
+    key = kernel_substr.rstrip(">")  # template argument lists may have grown a defaulted tail
     tot = 0
-    for r in csv.DictReader(open(path)):
-        if kernel_substr in r["kernel"]:
+    for r in csv.DictReader(open(files[-1])):
+        if key in r["kernel"]:
             tot += int(r["avg_bytes_corrected"])
     return tot or None
 
