@@ -57,6 +57,18 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
   const int nw = min(KSL_WAVES, nsl_total - slice0);  // K-slices (= working waves) of this workgroup
   const bool active = wave < nw;
   const int kt0 = min(slice0 + wave, nsl_total - 1) * CH;
+  // per-wave wall-clock stamps for tools/kslice_trace.py; compiled in with -DDIHIP_KSL_TRACE only (they cost the
+  // MT = 2 variants 4-6 spilled registers)
+#ifdef DIHIP_KSL_TRACE
+#define DIHIP_KSL_STAMP(I)                                                                                          \
+  do {                                                                                                              \
+    if (a.trace && lane == 0)                                                                                       \
+      a.trace[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * KSL_WAVES + wave) * 8 + (I)] = wall_clock64();       \
+  } while (0)
+#else
+#define DIHIP_KSL_STAMP(I) do { } while (0)
+#endif
+  DIHIP_KSL_STAMP(0);  // entry
 
   // units of this workgroup: blockIdx.x, + gridDim.x, ...; a unit is a column tile (SwiGLU: the gate / up tile pair)
   const int NB = gridDim.x;
@@ -67,19 +79,6 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
     const int hc = min(h, NH - 1);
     return (int)blockIdx.x + (DUAL == 2 ? hc >> 1 : hc) * NB;
   };
-
-  // ---- this wave's activations: XS k-steps x MT row tiles, 1 KiB contiguous per fragment ----
-  u32x4_t xf[XS][MT];
-  {
-    const u32x4_t* xp = reinterpret_cast<const u32x4_t*>(a.x) + (size_t)kt0 * KSTEPS * MT * 64 + lane;
-#pragma unroll
-    for (int i = 0; i < XS; ++i)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        xf[i][mt] = xp[(size_t)(i * MT + mt) * 64];
-        asm volatile("" : "+v"(xf[i][mt]));  // opaque: never re-loaded next to its use
-      }
-  }
 
   struct Slot {
     u32x4_t w;
@@ -107,7 +106,30 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
   const u32x4_t ones = FT == DIHIP_BF16 ? u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}
                                   : u32x4_t{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
 
+  // Prologue order: the weight ring is requested FIRST -- its HBM latency then runs under the activation loads, which
+  // all workgroups aim at the same 115-229 KB of L2 lines (256 workgroups x 229 KB = 58 MB through L2 at M = 32: the
+  // per-wave stamps of tools/kslice_trace.py show ~3 us until the loads are issued and ~5 us until the first MFMA, 20 %
+  // of the kernel -- the price of register-resident activations in every workgroup).  The fragments are nontemporal
+  // builtin loads: not rematerialisable, so they stay in their registers.
   Slot ring[P];
+  if (active) {
+#pragma unroll
+    for (int r = 0; r < RH; ++r) {
+      set_half(r);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) load_slot(ring[r * CH + c], c);
+    }
+  }
+  // ---- this wave's activations: XS k-steps x MT row tiles, 1 KiB contiguous per fragment ----
+  u32x4_t xf[XS][MT];
+  {
+    const u32x4_t* xp = reinterpret_cast<const u32x4_t*>(a.x) + (size_t)kt0 * KSTEPS * MT * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < XS; ++i)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) xf[i][mt] = __builtin_nontemporal_load(xp + (size_t)(i * MT + mt) * 64);
+  }
+  DIHIP_KSL_STAMP(1);  // ring + activation loads issued
   if (active) {
     if constexpr (XS_LDS) {
 #pragma unroll
@@ -120,14 +142,9 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
           xsl[wave][c][mt][lane] = sx;
         }
     }
-#pragma unroll
-    for (int r = 0; r < RH; ++r) {
-      set_half(r);
-#pragma unroll
-      for (int c = 0; c < CH; ++c) load_slot(ring[r * CH + c], c);
-    }
   }
 
+  DIHIP_KSL_STAMP(2);  // activation sums done: ring and activations have landed
   // NP is rounded up to whole bodies: a dummy pair re-loads the last tiles and stores nothing (a guarded pair would put
   // its loads behind a branch, and hipcc drains the queue at such a join)
   for (int p0 = 0; p0 < NP; p0 += PU)
@@ -195,7 +212,9 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
         for (int mt = 0; mt < MT; ++mt) xch[p & 1][wave][hh][mt][lane] = tot[mt];
       }
     }
+    if (p == 0) DIHIP_KSL_STAMP(3);  // first pair streamed
     __syncthreads();  // the pair's slices are in xch[p & 1]; its previous use (pair p - 2) was reduced before barrier p - 1
+    if (p == 0) DIHIP_KSL_STAMP(4);  // first barrier passed
     // ---- reduce over the K-slices in fixed order + epilogue: fragment f = (half, row tile) per wave ----
     constexpr int NFR = DUAL == 2 ? MT : 2 * MT;
     for (int f = wave; f < NFR; f += (int)(blockDim.x >> 6)) {
@@ -229,6 +248,8 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
       }
     }
   }
+  DIHIP_KSL_STAMP(5);  // end
+#undef DIHIP_KSL_STAMP
 }
 
 template <int WBITS, int FT, int MT, int EPI, int GPT>

@@ -582,6 +582,7 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
       g.slab = reinterpret_cast<float*>(c.ws);
       g.yfrag = c.y_layout == DIHIP_ACT_FRAG32;
       g.nunits = kp.nunits;
+      g.trace = debug_trace_buffer((size_t)kp.groups * kp.nslices * KSL_WAVES * 64);
       if (c.epi == EPI_ADDTO && c.n_gamma && c.n_out && g.nslices > 1 && c.N % 4 == 0 && c.N <= 8192) {
         g.n_gamma = c.n_gamma;
         g.n_eps = c.n_eps;

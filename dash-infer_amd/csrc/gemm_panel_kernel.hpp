@@ -59,6 +59,7 @@ struct PanelArgs {
   float n_eps;
   void* n_out;          // FT, row-major [M, N] or FRAG32 (n_frag_mt = 1 / 2)
   int n_frag_mt;
+  unsigned long long* trace;  // diagnostics (dihip_debug_set_trace; K-slice kernel): [workgroup][8 waves][8] wall-clock stamps, or null
 };
 
 template <int FT, int EPI>
