@@ -5,16 +5,15 @@ A small random model of the Qwen2 architecture (same graph as python/pyhie/allsp
 qkv GEMM + bias -> Rotary -> span attention over the paged cache -> o GEMM + residual -> RMSNorm -> SiLU(gate) * up -> down
 GEMM + residual; final norm -> bf16 lm_head -> greedy) is decoded from an empty cache by the product path
 (decoder.DecodeSession: every fused HIP entry point the bench uses, eager and through a captured hipGraph) and, token by
-token, by a numpy restatement built from the oracle's pieces (quantised linear of gemm_ref, cache codec of kv_codec,
-attention / glue).  The oracle is fed the tokens the GPU chose, so one near-tie cannot derail the comparison; token IDs
+token, by the numpy decoder of oracle/model.py (quantised linear of gemm_ref, cache codec of kv_codec, attention / glue;
+itself checked on CPU in test_oracle_model.py).  The oracle is fed the tokens the GPU chose, so one near-tie cannot derail the comparison; token IDs
 must agree wherever the oracle's top-2 margin exceeds the logit tolerance.
 """
 import numpy as np
 import pytest
 import torch
 
-from oracle import attention, gemm_ref, glue, kv_codec
-from oracle.numerics import bf16_round
+from oracle import glue, model as omodel
 
 pytestmark = pytest.mark.gpu
 
@@ -27,59 +26,20 @@ pytestmark = pytest.mark.gpu
 LOGIT_TOL = {"none": 1e-2, "i8": 1e-2, "u4": 2e-2}   # x max(1, max |logit|)
 
 
-class OracleModel:
-    def __init__(self, model, kv_mode):
-        cfg = model.cfg
-        self.cfg, self.kv_mode, self.spec = cfg, kv_mode, model.quant
-        f = lambda t: t.float().cpu().numpy()
-        self.layers = []
-        for li in range(len(model.layers)):
-            p = model.fp[li]
-            lw = {k: tuple((x.cpu().numpy() if x.dtype in (torch.uint8, torch.int8) else f(x)) for x in p[k])
-                  for k in ("qkv", "o", "gate", "up", "down")}
-            lw.update(qkv_bias=f(p["qkv_bias"]), ln1=f(p["ln1"]), ln2=f(p["ln2"]))
-            self.layers.append(lw)
-        self.embed, self.final_norm, self.lm_head = f(model.fp["embed"]), f(model.fp["final_norm"]), f(model.fp["lm_head"])
-        self.inv_freq = glue.rope_inv_freq(cfg.head_dim, cfg.rope_theta)
-        self.cache = None
-
-    def linear(self, x, w, ft, bias=None):
-        q, s, z = w
-        return gemm_ref.gemm_a16wx(x, q, s, z, self.spec.group, self.spec.wbits, bias=bias, ft=ft)
-
-    def kv_store(self, x):
-        """What the cache returns for rows x [g, H] written at this step."""
-        if self.kv_mode == "none":
-            return x
-        zero, scale = kv_codec.quant_params(x, self.kv_mode)
-        return kv_codec.dequantize(kv_codec.quantize(x, zero, scale, self.kv_mode), zero, scale)
-
-    def step(self, ids):
-        cfg = self.cfg
-        n, g, H = cfg.n_heads, cfg.n_kv, cfg.head_dim
-        B = len(ids)
-        if self.cache is None:
-            self.cache = [[([], []) for _ in range(B)] for _ in self.layers]
-        h = self.embed[np.asarray(ids)].astype(np.float32)
-        for li, lw in enumerate(self.layers):
-            xn = bf16_round(glue.rmsnorm(h, lw["ln1"], cfg.eps))
-            qkv = self.linear(xn, lw["qkv"], "bf16", bias=lw["qkv_bias"])
-            attn = np.empty((B, n * H), np.float32)
-            for b in range(B):
-                ks, vs = self.cache[li][b]
-                pos = len(ks)
-                q = bf16_round(glue.rope(qkv[b, : n * H].reshape(n, H), pos, self.inv_freq))
-                k = bf16_round(glue.rope(qkv[b, n * H:(n + g) * H].reshape(g, H), pos, self.inv_freq))
-                v = qkv[b, (n + g) * H:].reshape(g, H)
-                ks.append(self.kv_store(k))
-                vs.append(self.kv_store(v))
-                attn[b] = bf16_round(attention.decode_attention(q, np.stack(ks), np.stack(vs), 1.0 / np.sqrt(H))).reshape(-1)
-            h = h + self.linear(attn, lw["o"], "f32")
-            xn = bf16_round(glue.rmsnorm(h, lw["ln2"], cfg.eps))
-            act = bf16_round(glue.silu(self.linear(xn, lw["gate"], "f32")) * self.linear(xn, lw["up"], "f32"))
-            h = h + self.linear(act, lw["down"], "f32")
-        xn = bf16_round(glue.rmsnorm(h, self.final_norm, cfg.eps))
-        return (xn.astype(np.float64) @ self.lm_head.astype(np.float64)).astype(np.float32)
+def oracle_of(model, kv_mode):
+    """The numpy decoder (oracle/model.py) over the product model's own quantised weights (build_random_model(keep_fp=True))."""
+    cfg = model.cfg
+    f = lambda t: t.float().cpu().numpy()
+    layers = []
+    for li in range(len(model.layers)):
+        p = model.fp[li]
+        lw = {k: tuple((x.cpu().numpy() if x.dtype in (torch.uint8, torch.int8) else f(x)) for x in p[k])
+              for k in ("qkv", "o", "gate", "up", "down")}
+        lw.update(qkv_bias=f(p["qkv_bias"]), ln1=f(p["ln1"]), ln2=f(p["ln2"]))
+        layers.append(lw)
+    return omodel.DecoderOracle(layers, f(model.fp["embed"]), f(model.fp["final_norm"]), f(model.fp["lm_head"]), cfg.n_heads,
+                                cfg.n_kv, cfg.head_dim, model.quant.wbits, model.quant.group, eps=cfg.eps,
+                                rope_theta=cfg.rope_theta, kv_mode=kv_mode)
 
 
 SMALL = dict(hidden=512, layers=2, n_heads=4, n_kv=2, head_dim=128, inter=1024, vocab=2048)
@@ -122,7 +82,7 @@ def test_greedy_decode_matches_oracle(pkg, shape, wbits, group, kv_mode, batch, 
         torch.cuda.synchronize()
         gpu_logits.append(sess.logits.cpu().numpy().copy())
         gpu_ids.append(sess.ids.cpu().numpy().copy())
-    ref = OracleModel(model, kv_mode)
+    ref = oracle_of(model, kv_mode)
     cur, decided, worst = ids, 0, 0.0
     for t in range(steps):
         lo = ref.step(cur)

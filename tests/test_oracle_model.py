@@ -1,0 +1,46 @@
+"""The whole-decoder oracle (oracle/model.py) checked against itself on CPU: token-by-token decoding against the growing
+(possibly quantised) cache must give the same logits as recomputing the whole sequence with the prefill attention
+oracle -- two evaluation orders of one function, built from pieces that are pinned separately against the reference."""
+import numpy as np
+import pytest
+
+from oracle import model as omodel, quant
+from oracle.numerics import bf16_round
+
+
+def make_oracle(rng, wbits, group, kv_mode, hidden=256, n=2, g=1, H=128, inter=256, vocab=64, nlayers=2):
+    def qlin(K, N):
+        W = bf16_round(rng.normal(0, 0.05, (K, N)).astype(np.float32))
+        return (quant.iq_quantize_a16w8 if wbits == 8 else quant.iq_quantize_a16w4)(W, group, "bf16")
+    layers = []
+    for _ in range(nlayers):
+        layers.append(dict(qkv=qlin(hidden, (n + 2 * g) * H), o=qlin(n * H, hidden), gate=qlin(hidden, inter), up=qlin(hidden, inter),
+                           down=qlin(inter, hidden), qkv_bias=bf16_round(rng.normal(0, 0.05, (n + 2 * g) * H).astype(np.float32)),
+                           ln1=bf16_round(1 + rng.normal(0, 0.1, hidden).astype(np.float32)),
+                           ln2=bf16_round(1 + rng.normal(0, 0.1, hidden).astype(np.float32))))
+    embed = bf16_round(rng.normal(0, 1.0, (vocab, hidden)).astype(np.float32))
+    fn = bf16_round(1 + rng.normal(0, 0.1, hidden).astype(np.float32))
+    lm = bf16_round(rng.normal(0, 0.05, (hidden, vocab)).astype(np.float32))
+    return omodel.DecoderOracle(layers, embed, fn, lm, n, g, H, wbits, group, kv_mode=kv_mode)
+
+
+@pytest.mark.parametrize("wbits,group,kv_mode", [(8, -1, "none"), (4, 128, "none"), (4, 128, "i8"), (8, 128, "u4")])
+def test_incremental_decode_equals_full_recompute(wbits, group, kv_mode):
+    rng = np.random.default_rng(wbits + len(kv_mode))
+    m = make_oracle(rng, wbits, group, kv_mode)
+    seq = rng.integers(0, 64, 7)
+    step_logits = [m.step([t])[0] for t in seq]
+    for L in (1, 4, 7):
+        full = m.last_logits_from_scratch(seq[:L])[0]
+        # same operands and rounding points; only the softmax / P.V summation order of the two attention oracles differs
+        np.testing.assert_allclose(step_logits[L - 1], full, rtol=0, atol=2e-5 * max(1.0, float(np.abs(full).max())))
+
+
+def test_batch_rows_are_independent():
+    rng = np.random.default_rng(3)
+    m1, m2 = make_oracle(np.random.default_rng(5), 4, 128, "u4"), make_oracle(np.random.default_rng(5), 4, 128, "u4")
+    ids = rng.integers(0, 64, (3, 4))                      # 3 steps, batch 4
+    for t in range(3):
+        both = m1.step(ids[t])
+        one = m2.step(ids[t][1:2])
+        np.testing.assert_array_equal(both[1], one[0])
