@@ -971,6 +971,19 @@ int dihip_gemm_a16w4(void* stream, const void* x, const void* w_packed, const vo
                   ws_bytes, sync, dtype);
 }
 
+// RMSNorm of M rows of the f32 hidden stream into FT rows (row-major or FRAG32)
+static int launch_rmsnorm_rows(hipStream_t s, const float* h, const void* gamma, float eps, int M, int K, void* out, int frag_mt) {
+  const bool vec = K % 4 == 0 && (reinterpret_cast<uintptr_t>(h) % 16 == 0) && (reinterpret_cast<uintptr_t>(gamma) % 8 == 0);
+  uint16_t* xo = reinterpret_cast<uint16_t*>(out);
+  if (vec && K <= 4096)
+    hipLaunchKernelGGL((rmsnorm_f32_to_ft_kernel<DIHIP_BF16, 4>), dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, frag_mt);
+  else if (vec && K <= 8192)
+    hipLaunchKernelGGL((rmsnorm_f32_to_ft_kernel<DIHIP_BF16, 8>), dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, frag_mt);
+  else
+    hipLaunchKernelGGL(rmsnorm_f32_to_ft_wide_kernel<DIHIP_BF16>, dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, frag_mt);
+  return launch_status();
+}
+
 // For M > 4 the norm runs as its own small kernel into the tail of `ws`.
 // The normalised rows are private to the call, so they are written in whatever layout the GEMM kernel that
 // follows reads fastest (*x_layout).
@@ -991,16 +1004,7 @@ static int norm_to_ws(hipStream_t s, const float* h, const void* gamma, float ep
   *xnorm = reinterpret_cast<char*>(ws) + off;
   *ws_left = off;
   *x_layout = frag ? DIHIP_ACT_FRAG32 : DIHIP_ACT_ROWMAJOR;
-  const int fm = frag ? mt : 0;
-  const bool vec = K % 4 == 0 && (reinterpret_cast<uintptr_t>(h) % 16 == 0) && (reinterpret_cast<uintptr_t>(gamma) % 8 == 0);
-  uint16_t* xo = reinterpret_cast<uint16_t*>(*xnorm);
-  if (vec && K <= 4096)
-    hipLaunchKernelGGL((rmsnorm_f32_to_ft_kernel<DIHIP_BF16, 4>), dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, fm);
-  else if (vec && K <= 8192)
-    hipLaunchKernelGGL((rmsnorm_f32_to_ft_kernel<DIHIP_BF16, 8>), dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, fm);
-  else
-    hipLaunchKernelGGL(rmsnorm_f32_to_ft_wide_kernel<DIHIP_BF16>, dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, fm);
-  return launch_status();
+  return launch_rmsnorm_rows(s, h, gamma, eps, M, K, *xnorm, frag ? mt : 0);
 }
 
 int dihip_fused_norm_gemm(void* stream, int wbits, const float* h, const void* gamma, float eps, const void* w_packed,
@@ -1163,18 +1167,6 @@ int dihip_fused_gemm_addto_ex(void* stream, int wbits, const void* x, const void
   c.ws_bytes = ws_bytes;
   c.sync = sync;
   return run_gemm(reinterpret_cast<hipStream_t>(stream), c);
-}
-
-static int launch_rmsnorm_rows(hipStream_t s, const float* h, const void* gamma, float eps, int M, int K, void* out, int frag_mt) {
-  const bool vec = K % 4 == 0 && (reinterpret_cast<uintptr_t>(h) % 16 == 0) && (reinterpret_cast<uintptr_t>(gamma) % 8 == 0);
-  uint16_t* xo = reinterpret_cast<uint16_t*>(out);
-  if (vec && K <= 4096)
-    hipLaunchKernelGGL((rmsnorm_f32_to_ft_kernel<DIHIP_BF16, 4>), dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, frag_mt);
-  else if (vec && K <= 8192)
-    hipLaunchKernelGGL((rmsnorm_f32_to_ft_kernel<DIHIP_BF16, 8>), dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, frag_mt);
-  else
-    hipLaunchKernelGGL(rmsnorm_f32_to_ft_wide_kernel<DIHIP_BF16>, dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, frag_mt);
-  return launch_status();
 }
 
 int dihip_fused_gemm_addto_norm(void* stream, int wbits, const void* x, const void* w_packed, const void* sz_packed,
