@@ -111,7 +111,9 @@ __device__ __forceinline__ void append_row(float (&x)[8], void* span, int head, 
     for (int j = 0; j < 8; ++j) {
       float t = fminf(qz + x[j] / qs, QMAX);
       if constexpr (MODE == DIHIP_KV_I8) t = fmaxf(t, QMIN);
-      q[j] = (int)rintf(t);
+      t = rintf(t);
+      if constexpr (MODE == DIHIP_KV_U4) t = fmaxf(t, 0.f);  // saturating float -> u32 (impl_u4.cuh:79-93)
+      q[j] = (int)t;
     }
     if constexpr (MODE == DIHIP_KV_I8) {
       u32x2_t o = {0u, 0u};

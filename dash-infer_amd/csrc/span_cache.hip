@@ -68,9 +68,11 @@ __device__ __forceinline__ void store_token_head(void* span, const float (&x)[EP
       static_assert(MODE != DIHIP_KV_U4 || EPL % 2 == 0, "u4 packs two elements per byte");
 #pragma unroll
       for (int i = 0; i < EPL; i += 2) {
-        float t0 = rintf(fminf(qz + x[i] / qs, QMAX));
-        float t1 = rintf(fminf(qz + x[i + 1] / qs, QMAX));
-        const unsigned w0 = (unsigned)(int)t0 & 0xFu, w1 = (unsigned)(int)t1 & 0xFu;
+        // impl_u4.cuh:79-93: min(., 15), rint, static_cast<uint32_t> -- the float -> u32 convert
+        // SATURATES (negatives -> 0; reachable when zero clamps at 15 on an all-negative head)
+        float t0 = fmaxf(rintf(fminf(qz + x[i] / qs, QMAX)), 0.f);
+        float t1 = fmaxf(rintf(fminf(qz + x[i + 1] / qs, QMAX)), 0.f);
+        const unsigned w0 = (unsigned)t0 & 0xFu, w1 = (unsigned)t1 & 0xFu;
         data[(lane * EPL + i) >> 1] = (unsigned char)(w0 | (w1 << 4));
       }
     }

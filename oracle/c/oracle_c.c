@@ -197,7 +197,9 @@ void orc_span_write_head(void* span, const float* x, int head, int pos, int g, i
         float t = qz + orc_round_ft(x[d + i], ft) / qs; /* impl_u4.cuh:79-93 */
         t = fminf(t, QMAX);
         t = rintf(t);
-        w[i] = (uint32_t)t;
+        /* static_cast<uint32_t>(float) on the device saturates: negatives -> 0 (reachable when
+           zero clamps at 15 on an all-negative head); a plain C cast would be UB here */
+        w[i] = t > 0.f ? (uint32_t)t : 0u;
       }
       data[d / 2] = (uint8_t)((w[0] & 0xf) | ((w[1] & 0xf) << 4)); /* impl_u4.cuh:27-29 */
     }

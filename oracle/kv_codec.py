@@ -52,9 +52,10 @@ def quantize(x, zero, scale, mode):
     t = np.rint(t)
     if mode == "i8":
         return t.astype(np.int8)
-    # static_cast<uint32_t>(tmp) & 0xf: a (tiny) negative tmp would be UB on the GPU; the
-    # builder guarantees zero + min/scale >= -0.5 so rint() >= -0 here.
-    return (t.astype(np.int64) & 0xF).astype(np.uint8)
+    # static_cast<uint32_t>(tmp) & 0xf (impl_u4.cuh:79-93, :27-29): the device float -> u32 convert
+    # SATURATES, so a negative tmp (reachable: zero is clamped at 15 with no lower clamp on the
+    # elements, e.g. an all-negative head) becomes 0 -- it does not wrap mod 16.
+    return (np.maximum(t, 0).astype(np.int64) & 0xF).astype(np.uint8)
 
 
 def dequantize(qv, zero, scale):

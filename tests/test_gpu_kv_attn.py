@@ -71,6 +71,10 @@ def test_kv_append_byte_exact(ops, mode, ft):
         if step == 1:
             qkv[0, n * H: (n + 1) * H] = 0.5                 # constant K head -> scale clamps to EPS
             qkv[1, n * H: (n + 1) * H] = np.abs(qkv[1, n * H: (n + 1) * H]) + 1  # all-positive head
+            # all-negative heads: u4 zero clamps at 15 and elements saturate at 0 (impl_u4.cuh:79-103)
+            qkv[2, n * H: (n + 1) * H] = -np.abs(qkv[2, n * H: (n + 1) * H]) - 1
+            qkv[3, (n + g) * H: (n + g + 1) * H] = np.linspace(-2, -1, H)      # the VERDICT r1 reproducer (V head)
+            qkv[4, (n + 1) * H: (n + 2) * H] = -0.75                            # negative constant head
             qkv = RND[ft](qkv)
         q_out = torch.empty(B, n * H, dtype=TD[ft], device="cuda")
         ops.kv_append(kv, q_out, dev(qkv, ft), old, n, g, H)
@@ -100,7 +104,12 @@ def test_context_copy_prefix_gather_roundtrip(ops, mode):
     kv.sync()
     n = 8
     stride = (n + 2 * g) * H
-    rows = RND[ft](rng.normal(0, 2, (L, stride)).astype(np.float32))
+    rows = rng.normal(0, 2, (L, stride)).astype(np.float32)
+    rows[5, n * H: (n + 1) * H] = -np.abs(rows[5, n * H: (n + 1) * H]) - 1   # all-negative head (u4 saturation)
+    rows[6, (n + 1) * H: (n + 2) * H] = np.linspace(-2, -1, H)
+    rows[7, (n + 2) * H: (n + 3) * H] = -0.75                                # negative constant
+    rows[40, n * H: (n + 1) * H] = np.abs(rows[40, n * H: (n + 1) * H]) + 1  # all-positive head
+    rows = RND[ft](rows)
     rows_d = dev(rows, ft)
     ksrc = rows_d[:, n * H:]  # INTERLEAVED qkv rows: K starts after the n query heads
     ops.kv_context_copy(kv.k_ptrs[0], ksrc, stride, L, 0, g, H, S, mode)
@@ -278,7 +287,13 @@ def test_fused_rope_append_attention_matches_separate_ops(ops, n, g, S, lens, mo
     B = len(lens)
     pool, kv, ok, ov = build_batch(ops, rng, lens, n, g, H, S, mode, ft, extra_tokens=1)
     pool2, kv2, _, _ = build_batch(ops, np.random.default_rng(n + S + len(mode)), lens, n, g, H, S, mode, ft, extra_tokens=1)
-    qkv = bf16_round(rng.normal(0, 1, (B, (n + 2 * g) * H)).astype(np.float32))
+    qkv = rng.normal(0, 1, (B, (n + 2 * g) * H)).astype(np.float32)
+    # V heads are appended unrotated: all-negative / negative-constant / all-positive V heads reach
+    # the codec as written (u4: zero clamps at 15, elements saturate at 0 -- impl_u4.cuh:79-103)
+    qkv[0, (n + g) * H: (n + g + 1) * H] = np.linspace(-2, -1, H)
+    qkv[-1, (n + g + 1) * H: (n + g + 2) * H] = -0.75
+    qkv[0, (n + g + 1) * H: (n + g + 2) * H] = np.abs(qkv[0, (n + g + 1) * H: (n + g + 2) * H]) + 1
+    qkv = bf16_round(qkv)
     inv = glue.rope_inv_freq(H, 1000000.0)
     inv_d = torch.from_numpy(inv).cuda()
     old = torch.tensor(lens, dtype=torch.int32, device="cuda")
@@ -310,6 +325,16 @@ def test_fused_rope_append_attention_matches_separate_ops(ops, n, g, S, lens, mo
         ov[b].write(L, qkv[b, (n + g) * H:].reshape(g, H))
         ref.append(attention.decode_attention(rot[b, :n], ok[b].read_all(L + 1), ov[b].read_all(L + 1), scale))
     np.testing.assert_allclose(out.float().cpu().numpy().reshape(B, n, H), np.stack(ref), rtol=1e-2, atol=2.5e-3)
+    # the V spans the fused kernel wrote are byte-identical to the oracle's codec (V is not rotated, so no
+    # transcendental sits between the input and the bytes)
+    for b in range(B):
+        for i, sp in enumerate(ov[b].spans):
+            if (i + 1) * S <= lens[b] + 1 or i == lens[b] // S:
+                hb = {"none": H * 2, "i8": H, "u4": H // 2}[mode]
+                valid = min(S, lens[b] + 1 - i * S)
+                got = pool2.span_view(kv2.v_idx[b][i]).cpu().numpy()
+                np.testing.assert_array_equal(got[: g * S * hb].reshape(g, S, hb)[:, :valid],
+                                              sp[: g * S * hb].reshape(g, S, hb)[:, :valid], err_msg=f"V b{b} span{i}")
 
 
 @pytest.mark.gpu

@@ -22,6 +22,8 @@ def test_span_codec_numpy_equals_c(mode, S):
     toks = bf16_round(rng.normal(0, 1, (L, g, H)))
     toks[3, 0, :] = 0.25          # constant head: scale clamps to EPS
     toks[4, 1, :] = np.abs(toks[4, 1, :]) + 1.0  # all-positive head: u4 zero goes negative
+    toks[5, 0, :] = -np.abs(toks[5, 0, :]) - 1.0  # all-negative head: u4 zero clamps at 15, elements saturate at 0
+    toks[6, 1, :] = -0.75                          # negative constant head
     toks = bf16_round(toks)
     cspans = [np.zeros(cache.nbytes, np.uint8) for _ in range((L + S - 1) // S)]
     for t in range(L):
@@ -30,7 +32,7 @@ def test_span_codec_numpy_equals_c(mode, S):
             cbind.span_write_head(cspans[t // S], toks[t, h], h, t % S, g, S, H, mode, ft)
     for a, b in zip(cache.spans, cspans):
         np.testing.assert_array_equal(a, b)  # byte-exact span images
-    for t in (0, 3, 4, L - 1):
+    for t in (0, 3, 4, 5, 6, L - 1):
         for h in range(g):
             np.testing.assert_array_equal(cache.read(t)[h], cbind.span_read_head(cspans[t // S], h, t % S, g, S, H, mode, ft))
     # zero-straddling heads reconstruct within one quantisation step; the two special rows do
@@ -38,7 +40,34 @@ def test_span_codec_numpy_equals_c(mode, S):
     diff = np.abs(cache.read_all() - toks)
     diff[3, 0] = 0
     diff[4, 1] = 0
+    diff[5, 0] = 0
+    diff[6, 1] = 0
     assert diff.max() <= {"none": 0.0, "i8": 0.03, "u4": 0.5}[mode]
+
+
+def test_u4_all_negative_head_saturates_like_the_reference():
+    """Known answer worked from impl_u4.cuh:79-103,157-184 by hand: head = linspace(-2, -1, 128):
+    scale = 1/15, zero = min(0 + 2*15, 15) = 15 (no lower clamp on zero, upper clamp hits),
+    tmp = 15 + x*15 in [-15, 0] -> rint -> static_cast<uint32_t> SATURATES to 0 -> every nibble 0
+    (a wrap mod 16 would give 1,1,1,1,1,2,2,...).  numpy and C restatement both."""
+    g, S, H = 1, 16, 128
+    x = np.linspace(-2.0, -1.0, H).astype(np.float32)
+    zero, scale = kv_codec.quant_params(x[None], "u4")
+    assert zero[0] == 15.0 and abs(scale[0] - 1.0 / 15.0) < 1e-7
+    np.testing.assert_array_equal(kv_codec.quantize(x[None], zero, scale, "u4"), np.zeros((1, H), np.uint8))
+    span = np.full(kv_codec.span_bytes(g, S, H, "u4"), 0xAA, np.uint8)
+    cbind.span_write_head(span, x, 0, 3, g, S, H, "u4", "f32")
+    np.testing.assert_array_equal(span[3 * 64: 4 * 64], np.zeros(64, np.uint8))
+    # and a head that straddles the clamp: x in [-1, -0.5] -> zero 15, scale 1/30, tmp = 15 + 30 x in [-15, 0]
+    y = np.linspace(-1.0, -0.5, H).astype(np.float32)
+    zero, scale = kv_codec.quant_params(y[None], "u4")
+    assert zero[0] == 15.0
+    np.testing.assert_array_equal(kv_codec.quantize(y[None], zero, scale, "u4"), np.zeros((1, H), np.uint8))
+    # mixed: x in [-1.6, 0.1]: zero = rint(1.6*15/1.7) = 14, no saturation anywhere; bytes hit 0 and 15
+    m = np.linspace(-1.6, 0.1, H).astype(np.float32)
+    zero, scale = kv_codec.quant_params(m[None], "u4")
+    qv = kv_codec.quantize(m[None], zero, scale, "u4")
+    assert zero[0] == 14.0 and qv.min() == 0 and qv.max() == 15
 
 
 def test_span_bytes_match_reference_formula():
