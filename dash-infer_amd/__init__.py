@@ -13,7 +13,8 @@ import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "lib", "libdashinfer_hip.so")
+# DIHIP_LIB_DIR: another build of the same library (lib/trace: the GEMV kernels with their wall-clock stamps compiled in)
+LIB_PATH = os.path.join(os.environ.get("DIHIP_LIB_DIR") or os.path.join(PKG_DIR, "lib"), "libdashinfer_hip.so")
 OPS_LIB_PATH = os.path.join(PKG_DIR, "lib", "libdashinfer_hip_ops.so")
 
 __all__ = ["PKG_DIR", "REPO_ROOT", "LIB_PATH", "OPS_LIB_PATH"]

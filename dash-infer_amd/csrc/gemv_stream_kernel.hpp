@@ -52,6 +52,16 @@ __device__ __forceinline__ void stream_load_b32(uint32_t& dst, const void* sbase
 __device__ __forceinline__ void stream_load_plain_b128(u32x4_t& dst, const void* sbase, uint32_t voff) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase));
 }
+__device__ __forceinline__ void stream_load_plain_b64(u32x2_t& dst, const void* sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase));
+}
+// pins a wave-uniform pointer into SGPRs (folds away when it already lives there): the ring loads take their base
+// through an "s" constraint, and hipcc occasionally carries a uniform address computation on the VALU
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {  // DPP move, all rows / banks enabled
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
@@ -66,6 +76,14 @@ __device__ __forceinline__ void stream_landed(u32x4_t& w, uint32_t& s) { asm vol
 // vmcnt (loads return in order: a compiler-visible load issued after the ring would only be
 // usable once the whole ring has landed, serialising prologue and first HBM round trip).
 __device__ __forceinline__ void early_landed(u32x4_t& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void early_landed(u32x2_t& v) { asm volatile("" : "+v"(v)); }
+
+// PRO_ATTNMERGE: the activation row is the decode attention's output, taken straight from the split partials the
+// attention kernel left ([M * heads][nsplits][GEMV_AP_STRIDE] f32 records: o[128], m, l -- span_attn_common.hpp) and
+// combined here with the arithmetic of span_attn_split_merge_kernel (same order, same rounding: the merged row is
+// bit-identical to that kernel's output), so the merge launch between attention and o-projection disappears.
+constexpr int GEMV_AP_STRIDE = 132;  // == ATTN_PSTRIDE
+constexpr int GEMV_AP_SPLITS = 8;    // split slots loaded per vector (the attention plan of this form caps its splits here)
 
 // W4 expansion for the GEMV: pair I of a dword is (d >> 4I) & 0x000F000F; OR-ing the exponent of
 // 128.0 (bf16) gives OFFSET + q exactly in both halves.  mask / magic are passed as
@@ -118,6 +136,9 @@ struct GemvArgs {
   size_t w_estride, sz_estride;  // u32x4 / u32 elements between consecutive experts' packed tensors
   int x_div;                     // activation row of slot s = s / x_div
   int nslots;
+  // PRO_ATTNMERGE: x is unused; K == ap_heads * 128
+  const float* ap;  // attention split partials [M * ap_heads][ap_nsplits][GEMV_AP_STRIDE]
+  int ap_nsplits, ap_heads;
   int WK, WN;  // wave grid inside the workgroup, WK * WN == GEMV_WAVES, both powers of two (SwiGLU: WN >= 2)
   int RS;      // LDS activation row stride in elements (KT * KTILE + 8)
   unsigned long long* trace;  // diagnostics (dihip_debug_set_trace): [block][wave][8] wall-clock stamps, or null
@@ -135,21 +156,25 @@ __host__ __device__ inline size_t gemv_lds_bytes(int rows, int RS, int KT, int u
 // SLOT (mixture-of-experts): gridDim.y enumerates (token, expert-rank) slots; slot s streams the weights of expert
 // slot_expert[s] (all experts have one shape: base + expert * stride), reads activation row s / x_div and writes row s.
 template <int WBITS, int FT, int MR, int PRO, int EPI, int GPT, bool SLOT = false>
-__global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArgs a_in) {
-  GemvArgs a_slot;
+__global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArgs a) {
+  // the tensors of this launch (SLOT: of this slot's expert / activation row); everything else is read from `a`
+  const u32x4_t* p_w0 = a.w0;
+  const u32x4_t* p_w1 = a.w1;
+  const uint32_t* p_sz0 = a.sz0;
+  const uint32_t* p_sz1 = a.sz1;
+  const void* p_x = a.x;
+  void* p_y = a.y;
   if constexpr (SLOT) {
-    a_slot = a_in;
     const int s_ = blockIdx.y;
-    const int e_ = a_in.slot_expert[s_];
+    const int e_ = a.slot_expert[s_];
     if (e_ < 0) return;  // expert not on this rank (expert parallelism): the slot contributes nothing
-    a_slot.w0 = a_in.w0 + (size_t)e_ * a_in.w_estride;
-    a_slot.sz0 = a_in.sz0 + (size_t)e_ * a_in.sz_estride;
-    if (a_in.w1) a_slot.w1 = a_in.w1 + (size_t)e_ * a_in.w_estride;
-    if (a_in.sz1) a_slot.sz1 = a_in.sz1 + (size_t)e_ * a_in.sz_estride;
-    a_slot.x = reinterpret_cast<const uint16_t*>(a_in.x) + (size_t)(s_ / a_in.x_div) * a_in.ldx;
-    a_slot.y = reinterpret_cast<uint16_t*>(a_in.y) + (size_t)s_ * a_in.ldy;
+    p_w0 = a.w0 + (size_t)e_ * a.w_estride;
+    p_sz0 = a.sz0 + (size_t)e_ * a.sz_estride;
+    if (a.w1) p_w1 = a.w1 + (size_t)e_ * a.w_estride;
+    if (a.sz1) p_sz1 = a.sz1 + (size_t)e_ * a.sz_estride;
+    p_x = reinterpret_cast<const uint16_t*>(a.x) + (size_t)(s_ / a.x_div) * a.ldx;
+    p_y = reinterpret_cast<uint16_t*>(a.y) + (size_t)s_ * a.ldy;
   }
-  const GemvArgs& a = SLOT ? a_slot : a_in;
   using WT = WTraits<WBITS>;
   using EX = ExpandV<WBITS, FT>;
   constexpr int KSTEPS = WT::KSTEPS;
@@ -173,10 +198,19 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
   const int lgWK = __builtin_ctz(a.WK), lgWN = __builtin_ctz(a.WN);
   const int wk = wave & (a.WK - 1), wn = wave >> lgWK;
 
+  // per-wave wall-clock stamps (tools/gemv_bench TRACE=1): compiled in only with -DDIHIP_GEMV_TRACE=1 (`make trace` ->
+  // lib/trace/libdashinfer_hip.so).  In the product build they are absent: each one is an exec-masked branch that splits
+  // the scalar-heavy ramp into basic blocks and pins the kernel-argument loads behind it.
+#if defined(DIHIP_GEMV_TRACE) && DIHIP_GEMV_TRACE
 #define DIHIP_GEMV_STAMP(I)                                                                        \
   do {                                                                                             \
-    if (a.trace && lane == 0) a.trace[((size_t)blockIdx.x * GEMV_WAVES + wave) * 8 + (I)] = wall_clock64(); \
+    /* every lane stores the same value to the same slot: a wave-uniform branch only (a divergent `lane == 0` branch */ \
+    /* makes hipcc carry the ring pointers through VGPRs across it, which the "s" operands of the asm loads reject) */  \
+    if (a.trace) a.trace[((size_t)blockIdx.x * GEMV_WAVES + wave) * 8 + (I)] = wall_clock64();                    \
   } while (0)
+#else
+#define DIHIP_GEMV_STAMP(I) do { } while (0)
+#endif
   DIHIP_GEMV_STAMP(0);
 
   // ---- early activation loads -------------------------------------------------------------------
@@ -202,24 +236,49 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
       }
       const uint32_t i = (uint32_t)min(v0 + j * GEMV_THREADS + tid, nvec - 1);
       if constexpr (PRO == PRO_RMSNORM) {
-        const float* hrow = reinterpret_cast<const float*>(a.x) + (size_t)r * a.ldx;
+        const float* hrow = reinterpret_cast<const float*>(p_x) + (size_t)r * a.ldx;
         stream_load_plain_b128(ev[2 * j], hrow, i * 32u);
         stream_load_plain_b128(ev[2 * j + 1], hrow, i * 32u + 16u);
         stream_load_plain_b128(eg[j], a.gamma, i * 16u);
       } else {
-        stream_load_plain_b128(ev[j], reinterpret_cast<const uint16_t*>(a.x) + (size_t)r * a.ldx, i * 16u);
+        stream_load_plain_b128(ev[j], reinterpret_cast<const uint16_t*>(p_x) + (size_t)r * a.ldx, i * 16u);
       }
     }
   };
   constexpr int EARLY_LOADS = PRO == PRO_RMSNORM ? 3 * NE : NE;
-  issue_batch(0, 0);
+  // PRO_ATTNMERGE: one vector (8 dims of one head) per thread and batch: 2 x 16 bytes of o + {m, l} per split slot.
+  // Slots beyond ap_nsplits re-read the last split (uniform load count) and are neutralised in the merge.
+  constexpr int AMS = GEMV_AP_SPLITS;
+  u32x4_t am_o[PRO == PRO_ATTNMERGE ? 2 * AMS : 1];
+  u32x2_t am_ml[PRO == PRO_ATTNMERGE ? AMS : 1];
+  auto issue_merge_batch = [&](int r, int v0) {
+    if constexpr (PRO == PRO_ATTNMERGE) {
+      constexpr uint32_t RECB = GEMV_AP_STRIDE * 4u;  // bytes per record
+      const uint32_t i = (uint32_t)min(v0 + tid, nvec - 1);
+      const uint32_t rec0 = ((uint32_t)(r * a.ap_heads) + (i >> 4)) * (uint32_t)a.ap_nsplits * RECB;
+      const uint32_t dof = (i & 15u) * 32u;
+      // the clamp lives in a VGPR on purpose (opaque to the scalariser): eight s_min + address pairs would push this
+      // instantiation over the SGPR budget, after which hipcc parks wave-uniform ring pointers in VGPRs
+      uint32_t lim = (uint32_t)(a.ap_nsplits - 1) * RECB;
+      asm volatile("" : "+v"(lim));
+#pragma unroll
+      for (int sp = 0; sp < AMS; ++sp) {
+        const uint32_t off = rec0 + min((uint32_t)sp * RECB, lim);
+        stream_load_plain_b128(am_o[2 * sp], a.ap, off + dof);
+        stream_load_plain_b128(am_o[2 * sp + 1], a.ap, off + dof + 16u);
+        stream_load_plain_b64(am_ml[sp], a.ap, off + 512u);
+      }
+    }
+  };
+  if constexpr (PRO == PRO_ATTNMERGE) issue_merge_batch(0, 0);
+  else issue_batch(0, 0);
   DIHIP_GEMV_STAMP(7);
 
   // ---- this workgroup's units and this wave's share ---------------------------------------
   // units are dealt round-robin: workgroup b owns units b, b + NB, b + 2*NB, ... (SwiGLU: (gate, up) tile
   // pairs), which spreads every workgroup's address range over the whole matrix
   const int NB = gridDim.x;
-  const int u0 = blockIdx.x;
+  const int u0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x);  // pinned scalar: see uniform_ptr
   const int nu = a.nu_q + (u0 < a.nu_r ? 1 : 0);  // (NTILES - u0 + NB - 1) / NB without a device-side division
   const int nv = nu * DUAL;                  // half-units (one weight tile each)
   // K split in whole quantisation groups (per-channel: any k-tile boundary)
@@ -231,7 +290,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
   const int k_hi = min(a.KT, ((a.kgroups * (wk + 1)) >> lgWK) * gsz);
   const int nk = k_hi - k_lo;
   const int nvw = wn < nv ? (nv - wn + a.WN - 1) >> lgWN : 0;  // half-units v = wn, wn + WN, ...
-  const int total = nvw * nk;
+  const int total = __builtin_amdgcn_readfirstlane(nvw * nk);
 
   // ---- register ring ----------------------------------------------------------------------
   u32x4_t wb[D];
@@ -245,10 +304,10 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
   const bool second = DUAL == 2 && (wn & 1);
   const int t0 = u0 + (DUAL == 2 ? wn >> 1 : wn) * NB;
   const int tstep = (DUAL == 2 ? a.WN >> 1 : a.WN) * NB;
-  const char* const dummy_w = reinterpret_cast<const char*>(a.w0);
+  const char* const dummy_w = reinterpret_cast<const char*>(p_w0);
   const char* const dummy_s = dummy_w;
-  const char* wtile = reinterpret_cast<const char*>((second ? a.w1 : a.w0) + ((size_t)t0 * a.KT + k_lo) * 64);
-  const char* stile = QUANT ? reinterpret_cast<const char*>((second ? a.sz1 : a.sz0) + ((size_t)t0 * a.Gp + (subc ? g_lo : 0)) * 16)
+  const char* wtile = uniform_ptr(reinterpret_cast<const char*>((second ? p_w1 : p_w0) + ((size_t)t0 * a.KT + k_lo) * 64));
+  const char* stile = QUANT ? uniform_ptr(reinterpret_cast<const char*>((second ? p_sz1 : p_sz0) + ((size_t)t0 * a.Gp + (subc ? g_lo : 0)) * 16))
                             : dummy_s;
   const size_t wstep = (size_t)tstep * a.KT * 1024, sstep = QUANT ? (size_t)tstep * a.Gp * 64 : 0;
   int to_issue = total;  // real chunks not yet issued
@@ -377,6 +436,70 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
             }
             stage_vector(r, i, o);
           }
+        }
+      }
+    } else if constexpr (PRO == PRO_ATTNMERGE) {
+      // span_attn_split_merge_kernel, one batch of splits: bm = max m_j; c_j = exp(m_j - bm) (0 for an empty split);
+      // l = sum_j l_j c_j and o = sum_j o_j c_j by fmaf in split order from 0; x = o / l rounded to FT
+      auto merge_stage = [&](int i, const u32x4_t (&po)[2 * AMS], const u32x2_t (&pml)[AMS]) {
+        float mv[AMS], lv[AMS], bm = -INFINITY;
+#pragma unroll
+        for (int sp = 0; sp < AMS; ++sp) {
+          const bool in = sp < a.ap_nsplits;
+          mv[sp] = in ? __uint_as_float(pml[sp][0]) : -INFINITY;
+          lv[sp] = in ? __uint_as_float(pml[sp][1]) : 0.f;
+          bm = fmaxf(bm, mv[sp]);
+        }
+        float ll = 0.f, oo[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) oo[e] = 0.f;
+#pragma unroll
+        for (int sp = 0; sp < AMS; ++sp) {
+          const bool in = sp < a.ap_nsplits;
+          const float c = mv[sp] == -INFINITY ? 0.f : __expf(mv[sp] - bm);
+          ll = fmaf(lv[sp], c, ll);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float ov = in ? __uint_as_float(e < 4 ? po[2 * sp][e] : po[2 * sp + 1][e - 4]) : 0.f;
+            oo[e] = fmaf(ov, c, oo[e]);
+          }
+        }
+        u32x4_t o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float xa = ll > 0.f ? oo[2 * q] / ll : 0.f, xb = ll > 0.f ? oo[2 * q + 1] / ll : 0.f;
+          o[q] = f32_to_ft_bits<FT>(xa) | (f32_to_ft_bits<FT>(xb) << 16);
+        }
+        stage_vector(r, i, o);
+      };
+      if (r == 0) {
+        // the batch requested before the ring fill (asm loads the compiler does not see): consumed here, straight-line,
+        // and never re-issued -- a loop around hidden loads makes hipcc carry their destinations through register copies
+        // BEFORE the data has landed (v_mov of an in-flight register: NaN rows, found the hard way)
+        stream_wait<D * LPC>();
+#pragma unroll
+        for (int j = 0; j < 2 * AMS; ++j) early_landed(am_o[j]);
+#pragma unroll
+        for (int j = 0; j < AMS; ++j) early_landed(am_ml[j]);
+        DIHIP_GEMV_STAMP(2);
+        if (tid < nvec) merge_stage(tid, am_o, am_ml);
+      }
+      // everything else (further rows, rows longer than one batch) through loads the compiler counts itself
+      for (int v0 = r == 0 ? GEMV_THREADS : 0; v0 < nvec; v0 += GEMV_THREADS) {
+        const int i = v0 + tid;
+        if (i < nvec) {
+          const unsigned char* rec = reinterpret_cast<const unsigned char*>(a.ap) +
+                                     ((size_t)(r * a.ap_heads + (i >> 4)) * a.ap_nsplits) * (GEMV_AP_STRIDE * 4) + (i & 15) * 32;
+          u32x4_t po[2 * AMS];
+          u32x2_t pml[AMS];
+#pragma unroll
+          for (int sp = 0; sp < AMS; ++sp) {
+            const unsigned char* q = rec + (size_t)min(sp, a.ap_nsplits - 1) * (GEMV_AP_STRIDE * 4);
+            po[2 * sp] = gload<u32x4_t>(q);
+            po[2 * sp + 1] = gload<u32x4_t>(q + 16);
+            pml[sp] = gload<u32x2_t>(q - (i & 15) * 32 + 512);
+          }
+          merge_stage(i, po, pml);
         }
       }
     } else {
@@ -551,9 +674,9 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
       if (a.bias) v = __fadd_rn(v, load_ft<FT>(a.bias, n));
       v = apply_act(v, a.act);
       if (a.residual) v = ft_round<FT>(v) + load_ft<FT>(a.residual, (size_t)m * a.ldy + n);
-      store_ft<FT>(a.y, (size_t)m * a.ldy + n, v);
+      store_ft<FT>(p_y, (size_t)m * a.ldy + n, v);
     } else if constexpr (EPI == EPI_SWIGLU) {
-      store_ft<FT>(a.y, (size_t)m * a.ldy + n, (v / (1.f + expf(-v))) * v2);
+      store_ft<FT>(p_y, (size_t)m * a.ldy + n, (v / (1.f + expf(-v))) * v2);
     } else {
       const float base = a.h_res ? a.h_res[(size_t)m * a.N + n] : 0.f;
       a.h_out[(size_t)m * a.N + n] = __fadd_rn(base, __fmul_rn(a.alpha, v));
@@ -608,6 +731,8 @@ hipError_t launch_gemv_slots(const GemvArgs& a, int blocks, size_t lds_bytes, hi
   DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 1, PRO_PLAIN, EPI_ADDTO, GPT)   \
   DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 4, PRO_PLAIN, EPI_ADDTO, GPT)   \
   DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 1, PRO_RMSNORM, EPI_ADDTO, GPT) \
-  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 4, PRO_RMSNORM, EPI_ADDTO, GPT)
+  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 4, PRO_RMSNORM, EPI_ADDTO, GPT) \
+  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 1, PRO_ATTNMERGE, EPI_ADDTO, GPT) \
+  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 4, PRO_ATTNMERGE, EPI_ADDTO, GPT)
 
 }  // namespace dihip

@@ -63,7 +63,7 @@ __device__ __forceinline__ void attn_block_epilogue(const AttnArgs& a, float* ld
     }
   }
 
-  if (a.nsplits > 1) {
+  if (a.nsplits > 1 || a.force_partials) {
 #pragma unroll
     for (int e = 0; e < PER_THREAD; ++e) {
       const int idx = tid + e * ATTN_THREADS;
@@ -140,7 +140,8 @@ __global__ __launch_bounds__(128) void span_attn_split_merge_kernel(void* out, c
   const int bh = blockIdx.x, d = threadIdx.x;
   const float* base = partials + (size_t)bh * nsplits * ATTN_PSTRIDE;
   float mm = -INFINITY, ll = 0.f, oo = 0.f;
-  constexpr int MB = 16;  // splits per batch: all loads of a batch are in flight together
+  constexpr int MB = 32;  // splits per batch: all loads of a batch are in flight together (one round trip up to 32 splits:
+                          // the 17-split plan of batch 1 at 2048 tokens took two with MB = 16, ~1.3 us of a 4.5 us launch)
   for (int sb = 0; sb < nsplits; sb += MB) {
     float mv[MB], lv[MB], ov[MB];
 #pragma unroll
@@ -615,6 +616,21 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void span_attn_ft_mfma_kernel(cons
   unsigned* flag_lds = reinterpret_cast<unsigned*>(lds + 4 * HC * ATTN_PSTRIDE);
 
   const int tid = threadIdx.x, lane = tid & 63;
+  if constexpr (FUSED) {
+    if ((int)blockIdx.y >= a.g * a.nchunks) {  // cache-prefetch workgroup (see AttnArgs::pf_ptr); workgroup-uniform exit
+      const unsigned pw = ((blockIdx.z * (gridDim.y - a.g * a.nchunks) + (blockIdx.y - a.g * a.nchunks)) * gridDim.x + blockIdx.x);
+      const unsigned npw = gridDim.z * (gridDim.y - a.g * a.nchunks) * gridDim.x;
+      unsigned acc = 0;
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi) {
+        const unsigned* p = a.pf_ptr[bi];
+        const unsigned lines = a.pf_lines[bi];
+        for (unsigned i = pw * ATTN_THREADS + tid; i < lines; i += npw * ATTN_THREADS) acc ^= gload<unsigned>(p + (size_t)i * 32);
+      }
+      if (acc == 0x9E3779B9u && a.partials) a.partials[0] = 0.f;  // practically never: keeps the loads alive
+      return;
+    }
+  }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kb = lane >> 4, ni = lane & 15;
   const int split = blockIdx.x;
@@ -960,7 +976,8 @@ static bool attn_use_mfma(int mode, int dtype) {
   return mode == DIHIP_KV_U4 ? dtype == DIHIP_BF16 : (mode == DIHIP_KV_NONE || mode == DIHIP_KV_I8);
 }
 
-static AttnPlan attn_plan(int batch, int n_heads, int n_groups, int max_seq_len, int num_cus, bool mfma = false) {
+static AttnPlan attn_plan(int batch, int n_heads, int n_groups, int max_seq_len, int num_cus, bool mfma = false,
+                          int split_cap = 256) {
   AttnPlan p;
   const int hpg = n_heads / n_groups;
   p.mfma = mfma;
@@ -983,13 +1000,13 @@ static AttnPlan attn_plan(int batch, int n_heads, int n_groups, int max_seq_len,
     min_tps = e ? std::max(32, atoi(e)) : 128;
   }
   const long max_splits = std::max(1, (max_seq_len + min_tps - 1) / min_tps);  // >= 128 tokens per split
-  p.nsplits = (int)std::max<long>(1, std::min<long>(std::min<long>(want, max_splits), 256));
+  p.nsplits = (int)std::max<long>(1, std::min<long>(std::min<long>(want, max_splits), split_cap));
   static int force_splits = -1;  // DIHIP_ATTN_NSPLITS: diagnostics
   if (force_splits < 0) {
     const char* e = getenv("DIHIP_ATTN_NSPLITS");
     force_splits = e ? atoi(e) : 0;
   }
-  if (force_splits > 0) p.nsplits = (int)std::min<long>(force_splits, max_splits);
+  if (force_splits > 0) p.nsplits = (int)std::min<long>(std::min<long>(force_splits, max_splits), split_cap);
   p.partial_bytes = p.nsplits > 1 ? (size_t)batch * n_heads * p.nsplits * ATTN_PSTRIDE * sizeof(float) : 0;
   return p;
 }
@@ -1107,6 +1124,49 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
   return DIHIP_SA_SUCCESS;
 }
 
+// ---- cache prefetch riding on the decode-step attention launch (AttnArgs::pf_ptr) -----------------------------------
+struct PendingPrefetch {
+  const void* ptr[4];
+  size_t bytes[4];
+  int n;
+};
+static thread_local PendingPrefetch g_pending_pf = {};
+
+// fills a.pf_* from the pending list (consumed), returns the extra grid rows (blockIdx.y) to launch
+static int take_prefetch_rows(AttnArgs& a, int nsplits, int attn_rows, int batch) {
+  for (int i = 0; i < 4; ++i) {
+    a.pf_ptr[i] = nullptr;
+    a.pf_lines[i] = 0;
+  }
+  PendingPrefetch p = g_pending_pf;
+  g_pending_pf.n = 0;
+  static int enabled = -1;  // DIHIP_ATTN_PREFETCH=0: ignore the list (A/B)
+  if (enabled < 0) {
+    const char* e = getenv("DIHIP_ATTN_PREFETCH");
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!enabled || p.n <= 0) return 0;
+  size_t lines = 0;
+  for (int i = 0; i < p.n && i < 4; ++i) {
+    a.pf_ptr[i] = reinterpret_cast<const unsigned*>(p.ptr[i]);
+    a.pf_lines[i] = (unsigned)std::min<size_t>(p.bytes[i] / 128, 0x7fffffffu);
+    lines += a.pf_lines[i];
+  }
+  if (lines == 0) return 0;
+  int ncu = cached_num_cus();
+  if (ncu <= 0) ncu = 256;
+  static int want_wgs = -1;  // DIHIP_ATTN_PREFETCH_WGS: prefetch workgroups (default: the CUs the attention leaves idle)
+  if (want_wgs < 0) {
+    const char* e = getenv("DIHIP_ATTN_PREFETCH_WGS");
+    want_wgs = e ? std::max(1, atoi(e)) : 0;
+  }
+  const int used = nsplits * attn_rows * batch;
+  int wgs = want_wgs > 0 ? want_wgs : std::max(32, ncu - used);
+  wgs = (int)std::min<size_t>((size_t)wgs, (lines + ATTN_THREADS - 1) / ATTN_THREADS);
+  const int per_row = nsplits * batch;
+  return std::max(1, (wgs + per_row - 1) / per_row);
+}
+
 // decode-step form (Rotary + cache append folded in) for the 16-bit cache: span_attn_ft_mfma_kernel<FT, NONE, true>
 size_t span_attn_fused_mfma_workspace_bytes(int batch, int n_heads, int n_groups, int max_seq_len) {
   return attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true).partial_bytes;
@@ -1144,7 +1204,8 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
   a.nchunks = p.nchunks;
   a.scale = qk_scale;
   a.rope_tab = rope_table;
-  const dim3 grid(p.nsplits, n_groups * p.nchunks, batch);
+  const int pf_rows = take_prefetch_rows(a, p.nsplits, n_groups * p.nchunks, batch);
+  const dim3 grid(p.nsplits, n_groups * p.nchunks + pf_rows, batch);
   if (dtype == DIHIP_BF16)
     hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_NONE, true>), grid, dim3(ATTN_THREADS), 0, s, a);
   else
@@ -1159,9 +1220,107 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
   return launch_status();
 }
 
+// partials-only form of the above: no merge launch, the consumer (dihip_fused_attnmerge_gemm_addto) merges
+constexpr int ATTN_PARTIALS_SPLIT_CAP = 8;  // == GEMV_AP_SPLITS (gemv_stream_kernel.hpp)
+
+static bool fused_partials_covered(int batch, int n_heads, int n_groups, int kv_mode, int dtype) {
+  // (a capability, not a default: decoder.DecodeSession keeps the three-launch form unless DIHIP_DECODER_ATTN_MERGE=1 --
+  // measured on MI355X (profiles/r02_attn_merge_fold.txt) the pair is not faster than the launches it replaces: every
+  // o-projection workgroup re-reads all partials (115 KB at 8 splits: +2.4 us of address-pipeline time per CU), and
+  // capping the splits at 8 costs the attention kernel 3 us (10.5 vs 7.2 us))
+  return batch >= 1 && batch <= 4 && kv_mode == DIHIP_KV_NONE && (dtype == DIHIP_BF16) && attn_use_mfma(kv_mode, dtype) &&
+         n_heads % n_groups == 0 && n_heads / n_groups <= MF_HC;
+}
+
 }  // namespace dihip
 
 using namespace dihip;
+
+extern "C" {
+
+int dihip_span_attn_fused_partials_plan(int batch, int n_heads, int n_groups, int max_seq_len, int kv_mode, int dtype,
+                                        int* nsplits, size_t* partial_bytes) {
+  if (nsplits) *nsplits = 0;
+  if (partial_bytes) *partial_bytes = 0;
+  if (!fused_partials_covered(batch, n_heads, n_groups, kv_mode, dtype) || max_seq_len <= 0) return DIHIP_SUCCESS;
+  const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true, ATTN_PARTIALS_SPLIT_CAP);
+  if (nsplits) *nsplits = p.nsplits;
+  if (partial_bytes) *partial_bytes = (size_t)batch * n_heads * p.nsplits * ATTN_PSTRIDE * sizeof(float);
+  return DIHIP_SUCCESS;
+}
+
+int dihip_span_attn_decode_fused_partials(void* stream, float* partials, size_t partial_bytes, const void* qkv,
+                                          void* const* k_span_array, void* const* v_span_array,
+                                          const uint32_t* old_seq_lens_dev, const float* rope_table, int batch, int n_heads,
+                                          int n_groups, int head_size, int span_len, int n_spans_per_request, int max_seq_len,
+                                          int kv_mode, int dtype, float qk_scale) {
+  DIHIP_REQUIRE(batch >= 0 && n_heads > 0 && n_groups > 0 && n_spans_per_request > 0 && max_seq_len > 0, DIHIP_PARAM_ERROR,
+                "span_attn_decode_fused_partials: invalid parameter");
+  DIHIP_REQUIRE(partials && qkv && k_span_array && v_span_array && old_seq_lens_dev && rope_table, DIHIP_PARAM_ERROR,
+                "span_attn_decode_fused_partials: null pointer");
+  DIHIP_REQUIRE(head_size == 128, DIHIP_PARAM_ERROR, "span_attn: unsupported head size %d (only 128, dispatch.hpp:45-57)", head_size);
+  DIHIP_REQUIRE(span_len_valid(span_len), DIHIP_PARAM_ERROR, "span_attn: span length %d not in {16,32,64,128}", span_len);
+  DIHIP_REQUIRE((reinterpret_cast<uintptr_t>(qkv) & 15) == 0, DIHIP_PARAM_ERROR, "span_attn_decode_fused_partials: qkv must be 16-byte aligned");
+  if (batch == 0) return DIHIP_SUCCESS;
+  DIHIP_REQUIRE(fused_partials_covered(batch, n_heads, n_groups, kv_mode, dtype), DIHIP_PARAM_ERROR,
+                "span_attn_decode_fused_partials: configuration not covered (batch <= 4, 16-bit cache, bf16; see _plan)");
+  const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true, ATTN_PARTIALS_SPLIT_CAP);
+  const size_t need = (size_t)batch * n_heads * p.nsplits * ATTN_PSTRIDE * sizeof(float);
+  DIHIP_REQUIRE(partial_bytes >= need, DIHIP_MEMORY_ERROR, "span_attn_decode_fused_partials: partial buffer too small (%zu < %zu)",
+                partial_bytes, need);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  AttnArgs a{};
+  a.q = qkv;
+  a.kspans = k_span_array;
+  a.vspans = v_span_array;
+  a.seq_lens = old_seq_lens_dev;
+  a.partials = partials;
+  a.B = batch;
+  a.n = n_heads;
+  a.g = n_groups;
+  a.hpg = n_heads / n_groups;
+  a.S = span_len;
+  a.span_stride = n_spans_per_request;
+  a.nsplits = p.nsplits;
+  a.nchunks = p.nchunks;
+  a.scale = qk_scale;
+  a.rope_tab = rope_table;
+  a.force_partials = 1;
+  const int pf_rows = take_prefetch_rows(a, p.nsplits, n_groups * p.nchunks, batch);
+  const dim3 grid(p.nsplits, n_groups * p.nchunks + pf_rows, batch);
+  hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_NONE, true>), grid, dim3(ATTN_THREADS), 0, s, a);
+  return launch_status();
+}
+
+int dihip_span_attn_set_next_prefetch(const void* const* ptrs, const size_t* bytes, int count) {
+  DIHIP_REQUIRE(count >= 0 && count <= 4 && (count == 0 || (ptrs && bytes)), DIHIP_PARAM_ERROR,
+                "span_attn_set_next_prefetch: 0..4 buffers");
+  g_pending_pf.n = count;
+  for (int i = 0; i < count; ++i) {
+    g_pending_pf.ptr[i] = ptrs[i];
+    g_pending_pf.bytes[i] = ptrs[i] ? bytes[i] : 0;
+  }
+  return DIHIP_SUCCESS;
+}
+
+int dihip_span_attn_merge_partials(void* stream, void* output, const float* partials, int batch, int n_heads, int nsplits,
+                                   int dtype) {
+  DIHIP_REQUIRE(output && partials && batch >= 0 && n_heads > 0 && nsplits >= 1, DIHIP_PARAM_ERROR,
+                "span_attn_merge_partials: invalid parameter");
+  DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16 || dtype == DIHIP_F32, DIHIP_PARAM_ERROR, "span_attn_merge_partials: dtype");
+  if (batch == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 mg(batch * n_heads), mb(128);
+  if (dtype == DIHIP_BF16)
+    hipLaunchKernelGGL(span_attn_split_merge_kernel<DIHIP_BF16>, mg, mb, 0, s, output, partials, n_heads, nsplits, 0);
+  else if (dtype == DIHIP_F16)
+    hipLaunchKernelGGL(span_attn_split_merge_kernel<DIHIP_F16>, mg, mb, 0, s, output, partials, n_heads, nsplits, 0);
+  else
+    hipLaunchKernelGGL(span_attn_split_merge_kernel<DIHIP_F32>, mg, mb, 0, s, output, partials, n_heads, nsplits, 0);
+  return launch_status();
+}
+
+}  // extern "C"
 
 // handle of the reference-shaped API (span::SpanAttnHandle, span-attention/src/attn/span_attn_handle.hpp)
 struct dihip_span_attn_handle {

@@ -24,6 +24,14 @@ struct AttnArgs {
   // decode-step form (Rotary + DecoderCacheAppend folded in): q points at the fused pre-Rotary qkv rows
   // [B, (n + 2g) * H], seq_lens holds the tokens ALREADY cached (position of the new token)
   const float* rope_tab;  // [max_pos][64] {cos, sin}; non-null selects the decode-step form
+  // decode-step form: workgroups with blockIdx.y >= g * nchunks do not attend; they touch one dword per 128-byte line of up
+  // to 4 buffers (the weights of the launches that follow: o-projection, next layer's qkv), which pulls them into the
+  // 256 MB Infinity Cache while the attention -- 4 MB of KV on a fraction of the CUs -- leaves HBM idle.  The small
+  // GEMVs are first-byte-latency bound: on cache-resident weights they measured 1.4-1.6 us shorter (profiles/r02*).
+  const unsigned* pf_ptr[4];
+  unsigned pf_lines[4];
+  int force_partials;     // write the block's partial record even for a single split and leave the merge to the consumer
+                          // (the o-projection GEMV's PRO_ATTNMERGE prologue: no merge launch)
 };
 
 // decode-step form on the matrix cores (span_attn.hip); returns a DIHIP status, DIHIP_PARAM_ERROR with

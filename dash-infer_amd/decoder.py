@@ -299,6 +299,20 @@ class DecodeSession:
         # (16-bit cache: the decode-step form runs on the matrix cores at every batch size; quantised caches have the
         # MFMA kernels only at the op boundary, their decode-step form is the one-wave-per-head kernel)
         self.fused_attention = kv_mode == "none" or batch * self.g_loc <= 64
+        # batch <= 4, 16-bit cache: the attention kernel leaves its split partials and the o-projection GEMV merges them in
+        # its prologue (one launch less per layer).  Built, bit-identical, and NOT faster (see span_attn.hip:
+        # fused_partials_covered): an experiment switch, DIHIP_DECODER_ATTN_MERGE=1
+        self.attn_nsplits, self.attn_partials = 0, None
+        # weights of the following launches touched by idle CUs during the attention launch: measured SLOWER end to end
+        # (606 vs 627 tokens/s, profiles/r02_attn_merge_fold.txt: the prefetch traffic delays the attention's own,
+        # latency-bound loads more than the warmer GEMVs gain) -- kept as an experiment switch, off by default
+        self.attn_prefetch = batch <= 4 and os.environ.get("DIHIP_DECODER_ATTN_PREFETCH", "0") == "1"
+        if self.fused_attention and dt == torch.bfloat16 and os.environ.get("DIHIP_DECODER_ATTN_MERGE", "0") == "1":
+            lo = model.layers[0].o
+            ns, nbytes = ops.span_attn_partials_plan(batch, self.n_loc, self.g_loc, max_len, kv_mode, dt)
+            if ns > 0 and ops.gemv_plan(lo.wbits, batch, lo.N, lo.K, lo.group) is not None:
+                self.attn_nsplits = ns
+                self.attn_partials = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
         if not self.fused_attention and batch <= 32 and ops.prefers_frag(model.layers[0].o, batch):
             self.attn_frag = True
             self.attn = torch.zeros(ops.act_frag_numel(batch, self.n_loc * H), dtype=dt, device=device)
@@ -346,6 +360,50 @@ class DecodeSession:
             allp[..., 1] = 0.25 if self.kv_mode == "u4" else 0.02
             self.pool.pool.view(-1, per)[:, g * S * hb: g * S * hb + g * S * 8] = allp.view(torch.uint8).view(-1, g * S * 8)
 
+    # -- context (prefill) phase ----------------------------------------------------------------
+    def prefill(self, seqs, return_logits=True):
+        """Context phase of every request through the product's op-boundary entry points, in the order of the reference
+        graph (qwen_v15.py:210-388; SpanAttnOp::runContext, span_attn_op_cuda.cpp:205-330): embedding -> per layer
+        RMSNorm + qkv GEMM(+bias) -> Rotary on the fused rows -> ContextSpanCopy of K, V into the request's spans ->
+        causal prefill attention -> o GEMM + residual -> RMSNorm + gate/up GEMM + SwiGLU -> down GEMM + residual;
+        final norm + lm_head on the last row.  Leaves the session ready to decode: lens = len(seq), ids = greedy next
+        token.  seqs: one token-id list per request (single rank)."""
+        m, cfg = self.model, self.model.cfg
+        assert m.nranks == 1 and len(seqs) == self.B
+        n, g, H, dev = self.n_loc, self.g_loc, self.H, self.h.device
+        Lmax = max(len(s) for s in seqs)
+        l0, wb, gsz = m.layers[0], m.quant.wbits, m.quant.group
+        need = max(ops.lowp_workspace_bytes(wb, Lmax, p.N, p.K, gsz) for p in (l0.qkv, l0.o, l0.gate, l0.down))
+        need = max(need, int(lib().dihip_dense_workspace_bytes(1, m.lm_head.N, m.lm_head.K)))
+        sc = ops.Scratch(need, dev)
+        logits = torch.empty(self.B, m.vocab_local, dtype=torch.float32, device=dev) if return_logits else None
+        for b, seq in enumerate(seqs):
+            L = len(seq)
+            assert 0 < L <= self.max_len
+            ids = torch.as_tensor(seq, dtype=torch.int64, device=dev)
+            pos = torch.arange(L, dtype=torch.int32, device=dev)
+            h = ops.embedding(ids, m.embed)
+            for li, lw in enumerate(m.layers):
+                qkv = ops.fused_norm_gemm(h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sc)
+                ops.rope_qk_(qkv, pos, self.inv_freq, n, g, H)
+                kv = self.kv[li]
+                stride = (n + 2 * g) * H
+                ops.kv_context_copy(kv.k_ptrs[b], qkv[:, n * H:], stride, L, 0, g, H, self.pool.S, self.kv_mode)
+                ops.kv_context_copy(kv.v_ptrs[b], qkv[:, (n + g) * H:], stride, L, 0, g, H, self.pool.S, self.kv_mode)
+                attn = ops.prefill_attn(qkv[:, : n * H], qkv[:, n * H:(n + g) * H], qkv[:, (n + g) * H:], n, g, H, self.scale)
+                h = ops.fused_gemm_addto(attn, lw.o, h, sc, M=L)
+                act = ops.fused_norm_swiglu(h, lw.ln2, cfg.eps, lw.gate, lw.up, sc)
+                h = ops.fused_gemm_addto(act, lw.down, h, sc, M=L)
+            if return_logits:
+                ops.lm_head(h[L - 1:L].contiguous(), m.final_norm, cfg.eps, m.lm_head, sc, out=logits[b:b + 1])
+        lens = [len(s) for s in seqs]
+        if return_logits:
+            nxt = torch.argmax(logits, dim=-1).cpu()
+            self.set_state(nxt, lens)
+        else:
+            self.set_state(torch.zeros(self.B, dtype=torch.int64), lens)
+        return logits
+
     # -- one decode step -------------------------------------------------------------------
     def step(self):
         m, cfg, sc = self.model, self.model.cfg, self.scratch
@@ -357,7 +415,14 @@ class DecodeSession:
                 ops.prenorm_gemm(self.xn1, lw.qkv, lw.qkv_bias, sc, self.B, x_layout=self.xn1_layout, out=self.qkv)
             else:
                 ops.fused_norm_gemm(self.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sc, out=self.qkv)
-            if self.fused_attention:
+            if self.attn_prefetch and self.kv_mode == "none" and self.fused_attention:
+                # weights of the launches that follow, pulled into the Infinity Cache by the CUs the attention leaves idle
+                nxt = m.layers[li + 1].qkv if li + 1 < len(m.layers) else None
+                ops.span_attn_set_next_prefetch([lw.o.w, lw.o.sz] + ([nxt.w, nxt.sz] if nxt is not None else []))
+            if self.attn_nsplits:
+                ops.span_attn_decode_fused_partials(self.qkv, self.kv[li], self.old_lens, self.rope_tab, self.n_loc, self.g_loc,
+                                                    self.H, self.max_len, self.scale, self.attn_partials)
+            elif self.fused_attention:
                 ops.span_attn_decode_fused(self.qkv, self.kv[li], self.old_lens, self.rope_tab, self.n_loc, self.g_loc, self.H,
                                            self.max_len, self.scale, self.attn_ws, out=self.attn)
             else:
@@ -378,7 +443,13 @@ class DecodeSession:
                 else:
                     self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag)  # lm_head applies the final norm itself
                 continue
-            self._proj_residual(self.attn, lw.o, tp_on, frag=self.attn_frag)
+            if self.attn_nsplits:
+                h_res = self.h if (not tp_on or m.rank == 0) else None
+                ops.fused_attnmerge_gemm_addto(self.attn_partials, self.attn_nsplits, self.n_loc, lw.o, h_res, sc, out=self.h, M=self.B)
+                if tp_on:
+                    self.comm.allreduce_(self.h)
+            else:
+                self._proj_residual(self.attn, lw.o, tp_on, frag=self.attn_frag)
             ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act,
                                   y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
             self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag)
