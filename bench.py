@@ -81,7 +81,7 @@ def cpu_baseline(wbits, group, cores_hint=None):
     except Exception:  # noqa: BLE001 -- no libgomp handle: OpenMP's own default
         pass
     # repeat the one-layer sample for about budget_s seconds of CPU work (a single pass is tens of ms); median pass
-    budget_s, passes, t_start = 10.0, [], time.perf_counter()
+    budget_s, passes, t_start = 6.0, [], time.perf_counter()
     while len(passes) < 3 or (time.perf_counter() - t_start < budget_s and len(passes) < 400):
         passes.append(one_pass())
     passes.sort()
@@ -91,6 +91,94 @@ def cpu_baseline(wbits, group, cores_hint=None):
                       f"layers at batch 1, extrapolated x28; median of {len(passes)} passes in "
                       f"{time.perf_counter() - t_start:.1f} s: {t_layer * 1e3:.1f} ms/layer (min {passes[0] * 1e3:.1f}, "
                       f"max {passes[-1] * 1e3:.1f})"}
+
+
+def cpu_baseline_torch(wbits, group, seq_len=SEQ_LEN, budget_s=15.0):
+    """the reference's x86 path cannot be built here (oneDNN / MKL / intel_gemm are LFS stubs), so the
+    SAME decode graph is timed through PyTorch-CPU (oneDNN + MKL, the libraries the reference's x86 operators call:
+    csrc/core/operator/general/gemm/gemm_op_cpu.cpp:75-126, generate_opt/batch_mqa/batch_mqa_op.cpp:140-179) on this box's
+    host cores: f32 activations, linear layers as bf16(x) . bf16(W_dequantised) -> f32, attention as alpha Q K^T -> f32 softmax
+    -> P V over a contiguous f32 cache of `seq_len` tokens, RMSNorm / RoPE / SwiGLU / residual in f32, bf16 lm_head.  Whole
+    Qwen2-7B step = 28 decoder layers + final norm + lm_head at batch 1; the timed sample runs the layer graph over 4 distinct
+    layers' weights in rotation (1.9 GB: larger than the last-level caches) and the lm_head once per 28 layer passes."""
+    import platform
+    import torch
+    torch.manual_seed(0)
+    hid, n, g, H, inter, vocab, L = 3584, 28, 4, 128, 18944, 152064, 28
+    cores = os.cpu_count() or 1
+
+    def mk(K, N):  # a dequantised weight as the x86 path would hold it: bf16 [K, N]
+        return (torch.randn(K, N, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+
+    nrot = 4
+    layers = [dict(qkv=mk(hid, (n + 2 * g) * H), qkv_b=torch.zeros((n + 2 * g) * H), o=mk(n * H, hid), gate=mk(hid, inter),
+                   up=mk(hid, inter), down=mk(inter, hid), ln1=torch.ones(hid), ln2=torch.ones(hid),
+                   k=torch.randn(g, seq_len + 1, H), v=torch.randn(g, seq_len + 1, H)) for _ in range(nrot)]
+    lm_head, fnorm = mk(hid, vocab), torch.ones(hid)
+    inv = 1.0 / (1e6 ** (torch.arange(0, H, 2, dtype=torch.float32) / H))
+    ang = seq_len * inv
+    cos, sin = torch.cos(ang), torch.sin(ang)
+
+    def lin(x, w):
+        return torch.mm(x.to(torch.bfloat16), w).float()
+
+    def rms(x, gam):
+        return (gam * x) * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-6)
+
+    def rope(t):  # [heads, H]
+        a, b = t[:, : H // 2], t[:, H // 2:]
+        return torch.cat([a * cos - b * sin, b * cos + a * sin], -1)
+
+    def layer(h, w):
+        qkv = lin(rms(h, w["ln1"]), w["qkv"]) + w["qkv_b"]
+        q = rope(qkv[0, : n * H].view(n, H)).view(g, n // g, H)
+        w["k"][:, seq_len] = rope(qkv[0, n * H:(n + g) * H].view(g, H))
+        w["v"][:, seq_len] = qkv[0, (n + g) * H:].view(g, H)
+        p = torch.softmax(torch.bmm(q, w["k"].transpose(1, 2)) * (H ** -0.5), -1)   # [g, n/g, L+1]
+        att = torch.bmm(p, w["v"]).reshape(1, n * H)
+        h = h + lin(att, w["o"])
+        x2 = rms(h, w["ln2"])
+        act = torch.nn.functional.silu(lin(x2, w["gate"])) * lin(x2, w["up"])
+        return h + lin(act, w["down"])
+
+    def one_step_sample():  # 28 layer passes + lm_head = one token
+        h = torch.randn(1, hid)
+        t0 = time.perf_counter()
+        for i in range(L):
+            h = layer(h, layers[i % nrot])
+        logits = lin(rms(h, fnorm), lm_head)
+        int(torch.argmax(logits))
+        return time.perf_counter() - t0
+
+    with torch.no_grad():
+        best = (None, None)
+        for nthr in sorted({cores, max(1, cores // 2), max(1, cores // 4), min(cores, 64), min(cores, 32)}, reverse=True):
+            torch.set_num_threads(nthr)
+            one_step_sample()
+            t = min(one_step_sample() for _ in range(2))
+            if best[0] is None or t < best[0]:
+                best = (t, nthr)
+        torch.set_num_threads(best[1])
+        ts, t_start = [], time.perf_counter()
+        while len(ts) < 3 or (time.perf_counter() - t_start < budget_s and len(ts) < 200):
+            ts.append(one_step_sample())
+    ts.sort()
+    med = ts[len(ts) // 2]
+    cpu_model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        cpu_model = platform.processor()
+    return {"value": round(1.0 / med, 3), "unit": "tokens/s", "cores": best[1], "kind": "oneDNN-stand-in",
+            "library": f"PyTorch-CPU {torch.__version__} (oneDNN / MKL), torch.set_num_threads({best[1]}) of {cores} logical CPUs; {cpu_model}",
+            "sample": f"whole Qwen2-7B decode step at batch 1, seq {seq_len}: 28 x [RMSNorm, qkv bf16 GEMV + bias, RoPE, GQA attention over "
+                      f"{seq_len + 1} cached tokens (f32), o GEMV + residual, RMSNorm, gate/up GEMV + SwiGLU, down GEMV + residual] over "
+                      f"{nrot} distinct layers' bf16 weights in rotation + final norm + bf16 lm_head + argmax; median of {len(ts)} steps in "
+                      f"{time.perf_counter() - t_start:.1f} s ({med * 1e3:.1f} ms/token; min {ts[0] * 1e3:.1f}, max {ts[-1] * 1e3:.1f}); "
+                      f"weights dequantised to bf16 as the x86 path holds them (int{wbits} g{group} on the GPU)"}
 
 
 def kernel_breakdown(sess, torch, ops, iters=5):
@@ -318,9 +406,13 @@ def main():
             out["roofline_error"] = repr(e)
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(wbits, group)
+                out["cpu_baseline"] = cpu_baseline_torch(wbits, group)
             except Exception as e:
                 out["cpu_baseline_error"] = repr(e)
+            try:  # second figure: the plain-C oracle loop (the restated CPU_SubC_Ref), linear layers only
+                out["cpu_baseline_port"] = cpu_baseline(wbits, group)
+            except Exception as e:
+                out["cpu_baseline_port_error"] = repr(e)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

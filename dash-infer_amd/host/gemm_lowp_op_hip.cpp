@@ -84,7 +84,11 @@ class GemmLowpHIP : public AsOperator {
     AsTensor* y = tensor_map_->at(out_names_[0]).get();
     AsTensor* wsp = tensor_map_->at("workspace").get();
     const void* bias = weights_.size() == 4 ? weights_[3]->GetDataPtr() : nullptr;
-    const void* residual = in_names_.size() > 1 ? tensor_map_->at(in_names_[1])->GetDataPtr() : nullptr;  // fused binary ADD
+    // fused binary ADD (the residual): under tensor parallelism only rank 0 applies it -- the partial results of the
+    // ranks are summed by the AllReduce that follows, and the residual must enter that sum once
+    // (GemmOpBase::Reshape, csrc/core/operator/general/gemm/gemm_op.cpp:133-137: binary_type_ = UNDEFINED on rank != 0)
+    const bool add_residual = in_names_.size() > 1 && (ctx_->GetNranks() <= 1 || ctx_->GetRank() == 0);
+    const void* residual = add_residual ? tensor_map_->at(in_names_[1])->GetDataPtr() : nullptr;
     if (x->GetDataType() != ftype_) return AsStatus::ALLSPARK_PARAM_ERROR;
     hipStream_t s = static_cast<const HIPContext*>(ctx_)->GetStream();
     auto fn = WBITS == 8 ? dihip_gemm_a16w8 : dihip_gemm_a16w4;

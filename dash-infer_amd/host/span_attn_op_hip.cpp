@@ -40,8 +40,26 @@ class SpanAttnOpHIP : public AsOperator {
     tensor_map_->at(out_names_[0])->SetDataType(dtype_);
     auto it = op_proto.attr.find("alpha");
     if (it != op_proto.attr.end()) alpha_ = *(const float*)it->second.c_str();
-    n_ = ctx_->GetNumberHeads() / ctx_->GetNranks();
-    g_ = std::max(1, (ctx_->GetNumberGroups() == 0 ? ctx_->GetNumberHeads() : ctx_->GetNumberGroups()) / ctx_->GetNranks());
+    // This rank's heads.  g >= nranks: the reference's even split (head_gqa.h:29-49; g % nranks != 0 is its PARAM_ERROR).
+    // g < nranks (Qwen2-7B at TP = 8; the reference refuses): each KV head is replicated on nranks / g ranks which divide
+    // its query heads, larger shares first -- the rule of dash-infer_amd/tp.py::shard_heads (7 heads on 2 ranks: 4 + 3),
+    // which is also how the qkv weight was column-split for this rank.
+    {
+      const int n = ctx_->GetNumberHeads(), nr = std::max(1, ctx_->GetNranks()), rank = ctx_->GetRank();
+      const int g = ctx_->GetNumberGroups() == 0 ? n : ctx_->GetNumberGroups();
+      if (n <= 0 || g <= 0 || n % g != 0) return AsStatus::ALLSPARK_PARAM_ERROR;
+      if (g >= nr) {
+        if (g % nr != 0) return AsStatus::ALLSPARK_PARAM_ERROR;
+        g_ = g / nr;
+        n_ = n / nr;
+      } else {
+        if (nr % g != 0) return AsStatus::ALLSPARK_PARAM_ERROR;
+        const int rep = nr / g, hpg = n / g, idx = rank % rep;
+        g_ = 1;
+        n_ = hpg / rep + (idx < hpg % rep ? 1 : 0);
+        if (n_ <= 0) return AsStatus::ALLSPARK_PARAM_ERROR;  // more ranks than query heads per KV head
+      }
+    }
     h_ = ctx_->GetSizePerHead();
     if (alpha_ < 0) alpha_ = 1.0f / std::sqrt((float)h_);
     span_ = ctx_->GetCacheSpanSize();

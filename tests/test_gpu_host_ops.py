@@ -263,3 +263,84 @@ def test_moe_a16w8_operator(env):
         m.create_op("MOEA16W8", "bad", ["x", "router"], ["y2"], ["gu", "gu.scales", "gu.zeros", "dn", "dn.scales", "dn.zeros"],
                     f"num_experts=i:{E}")
     m.close()
+
+
+def test_row_split_gemm_adds_the_residual_on_rank0_only(env):
+    """Tensor parallel o_proj / down_proj (HSPLIT) with the fused binary ADD: the AllReduce sums the ranks' outputs, so the
+    residual must enter once -- GemmOpBase::Reshape drops it on rank != 0 (gemm_op.cpp:133-137).  Two ranks' operators over
+    the two K halves: out_0 + out_1 == x.W + residual (not + 2 residual)."""
+    hostapi, ops = env
+    rng = np.random.default_rng(21)
+    K, N, M, G = 512, 256, 3, 128
+    W = bf16_round(rng.normal(0, 0.05, (K, N)).astype(np.float32))
+    q, s, z = quant.iq_quantize_a16w4(W, G, "bf16")
+    x = bf16_round(rng.normal(0, 1, (M, 1, K)).astype(np.float32))
+    res = bf16_round(rng.normal(0, 1, (M, 1, N)).astype(np.float32))
+    outs = []
+    for rank in range(2):
+        rows = slice(rank * K // 2, (rank + 1) * K // 2)
+        grp = slice(rank * K // 2 // G, (rank + 1) * K // 2 // G)
+        m = hostapi.Model(ops.cur_stream(), 4, 2, 128, 16, rank=rank, nranks=2)
+        m.set_weight("w", torch.from_numpy(np.ascontiguousarray(q[rows])).cuda(), "u8")
+        m.set_weight("w.scales", dev(s[grp]), "bf16")
+        m.set_weight("w.zeros", dev(z[grp]), "bf16")
+        m.set_tensor("x", dev(x[:, :, rows]), "bf16")
+        m.set_tensor("res", dev(res), "bf16")
+        op = m.create_op("GemmA16W4", "decoder.layer.0.attention.output", ["x", "res"], ["y"], ["w", "w.scales", "w.zeros"],
+                         f"alpha=f:1.0;GroupSize=i:{G}")
+        m.reshape(op)
+        m.forward(op)
+        dt, shape, ptr = m.get_tensor("y")
+        outs.append(view_of(ptr, shape, torch.bfloat16).float().cpu().numpy().reshape(M, N))
+        m.close()
+    full = gemm_ref.gemm_a16wx(x.reshape(M, K), q, s, z, G, 4, ft="f32", round_out=False)
+    want = full + res.reshape(M, N)
+    got = outs[0] + outs[1]
+    tol = 3 * 2 ** -8 * np.abs(want).max()
+    assert np.abs(got - want).max() <= tol, np.abs(got - want).max()
+    assert np.abs(got - (want + res.reshape(M, N))).max() > 10 * tol  # the bug this guards against: the residual summed twice
+
+
+@pytest.mark.parametrize("rank,want_n", [(0, 4), (1, 3), (6, 4), (7, 3)])
+def test_span_attention_operator_with_replicated_kv_heads(env, rank, want_n):
+    """Qwen2-7B at TP = 8 (28 query / 4 KV heads): fewer KV heads than ranks -- each KV head lives on two ranks which take 4 and
+    3 of its query heads (dash-infer_amd/tp.py::shard_heads; the reference refuses, head_gqa.h:29-49).  The operator derives
+    the rank's head counts by the same rule: Reshape accepts the rank's fused qkv width and decode runs."""
+    from dash_infer_amd import tp
+    hostapi, ops = env
+    shard = tp.shard_heads(28, 4, 8)[rank]
+    assert len(shard.q_heads) == want_n and len(shard.kv_heads) == 1
+    rng = np.random.default_rng(rank)
+    n, g, H, S, L = want_n, 1, 128, 16, 21
+    m = hostapi.Model(ops.cur_stream(), 28, 4, H, S, cache_mode=0, max_batch=1, max_len=64, rank=rank, nranks=8)
+    pool = ops.SpanPool(16, g, S, H, "none", torch.bfloat16)
+    kv = ops.KVCacheSet(pool, 1, 4)
+    kv.ensure(0, L + 1)
+    kc, vc = kv_codec.SpanCache(g, S, H, "none"), kv_codec.SpanCache(g, S, H, "none")
+    for t in range(L):
+        kc.write(t, rng.normal(0, 1, (g, H)))
+        vc.write(t, rng.normal(0, 1, (g, H)))
+    for i, sp in enumerate(kc.spans):
+        pool.span_view(kv.k_idx[0][i]).copy_(torch.from_numpy(sp))
+    for i, sp in enumerate(vc.spans):
+        pool.span_view(kv.v_idx[0][i]).copy_(torch.from_numpy(sp))
+    qkv = bf16_round(rng.normal(0, 1, (1, 1, (n + 2 * g) * H)).astype(np.float32))
+    m.set_tensor("qkv", dev(qkv), "bf16")
+    op = m.create_op("DecOptMQA", "decoder.layer.0.attention", ["qkv"], ["out"])
+    kptrs = [[[int(kv.k_host[0, i]) for i in range(kv.max_spans)]]]
+    vptrs = [[[int(kv.v_host[0, i]) for i in range(kv.max_spans)]]]
+    m.set_runtime(False, [L], kptrs, vptrs)
+    m.reshape(op)
+    m.forward(op)
+    dt, shape, ptr = m.get_tensor("out")
+    assert shape == [1, 1, n * H]
+    out = view_of(ptr, shape, torch.bfloat16).float().cpu().numpy().reshape(n, H)
+    kc.write(L, qkv[0, 0, n * H:(n + g) * H].reshape(g, H))
+    vc.write(L, qkv[0, 0, (n + g) * H:].reshape(g, H))
+    ref = attention.decode_attention(qkv[0, 0, : n * H].reshape(n, H), kc.read_all(L + 1), vc.read_all(L + 1), 1.0 / np.sqrt(H))
+    np.testing.assert_allclose(out, ref, rtol=1e-2, atol=2.5e-3)
+    # a width that belongs to another rank's share is rejected
+    m.set_tensor("qkv", dev(np.zeros((1, 1, ((7 - want_n) + 2) * H), np.float32)), "bf16")
+    with pytest.raises(hostapi.HostError):
+        m.reshape(op)
+    m.close()

@@ -44,3 +44,43 @@ def test_batch_rows_are_independent():
         both = m1.step(ids[t])
         one = m2.step(ids[t][1:2])
         np.testing.assert_array_equal(both[1], one[0])
+
+
+@pytest.mark.parametrize("rounding", ["x86", "ft_graph"])
+@pytest.mark.parametrize("kv_mode", ["none", "i8"])
+def test_prefill_then_step_equals_step_by_step(rounding, kv_mode):
+    """DecoderOracle.prefill (whole prompt at once, causal prefill attention over the fresh K / V, weights dequantised once)
+    leaves the cache token-by-token decoding would have left: with the 16-bit cache the two evaluation orders give the
+    same logits to summation-order accuracy and later steps continue identically; both rounding modes."""
+    rng = np.random.default_rng(11)
+    a = make_oracle(rng, 4, 128, kv_mode)
+    b = make_oracle(np.random.default_rng(11), 4, 128, kv_mode)
+    a.rounding = b.rounding = rounding
+    a._wcache = {}
+    seqs = [[int(t) for t in rng.integers(0, 64, 9)], [int(t) for t in rng.integers(0, 64, 5)]]
+    lo = a.prefill(seqs)
+    for bi, seq in enumerate(seqs):
+        c = make_oracle(np.random.default_rng(11), 4, 128, kv_mode)
+        c.rounding = rounding
+        for t in seq:
+            ref = c.step([t])[0]
+        if kv_mode == "none":
+            np.testing.assert_allclose(lo[bi], ref, rtol=0, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+        else:
+            # the context phase attends over the fresh (unquantised) K / V, step() over the quantised cache (as the reference)
+            np.testing.assert_allclose(lo[bi], ref, rtol=0, atol=0.15 * max(1.0, float(np.abs(ref).max())))
+    nxt = a.step([3, 4])
+    assert nxt.shape == (2, 64) and np.isfinite(nxt).all()
+    assert len(a.cache[0][0][0]) == 10 and len(a.cache[0][1][0]) == 6
+
+
+def test_rounding_modes_differ_only_at_the_documented_points():
+    rng = np.random.default_rng(4)
+    a = make_oracle(rng, 4, 128, "none")
+    b = make_oracle(np.random.default_rng(4), 4, 128, "none")
+    b.rounding = "ft_graph"
+    seq = [1, 5, 9]
+    for t in seq:
+        la, lb = a.step([t])[0], b.step([t])[0]
+    d = float(np.abs(la - lb).max())
+    assert 0 < d < 0.1 * max(1.0, float(np.abs(la).max())), d  # bf16 residual / gate / up rounding: small but not zero
