@@ -377,6 +377,8 @@ def main():
                    "layers": len(model.layers)},
         "step_hbm": {"algorithmic_bytes_per_rank": int(step_bytes), "achieved_GBps_per_gpu": round(step_gbs, 1),
                      "frac_of_peak": round(step_gbs / HBM_PEAK_GBS, 4)},
+        "comm_backend": (comm.backend if comm is not None else None),  # which all-reduce ran: never a silent substitute
+        "ar_overlap": bool(getattr(sess, "ar_overlap", False)),        # all-reduce on a side stream + weight prefetch beside it
         "build_s": round(t_build, 1),
         "last_ids": last_ids[:4],
     }

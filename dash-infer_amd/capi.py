@@ -83,6 +83,7 @@ _SIGS = {
     "dihip_argmax_partial": (i32, [vp, vp, vp, i32, i32, i32, vp, sz]),
     "dihip_argmax_merge": (i32, [vp, vp, vp, i32, i32]),
     "dihip_embedding": (i32, [vp, vp, vp, vp, i32, i32, i32]),
+    "dihip_embedding_v": (i32, [vp, vp, vp, vp, i32, i32, i32, i32]),
     "dihip_increment_u32": (i32, [vp, vp, i32]),
     "dihip_prefetch": (i32, [vp, C.POINTER(vp), C.POINTER(sz), i32, i32]),
     "dihip_rccl_unique_id": (i32, [vp]),
@@ -90,6 +91,18 @@ _SIGS = {
     "dihip_rccl_comm_destroy": (i32, [vp]),
     "dihip_allreduce_sum": (i32, [vp, vp, vp, vp, sz, i32]),
     "dihip_allgather_bytes": (i32, [vp, vp, vp, vp, sz]),
+    "dihip_allgather_rows": (i32, [vp, vp, vp, vp, vp, i32, sz, i32]),
+    "dihip_gather_rows_transpose": (i32, [vp, vp, vp, i32, i32, sz]),
+    "dihip_p2p_ar_buffer_bytes": (sz, []),
+    "dihip_p2p_ar_max_bytes": (sz, []),
+    "dihip_p2p_ar_alloc": (i32, [C.POINTER(vp)]),
+    "dihip_p2p_ar_free": (i32, [vp]),
+    "dihip_ipc_get_handle": (i32, [vp, vp]),
+    "dihip_ipc_open_handle": (i32, [vp, C.POINTER(vp)]),
+    "dihip_ipc_close_handle": (i32, [vp]),
+    "dihip_p2p_ar_create": (i32, [C.POINTER(vp), i32, i32, C.POINTER(vp)]),
+    "dihip_p2p_ar_destroy": (i32, [vp]),
+    "dihip_p2p_allreduce_sum": (i32, [vp, vp, vp, vp, sz, i32]),
     "dihip_debug_set_trace": (i32, [vp, sz]),
     "dihip_debug_gemv_plan": (i32, [i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32),
                               C.POINTER(sz)]),

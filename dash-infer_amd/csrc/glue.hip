@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void argmax_stage2(int64_t* __restrict__ ids, 
   __syncthreads();
   if (threadIdx.x == 0) {
     ArgPair r = arg_better(arg_better(red[0], red[1]), arg_better(red[2], red[3]));
-    ids[m] = (int64_t)r.i;
+    ids[m] = r.i == 0x7fffffff ? 0 : (int64_t)r.i;  // an all-NaN row never beats the sentinel: a valid id, not 2^31 - 1
     if (adv_a) adv_a[m] += 1u;
     if (adv_b) adv_b[m] += 1u;
   }
@@ -121,16 +121,18 @@ __global__ __launch_bounds__(64) void argmax_merge_kernel(int64_t* ids, ArgPair*
   for (int i = threadIdx.x; i < count; i += 64) best = arg_better(best, in[(size_t)m * row_stride + (size_t)i * elem_stride]);
   best = wave_argmax(best);
   if (threadIdx.x == 0) {
-    if (ids) ids[m] = (int64_t)best.i;
-    if (pairs_out) pairs_out[m] = ArgPair{best.v, best.i + index_offset};
+    if (ids) ids[m] = best.i == 0x7fffffff ? 0 : (int64_t)best.i;
+    if (pairs_out) pairs_out[m] = ArgPair{best.v, best.i == 0x7fffffff ? best.i : best.i + index_offset};  // sentinel stays a sentinel
   }
 }
 
 template <int FT>
 __global__ __launch_bounds__(256) void embedding_kernel(float* __restrict__ h, const int64_t* __restrict__ ids,
-                                                        const void* __restrict__ table, int K) {
+                                                        const void* __restrict__ table, int K, int vocab) {
   const int m = blockIdx.x;
-  const size_t row = (size_t)ids[m] * K;
+  int64_t id = ids[m];
+  if (vocab > 0) id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // an id out of range reads a valid row instead of faulting
+  const size_t row = (size_t)id * K;
   for (int k = threadIdx.x; k < K; k += 256) h[(size_t)m * K + k] = load_ft<FT>(table, row + k);
 }
 
@@ -276,7 +278,15 @@ int dihip_embedding(void* stream, float* h, const int64_t* ids, const void* tabl
   DIHIP_REQUIRE(M >= 0 && K > 0 && h && ids && table, DIHIP_PARAM_ERROR, "embedding: bad argument");
   if (M == 0) return DIHIP_SUCCESS;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  FT_SWITCH(dtype, hipLaunchKernelGGL((embedding_kernel<FT>), dim3(M), dim3(256), 0, s, h, ids, table, K));
+  FT_SWITCH(dtype, hipLaunchKernelGGL((embedding_kernel<FT>), dim3(M), dim3(256), 0, s, h, ids, table, K, 0));
+  return launch_status();
+}
+
+int dihip_embedding_v(void* stream, float* h, const int64_t* ids, const void* table, int M, int K, int vocab, int dtype) {
+  DIHIP_REQUIRE(M >= 0 && K > 0 && vocab > 0 && h && ids && table, DIHIP_PARAM_ERROR, "embedding: bad argument");
+  if (M == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  FT_SWITCH(dtype, hipLaunchKernelGGL((embedding_kernel<FT>), dim3(M), dim3(256), 0, s, h, ids, table, K, vocab));
   return launch_status();
 }
 

@@ -792,7 +792,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void span_attn_ft_mfma_kernel(cons
       rotate(knew, cs_row);
       vnew = *reinterpret_cast<const u32x4_t*>(vrow + (lane & 15) * 8);
       if (hc == 0 && wave == 0) {  // one writer per (request, group): DecoderCacheAppend
-        const int sp = newpos / a.S, pos = newpos - sp * a.S;
+        const int sp = min(newpos / a.S, a.span_stride - 1), pos = newpos - (newpos / a.S) * a.S;  // clamped: never past the span table
         unsigned char* kd = reinterpret_cast<unsigned char*>(const_cast<void*>(ksp[sp])) + ((size_t)grp * a.S + pos) * ROWB;
         unsigned char* vd = reinterpret_cast<unsigned char*>(const_cast<void*>(vsp[sp])) + ((size_t)grp * a.S + pos) * ROWB;
         if (ni == 0) {

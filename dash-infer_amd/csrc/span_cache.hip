@@ -131,6 +131,7 @@ __global__ __launch_bounds__(64) void kv_append_kernel(void* const* k_spans, voi
   if (head >= g) return;
   const uint32_t old_len = old_seq_lens[b];
   const uint32_t span_idx = old_len / S, pos = old_len % S;
+  if (span_idx >= (uint32_t)span_stride) return;  // past the request's span table (a replay beyond max_len): drop the write
   float kx[EPL], vx[EPL];
 #pragma unroll
   for (int i = 0; i < EPL; ++i) {
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(64) void rope_kv_append_kernel(void* const* k_spans
   for (int i = 0; i < EPL; ++i) store_ft<FT>(q_out, ((size_t)b * n + head) * H + lane * EPL + i, qx[i]);
   if (head >= g) return;
   const uint32_t span_idx = old_len / S, p = old_len % S;
+  if (span_idx >= (uint32_t)span_stride) return;  // past the request's span table: drop the write
   float kx[EPL], vx[EPL];
 #pragma unroll
   for (int i = 0; i < EPL; ++i) {

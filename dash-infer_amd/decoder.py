@@ -185,6 +185,7 @@ def build_random_model(cfg: ModelConfig, spec: QuantSpec, seed=1234, device="cud
 class RcclComm:
     """RCCL communicator created through the C-ABI; the 128-byte unique id travels over the
     torch.distributed process group (plumbing)."""
+    backend = "rccl"
 
     def __init__(self, rank, nranks, device):
         import torch.distributed as dist
@@ -212,8 +213,9 @@ class RcclComm:
 
 
 class TorchComm:
-    """Fallback communicator: the same collectives through torch.distributed (backend nccl = RCCL).
-    Used only if creating a communicator through the C-ABI fails (e.g. two RCCL builds in one process)."""
+    """The same collectives through torch.distributed (backend nccl = RCCL): diagnostics only, selected explicitly with
+    DIHIP_TP_ALLREDUCE=torch -- never a silent fallback."""
+    backend = "torch.distributed"
 
     def __init__(self, rank, nranks):
         self.rank, self.nranks = rank, nranks
@@ -229,20 +231,75 @@ class TorchComm:
         return dst
 
 
-def make_comm(rank, nranks, device):
-    """RCCL communicator through the C-ABI, verified with one all-reduce; torch.distributed otherwise."""
-    import sys
-    try:
+class P2PComm:
+    """One-shot peer-to-peer all-reduce (csrc/p2p_allreduce.hip): every rank writes its row into every peer's receive buffer
+    over xGMI; the receive buffers are exchanged as IPC handles over the torch.distributed process group (plumbing).
+    The (rare, tiny) all-gather of the arg-max pairs and messages beyond the slot size go through `rccl`."""
+    backend = "p2p-oneshot"
+
+    def __init__(self, rank, nranks, device, rccl):
+        import torch.distributed as dist
+        self.rank, self.nranks, self.rccl = rank, nranks, rccl
+        l = lib()
+        self.buf = C.c_void_p()
+        check(l.dihip_p2p_ar_alloc(C.byref(self.buf)), "dihip_p2p_ar_alloc")
+        raw = (C.c_ubyte * 64)()
+        check(l.dihip_ipc_get_handle(self.buf, raw), "dihip_ipc_get_handle")
+        mine = torch.tensor(list(raw), dtype=torch.uint8, device=device)
+        allh = [torch.zeros(64, dtype=torch.uint8, device=device) for _ in range(nranks)]
+        dist.all_gather(allh, mine)
+        ptrs = (C.c_void_p * nranks)()
+        self.opened = []
+        for r in range(nranks):
+            if r == rank:
+                ptrs[r] = self.buf.value
+            else:
+                p = C.c_void_p()
+                check(l.dihip_ipc_open_handle(bytes(allh[r].cpu().tolist()), C.byref(p)), "dihip_ipc_open_handle")
+                ptrs[r] = p.value
+                self.opened.append(p)
+        self.handle = C.c_void_p()
+        check(l.dihip_p2p_ar_create(C.byref(self.handle), rank, nranks, ptrs), "dihip_p2p_ar_create")
+        self.max_bytes = int(l.dihip_p2p_ar_max_bytes())
+        dist.barrier()  # every rank has opened every buffer before the first push
+
+    def allreduce_(self, t):
+        nbytes = t.numel() * t.element_size()
+        if nbytes > self.max_bytes or nbytes % 8:
+            return self.rccl.allreduce_(t)
+        check(lib().dihip_p2p_allreduce_sum(self.handle, ops.cur_stream(), ops.ptr(t), ops.ptr(t), t.numel(), ops.dt_code(t)),
+              "dihip_p2p_allreduce_sum")
+        return t
+
+    def allgather(self, src, dst):
+        return self.rccl.allgather(src, dst)
+
+
+def make_comm(rank, nranks, device, backend=None):
+    """The tensor-parallel communicator, verified with one all-reduce.  backend (default: $DIHIP_TP_ALLREDUCE or "rccl"):
+      "rccl"  ncclAllReduce over xGMI through the C-ABI (dihip_allreduce_sum)
+      "p2p"   one-shot peer-to-peer all-reduce for decode-sized rows (dihip_p2p_allreduce_sum), RCCL for the rest
+      "torch" torch.distributed collectives (diagnostics only)
+    A backend that cannot be created or returns a wrong sum RAISES: a benchmark line must never come from a silently
+    substituted path (VERDICT r1 #8).  `.backend` names what runs."""
+    backend = backend or os.environ.get("DIHIP_TP_ALLREDUCE", "rccl")
+    if backend == "torch":
+        c = TorchComm(rank, nranks)
+    elif backend in ("rccl", "p2p"):
         c = RcclComm(rank, nranks, device)
-        probe = torch.full((8,), float(rank + 1), dtype=torch.float32, device=device)
-        c.allreduce_(probe)
-        torch.cuda.synchronize()
-        if abs(float(probe[0]) - nranks * (nranks + 1) / 2) > 1e-3:
-            raise RuntimeError("C-ABI all-reduce returned a wrong sum")
-        return c
-    except Exception as e:  # noqa: BLE001
-        print(f"[rank {rank}] dihip RCCL communicator unavailable ({e}); using torch.distributed collectives", file=sys.stderr)
-        return TorchComm(rank, nranks)
+        if backend == "p2p":
+            c = P2PComm(rank, nranks, device, c)
+    else:
+        raise ValueError(f"unknown tensor-parallel all-reduce backend {backend!r}")
+    for dt, n in ((torch.float32, 8), (torch.bfloat16, 3584)):
+        probe = torch.full((n,), float(rank + 1), dtype=dt, device=device)
+        for _ in range(3):  # repeated: the one-shot protocol alternates two slot sets
+            probe.fill_(float(rank + 1))
+            c.allreduce_(probe)
+            torch.cuda.synchronize()
+            if abs(float(probe[0]) - nranks * (nranks + 1) / 2) > 1e-3 or abs(float(probe[-1]) - nranks * (nranks + 1) / 2) > 1e-3:
+                raise RuntimeError(f"[rank {rank}] all-reduce backend {c.backend} returned a wrong sum ({float(probe[0])})")
+    return c
 
 
 class DecodeSession:
@@ -328,6 +385,12 @@ class DecodeSession:
                 return torch.zeros(n, dtype=dt, device=device), (ops.ACT_FRAG32 if frag else ops.ACT_ROWMAJOR)
             self.xn1, self.xn1_layout = norm_buf(l0_.qkv, False)
             self.xn2, self.xn2_layout = norm_buf(l0_.gate, True)
+        # Tensor-parallel all-reduce schedule.  Default: on the compute stream.  DIHIP_TP_OVERLAP=1: the north star's schedule
+        # -- the collective on a side HIP stream between two events (record after the producing GEMV -> side stream waits ->
+        # all-reduce -> record -> compute stream waits), while the compute stream pulls the weights of the NEXT GEMV into
+        # the Infinity Cache (the only work of the decode chain that does not depend on the reduced row).
+        self.ar_overlap = comm is not None and model.nranks > 1 and os.environ.get("DIHIP_TP_OVERLAP", "0") == "1"
+        self.side_stream = torch.cuda.Stream(device=device) if self.ar_overlap else None
         self.argmax_ws = torch.empty(batch * 64 * 8, dtype=torch.uint8, device=device)
         nr = model.nranks
         self.pair = torch.empty(batch * 8, dtype=torch.uint8, device=device)
@@ -447,12 +510,13 @@ class DecodeSession:
                 h_res = self.h if (not tp_on or m.rank == 0) else None
                 ops.fused_attnmerge_gemm_addto(self.attn_partials, self.attn_nsplits, self.n_loc, lw.o, h_res, sc, out=self.h, M=self.B)
                 if tp_on:
-                    self.comm.allreduce_(self.h)
+                    self._allreduce(self.h, (lw.gate.w, lw.up.w))
             else:
-                self._proj_residual(self.attn, lw.o, tp_on, frag=self.attn_frag)
+                self._proj_residual(self.attn, lw.o, tp_on, frag=self.attn_frag, next_weights=(lw.gate.w, lw.up.w))
             ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act,
                                   y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
-            self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag)
+            nxt = m.layers[li + 1].qkv if li + 1 < len(m.layers) else m.lm_head
+            self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag, next_weights=(nxt.w,))
         ops.lm_head(self.h, m.final_norm, cfg.eps, m.lm_head, sc, out=self.logits)
         if tp_on:
             check(lib().dihip_argmax_partial(ops.cur_stream(), ops.ptr(self.pair), ops.ptr(self.logits), self.B,
@@ -466,14 +530,32 @@ class DecodeSession:
         else:
             ops.argmax(self.logits, ws=self.argmax_ws, out=self.ids, advance=(self.old_lens, self.new_lens))
 
-    def _proj_residual(self, x, pw, tp_on, frag=False):
+    def _allreduce(self, t, next_weights=()):
+        """Sum all-reduce of the hidden rows; with the overlap schedule on the side stream, beside a cache prefetch of the
+        weights the next launch streams."""
+        if not self.ar_overlap:
+            self.comm.allreduce_(t)
+            return
+        cur = torch.cuda.current_stream()
+        produced = torch.cuda.Event()
+        produced.record(cur)
+        self.side_stream.wait_event(produced)
+        with torch.cuda.stream(self.side_stream):
+            self.comm.allreduce_(t)
+            reduced = torch.cuda.Event()
+            reduced.record(self.side_stream)
+        if next_weights:
+            ops.prefetch([w for w in next_weights if w is not None], workgroups=64)
+        cur.wait_event(reduced)
+
+    def _proj_residual(self, x, pw, tp_on, frag=False, next_weights=()):
         """h += x . W  (row-parallel under TP: rank 0 carries the residual, then all-reduce --
         the reference applies the fused residual ADD on rank 0 only, gemm_op.cpp:133-137)."""
         lay = ops.ACT_FRAG32 if frag else ops.ACT_ROWMAJOR
         h_res = self.h if (not tp_on or self.model.rank == 0) else None
         ops.fused_gemm_addto(x, pw, h_res, self.scratch, out=self.h, x_layout=lay, M=self.B)
         if tp_on:
-            self.comm.allreduce_(self.h)
+            self._allreduce(self.h, next_weights)
 
     # -- hipGraph capture --------------------------------------------------------------------
     def capture(self, warmup=2, steps_per_graph=1):

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -32,6 +33,7 @@ enum class AsStatus : int {
   ALLSPARK_RUNTIME_ERROR = 5,
   ALLSPARK_EXCEED_LIMIT_ERROR = 7,
   ALLSPARK_INVALID_CALL_ERROR = 8,
+  ALLSPARK_CACHE_MEMORY_OUT = 11,
 };
 #define AS_CHECK_STATUS(expr)                                     \
   do {                                                            \
@@ -167,13 +169,24 @@ class HIPContext : public DeviceContext {
   void* comm_ = nullptr;
 };
 
+// VirtualCache (csrc/runtime/cache/virtual_cache.h:93-139): the per-request paged cache of all layers, as the span
+// operators see it.  GetCache(layer, increment) grows the layer's sequence by `increment` tokens -- claiming spans from the
+// cache manager when a span boundary is crossed -- and returns the layer's span-pointer vector as a POINTER tensor on the
+// host.  The managers behind it (CacheSpanManager, CacheFrameManager, prefix cache) are host code of the reference and
+// are reused as they are; only this interface crosses into the operator.
+class VirtualCache {
+ public:
+  virtual ~VirtualCache() = default;
+  virtual const AsTensor& GetCache(int layer_id, int increment) = 0;  // throws AsException (PARAM_ERROR, CACHE_MEMORY_OUT)
+  virtual size_t GetSeqLength(int layer_id) const = 0;
+  virtual int GetLayerNum() const = 0;
+};
+
 // per-request generation state (generate_context.h:32-70): step = tokens already in the cache
 struct GenerateContext {
   int step = 0;
   int prefix_len = 0;
-  // VirtualCache::GetCache(layer, inc) of the reference returns the request's span pointer vector
-  // for a layer; here the vectors are handed over directly: [layer][span]
-  std::vector<std::vector<void*>> k_spans, v_spans;
+  std::shared_ptr<VirtualCache> virtual_k_cache, virtual_v_cache;  // generate_context.h:60-61
 };
 
 struct RuntimeContext {

@@ -1,11 +1,56 @@
 // host_capi.cpp -- C test harness of the operator layer (include/dashinfer_hip_host.h).
 #include "dashinfer_hip_host.h"
 
+#include <mutex>
 #include <sstream>
+#include <thread>
 
 #include "operator.h"
 
 using namespace allspark;
+
+// Test stand-in for SpannedVirtualCache (csrc/runtime/cache/virtual_cache.{h,cpp}): every layer owns a pre-assigned list of
+// span pointers (the harness hands them in, so that tests know which span holds what) and claims them in order as the
+// sequence grows.  Thread-safe per object, like the reference's (the model allocates the layers concurrently).
+class ListVirtualCache : public VirtualCache {
+ public:
+  ListVirtualCache(std::vector<std::vector<void*>> spans, int span_len, size_t initial_len)
+      : spans_(std::move(spans)), span_len_(span_len), len_(spans_.size(), initial_len) {
+    for (size_t l = 0; l < spans_.size(); ++l) {
+      views_.push_back(nullptr);
+      refresh(l);
+    }
+  }
+  const AsTensor& GetCache(int layer, int increment) override {
+    std::lock_guard<std::mutex> g(mu_);
+    if (layer < 0 || layer >= (int)spans_.size() || increment < 0) throw AsException("GetCache: bad argument", AsStatus::ALLSPARK_PARAM_ERROR);
+    const size_t new_len = len_[layer] + (size_t)increment;
+    if ((new_len + span_len_ - 1) / span_len_ > spans_[layer].size())
+      throw AsException("GetCache: no span left", AsStatus::ALLSPARK_CACHE_MEMORY_OUT);
+    len_[layer] = new_len;
+    refresh(layer);
+    ++calls_;
+    return *views_[layer];
+  }
+  size_t GetSeqLength(int layer) const override {
+    std::lock_guard<std::mutex> g(mu_);
+    return layer >= 0 && layer < (int)len_.size() ? len_[layer] : 0;
+  }
+  int GetLayerNum() const override { return (int)spans_.size(); }
+  long calls() const { return calls_; }
+
+ private:
+  void refresh(size_t l) {  // the POINTER tensor covers the spans claimed so far
+    const int64_t n = (int64_t)((len_[l] + span_len_ - 1) / span_len_);
+    views_[l] = std::make_unique<AsTensor>("span_ptrs", DeviceType::CPU, POINTER, Shape{n}, spans_[l].data());
+  }
+  std::vector<std::vector<void*>> spans_;
+  int span_len_;
+  std::vector<size_t> len_;
+  std::vector<std::unique_ptr<AsTensor>> views_;
+  mutable std::mutex mu_;
+  long calls_ = 0;
+};
 
 struct dihost_model {
   HIPContext ctx;
@@ -32,7 +77,7 @@ const char* dihost_last_error(void) { return g_err.c_str(); }
 const char* dihost_registered_ops(void) {
   static std::string s;
   s.clear();
-  for (const char* t : {"GemmA16W8", "GemmA16W4", "DecOptMHA", "DecOptMQA", "AllReduce", "MOEA16W8", "Gemm", "Rotary"}) {
+  for (const char* t : {"GemmA16W8", "GemmA16W4", "DecOptMHA", "DecOptMQA", "AllReduce", "AllGather", "MOEA16W8", "Gemm", "Rotary"}) {
     try {
       (void)OpFactory::getInstance().GetOperator({t, DeviceType::HIP});
       s += (s.empty() ? "" : ",");
@@ -142,13 +187,15 @@ int dihost_set_runtime(dihost_model_t m, int is_context, int n_requests, const i
   for (int r = 0; r < n_requests; ++r) {
     auto gc = std::make_shared<GenerateContext>();
     gc->step = steps ? steps[r] : 0;
-    gc->k_spans.resize(n_layers);
-    gc->v_spans.resize(n_layers);
+    std::vector<std::vector<void*>> ks(n_layers), vs(n_layers);
     for (int l = 0; l < n_layers; ++l)
       for (int i = 0; i < spans_per_req; ++i) {
-        gc->k_spans[l].push_back(k_spans[((size_t)r * n_layers + l) * spans_per_req + i]);
-        gc->v_spans[l].push_back(v_spans[((size_t)r * n_layers + l) * spans_per_req + i]);
+        ks[l].push_back(k_spans[((size_t)r * n_layers + l) * spans_per_req + i]);
+        vs[l].push_back(v_spans[((size_t)r * n_layers + l) * spans_per_req + i]);
       }
+    // the caches already hold `step` tokens (prefill / earlier steps of the test wrote them)
+    gc->virtual_k_cache = std::make_shared<ListVirtualCache>(std::move(ks), m->ctx.GetCacheSpanSize(), (size_t)gc->step);
+    gc->virtual_v_cache = std::make_shared<ListVirtualCache>(std::move(vs), m->ctx.GetCacheSpanSize(), (size_t)gc->step);
     m->rt.gen_ctx_list.push_back(gc);
   }
   return 0;
@@ -167,6 +214,27 @@ int dihost_op_alloc(dihost_model_t m, int id) {
   AsOperator* op = get_op(m, id);
   return op ? (int)op->CallAlloc(&m->rt) : (int)AsStatus::ALLSPARK_PARAM_ERROR;
 }
+// CallAlloc of several operators at once, one thread each, as the model does with CONFIG_CONCURRENT_SPAN
+// (model.cpp:1253-1262); returns the first non-success status
+int dihost_ops_alloc_concurrent(dihost_model_t m, const int* ids, int count) {
+  std::vector<int> rc(count, 0);
+  std::vector<std::thread> th;
+  for (int i = 0; i < count; ++i)
+    th.emplace_back([&, i] {
+      AsOperator* op = get_op(m, ids[i]);
+      rc[i] = op ? (int)op->CallAlloc(&m->rt) : (int)AsStatus::ALLSPARK_PARAM_ERROR;
+    });
+  for (auto& t : th) t.join();
+  for (int v : rc)
+    if (v) return v;
+  return 0;
+}
+// cached sequence length of a request's K cache for a layer (VirtualCache::GetSeqLength), -1 if unknown
+long dihost_cache_seq_len(dihost_model_t m, int request, int layer) {
+  if (request < 0 || request >= (int)m->rt.gen_ctx_list.size() || !m->rt.gen_ctx_list[request]->virtual_k_cache) return -1;
+  return (long)m->rt.gen_ctx_list[request]->virtual_k_cache->GetSeqLength(layer);
+}
+
 int dihost_op_forward(dihost_model_t m, int id) {
   AsOperator* op = get_op(m, id);
   return op ? (int)op->CallForward(&m->rt) : (int)AsStatus::ALLSPARK_PARAM_ERROR;

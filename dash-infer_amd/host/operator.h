@@ -12,7 +12,11 @@ namespace allspark {
 
 class AsException : public std::runtime_error {
  public:
-  explicit AsException(const std::string& what) : std::runtime_error(what) {}
+  explicit AsException(const std::string& what, AsStatus st = AsStatus::ALLSPARK_UNKNOWN_ERROR) : std::runtime_error(what), st_(st) {}
+  AsStatus status() const { return st_; }  // the reference encodes the status in the message (AS_THROW); kept as a member here
+
+ private:
+  AsStatus st_;
 };
 
 class AsOperator {

@@ -98,21 +98,55 @@ class SpanAttnOpHIP : public AsOperator {
     return AsStatus::ALLSPARK_SUCCESS;
   }
 
+  // SpanAttnOp::Alloc (span_attn_op.cpp:315-368): before every step each request claims the cache for the tokens this
+  // step appends -- seq_ for the request being prefilled, one per request in a decode batch -- through
+  // VirtualCache::GetCache(layer, increment), after the reference's sanity check that the cached length equals
+  // gen_ctx->step.  The model may call the Alloc of different layers concurrently (CONFIG_CONCURRENT_SPAN,
+  // model.cpp:1253-1262): this touches no operator state, only the (thread-safe) cache object of its own layer.
+  AsStatus Alloc(RuntimeContext* rt) override {
+    auto claim = [&](GenerateContext* gc) -> AsStatus {
+      if (!gc || !gc->virtual_k_cache || !gc->virtual_v_cache) return AsStatus::ALLSPARK_PARAM_ERROR;
+      if ((size_t)gc->step != gc->virtual_k_cache->GetSeqLength(layer_num_) ||
+          (size_t)gc->step != gc->virtual_v_cache->GetSeqLength(layer_num_))
+        return AsStatus::ALLSPARK_RUNTIME_ERROR;  // "gen_ctx step and cached seq len mismatch"
+      try {
+        (void)gc->virtual_k_cache->GetCache(layer_num_, seq_);
+        (void)gc->virtual_v_cache->GetCache(layer_num_, seq_);
+      } catch (const AsException& e) {
+        return e.status();
+      }
+      return AsStatus::ALLSPARK_SUCCESS;
+    };
+    if (rt->is_context) return claim(rt->GetContextGenCtx());
+    if (rt->GetGenCtxListSize() != batch_) return AsStatus::ALLSPARK_PARAM_ERROR;
+    for (int b = 0; b < batch_; ++b) AS_CHECK_STATUS(claim(rt->GetGenCtx(b)));
+    return AsStatus::ALLSPARK_SUCCESS;
+  }
+
   AsStatus Forward(RuntimeContext* rt) override { return rt->is_context ? runContext(rt) : runDecoder(rt); }
 
  private:
   hipStream_t Stream() const { return static_cast<const HIPContext*>(ctx_)->GetStream(); }
 
+  // this layer's span pointers of one request (the POINTER tensor of VirtualCache::GetCache(layer, 0)) -> staging row b
   AsStatus stageSpans(const GenerateContext* gc, int b, int ntokens) {
     const int need = (ntokens + span_ - 1) / span_;
-    if (layer_num_ >= (int)gc->k_spans.size() || (int)gc->k_spans[layer_num_].size() < need ||
-        (int)gc->v_spans[layer_num_].size() < need || need > max_spans_)
-      return AsStatus::ALLSPARK_EXCEED_LIMIT_ERROR;  // the cache manager did not provide the span (Alloc failed upstream)
+    if (!gc->virtual_k_cache || !gc->virtual_v_cache || need > max_spans_) return AsStatus::ALLSPARK_EXCEED_LIMIT_ERROR;
+    const AsTensor *kt, *vt;
+    try {
+      kt = &gc->virtual_k_cache->GetCache(layer_num_, 0);
+      vt = &gc->virtual_v_cache->GetCache(layer_num_, 0);
+    } catch (const AsException& e) {
+      return e.status();
+    }
+    if (kt->Count() < need || vt->Count() < need) return AsStatus::ALLSPARK_EXCEED_LIMIT_ERROR;  // Alloc was not called / failed upstream
+    void* const* ks = reinterpret_cast<void* const*>(kt->GetDataPtr());
+    void* const* vs = reinterpret_cast<void* const*>(vt->GetDataPtr());
     void** kh = reinterpret_cast<void**>(k_arr_host_->GetDataPtr()) + (size_t)b * max_spans_;
     void** vh = reinterpret_cast<void**>(v_arr_host_->GetDataPtr()) + (size_t)b * max_spans_;
     for (int i = 0; i < need; ++i) {
-      kh[i] = gc->k_spans[layer_num_][i];
-      vh[i] = gc->v_spans[layer_num_][i];
+      kh[i] = ks[i];
+      vh[i] = vs[i];
     }
     return AsStatus::ALLSPARK_SUCCESS;
   }

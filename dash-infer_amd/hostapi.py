@@ -22,6 +22,8 @@ _SIGS = {
     "dihost_op_reshape": (i32, [vp, i32]),
     "dihost_op_alloc": (i32, [vp, i32]),
     "dihost_op_forward": (i32, [vp, i32]),
+    "dihost_ops_alloc_concurrent": (i32, [vp, C.POINTER(i32), i32]),
+    "dihost_cache_seq_len": (C.c_long, [vp, i32, i32]),
     "dihost_last_error": (C.c_char_p, []),
     "dihost_registered_ops": (C.c_char_p, []),
 }

@@ -471,7 +471,7 @@ def argmax(logits, ws=None, out=None, advance=()):
 def embedding(ids, table, out=None):
     M, K = ids.shape[0], table.shape[1]
     h = out if out is not None else torch.empty(M, K, dtype=torch.float32, device=table.device)
-    check(lib().dihip_embedding(cur_stream(), ptr(h), ptr(ids), ptr(table), M, K, dt_code(table)), "dihip_embedding")
+    check(lib().dihip_embedding_v(cur_stream(), ptr(h), ptr(ids), ptr(table), M, K, table.shape[0], dt_code(table)), "dihip_embedding_v")
     return h
 
 

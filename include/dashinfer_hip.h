@@ -375,6 +375,10 @@ int dihip_argmax_merge(void* stream, int64_t* ids, const void* pairs, int nparts
 /* embedding lookup into the f32 hidden stream: h[m,:] = float(table[ids[m],:])                */
 int dihip_embedding(void* stream, float* h, const int64_t* ids, const void* table, int M, int K,
                     int dtype);
+/* the same with the ids clamped to [0, vocab): an id out of range (e.g. the arg-max of an all-NaN row upstream) reads a
+ * valid row instead of faulting */
+int dihip_embedding_v(void* stream, float* h, const int64_t* ids, const void* table, int M, int K, int vocab,
+                      int dtype);
 /* seq_lens[b] += 1 (device-side step counter for graph replay) */
 int dihip_increment_u32(void* stream, uint32_t* v, int count);
 /* Read-only prefetch of up to 8 buffers into the on-die Infinity Cache (no reference counterpart):
@@ -397,6 +401,34 @@ int dihip_allreduce_sum(void* comm, void* stream, const void* in, void* out, siz
  * `bytes_per_rank` bytes; out holds nranks * bytes_per_rank in rank order.                     */
 int dihip_allgather_bytes(void* comm, void* stream, const void* in, void* out,
                           size_t bytes_per_rank);
+/* AllGatherOp (csrc/core/operator/nccl/allgather/allgather_op.cpp:27-58): every rank contributes `rows` rows of
+ * row_bytes; out = row-major [rows][nranks * row_bytes] (rank r's piece of row m at column offset r * row_bytes) --
+ * ncclAllGather into tmp (>= nranks * rows * row_bytes) followed by the axis-0/1 transpose.  nranks == 1: copy.  */
+int dihip_allgather_rows(void* comm, void* stream, const void* in, void* tmp, void* out, int rows,
+                         size_t row_bytes, int nranks);
+/* its second half on its own: rank-major tmp [nranks][rows][row_bytes] -> row-major out [rows][nranks * row_bytes] */
+int dihip_gather_rows_transpose(void* stream, void* out, const void* tmp, int nranks, int rows, size_t row_bytes);
+
+/* 6b. One-shot peer-to-peer sum all-reduce for decode-sized messages (<= dihip_p2p_ar_max_bytes(): one hidden row per
+ * request).  Every rank writes its row directly into a slot of every peer's receive buffer over xGMI (point-to-point
+ * links: one hop, all links in parallel), raises a flag, waits for the flags addressed to itself and sums the rows in
+ * rank order in f32 -- one launch and one hop instead of the 2 (n - 1) dependent hops of a ring, results bit-identical
+ * on all ranks.  Same call shape as dihip_allreduce_sum (the AllReduceOp replacement,
+ * csrc/core/operator/nccl/allreduce/allreduce_op.cpp:84-92); graph-capturable (the epoch lives on the device).
+ * Setup, once per process group: every rank allocates a receive buffer (dihip_p2p_ar_alloc), publishes its 64-byte IPC
+ * handle (dihip_ipc_get_handle; exchange by any host transport), opens the peers' handles (dihip_ipc_open_handle) and
+ * builds the communicator from the nranks device pointers (its own buffer at index `rank`).  Ranks living in one
+ * process (tests) pass the raw pointers.  count * sizeof(element) must be a multiple of 8; in / out 8-byte aligned.  */
+size_t dihip_p2p_ar_buffer_bytes(void);
+size_t dihip_p2p_ar_max_bytes(void);
+int dihip_p2p_ar_alloc(void** buf);
+int dihip_p2p_ar_free(void* buf);
+int dihip_ipc_get_handle(void* dev_ptr, void* handle64);
+int dihip_ipc_open_handle(const void* handle64, void** dev_ptr);
+int dihip_ipc_close_handle(void* dev_ptr);
+int dihip_p2p_ar_create(void** comm, int rank, int nranks, void* const* bufs);
+int dihip_p2p_ar_destroy(void* comm);
+int dihip_p2p_allreduce_sum(void* comm, void* stream, const void* in, void* out, size_t count, int dtype);
 
 /* =============================================================================================
  * 7. Diagnostics (no reference counterpart)

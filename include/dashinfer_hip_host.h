@@ -30,7 +30,9 @@ int dihost_get_tensor(dihost_model_t m, const char* name, int* dtype, int* ndim,
 int dihost_op_create(dihost_model_t m, int* op_id, const char* op_type, const char* op_name, const char* inputs,
                      const char* outputs, const char* weights, const char* attrs);
 /* runtime context: is_context, one entry per request: step (tokens in cache); span pointer tables
- * k_spans / v_spans: host arrays [n_requests][n_layers][spans_per_req] of device pointers */
+ * k_spans / v_spans: host arrays [n_requests][n_layers][spans_per_req] of device pointers -- the spans each
+ * request's VirtualCache (a list-backed stand-in for SpannedVirtualCache) claims in order as CallAlloc grows it;
+ * the caches start at `step` tokens */
 int dihost_set_runtime(dihost_model_t m, int is_context, int n_requests, const int* steps, int n_layers, int spans_per_req,
                        void* const* k_spans, void* const* v_spans);
 /* prefix-cache hit of the request being prefilled: tokens already present in its first spans */
@@ -38,6 +40,11 @@ int dihost_set_prefix_len(dihost_model_t m, int request, int prefix_len);
 int dihost_op_reshape(dihost_model_t m, int op_id);
 int dihost_op_alloc(dihost_model_t m, int op_id);
 int dihost_op_forward(dihost_model_t m, int op_id);
+/* CallAlloc of `count` operators at once, one host thread each (the model's CONFIG_CONCURRENT_SPAN mode,
+ * csrc/core/model/model.cpp:1253-1262); first non-success AsStatus or 0 */
+int dihost_ops_alloc_concurrent(dihost_model_t m, const int* op_ids, int count);
+/* VirtualCache::GetSeqLength of a request's K cache for one layer (-1: unknown request) */
+long dihost_cache_seq_len(dihost_model_t m, int request, int layer);
 const char* dihost_last_error(void);
 /* "GemmA16W8,GemmA16W4,DecOptMHA,DecOptMQA,AllReduce": op types registered for DeviceType::HIP */
 const char* dihost_registered_ops(void);

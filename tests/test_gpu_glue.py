@@ -64,3 +64,18 @@ def test_binary_ops_and_embedding(ops):
     np.testing.assert_array_equal(ops.embedding(ids, dev(table)).cpu().numpy(), table[[3, 49, 0, 3]])
     v = torch.tensor([0, 5, 2047], dtype=torch.int32, device="cuda")
     assert ops.increment_u32_(v).tolist() == [1, 6, 2048]
+
+
+def test_nan_logits_and_wild_ids_stay_in_range(ops):
+    """an all-NaN logits row must give a valid token id (0), not the 2^31 - 1 sentinel, and an id out of
+    range must not make the embedding read outside its table."""
+    logits = torch.randn(3, 5000, device="cuda")
+    logits[1] = float("nan")
+    ids = ops.argmax(logits)
+    torch.cuda.synchronize()
+    assert ids.tolist()[0] == int(torch.argmax(logits[0])) and ids.tolist()[1] == 0 and ids.tolist()[2] == int(torch.argmax(logits[2]))
+    table = torch.randn(10, 64, device="cuda").to(torch.bfloat16)
+    wild = torch.tensor([3, 2 ** 31 - 1, -5, 9], dtype=torch.int64, device="cuda")
+    h = ops.embedding(wild, table)
+    torch.cuda.synchronize()
+    assert torch.equal(h[0], table[3].float()) and torch.equal(h[1], table[9].float()) and torch.equal(h[2], table[0].float())

@@ -59,6 +59,7 @@ def test_gemm_lowp_operator(env, wbits, G, act):
             op = m.create_op("GemmA16W4" if wbits == 4 else "GemmA16W8", "decoder.layer.0.ffn.gate", ["x"], ["y"],
                              ["w", "w.scales", "w.zeros", "w.bias"], attrs)
         m.reshape(op)
+        m.alloc(op)
         m.forward(op)
         dt, shape, ptr = m.get_tensor("y")
         assert dt == hostapi.DT["bf16"] and shape == [M, 1, N]
@@ -152,6 +153,7 @@ def test_allreduce_operator_single_rank(env):
     m.set_tensor("x", x, "bf16")
     op = m.create_op("AllReduce", "decoder.layer.0.allreduce", ["x"], ["y"])
     m.reshape(op)
+    m.alloc(op)
     m.forward(op)
     _, shape, ptr = m.get_tensor("y")
     assert torch.equal(view_of(ptr, shape, torch.bfloat16), x)
@@ -179,15 +181,17 @@ def test_span_attention_operator_prefill_over_cached_prefix(env, mode):
     op = m.create_op("DecOptMQA", "decoder.layer.0.attention", ["qkv"], ["attn_out"])
     m.set_runtime(True, [0], [[kpA]], [[vpA]])
     m.reshape(op)
+    m.alloc(op)
     m.forward(op)
     # request B: same first two spans, fresh ones behind
     kpB = kpA[: P // S] + [pool.alloc()[0] for _ in range(spr - P // S)]
     vpB = vpA[: P // S] + [pool.alloc()[0] for _ in range(spr - P // S)]
     qkvB = bf16_round(rng.normal(0, 1, (Lnew, (n + 2 * g) * H)).astype(np.float32))
     m.set_tensor("qkv", dev(qkvB.reshape(1, Lnew, -1)), "bf16")
-    m.set_runtime(True, [0], [[kpB]], [[vpB]])
+    m.set_runtime(True, [P], [[kpB]], [[vpB]])  # the request's cache already holds the shared prefix (gen_ctx->step == prefix_len)
     m.set_prefix_len(0, P)
     m.reshape(op)
+    m.alloc(op)
     m.forward(op)
     _, shape, ptr = m.get_tensor("attn_out")
     out = view_of(ptr, shape, torch.bfloat16).float().cpu().numpy().reshape(Lnew, n, H)
@@ -252,6 +256,7 @@ def test_moe_a16w8_operator(env):
             op = m.create_op("MOEA16W8", "decoder.layer.0.mlp.moe", ["x", "router"], ["y"],
                              ["gu", "gu.scales", "gu.zeros", "dn", "dn.scales", "dn.zeros"], f"num_experts=i:{E};num_experts_per_tok=i:{k}")
         m.reshape(op)
+        m.alloc(op)
         m.forward(op)
         dt, shape, ptr = m.get_tensor("y")
         assert dt == hostapi.DT["bf16"] and shape == [T, 1, hidden]
@@ -289,6 +294,7 @@ def test_row_split_gemm_adds_the_residual_on_rank0_only(env):
         op = m.create_op("GemmA16W4", "decoder.layer.0.attention.output", ["x", "res"], ["y"], ["w", "w.scales", "w.zeros"],
                          f"alpha=f:1.0;GroupSize=i:{G}")
         m.reshape(op)
+        m.alloc(op)
         m.forward(op)
         dt, shape, ptr = m.get_tensor("y")
         outs.append(view_of(ptr, shape, torch.bfloat16).float().cpu().numpy().reshape(M, N))
@@ -331,6 +337,7 @@ def test_span_attention_operator_with_replicated_kv_heads(env, rank, want_n):
     vptrs = [[[int(kv.v_host[0, i]) for i in range(kv.max_spans)]]]
     m.set_runtime(False, [L], kptrs, vptrs)
     m.reshape(op)
+    m.alloc(op)
     m.forward(op)
     dt, shape, ptr = m.get_tensor("out")
     assert shape == [1, 1, n * H]
@@ -344,3 +351,63 @@ def test_span_attention_operator_with_replicated_kv_heads(env, rank, want_n):
     with pytest.raises(hostapi.HostError):
         m.reshape(op)
     m.close()
+
+
+def test_span_attention_alloc_claims_spans_through_the_virtual_cache(env):
+    """SpanAttnOp::Alloc (span_attn_op.cpp:315-368): every step each request's cache grows by the tokens the step appends,
+    through VirtualCache::GetCache(layer, increment); the sanity check step == cached length is the reference's; running out
+    of spans surfaces as ALLSPARK_CACHE_MEMORY_OUT; the Alloc of different layers may run concurrently (model.cpp:1253-1262)."""
+    import ctypes as C
+    hostapi, ops = env
+    n, g, H, S, layers, max_len = 4, 2, 128, 16, 6, 64
+    spr = max_len // S
+    m = hostapi.Model(ops.cur_stream(), n, g, H, S, 0, max_batch=2, max_len=max_len)
+    pool = ops.SpanPool(2 * 2 * layers * spr + 1, g, S, H, "none", torch.bfloat16)
+    kp = [[[pool.alloc()[0] for _ in range(spr)] for _ in range(layers)] for _ in range(2)]
+    vp_ = [[[pool.alloc()[0] for _ in range(spr)] for _ in range(layers)] for _ in range(2)]
+    m.set_tensor("qkv", torch.zeros(2, 1, (n + 2 * g) * H, dtype=torch.bfloat16, device="cuda"), "bf16")
+    opids = [m.create_op("DecOptMQA", f"decoder.layer.{l}.attention", ["qkv"], [f"out{l}"]) for l in range(layers)]
+    steps = [15, 31]   # both requests are about to cross a span boundary
+    m.set_runtime(False, steps, kp, vp_)
+    for o in opids:
+        m.reshape(o)
+    lib = hostapi.lib()
+    assert lib.dihost_ops_alloc_concurrent(m.h, (C.c_int * layers)(*opids), layers) == 0
+    for l in range(layers):
+        assert lib.dihost_cache_seq_len(m.h, 0, l) == 16 and lib.dihost_cache_seq_len(m.h, 1, l) == 32
+    for o in opids:
+        m.forward(o)   # decode attention over the claimed spans (zeros: only checks that every span was there)
+    torch.cuda.synchronize()
+    # a second Alloc without advancing gen_ctx->step: the reference's sanity check (cached length != step)
+    with pytest.raises(hostapi.HostError) as e:
+        m.alloc(opids[0])
+    assert e.value.code == 5
+    # out of spans: a request at the end of its last span
+    m.set_runtime(False, [max_len, 3], kp, vp_)
+    with pytest.raises(hostapi.HostError) as e:
+        m.alloc(opids[1])
+    assert e.value.code == 11  # ALLSPARK_CACHE_MEMORY_OUT
+    m.close()
+
+
+def test_allgather_operator_single_rank_and_row_transpose(env):
+    """AllGatherOp (allgather_op.cpp:27-58,134-163): out = [rows, nranks * n]; one rank = copy.  The rank-major -> row-major
+    transpose behind ncclAllGather is exercised through the C-ABI with a one-rank 'gathered' buffer built by hand."""
+    hostapi, ops = env
+    from dash_infer_amd.capi import check, lib
+    m = hostapi.Model(ops.cur_stream(), 4, 2, 128, 16)
+    x = torch.randn(3, 1, 40, device="cuda").to(torch.bfloat16)
+    m.set_tensor("x", x, "bf16")
+    op = m.create_op("AllGather", "embedding.allgather", ["x"], ["y"])
+    m.reshape(op)
+    m.forward(op)
+    dt, shape, ptr = m.get_tensor("y")
+    assert shape == [3, 1, 40] and torch.equal(view_of(ptr, shape, torch.bfloat16), x)
+    m.close()
+    # the transpose behind the collective: "ranks" x rows x row bytes as ncclAllGather leaves them, 16- / 4- / 1-byte paths
+    for nr, rows, rb in ((4, 5, 24), (8, 3, 256), (2, 7, 5), (8, 1, 7168)):
+        tmp = torch.randint(0, 256, (nr * rows * rb,), dtype=torch.uint8, device="cuda")
+        out = torch.empty_like(tmp)
+        check(lib().dihip_gather_rows_transpose(ops.cur_stream(), ops.ptr(out), ops.ptr(tmp), nr, rows, rb), "gather_rows_transpose")
+        torch.cuda.synchronize()
+        assert torch.equal(out, tmp.view(nr, rows, rb).transpose(0, 1).reshape(-1)), (nr, rows, rb)

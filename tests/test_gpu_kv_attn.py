@@ -276,7 +276,9 @@ def test_span_attention_baseline_shapes(ops, mode, B):
 # ------------------------------------------------- fused Rotary + append + attention (3b) -----
 @pytest.mark.parametrize("mode", ["none", "i8", "u4"])
 @pytest.mark.parametrize("n,g,S,lens", [(28, 4, 128, [2048]), (14, 2, 32, [0, 1, 31, 32, 500]), (8, 8, 16, [77, 300]),
-                                        (32, 2, 64, [1000])])
+                                        (32, 2, 64, [1000]),
+                                        # per-rank head counts of Qwen2-7B at TP = 8 (one KV head, 4 or 3 query heads), small batches
+                                        (4, 1, 16, [0, 3]), (3, 1, 16, [5, 0, 17]), (4, 1, 16, [1, 2, 3, 4]), (3, 1, 128, [2048, 77])])
 def test_fused_rope_append_attention_matches_separate_ops(ops, n, g, S, lens, mode):
     """dihip_span_attn_decode_fused == dihip_rope_kv_append + dihip_span_attn_decode: the spans
     must be BYTE-identical afterwards, the attention output equal to f32-accumulation accuracy;
