@@ -27,8 +27,16 @@ WORKLOADS = {
     "int4_b1":       (4, 128, "none", 1, True),
     "int8_b1":       (8, -1, "none", 1, False),
     "int4_b32_u4kv": (4, 128, "u4", 32, True),
+    # BASELINE configs[3]: ONE RANK'S SHARE of Qwen2-72B int4 g128 at TP = 8 (per-rank shapes of SURVEY 8(a3): 8 query / 1 KV
+    # head, qkv 8192 -> 1280, o 1024 -> 8192, gate/up 8192 -> 3712, down 3712 -> 8192, vocabulary slice 19008; 80 layers),
+    # batch 16, 4096 cached tokens.  The all-reduces are NOT in it (one GPU): it is the rank-local part of the TP = 8 step.
+    "cfg3_rank":     (4, 128, "none", 16, True),
+    # BASELINE configs[4] (decode part): the MoE feed-forward block of Qwen2-57B-A14B -- router, top-8 of 64 int8 experts
+    # (3584 -> 2560 -> 3584), combine -- 16 tokens, 28 layers' expert stacks; attention / shared expert are the dense path
+    "moe_layer":     (8, -1, "none", 16, False),
 }
 SEQ_LEN = 2048
+SEQ_LEN_OF = {"cfg3_rank": 4096}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -181,6 +189,71 @@ def cpu_baseline_torch(wbits, group, seq_len=SEQ_LEN, budget_s=15.0):
                       f"weights dequantised to bf16 as the x86 path holds them (int{wbits} g{group} on the GPU)"}
 
 
+def moe_layer_bench(args, torch, ops):
+    """--workload moe_layer: one "step" = the mixture-of-experts block of all 28 layers for a batch of 16 tokens (each layer
+    its own 64-expert stack: 49 GB, nothing cache-resident).  Algorithmic bytes per layer: every (token, expert) slot streams
+    3 * hidden * width int8 weights + scales unless another slot of the step picked the same expert; counted per distinct
+    expert actually selected by the synthetic router logits."""
+    E, k, hidden, proj, wbits, L, T = 64, 8, 3584, 2560, 8, 28, 16
+    dt = torch.bfloat16
+
+    def experts(N, K):
+        q = torch.randint(-128, 128, (K, N), dtype=torch.int8, device="cuda")
+        s = (torch.rand(1, N, device="cuda") * 0.002 + 0.007).to(dt)
+        z = (torch.rand(1, N, device="cuda") * 4 - 2).to(dt)
+        return ops.pack_experts([q] * E, [s] * E, [z] * E, -1, wbits)
+
+    t0 = time.time()
+    stacks = [(experts(proj, hidden), experts(proj, hidden), experts(hidden, proj)) for _ in range(L)]
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn(T, hidden, device="cuda", generator=gen).to(dt)
+    logits = [torch.randn(T, E, device="cuda", generator=gen).to(dt) for _ in range(L)]
+    ws = torch.empty(int(ops.lib().dihip_moe_workspace_bytes(T, k, hidden, proj)), dtype=torch.uint8, device="cuda")
+    out = torch.empty(T, hidden, dtype=dt, device="cuda")
+    distinct = 0
+    for li in range(L):
+        _, ex = ops.moe_route(logits[li], k)
+        distinct += int(torch.unique(ex).numel())
+    t_build = time.time() - t0
+
+    def step():
+        for li, (g, u, d) in enumerate(stacks):
+            sc, ex = ops.moe_route(logits[li], k)
+            ops.moe_experts(x, ex, sc, g, u, d, ws=ws, out=out)
+
+    step()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        step()
+    for _ in range(args.warmup):
+        gr.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gr.replay()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = elapsed / args.steps * 1e3
+    bytes_step = distinct * (3 * hidden * proj + 2 * (2 * proj + hidden) * 2)  # int8 weights + bf16 (scale, zero) per column
+    gbs = bytes_step / (ms * 1e-3) / 1e9
+    return {
+        "metric": "MoE feed-forward block: tokens/sec through 28 layers (+ achieved HBM GB/s), Qwen2-57B-A14B int8 experts",
+        "value": round(T * args.steps / elapsed, 2), "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic (random int8 expert weights, random router logits)",
+        "config": {"workload": f"Qwen2-57B-A14B moe_layer: router softmax/top-{k} + {E} int8 per-channel experts ({hidden}->{proj}->{hidden}) + "
+                               f"combine, {T} tokens, {L} layers' expert stacks (attention, shared expert and the TP all-reduce are "
+                               "not in this workload), hipGraph=on", "global_batch": T, "parallelism": "tp1", "layers": L},
+        "step_hbm": {"algorithmic_bytes_per_rank": int(bytes_step), "achieved_GBps_per_gpu": round(gbs, 1),
+                     "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4), "distinct_experts_per_step": distinct},
+        "roofline": {"bound": "hbm", "kernel": "dihip::gemv_stream_kernel<8, 2, 1, 0, *, 0, true> (expert GEMVs over (token, expert) slots)",
+                     "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                     "traffic": None, "note": "whole-block figure: route + gate/up + down + combine launches"},
+        "build_s": round(t_build, 1),
+    }
+
+
 def kernel_breakdown(sess, torch, ops, iters=5):
     """Average launch duration of every hot-path kernel: the launches of all layers (each layer its
     own weights: 1.9+ GB per sweep, far beyond the 256 MB Infinity Cache) are captured into one
@@ -277,7 +350,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--workload", default="int4_b1", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="int4_b1", choices=list(WORKLOADS))  # int4_b1 = the headline configuration
     ap.add_argument("--layers", type=int, default=None, help="debug: fewer decoder layers (result marked invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="debug: eager launches instead of hipGraph replay")
@@ -299,10 +372,22 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        comm = decoder.make_comm(rank, world, torch.device("cuda", local_rank))
+        comm = decoder.make_comm(rank, world, torch.device("cuda", local_rank), allow_labelled_fallback=True)
 
     wbits, group, kv_mode, batch, gptq = WORKLOADS[args.workload]
+    if args.workload == "moe_layer":
+        assert world == 1, "moe_layer is a one-GPU workload"
+        out = moe_layer_bench(args, torch, ops)
+        print(json.dumps(out), flush=True)
+        return
+    global SEQ_LEN
+    SEQ_LEN = SEQ_LEN_OF.get(args.workload, SEQ_LEN)
     cfg = decoder.QWEN2_7B
+    model_name = "Qwen2-7B"
+    if args.workload == "cfg3_rank":
+        assert world == 1, "cfg3_rank times ONE rank's share of the TP = 8 step on one GPU (use --gpus 1)"
+        cfg = decoder.ModelConfig("Qwen2-72B/TP8-rank", hidden=8192, layers=80, n_heads=8, n_kv=1, head_dim=128, inter=3712, vocab=19008)
+        model_name = "Qwen2-72B (rank-local share of TP=8: all-reduce excluded)"
     spec = decoder.QuantSpec(wbits, group, gptq_like_zeros=gptq)
     t_build = time.time()
     model = decoder.build_random_model(cfg, spec, seed=1234, rank=rank, nranks=world, layers=args.layers)
@@ -358,7 +443,7 @@ def main():
     step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
 
     out = {
-        "metric": "decode tokens/sec (whole job) + achieved HBM GB/s, Qwen2-7B weight-only quantized decode",
+        "metric": f"decode tokens/sec (whole job) + achieved HBM GB/s, {model_name} weight-only quantized decode",
         "value": round(tokens_per_s, 2),
         "unit": "tokens/s",
         "n_gpus": world,
@@ -369,8 +454,8 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "bf16",
-        "data": "synthetic (random-init InstantQuant weights of the Qwen2-7B architecture, random 2048-token KV history)",
-        "config": {"workload": f"Qwen2-7B {args.workload}: int{wbits} weight-only group {group}, KV {kv_mode}, batch {batch}, "
+        "data": f"synthetic (random-init InstantQuant weights of the {cfg.name} shapes, random {SEQ_LEN}-token KV history)",
+        "config": {"workload": f"{model_name} {args.workload}: int{wbits} weight-only group {group}, KV {kv_mode}, batch {batch}, "
                                f"seq {SEQ_LEN}, TP={world}, greedy, hipGraph={'on' if graph_on else 'off'}, "
                                f"{max(1, args.steps_per_graph)} steps per graph",
                    "global_batch": batch, "seq_len": SEQ_LEN, "parallelism": f"tp{world}",
@@ -406,7 +491,7 @@ def main():
             out["kernels"] = kb
         except Exception as e:  # never lose the headline number to the breakdown
             out["roofline_error"] = repr(e)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload in ("int4_b1", "int8_b1", "int4_b32_u4kv"):  # the CPU graph below is Qwen2-7B's
             try:
                 out["cpu_baseline"] = cpu_baseline_torch(wbits, group)
             except Exception as e:

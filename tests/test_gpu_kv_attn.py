@@ -428,3 +428,45 @@ def test_attention_partials_merged_by_the_o_projection(ops, n, g, S, lens, wbits
     want0 = ops.fused_gemm_addto(merged, pw, None, sc, M=B)
     got0 = ops.fused_attnmerge_gemm_addto(partials, ns, n, pw, None, sc, M=B)
     assert torch.equal(want0, got0)
+
+
+# ------------------------------------------------------------- long contexts (reference: up to 128 000 tokens) -----
+def _random_span_bytes(rng, nspans, g, S, H, mode):
+    """Span images with plausible contents written directly (a Python codec loop over 131 072 tokens would take minutes):
+    16-bit cache: K, V ~ N(0, 1) in bf16; quantised: uniform codes with per-token-head (zero, scale) in the codec's range."""
+    if mode == "none":
+        from oracle.numerics import bf16_bits
+        x = bf16_round(rng.normal(0, 1, (nspans, g * S * H)).astype(np.float32))
+        return np.ascontiguousarray(bf16_bits(x)).view(np.uint8).reshape(nspans, -1)
+    hb = H if mode == "i8" else H // 2
+    data = rng.integers(0, 256, (nspans, g * S * hb), dtype=np.uint8)
+    params = np.empty((nspans, g * S, 2), np.float32)
+    params[..., 0] = np.rint(rng.uniform(-20, 20, (nspans, g * S))) if mode == "i8" else np.rint(rng.uniform(4, 11, (nspans, g * S)))
+    params[..., 1] = rng.uniform(0.01, 0.03, (nspans, g * S)) if mode == "i8" else rng.uniform(0.15, 0.35, (nspans, g * S))
+    return np.concatenate([data, params.reshape(nspans, -1).view(np.uint8)], axis=1)
+
+
+@pytest.mark.parametrize("mode", ["none", "i8", "u4"])
+@pytest.mark.parametrize("L", [16385, 32768, 131072])
+def test_span_attention_long_context(ops, L, mode):
+    """One request at 16 385 / 32 768 / 131 072 tokens (span-attention/test/test_lib/test_quant_none.cpp:935-940 runs to
+    128 000; beyond 16 k the reference switches to its tiled multi-CTA softmax, tiled_softmax.cuh:27-126 -- here the split
+    count grows to the 256-split cap instead), all three cache modes, against the plain-C oracle over the same span bytes."""
+    rng = np.random.default_rng(L % 1000 + len(mode))
+    n, g, H, S, ft = 8, 2, 128, 128, "bf16"
+    nspans = (L + S - 1) // S
+    pool = ops.SpanPool(2 * nspans + 3, g, S, H, mode, TD[ft])
+    kv = ops.KVCacheSet(pool, 1, nspans)
+    kv.ensure(0, L)
+    kb, vb = _random_span_bytes(rng, nspans, g, S, H, mode), _random_span_bytes(rng, nspans, g, S, H, mode)
+    assert kb.shape[1] == pool.nbytes
+    for i in range(nspans):
+        pool.span_view(kv.k_idx[0][i]).copy_(torch.from_numpy(kb[i]))
+        pool.span_view(kv.v_idx[0][i]).copy_(torch.from_numpy(vb[i]))
+    kv.sync()
+    q = bf16_round(rng.normal(0, 1, (1, n, H)).astype(np.float32))
+    scale = 1.0 / np.sqrt(H)
+    out = run_attn(ops, kv, q, [L], n, g, H, ft, scale)
+    ref = cbind.span_attn_decode(q[0], [kb[i] for i in range(nspans)], [vb[i] for i in range(nspans)], L, n, g, H, S, mode, ft, scale)
+    # averaging 10^5 random rows leaves outputs of 1e-2 ... 2e-1: the bound is relative to the output scale
+    np.testing.assert_allclose(out[0], ref, rtol=2e-2, atol=1e-2 * float(np.abs(ref).max()))
