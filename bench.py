@@ -296,14 +296,12 @@ def kernel_breakdown(sess, torch, ops, iters=5):
     timed("qkv_norm_gemv", l0.qkv.nbytes + act_b(l0.qkv),
           lambda li, lw: ops.fused_norm_gemm(sess.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sc, out=sess.qkv))
     kvb = {"none": sess.H * 2, "i8": sess.H + 8, "u4": sess.H // 2 + 8}[sess.kv_mode]
-    if getattr(sess, "attn_nsplits", 0):
-        # the decode-step pair as the step runs it: partials-only attention, merge folded into the o-projection's prologue
-        timed("rope_append_span_attention_partials", B * 2 * sess.g_loc * SEQ_LEN * kvb,
-              lambda li, lw: ops.span_attn_decode_fused_partials(sess.qkv, sess.kv[li], sess.old_lens, sess.rope_tab, sess.n_loc,
-                                                                 sess.g_loc, sess.H, sess.max_len, sess.scale, sess.attn_partials))
-        timed("o_gemv_attnmerge_addto", l0.o.nbytes + sess.attn_partials.numel() * 4 + B * l0.o.N * 4,
-              lambda li, lw: ops.fused_attnmerge_gemm_addto(sess.attn_partials, sess.attn_nsplits, sess.n_loc, lw.o, sess.h, sc,
-                                                            out=sess.partial, M=B))
+    if getattr(sess, "front", False):
+        # the front half as the step runs it: RMSNorm + qkv GEMV + Rotary + append + attention in one launch, + the split merge
+        timed("front_qkv_attention", l0.qkv.nbytes + act_b(l0.qkv) + B * 2 * sess.g_loc * SEQ_LEN * kvb,
+              lambda li, lw: ops.decode_front(sess.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sess.kv[li], sess.old_lens, sess.rope_tab,
+                                              sess.n_loc, sess.g_loc, sess.H, sess.max_len, sess.scale, sess.front_ws, sess.front_sync,
+                                              sess.qkv, sess.attn))
     if sess.fused_attention:
         timed("rope_append_span_attention", B * 2 * sess.g_loc * SEQ_LEN * kvb,
               lambda li, lw: ops.span_attn_decode_fused(sess.qkv, sess.kv[li], sess.old_lens, sess.rope_tab, sess.n_loc, sess.g_loc,

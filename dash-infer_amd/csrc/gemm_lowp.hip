@@ -229,9 +229,6 @@ struct GemmCall {
   size_t ws_bytes;
   void* sync;
   int x_layout, y_layout;  // DIHIP_ACT_ROWMAJOR / DIHIP_ACT_FRAG32 (small-batch kernel only)
-  // PRO_ATTNMERGE: the activation rows are merged from the decode attention's split partials (x unused)
-  const float* ap;
-  int ap_nsplits, ap_heads;
   // EPI_ADDTO: RMSNorm of the finished rows wanted in n_out (dihip_fused_gemm_addto_norm); *n_done is set when the kernel
   // family that served the call has produced it (split-K slab reduction), otherwise the caller runs the norm kernel
   const void* n_gamma;
@@ -331,8 +328,6 @@ static hipError_t dispatch_gemv(const GemvPlan& p, int pro, int epi, const GemvA
   CASE(4, PRO_PLAIN, EPI_ADDTO)
   CASE(1, PRO_RMSNORM, EPI_ADDTO)
   CASE(4, PRO_RMSNORM, EPI_ADDTO)
-  CASE(1, PRO_ATTNMERGE, EPI_ADDTO)
-  CASE(4, PRO_ATTNMERGE, EPI_ADDTO)
 #undef CASE
   return hipErrorInvalidValue;
 }
@@ -495,6 +490,50 @@ int run_gemv_slots(hipStream_t stream, int wbits, int epi, const void* x, int ld
   return DIHIP_SUCCESS;
 }
 
+// GemvArgs + launch geometry of the fused RMSNorm + qkv GEMV as the decode GEMV would run it (decode_front.hip builds its
+// fused launch from it); false when the call is not served by gemv_stream_kernel (M > 4, odd alignment, ...)
+bool gemv_front_plan(int wbits, const float* h, const void* gamma, float eps, const void* w_packed, const void* sz_packed,
+                     const void* bias, void* y, int M, int N, int K, int group_size, GemvArgs* g_out, int* blocks, size_t* lds_bytes,
+                     int* mr, int* gpt) {
+  if (!gemv_stream_enabled() || wbits == 16 || M < 1) return false;
+  const LowpDims d = lowp_dims(wbits, N, K, group_size);
+  if (K != d.Kp || K % 8 != 0 || (reinterpret_cast<uintptr_t>(h) % 16) || (reinterpret_cast<uintptr_t>(gamma) % 16)) return false;
+  const GemvPlan gp = make_gemv_plan(wbits, M, N, K, group_size, false);
+  if (!gp.ok) return false;
+  GemvArgs g{};
+  g.w0 = reinterpret_cast<const u32x4_t*>(w_packed);
+  g.sz0 = reinterpret_cast<const uint32_t*>(sz_packed);
+  g.x = h;
+  g.ldx = K;
+  g.gamma = gamma;
+  g.eps = eps;
+  g.bias = bias;
+  g.y = y;
+  g.ldy = N;
+  g.alpha = 1.f;
+  g.act = DIHIP_ACT_NONE;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.KT = d.KT;
+  g.NTILES = d.NTILES;
+  g.Gp = lowp_dims(4, N, K, group_size).Gp;
+  g.ktpg = gp.ktpg;
+  g.kgroups = gp.kgroups;
+  g.upb = gp.upb;
+  g.nu_q = d.NTILES / gp.blocks;
+  g.nu_r = d.NTILES % gp.blocks;
+  g.WK = gp.WK;
+  g.WN = gp.WN;
+  g.RS = gp.RS;
+  *g_out = g;
+  *blocks = gp.blocks;
+  *lds_bytes = gp.lds_bytes;
+  *mr = gp.MR;
+  *gpt = gp.ktpg == 1 ? 1 : 0;
+  return true;
+}
+
 static int run_gemm(hipStream_t stream, const GemmCall& c) {
   DIHIP_REQUIRE(c.M >= 0 && c.N > 0 && c.K > 0, DIHIP_PARAM_ERROR, "gemm_lowp: bad shape M=%d N=%d K=%d",
                 c.M, c.N, c.K);
@@ -503,7 +542,7 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
                 "gemm_lowp: activation type must be FLOAT16 or BFLOAT16 (gemm_a16w8.cpp:21-125)");
   DIHIP_REQUIRE(c.group_size <= 0 || c.group_size % 32 == 0, DIHIP_PARAM_ERROR,
                 "gemm_lowp: GroupSize %d must be a multiple of 32", c.group_size);
-  DIHIP_REQUIRE((c.x || c.pro == PRO_ATTNMERGE) && c.w0 && (c.sz0 || c.wbits == 16), DIHIP_PARAM_ERROR, "gemm_lowp: null input pointer");
+  DIHIP_REQUIRE(c.x && c.w0 && (c.sz0 || c.wbits == 16), DIHIP_PARAM_ERROR, "gemm_lowp: null input pointer");
   const bool dual = c.epi == EPI_SWIGLU;
   const LowpDims d = lowp_dims(c.wbits, c.N, c.K, c.group_size);
   const bool gemv_aligned = (c.K == d.Kp) && (c.ldx % 8 == 0) && (reinterpret_cast<uintptr_t>(c.x) % 16 == 0) &&
@@ -544,9 +583,6 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
       g.WK = gp.WK;
       g.WN = gp.WN;
       g.RS = gp.RS;
-      g.ap = c.ap;
-      g.ap_nsplits = c.ap_nsplits;
-      g.ap_heads = c.ap_heads;
       g.trace = debug_trace_buffer((size_t)gp.blocks * GEMV_WAVES * 64);
       hipError_t e = hipErrorInvalidValue;
       if (f16_std) e = c.wbits == 4 ? dispatch_gemv_f16<4>(gp, g, stream) : dispatch_gemv_f16<8>(gp, g, stream);
@@ -558,8 +594,6 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
       return DIHIP_SUCCESS;
     }
   }
-  DIHIP_REQUIRE(c.pro != PRO_ATTNMERGE, DIHIP_PARAM_ERROR,
-                "gemm_lowp: the attention-merge prologue is served by the decode GEMV only (M <= 4, K %% k-tile == 0; M=%d K=%d)", c.M, c.K);
   // batched decode with FRAG32 activations: panels of 8 column tiles sharing x through LDS (gemm_panel_kernel.hpp)
   if (c.dtype == DIHIP_BF16 && gemv_stream_enabled() && c.x_layout == DIHIP_ACT_FRAG32 && c.pro == PRO_PLAIN && c.M > 4 &&
       c.M <= 32 && c.wbits != 16 && c.K == d.Kp && (d.group == 0 || d.group % d.KTILE == 0)) {
@@ -1164,40 +1198,6 @@ int dihip_fused_gemm_addto_ex(void* stream, int wbits, const void* x, const void
   c.x = x;
   c.ldx = K;
   c.x_layout = x_layout;
-  c.w0 = w_packed;
-  c.sz0 = sz_packed;
-  c.h_res = h_res;
-  c.h_out = h_out;
-  c.M = M;
-  c.N = N;
-  c.K = K;
-  c.group_size = group_size;
-  c.alpha = 1.f;
-  c.ws = ws;
-  c.ws_bytes = ws_bytes;
-  c.sync = sync;
-  return run_gemm(reinterpret_cast<hipStream_t>(stream), c);
-}
-
-int dihip_fused_attnmerge_gemm_addto(void* stream, int wbits, const float* attn_partials, int nsplits, int n_heads,
-                                     const void* w_packed, const void* sz_packed, const float* h_res, float* h_out, int M,
-                                     int N, int K, int group_size, void* ws, size_t ws_bytes, void* sync, int dtype) {
-  DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "fused path is bf16 only");
-  DIHIP_REQUIRE(attn_partials && h_out && sync, DIHIP_PARAM_ERROR, "attnmerge addto: null pointer");
-  DIHIP_REQUIRE(n_heads > 0 && K == n_heads * 128, DIHIP_PARAM_ERROR, "attnmerge addto: K %d != heads %d x 128", K, n_heads);
-  DIHIP_REQUIRE(nsplits >= 1 && nsplits <= GEMV_AP_SPLITS, DIHIP_PARAM_ERROR, "attnmerge addto: %d splits (1..%d)", nsplits,
-                GEMV_AP_SPLITS);
-  DIHIP_REQUIRE(M >= 0 && M <= 4, DIHIP_PARAM_ERROR, "attnmerge addto: M %d > 4 (decode-step form)", M);
-  GemmCall c{};
-  c.wbits = wbits;
-  c.dtype = dtype;
-  c.pro = PRO_ATTNMERGE;
-  c.epi = EPI_ADDTO;
-  c.x = nullptr;
-  c.ldx = K;
-  c.ap = attn_partials;
-  c.ap_nsplits = nsplits;
-  c.ap_heads = n_heads;
   c.w0 = w_packed;
   c.sz0 = sz_packed;
   c.h_res = h_res;

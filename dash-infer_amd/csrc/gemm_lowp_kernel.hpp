@@ -31,7 +31,7 @@
 
 namespace dihip {
 
-enum { PRO_PLAIN = 0, PRO_RMSNORM = 1, PRO_ATTNMERGE = 2 };  // ATTNMERGE (gemv_stream_kernel only): x = merge of the decode attention's split partials
+enum { PRO_PLAIN = 0, PRO_RMSNORM = 1 };
 enum { EPI_STD = 0, EPI_SWIGLU = 1, EPI_ADDTO = 2 };
 
 constexpr int GEMM_THREADS = 256;

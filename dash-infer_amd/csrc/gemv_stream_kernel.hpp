@@ -52,9 +52,6 @@ __device__ __forceinline__ void stream_load_b32(uint32_t& dst, const void* sbase
 __device__ __forceinline__ void stream_load_plain_b128(u32x4_t& dst, const void* sbase, uint32_t voff) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase));
 }
-__device__ __forceinline__ void stream_load_plain_b64(u32x2_t& dst, const void* sbase, uint32_t voff) {
-  asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase));
-}
 // pins a wave-uniform pointer into SGPRs (folds away when it already lives there): the ring loads take their base
 // through an "s" constraint, and hipcc occasionally carries a uniform address computation on the VALU
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {
@@ -76,14 +73,7 @@ __device__ __forceinline__ void stream_landed(u32x4_t& w, uint32_t& s) { asm vol
 // vmcnt (loads return in order: a compiler-visible load issued after the ring would only be
 // usable once the whole ring has landed, serialising prologue and first HBM round trip).
 __device__ __forceinline__ void early_landed(u32x4_t& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void early_landed(u32x2_t& v) { asm volatile("" : "+v"(v)); }
 
-// PRO_ATTNMERGE: the activation row is the decode attention's output, taken straight from the split partials the
-// attention kernel left ([M * heads][nsplits][GEMV_AP_STRIDE] f32 records: o[128], m, l -- span_attn_common.hpp) and
-// combined here with the arithmetic of span_attn_split_merge_kernel (same order, same rounding: the merged row is
-// bit-identical to that kernel's output), so the merge launch between attention and o-projection disappears.
-constexpr int GEMV_AP_STRIDE = 132;  // == ATTN_PSTRIDE
-constexpr int GEMV_AP_SPLITS = 8;    // split slots loaded per vector (the attention plan of this form caps its splits here)
 
 // W4 expansion for the GEMV: pair I of a dword is (d >> 4I) & 0x000F000F; OR-ing the exponent of
 // 128.0 (bf16) gives OFFSET + q exactly in both halves.  mask / magic are passed as
@@ -136,9 +126,9 @@ struct GemvArgs {
   size_t w_estride, sz_estride;  // u32x4 / u32 elements between consecutive experts' packed tensors
   int x_div;                     // activation row of slot s = s / x_div
   int nslots;
-  // PRO_ATTNMERGE: x is unused; K == ap_heads * 128
-  const float* ap;  // attention split partials [M * ap_heads][ap_nsplits][GEMV_AP_STRIDE]
-  int ap_nsplits, ap_heads;
+  // PUB (fused decode-step launch): publication counters and the head geometry that maps a column tile to its KV group
+  unsigned* front_counter;
+  int front_n, front_g, front_hpg;
   int WK, WN;  // wave grid inside the workgroup, WK * WN == GEMV_WAVES, both powers of two (SwiGLU: WN >= 2)
   int RS;      // LDS activation row stride in elements (KT * KTILE + 8)
   unsigned long long* trace;  // diagnostics (dihip_debug_set_trace): [block][wave][8] wall-clock stamps, or null
@@ -155,8 +145,19 @@ __host__ __device__ inline size_t gemv_lds_bytes(int rows, int RS, int KT, int u
 // GPT: every k-tile is one quantisation group (W4 g128, W8 g64): no accumulator carry between chunks
 // SLOT (mixture-of-experts): gridDim.y enumerates (token, expert-rank) slots; slot s streams the weights of expert
 // slot_expert[s] (all experts have one shape: base + expert * stride), reads activation row s / x_div and writes row s.
-template <int WBITS, int FT, int MR, int PRO, int EPI, int GPT, bool SLOT = false>
-__global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArgs a) {
+// PUB (decode_front.hip): this GEMV produces the fused qkv row for attention workgroups of the SAME launch: the row is stored
+// write-through (agent scope) and, once a workgroup's stores have left, it adds its column tiles to the publication counter
+// of the KV group(s) they belong to (a.front_counter[m * front_g + group], one count per 16-column tile and row).
+template <int FT>
+__device__ __forceinline__ void store_ft_wt(void* p, size_t i, float v) {  // FT store that another CU may read in this launch
+  static_assert(FT == DIHIP_BF16 || FT == DIHIP_F16, "16-bit rows");
+  unsigned short* q = reinterpret_cast<unsigned short*>(p) + i;
+  const unsigned bits = f32_to_ft_bits<FT>(v);
+  asm volatile("global_store_short %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(q), "v"(bits) : "memory");
+}
+
+template <int WBITS, int FT, int MR, int PRO, int EPI, int GPT, bool SLOT = false, bool PUB = false>
+__device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bid, const int nblocks, unsigned char* smem) {
   // the tensors of this launch (SLOT: of this slot's expert / activation row); everything else is read from `a`
   const u32x4_t* p_w0 = a.w0;
   const u32x4_t* p_w1 = a.w1;
@@ -184,7 +185,6 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
   constexpr int D = GEMV_RING;
   constexpr int LPC = QUANT ? 2 : 1;  // loads per chunk
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int rows = MR == 1 ? 1 : a.M;  // <= 16
   uint16_t* xs = reinterpret_cast<uint16_t*>(smem + 256);
   float* xsum_tab = reinterpret_cast<float*>(smem + 256 + gemv_xs_bytes(rows, a.RS));
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
   do {                                                                                             \
     /* every lane stores the same value to the same slot: a wave-uniform branch only (a divergent `lane == 0` branch */ \
     /* makes hipcc carry the ring pointers through VGPRs across it, which the "s" operands of the asm loads reject) */  \
-    if (a.trace) a.trace[((size_t)blockIdx.x * GEMV_WAVES + wave) * 8 + (I)] = wall_clock64();                    \
+    if (a.trace) a.trace[((size_t)bid * GEMV_WAVES + wave) * 8 + (I)] = wall_clock64();                           \
   } while (0)
 #else
 #define DIHIP_GEMV_STAMP(I) do { } while (0)
@@ -217,16 +217,22 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
   // Every thread owns 8-element vectors i = j*THREADS + tid of a row (k = 8i): PRO_PLAIN loads 16
   // bytes of x, PRO_RMSNORM 2 x 16 bytes of the f32 hidden stream + 16 bytes of gamma.  Vector
   // indices beyond the row are clamped (harmless reload) instead of predicated.
+  // `ev` / `eg` hold ONLY the batch issued here, ahead of the ring fill (row 0, vectors 0 ..): written by this asm, read after
+  // the wait in the prologue, never assigned again.  (They used to be re-loaded for the later rows: two definitions make a
+  // phi, the compiler resolves a phi with register copies wherever it likes -- it put them BEFORE the wait, and row 0 of a
+  // batch was now and then read before it had landed.  tools/audit_asm_loads.py checks the build for this.)
+  // Every later batch (rows > 0, rows longer than one batch) uses fetch_batch: loads the compiler tracks itself.
   const int Kp = a.KT * KTILE;  // == K (host contract)
   const int nvec = Kp >> 3;
   constexpr int NE = PRO == PRO_RMSNORM ? 2 : 8;  // vectors per thread per batch
-  u32x4_t ev[PRO == PRO_RMSNORM ? 2 * NE : NE];
-  u32x4_t eg[PRO == PRO_RMSNORM ? NE : 1];
-  auto issue_batch = [&](int r, int v0) {
+  constexpr int NV = PRO == PRO_RMSNORM ? 2 * NE : NE, NG = PRO == PRO_RMSNORM ? NE : 1;
+  u32x4_t ev[NV];
+  u32x4_t eg[NG];
+  {
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
       // sub-batches entirely beyond the row are skipped (wave-uniform); a partial one is clamped
-      if (j > 0 && v0 + j * GEMV_THREADS >= nvec) {
+      if (j > 0 && j * GEMV_THREADS >= nvec) {
         ev[PRO == PRO_RMSNORM ? 2 * j : j] = u32x4_t{0u, 0u, 0u, 0u};
         if constexpr (PRO == PRO_RMSNORM) {
           ev[2 * j + 1] = u32x4_t{0u, 0u, 0u, 0u};
@@ -234,51 +240,45 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
         }
         continue;
       }
-      const uint32_t i = (uint32_t)min(v0 + j * GEMV_THREADS + tid, nvec - 1);
+      const uint32_t i = (uint32_t)min(j * GEMV_THREADS + tid, nvec - 1);
       if constexpr (PRO == PRO_RMSNORM) {
-        const float* hrow = reinterpret_cast<const float*>(p_x) + (size_t)r * a.ldx;
-        stream_load_plain_b128(ev[2 * j], hrow, i * 32u);
-        stream_load_plain_b128(ev[2 * j + 1], hrow, i * 32u + 16u);
+        stream_load_plain_b128(ev[2 * j], p_x, i * 32u);
+        stream_load_plain_b128(ev[2 * j + 1], p_x, i * 32u + 16u);
         stream_load_plain_b128(eg[j], a.gamma, i * 16u);
       } else {
-        stream_load_plain_b128(ev[j], reinterpret_cast<const uint16_t*>(p_x) + (size_t)r * a.ldx, i * 16u);
+        stream_load_plain_b128(ev[j], p_x, i * 16u);
       }
     }
-  };
-  constexpr int EARLY_LOADS = PRO == PRO_RMSNORM ? 3 * NE : NE;
-  // PRO_ATTNMERGE: one vector (8 dims of one head) per thread and batch: 2 x 16 bytes of o + {m, l} per split slot.
-  // Slots beyond ap_nsplits re-read the last split (uniform load count) and are neutralised in the merge.
-  constexpr int AMS = GEMV_AP_SPLITS;
-  u32x4_t am_o[PRO == PRO_ATTNMERGE ? 2 * AMS : 1];
-  u32x2_t am_ml[PRO == PRO_ATTNMERGE ? AMS : 1];
-  auto issue_merge_batch = [&](int r, int v0) {
-    if constexpr (PRO == PRO_ATTNMERGE) {
-      constexpr uint32_t RECB = GEMV_AP_STRIDE * 4u;  // bytes per record
-      const uint32_t i = (uint32_t)min(v0 + tid, nvec - 1);
-      const uint32_t rec0 = ((uint32_t)(r * a.ap_heads) + (i >> 4)) * (uint32_t)a.ap_nsplits * RECB;
-      const uint32_t dof = (i & 15u) * 32u;
-      // the clamp lives in a VGPR on purpose (opaque to the scalariser): eight s_min + address pairs would push this
-      // instantiation over the SGPR budget, after which hipcc parks wave-uniform ring pointers in VGPRs
-      uint32_t lim = (uint32_t)(a.ap_nsplits - 1) * RECB;
-      asm volatile("" : "+v"(lim));
+  }
+  auto fetch_batch = [&](int r, int v0, u32x4_t (&V)[NV], u32x4_t (&G)[NG]) {
 #pragma unroll
-      for (int sp = 0; sp < AMS; ++sp) {
-        const uint32_t off = rec0 + min((uint32_t)sp * RECB, lim);
-        stream_load_plain_b128(am_o[2 * sp], a.ap, off + dof);
-        stream_load_plain_b128(am_o[2 * sp + 1], a.ap, off + dof + 16u);
-        stream_load_plain_b64(am_ml[sp], a.ap, off + 512u);
+    for (int j = 0; j < NE; ++j) {
+      if (j > 0 && v0 + j * GEMV_THREADS >= nvec) {
+        V[PRO == PRO_RMSNORM ? 2 * j : j] = u32x4_t{0u, 0u, 0u, 0u};
+        if constexpr (PRO == PRO_RMSNORM) {
+          V[2 * j + 1] = u32x4_t{0u, 0u, 0u, 0u};
+          G[j] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+        continue;
+      }
+      const size_t i = (size_t)min(v0 + j * GEMV_THREADS + tid, nvec - 1);
+      if constexpr (PRO == PRO_RMSNORM) {
+        const u32x4_t* hrow = reinterpret_cast<const u32x4_t*>(reinterpret_cast<const float*>(p_x) + (size_t)r * a.ldx);
+        V[2 * j] = hrow[2 * i];
+        V[2 * j + 1] = hrow[2 * i + 1];
+        G[j] = reinterpret_cast<const u32x4_t*>(a.gamma)[i];
+      } else {
+        V[j] = reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(p_x) + (size_t)r * a.ldx)[i];
       }
     }
   };
-  if constexpr (PRO == PRO_ATTNMERGE) issue_merge_batch(0, 0);
-  else issue_batch(0, 0);
   DIHIP_GEMV_STAMP(7);
 
   // ---- this workgroup's units and this wave's share ---------------------------------------
   // units are dealt round-robin: workgroup b owns units b, b + NB, b + 2*NB, ... (SwiGLU: (gate, up) tile
   // pairs), which spreads every workgroup's address range over the whole matrix
-  const int NB = gridDim.x;
-  const int u0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x);  // pinned scalar: see uniform_ptr
+  const int NB = nblocks;
+  const int u0 = __builtin_amdgcn_readfirstlane(bid);  // pinned scalar: see uniform_ptr
   const int nu = a.nu_q + (u0 < a.nu_r ? 1 : 0);  // (NTILES - u0 + NB - 1) / NB without a device-side division
   const int nv = nu * DUAL;                  // half-units (one weight tile each)
   // K split in whole quantisation groups (per-channel: any k-tile boundary)
@@ -377,33 +377,52 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
       if ((i & (KTILE / 8 - 1)) == 0) xsum_tab[(i / (KTILE / 8)) * 16 + r] = sum;
     }
   };
-  for (int r = 0; r < rows; ++r) {
-    if constexpr (PRO == PRO_RMSNORM) {
-      // LayerNormNoBeta of the f32 hidden stream (csrc/core/kernel/cpu/layernorm.cpp:110-157):
-      // rstd = 1/sqrt(mean(x^2)+eps); x_norm = FT((gamma*x)*rstd)
-      float ss = 0.f;
-      for (int v0 = 0; v0 < nvec; v0 += NE * GEMV_THREADS) {
-        if (r > 0 || v0 > 0) {
-          issue_batch(r, v0);
-          stream_wait<0>();
-        } else {
-          stream_wait<D * LPC>();  // everything older than the ring fill has landed
+  stream_wait<D * LPC>();  // everything older than the ring fill has landed: the early batch
+#pragma unroll
+  for (int j = 0; j < NV; ++j) early_landed(ev[j]);
+#pragma unroll
+  for (int j = 0; j < NG; ++j) early_landed(eg[j]);
+  DIHIP_GEMV_STAMP(2);
+  if constexpr (PRO == PRO_RMSNORM) {
+    // LayerNormNoBeta of the f32 hidden stream (csrc/core/kernel/cpu/layernorm.cpp:110-157):
+    // rstd = 1/sqrt(mean(x^2)+eps); x_norm = FT((gamma*x)*rstd)
+    auto sumsq = [&](int v0, const u32x4_t (&V)[NV], float ss) {
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        if (v0 + j * GEMV_THREADS + tid < nvec) {
+          const f32x4_t h0 = __builtin_bit_cast(f32x4_t, V[2 * j]), h1 = __builtin_bit_cast(f32x4_t, V[2 * j + 1]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ss = fmaf(h0[q], h0[q], ss);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ss = fmaf(h1[q], h1[q], ss);
         }
+      }
+      return ss;
+    };
+    auto norm_stage = [&](int r, int v0, const u32x4_t (&V)[NV], const u32x4_t (&G)[NG], float rstd) {
 #pragma unroll
-        for (int j = 0; j < 2 * NE; ++j) early_landed(ev[j]);
+      for (int j = 0; j < NE; ++j) {
+        const int i = v0 + j * GEMV_THREADS + tid;
+        if (i < nvec) {
+          const f32x4_t h0 = __builtin_bit_cast(f32x4_t, V[2 * j]), h1 = __builtin_bit_cast(f32x4_t, V[2 * j + 1]);
+          u32x4_t o;
 #pragma unroll
-        for (int j = 0; j < NE; ++j) early_landed(eg[j]);
-        if (r == 0 && v0 == 0) DIHIP_GEMV_STAMP(2);
-#pragma unroll
-        for (int j = 0; j < NE; ++j) {
-          if (v0 + j * GEMV_THREADS + tid < nvec) {
-            const f32x4_t h0 = __builtin_bit_cast(f32x4_t, ev[2 * j]), h1 = __builtin_bit_cast(f32x4_t, ev[2 * j + 1]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ss = fmaf(h0[q], h0[q], ss);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ss = fmaf(h1[q], h1[q], ss);
+          for (int q = 0; q < 4; ++q) {
+            const float ga = ft_bits_to_f32<FT>(G[j][q] & 0xFFFFu), gb = ft_bits_to_f32<FT>(G[j][q] >> 16);
+            const float xa = q < 2 ? h0[2 * q] : h1[2 * q - 4], xb = q < 2 ? h0[2 * q + 1] : h1[2 * q - 3];
+            o[q] = f32_to_ft_bits<FT>((ga * xa) * rstd) | (f32_to_ft_bits<FT>((gb * xb) * rstd) << 16);
           }
+          stage_vector(r, i, o);
         }
+      }
+    };
+    // V / G: the first batch of row r, landed; later batches of a long row are fetched (twice: sum, then normalise)
+    auto rms_row = [&](int r, const u32x4_t (&V)[NV], const u32x4_t (&G)[NG]) {
+      u32x4_t tv[NV], tg[NG];
+      float ss = sumsq(0, V, 0.f);
+      for (int v0 = NE * GEMV_THREADS; v0 < nvec; v0 += NE * GEMV_THREADS) {
+        fetch_batch(r, v0, tv, tg);
+        ss = sumsq(v0, tv, ss);
       }
       ss = wave_sum(ss);
       if (r > 0) __syncthreads();  // previous row's readers of `red` are done
@@ -413,115 +432,42 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
 #pragma unroll
       for (int w = 0; w < GEMV_WAVES; ++w) tot_ss += red[w];
       const float rstd = 1.f / sqrtf(tot_ss / (float)a.K + a.eps);
-      for (int v0 = 0; v0 < nvec; v0 += NE * GEMV_THREADS) {
-        if (nvec > NE * GEMV_THREADS) {  // multi-batch rows: fetch again (single-batch rows still hold their vectors)
-          issue_batch(r, v0);
-          stream_wait<0>();
+      norm_stage(r, 0, V, G, rstd);
+      for (int v0 = NE * GEMV_THREADS; v0 < nvec; v0 += NE * GEMV_THREADS) {
+        fetch_batch(r, v0, tv, tg);
+        norm_stage(r, v0, tv, tg, rstd);
+      }
+    };
+    rms_row(0, ev, eg);
+    for (int r = 1; r < rows; ++r) {
+      u32x4_t lv[NV], lg[NG];
+      fetch_batch(r, 0, lv, lg);
+      rms_row(r, lv, lg);
+    }
+  } else {
+    auto plain_row = [&](int r, const u32x4_t (&V)[NV]) {
 #pragma unroll
-          for (int j = 0; j < 2 * NE; ++j) early_landed(ev[j]);
-#pragma unroll
-          for (int j = 0; j < NE; ++j) early_landed(eg[j]);
-        }
+      for (int j = 0; j < NE; ++j) {
+        const int i = j * GEMV_THREADS + tid;
+        if (i < nvec) stage_vector(r, i, V[j]);
+      }
+      for (int v0 = NE * GEMV_THREADS; v0 < nvec; v0 += NE * GEMV_THREADS) {
+        u32x4_t tv[NV], tg[NG];
+        fetch_batch(r, v0, tv, tg);
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
           const int i = v0 + j * GEMV_THREADS + tid;
-          if (i < nvec) {
-            const f32x4_t h0 = __builtin_bit_cast(f32x4_t, ev[2 * j]), h1 = __builtin_bit_cast(f32x4_t, ev[2 * j + 1]);
-            u32x4_t o;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float ga = ft_bits_to_f32<FT>(eg[j][q] & 0xFFFFu), gb = ft_bits_to_f32<FT>(eg[j][q] >> 16);
-              const float xa = q < 2 ? h0[2 * q] : h1[2 * q - 4], xb = q < 2 ? h0[2 * q + 1] : h1[2 * q - 3];
-              o[q] = f32_to_ft_bits<FT>((ga * xa) * rstd) | (f32_to_ft_bits<FT>((gb * xb) * rstd) << 16);
-            }
-            stage_vector(r, i, o);
-          }
+          if (i < nvec) stage_vector(r, i, tv[j]);
         }
       }
-    } else if constexpr (PRO == PRO_ATTNMERGE) {
-      // span_attn_split_merge_kernel, one batch of splits: bm = max m_j; c_j = exp(m_j - bm) (0 for an empty split);
-      // l = sum_j l_j c_j and o = sum_j o_j c_j by fmaf in split order from 0; x = o / l rounded to FT
-      auto merge_stage = [&](int i, const u32x4_t (&po)[2 * AMS], const u32x2_t (&pml)[AMS]) {
-        float mv[AMS], lv[AMS], bm = -INFINITY;
-#pragma unroll
-        for (int sp = 0; sp < AMS; ++sp) {
-          const bool in = sp < a.ap_nsplits;
-          mv[sp] = in ? __uint_as_float(pml[sp][0]) : -INFINITY;
-          lv[sp] = in ? __uint_as_float(pml[sp][1]) : 0.f;
-          bm = fmaxf(bm, mv[sp]);
-        }
-        float ll = 0.f, oo[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) oo[e] = 0.f;
-#pragma unroll
-        for (int sp = 0; sp < AMS; ++sp) {
-          const bool in = sp < a.ap_nsplits;
-          const float c = mv[sp] == -INFINITY ? 0.f : __expf(mv[sp] - bm);
-          ll = fmaf(lv[sp], c, ll);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float ov = in ? __uint_as_float(e < 4 ? po[2 * sp][e] : po[2 * sp + 1][e - 4]) : 0.f;
-            oo[e] = fmaf(ov, c, oo[e]);
-          }
-        }
-        u32x4_t o;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float xa = ll > 0.f ? oo[2 * q] / ll : 0.f, xb = ll > 0.f ? oo[2 * q + 1] / ll : 0.f;
-          o[q] = f32_to_ft_bits<FT>(xa) | (f32_to_ft_bits<FT>(xb) << 16);
-        }
-        stage_vector(r, i, o);
-      };
-      if (r == 0) {
-        // the batch requested before the ring fill (asm loads the compiler does not see): consumed here, straight-line,
-        // and never re-issued -- a loop around hidden loads makes hipcc carry their destinations through register copies
-        // BEFORE the data has landed (v_mov of an in-flight register: NaN rows, found the hard way)
-        stream_wait<D * LPC>();
-#pragma unroll
-        for (int j = 0; j < 2 * AMS; ++j) early_landed(am_o[j]);
-#pragma unroll
-        for (int j = 0; j < AMS; ++j) early_landed(am_ml[j]);
-        DIHIP_GEMV_STAMP(2);
-        if (tid < nvec) merge_stage(tid, am_o, am_ml);
-      }
-      // everything else (further rows, rows longer than one batch) through loads the compiler counts itself
-      for (int v0 = r == 0 ? GEMV_THREADS : 0; v0 < nvec; v0 += GEMV_THREADS) {
-        const int i = v0 + tid;
-        if (i < nvec) {
-          const unsigned char* rec = reinterpret_cast<const unsigned char*>(a.ap) +
-                                     ((size_t)(r * a.ap_heads + (i >> 4)) * a.ap_nsplits) * (GEMV_AP_STRIDE * 4) + (i & 15) * 32;
-          u32x4_t po[2 * AMS];
-          u32x2_t pml[AMS];
-#pragma unroll
-          for (int sp = 0; sp < AMS; ++sp) {
-            const unsigned char* q = rec + (size_t)min(sp, a.ap_nsplits - 1) * (GEMV_AP_STRIDE * 4);
-            po[2 * sp] = gload<u32x4_t>(q);
-            po[2 * sp + 1] = gload<u32x4_t>(q + 16);
-            pml[sp] = gload<u32x2_t>(q - (i & 15) * 32 + 512);
-          }
-          merge_stage(i, po, pml);
-        }
-      }
-    } else {
-      for (int v0 = 0; v0 < nvec; v0 += NE * GEMV_THREADS) {
-        if (r > 0 || v0 > 0) {
-          issue_batch(r, v0);
-          stream_wait<0>();
-        } else {
-          stream_wait<D * LPC>();
-        }
-#pragma unroll
-        for (int j = 0; j < NE; ++j) early_landed(ev[j]);
-        if (r == 0 && v0 == 0) DIHIP_GEMV_STAMP(2);
-#pragma unroll
-        for (int j = 0; j < NE; ++j) {
-          const int i = v0 + j * GEMV_THREADS + tid;
-          if (i < nvec) stage_vector(r, i, ev[j]);
-        }
-      }
+    };
+    plain_row(0, ev);
+    for (int r = 1; r < rows; ++r) {
+      u32x4_t lv[NV], lg[NG];
+      fetch_batch(r, 0, lv, lg);
+      plain_row(r, lv);
     }
   }
-  (void)EARLY_LOADS;
   __syncthreads();
   DIHIP_GEMV_STAMP(3);
 
@@ -633,16 +579,15 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
   for (; c < total; c += D) {
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      if (c + j < total) {
-        stream_wait<(D - 1) * LPC>();
-        stream_landed(wb[j], sb[j]);
-        DIHIP_GEMV_CONSUME(j);
-        if (to_issue > 0) {
-          DIHIP_GEMV_ISSUE(j);
-          --to_issue;
-        } else {
-          DIHIP_GEMV_DUMMY(j);
-        }
+      if (c + j >= total) break;  // (a break, not a guard: no path consumes slot j + 1 without slot j -- tools/audit_asm_loads.py)
+      stream_wait<(D - 1) * LPC>();
+      stream_landed(wb[j], sb[j]);
+      DIHIP_GEMV_CONSUME(j);
+      if (to_issue > 0) {
+        DIHIP_GEMV_ISSUE(j);
+        --to_issue;
+      } else {
+        DIHIP_GEMV_DUMMY(j);
       }
     }
   }
@@ -674,7 +619,8 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
       if (a.bias) v = __fadd_rn(v, load_ft<FT>(a.bias, n));
       v = apply_act(v, a.act);
       if (a.residual) v = ft_round<FT>(v) + load_ft<FT>(a.residual, (size_t)m * a.ldy + n);
-      store_ft<FT>(p_y, (size_t)m * a.ldy + n, v);
+      if constexpr (PUB) store_ft_wt<FT>(p_y, (size_t)m * a.ldy + n, v);
+      else store_ft<FT>(p_y, (size_t)m * a.ldy + n, v);
     } else if constexpr (EPI == EPI_SWIGLU) {
       store_ft<FT>(p_y, (size_t)m * a.ldy + n, (v / (1.f + expf(-v))) * v2);
     } else {
@@ -682,8 +628,30 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
       a.h_out[(size_t)m * a.N + n] = __fadd_rn(base, __fmul_rn(a.alpha, v));
     }
   }
+  if constexpr (PUB) {
+    // publish: all write-through stores of this workgroup have been acknowledged (vmcnt(0) per wave, then the barrier), then one
+    // lane adds the workgroup's tiles to their groups' counters.  Column tile t = 8 tiles per head of 128: heads [0, n) are
+    // query heads (group = head / hpg), [n, n + g) K heads, [n + g, n + 2g) V heads.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      for (int u = 0; u < nu; ++u) {
+        const int head = (u0 + u * NB) >> 3;
+        const int grp = head < a.front_n ? head / a.front_hpg : (head < a.front_n + a.front_g ? head - a.front_n : head - a.front_n - a.front_g);
+        for (int m = 0; m < rows; ++m)
+          __hip_atomic_fetch_add(a.front_counter + ((size_t)m * a.front_g + grp) * 32 /* FRONT_SYNC_STRIDE */, 1u, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
   DIHIP_GEMV_STAMP(6);
 #undef DIHIP_GEMV_STAMP
+}
+
+template <int WBITS, int FT, int MR, int PRO, int EPI, int GPT, bool SLOT = false>
+__global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  gemv_stream_body<WBITS, FT, MR, PRO, EPI, GPT, SLOT, false>(a, (int)blockIdx.x, (int)gridDim.x, smem);
 }
 
 template <int WBITS, int FT, int MR, int PRO, int EPI, int GPT>
@@ -731,8 +699,6 @@ hipError_t launch_gemv_slots(const GemvArgs& a, int blocks, size_t lds_bytes, hi
   DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 1, PRO_PLAIN, EPI_ADDTO, GPT)   \
   DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 4, PRO_PLAIN, EPI_ADDTO, GPT)   \
   DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 1, PRO_RMSNORM, EPI_ADDTO, GPT) \
-  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 4, PRO_RMSNORM, EPI_ADDTO, GPT) \
-  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 1, PRO_ATTNMERGE, EPI_ADDTO, GPT) \
-  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 4, PRO_ATTNMERGE, EPI_ADDTO, GPT)
+  DIHIP_DEFINE_GEMV_LAUNCH(WBITS, FT, 4, PRO_RMSNORM, EPI_ADDTO, GPT)
 
 }  // namespace dihip

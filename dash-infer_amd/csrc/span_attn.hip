@@ -23,113 +23,9 @@
 #include <vector>
 
 #include "span_attn_common.hpp"
+#include "span_attn_ft_mfma.hpp"
 
 namespace dihip {
-
-// Block epilogue shared by the decode kernels: the 4 waves have left one (o[128], m, l) record per head in
-// `lds` ([wave][HC] records of ATTN_PSTRIDE floats).  Combines them and writes the output, or, for split
-// sequences, the block's partial record for span_attn_split_merge_kernel.
-template <int FT, int HC>
-__device__ __forceinline__ void attn_block_epilogue(const AttnArgs& a, float* lds, unsigned* flag_lds, int b, int h0, int nh,
-                                                    int split) {
-  constexpr int H = 128;
-  const int tid = threadIdx.x;
-  __syncthreads();
-  // thread -> (head, dim) pairs of the block result; kept in registers for the epilogue
-  constexpr int PER_THREAD = (HC * H + ATTN_THREADS - 1) / ATTN_THREADS;
-  float bo[PER_THREAD], bm[PER_THREAD], bl[PER_THREAD];
-#pragma unroll
-  for (int e = 0; e < PER_THREAD; ++e) {
-    const int idx = tid + e * ATTN_THREADS;
-    const int h = idx / H, d = idx - h * H;
-    bo[e] = 0.f;
-    bm[e] = -INFINITY;
-    bl[e] = 0.f;
-    if (h < nh) {
-      float mm = -INFINITY;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) mm = fmaxf(mm, lds[(w * HC + h) * ATTN_PSTRIDE + H]);
-      float ll = 0.f, oo = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const float* rec = lds + (w * HC + h) * ATTN_PSTRIDE;
-        const float c = safe_exp_diff(rec[H], mm);
-        ll += rec[H + 1] * c;
-        oo += rec[d] * c;
-      }
-      bo[e] = oo;
-      bm[e] = mm;
-      bl[e] = ll;
-    }
-  }
-
-  if (a.nsplits > 1 || a.force_partials) {
-#pragma unroll
-    for (int e = 0; e < PER_THREAD; ++e) {
-      const int idx = tid + e * ATTN_THREADS;
-      const int h = idx / H, d = idx - h * H;
-      if (h < nh) {
-        float* rec = a.partials + (((size_t)b * a.n + h0 + h) * a.nsplits + split) * ATTN_PSTRIDE;
-        rec[d] = bo[e];
-        if (d == 0) {
-          rec[H] = bm[e];
-          rec[H + 1] = bl[e];
-        }
-      }
-    }
-    // The split partials are normally merged by span_attn_split_merge_kernel (next launch).  An in-kernel hand-off
-    // to the last-arriving workgroup needs an agent-scope release/acquire per workgroup (L2 write-back +
-    // invalidate): measured ~20 us per layer at batch 32 against ~3 us for the extra launch.  a.counters != null
-    // selects the hand-off (small grids only, see run_decode).
-    if (a.counters == nullptr) return;
-    unsigned* counter = a.counters + (size_t)b * gridDim.y + blockIdx.y;
-    if (!arrive_and_check_last(counter, (unsigned)a.nsplits, flag_lds)) return;
-#pragma unroll
-    for (int e = 0; e < PER_THREAD; ++e) {
-      const int idx = tid + e * ATTN_THREADS;
-      const int h = idx / H, d = idx - h * H;
-      if (h < nh) {
-        const float* base = a.partials + ((size_t)b * a.n + h0 + h) * a.nsplits * ATTN_PSTRIDE;
-        float mm = -INFINITY, ll = 0.f, oo = 0.f;
-        for (int sb = 0; sb < a.nsplits; sb += 16) {
-          float mv[16], lv[16], ov[16];
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const bool in = sb + j < a.nsplits;
-            const float* rec = base + (size_t)(in ? sb + j : 0) * ATTN_PSTRIDE;
-            mv[j] = in ? rec[H] : -INFINITY;
-            lv[j] = in ? rec[H + 1] : 0.f;
-            ov[j] = in ? rec[d] : 0.f;
-          }
-          float bmx = mm;
-#pragma unroll
-          for (int j = 0; j < 16; ++j) bmx = fmaxf(bmx, mv[j]);
-          const float carry = safe_exp_diff(mm, bmx);
-          ll *= carry;
-          oo *= carry;
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const float c = safe_exp_diff(mv[j], bmx);
-            ll = fmaf(lv[j], c, ll);
-            oo = fmaf(ov[j], c, oo);
-          }
-          mm = bmx;
-        }
-        bo[e] = oo;
-        bl[e] = ll;
-      }
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < PER_THREAD; ++e) {
-    const int idx = tid + e * ATTN_THREADS;
-    const int h = idx / H, d = idx - h * H;
-    if (h < nh) {
-      const size_t idx = a.out_frag_mt ? act_frag_index(b, (h0 + h) * H + d, a.out_frag_mt) : ((size_t)b * a.n + h0 + h) * H + d;
-      store_ft<FT>(a.out, idx, bl[e] > 0.f ? bo[e] / bl[e] : 0.f);
-    }
-  }
-}
 
 // One workgroup (128 threads = head dims) per (request, head): combines the nsplits partial records.  Splits
 // beyond the sequence hold neutral records (m = -inf, l = 0), so no length is needed.
@@ -354,8 +250,6 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const At
 //       (v_perm_b32); the k-slot <-> token and row <-> dim maps are free, so no LDS is involved.  The V
 //       zero-points leave through  sum_t P'_t (128 + z_t)  with the SAME rounded P'.
 // Everything else (split partials, last-arriver merge) is the epilogue shared with the VALU kernel.
-constexpr int MF_HC = 16;   // query heads per workgroup chunk (MFMA N)
-constexpr int MF_TOK = 32;  // tokens per wave iteration
 
 __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const AttnArgs a) {
   constexpr int H = 128;
@@ -575,390 +469,6 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
 // ---- 16-bit KV cache (bf16 / f16, the default cache mode) on the matrix cores -----------------------------
 // Same transposed formulation as the u4 kernel (S^T = K.Q^T, lane-local softmax, O^T = V^T.P^T with P as
 // bf16/f16 hi + lo).  K rows are A fragments as stored (lane (kb, token) <- 16 bytes = dims ks*32 + kb*8..).
-// V^T needs 8 tokens of one dim per lane: the 32-token V tile goes through a per-wave LDS tile (coalesced
-// 16-byte loads, ds_write_b128, row pitch 288 B) and comes back with ds_read_b64_tr_b16, the gfx950 transpose
-// read (tools/trread_test.cpp pins its lane mapping): two reads give the 8 k-slots of one dim tile, pitch 288
-// makes the 16 lanes of a read hit 32 distinct banks.  Registers hold ONE K tile pair and ONE V tile: V(t+1) is
-// requested as soon as V(t) sits in LDS, K(t+1) as soon as the scores of t are done -- the loads are in
-// flight during softmax and P.V without a second register set.
-constexpr int MF_VPITCH = 288;  // bytes per token row of the LDS V tile (256 + 32)
-
-
-template <int FT>
-__device__ __forceinline__ f32x4_t mfma_ft(const u32x4_t& a_, const u32x4_t& b_, const f32x4_t& c_) {
-  if constexpr (FT == DIHIP_BF16)
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a_), __builtin_bit_cast(bf16x8_t, b_), c_, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a_), __builtin_bit_cast(f16x8_t, b_), c_, 0, 0, 0);
-}
-
-
-// MODE = DIHIP_KV_NONE: rows are FT.  MODE = DIHIP_KV_I8: rows are int8 with per-token {zero, scale}; bytes become
-// exact FT integers 128 + q (byte ^ 0x80 -> v_cvt_f32_ubyte -> packed convert) on the way to the K fragments / the LDS
-// V tile, and zero-points and scales are applied to the f32 scores and to P exactly as in the u4 kernel.
-// FUSED (16-bit cache only): the decode-step form.  a.q is the fused pre-Rotary qkv row, a.seq_lens the tokens already
-// cached.  Query heads are rotated in the prologue (the rotate-half partner d +- 64 of a lane's dims is k-step ks +- 2 of
-// the SAME lane); the workgroup whose range holds the new token rotates / rounds this step's K head and takes its V
-// head, one wave writes both into the span (byte-identical to DecoderCacheAppend), and every lane whose (clamped)
-// token is the new one uses the register copy -- the span row itself may not be written yet.
-template <int FT, int MODE, bool FUSED>
-__global__ __launch_bounds__(ATTN_THREADS, 2) void span_attn_ft_mfma_kernel(const AttnArgs a) {
-  constexpr int H = 128;
-  constexpr int HC = MF_HC;
-  constexpr bool Q8 = MODE == DIHIP_KV_I8;
-  static_assert(!FUSED || MODE == DIHIP_KV_NONE, "the decode-step form covers the 16-bit cache");
-  constexpr int ROWB = Q8 ? H : H * 2;  // bytes per token-head row in the span
-  constexpr int EPI_BYTES = (4 * HC * ATTN_PSTRIDE + 4) * 4;
-  constexpr int VT_BYTES = 4 * MF_TOK * MF_VPITCH;
-  // the per-wave V tiles and the epilogue records share one buffer (a barrier separates the two uses)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[EPI_BYTES > VT_BYTES ? EPI_BYTES : VT_BYTES];
-  float* lds = reinterpret_cast<float*>(smem);
-  unsigned* flag_lds = reinterpret_cast<unsigned*>(lds + 4 * HC * ATTN_PSTRIDE);
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  if constexpr (FUSED) {
-    if ((int)blockIdx.y >= a.g * a.nchunks) {  // cache-prefetch workgroup (see AttnArgs::pf_ptr); workgroup-uniform exit
-      const unsigned pw = ((blockIdx.z * (gridDim.y - a.g * a.nchunks) + (blockIdx.y - a.g * a.nchunks)) * gridDim.x + blockIdx.x);
-      const unsigned npw = gridDim.z * (gridDim.y - a.g * a.nchunks) * gridDim.x;
-      unsigned acc = 0;
-#pragma unroll
-      for (int bi = 0; bi < 4; ++bi) {
-        const unsigned* p = a.pf_ptr[bi];
-        const unsigned lines = a.pf_lines[bi];
-        for (unsigned i = pw * ATTN_THREADS + tid; i < lines; i += npw * ATTN_THREADS) acc ^= gload<unsigned>(p + (size_t)i * 32);
-      }
-      if (acc == 0x9E3779B9u && a.partials) a.partials[0] = 0.f;  // practically never: keeps the loads alive
-      return;
-    }
-  }
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kb = lane >> 4, ni = lane & 15;
-  const int split = blockIdx.x;
-  const int grp = blockIdx.y / a.nchunks, hc = blockIdx.y % a.nchunks;
-  const int b = blockIdx.z;
-  const int h0 = grp * a.hpg + hc * HC;
-  const int nh = min(HC, a.hpg - hc * HC);
-  unsigned char* vt = smem + wave * (MF_TOK * MF_VPITCH);
-
-  const int len = (int)a.seq_lens[b] + (FUSED ? 1 : 0);
-  const int newpos = len - 1;  // FUSED: position of this step's token
-  const int tps = ((len + a.nsplits - 1) / a.nsplits + 31) & ~31;
-  const int t0 = split * tps;
-  const int t1 = min(len, t0 + tps);
-  const void* const* ksp = a.kspans + (size_t)b * a.span_stride;
-  const void* const* vsp = a.vspans + (size_t)b * a.span_stride;
-  const size_t par_off = (size_t)a.g * a.S * ROWB;  // int8: (zero, scale) pairs follow the data of all groups
-
-  // K: tile c.  FT rows: k-step ks = dims ks*32 + kb*8.. (4 x 16 B per token);  int8 rows: dims kb*32.. (2 x 16 B)
-  u32x4_t kreg[2][Q8 ? 2 : 4];
-  // V: FT rows: load i = tokens i*4 + (lane>>4), bytes (lane&15)*16..;  int8: tokens i*8 + (lane>>3), bytes (lane&7)*16..
-  u32x4_t vreg[Q8 ? 4 : 8];
-  f32x4_t kpar[Q8 ? 2 : 1][2], vpar[Q8 ? 2 : 1][2];  // int8: {zero, scale} of tokens c*16 + kb*4 + {0,1 | 2,3}
-  // tile bases are wave-uniform (scalar span pointer loads); tokens past the range re-read the last valid
-  // token of the tile (finite data: an uninitialised row could hold NaN bit patterns, and 0 * NaN = NaN)
-  auto tile_base = [&](int tb, int c, int& row0, int& last) {
-    int base = tb + c * 16;
-    base = base < t1 ? base : ((t1 - 1) & ~15);
-    const int sp = __builtin_amdgcn_readfirstlane(base / a.S);
-    row0 = grp * a.S + (base - sp * a.S);
-    last = min(15, t1 - 1 - base);  // last valid token of the tile, relative
-    return sp;
-  };
-  auto load_k = [&](int tb) {
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      int row0, last;
-      const int sp = tile_base(tb, c, row0, last);
-      const unsigned char* kbase = reinterpret_cast<const unsigned char*>(ksp[sp]);
-      const unsigned char* kd = kbase + (size_t)row0 * ROWB;
-      if constexpr (Q8) {
-        const uint32_t off = (uint32_t)(min(ni, last) * ROWB + kb * 32);
-        kreg[c][0] = gload<u32x4_t>(kd + off);
-        kreg[c][1] = gload<u32x4_t>(kd + off + 16);
-        const unsigned char* kq = kbase + par_off + (size_t)row0 * 8 + kb * 32;
-        kpar[c][0] = gload<f32x4_t>(kq);
-        kpar[c][1] = gload<f32x4_t>(kq + 16);
-      } else {
-        const uint32_t off = (uint32_t)(min(ni, last) * ROWB + kb * 16);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) kreg[c][ks] = gload<u32x4_t>(kd + off + ks * 64);
-      }
-    }
-  };
-  auto load_v = [&](int tb) {
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      int row0, last;
-      const int sp = tile_base(tb, c, row0, last);
-      const unsigned char* vbase = reinterpret_cast<const unsigned char*>(vsp[sp]);
-      const unsigned char* vd = vbase + (size_t)row0 * ROWB;
-      if constexpr (Q8) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const uint32_t off = (uint32_t)(min(i * 8 + (lane >> 3), last) * ROWB + (lane & 7) * 16);
-          vreg[c * 2 + i] = gload<u32x4_t>(vd + off);
-        }
-        const unsigned char* vq = vbase + par_off + (size_t)row0 * 8 + kb * 32;
-        vpar[c][0] = gload<f32x4_t>(vq);
-        vpar[c][1] = gload<f32x4_t>(vq + 16);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint32_t off = (uint32_t)(min(i * 4 + (lane >> 4), last) * ROWB + (lane & 15) * 16);
-          vreg[c * 4 + i] = gload<u32x4_t>(vd + off);
-        }
-      }
-    }
-  };
-  // 4 int8 bytes of a dword -> 4 exact FT values 128 + q (two packed dwords)
-  auto expand8 = [&](uint32_t d0, uint32_t d1) {  // 8 bytes -> one MFMA operand register quad
-    const uint32_t u0 = d0 ^ 0x80808080u, u1 = d1 ^ 0x80808080u;
-    return u32x4_t{pack_ft2<FT>((float)(u0 & 0xFFu), (float)((u0 >> 8) & 0xFFu)),
-                   pack_ft2<FT>((float)((u0 >> 16) & 0xFFu), (float)(u0 >> 24)),
-                   pack_ft2<FT>((float)(u1 & 0xFFu), (float)((u1 >> 8) & 0xFFu)),
-                   pack_ft2<FT>((float)((u1 >> 16) & 0xFFu), (float)(u1 >> 24))};
-  };
-
-  const int tb0 = t0 + wave * MF_TOK;
-  const bool active = tb0 < t1;
-  if (active) {
-    load_v(tb0);
-    load_k(tb0);
-  }
-
-  // rotate-half on a lane's fragments: dims ks*32 + kb*8 + e (ks = 0, 1) pair with ks + 2; table row = position.
-  // Same arithmetic and rounding as dihip_rope_qk / the Rotary op: two products, one add, rounded to FT.
-  auto rotate = [&](u32x4_t (&f)[4], const float* cs_row) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const f32x4_t* t = reinterpret_cast<const f32x4_t*>(cs_row + (ks * 32 + kb * 8) * 2);
-      const f32x4_t c0 = t[0], c1 = t[1], c2 = t[2], c3 = t[3];  // {cos, sin} x 8 dims
-      const float cosv[8] = {c0[0], c0[2], c1[0], c1[2], c2[0], c2[2], c3[0], c3[2]};
-      const float sinv[8] = {c0[1], c0[3], c1[1], c1[3], c2[1], c2[3], c3[1], c3[3]};
-      u32x4_t lo_, hi_;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float x0[2], x1[2], r0[2], r1[2];
-        x0[0] = ft_bits_to_f32<FT>(f[ks][j] & 0xFFFFu);
-        x0[1] = ft_bits_to_f32<FT>(f[ks][j] >> 16);
-        x1[0] = ft_bits_to_f32<FT>(f[ks + 2][j] & 0xFFFFu);
-        x1[1] = ft_bits_to_f32<FT>(f[ks + 2][j] >> 16);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          r0[e] = x0[e] * cosv[2 * j + e] - x1[e] * sinv[2 * j + e];
-          r1[e] = x1[e] * cosv[2 * j + e] + x0[e] * sinv[2 * j + e];
-        }
-        lo_[j] = f32_to_ft_bits<FT>(r0[0]) | (f32_to_ft_bits<FT>(r0[1]) << 16);
-        hi_[j] = f32_to_ft_bits<FT>(r1[0]) | (f32_to_ft_bits<FT>(r1[1]) << 16);
-      }
-      f[ks] = lo_;
-      f[ks + 2] = hi_;
-    }
-  };
-  // Q as the B operand, unscaled (exact FT values): lane (kb, head ni) holds the 8 dims of k-step ks in the order
-  // of the K fragments (FT rows: ks*32 + kb*8..; int8 rows: kb*32 + ks*8..)
-  u32x4_t qf[4];
-  float qsum = 0.f;
-  const size_t qrow_stride = FUSED ? (size_t)(a.n + 2 * a.g) * H : (size_t)a.n * H;
-  const float* cs_row = FUSED ? a.rope_tab + (size_t)newpos * 128 : nullptr;
-  {
-    const bool hv = ni < nh;
-    const uint16_t* qrow = reinterpret_cast<const uint16_t*>(a.q) + (size_t)b * qrow_stride + (size_t)(h0 + (hv ? ni : 0)) * H;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      qf[ks] = *reinterpret_cast<const u32x4_t*>(qrow + (Q8 ? kb * 32 + ks * 8 : ks * 32 + kb * 8));
-      if constexpr (Q8) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) qsum += hv ? ft_bits_to_f32<FT>(qf[ks][j] & 0xFFFFu) + ft_bits_to_f32<FT>(qf[ks][j] >> 16) : 0.f;
-      }
-    }
-    if constexpr (FUSED) rotate(qf, cs_row);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      if (!hv) qf[ks] = u32x4_t{0u, 0u, 0u, 0u};
-    if constexpr (Q8) {
-      qsum = rows_sum(qsum);
-    }
-  }
-  // FUSED: this step's K (rotated, rounded) and V head of the group, as the cache will hold them
-  const bool has_new = FUSED && newpos >= t0 && newpos < t0 + tps;  // workgroup-uniform (all head chunks of the group)
-  u32x4_t knew[4] = {}, vnew = {};
-  if constexpr (FUSED) {
-    if (has_new) {
-      const uint16_t* krow = reinterpret_cast<const uint16_t*>(a.q) + (size_t)b * qrow_stride + (size_t)(a.n + grp) * H;
-      const uint16_t* vrow = krow + (size_t)a.g * H;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) knew[ks] = *reinterpret_cast<const u32x4_t*>(krow + ks * 32 + kb * 8);
-      rotate(knew, cs_row);
-      vnew = *reinterpret_cast<const u32x4_t*>(vrow + (lane & 15) * 8);
-      if (hc == 0 && wave == 0) {  // one writer per (request, group): DecoderCacheAppend
-        const int sp = min(newpos / a.S, a.span_stride - 1), pos = newpos - (newpos / a.S) * a.S;  // clamped: never past the span table
-        unsigned char* kd = reinterpret_cast<unsigned char*>(const_cast<void*>(ksp[sp])) + ((size_t)grp * a.S + pos) * ROWB;
-        unsigned char* vd = reinterpret_cast<unsigned char*>(const_cast<void*>(vsp[sp])) + ((size_t)grp * a.S + pos) * ROWB;
-        if (ni == 0) {
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) gstore<u32x4_t>(kd + ks * 64 + kb * 16, knew[ks]);
-        }
-        if (lane < 16) gstore<u32x4_t>(vd + lane * 16, vnew);
-      }
-    }
-  }
-
-  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
-  float m = -INFINITY, l = 0.f, czero = 0.f;
-  f32x4_t o[8];  // O^T tile dt: rows (dims) dt*16 + kb*4 + r, column = head ni
-#pragma unroll
-  for (int dt = 0; dt < 8; ++dt) o[dt] = zero4;
-  // transpose-read addresses: lane p of a 16-lane group supplies row p/4 (token), columns (p%4)*4.. of a 4 x 16 block
-  const unsigned char* tr0 = vt + (kb * 4 + (ni >> 2)) * MF_VPITCH + (ni & 3) * 8;
-
-  if (active) {
-    constexpr int STEP = 4 * MF_TOK;
-    for (int tb = tb0; tb < t1; tb += STEP) {
-      // FUSED: lanes whose (clamped) token is this step's token take the register copy (see above)
-      if constexpr (FUSED) {
-        if (has_new) {
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            int base = tb + c * 16;
-            base = base < t1 ? base : ((t1 - 1) & ~15);
-            const int last = min(15, t1 - 1 - base);
-            if (base + min(ni, last) == newpos) {
-#pragma unroll
-              for (int ks = 0; ks < 4; ++ks) kreg[c][ks] = knew[ks];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (base + min(i * 4 + (lane >> 4), last) == newpos) vreg[c * 4 + i] = vnew;
-          }
-        }
-      }
-      // ---- V(t) into this wave's LDS tile (FT elements, [token][dim]), then request V(t + 1) into the same registers
-      float vzp[2][4], vsc[2][4];  // int8: parameters of this lane's tokens (c, kb*4 + rr), read before the refill
-      if constexpr (Q8) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          unsigned char* dst = vt + (i * 8 + (lane >> 3)) * MF_VPITCH + (lane & 7) * 32;
-          *reinterpret_cast<u32x4_t*>(dst) = expand8(vreg[i][0], vreg[i][1]);
-          *reinterpret_cast<u32x4_t*>(dst + 16) = expand8(vreg[i][2], vreg[i][3]);
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            vzp[c][rr] = vpar[c][rr >> 1][(rr & 1) * 2];
-            vsc[c][rr] = vpar[c][rr >> 1][(rr & 1) * 2 + 1];
-          }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          *reinterpret_cast<u32x4_t*>(vt + (i * 4 + (lane >> 4)) * MF_VPITCH + (lane & 15) * 16) = vreg[i];
-      }
-      load_v(tb + STEP);
-      // ---- scores of the 32 tokens (transposed): sc[c][r] = token tb + c*16 + kb*4 + r, head ni
-      float sc[2][4];
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        f32x4_t acc = zero4;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          if constexpr (Q8) {
-            acc = mfma_ft<FT>(expand8(kreg[c][ks >> 1][(ks & 1) * 2], kreg[c][ks >> 1][(ks & 1) * 2 + 1]), qf[ks], acc);
-          } else {
-            acc = mfma_ft<FT>(kreg[c][ks], qf[ks], acc);
-          }
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          float v = acc[rr] * a.scale;
-          if constexpr (Q8) {
-            const float kz = kpar[c][rr >> 1][(rr & 1) * 2], ksc = kpar[c][rr >> 1][(rr & 1) * 2 + 1];
-            v = (ksc * a.scale) * fmaf(-(128.f + kz), qsum, acc[rr]);
-          }
-          sc[c][rr] = tb + c * 16 + kb * 4 + rr < t1 ? v : -INFINITY;
-        }
-      }
-      load_k(tb + STEP);
-      // ---- online softmax (lane-local + two cross-row shuffles)
-      float mn = m;
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) mn = fmaxf(mn, sc[c][rr]);
-      mn = rows_max(mn);
-      const float corr = safe_exp_diff(m, mn);
-      m = mn;
-      float ps = 0.f, cz = 0.f;
-      uint32_t pk[4], pl[4];
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-          float pv[2], zz[2] = {0.f, 0.f};
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const int rr = 2 * h2 + e;
-            const float p_ = safe_exp_diff(sc[c][rr], mn);
-            ps += p_;
-            pv[e] = p_;
-            if constexpr (Q8) {
-              const bool valid = tb + c * 16 + kb * 4 + rr < t1;  // p == 0 there, but the parameters may be junk
-              pv[e] = valid ? p_ * vsc[c][rr] : 0.f;
-              zz[e] = valid ? 128.f + vzp[c][rr] : 0.f;
-            }
-          }
-          const uint32_t hi = pack_ft2<FT>(pv[0], pv[1]);
-          const float h0f = ft_bits_to_f32<FT>(hi & 0xFFFFu), h1f = ft_bits_to_f32<FT>(hi >> 16);
-          const uint32_t lo = pack_ft2<FT>(pv[0] - h0f, pv[1] - h1f);
-          pk[c * 2 + h2] = hi;
-          pl[c * 2 + h2] = lo;
-          if constexpr (Q8) {
-            cz = fmaf(h0f + ft_bits_to_f32<FT>(lo & 0xFFFFu), zz[0], cz);
-            cz = fmaf(h1f + ft_bits_to_f32<FT>(lo >> 16), zz[1], cz);
-          }
-        }
-      l = l * corr + ps;
-      czero = czero * corr + cz;
-      if (__builtin_amdgcn_ballot_w64(corr != 1.f) != 0ull) {
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) o[dt][rr] *= corr;
-      }
-      // ---- O^T += V^T . P: A = V^T from the LDS tile by transpose reads; k-slot j = token (j>>2)*16 + kb*4 + (j&3)
-      const u32x4_t pkv = {pk[0], pk[1], pk[2], pk[3]};
-      const u32x4_t plv = {pl[0], pl[1], pl[2], pl[3]};
-#pragma unroll
-      for (int dt = 0; dt < 8; ++dt) {
-        const u32x2_t lo2 = lds_read_tr16(tr0 + dt * 32);
-        const u32x2_t hi2 = lds_read_tr16(tr0 + dt * 32 + 16 * MF_VPITCH);
-        const u32x4_t vf = {lo2[0], lo2[1], hi2[0], hi2[1]};
-        o[dt] = mfma_ft<FT>(vf, pkv, o[dt]);
-        o[dt] = mfma_ft<FT>(vf, plv, o[dt]);
-      }
-    }
-  }
-  l = rows_sum(l);
-  if constexpr (Q8) {
-    czero = rows_sum(czero);
-  }
-  __syncthreads();  // every wave is done with its V tile: the buffer now holds the epilogue records
-  if (ni < nh) {
-    float* rec = lds + (wave * HC + ni) * ATTN_PSTRIDE;
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-      f32x4_t x = o[dt];
-      if constexpr (Q8) x = f32x4_t{x[0] - czero, x[1] - czero, x[2] - czero, x[3] - czero};
-      *reinterpret_cast<f32x4_t*>(rec + dt * 16 + kb * 4) = x;
-    }
-    if (kb == 0) {
-      rec[H] = m;
-      rec[H + 1] = l;
-    }
-  }
-  attn_block_epilogue<FT, HC>(a, lds, flag_lds, b, h0, nh, split);
-}
-
 // ------------------------------------------------------------------------------------------
 struct AttnPlan {
   int HC, nchunks, nsplits;
@@ -1220,16 +730,15 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
   return launch_status();
 }
 
-// partials-only form of the above: no merge launch, the consumer (dihip_fused_attnmerge_gemm_addto) merges
-constexpr int ATTN_PARTIALS_SPLIT_CAP = 8;  // == GEMV_AP_SPLITS (gemv_stream_kernel.hpp)
-
-static bool fused_partials_covered(int batch, int n_heads, int n_groups, int kv_mode, int dtype) {
-  // (a capability, not a default: decoder.DecodeSession keeps the three-launch form unless DIHIP_DECODER_ATTN_MERGE=1 --
-  // measured on MI355X (profiles/r02_attn_merge_fold.txt) the pair is not faster than the launches it replaces: every
-  // o-projection workgroup re-reads all partials (115 KB at 8 splits: +2.4 us of address-pipeline time per CU), and
-  // capping the splits at 8 costs the attention kernel 3 us (10.5 vs 7.2 us))
-  return batch >= 1 && batch <= 4 && kv_mode == DIHIP_KV_NONE && (dtype == DIHIP_BF16) && attn_use_mfma(kv_mode, dtype) &&
-         n_heads % n_groups == 0 && n_heads / n_groups <= MF_HC;
+// plan of the decode-step MFMA attention for the fused front launch (decode_front.hip): 0 = not covered
+int span_attn_front_plan(int batch, int n_heads, int n_groups, int max_seq_len, int kv_mode, int dtype, int* nsplits, int* nchunks,
+                         size_t* partial_bytes) {
+  if (kv_mode != DIHIP_KV_NONE || dtype != DIHIP_BF16 || !attn_use_mfma(kv_mode, dtype) || n_heads % n_groups) return 0;
+  const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true);
+  *nsplits = p.nsplits;
+  *nchunks = p.nchunks;
+  *partial_bytes = (size_t)batch * n_heads * p.nsplits * ATTN_PSTRIDE * sizeof(float);  // partial records are always written
+  return 1;
 }
 
 }  // namespace dihip
@@ -1237,60 +746,6 @@ static bool fused_partials_covered(int batch, int n_heads, int n_groups, int kv_
 using namespace dihip;
 
 extern "C" {
-
-int dihip_span_attn_fused_partials_plan(int batch, int n_heads, int n_groups, int max_seq_len, int kv_mode, int dtype,
-                                        int* nsplits, size_t* partial_bytes) {
-  if (nsplits) *nsplits = 0;
-  if (partial_bytes) *partial_bytes = 0;
-  if (!fused_partials_covered(batch, n_heads, n_groups, kv_mode, dtype) || max_seq_len <= 0) return DIHIP_SUCCESS;
-  const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true, ATTN_PARTIALS_SPLIT_CAP);
-  if (nsplits) *nsplits = p.nsplits;
-  if (partial_bytes) *partial_bytes = (size_t)batch * n_heads * p.nsplits * ATTN_PSTRIDE * sizeof(float);
-  return DIHIP_SUCCESS;
-}
-
-int dihip_span_attn_decode_fused_partials(void* stream, float* partials, size_t partial_bytes, const void* qkv,
-                                          void* const* k_span_array, void* const* v_span_array,
-                                          const uint32_t* old_seq_lens_dev, const float* rope_table, int batch, int n_heads,
-                                          int n_groups, int head_size, int span_len, int n_spans_per_request, int max_seq_len,
-                                          int kv_mode, int dtype, float qk_scale) {
-  DIHIP_REQUIRE(batch >= 0 && n_heads > 0 && n_groups > 0 && n_spans_per_request > 0 && max_seq_len > 0, DIHIP_PARAM_ERROR,
-                "span_attn_decode_fused_partials: invalid parameter");
-  DIHIP_REQUIRE(partials && qkv && k_span_array && v_span_array && old_seq_lens_dev && rope_table, DIHIP_PARAM_ERROR,
-                "span_attn_decode_fused_partials: null pointer");
-  DIHIP_REQUIRE(head_size == 128, DIHIP_PARAM_ERROR, "span_attn: unsupported head size %d (only 128, dispatch.hpp:45-57)", head_size);
-  DIHIP_REQUIRE(span_len_valid(span_len), DIHIP_PARAM_ERROR, "span_attn: span length %d not in {16,32,64,128}", span_len);
-  DIHIP_REQUIRE((reinterpret_cast<uintptr_t>(qkv) & 15) == 0, DIHIP_PARAM_ERROR, "span_attn_decode_fused_partials: qkv must be 16-byte aligned");
-  if (batch == 0) return DIHIP_SUCCESS;
-  DIHIP_REQUIRE(fused_partials_covered(batch, n_heads, n_groups, kv_mode, dtype), DIHIP_PARAM_ERROR,
-                "span_attn_decode_fused_partials: configuration not covered (batch <= 4, 16-bit cache, bf16; see _plan)");
-  const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true, ATTN_PARTIALS_SPLIT_CAP);
-  const size_t need = (size_t)batch * n_heads * p.nsplits * ATTN_PSTRIDE * sizeof(float);
-  DIHIP_REQUIRE(partial_bytes >= need, DIHIP_MEMORY_ERROR, "span_attn_decode_fused_partials: partial buffer too small (%zu < %zu)",
-                partial_bytes, need);
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  AttnArgs a{};
-  a.q = qkv;
-  a.kspans = k_span_array;
-  a.vspans = v_span_array;
-  a.seq_lens = old_seq_lens_dev;
-  a.partials = partials;
-  a.B = batch;
-  a.n = n_heads;
-  a.g = n_groups;
-  a.hpg = n_heads / n_groups;
-  a.S = span_len;
-  a.span_stride = n_spans_per_request;
-  a.nsplits = p.nsplits;
-  a.nchunks = p.nchunks;
-  a.scale = qk_scale;
-  a.rope_tab = rope_table;
-  a.force_partials = 1;
-  const int pf_rows = take_prefetch_rows(a, p.nsplits, n_groups * p.nchunks, batch);
-  const dim3 grid(p.nsplits, n_groups * p.nchunks + pf_rows, batch);
-  hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_NONE, true>), grid, dim3(ATTN_THREADS), 0, s, a);
-  return launch_status();
-}
 
 int dihip_span_attn_set_next_prefetch(const void* const* ptrs, const size_t* bytes, int count) {
   DIHIP_REQUIRE(count >= 0 && count <= 4 && (count == 0 || (ptrs && bytes)), DIHIP_PARAM_ERROR,

@@ -8,6 +8,7 @@ namespace dihip {
 constexpr int ATTN_THREADS = 256;
 constexpr int ATTN_TB = 2;              // tokens per lane slot per iteration
 constexpr int ATTN_TOK_PER_ITER = 32;  // 4 waves x 4 token slots x ATTN_TB tokens
+constexpr int FRONT_SYNC_STRIDE = 32;  // unsigned words between the per-(request, group) sync counters: one 128-byte line each
 constexpr int ATTN_PSTRIDE = 132;      // floats per partial record: o[128], m, l, pad
 
 struct AttnArgs {
@@ -30,8 +31,13 @@ struct AttnArgs {
   // GEMVs are first-byte-latency bound: on cache-resident weights they measured 1.4-1.6 us shorter (profiles/r02*).
   const unsigned* pf_ptr[4];
   unsigned pf_lines[4];
+  // fused decode-step launch (decode_front.hip): qkv-publication counters [B * g], see span_attn_ft_mfma_body<.., FRONT>
+  unsigned* front_counter;
+  unsigned* front_done;
+  unsigned front_target;
+  int front_presleep;     // s_sleep(127) repetitions before the first poll (the GEMV cannot be done earlier)
   int force_partials;     // write the block's partial record even for a single split and leave the merge to the consumer
-                          // (the o-projection GEMV's PRO_ATTNMERGE prologue: no merge launch)
+                          // (decode_front.hip launches dihip_span_attn_merge_partials itself)
 };
 
 // decode-step form on the matrix cores (span_attn.hip); returns a DIHIP status, DIHIP_PARAM_ERROR with

@@ -367,20 +367,21 @@ class DecodeSession:
         # (16-bit cache: the decode-step form runs on the matrix cores at every batch size; quantised caches have the
         # MFMA kernels only at the op boundary, their decode-step form is the one-wave-per-head kernel)
         self.fused_attention = kv_mode == "none" or batch * self.g_loc <= 64
-        # batch <= 4, 16-bit cache: the attention kernel leaves its split partials and the o-projection GEMV merges them in
-        # its prologue (one launch less per layer).  Built, bit-identical, and NOT faster (see span_attn.hip:
-        # fused_partials_covered): an experiment switch, DIHIP_DECODER_ATTN_MERGE=1
-        self.attn_nsplits, self.attn_partials = 0, None
+        # batch <= 4, 16-bit cache: RMSNorm + qkv GEMV and Rotary + append + attention of a layer as ONE launch (the attention
+        # workgroups resolve addresses and pull K / V while the GEMV streams, then wait for the qkv row): dihip_decode_front.
+        # Bit-identical to the two calls and measured SLOWER (22.2 us vs 18.8 us per layer, 608 vs 640 tokens/s: the
+        # attention's dependent loads run at loaded latency while the GEMV streams; profiles/r02_attn_merge_fold.txt) --
+        # an experiment switch, DIHIP_DECODER_FRONT=1.  It needs all of its workgroups co-resident (one decode stream per GPU).
+        self.front = (batch <= 4 and kv_mode == "none" and dt == torch.bfloat16 and os.environ.get("DIHIP_DECODER_FRONT", "0") == "1"
+                      and ops.decode_front_supported(model.layers[0].qkv, batch, self.n_loc, self.g_loc, H, max_len, kv_mode, dt))
+        if self.front:
+            self.front_ws = torch.empty(int(lib().dihip_decode_front_workspace_bytes(batch, self.n_loc, self.g_loc, max_len)),
+                                        dtype=torch.uint8, device=device)
+            self.front_sync = torch.zeros(int(lib().dihip_decode_front_sync_bytes(batch, self.g_loc)), dtype=torch.uint8, device=device)
         # weights of the following launches touched by idle CUs during the attention launch: measured SLOWER end to end
         # (606 vs 627 tokens/s, profiles/r02_attn_merge_fold.txt: the prefetch traffic delays the attention's own,
         # latency-bound loads more than the warmer GEMVs gain) -- kept as an experiment switch, off by default
         self.attn_prefetch = batch <= 4 and os.environ.get("DIHIP_DECODER_ATTN_PREFETCH", "0") == "1"
-        if self.fused_attention and dt == torch.bfloat16 and os.environ.get("DIHIP_DECODER_ATTN_MERGE", "0") == "1":
-            lo = model.layers[0].o
-            ns, nbytes = ops.span_attn_partials_plan(batch, self.n_loc, self.g_loc, max_len, kv_mode, dt)
-            if ns > 0 and ops.gemv_plan(lo.wbits, batch, lo.N, lo.K, lo.group) is not None:
-                self.attn_nsplits = ns
-                self.attn_partials = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
         if not self.fused_attention and batch <= 32 and ops.prefers_frag(model.layers[0].o, batch):
             self.attn_frag = True
             self.attn = torch.zeros(ops.act_frag_numel(batch, self.n_loc * H), dtype=dt, device=device)
@@ -485,6 +486,15 @@ class DecodeSession:
         tp_on = self.comm is not None and m.nranks > 1
         nf = self.norm_fuse and not tp_on
         for li, lw in enumerate(m.layers):
+            if self.front:
+                ops.decode_front(self.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, self.kv[li], self.old_lens, self.rope_tab, self.n_loc,
+                                 self.g_loc, self.H, self.max_len, self.scale, self.front_ws, self.front_sync, self.qkv, self.attn)
+                self._proj_residual(self.attn, lw.o, tp_on, frag=False, next_weights=(lw.gate.w, lw.up.w))
+                ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act,
+                                      y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
+                nxt = m.layers[li + 1].qkv if li + 1 < len(m.layers) else m.lm_head
+                self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag, next_weights=(nxt.w,))
+                continue
             if nf and li > 0:
                 ops.prenorm_gemm(self.xn1, lw.qkv, lw.qkv_bias, sc, self.B, x_layout=self.xn1_layout, out=self.qkv)
             else:
@@ -493,10 +503,7 @@ class DecodeSession:
                 # weights of the launches that follow, pulled into the Infinity Cache by the CUs the attention leaves idle
                 nxt = m.layers[li + 1].qkv if li + 1 < len(m.layers) else None
                 ops.span_attn_set_next_prefetch([lw.o.w, lw.o.sz] + ([nxt.w, nxt.sz] if nxt is not None else []))
-            if self.attn_nsplits:
-                ops.span_attn_decode_fused_partials(self.qkv, self.kv[li], self.old_lens, self.rope_tab, self.n_loc, self.g_loc,
-                                                    self.H, self.max_len, self.scale, self.attn_partials)
-            elif self.fused_attention:
+            if self.fused_attention:
                 ops.span_attn_decode_fused(self.qkv, self.kv[li], self.old_lens, self.rope_tab, self.n_loc, self.g_loc, self.H,
                                            self.max_len, self.scale, self.attn_ws, out=self.attn)
             else:
@@ -517,13 +524,7 @@ class DecodeSession:
                 else:
                     self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag)  # lm_head applies the final norm itself
                 continue
-            if self.attn_nsplits:
-                h_res = self.h if (not tp_on or m.rank == 0) else None
-                ops.fused_attnmerge_gemm_addto(self.attn_partials, self.attn_nsplits, self.n_loc, lw.o, h_res, sc, out=self.h, M=self.B)
-                if tp_on:
-                    self._allreduce(self.h, (lw.gate.w, lw.up.w))
-            else:
-                self._proj_residual(self.attn, lw.o, tp_on, frag=self.attn_frag, next_weights=(lw.gate.w, lw.up.w))
+            self._proj_residual(self.attn, lw.o, tp_on, frag=self.attn_frag, next_weights=(lw.gate.w, lw.up.w))
             ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act,
                                   y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
             nxt = m.layers[li + 1].qkv if li + 1 < len(m.layers) else m.lm_head

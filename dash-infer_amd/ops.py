@@ -383,23 +383,19 @@ def span_attn_decode_fused(qkv, kv, old_lens_dev, rope_tab, n, g, H, max_len, sc
     return out
 
 
-def span_attn_partials_plan(batch, n, g, max_len, mode, dtype):
-    """(nsplits, bytes) of the partials-only decode-step attention; nsplits == 0: not covered (use span_attn_decode_fused)."""
-    ns, nb = C.c_int(0), C.c_size_t(0)
-    check(lib().dihip_span_attn_fused_partials_plan(batch, n, g, max_len, capi.KV[mode], dt_code(dtype), C.byref(ns), C.byref(nb)),
-          "dihip_span_attn_fused_partials_plan")
-    return ns.value, nb.value
+def decode_front_supported(pw, M, n, g, H, max_len, mode, dtype):
+    return bool(lib().dihip_decode_front_supported(pw.wbits, M, pw.K, pw.group, n, g, H, max_len, capi.KV[mode], dt_code(dtype)))
 
 
-def span_attn_decode_fused_partials(qkv, kv, old_lens_dev, rope_tab, n, g, H, max_len, scale, partials):
-    """Rotary + cache append + paged decode attention of one step, leaving the split partials (f32) for the o-projection."""
-    B = qkv.shape[0]
+def decode_front(h, gamma, eps, pw, bias, kv, old_lens_dev, rope_tab, n, g, H, max_len, scale, ws, sync, qkv_out, attn_out):
+    """RMSNorm + qkv GEMV(+bias) + Rotary + cache append + paged decode attention of one layer: one launch + the split merge."""
+    M = h.shape[0]
     pool = kv.pool
-    check(lib().dihip_span_attn_decode_fused_partials(cur_stream(), ptr(partials), partials.numel() * partials.element_size(),
-                                                      ptr(qkv), ptr(kv.k_ptrs), ptr(kv.v_ptrs), ptr(old_lens_dev), ptr(rope_tab), B, n, g,
-                                                      H, pool.S, kv.max_spans, max_len, capi.KV[pool.mode], dt_code(qkv), float(scale)),
-          "dihip_span_attn_decode_fused_partials")
-    return partials
+    check(lib().dihip_decode_front(cur_stream(), pw.wbits, ptr(h), ptr(gamma), float(eps), ptr(pw.w), ptr(pw.sz), ptr(bias), ptr(qkv_out),
+                                   ptr(attn_out), M, pw.K, pw.group, ptr(kv.k_ptrs), ptr(kv.v_ptrs), ptr(old_lens_dev), ptr(rope_tab), n, g, H,
+                                   pool.S, kv.max_spans, max_len, capi.KV[pool.mode], dt_code(qkv_out), float(scale), ptr(ws), ws.numel(),
+                                   ptr(sync), sync.numel()), "dihip_decode_front")
+    return attn_out
 
 
 def span_attn_set_next_prefetch(tensors):
@@ -418,16 +414,6 @@ def span_attn_merge_partials(partials, batch, n, nsplits, dtype=torch.bfloat16):
     return out
 
 
-def fused_attnmerge_gemm_addto(partials, nsplits, n_heads, pw, h_res, scratch, out=None, M=1):
-    """h_out = h_res + merge(attention split partials) . W  (the merge launch folded into the o-projection's prologue)."""
-    h_out = out if out is not None else torch.empty(M, pw.N, dtype=torch.float32, device=partials.device)
-    check(lib().dihip_fused_attnmerge_gemm_addto(cur_stream(), pw.wbits, ptr(partials), nsplits, n_heads, ptr(pw.w), ptr(pw.sz),
-                                                 ptr(h_res), ptr(h_out), M, pw.N, pw.K, pw.group, ptr(scratch.ws), scratch.ws_bytes,
-                                                 ptr(scratch.sync), dt_code(pw.dtype)), "dihip_fused_attnmerge_gemm_addto")
-    return h_out
-
-
-# ------------------------------------------------------------------------------ glue --------
 def rmsnorm(x, gamma, eps):
     y = torch.empty_like(x)
     check(lib().dihip_rmsnorm(cur_stream(), ptr(y), ptr(x), ptr(gamma), float(eps), x.numel() // x.shape[-1],

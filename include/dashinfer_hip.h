@@ -284,39 +284,39 @@ int dihip_span_attn_decode_fused(void* stream, void* output, const void* qkv, vo
                                  int head_size, int span_len, int n_spans_per_request, int max_seq_len,
                                  int kv_mode, int dtype, float qk_scale, void* ws, size_t ws_bytes);
 
-/* 3c. The same decode step WITHOUT the merge launch (batch <= 4, 16-bit cache, bf16): the attention kernel leaves
- * the per-split partial records  f32 [batch * n_heads][nsplits][132] = { o[128] (unnormalised), m, l, pad }
- * in `partials`, and the o-projection merges them while it stages its activation row:
- *   dihip_fused_attnmerge_gemm_addto: h_out = h_res + merge(partials) . W_o        (M = batch <= 4, K = n_heads * 128)
- * The merged row is bit-identical to the FT output of dihip_span_attn_decode_fused (same arithmetic in the same
- * order), so the pair equals dihip_span_attn_decode_fused + dihip_fused_gemm_addto with one launch less per layer --
- * the replaced reference sequence is the `reduce` kernel of the span-attention library
- * (span-attention/src/attn/span_attention.hpp:240-330) followed by the o_proj GemmA16W4/A16W8 + ADD ops
- * (qwen_v15.py:296-310).
- *   _plan: nsplits = 0 when the configuration is not covered (use 3b); partial_bytes = size of `partials`.  */
-int dihip_span_attn_fused_partials_plan(int batch, int n_heads, int n_groups, int max_seq_len, int kv_mode,
-                                        int dtype, int* nsplits, size_t* partial_bytes);
-int dihip_span_attn_decode_fused_partials(void* stream, float* partials, size_t partial_bytes, const void* qkv,
-                                          void* const* k_span_array, void* const* v_span_array,
-                                          const uint32_t* old_seq_lens_dev, const float* rope_table,
-                                          int batch, int n_heads, int n_groups, int head_size, int span_len,
-                                          int n_spans_per_request, int max_seq_len, int kv_mode, int dtype,
-                                          float qk_scale);
-/* Cache prefetch riding on the NEXT decode-step attention launch of the calling thread (3b with the 16-bit cache, 3c):
+/* Cache prefetch riding on the NEXT decode-step attention launch of the calling thread (3b with the 16-bit cache):
  * the launch gets extra workgroups -- on the CUs the attention leaves idle -- that touch every 128-byte line of up to 4
  * device buffers, pulling them into the 256 MB Infinity Cache while HBM is otherwise idle.  Meant for the weights of
  * the launches that follow (o-projection, the next layer's qkv): those GEMVs are bound by first-byte latency.  The
  * list is consumed by that launch (kernel arguments: captured into a hipGraph like any other); count = 0 clears it.
  * Purely a performance hint: results do not change.  */
 int dihip_span_attn_set_next_prefetch(const void* const* ptrs, const size_t* bytes, int count);
-/* stand-alone merge of the partial records into the FT [batch, n_heads * 128] attention output (consumers other than
- * dihip_fused_attnmerge_gemm_addto; also the parity reference of its prologue) */
+/* merge of the per-split partial records  f32 [batch * n_heads][nsplits][132] = { o[128] (unnormalised), m, l, pad }  of a
+ * decode attention launch into the FT [batch, n_heads * 128] output (the second launch of 3b / 3d) */
 int dihip_span_attn_merge_partials(void* stream, void* output, const float* partials, int batch, int n_heads,
                                    int nsplits, int dtype);
-int dihip_fused_attnmerge_gemm_addto(void* stream, int wbits, const float* attn_partials, int nsplits,
-                                     int n_heads, const void* w_packed, const void* sz_packed,
-                                     const float* h_res, float* h_out, int M, int N, int K, int group_size,
-                                     void* ws, size_t ws_bytes, void* sync, int dtype);
+/* 3d. The front half of a decode layer in ONE launch (+ the split merge): RMSNorm + qkv GEMV (+bias) and Rotary + cache
+ * append + paged attention -- replaces dihip_fused_norm_gemm + dihip_span_attn_decode_fused, i.e. the reference's
+ * Gemm[A16W8|A16W4](qkv) + Rotary + DecOptMQA operators of one layer (qwen_v15.py:218-262, span_attn_op.cpp:90-169).
+ * The attention workgroups ride in the GEMV's launch: they resolve lengths / span pointers and pull their K / V tiles while
+ * the GEMV workgroups stream the weights, wait for the qkv row on a per-(request, KV group) counter and finish.  Results
+ * are bit-identical to the two calls it replaces (qkv row, span bytes, attention output).
+ *   h [M, K] f32 hidden stream, gamma FT [K]; w / sz packed qkv weight [(n + 2g) * 128 columns]; bias FT or NULL
+ *   qkv (out) FT [M, (n + 2g) * 128]; attn_out FT [M, n * 128]
+ *   ws >= dihip_decode_front_workspace_bytes (split partials); sync >= dihip_decode_front_sync_bytes, zeroed ONCE by the
+ *   caller (the launch leaves it zero)
+ * Covered (dihip_decode_front_supported == 1): M <= 4, bf16, 16-bit cache, head size 128, K a multiple of the k-tile, and a
+ * grid that is resident at once; otherwise the call returns DIHIP_PARAM_ERROR and the caller uses the two calls.  */
+size_t dihip_decode_front_sync_bytes(int batch, int n_groups);
+size_t dihip_decode_front_workspace_bytes(int batch, int n_heads, int n_groups, int max_seq_len);
+int dihip_decode_front_supported(int wbits, int M, int K, int group_size, int n_heads, int n_groups, int head_size,
+                                 int max_seq_len, int kv_mode, int dtype);
+int dihip_decode_front(void* stream, int wbits, const float* h, const void* gamma, float eps, const void* w_packed,
+                       const void* sz_packed, const void* bias, void* qkv, void* attn_out, int M, int K,
+                       int group_size, void* const* k_span_array, void* const* v_span_array,
+                       const uint32_t* old_seq_lens_dev, const float* rope_table, int n_heads, int n_groups,
+                       int head_size, int span_len, int n_spans_per_request, int max_seq_len, int kv_mode,
+                       int dtype, float qk_scale, void* ws, size_t ws_bytes, void* sync, size_t sync_bytes);
 
 /* =============================================================================================
  * 4. Prefill attention (replaces xformer_prefill_attention,

@@ -14,5 +14,5 @@ if sys.argv[1] == "allreduce":
     tp_loopback_lib.run_p2p_allreduce(int(sys.argv[2]))
 else:
     nranks, kv, batch, wbits, group, overlap = int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), bool(int(sys.argv[7]))
-    tp_loopback_lib.run_tp_decode(nranks, kv, batch, wbits, group, "p2p", overlap)
+    tp_loopback_lib.run_tp_decode(nranks, kv, batch, wbits, group, sys.argv[8] if len(sys.argv) > 8 else "p2p", overlap)
 print("P2P_WORKER_OK")

@@ -1,0 +1,61 @@
+"""The hand-counted `s_waitcnt vmcnt(N)` kernels against tools/audit_asm_loads.py (no GPU: it reads the built objects).
+
+The streaming GEMV issues its loads from inline asm; the compiler does not know their destinations are in flight.
+A build whose register allocation reads one of them before the wait is wrong on the GPU only some of the time --
+this catches the straight-line form of it at build time."""
+import glob
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("audit_asm_loads", os.path.join(ROOT, "tools", "audit_asm_loads.py"))
+audit_asm_loads = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(audit_asm_loads)
+
+OBJ_DIR = os.path.join(ROOT, "dash-infer_amd", "lib", "obj")
+OBJECTS = sorted(glob.glob(os.path.join(OBJ_DIR, "gemv_stream_inst_*.o"))) + [os.path.join(OBJ_DIR, "decode_front.o")]
+
+
+def test_the_tool_sees_a_read_before_the_wait_and_not_after():
+    early = [("global_load_dwordx4", "v[10:13], v1, s[2:3]"), ("global_load_dword", "v20, v1, s[4:5]"),
+             ("v_mov_b32_e32", "v30, v11"),            # copy of a register still in flight
+             ("s_waitcnt", "vmcnt(1)"),
+             ("v_add_f32_e32", "v31, v10, v12"),        # the x4 load has landed (one newer load may be outstanding)
+             ("v_mov_b32_e32", "v32, v20"),             # the newer one has not
+             ("s_waitcnt", "vmcnt(0)"), ("v_mov_b32_e32", "v33, v20")]
+    got = audit_asm_loads.audit_kernel("k", {"entry": early}, ["entry"])
+    assert sorted({f.split(":")[0] for f in got}) == ["k entry+2", "k entry+5"], got  # (both rules see the first one)
+    # an ALU write re-defines the register (the zero-filling arm of `valid ? load : 0`); a newer load may overwrite it
+    fine = [("global_load_dwordx4", "v[10:13], v1, s[2:3]"), ("v_mov_b32_e32", "v10, 0"), ("v_mov_b32_e32", "v11, v10"),
+            ("global_load_dwordx4", "v[10:13], v1, s[2:3]"), ("s_waitcnt", "vmcnt(0)"), ("v_mov_b32_e32", "v5, v12")]
+    assert not audit_asm_loads.audit_kernel("k", {"entry": fine}, ["entry"])
+
+
+def test_the_tool_follows_an_early_activation_load_across_blocks():
+    """the bug it was written for: batch 0 of the activations is loaded ahead of the ring fill, and the compiler resolved a
+    phi on those registers with copies placed before the wait (row 0 of a batch read before it had landed)"""
+    def kernel(copy_before_wait):
+        tail = [("v_mov_b64_e32", "v[84:85], v[56:57]"), ("s_waitcnt", "vmcnt(4)")]
+        return {"entry": [("global_load_dwordx4", "v[54:57], v3, s[40:41]"), ("s_cbranch_scc1", "L1")],
+                "L0": [("global_load_dwordx4", "v[10:13], v75, s[26:27] nt"), ("global_load_dword", "v2, v74, s[24:25]"), ("s_branch", "L2")],
+                "L1": [("global_load_dword", "v2, v1, s[18:19]"), ("global_load_dword", "v2, v1, s[18:19]")],
+                "L2": [("global_load_dwordx4", "v[14:17], v75, s[26:27] nt"), ("global_load_dword", "v3, v74, s[24:25]")],
+                "L3": tail if copy_before_wait else tail[::-1]}, ["entry", "L0", "L1", "L2", "L3"]
+    got = audit_asm_loads.audit_kernel("k", *kernel(True))
+    assert len(got) == 1 and "L3+0" in next(iter(got)) and "issued in entry" in next(iter(got)), got
+    assert not audit_asm_loads.audit_kernel("k", *kernel(False))
+    # a wait that leaves more operations outstanding than were issued since does not cover the load
+    blocks, order = kernel(False)
+    blocks["L3"] = [("s_waitcnt", "vmcnt(5)"), ("v_mov_b64_e32", "v[84:85], v[56:57]")]
+    assert len(audit_asm_loads.audit_kernel("k", blocks, order)) == 1
+
+
+@pytest.mark.skipif(not all(os.path.exists(o) for o in OBJECTS) or not os.path.exists(audit_asm_loads.OBJDUMP),
+                    reason="objects not built (python -c 'import __graft_entry__ as g; g.build()')")
+@pytest.mark.parametrize("obj", OBJECTS, ids=[os.path.basename(o) for o in OBJECTS])
+def test_no_register_is_read_while_its_load_is_in_flight(obj):
+    kernels, findings = audit_asm_loads.audit(obj)
+    assert kernels > 0
+    assert not findings, "\n".join(findings[:20])

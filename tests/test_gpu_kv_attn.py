@@ -366,70 +366,6 @@ def test_span_attention_frag32_output(ops, mode, B):
     assert torch.equal(ops.act_from_frag(fr, B, n * H).view(torch.int16), rm.view(torch.int16))
 
 
-# ------------------------------- partials-only attention + merge folded into the o-projection (3c) -----
-@pytest.mark.gpu
-@pytest.mark.parametrize("wbits,group", [(4, 128), (8, -1), (8, 128)])
-@pytest.mark.parametrize("n,g,S,lens", [(28, 4, 128, [2048]), (28, 4, 128, [2111]), (14, 2, 32, [0, 1, 31, 500]), (8, 8, 16, [77, 300]),
-                                        (4, 1, 64, [1000, 5, 64]), (40, 8, 128, [700, 2])])
-def test_attention_partials_merged_by_the_o_projection(ops, n, g, S, lens, wbits, group):
-    """dihip_span_attn_decode_fused_partials leaves split partials; dihip_fused_attnmerge_gemm_addto merges them in its
-    prologue.  (i) the spans are byte-identical to the two-launch form's; (ii) the merged row equals the two-launch
-    attention output to f32-accumulation accuracy and the oracle to 1e-2; (iii) h_out is BIT-identical to the o-projection
-    over the stand-alone merge of the same partials (the prologue repeats that kernel's arithmetic)."""
-    from oracle import glue, quant
-    rng = np.random.default_rng(n + S + len(lens))
-    H, ft, mode = 128, "bf16", "none"
-    B = len(lens)
-    pool, kv, ok, ov = build_batch(ops, rng, lens, n, g, H, S, mode, ft, extra_tokens=1)
-    pool2, kv2, _, _ = build_batch(ops, np.random.default_rng(n + S + len(lens)), lens, n, g, H, S, mode, ft, extra_tokens=1)
-    qkv = bf16_round(rng.normal(0, 1, (B, (n + 2 * g) * H)).astype(np.float32))
-    inv_d = torch.from_numpy(glue.rope_inv_freq(H, 1000000.0)).cuda()
-    old = torch.tensor(lens, dtype=torch.int32, device="cuda")
-    scale = 1.0 / np.sqrt(H)
-    max_len = max(lens) + 1
-    tab = ops.rope_table(inv_d, max_len + 3, H)
-    # two-launch form
-    ws = torch.empty(ops.span_attn_fused_workspace(B, n, g, H, max_len), dtype=torch.uint8, device="cuda")
-    ref_out = ops.span_attn_decode_fused(dev(qkv, ft), kv, old, tab, n, g, H, max_len, scale, ws)
-    # partials-only form
-    ns, nbytes = ops.span_attn_partials_plan(B, n, g, max_len, mode, torch.bfloat16)
-    assert 1 <= ns <= 8 and nbytes == B * n * ns * 132 * 4
-    partials = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device="cuda")
-    junk = torch.ones(1024 * 1024 + 8, dtype=torch.uint8, device="cuda")
-    ops.span_attn_set_next_prefetch([junk])  # prefetch workgroups ride on the launch: results must not change
-    ops.span_attn_decode_fused_partials(dev(qkv, ft), kv2, old, tab, n, g, H, max_len, scale, partials)
-    torch.cuda.synchronize()
-    for b in range(B):
-        for i in range(len(kv.k_idx[b])):
-            assert torch.equal(pool.span_view(kv.k_idx[b][i]), pool2.span_view(kv2.k_idx[b][i])), f"K span {b}/{i}"
-            assert torch.equal(pool.span_view(kv.v_idx[b][i]), pool2.span_view(kv2.v_idx[b][i])), f"V span {b}/{i}"
-    merged = ops.span_attn_merge_partials(partials, B, n, ns)
-    np.testing.assert_allclose(merged.float().cpu().numpy(), ref_out.float().cpu().numpy(), rtol=1e-2, atol=2.5e-3)
-    heads = qkv[:, : (n + g) * H].reshape(B, n + g, H)
-    rot = bf16_round(glue.rope(heads, np.array(lens, np.int32), glue.rope_inv_freq(H, 1000000.0)))
-    ref = []
-    for b, L in enumerate(lens):
-        ok[b].write(L, rot[b, n:])
-        ov[b].write(L, qkv[b, (n + g) * H:].reshape(g, H))
-        ref.append(attention.decode_attention(rot[b, :n], ok[b].read_all(L + 1), ov[b].read_all(L + 1), scale))
-    np.testing.assert_allclose(merged.float().cpu().numpy().reshape(B, n, H), np.stack(ref), rtol=1e-2, atol=2.5e-3)
-    # o-projection over the partials == o-projection over the merged row, bit for bit
-    K, N = n * H, (3584 if n == 28 else 1024)  # n = 28: the Qwen2-7B o-projection (224 single-tile workgroups)
-    W = bf16_round(rng.normal(0, 0.05, (K, N)).astype(np.float32))
-    qw, sw, zw = (quant.iq_quantize_a16w8 if wbits == 8 else quant.iq_quantize_a16w4)(W, group, ft)
-    pw = ops.pack_lowp(torch.from_numpy(qw).cuda(), dev(sw, ft), dev(zw, ft), group, wbits)
-    sc = ops.Scratch(ops.lowp_workspace_bytes(wbits, B, N, K, group))
-    h_res = torch.from_numpy(rng.normal(0, 1, (B, N)).astype(np.float32)).cuda()
-    want = ops.fused_gemm_addto(merged, pw, h_res, sc, M=B)
-    got = ops.fused_attnmerge_gemm_addto(partials, ns, n, pw, h_res, sc, M=B)
-    torch.cuda.synchronize()
-    assert torch.equal(want, got), f"max diff {(want - got).abs().max().item():.3e}"
-    # no residual (row-parallel TP ranks other than 0)
-    want0 = ops.fused_gemm_addto(merged, pw, None, sc, M=B)
-    got0 = ops.fused_attnmerge_gemm_addto(partials, ns, n, pw, None, sc, M=B)
-    assert torch.equal(want0, got0)
-
-
 # ------------------------------------------------------------- long contexts (reference: up to 128 000 tokens) -----
 def _random_span_bytes(rng, nspans, g, S, H, mode):
     """Span images with plausible contents written directly (a Python codec loop over 131 072 tokens would take minutes):
@@ -470,3 +406,55 @@ def test_span_attention_long_context(ops, L, mode):
     ref = cbind.span_attn_decode(q[0], [kb[i] for i in range(nspans)], [vb[i] for i in range(nspans)], L, n, g, H, S, mode, ft, scale)
     # averaging 10^5 random rows leaves outputs of 1e-2 ... 2e-1: the bound is relative to the output scale
     np.testing.assert_allclose(out[0], ref, rtol=2e-2, atol=1e-2 * float(np.abs(ref).max()))
+
+
+# ------------------------------------------- front half of a decode layer in one launch (3d) -----
+@pytest.mark.gpu
+@pytest.mark.parametrize("wbits,group", [(4, 128), (8, -1)])
+@pytest.mark.parametrize("n,g,S,lens,K", [(28, 4, 128, [2048], 3584), (28, 4, 128, [2111], 3584), (14, 2, 32, [0, 1, 31, 500], 896),
+                                          (8, 8, 16, [77, 300], 1024), (4, 1, 64, [1000, 5, 64], 1024), (3, 1, 16, [5, 0], 384)])
+def test_decode_front_equals_the_two_calls_it_replaces(ops, n, g, S, lens, K, wbits, group):
+    """dihip_decode_front (RMSNorm + qkv GEMV + Rotary + append + attention in one launch: attention workgroups wait for the
+    GEMV workgroups of the same launch) == dihip_fused_norm_gemm + dihip_span_attn_decode_fused, BIT for bit: qkv row, span
+    bytes, attention output; repeated launches on the same sync words (they must be left zero); and both agree with the
+    oracle through the separate-call tests above."""
+    from oracle import glue, quant
+    rng = np.random.default_rng(n + S + len(lens) + wbits)
+    H, ft, mode = 128, "bf16", "none"
+    B = len(lens)
+    N = (n + 2 * g) * H
+    pool, kv, _, _ = build_batch(ops, rng, lens, n, g, H, S, mode, ft, extra_tokens=3)
+    pool2, kv2, _, _ = build_batch(ops, np.random.default_rng(n + S + len(lens) + wbits), lens, n, g, H, S, mode, ft, extra_tokens=3)
+    W = bf16_round(rng.normal(0, 0.05, (K, N)).astype(np.float32))
+    qw, sw, zw = (quant.iq_quantize_a16w8 if wbits == 8 else quant.iq_quantize_a16w4)(W, group, ft)
+    pw = ops.pack_lowp(torch.from_numpy(qw).cuda(), dev(sw, ft), dev(zw, ft), group, wbits)
+    bias = dev(bf16_round(rng.normal(0, 0.1, N).astype(np.float32)), ft)
+    gamma = dev(bf16_round(1 + rng.normal(0, 0.1, K).astype(np.float32)), ft)
+    inv_d = torch.from_numpy(glue.rope_inv_freq(H, 1000000.0)).cuda()
+    max_len = max(lens) + 4
+    tab = ops.rope_table(inv_d, max_len + 3, H)
+    scale = 1.0 / np.sqrt(H)
+    assert ops.decode_front_supported(pw, B, n, g, H, max_len, mode, torch.bfloat16)
+    sc = ops.Scratch(ops.lowp_workspace_bytes(wbits, B, N, K, group))
+    ws = torch.empty(ops.span_attn_fused_workspace(B, n, g, H, max_len), dtype=torch.uint8, device="cuda")
+    ws2 = torch.empty(int(ops.lib().dihip_decode_front_workspace_bytes(B, n, g, max_len)), dtype=torch.uint8, device="cuda")
+    sync = torch.zeros(int(ops.lib().dihip_decode_front_sync_bytes(B, g)), dtype=torch.uint8, device="cuda")
+    old = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    old2 = old.clone()
+    for step in range(3):
+        h = torch.from_numpy(rng.normal(0, 1, (B, K)).astype(np.float32)).cuda()
+        qkv_ref = ops.fused_norm_gemm(h, gamma, 1e-6, pw, bias, sc)
+        out_ref = ops.span_attn_decode_fused(qkv_ref, kv, old, tab, n, g, H, max_len, scale, ws)
+        qkv = torch.full((B, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        out = torch.full((B, n * H), float("nan"), dtype=torch.bfloat16, device="cuda")
+        ops.decode_front(h, gamma, 1e-6, pw, bias, kv2, old2, tab, n, g, H, max_len, scale, ws2, sync, qkv, out)
+        torch.cuda.synchronize()
+        assert torch.equal(qkv.view(torch.int16), qkv_ref.view(torch.int16)), f"step {step}: qkv row differs"
+        assert torch.equal(out.view(torch.int16), out_ref.view(torch.int16)), f"step {step}: attention output differs"
+        assert int(sync.view(torch.int32).abs().sum()) == 0, "the launch must leave its sync words zero"
+        for b in range(B):
+            for i in range(len(kv.k_idx[b])):
+                assert torch.equal(pool.span_view(kv.k_idx[b][i]), pool2.span_view(kv2.k_idx[b][i])), f"K span {b}/{i}"
+                assert torch.equal(pool.span_view(kv.v_idx[b][i]), pool2.span_view(kv2.v_idx[b][i])), f"V span {b}/{i}"
+        old += 1
+        old2 += 1

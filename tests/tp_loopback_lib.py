@@ -1,5 +1,6 @@
 """Library of the tensor-parallel loop-back tests (tests/test_gpu_tp_loopback.py, tests/p2p_worker.py): the ranks of a TP
 group as threads of one process on one GPU.  See test_gpu_tp_loopback.py."""
+import os
 import threading
 
 import numpy as np
@@ -218,6 +219,8 @@ def run_tp_decode(nranks, kv_mode, batch, wbits, group, comm_kind, overlap):
         for r in range(1, nranks):
             assert np.array_equal(results[r][t][1], ids_tp)            # every rank holds the same next token
         ref_logits, ref_ids = ref[t]
+        if os.environ.get("DIHIP_TP_TEST_VERBOSE"):
+            print("step", t, "row max err", np.abs(logits - ref_logits).max(axis=1), "ids", ids_tp, ref_ids, flush=True)
         np.testing.assert_allclose(logits, ref_logits, rtol=0, atol=tol)
         top2 = np.sort(ref_logits, axis=-1)[:, -2:]
         sure = (top2[:, 1] - top2[:, 0]) > 2 * tol
