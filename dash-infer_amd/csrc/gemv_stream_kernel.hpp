@@ -221,7 +221,7 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
   // the wait in the prologue, never assigned again.  (They used to be re-loaded for the later rows: two definitions make a
   // phi, the compiler resolves a phi with register copies wherever it likes -- it put them BEFORE the wait, and row 0 of a
   // batch was now and then read before it had landed.  tools/audit_asm_loads.py checks the build for this.)
-  // Every later batch (rows > 0, rows longer than one batch) uses fetch_batch: loads the compiler tracks itself.
+  // Every later batch (rows > 0, rows longer than one batch) goes through fetch_batch into registers of its own.
   const int Kp = a.KT * KTILE;  // == K (host contract)
   const int nvec = Kp >> 3;
   constexpr int NE = PRO == PRO_RMSNORM ? 2 : 8;  // vectors per thread per batch
@@ -250,6 +250,8 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
       }
     }
   }
+  // (asm loads as well, waited for on the spot: loads the compiler tracks itself make it guard every later re-use of their
+  // registers with `s_waitcnt vmcnt(0)` -- also on the paths that never issued them, which drained the ring before the main loop)
   auto fetch_batch = [&](int r, int v0, u32x4_t (&V)[NV], u32x4_t (&G)[NG]) {
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
@@ -261,16 +263,21 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
         }
         continue;
       }
-      const size_t i = (size_t)min(v0 + j * GEMV_THREADS + tid, nvec - 1);
+      const uint32_t i = (uint32_t)min(v0 + j * GEMV_THREADS + tid, nvec - 1);
       if constexpr (PRO == PRO_RMSNORM) {
-        const u32x4_t* hrow = reinterpret_cast<const u32x4_t*>(reinterpret_cast<const float*>(p_x) + (size_t)r * a.ldx);
-        V[2 * j] = hrow[2 * i];
-        V[2 * j + 1] = hrow[2 * i + 1];
-        G[j] = reinterpret_cast<const u32x4_t*>(a.gamma)[i];
+        const float* hrow = reinterpret_cast<const float*>(p_x) + (size_t)r * a.ldx;
+        stream_load_plain_b128(V[2 * j], hrow, i * 32u);
+        stream_load_plain_b128(V[2 * j + 1], hrow, i * 32u + 16u);
+        stream_load_plain_b128(G[j], a.gamma, i * 16u);
       } else {
-        V[j] = reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(p_x) + (size_t)r * a.ldx)[i];
+        stream_load_plain_b128(V[j], reinterpret_cast<const uint16_t*>(p_x) + (size_t)r * a.ldx, i * 16u);
       }
     }
+    stream_wait<0>();
+#pragma unroll
+    for (int j = 0; j < NV; ++j) early_landed(V[j]);
+#pragma unroll
+    for (int j = 0; j < NG; ++j) early_landed(G[j]);
   };
   DIHIP_GEMV_STAMP(7);
 
@@ -338,10 +345,13 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
       isp = stile;                                                   \
     }                                                                \
   } while (0)
-  // (tail) dummy loads that keep the vmcnt arithmetic uniform: one L2-resident line, never used
+  // (tail) dummy loads that keep the vmcnt arithmetic uniform: one L2-resident line, never used.  They go INTO the slot's
+  // own registers, like a real chunk: a load into a scratch variable is a dead definition, the compiler hands its register
+  // to the next value that needs one, and the load lands on top of that value whenever it arrives (it was the zero the
+  // accumulators are reset from).  The slots are kept alive up to the final wait below for the same reason.
 #define DIHIP_GEMV_DUMMY(SLOT)                                       \
   do {                                                               \
-    stream_load_b32(sb[SLOT], dummy_w, 0u);                          \
+    stream_load_b128(wb[SLOT], dummy_w, 0u);                         \
     if constexpr (QUANT) stream_load_b32(sb[SLOT], dummy_w, 0u);     \
   } while (0)
 #pragma unroll
@@ -593,6 +603,8 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
   }
   // the ring registers die here: no load may still be in flight into them
   stream_wait<0>();
+#pragma unroll
+  for (int j = 0; j < D; ++j) asm volatile("" ::"v"(wb[j]), "v"(sb[j]));  // (alive until here: see DIHIP_GEMV_DUMMY)
 #undef DIHIP_GEMV_ISSUE
 #undef DIHIP_GEMV_DUMMY
 #undef DIHIP_GEMV_CONSUME

@@ -27,10 +27,12 @@ def test_the_tool_sees_a_read_before_the_wait_and_not_after():
              ("s_waitcnt", "vmcnt(0)"), ("v_mov_b32_e32", "v33, v20")]
     got = audit_asm_loads.audit_kernel("k", {"entry": early}, ["entry"])
     assert sorted({f.split(":")[0] for f in got}) == ["k entry+2", "k entry+5"], got  # (both rules see the first one)
-    # an ALU write re-defines the register (the zero-filling arm of `valid ? load : 0`); a newer load may overwrite it
-    fine = [("global_load_dwordx4", "v[10:13], v1, s[2:3]"), ("v_mov_b32_e32", "v10, 0"), ("v_mov_b32_e32", "v11, v10"),
-            ("global_load_dwordx4", "v[10:13], v1, s[2:3]"), ("s_waitcnt", "vmcnt(0)"), ("v_mov_b32_e32", "v5, v12")]
-    assert not audit_asm_loads.audit_kernel("k", {"entry": fine}, ["entry"])
+    # the zero-filling arm of `valid ? load : 0` is another path; a newer load may take the same destination
+    arms = {"entry": [("s_cbranch_scc1", "L1")],
+            "L0": [("global_load_dwordx4", "v[10:13], v1, s[2:3]"), ("global_load_dwordx4", "v[10:13], v1, s[2:3]"), ("s_branch", "L2")],
+            "L1": [("v_mov_b32_e32", "v10, 0"), ("v_mov_b32_e32", "v11, v10")],
+            "L2": [("s_waitcnt", "vmcnt(0)"), ("v_mov_b32_e32", "v5, v12")]}
+    assert not audit_asm_loads.audit_kernel("k", arms, ["entry", "L0", "L1", "L2"])
 
 
 def test_the_tool_follows_an_early_activation_load_across_blocks():
@@ -50,6 +52,18 @@ def test_the_tool_follows_an_early_activation_load_across_blocks():
     blocks, order = kernel(False)
     blocks["L3"] = [("s_waitcnt", "vmcnt(5)"), ("v_mov_b64_e32", "v[84:85], v[56:57]")]
     assert len(audit_asm_loads.audit_kernel("k", blocks, order)) == 1
+
+
+def test_the_tool_sees_a_load_landing_on_a_register_given_to_another_value():
+    """the tail's dummy loads went into a scratch variable: a dead definition, so the compiler reused the register (for the
+    zero the accumulators are reset from) while the load was still on its way"""
+    blocks = {"entry": [("global_load_dword", "v51, v50, s[40:41]"), ("global_load_dword", "v76, v50, s[40:41]"), ("s_branch", "L1")],
+              "L1": [("s_waitcnt", "vmcnt(14)"), ("v_mov_b32_e32", "v51, v50"), ("v_mov_b64_e32", "v[44:45], v[50:51]"), ("s_waitcnt", "vmcnt(0)")]}
+    got = audit_asm_loads.audit_kernel("k", blocks, ["entry", "L1"])
+    assert len(got) == 1 and "L1+1" in next(iter(got)) and "yet to land" in next(iter(got)), got
+    # into the slot's own registers, untouched until the wait: fine
+    blocks["entry"][0] = ("global_load_dwordx4", "v[2:5], v50, s[40:41] nt")
+    assert not audit_asm_loads.audit_kernel("k", blocks, ["entry", "L1"])
 
 
 @pytest.mark.skipif(not all(os.path.exists(o) for o in OBJECTS) or not os.path.exists(audit_asm_loads.OBJDUMP),

@@ -75,7 +75,12 @@ def step(state, mn, ops, where, findings):
     for dest, text in state:
         if dest & reads:
             findings.add("%s: `%s %s` reads a register of `%s` still in flight" % (where, mn, ops, text))
-    if writes:  # an ALU write re-defines the register on this path (it is dead as a load destination there)
+    if writes:
+        # inside one block there is no other arm: the compiler took the destination for dead (a load whose result is
+        # never read -- the tail's dummy loads) and gave the register to something else; the load lands on top of it
+        for dest, text in state:
+            if dest & writes:
+                findings.add("%s: `%s %s` writes a register `%s` has yet to land in" % (where, mn, ops, text))
         state = tuple((d - writes, t) for d, t in state)
     if is_load:
         dest = frozenset() if "lds" in ops.split() else frozenset(regs_of(parts[0]))
@@ -106,16 +111,25 @@ def is_vmem(mn):
     return mn.startswith(LOADS) or mn.startswith(STORES) or mn.startswith(ATOMICS)
 
 
-def audit_early_loads(name, blocks, order, findings):
-    """The activation loads issued ahead of the ring fill (`global_load_dwordx4` without `nt`): from each one, every path
-    forward until a wait that provably covers it -- `vmcnt(N)` with N <= the VMEM operations issued on the path since --
-    must not read its destination.  (The ring fill between has two arms per slot, real chunk or dummy, with the same
-    number of loads each, so the count is the same on every path and the walk stays linear.)"""
+def audit_loads_forward(name, blocks, order, findings):
+    """Every `global_load`, every path forward from it, until a wait that provably covers it -- `vmcnt(N)` with N <= the VMEM
+    operations issued on the path since (the ring fill has two arms per slot, real chunk or dummy, with the same number of
+    loads each, so the count does not depend on the path) -- or until a newer load takes the same destination:
+      * nothing else may WRITE the destination: the compiler only does that when it takes the load's result for dead (a load
+        into a scratch variable -- the tail's dummy loads were that) and has given the register to another value, which the
+        data then lands on top of (it was the zero the accumulators are reset from);
+      * the activation loads issued ahead of the ring fill (`global_load_dwordx4` without `nt`) may not be READ either.  For the
+        ring loads a read ends the walk instead: the unrolled main loop has paths that cannot execute (the compiler keeps "real
+        refill or dummy" in a scalar flag tested two blocks later), on which the counted waits look too weak; their
+        consumption is straight-line `wait, consume, refill` code, which rule (1) checks exactly."""
     succ = successors(blocks, order)
     for lab in order:
         for n, (mn, ops) in enumerate(blocks[lab]):
-            if not (mn == "global_load_dwordx4" and " nt" not in " " + ops):
+            # the hand-issued loads all use the scalar-base form `vDst, vOff, s[base]`; a load the compiler emits with `off`
+            # addressing is one it tracks (and waits for) itself
+            if not mn.startswith("global_load") or "lds" in ops.split() or ", s[" not in ops:
                 continue
+            early = mn == "global_load_dwordx4" and " nt" not in " " + ops
             dest0 = frozenset(regs_of(ops.split(",")[0]))
             text = mn + " " + ops
             seen = set()
@@ -133,19 +147,29 @@ def audit_early_loads(name, blocks, order, findings):
                             break
                         continue
                     parts = o2.split(",", 1)
-                    load = m2.startswith(LOADS)
-                    no_dest = m2.startswith(STORES + ("ds_write", "ds_store", "s_", "v_cmp", "v_cmpx", "v_nop", "v_readfirstlane", "v_readlane"))
+                    no_dest = m2.startswith(NO_DEST)
                     reads = regs_of(o2 if no_dest else (parts[1] if len(parts) > 1 else ""))
                     if dest & reads:
-                        findings.add("%s %s+%d: `%s %s` reads a register of `%s` (issued in %s) before a wait covers it"
-                                     % (name, b, k, m2, o2, text, lab))
-                    if not no_dest:  # re-defined on this path (ALU write, or a newer load into the same register)
-                        dest = dest - frozenset(regs_of(parts[0]))
+                        if early:
+                            findings.add("%s %s+%d: `%s %s` reads a register of `%s` (issued in %s) before a wait covers it"
+                                         % (name, b, k, m2, o2, text, lab))
+                        else:
+                            closed = True
+                            break
+                    if not no_dest:
+                        hit = dest & frozenset(regs_of(parts[0]))
+                        if hit and not m2.startswith(LOADS):
+                            findings.add("%s %s+%d: `%s %s` writes a register `%s` (issued in %s) has yet to land in"
+                                         % (name, b, k, m2, o2, text, lab))
+                        dest = dest - hit
                         if not dest:
                             closed = True
                             break
                     if is_vmem(m2):
                         c += 1
+                    if m2 == "s_endpgm":
+                        closed = True
+                        break
                 if closed:
                     continue
                 for t in succ[b]:
@@ -155,17 +179,20 @@ def audit_early_loads(name, blocks, order, findings):
                         work.append((t, 0, c, dest))
 
 
+NO_DEST = STORES + ("ds_write", "ds_store", "s_", "v_cmp", "v_cmpx", "v_nop", "v_readfirstlane", "v_readlane")
+
+
 def audit_kernel(name, blocks, order):
     """blocks: {label: [(mnemonic, operands)]}, order: labels in layout order -> set of findings.
     (1) Each basic block on its own, starting from an empty in-flight list: inside a block the vmcnt arithmetic is exact
     for the loads the block itself issued, so every finding is real; what is carried in from other blocks is not seen.
-    (2) The early activation loads across blocks: audit_early_loads."""
+    (2) Across blocks: audit_loads_forward."""
     findings = set()
     for lab in order:
         state = ()
         for n, (mn, ops) in enumerate(blocks[lab]):
             state = step(state, mn, ops, "%s %s+%d" % (name, lab, n), findings)
-    audit_early_loads(name, blocks, order, findings)
+    audit_loads_forward(name, blocks, order, findings)
     return findings
 
 
