@@ -49,6 +49,10 @@ __device__ __forceinline__ void stream_load_b128(u32x4_t& dst, const void* sbase
 __device__ __forceinline__ void stream_load_b32(uint32_t& dst, const void* sbase, uint32_t voff) {
   asm volatile("global_load_dword %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase));
 }
+// a second load into the SAME register (read-write operand: the register's current value is not dead)
+__device__ __forceinline__ void stream_reload_b32(uint32_t& dst, const void* sbase, uint32_t voff) {
+  asm volatile("global_load_dword %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(sbase));
+}
 __device__ __forceinline__ void stream_load_plain_b128(u32x4_t& dst, const void* sbase, uint32_t voff) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase));
 }
@@ -345,14 +349,19 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
       isp = stile;                                                   \
     }                                                                \
   } while (0)
-  // (tail) dummy loads that keep the vmcnt arithmetic uniform: one L2-resident line, never used.  They go INTO the slot's
-  // own registers, like a real chunk: a load into a scratch variable is a dead definition, the compiler hands its register
-  // to the next value that needs one, and the load lands on top of that value whenever it arrives (it was the zero the
-  // accumulators are reset from).  The slots are kept alive up to the final wait below for the same reason.
+  // (tail) dummy loads that keep the vmcnt arithmetic uniform: one L2-resident word each, never used.  Both go into the
+  // slot's scale register -- the second one as a read-write operand, so that the first is not a dead definition -- and the
+  // slots stay alive up to the final wait below.  (A load into a dead variable gets whatever register is free; the compiler
+  // hands that register to the next value that needs one, and the load lands on top of it whenever it arrives: it was the
+  // zero the accumulators are reset from.)
 #define DIHIP_GEMV_DUMMY(SLOT)                                       \
   do {                                                               \
-    stream_load_b128(wb[SLOT], dummy_w, 0u);                         \
-    if constexpr (QUANT) stream_load_b32(sb[SLOT], dummy_w, 0u);     \
+    if constexpr (QUANT) {                                           \
+      stream_load_b32(sb[SLOT], dummy_w, 0u);                        \
+      stream_reload_b32(sb[SLOT], dummy_w, 0u);                      \
+    } else {                                                         \
+      stream_load_b128(wb[SLOT], dummy_w, 0u); /* no scale word */   \
+    }                                                                \
   } while (0)
 #pragma unroll
   for (int j = 0; j < D; ++j) {
