@@ -87,7 +87,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const At
   const int h0 = grp * a.hpg + hc * HC;
   const int nh = min(HC, a.hpg - hc * HC);
 
-  const int len = (int)a.seq_lens[b];
+  const int len = (int)a.seq_lens[b] + a.len_bias;
   const int tps = ((len + a.nsplits - 1) / a.nsplits + 15) & ~15;
   const int t0 = split * tps;
   const int t1 = min(len, t0 + tps);
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
   const int h0 = grp * a.hpg + hc * HC;
   const int nh = min(HC, a.hpg - hc * HC);
 
-  const int len = (int)a.seq_lens[b];
+  const int len = (int)a.seq_lens[b] + a.len_bias;
   const int tps = ((len + a.nsplits - 1) / a.nsplits + 31) & ~31;
   const int t0 = split * tps;
   const int t1 = min(len, t0 + tps);
@@ -537,7 +537,7 @@ static bool span_len_valid(int S) { return S == 16 || S == 32 || S == 64 || S ==
 static int run_decode(hipStream_t s, void* out, const void* q, const void* const* ks, const void* const* vs,
                       const uint32_t* seq_lens_dev, int batch, int n, int g, int H, int S, int span_stride,
                       int max_seq_len, int mode, int dtype, float scale, void* ws, size_t ws_bytes, unsigned* counters,
-                      int num_cus, int out_layout = DIHIP_ACT_ROWMAJOR) {
+                      int num_cus, int out_layout = DIHIP_ACT_ROWMAJOR, int len_bias = 0) {
   if (H != 128) {
     set_last_error("span_attn: unsupported head size %d (only 128, dispatch.hpp:45-57)", H);
     return DIHIP_SA_PARAM_ERROR;
@@ -562,6 +562,7 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
   a.kspans = ks;
   a.vspans = vs;
   a.seq_lens = seq_lens_dev;
+  a.len_bias = len_bias;
   a.partials = reinterpret_cast<float*>(ws);
   static int ticket_max = -1;  // DIHIP_ATTN_TICKET_MAX_WGS: in-kernel last-arriver merge up to this many workgroups (0 = never)
   if (ticket_max < 0) {
@@ -803,6 +804,26 @@ size_t dihip_span_attn_decode_workspace_bytes(int batch, int n_heads, int head_s
   }
   return worst + 256;
 }
+
+}  // extern "C"
+
+namespace dihip {
+int span_attn_decode_biased(void* stream, void* output, const void* query, const void* const* k_span_array,
+                            const void* const* v_span_array, const uint32_t* seq_lens_dev, int len_bias, int batch, int n_heads,
+                            int n_groups, int span_len, int n_spans_per_request, int max_seq_len, int kv_mode, int dtype,
+                            float qk_scale, void* ws, size_t ws_bytes) {
+  const int st = run_decode(reinterpret_cast<hipStream_t>(stream), output, query, k_span_array, v_span_array, seq_lens_dev, batch,
+                            n_heads, n_groups, 128, span_len, n_spans_per_request, max_seq_len, kv_mode, dtype, qk_scale, ws,
+                            ws_bytes, nullptr, 0, DIHIP_ACT_ROWMAJOR, len_bias);
+  if (st == DIHIP_SA_SUCCESS) return DIHIP_SUCCESS;
+  return st == DIHIP_SA_PARAM_ERROR ? DIHIP_PARAM_ERROR : DIHIP_RUNTIME_ERROR;
+}
+size_t span_attn_decode_workspace_bytes(int batch, int n_heads, int n_groups, int max_seq_len, int kv_mode, int dtype) {
+  return attn_plan(batch, n_heads, n_groups, max_seq_len, 0, attn_use_mfma(kv_mode, dtype)).partial_bytes;
+}
+}  // namespace dihip
+
+extern "C" {
 
 int dihip_span_attn_decode(void* stream, void* output, const void* query, const void* const* k_span_array,
                            const void* const* v_span_array, const uint32_t* seq_lens_dev, int batch, int n_heads,

@@ -36,6 +36,7 @@ struct AttnArgs {
   unsigned* front_done;
   unsigned front_target;
   int front_presleep;     // s_sleep(127) repetitions before the first poll (the GEMV cannot be done earlier)
+  int len_bias;           // sequence length = seq_lens[b] + len_bias (decode step on the op-boundary kernels: lengths BEFORE the append, + 1)
   int force_partials;     // write the block's partial record even for a single split and leave the merge to the consumer
                           // (decode_front.hip launches dihip_span_attn_merge_partials itself)
 };
@@ -47,6 +48,16 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
                          int span_len, int n_spans_per_request, int max_seq_len, int kv_mode, int dtype, float qk_scale, void* ws,
                          size_t ws_bytes, bool* handled);
 size_t span_attn_fused_mfma_workspace_bytes(int batch, int n_heads, int n_groups, int max_seq_len);
+// the op-boundary decode kernels (span_attn.hip: run_decode) on lengths seq_lens[b] + len_bias; returns a DIHIP status
+int span_attn_decode_biased(void* stream, void* output, const void* query, const void* const* k_span_array,
+                            const void* const* v_span_array, const uint32_t* seq_lens_dev, int len_bias, int batch, int n_heads,
+                            int n_groups, int span_len, int n_spans_per_request, int max_seq_len, int kv_mode, int dtype,
+                            float qk_scale, void* ws, size_t ws_bytes);
+size_t span_attn_decode_workspace_bytes(int batch, int n_heads, int n_groups, int max_seq_len, int kv_mode, int dtype);
+// Rotary (cos / sin from the dihip_rope_table table) + cache append + rotated q, as dihip_rope_kv_append (span_cache.hip)
+int rope_table_kv_append(void* stream, void* const* k_spans, void* const* v_spans, void* q_out, const void* qkv,
+                         const uint32_t* old_seq_lens, const float* rope_table, int batch, int num_heads, int num_groups,
+                         int span_len, int span_stride, int kv_mode, int dtype);
 
 // sum over the 16 lanes of a DPP row (all 16 lanes receive the total)
 __device__ __forceinline__ float row16_sum(float v) {

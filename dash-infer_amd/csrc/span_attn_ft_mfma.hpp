@@ -199,7 +199,7 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   const int nh = min(HC, a.hpg - hc * HC);
   unsigned char* vt = smem + wave * (MF_TOK * MF_VPITCH);
 
-  const int len = (int)a.seq_lens[b] + (FUSED ? 1 : 0);
+  const int len = (int)a.seq_lens[b] + (FUSED ? 1 : a.len_bias);
   const int newpos = len - 1;  // FUSED: position of this step's token
   const int tps = ((len + a.nsplits - 1) / a.nsplits + 31) & ~31;
   const int t0 = split * tps;

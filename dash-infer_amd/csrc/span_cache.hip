@@ -151,7 +151,7 @@ template <int FT, int MODE>
 __global__ __launch_bounds__(64) void rope_kv_append_kernel(void* const* k_spans, void* const* v_spans, void* q_out,
                                                             const void* qkv, const uint32_t* old_seq_lens,
                                                             const float* __restrict__ inv_freq, int n, int g, int S,
-                                                            int span_stride) {
+                                                            int span_stride, const float* __restrict__ rope_tab = nullptr) {
   constexpr int EPL = 2, H = 128;
   const int b = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
   const size_t row = (size_t)b * (n + 2 * g) * H;
@@ -159,7 +159,16 @@ __global__ __launch_bounds__(64) void rope_kv_append_kernel(void* const* k_spans
   // lane holds d = 2*lane, 2*lane+1; the rotate-half partner (d +- 64) lives in lane ^ 32
   float cs[EPL], sn[EPL];
 #pragma unroll
-  for (int i = 0; i < EPL; ++i) rope_sincos(old_len, inv_freq[(lane * EPL + i) & 63], &sn[i], &cs[i]);
+  for (int i = 0; i < EPL; ++i) {
+    // rope_tab: the same values, precomputed per position by dihip_rope_table ({cos, sin} pairs, 64 per position)
+    if (rope_tab) {
+      const float2 t = reinterpret_cast<const float2*>(rope_tab)[(size_t)old_len * 64 + ((lane * EPL + i) & 63)];
+      cs[i] = t.x;
+      sn[i] = t.y;
+    } else {
+      rope_sincos(old_len, inv_freq[(lane * EPL + i) & 63], &sn[i], &cs[i]);
+    }
+  }
   auto rotate = [&](float (&x)[EPL]) {
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
@@ -368,3 +377,21 @@ int dihip_span_scatter(void* stream, void* const* spans, const void* src_cont, i
 }
 
 }  // extern "C"
+
+namespace dihip {
+int rope_table_kv_append(void* stream, void* const* k_spans, void* const* v_spans, void* q_out, const void* qkv,
+                         const uint32_t* old_seq_lens, const float* rope_table, int batch, int num_heads, int num_groups,
+                         int span_len, int span_stride, int kv_mode, int dtype) {
+  DIHIP_REQUIRE(k_spans && v_spans && q_out && qkv && old_seq_lens && rope_table, DIHIP_PARAM_ERROR, "rope_table_kv_append: null pointer");
+  if (batch == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const bool ok = kv_dispatch(dtype, kv_mode, 128, [&](auto ftc, auto mc, auto ec) {
+    constexpr int FT = decltype(ftc)::value, MODE = decltype(mc)::value;
+    (void)ec;
+    hipLaunchKernelGGL((rope_kv_append_kernel<FT, MODE>), dim3(batch, num_heads), dim3(64), 0, s, k_spans, v_spans, q_out, qkv,
+                       old_seq_lens, static_cast<const float*>(nullptr), num_heads, num_groups, span_len, span_stride, rope_table);
+  });
+  if (!ok) return DIHIP_PARAM_ERROR;
+  return launch_status();
+}
+}  // namespace dihip

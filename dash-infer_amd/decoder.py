@@ -361,12 +361,10 @@ class DecodeSession:
                                    dtype=torch.uint8, device=device)
         self.attn_sync = torch.zeros(int(lib().dihip_span_attn_sync_bytes(batch, self.n_loc)), dtype=torch.uint8, device=device)
         self.rope_tab = ops.rope_table(self.inv_freq, max_len + 1, H)
-        # Rotary + cache append + attention in one launch pair: the latency-bound regime (few requests:
-        # one wave per query head, no cross-wave reductions).  Large batches stream thousands of tokens
-        # per workgroup and use the row-sharing op-boundary kernels instead.
-        # (16-bit cache: the decode-step form runs on the matrix cores at every batch size; quantised caches have the
-        # MFMA kernels only at the op boundary, their decode-step form is the one-wave-per-head kernel)
-        self.fused_attention = kv_mode == "none" or batch * self.g_loc <= 64
+        # 16-bit cache: Rotary + cache append + attention in ONE launch (+ the split merge), both contractions on the matrix
+        # cores, at every batch size.  Quantised caches: the quantising append launch, then the matrix-core decode kernels
+        # (dihip_span_attn_decode_fused would issue the same two launches; the explicit pair also has the FRAG32 output).
+        self.fused_attention = kv_mode == "none"
         # batch <= 4, 16-bit cache: RMSNorm + qkv GEMV and Rotary + append + attention of a layer as ONE launch (the attention
         # workgroups resolve addresses and pull K / V while the GEMV streams, then wait for the qkv row): dihip_decode_front.
         # Bit-identical to the two calls and measured SLOWER (22.2 us vs 18.8 us per layer, 608 vs 640 tokens/s: the

@@ -274,6 +274,8 @@ size_t dihip_span_attn_sync_bytes(int batch, int n_heads);
  * kv_mode), attention runs over old_seq_lens[b] + 1 tokens.
  *   qkv        : FT [batch, (n + 2g) * H], pre-Rotary fused rows (16-byte aligned)
  *   rope_table : f32 [max_pos][H/2]{cos, sin} built once by dihip_rope_table
+ *   max_seq_len: upper bound of old_seq_lens[b] + 1 (sizes the split plan, as in 3)
+ * 16-bit cache: one launch (+ split merge); int8 / uint4 cache: the append launch, then the decode kernels of 3.
  *   ws         : >= dihip_span_attn_fused_workspace_bytes(...) (contents need no initialisation)  */
 int dihip_rope_table(void* stream, float* table, const float* inv_freq, int max_pos, int head_size);
 size_t dihip_span_attn_fused_workspace_bytes(int batch, int n_heads, int n_groups, int head_size,
