@@ -1255,6 +1255,14 @@ int dihip_fused_gemm_addto_norm(void* stream, int wbits, const void* x, const vo
   return launch_rmsnorm_rows(s, h_out, gamma, eps, M, N, xnorm, c.n_frag_mt);  // this plan has no slab reduction to ride on
 }
 
+// LayerNormNoBeta of the f32 hidden rows into FT rows, on its own (the MoE layer feeds four consumers from it)
+int dihip_rmsnorm_rows(void* stream, void* xnorm, const float* h, const void* gamma, float eps, int M, int K, int dtype) {
+  DIHIP_REQUIRE(M >= 0 && K > 0 && xnorm && h && gamma, DIHIP_PARAM_ERROR, "rmsnorm_rows: bad argument");
+  DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "rmsnorm_rows: bf16 rows only");
+  if (M == 0) return DIHIP_SUCCESS;
+  return launch_rmsnorm_rows(reinterpret_cast<hipStream_t>(stream), h, gamma, eps, M, K, xnorm, 0);
+}
+
 int dihip_prenorm_gemm(void* stream, int wbits, const void* xnorm, int x_layout, const void* w_packed, const void* sz_packed,
                        const void* bias, void* y, int M, int N, int K, int group_size, int act, void* ws, size_t ws_bytes,
                        void* sync, int dtype) {

@@ -35,7 +35,8 @@ __device__ __forceinline__ ScoreIdx better(ScoreIdx a, ScoreIdx b) {  // larger 
 // one wave per token: softmax over E <= 256 router logits, then top_k picks in descending order
 template <int FT>
 __global__ __launch_bounds__(64) void moe_route_kernel(float* __restrict__ scores, int* __restrict__ experts,
-                                                        const void* __restrict__ logits, int E, int top_k) {
+                                                        const void* __restrict__ logits, int E, int top_k, int ep_first,
+                                                        int ep_count) {
   const int t = blockIdx.x, lane = threadIdx.x;
   float v[4];
   float mx = -INFINITY;
@@ -63,7 +64,10 @@ __global__ __launch_bounds__(64) void moe_route_kernel(float* __restrict__ score
     for (int o = 32; o > 0; o >>= 1) best = better(best, ScoreIdx{__shfl_xor(best.v, o, 64), __shfl_xor(best.i, o, 64)});
     if (lane == 0) {
       scores[(size_t)t * top_k + k] = best.v;
-      experts[(size_t)t * top_k + k] = best.i;
+      // expert parallelism (moe_op.cpp:103-117: rank r owns experts [r * ep_num, (r + 1) * ep_num)): the index becomes the
+      // position in this rank's stack, -1 for an expert that lives elsewhere (its slot is skipped, its term arrives by all-reduce)
+      const int local = best.i - ep_first;
+      experts[(size_t)t * top_k + k] = (local >= 0 && local < ep_count) ? local : -1;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -103,6 +107,24 @@ __global__ __launch_bounds__(256) void moe_finalize_kernel(void* __restrict__ ou
   if (pair) store_ft<FT>(out, (size_t)t * cols + c + 1, a1);
 }
 
+// Tail of the reference's MoE layer graph (python/pyhie/allspark/model/qwen_v20_moe.py:366-382) in one pass over the rows:
+//   CalcExpert  c = shared_down * sigmoid_gate[t]   (calc_expert.cu:27-35; rounded to FT like the operator's output tensor)
+//   expert_add + final_add:  h_out = h_res + moe_out + c   in f32 (the decoder's residual stream is f32; h_res == nullptr on
+//   the ranks that do not carry the residual under tensor / expert parallelism: the sum over ranks happens in the all-reduce)
+template <int FT>
+__global__ __launch_bounds__(256) void moe_shared_combine_kernel(float* __restrict__ h_out, const float* __restrict__ h_res,
+                                                                 const void* __restrict__ moe_out, const void* __restrict__ shared_out,
+                                                                 const void* __restrict__ shared_gate, int cols) {
+  const int t = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const size_t i = (size_t)t * cols + c;
+  const float gate = load_ft<FT>(shared_gate, t);
+  const float calc = ft_round<FT>(load_ft<FT>(shared_out, i) * gate);
+  const float base = h_res ? h_res[i] : 0.f;
+  h_out[i] = (base + load_ft<FT>(moe_out, i)) + calc;
+}
+
 }  // namespace dihip
 
 using namespace dihip;
@@ -111,17 +133,24 @@ extern "C" {
 
 int dihip_moe_route(void* stream, const void* router_logits, int num_tokens, int num_experts, int top_k, float* scores,
                     int32_t* experts, int dtype) {
+  return dihip_moe_route_ep(stream, router_logits, num_tokens, num_experts, top_k, scores, experts, dtype, 0, num_experts);
+}
+
+int dihip_moe_route_ep(void* stream, const void* router_logits, int num_tokens, int num_experts, int top_k, float* scores,
+                       int32_t* experts, int dtype, int ep_first, int ep_count) {
+  DIHIP_REQUIRE(ep_first >= 0 && ep_count > 0 && ep_first + ep_count <= num_experts, DIHIP_PARAM_ERROR,
+                "moe_route: expert window [%d, %d) outside the %d experts", ep_first, ep_first + ep_count, num_experts);
   DIHIP_REQUIRE(num_tokens >= 0 && num_experts > 0 && num_experts <= 256 && top_k > 0 && top_k <= num_experts, DIHIP_PARAM_ERROR,
                 "moe_route: need 0 < top_k <= num_experts <= 256 (moe_op.cpp:69-73)");
   DIHIP_REQUIRE(router_logits && scores && experts, DIHIP_PARAM_ERROR, "moe_route: null pointer");
   if (num_tokens == 0) return DIHIP_SUCCESS;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == DIHIP_BF16)
-    hipLaunchKernelGGL(moe_route_kernel<DIHIP_BF16>, dim3(num_tokens), dim3(64), 0, s, scores, experts, router_logits, num_experts, top_k);
+    hipLaunchKernelGGL(moe_route_kernel<DIHIP_BF16>, dim3(num_tokens), dim3(64), 0, s, scores, experts, router_logits, num_experts, top_k, ep_first, ep_count);
   else if (dtype == DIHIP_F16)
-    hipLaunchKernelGGL(moe_route_kernel<DIHIP_F16>, dim3(num_tokens), dim3(64), 0, s, scores, experts, router_logits, num_experts, top_k);
+    hipLaunchKernelGGL(moe_route_kernel<DIHIP_F16>, dim3(num_tokens), dim3(64), 0, s, scores, experts, router_logits, num_experts, top_k, ep_first, ep_count);
   else if (dtype == DIHIP_F32)
-    hipLaunchKernelGGL(moe_route_kernel<DIHIP_F32>, dim3(num_tokens), dim3(64), 0, s, scores, experts, router_logits, num_experts, top_k);
+    hipLaunchKernelGGL(moe_route_kernel<DIHIP_F32>, dim3(num_tokens), dim3(64), 0, s, scores, experts, router_logits, num_experts, top_k, ep_first, ep_count);
   else
     DIHIP_REQUIRE(false, DIHIP_PARAM_ERROR, "moe_route: unsupported dtype %d", dtype);
   return launch_status();
@@ -158,6 +187,22 @@ int dihip_moe_experts(void* stream, int wbits, const void* x, const int32_t* exp
   if (st) return st;
   hipLaunchKernelGGL(moe_finalize_kernel<DIHIP_BF16>, dim3((hidden + 511) / 512, num_tokens), dim3(256), 0, s, out, ys, scores, experts,
                      top_k, hidden);
+  return launch_status();
+}
+
+int dihip_moe_shared_combine(void* stream, float* h_out, const float* h_res, const void* moe_out, const void* shared_out,
+                             const void* shared_gate, int num_tokens, int hidden, int dtype) {
+  DIHIP_REQUIRE(num_tokens >= 0 && hidden > 0, DIHIP_PARAM_ERROR, "moe_shared_combine: bad shape");
+  DIHIP_REQUIRE(h_out && moe_out && shared_out && shared_gate, DIHIP_PARAM_ERROR, "moe_shared_combine: null pointer");
+  if (num_tokens == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((hidden + 255) / 256, num_tokens);
+  if (dtype == DIHIP_BF16)
+    hipLaunchKernelGGL(moe_shared_combine_kernel<DIHIP_BF16>, grid, dim3(256), 0, s, h_out, h_res, moe_out, shared_out, shared_gate, hidden);
+  else if (dtype == DIHIP_F16)
+    hipLaunchKernelGGL(moe_shared_combine_kernel<DIHIP_F16>, grid, dim3(256), 0, s, h_out, h_res, moe_out, shared_out, shared_gate, hidden);
+  else
+    DIHIP_REQUIRE(false, DIHIP_PARAM_ERROR, "moe_shared_combine: 16-bit activations only (dtype %d)", dtype);
   return launch_status();
 }
 

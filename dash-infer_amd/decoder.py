@@ -26,6 +26,15 @@ from .capi import check, lib
 
 
 @dataclass
+class MoEConfig:
+    """Mixture-of-experts feed-forward block (python/pyhie/allspark/model/qwen_v20_moe.py:318-382): `num_experts` routed experts
+    (hidden -> moe_inter -> hidden), `top_k` per token, + one shared expert of width ModelConfig.inter behind a sigmoid gate."""
+    num_experts: int
+    top_k: int
+    moe_inter: int
+
+
+@dataclass
 class ModelConfig:
     name: str
     hidden: int
@@ -37,10 +46,13 @@ class ModelConfig:
     vocab: int
     eps: float = 1e-6
     rope_theta: float = 1000000.0
+    moe: Optional[MoEConfig] = None   # set: every layer's feed-forward block is the MoE block (inter = the shared expert's width)
 
 
 QWEN2_7B = ModelConfig("Qwen2-7B", 3584, 28, 28, 4, 128, 18944, 152064)
 QWEN2_72B = ModelConfig("Qwen2-72B", 8192, 80, 64, 8, 128, 29696, 152064)  # GPTQ-padded intermediate
+# BASELINE configs[4]: 64 experts of width 2560, top-8, shared expert of width 20480
+QWEN2_57B_A14B = ModelConfig("Qwen2-57B-A14B", 3584, 28, 28, 4, 128, 20480, 151936, moe=MoEConfig(64, 8, 2560))
 
 
 @dataclass
@@ -60,6 +72,13 @@ class LayerWeights:
     gate: ops.PackedWeight
     up: ops.PackedWeight
     down: ops.PackedWeight
+    # mixture-of-experts layers (cfg.moe): gate / up / down above are the SHARED expert
+    router: Optional[ops.PackedWeight] = None        # W16 [hidden, num_experts] (replicated)
+    shared_sig: Optional[ops.PackedWeight] = None    # W16 [hidden, 1]: the shared expert's sigmoid gate (replicated)
+    exp_gate: Optional[ops.PackedExperts] = None     # this rank's experts (expert parallelism: E / nranks consecutive experts)
+    exp_up: Optional[ops.PackedExperts] = None
+    exp_down: Optional[ops.PackedExperts] = None
+    ep: Optional[tuple] = None                       # (first expert, count) of this rank
 
 
 @dataclass
@@ -163,6 +182,34 @@ def build_random_model(cfg: ModelConfig, spec: QuantSpec, seed=1234, device="cud
             down=_pack(*qs["down"], spec, rows=ffn_cols if nranks > 1 else None, n_full=cfg.hidden),
         )
         wbytes += sum(p.nbytes for p in (lw.qkv, lw.o, lw.gate, lw.up, lw.down))
+        if cfg.moe is not None:
+            mc = cfg.moe
+            assert mc.num_experts % nranks == 0, "expert parallelism: the experts must divide over the ranks (moe_op.cpp:103-105)"
+            per = mc.num_experts // nranks
+            lw.ep = (rank * per, per)
+            w_router = rand((cfg.hidden, mc.num_experts), base + 8, std=0.5)   # spread-out logits: a decisive top-k
+            w_sig = rand((cfg.hidden, 1), base + 9, std=0.05)
+            lw.router, lw.shared_sig = ops.pack_dense(w_router), ops.pack_dense(w_sig)
+            eq = {"gate": [], "up": [], "down": []}
+            for e in range(mc.num_experts):
+                mine = lw.ep[0] <= e < lw.ep[0] + per
+                if not (mine or fp is not None):
+                    continue
+                for j, (name, shape) in enumerate((("gate", (cfg.hidden, mc.moe_inter)), ("up", (cfg.hidden, mc.moe_inter)),
+                                                   ("down", (mc.moe_inter, cfg.hidden)))):
+                    eq[name].append((e, quantize.quantize(rand(shape, base + 20 + 3 * e + j), spec.wbits, spec.group, spec.gptq_like_zeros)))
+            def stack(name):
+                local = [q for e, q in eq[name] if lw.ep[0] <= e < lw.ep[0] + per]
+                return ops.pack_experts([q[0] for q in local], [q[1] for q in local], [q[2] for q in local], spec.group, spec.wbits)
+            lw.exp_gate, lw.exp_up, lw.exp_down = stack("gate"), stack("up"), stack("down")
+            # streamed per token: the router, top_k experts, the shared expert (already counted) and its gate
+            per_expert = (lw.exp_gate.w.numel() + lw.exp_gate.sz.numel() + lw.exp_up.w.numel() + lw.exp_up.sz.numel()
+                          + lw.exp_down.w.numel() + lw.exp_down.sz.numel()) // per
+            wbytes += lw.router.nbytes + lw.shared_sig.nbytes + mc.top_k * per_expert // nranks
+            if fp is not None:
+                fp[li]["moe"] = {"router": w_router, "shared_gate_w": w_sig, "top_k": mc.top_k,
+                                 "experts_gate": [q for _, q in eq["gate"]], "experts_up": [q for _, q in eq["up"]],
+                                 "experts_down": [q for _, q in eq["down"]]}
         out_layers.append(lw)
         del w_qkv, w_o, w_gate, w_up, w_down, qs
     embed = rand((cfg.vocab, cfg.hidden), seed + 900001)
@@ -341,6 +388,18 @@ class DecodeSession:
         self.qkv = torch.empty(batch, (self.n_loc + 2 * self.g_loc) * H, dtype=dt, device=device)
         self.q = torch.empty(batch, self.n_loc * H, dtype=dt, device=device)
         self.attn = torch.empty(batch, self.n_loc * H, dtype=dt, device=device)
+        if cfg.moe is not None:
+            mc, i_loc = cfg.moe, model.layers[0].gate.N
+            self.moe_xn = torch.empty(batch, cfg.hidden, dtype=dt, device=device)
+            self.moe_logits = torch.empty(batch, mc.num_experts, dtype=dt, device=device)
+            self.moe_scores = torch.empty(batch, mc.top_k, dtype=f32, device=device)
+            self.moe_experts = torch.empty(batch, mc.top_k, dtype=torch.int32, device=device)
+            self.moe_out = torch.empty(batch, cfg.hidden, dtype=dt, device=device)
+            self.moe_act = torch.empty(batch, i_loc, dtype=dt, device=device)
+            self.moe_shared = torch.empty(batch, cfg.hidden, dtype=dt, device=device)
+            self.moe_sig = torch.empty(batch, 1, dtype=dt, device=device)
+            self.moe_ws = torch.empty(int(lib().dihip_moe_workspace_bytes(batch, mc.top_k, cfg.hidden, mc.moe_inter)), dtype=torch.uint8, device=device)
+            self.moe_dense_scratch = ops.Scratch(int(lib().dihip_dense_workspace_bytes(batch, mc.num_experts, cfg.hidden)), device)
         self.attn_frag = False  # set below: the op-boundary attention can write the o-projection's fragment layout
         # the SwiGLU output only feeds the down projection: when both run on the small-batch kernel it is
         # kept in the MFMA-fragment layout that kernel loads with contiguous 1 KiB wave-loads
@@ -370,7 +429,7 @@ class DecodeSession:
         # Bit-identical to the two calls and measured SLOWER (22.2 us vs 18.8 us per layer, 608 vs 640 tokens/s: the
         # attention's dependent loads run at loaded latency while the GEMV streams; profiles/r02_attn_merge_fold.txt) --
         # an experiment switch, DIHIP_DECODER_FRONT=1.  It needs all of its workgroups co-resident (one decode stream per GPU).
-        self.front = (batch <= 4 and kv_mode == "none" and dt == torch.bfloat16 and os.environ.get("DIHIP_DECODER_FRONT", "0") == "1"
+        self.front = (batch <= 4 and kv_mode == "none" and dt == torch.bfloat16 and os.environ.get("DIHIP_DECODER_FRONT", "0") == "1" and cfg.moe is None
                       and ops.decode_front_supported(model.layers[0].qkv, batch, self.n_loc, self.g_loc, H, max_len, kv_mode, dt))
         if self.front:
             self.front_ws = torch.empty(int(lib().dihip_decode_front_workspace_bytes(batch, self.n_loc, self.g_loc, max_len)),
@@ -386,7 +445,7 @@ class DecodeSession:
         # Batched decode (4 < batch <= 32, one rank): the RMSNorm after each residual GEMM is produced by that GEMM call
         # (riding on its split-K reduction) and handed to the next GEMM in its preferred layout -- two launches less
         # per layer.  Under TP the all-reduce sits between the GEMM and the norm, so the separate norm stays.
-        self.norm_fuse = (4 < batch <= 32 and (comm is None or model.nranks == 1)
+        self.norm_fuse = (4 < batch <= 32 and (comm is None or model.nranks == 1) and cfg.moe is None
                           and os.environ.get("DIHIP_DECODER_NORM_FUSE", "1") != "0")  # =0: diagnostics
         if self.norm_fuse:
             def norm_buf(pw, dual):
@@ -509,6 +568,10 @@ class DecodeSession:
                 ops.span_attn_decode(self.q, self.kv[li], self.new_lens, self.n_loc, self.g_loc, self.H, self.max_len,
                                      self.scale, self.attn_ws, self.attn_sync, out=self.attn,
                                      out_layout=ops.ACT_FRAG32 if self.attn_frag else ops.ACT_ROWMAJOR)
+            if cfg.moe is not None:
+                self._proj_residual(self.attn, lw.o, tp_on, frag=self.attn_frag)
+                self._moe_block(lw, tp_on)
+                continue
             if nf:
                 ops.fused_gemm_addto_norm(self.attn, lw.o, self.h, sc, lw.ln2, cfg.eps, self.xn2, out=self.h,
                                           x_layout=ops.ACT_FRAG32 if self.attn_frag else ops.ACT_ROWMAJOR,
@@ -539,6 +602,27 @@ class DecodeSession:
             ops.increment_u32_(self.new_lens)
         else:
             ops.argmax(self.logits, ws=self.argmax_ws, out=self.ids, advance=(self.old_lens, self.new_lens))
+
+    def _moe_block(self, lw, tp_on):
+        """The mixture-of-experts feed-forward block (python/pyhie/allspark/model/qwen_v20_moe.py:318-382):
+          ffn_ln -> mlp.gate (router Gemm) -> MOE (softmax, top-k, this rank's experts, combine)
+                 -> shared_expert gate_up Gemm + UnaryGLU -> down Gemm ; shared_expert_gate (Gemm, SIGMOID) ; CalcExpert
+                 -> expert_add, final_add  [-> all-reduce]
+        Under expert parallelism (attribute use_ep) a rank runs the experts it owns and the shared expert's column / row
+        slices; the reference all-reduces the MOE output and the CalcExpert output separately, here the two partial sums and
+        the residual (rank 0) are added first and the f32 hidden rows are all-reduced once -- the same sum."""
+        cfg, m, sc, B = self.model.cfg, self.model, self.scratch, self.B
+        ops.rmsnorm_rows(self.h, lw.ln2, cfg.eps, out=self.moe_xn)
+        ops.gemm_dense(self.moe_xn, lw.router, out=self.moe_logits, scratch=self.moe_dense_scratch)
+        ops.moe_route(self.moe_logits, cfg.moe.top_k, ep=lw.ep, scores=self.moe_scores, experts=self.moe_experts)
+        ops.moe_experts(self.moe_xn, self.moe_experts, self.moe_scores, lw.exp_gate, lw.exp_up, lw.exp_down, ws=self.moe_ws, out=self.moe_out)
+        ops.prenorm_swiglu(self.moe_xn, lw.gate, lw.up, sc, B, out=self.moe_act)
+        ops.gemm_lowp(self.moe_act, lw.down, scratch=sc, out=self.moe_shared)
+        ops.gemm_dense(self.moe_xn, lw.shared_sig, act="sigmoid", out=self.moe_sig, scratch=self.moe_dense_scratch)
+        h_res = self.h if (not tp_on or m.rank == 0) else None
+        ops.moe_shared_combine(self.h, h_res, self.moe_out, self.moe_shared, self.moe_sig)
+        if tp_on:
+            self._allreduce(self.h)
 
     def _allreduce(self, t, next_weights=()):
         """Sum all-reduce of the hidden rows; with the overlap schedule on the side stream, beside a cache prefetch of the

@@ -86,10 +86,10 @@ def gemv_plan(wbits, M, N, K, group, dual=False):
     return {"blocks": blocks.value, "upb": upb.value, "WK": wk.value, "WN": wn.value, "lds_bytes": lds.value}
 
 
-def gemm_lowp(x, pw, bias=None, residual=None, act=None, alpha=1.0, scratch=None, use_sync=True):
+def gemm_lowp(x, pw, bias=None, residual=None, act=None, alpha=1.0, scratch=None, use_sync=True, out=None):
     """op GemmA16W8 / GemmA16W4: x FT [..., K] -> FT [..., N]."""
     M = x.numel() // pw.K
-    y = torch.empty(*x.shape[:-1], pw.N, dtype=x.dtype, device=x.device)
+    y = out if out is not None else torch.empty(*x.shape[:-1], pw.N, dtype=x.dtype, device=x.device)
     if scratch is None:
         scratch = Scratch(lowp_workspace_bytes(pw.wbits, max(M, 1), pw.N, pw.K, pw.group), x.device)
     fn = lib().dihip_gemm_a16w8 if pw.wbits == 8 else lib().dihip_gemm_a16w4
@@ -99,9 +99,9 @@ def gemm_lowp(x, pw, bias=None, residual=None, act=None, alpha=1.0, scratch=None
     return y
 
 
-def gemm_dense(x, pw, bias=None, residual=None, act=None, alpha=1.0, scratch=None):
+def gemm_dense(x, pw, bias=None, residual=None, act=None, alpha=1.0, scratch=None, out=None):
     M = x.numel() // pw.K
-    y = torch.empty(*x.shape[:-1], pw.N, dtype=x.dtype, device=x.device)
+    y = out if out is not None else torch.empty(*x.shape[:-1], pw.N, dtype=x.dtype, device=x.device)
     if scratch is None:
         scratch = Scratch(lib().dihip_dense_workspace_bytes(max(M, 1), pw.N, pw.K), x.device)
     check(lib().dihip_gemm_a16w16(cur_stream(), ptr(x), ptr(pw.w), ptr(bias), ptr(residual), ptr(y), M, pw.N, pw.K,
@@ -140,12 +140,22 @@ def pack_experts(qs, scales, zeros, group, wbits):
     return PackedExperts(w, sz, wbits, p0.N, p0.K, p0.group, E)
 
 
-def moe_route(logits, top_k):
+def moe_route(logits, top_k, ep=None, scores=None, experts=None):
+    """ep = (first, count): expert-parallel window of this rank (indices come out local to it, -1 elsewhere)."""
     T, E = logits.shape
-    scores = torch.empty(T, top_k, dtype=torch.float32, device=logits.device)
-    experts = torch.empty(T, top_k, dtype=torch.int32, device=logits.device)
-    check(lib().dihip_moe_route(cur_stream(), ptr(logits), T, E, top_k, ptr(scores), ptr(experts), dt_code(logits)), "dihip_moe_route")
+    scores = scores if scores is not None else torch.empty(T, top_k, dtype=torch.float32, device=logits.device)
+    experts = experts if experts is not None else torch.empty(T, top_k, dtype=torch.int32, device=logits.device)
+    first, count = ep if ep is not None else (0, E)
+    check(lib().dihip_moe_route_ep(cur_stream(), ptr(logits), T, E, top_k, ptr(scores), ptr(experts), dt_code(logits), first, count),
+          "dihip_moe_route_ep")
     return scores, experts
+
+
+def moe_shared_combine(h_out, h_res, moe_out, shared_out, shared_gate):
+    T, hidden = moe_out.shape
+    check(lib().dihip_moe_shared_combine(cur_stream(), ptr(h_out), ptr(h_res), ptr(moe_out), ptr(shared_out), ptr(shared_gate), T, hidden,
+                                         dt_code(moe_out)), "dihip_moe_shared_combine")
+    return h_out
 
 
 def moe_experts(x, experts, scores, gate, up, down, ws=None, out=None):
@@ -419,6 +429,14 @@ def rmsnorm(x, gamma, eps):
     check(lib().dihip_rmsnorm(cur_stream(), ptr(y), ptr(x), ptr(gamma), float(eps), x.numel() // x.shape[-1],
                               x.shape[-1], dt_code(x)), "dihip_rmsnorm")
     return y
+
+
+def rmsnorm_rows(h, gamma, eps, out=None):
+    """f32 hidden rows -> FT normalised rows (the norm the fused GEMV entries apply, as its own launch)."""
+    M, K = h.shape
+    out = out if out is not None else torch.empty(M, K, dtype=gamma.dtype, device=h.device)
+    check(lib().dihip_rmsnorm_rows(cur_stream(), ptr(out), ptr(h), ptr(gamma), float(eps), M, K, dt_code(gamma)), "dihip_rmsnorm_rows")
+    return out
 
 
 def rope_qk_(qkv, positions, inv_freq, n, g, H):

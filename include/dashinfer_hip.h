@@ -154,6 +154,10 @@ int dihip_fused_gemm_addto_norm(void* stream, int wbits, const void* x, const vo
                                 const void* sz_packed, const float* h_res, float* h_out, int M, int N,
                                 int K, int group_size, void* ws, size_t ws_bytes, void* sync, int dtype,
                                 int x_layout, const void* gamma, float eps, void* xnorm, int xnorm_layout);
+/* LayerNormNoBeta (csrc/core/kernel/cpu/layernorm.cpp:110-157) of M rows of the f32 hidden stream into FT rows (row-major),
+ * as its own call: the norm every fused entry above applies, for graphs with several consumers of it (the MoE layer) */
+int dihip_rmsnorm_rows(void* stream, void* xnorm, const float* h, const void* gamma, float eps, int M, int K,
+                       int dtype);
 int dihip_prenorm_gemm(void* stream, int wbits, const void* xnorm, int x_layout, const void* w_packed,
                        const void* sz_packed, const void* bias, void* y, int M, int N, int K,
                        int group_size, int act, void* ws, size_t ws_bytes, void* sync, int dtype);
@@ -176,12 +180,25 @@ int dihip_prenorm_swiglu(void* stream, int wbits, const void* xnorm, int x_layou
  *   dihip_moe_experts: out FT [T, hidden]; ws >= dihip_moe_workspace_bytes (no initialisation needed)      */
 int dihip_moe_route(void* stream, const void* router_logits, int num_tokens, int num_experts, int top_k,
                     float* scores, int32_t* experts, int dtype);
+/* expert parallelism (attribute use_ep, moe_op.cpp:103-117: rank r owns experts [r * E / nranks, (r + 1) * E / nranks)):
+ * the indices come out as positions in the rank's own stack [ep_first, ep_first + ep_count), -1 for experts held elsewhere
+ * (dihip_moe_experts skips those slots; the all-reduce that follows the operator supplies their terms) */
+int dihip_moe_route_ep(void* stream, const void* router_logits, int num_tokens, int num_experts, int top_k,
+                       float* scores, int32_t* experts, int dtype, int ep_first, int ep_count);
 size_t dihip_moe_workspace_bytes(int num_tokens, int top_k, int hidden, int proj);
 int dihip_moe_experts(void* stream, int wbits, const void* x, const int32_t* experts, const float* scores,
                       const void* gate_packed, const void* gate_sz, const void* up_packed,
                       const void* up_sz, const void* down_packed, const void* down_sz, int num_tokens,
                       int top_k, int hidden, int proj, int group_size, void* out, void* ws,
                       size_t ws_bytes, int dtype);
+/* Tail of the MoE layer graph (python/pyhie/allspark/model/qwen_v20_moe.py:366-382): CalcExpert (shared-expert output x its
+ * sigmoid gate, csrc/core/kernel/cuda/calc_expert.cu:27-35, rounded to FT) + expert_add + final_add on the f32 hidden rows:
+ *   h_out[t, :] = (h_res ? h_res[t, :] : 0) + moe_out[t, :] + FT(shared_out[t, :] * shared_gate[t])
+ * moe_out / shared_out FT [T, hidden], shared_gate FT [T] (the Gemm with activation SIGMOID, N = 1); h_res == NULL on ranks
+ * that do not carry the residual (the sum over ranks is the all-reduce of h_out that follows).  In place (h_out == h_res) is fine. */
+int dihip_moe_shared_combine(void* stream, float* h_out, const float* h_res, const void* moe_out,
+                             const void* shared_out, const void* shared_gate, int num_tokens, int hidden,
+                             int dtype);
 
 /* =============================================================================================
  * 2. KV span writers (replace csrc/core/kernel/cuda/cuda_kernel_span_cache.h:12-41)

@@ -19,7 +19,7 @@ the prefill attention oracle.
 """
 import numpy as np
 
-from . import attention, gemm_ref, glue, kv_codec
+from . import attention, gemm_ref, glue, kv_codec, moe
 from .numerics import bf16_round
 
 
@@ -75,11 +75,36 @@ class DecoderOracle:
         return q, k, v
 
     def _mlp(self, h, lw):
+        if "moe" in lw:
+            return self._moe_mlp(h, lw)
         xn = bf16_round(glue.rmsnorm(h, lw["ln2"], self.eps))
         gate = self._ft(glue.silu(self.linear(xn, lw["gate"], "f32")))
         up = self._ft(self.linear(xn, lw["up"], "f32"))
         act = bf16_round(gate * up)
         return self._residual(h, self.linear(act, lw["down"], "f32"))
+
+    def _moe_mlp(self, h, lw):
+        """The mixture-of-experts layer of python/pyhie/allspark/model/qwen_v20_moe.py:318-382: router Gemm -> MOE (softmax,
+        top-k, expert FFNs, combine: oracle/moe.py) ; shared expert (gate_up Gemm -> UnaryGLU -> down Gemm) scaled by its
+        sigmoid gate (Gemm with activation SIGMOID, N = 1; CalcExpert, calc_expert.cu:27-35) ; expert_add ; final_add.
+        lw["moe"]: router f32 [hidden, E], top_k, experts_gate / _up / _down: lists of (q, s, z), shared_gate_w f32 [hidden, 1];
+        the shared expert's projections are lw["gate"] / ["up"] / ["down"]."""
+        m = lw["moe"]
+        xn = bf16_round(glue.rmsnorm(h, lw["ln2"], self.eps))
+        x64 = xn.astype(np.float64)
+        logits = bf16_round((x64 @ np.asarray(m["router"], np.float64)).astype(np.float32))          # Gemm output, FT
+        scores, experts = moe.route(logits, m["top_k"])
+        moe_out = moe.experts_ffn(xn, experts, scores, m["experts_gate"], m["experts_up"], m["experts_down"], self.group, self.wbits, ft="bf16")
+        gate = self._ft(glue.silu(self.linear(xn, lw["gate"], "f32")))
+        up = self._ft(self.linear(xn, lw["up"], "f32"))
+        act = bf16_round(gate * up)
+        shared = bf16_round(self.linear(act, lw["down"], "f32"))                                       # Gemm output, FT
+        z = (x64 @ np.asarray(m["shared_gate_w"], np.float64)).astype(np.float32)                    # [B, 1]
+        sig = bf16_round((1.0 / (1.0 + np.exp(-z.astype(np.float64)))).astype(np.float32))
+        calc = bf16_round(shared * sig)                                                                # CalcExpert output, FT
+        if self.rounding == "ft_graph":
+            return bf16_round(bf16_round(moe_out + calc) + bf16_round(h))                              # expert_add, final_add
+        return ((h + moe_out) + calc).astype(np.float32)
 
     def _logits(self, h):
         xn = bf16_round(glue.rmsnorm(h, self.final_norm, self.eps))

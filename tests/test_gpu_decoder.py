@@ -36,6 +36,12 @@ def oracle_of(model, kv_mode):
         lw = {k: tuple((x.cpu().numpy() if x.dtype in (torch.uint8, torch.int8) else f(x)) for x in p[k])
               for k in ("qkv", "o", "gate", "up", "down")}
         lw.update(qkv_bias=f(p["qkv_bias"]), ln1=f(p["ln1"]), ln2=f(p["ln2"]))
+        if "moe" in p:
+            conv = lambda q: tuple((x.cpu().numpy() if x.dtype in (torch.uint8, torch.int8) else f(x)) for x in q)
+            mo = p["moe"]
+            lw["moe"] = {"router": f(mo["router"]), "shared_gate_w": f(mo["shared_gate_w"]), "top_k": mo["top_k"],
+                         "experts_gate": [conv(q) for q in mo["experts_gate"]], "experts_up": [conv(q) for q in mo["experts_up"]],
+                         "experts_down": [conv(q) for q in mo["experts_down"]]}
         layers.append(lw)
     return omodel.DecoderOracle(layers, f(model.fp["embed"]), f(model.fp["final_norm"]), f(model.fp["lm_head"]), cfg.n_heads,
                                 cfg.n_kv, cfg.head_dim, model.quant.wbits, model.quant.group, eps=cfg.eps,
@@ -97,6 +103,46 @@ def test_greedy_decode_matches_oracle(pkg, shape, wbits, group, kv_mode, batch, 
         cur = gpu_ids[t]  # follow the product path's choice: a near-tie must not derail the later steps
     assert decided >= steps * batch // 4, "too few decisive steps for the token-ID check to mean anything"
     print(f"worst logit error {worst:.2e}; {decided}/{steps * batch} decisive greedy choices")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Mixture-of-experts decoder (BASELINE configs[4] architecture, python/pyhie/allspark/model/qwen_v20_moe.py:318-382): every
+# layer's feed-forward block is router -> top-k of the routed experts -> combine, + the shared expert behind its sigmoid
+# gate.  Same comparison as above against oracle/model.py::_moe_mlp (router / experts of oracle/moe.py).
+MOE_SMALL = dict(hidden=512, layers=2, n_heads=4, n_kv=2, head_dim=128, inter=512, vocab=2048)
+
+
+@pytest.mark.parametrize("wbits,group,batch,experts,top_k", [(8, -1, 1, 8, 2), (4, 128, 3, 8, 2), (8, -1, 4, 16, 4)])
+def test_moe_greedy_decode_matches_oracle(pkg, wbits, group, batch, experts, top_k):
+    from dash_infer_amd import decoder
+    cfg = decoder.ModelConfig("moe-test", **MOE_SMALL, moe=decoder.MoEConfig(experts, top_k, 256))
+    model = decoder.build_random_model(cfg, decoder.QuantSpec(wbits, group), seed=2468, keep_fp=True)
+    steps = 5
+    sess = decoder.DecodeSession(model, batch, max_len=32, span_len=16, kv_mode="none")
+    rng = np.random.default_rng(batch * 5 + wbits)
+    ids = rng.integers(0, cfg.vocab, batch)
+    sess.set_state(ids, [0] * batch)
+    gpu_logits, gpu_ids = [], []
+    for _ in range(steps):
+        sess.step()
+        torch.cuda.synchronize()
+        gpu_logits.append(sess.logits.cpu().numpy().copy())
+        gpu_ids.append(sess.ids.cpu().numpy().copy())
+    ref = oracle_of(model, "none")
+    cur, decided, worst = ids, 0, 0.0
+    for t in range(steps):
+        lo = ref.step(cur)
+        tol = 1e-2 * max(1.0, float(np.abs(lo).max()))
+        err = float(np.abs(gpu_logits[t] - lo).max())
+        worst = max(worst, err)
+        assert err <= tol, f"step {t}: logits differ by {err:.3e} (max |logit| {np.abs(lo).max():.2f})"
+        top2 = np.sort(lo, axis=-1)[:, -2:]
+        sure = (top2[:, 1] - top2[:, 0]) > 2 * tol
+        assert np.array_equal(gpu_ids[t][sure], glue.greedy(lo)[sure]), f"step {t}: greedy token IDs differ"
+        decided += int(sure.sum())
+        cur = gpu_ids[t]
+    assert decided >= steps * batch // 4
+    print(f"MoE: worst logit error {worst:.2e}; {decided}/{steps * batch} decisive greedy choices")
 
 
 # ------------------------------------------------------------------------------------------------------------------

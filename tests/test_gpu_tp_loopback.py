@@ -42,6 +42,8 @@ def test_p2p_allreduce_between_rank_threads(pkg, nranks):
     (8, "none", 2, 4, 128, "p2p", False),     # the same through the product's one-shot P2P all-reduce (rank threads, own streams)
     (4, "none", 1, 4, 128, "p2p", True),      # + the north-star schedule: all-reduce on a side stream between events, weight prefetch beside it
     (2, "i8", 3, 8, -1, "host", True),
+    (2, "none", 2, 8, -1, "host-moe", False),  # mixture-of-experts layers under expert parallelism (4 of 8 experts per rank)
+    (4, "none", 1, 4, 128, "host-moe", False),
 ])
 def test_tp_decode_matches_single_rank(pkg, monkeypatch, nranks, kv_mode, batch, wbits, group, comm_kind, overlap):
     if comm_kind == "p2p":
@@ -49,4 +51,5 @@ def test_tp_decode_matches_single_rank(pkg, monkeypatch, nranks, kv_mode, batch,
         return
     from tests import tp_loopback_lib
     monkeypatch.setenv("DIHIP_TP_OVERLAP", "1" if overlap else "0")
-    tp_loopback_lib.run_tp_decode(nranks, kv_mode, batch, wbits, group, comm_kind, overlap)
+    moe = comm_kind.endswith("-moe")
+    tp_loopback_lib.run_tp_decode(nranks, kv_mode, batch, wbits, group, comm_kind.split("-")[0], overlap, moe=moe)

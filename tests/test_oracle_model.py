@@ -84,3 +84,37 @@ def test_rounding_modes_differ_only_at_the_documented_points():
         la, lb = a.step([t])[0], b.step([t])[0]
     d = float(np.abs(la - lb).max())
     assert 0 < d < 0.1 * max(1.0, float(np.abs(la).max())), d  # bf16 residual / gate / up rounding: small but not zero
+
+
+def add_moe(rng, m, wbits, group, hidden=256, num_experts=4, top_k=2, moe_inter=128):
+    def qlin(K, N):
+        W = bf16_round(rng.normal(0, 0.05, (K, N)).astype(np.float32))
+        return (quant.iq_quantize_a16w8 if wbits == 8 else quant.iq_quantize_a16w4)(W, group, "bf16")
+    for lw in m.layers:
+        lw["moe"] = {"router": bf16_round(rng.normal(0, 0.5, (hidden, num_experts)).astype(np.float32)), "top_k": top_k,
+                     "shared_gate_w": bf16_round(rng.normal(0, 0.05, (hidden, 1)).astype(np.float32)),
+                     "experts_gate": [qlin(hidden, moe_inter) for _ in range(num_experts)],
+                     "experts_up": [qlin(hidden, moe_inter) for _ in range(num_experts)],
+                     "experts_down": [qlin(moe_inter, hidden) for _ in range(num_experts)]}
+    return m
+
+
+def test_moe_layers_incremental_equals_full_recompute_and_route_through_the_experts():
+    """the mixture-of-experts block (qwen_v20_moe.py:318-382) in both evaluation orders; and it IS the sum of its parts:
+    with the routed experts' down projections zeroed the block reduces to the gated shared expert, with the shared expert's
+    zeroed to the routed experts alone"""
+    rng = np.random.default_rng(11)
+    m = add_moe(rng, make_oracle(rng, 8, -1, "none"), 8, -1)
+    seq = rng.integers(0, 64, 5)
+    step_logits = [m.step([t])[0] for t in seq]
+    full = m.last_logits_from_scratch(seq)[0]
+    np.testing.assert_allclose(step_logits[-1], full, rtol=0, atol=2e-5 * max(1.0, float(np.abs(full).max())))
+    # parts: zero the shared expert's down projection -> the routed experts alone; zero the routed experts' -> the gated shared expert
+    h = rng.normal(0, 1, (3, 256)).astype(np.float32)
+    lw = m.layers[0]
+    zeroed = lambda w: (w[0], w[1] * 0, w[2])
+    routed_only = dict(lw, down=zeroed(lw["down"]))
+    shared_only = dict(lw, moe=dict(lw["moe"], experts_down=[zeroed(w) for w in lw["moe"]["experts_down"]]))
+    whole, a, b = m._moe_mlp(h, lw) - h, m._moe_mlp(h, routed_only) - h, m._moe_mlp(h, shared_only) - h
+    np.testing.assert_allclose(whole, a + b, rtol=0, atol=1e-5)
+    assert np.abs(a).max() > 1e-3 and np.abs(b).max() > 1e-3
