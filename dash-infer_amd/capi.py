@@ -41,6 +41,7 @@ _SIGS = {
     "dihip_moe_route": (i32, [vp, vp, i32, i32, i32, vp, vp, i32]),
     "dihip_rmsnorm_rows": (i32, [vp, vp, vp, vp, f32, i32, i32, i32]),
     "dihip_moe_route_ep": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32]),
+    "dihip_calc_expert": (i32, [vp, vp, vp, vp, i32, i32, i32]),
     "dihip_moe_shared_combine": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32]),
     "dihip_moe_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "dihip_moe_experts": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, sz, i32]),

@@ -125,6 +125,17 @@ __global__ __launch_bounds__(256) void moe_shared_combine_kernel(float* __restri
   h_out[i] = (base + load_ft<FT>(moe_out, i)) + calc;
 }
 
+// CalcExpert (csrc/core/kernel/cuda/calc_expert.cu:27-35): out[t, c] = in[t, c] * expert_weight[t]
+template <int FT>
+__global__ __launch_bounds__(256) void calc_expert_kernel(void* __restrict__ out, const void* __restrict__ in,
+                                                          const void* __restrict__ expert_weight, int cols) {
+  const int t = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const size_t i = (size_t)t * cols + c;
+  store_ft<FT>(out, i, load_ft<FT>(in, i) * load_ft<FT>(expert_weight, t));
+}
+
 }  // namespace dihip
 
 using namespace dihip;
@@ -203,6 +214,22 @@ int dihip_moe_shared_combine(void* stream, float* h_out, const float* h_res, con
     hipLaunchKernelGGL(moe_shared_combine_kernel<DIHIP_F16>, grid, dim3(256), 0, s, h_out, h_res, moe_out, shared_out, shared_gate, hidden);
   else
     DIHIP_REQUIRE(false, DIHIP_PARAM_ERROR, "moe_shared_combine: 16-bit activations only (dtype %d)", dtype);
+  return launch_status();
+}
+
+int dihip_calc_expert(void* stream, void* out, const void* in, const void* expert_weight, int num_tokens, int hidden, int dtype) {
+  DIHIP_REQUIRE(num_tokens >= 0 && hidden > 0 && out && in && expert_weight, DIHIP_PARAM_ERROR, "calc_expert: bad argument");
+  if (num_tokens == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((hidden + 255) / 256, num_tokens);
+  if (dtype == DIHIP_BF16)
+    hipLaunchKernelGGL(calc_expert_kernel<DIHIP_BF16>, grid, dim3(256), 0, s, out, in, expert_weight, hidden);
+  else if (dtype == DIHIP_F16)
+    hipLaunchKernelGGL(calc_expert_kernel<DIHIP_F16>, grid, dim3(256), 0, s, out, in, expert_weight, hidden);
+  else if (dtype == DIHIP_F32)
+    hipLaunchKernelGGL(calc_expert_kernel<DIHIP_F32>, grid, dim3(256), 0, s, out, in, expert_weight, hidden);
+  else
+    DIHIP_REQUIRE(false, DIHIP_PARAM_ERROR, "calc_expert: unsupported dtype %d", dtype);
   return launch_status();
 }
 

@@ -77,7 +77,7 @@ const char* dihost_last_error(void) { return g_err.c_str(); }
 const char* dihost_registered_ops(void) {
   static std::string s;
   s.clear();
-  for (const char* t : {"GemmA16W8", "GemmA16W4", "DecOptMHA", "DecOptMQA", "AllReduce", "AllGather", "MOEA16W8", "Gemm", "Rotary"}) {
+  for (const char* t : {"GemmA16W8", "GemmA16W4", "DecOptMHA", "DecOptMQA", "AllReduce", "AllGather", "MOEA16W8", "CalcExpert", "Gemm", "Rotary"}) {
     try {
       (void)OpFactory::getInstance().GetOperator({t, DeviceType::HIP});
       s += (s.empty() ? "" : ",");

@@ -4,7 +4,9 @@
 //   weights stacked over the experts, the A16W8 triple per projection (gemm_a16w8.cpp:26-31 order W, scales, zeros):
 //           gate_up_proj  int8 [E, hidden, 2*proj]  + scales / zeros FT [E, G, 2*proj]   (columns [gate | up], unary.cu:122-132)
 //           down_proj     int8 [E, proj, hidden]    + scales / zeros FT [E, G, hidden]
-//   attrs   num_experts, num_experts_per_tok (moe_op.cpp:63-80), GroupSize (optional, gemm_a16w8.cpp:66-74)
+//   attrs   num_experts, num_experts_per_tok (moe_op.cpp:63-80), GroupSize (optional, gemm_a16w8.cpp:66-74), use_ep (optional,
+//           moe_op.cpp:103-117: rank r holds experts [r * E / nranks, (r + 1) * E / nranks) -- the stacks then have E / nranks
+//           entries -- and leaves the other experts' terms to the AllReduce that follows the operator)
 //   output  [T(,1), hidden]
 // InitV2 re-lays every expert out once (column halves of gate_up become the gate and the up stack of dihip tile-major
 // tensors); Reshape sizes the routing tensors and grows the shared "workspace"; Forward only enqueues on the context
@@ -38,11 +40,19 @@ class MoeA16W8HIP : public AsOperator {
     if (!geti("num_experts", &num_expert_) || num_expert_ <= 0 || num_expert_ > 256) return AsStatus::ALLSPARK_PARAM_ERROR;  // :65-74
     if (!geti("num_experts_per_tok", &top_k_) || top_k_ <= 0 || top_k_ > num_expert_) return AsStatus::ALLSPARK_PARAM_ERROR;  // :75-80
     geti("GroupSize", &group_size_);
+    ep_num_ = num_expert_;
+    ep_first_ = 0;
+    if (attr.find("use_ep") != attr.end()) {  // moe_op.cpp:103-108
+      const int nranks = std::max(1, ctx.GetNranks());
+      if (num_expert_ % nranks) return AsStatus::ALLSPARK_PARAM_ERROR;
+      ep_num_ = num_expert_ / nranks;
+      ep_first_ = ctx.GetRank() * ep_num_;
+    }
     const AsTensor* gu = weights_[0];
     const AsTensor* dn = weights_[3];
     if (gu->GetShape().size() != 3 || dn->GetShape().size() != 3 || gu->GetDataType() != INT8 || dn->GetDataType() != INT8)
       return AsStatus::ALLSPARK_PARAM_ERROR;
-    if ((int)gu->GetShape()[0] != num_expert_ || (int)dn->GetShape()[0] != num_expert_) return AsStatus::ALLSPARK_PARAM_ERROR;
+    if ((int)gu->GetShape()[0] != ep_num_ || (int)dn->GetShape()[0] != ep_num_) return AsStatus::ALLSPARK_PARAM_ERROR;
     hidden_ = (int)gu->GetShape()[1];       // moe_op.cpp:120-121
     proj_ = (int)gu->GetShape()[2] / 2;
     if ((int)dn->GetShape()[1] != proj_ || (int)dn->GetShape()[2] != hidden_) return AsStatus::ALLSPARK_PARAM_ERROR;
@@ -54,12 +64,12 @@ class MoeA16W8HIP : public AsOperator {
     const size_t wb_gu = dihip_gemm_lowp_packed_weight_bytes(8, proj_, hidden_), sb_gu = dihip_gemm_lowp_packed_sz_bytes(proj_, hidden_, group_size_);
     const size_t wb_dn = dihip_gemm_lowp_packed_weight_bytes(8, hidden_, proj_), sb_dn = dihip_gemm_lowp_packed_sz_bytes(hidden_, proj_, group_size_);
     auto mk = [&](const char* n, size_t bytes) { return std::make_unique<AsTensor>(op_name_ + n, DeviceType::HIP, INT8, Shape{(int64_t)bytes}); };
-    gate_w_ = mk(".gate_w", wb_gu * num_expert_);
-    up_w_ = mk(".up_w", wb_gu * num_expert_);
-    down_w_ = mk(".down_w", wb_dn * num_expert_);
-    gate_sz_ = mk(".gate_sz", sb_gu * num_expert_);
-    up_sz_ = mk(".up_sz", sb_gu * num_expert_);
-    down_sz_ = mk(".down_sz", sb_dn * num_expert_);
+    gate_w_ = mk(".gate_w", wb_gu * ep_num_);
+    up_w_ = mk(".up_w", wb_gu * ep_num_);
+    down_w_ = mk(".down_w", wb_dn * ep_num_);
+    gate_sz_ = mk(".gate_sz", sb_gu * ep_num_);
+    up_sz_ = mk(".up_sz", sb_gu * ep_num_);
+    down_sz_ = mk(".down_sz", sb_dn * ep_num_);
     // staging for one expert's column halves: W [hidden, proj] int8, scales / zeros [G, proj] FT
     auto tmp_w = mk(".tmp_w", (size_t)hidden_ * proj_), tmp_s = mk(".tmp_s", (size_t)G * proj_ * 2), tmp_z = mk(".tmp_z", (size_t)G * proj_ * 2);
     for (auto* t : {gate_w_.get(), up_w_.get(), down_w_.get(), gate_sz_.get(), up_sz_.get(), down_sz_.get(), tmp_w.get(), tmp_s.get(), tmp_z.get()})
@@ -67,7 +77,7 @@ class MoeA16W8HIP : public AsOperator {
     const char* guw = (const char*)weights_[0]->GetDataPtr();
     const char* gus = (const char*)weights_[1]->GetDataPtr();
     const char* guz = (const char*)weights_[2]->GetDataPtr();
-    for (int e = 0; e < num_expert_; ++e) {
+    for (int e = 0; e < ep_num_; ++e) {
       for (int half = 0; half < 2; ++half) {  // columns [0, proj) = gate, [proj, 2 proj) = up
         const char* w0 = guw + ((size_t)e * hidden_ * 2 * proj_) + (size_t)half * proj_;
         const char* s0 = gus + ((size_t)e * G * 2 * proj_ + (size_t)half * proj_) * 2;
@@ -121,8 +131,8 @@ class MoeA16W8HIP : public AsOperator {
     AsTensor* wsp = tensor_map_->at("workspace").get();
     if (x->GetDataType() != ftype_) return AsStatus::ALLSPARK_PARAM_ERROR;
     hipStream_t s = static_cast<const HIPContext*>(ctx_)->GetStream();
-    AS_CHECK_STATUS(FromDihip(dihip_moe_route(s, lg->GetDataPtr(), total_token_, num_expert_, top_k_, (float*)experts_score_->GetDataPtr(),
-                                              (int32_t*)topk_indice_->GetDataPtr(), DihipDtype(lg->GetDataType()))));
+    AS_CHECK_STATUS(FromDihip(dihip_moe_route_ep(s, lg->GetDataPtr(), total_token_, num_expert_, top_k_, (float*)experts_score_->GetDataPtr(),
+                                                 (int32_t*)topk_indice_->GetDataPtr(), DihipDtype(lg->GetDataType()), ep_first_, ep_num_)));
     return FromDihip(dihip_moe_experts(s, 8, x->GetDataPtr(), (const int32_t*)topk_indice_->GetDataPtr(), (const float*)experts_score_->GetDataPtr(),
                                        gate_w_->GetDataPtr(), gate_sz_->GetDataPtr(), up_w_->GetDataPtr(), up_sz_->GetDataPtr(),
                                        down_w_->GetDataPtr(), down_sz_->GetDataPtr(), total_token_, top_k_, hidden_, proj_, group_size_,
@@ -130,11 +140,54 @@ class MoeA16W8HIP : public AsOperator {
   }
 
  private:
-  int num_expert_ = 0, top_k_ = 0, hidden_ = 0, proj_ = 0, group_size_ = -1, total_token_ = 0;
+  int num_expert_ = 0, top_k_ = 0, hidden_ = 0, proj_ = 0, group_size_ = -1, total_token_ = 0, ep_num_ = 0, ep_first_ = 0;
   DataType ftype_ = BFLOAT16;
   std::unique_ptr<AsTensor> gate_w_, up_w_, down_w_, gate_sz_, up_sz_, down_sz_, experts_score_, topk_indice_;
 };
 
 REGISTER_OP(MOEA16W8, HIP, MoeA16W8HIP)
+
+// op type "CalcExpert" (csrc/core/operator/general/calc_expert/calc_expert_op.cpp:14-68): out[t, :] = in[t, :] * expert_weight[t]
+// -- the shared expert's output scaled by its sigmoid gate (python/pyhie/allspark/model/qwen_v20_moe.py:366-371).
+class CalcExpertHIP : public AsOperator {
+ public:
+  explicit CalcExpertHIP(const std::string& op_type = "") : AsOperator(op_type) {}
+
+  AsStatus InitV2(const OperatorProto& op_proto, const DeviceContext& ctx, const TensorMap& weights_map, TensorMap& weights_buffer,
+                  TensorMap* tensor_map, RuntimeContext* runtime_ctx) override {
+    (void)weights_buffer;
+    (void)runtime_ctx;
+    AS_CHECK_STATUS(AsOperator::Init(op_proto, ctx, weights_map, tensor_map));
+    if (ctx.GetDeviceType() != DeviceType::HIP || in_names_.size() != 2) return AsStatus::ALLSPARK_PARAM_ERROR;
+    if (op_proto.attr.find("num_experts") == op_proto.attr.end()) return AsStatus::ALLSPARK_PARAM_ERROR;  // calc_expert_op.cpp:26-31
+    return AsStatus::ALLSPARK_SUCCESS;
+  }
+
+  AsStatus Reshape(RuntimeContext*) override {
+    AsTensor* x = tensor_map_->at(in_names_[0]).get();
+    Shape shape = x->GetShape();
+    if (shape.empty()) return AsStatus::ALLSPARK_PARAM_ERROR;
+    hidden_ = (int)shape.back();
+    total_token_ = (int)(x->Count() / hidden_);
+    if (tensor_map_->at(in_names_[1])->Count() != total_token_) return AsStatus::ALLSPARK_PARAM_ERROR;
+    AsTensor* y = tensor_map_->at(out_names_[0]).get();
+    y->SetDataType(x->GetDataType());
+    return y->SetShape(std::move(shape));
+  }
+
+  AsStatus Forward(RuntimeContext*) override {
+    AsTensor* x = tensor_map_->at(in_names_[0]).get();
+    AsTensor* w = tensor_map_->at(in_names_[1]).get();
+    AsTensor* y = tensor_map_->at(out_names_[0]).get();
+    if (w->GetDataType() != x->GetDataType()) return AsStatus::ALLSPARK_PARAM_ERROR;
+    return FromDihip(dihip_calc_expert(static_cast<const HIPContext*>(ctx_)->GetStream(), y->GetDataPtr(), x->GetDataPtr(), w->GetDataPtr(),
+                                       total_token_, hidden_, DihipDtype(x->GetDataType())));
+  }
+
+ private:
+  int total_token_ = 0, hidden_ = 0;
+};
+
+REGISTER_OP(CalcExpert, HIP, CalcExpertHIP)
 
 }  // namespace allspark

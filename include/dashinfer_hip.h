@@ -191,6 +191,9 @@ int dihip_moe_experts(void* stream, int wbits, const void* x, const int32_t* exp
                       const void* up_sz, const void* down_packed, const void* down_sz, int num_tokens,
                       int top_k, int hidden, int proj, int group_size, void* out, void* ws,
                       size_t ws_bytes, int dtype);
+/* CalcExpertKernelLauncher (csrc/core/kernel/cuda/calc_expert.cu:27-35; op CalcExpert): out[t, :] = in[t, :] * expert_weight[t] */
+int dihip_calc_expert(void* stream, void* out, const void* in, const void* expert_weight, int num_tokens,
+                      int hidden, int dtype);
 /* Tail of the MoE layer graph (python/pyhie/allspark/model/qwen_v20_moe.py:366-382): CalcExpert (shared-expert output x its
  * sigmoid gate, csrc/core/kernel/cuda/calc_expert.cu:27-35, rounded to FT) + expert_add + final_add on the f32 hidden rows:
  *   h_out[t, :] = (h_res ? h_res[t, :] : 0) + moe_out[t, :] + FT(shared_out[t, :] * shared_gate[t])

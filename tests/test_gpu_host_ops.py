@@ -270,6 +270,62 @@ def test_moe_a16w8_operator(env):
     m.close()
 
 
+def test_moe_expert_parallel_ranks_sum_to_the_whole_and_calc_expert(env):
+    """MOEA16W8 with attribute use_ep (moe_op.cpp:103-117): rank r holds the stack of experts [r * E / nranks, ...) and computes
+    only their terms; the ranks' outputs sum (the AllReduce after the operator) to the single-rank result.  Then op type
+    CalcExpert (calc_expert_op.cpp:14-68): rows scaled by a per-token weight, against numpy."""
+    from oracle import moe
+    hostapi, ops = env
+    rng = np.random.default_rng(21)
+    E, k, hidden, proj, G, T, nranks = 8, 3, 256, 256, -1, 4, 2
+    def experts(K, N):
+        qs, ss, zs = [], [], []
+        for _ in range(E):
+            q, s_, z = quant.iq_quantize_a16w8(bf16_round(rng.normal(0, 0.05, (K, N)).astype(np.float32)), G, "bf16")
+            qs.append(q); ss.append(s_); zs.append(z)
+        return np.stack(qs), np.stack(ss), np.stack(zs)
+    gq, gs, gz = experts(hidden, proj)
+    uq, us, uz = experts(hidden, proj)
+    dq, ds, dz = experts(proj, hidden)
+    x = bf16_round(rng.normal(0, 1, (T, 1, hidden)).astype(np.float32))
+    logits = bf16_round(rng.normal(0, 1.5, (T, 1, E)).astype(np.float32))
+    total = np.zeros((T, hidden), np.float32)
+    for rank in range(nranks):
+        lo, hi = rank * E // nranks, (rank + 1) * E // nranks
+        m = hostapi.Model(ops.cur_stream(), 4, 2, 128, 16, rank=rank, nranks=nranks)
+        m.set_weight("gu", torch.from_numpy(np.concatenate([gq[lo:hi], uq[lo:hi]], axis=2)).cuda(), "i8")
+        m.set_weight("gu.scales", dev(np.concatenate([gs[lo:hi], us[lo:hi]], axis=2)), "bf16")
+        m.set_weight("gu.zeros", dev(np.concatenate([gz[lo:hi], uz[lo:hi]], axis=2)), "bf16")
+        m.set_weight("dn", torch.from_numpy(dq[lo:hi]).cuda(), "i8")
+        m.set_weight("dn.scales", dev(ds[lo:hi]), "bf16")
+        m.set_weight("dn.zeros", dev(dz[lo:hi]), "bf16")
+        m.set_tensor("x", dev(x), "bf16")
+        m.set_tensor("router", dev(logits), "bf16")
+        op = m.create_op("MOEA16W8", "moe", ["x", "router"], ["y"], ["gu", "gu.scales", "gu.zeros", "dn", "dn.scales", "dn.zeros"],
+                         f"num_experts=i:{E};num_experts_per_tok=i:{k};use_ep=i:1")
+        m.reshape(op)
+        m.alloc(op)
+        m.forward(op)
+        _, shape, ptr = m.get_tensor("y")
+        total += view_of(ptr, shape, torch.bfloat16).float().cpu().numpy().reshape(T, hidden)
+        if rank == 0:
+            # CalcExpert on this rank's output
+            w = bf16_round(rng.uniform(0, 1, (T, 1, 1)).astype(np.float32))
+            m.set_tensor("w", dev(w), "bf16")
+            ce = m.create_op("CalcExpert", "calc", ["y", "w"], ["c"], [], "num_experts=f:1")
+            m.reshape(ce)
+            m.alloc(ce)
+            m.forward(ce)
+            _, cshape, cptr = m.get_tensor("c")
+            got = view_of(cptr, cshape, torch.bfloat16).float().cpu().numpy().reshape(T, hidden)
+            y0 = view_of(ptr, shape, torch.bfloat16).float().cpu().numpy().reshape(T, hidden)
+            np.testing.assert_array_equal(got, bf16_round(y0 * w.reshape(T, 1)))
+        m.close()
+    s_ref, e_ref = moe.route(logits.reshape(T, E), k)
+    ref = moe.experts_ffn(x.reshape(T, hidden), e_ref, s_ref, list(zip(gq, gs, gz)), list(zip(uq, us, uz)), list(zip(dq, ds, dz)), G, 8)
+    np.testing.assert_allclose(total, ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max())
+
+
 def test_row_split_gemm_adds_the_residual_on_rank0_only(env):
     """Tensor parallel o_proj / down_proj (HSPLIT) with the fused binary ADD: the AllReduce sums the ranks' outputs, so the
     residual must enter once -- GemmOpBase::Reshape drops it on rank != 0 (gemm_op.cpp:133-137).  Two ranks' operators over

@@ -14,7 +14,7 @@ def test_ops_library_exports_header_symbols(pkg):
 def test_op_registry(pkg):
     from dash_infer_amd import hostapi
     ops = hostapi.lib().dihost_registered_ops().decode().split(",")
-    assert sorted(ops) == sorted(["GemmA16W8", "GemmA16W4", "DecOptMHA", "DecOptMQA", "AllReduce", "AllGather", "MOEA16W8"])
+    assert sorted(ops) == sorted(["GemmA16W8", "GemmA16W4", "DecOptMHA", "DecOptMQA", "AllReduce", "AllGather", "MOEA16W8", "CalcExpert"])
 
 
 def test_unknown_op_type_is_rejected(pkg):
