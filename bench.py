@@ -334,13 +334,15 @@ def pmc_traffic(kernel_substr):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.csv")))
     if not files:
-        return None
+        return None, None
     key = kernel_substr.rstrip(">")  # template argument lists may have grown a defaulted tail
     tot = 0
     for r in csv.DictReader(open(files[-1])):
         if key in r["kernel"]:
             tot += int(r["avg_bytes_corrected"])
-    return tot or None
+    # not measured by THIS run: counters need their own rocprofv3 passes (tools/gpu_pmc.sh); the summary read here is named
+    return (tot or None), "committed PMC summary profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, " \
+                          "gfx950 FETCH_SIZE x2 correction); not collected by this run" % os.path.basename(files[-1])
 
 
 def main():
@@ -481,10 +483,11 @@ def main():
                 fam = "gemm_panel_kernel" if os.environ.get("DIHIP_GEMM_KSLICE", "1") == "0" else "gemm_kslice_kernel"
                 kname = "%s<%d, 2, %d, 1, %d>" % (fam, wbits, 2 if batch > 16 else 1, gpt)
                 kdesc = " (gate/up small-batch GEMM + SwiGLU; the timed launch pair includes the RMSNorm kernel)"
+            traffic, traffic_source = pmc_traffic(kname) if (args.workload == "int4_b1" and world == 1) else (None, None)  # PMC pass: TP=1 shapes
             out["roofline"] = {"bound": "hbm", "kernel": "dihip::" + kname + kdesc,
                                "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4),
-                               "traffic": pmc_traffic(kname) if (args.workload == "int4_b1" and world == 1) else None,  # PMC pass: TP=1 shapes
+                               "traffic": traffic, "traffic_source": traffic_source,
                                "avg_launch_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["bytes"]}
             out["kernels"] = kb
         except Exception as e:  # never lose the headline number to the breakdown
