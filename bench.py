@@ -372,7 +372,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        comm = decoder.make_comm(rank, world, torch.device("cuda", local_rank), allow_labelled_fallback=True)
+        # "auto": the one-shot peer-to-peer all-reduce if its guarded set-up + probe pass on every rank, RCCL otherwise (labelled)
+        comm = decoder.make_comm(rank, world, torch.device("cuda", local_rank), backend=os.environ.get("DIHIP_TP_ALLREDUCE", "auto"),
+                                 allow_labelled_fallback=True)
 
     wbits, group, kv_mode, batch, gptq = WORKLOADS[args.workload]
     if args.workload == "moe_layer":

@@ -108,6 +108,8 @@ _SIGS = {
     "dihip_ipc_close_handle": (i32, [vp]),
     "dihip_p2p_ar_create": (i32, [C.POINTER(vp), i32, i32, C.POINTER(vp)]),
     "dihip_p2p_ar_destroy": (i32, [vp]),
+    "dihip_p2p_ar_set_timeout": (i32, [vp, C.c_ulonglong, i32]),
+    "dihip_p2p_ar_error": (i32, [vp, vp]),
     "dihip_p2p_allreduce_sum": (i32, [vp, vp, vp, vp, sz, i32]),
     "dihip_debug_set_trace": (i32, [vp, sz]),
     "dihip_debug_gemv_plan": (i32, [i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32),

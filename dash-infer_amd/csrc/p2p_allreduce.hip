@@ -44,17 +44,22 @@ constexpr size_t P2P_BUFFER_BYTES = P2P_DATA_BYTES + P2P_FLAGS_BYTES;
 struct P2PState {  // device-resident, private to the rank
   unsigned epoch;  // completed calls
   unsigned done;   // workgroups of the running call that have finished
+  unsigned error;  // a wait gave up (probe mode: dihip_p2p_ar_set_timeout(.., trap = 0)); the communicator is unusable afterwards
 };
 
 struct P2PComm {
   int rank, nranks;
   unsigned char* bufs[P2P_MAX_RANKS];
   P2PState* state;
+  unsigned long long max_spins = 1ull << 24;  // tens of seconds
+  int trap = 1;
 };
 
 struct P2PArgs {
   unsigned char* bufs[P2P_MAX_RANKS];
   P2PState* state;
+  unsigned long long max_spins;
+  int trap;
   const void* in;
   void* out;
   unsigned count;  // elements
@@ -105,7 +110,11 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PArg
     // signed distance: flags only move forward, a flag "ahead" of this epoch cannot occur for this parity
     while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1ull << 24)) __builtin_trap();  // tens of seconds without the peer's row: fail loudly, never hang the box
+      if (++spins > a.max_spins) {  // without the peer's row for that long: fail loudly, never hang the box
+        if (a.trap) __builtin_trap();
+        __hip_atomic_store(&a.state->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // probe mode: report and leave
+        break;
+      }
     }
   }
   __syncthreads();
@@ -243,6 +252,8 @@ int dihip_p2p_allreduce_sum(void* comm, void* stream, const void* in, void* out,
   P2PArgs a{};
   for (int r = 0; r < c->nranks; ++r) a.bufs[r] = c->bufs[r];
   a.state = c->state;
+  a.max_spins = c->max_spins;
+  a.trap = c->trap;
   a.in = in;
   a.out = out;
   a.count = (unsigned)count;
@@ -256,6 +267,24 @@ int dihip_p2p_allreduce_sum(void* comm, void* stream, const void* in, void* out,
   else if (dtype == DIHIP_F16) hipLaunchKernelGGL(p2p_allreduce_kernel<DIHIP_F16>, dim3(wgs), dim3(P2P_THREADS), 0, s, a);
   else hipLaunchKernelGGL(p2p_allreduce_kernel<DIHIP_F32>, dim3(wgs), dim3(P2P_THREADS), 0, s, a);
   return launch_status();
+}
+
+int dihip_p2p_ar_set_timeout(void* comm, unsigned long long max_spins, int trap) {
+  DIHIP_REQUIRE(comm && max_spins > 0, DIHIP_PARAM_ERROR, "p2p_ar_set_timeout: bad argument");
+  P2PComm* c = reinterpret_cast<P2PComm*>(comm);
+  c->max_spins = max_spins;
+  c->trap = trap ? 1 : 0;
+  return DIHIP_SUCCESS;
+}
+
+int dihip_p2p_ar_error(void* comm, int* error) {
+  DIHIP_REQUIRE(comm && error, DIHIP_PARAM_ERROR, "p2p_ar_error: null pointer");
+  P2PComm* c = reinterpret_cast<P2PComm*>(comm);
+  unsigned e = 0;
+  const hipError_t rc = hipMemcpy(&e, &c->state->error, sizeof(e), hipMemcpyDeviceToHost);  // synchronises with the device
+  DIHIP_REQUIRE(rc == hipSuccess, DIHIP_RUNTIME_ERROR, "p2p_ar_error: hipMemcpy: %s", hipGetErrorString(rc));
+  *error = (int)e;
+  return DIHIP_SUCCESS;
 }
 
 }  // extern "C"

@@ -278,37 +278,84 @@ class TorchComm:
         return dst
 
 
+class P2PUnavailable(RuntimeError):
+    """raised on EVERY rank (the ranks agree first) when the peer-to-peer all-reduce cannot be set up or fails its probe"""
+
+
+def _all_ranks_ok(ok, device):
+    import torch.distributed as dist
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 class P2PComm:
     """One-shot peer-to-peer all-reduce (csrc/p2p_allreduce.hip): every rank writes its row into every peer's receive buffer
     over xGMI; the receive buffers are exchanged as IPC handles over the torch.distributed process group (plumbing).
-    The (rare, tiny) all-gather of the arg-max pairs and messages beyond the slot size go through `rccl`."""
+    The (rare, tiny) all-gather of the arg-max pairs and messages beyond the slot size go through `rccl`.
+
+    guarded=True (make_comm backend "auto"): every local stage is followed by an agreement between the ranks, and the first
+    exchanges run in the kernel's probe mode (a wait that gives up sets an error word instead of trapping), so that a node
+    on which the IPC / peer path does not work ends in P2PUnavailable on all ranks -- not in a hang, a trap or a rank that
+    sits alone in a collective."""
     backend = "p2p-oneshot"
 
-    def __init__(self, rank, nranks, device, rccl):
+    def __init__(self, rank, nranks, device, rccl, guarded=False):
         import torch.distributed as dist
         self.rank, self.nranks, self.rccl = rank, nranks, rccl
         l = lib()
-        self.buf = C.c_void_p()
-        check(l.dihip_p2p_ar_alloc(C.byref(self.buf)), "dihip_p2p_ar_alloc")
+        self.buf, self.handle, self.opened = C.c_void_p(), C.c_void_p(), []
         raw = (C.c_ubyte * 64)()
-        check(l.dihip_ipc_get_handle(self.buf, raw), "dihip_ipc_get_handle")
+
+        def stage(what, fn):
+            err = None
+            try:
+                fn()
+            except Exception as e:  # noqa: BLE001
+                if not guarded:
+                    raise
+                err = e
+            if guarded and not _all_ranks_ok(err is None, device):
+                raise P2PUnavailable(f"{what}: {err if err is not None else 'failed on another rank'}")
+
+        def alloc():
+            check(l.dihip_p2p_ar_alloc(C.byref(self.buf)), "dihip_p2p_ar_alloc")
+            check(l.dihip_ipc_get_handle(self.buf, raw), "dihip_ipc_get_handle")
+        stage("receive buffer / IPC handle", alloc)
         mine = torch.tensor(list(raw), dtype=torch.uint8, device=device)
         allh = [torch.zeros(64, dtype=torch.uint8, device=device) for _ in range(nranks)]
         dist.all_gather(allh, mine)
-        ptrs = (C.c_void_p * nranks)()
-        self.opened = []
-        for r in range(nranks):
-            if r == rank:
-                ptrs[r] = self.buf.value
-            else:
-                p = C.c_void_p()
-                check(l.dihip_ipc_open_handle(bytes(allh[r].cpu().tolist()), C.byref(p)), "dihip_ipc_open_handle")
-                ptrs[r] = p.value
-                self.opened.append(p)
-        self.handle = C.c_void_p()
-        check(l.dihip_p2p_ar_create(C.byref(self.handle), rank, nranks, ptrs), "dihip_p2p_ar_create")
+
+        def connect():
+            ptrs = (C.c_void_p * nranks)()
+            for r in range(nranks):
+                if r == rank:
+                    ptrs[r] = self.buf.value
+                else:
+                    p = C.c_void_p()
+                    check(l.dihip_ipc_open_handle(bytes(allh[r].cpu().tolist()), C.byref(p)), "dihip_ipc_open_handle")
+                    ptrs[r] = p.value
+                    self.opened.append(p)
+            check(l.dihip_p2p_ar_create(C.byref(self.handle), rank, nranks, ptrs), "dihip_p2p_ar_create")
+        stage("opening the peers' buffers", connect)
         self.max_bytes = int(l.dihip_p2p_ar_max_bytes())
         dist.barrier()  # every rank has opened every buffer before the first push
+        if guarded:
+            def probe():
+                check(l.dihip_p2p_ar_set_timeout(self.handle, 1 << 19, 0), "dihip_p2p_ar_set_timeout")  # ~ a second, no trap
+                want = nranks * (nranks + 1) / 2
+                for dt, n in ((torch.float32, 8), (torch.bfloat16, 3584)):
+                    for _ in range(4):
+                        t = torch.full((n,), float(rank + 1), dtype=dt, device=device)
+                        self.allreduce_(t)
+                        e = C.c_int(0)
+                        check(l.dihip_p2p_ar_error(self.handle, C.byref(e)), "dihip_p2p_ar_error")
+                        if e.value:
+                            raise RuntimeError("a peer's row did not arrive (probe timeout)")
+                        if abs(float(t[0]) - want) > 1e-3 or abs(float(t[-1]) - want) > 1e-3:
+                            raise RuntimeError(f"wrong sum {float(t[0])} (expected {want})")
+                check(l.dihip_p2p_ar_set_timeout(self.handle, 1 << 24, 1), "dihip_p2p_ar_set_timeout")
+            stage("probe exchange", probe)
 
     def allreduce_(self, t):
         nbytes = t.numel() * t.element_size()
@@ -326,6 +373,8 @@ def make_comm(rank, nranks, device, backend=None, allow_labelled_fallback=False)
     """The tensor-parallel communicator, verified with one all-reduce.  backend (default: $DIHIP_TP_ALLREDUCE or "rccl"):
       "rccl"  ncclAllReduce over xGMI through the C-ABI (dihip_allreduce_sum)
       "p2p"   one-shot peer-to-peer all-reduce for decode-sized rows (dihip_p2p_allreduce_sum), RCCL for the rest
+      "auto"  "p2p" if its guarded set-up and probe succeed on every rank (P2PComm(guarded=True)), else "rccl" -- and
+              `.backend` says which and why (bench.py's default: the peer-to-peer path has never run between processes)
       "torch" torch.distributed collectives (diagnostics only)
     A backend that cannot be created or returns a wrong sum RAISES: a benchmark line must never come from a silently
     substituted path.  `.backend` names what runs.  allow_labelled_fallback (bench.py on a multi-GPU node it
@@ -334,11 +383,19 @@ def make_comm(rank, nranks, device, backend=None, allow_labelled_fallback=False)
     backend = backend or os.environ.get("DIHIP_TP_ALLREDUCE", "rccl")
     if backend == "torch":
         c = TorchComm(rank, nranks)
-    elif backend in ("rccl", "p2p"):
+    elif backend in ("rccl", "p2p", "auto"):
         try:
             c = RcclComm(rank, nranks, device)
             if backend == "p2p":
                 c = P2PComm(rank, nranks, device, c)
+            elif backend == "auto":
+                try:
+                    c = P2PComm(rank, nranks, device, c, guarded=True)
+                except P2PUnavailable as e:
+                    import sys
+                    print(f"[rank {rank}] peer-to-peer all-reduce unavailable ({e}); RCCL all-reduce instead (recorded in comm_backend)",
+                          file=sys.stderr)
+                    c.backend = f"rccl (p2p-oneshot unavailable: {str(e)[:120]})"
         except Exception as e:  # noqa: BLE001
             if not allow_labelled_fallback:
                 raise

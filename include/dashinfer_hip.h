@@ -451,6 +451,12 @@ int dihip_ipc_close_handle(void* dev_ptr);
 int dihip_p2p_ar_create(void** comm, int rank, int nranks, void* const* bufs);
 int dihip_p2p_ar_destroy(void* comm);
 int dihip_p2p_allreduce_sum(void* comm, void* stream, const void* in, void* out, size_t count, int dtype);
+/* How long a call waits for a peer's row (polls of ~100 ns; default 2^24) and what happens then: trap != 0 (default) aborts the
+ * process -- a hung collective must never hang the box; trap == 0 is for PROBING a freshly created communicator: the kernel
+ * gives up, sets an error word and returns; dihip_p2p_ar_error reads it (synchronises).  After an error the communicator's
+ * epochs are out of step with its peers': destroy it. */
+int dihip_p2p_ar_set_timeout(void* comm, unsigned long long max_spins, int trap);
+int dihip_p2p_ar_error(void* comm, int* error);
 
 /* =============================================================================================
  * 7. Diagnostics (no reference counterpart)
