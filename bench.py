@@ -34,9 +34,12 @@ WORKLOADS = {
     # BASELINE configs[4] (decode part): the MoE feed-forward block of Qwen2-57B-A14B -- router, top-8 of 64 int8 experts
     # (3584 -> 2560 -> 3584), combine -- 16 tokens, 28 layers' expert stacks; attention / shared expert are the dense path
     "moe_layer":     (8, -1, "none", 16, False),
+    # BASELINE configs[4] as a whole decode step on ONE GPU: Qwen2-57B-A14B int8 per-channel (attention, router, 64 routed experts
+    # top-8, shared expert behind its sigmoid gate; 28 layers, ~57 GB of int8 weights), batch 16, 1024 cached tokens ("prefix")
+    "cfg5_moe":      (8, -1, "none", 16, False),
 }
 SEQ_LEN = 2048
-SEQ_LEN_OF = {"cfg3_rank": 4096}
+SEQ_LEN_OF = {"cfg3_rank": 4096, "cfg5_moe": 1024}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -390,6 +393,8 @@ def main():
         assert world == 1, "cfg3_rank times ONE rank's share of the TP = 8 step on one GPU (use --gpus 1)"
         cfg = decoder.ModelConfig("Qwen2-72B/TP8-rank", hidden=8192, layers=80, n_heads=8, n_kv=1, head_dim=128, inter=3712, vocab=19008)
         model_name = "Qwen2-72B (rank-local share of TP=8: all-reduce excluded)"
+    if args.workload == "cfg5_moe":
+        cfg, model_name = decoder.QWEN2_57B_A14B, "Qwen2-57B-A14B"
     spec = decoder.QuantSpec(wbits, group, gptq_like_zeros=gptq)
     t_build = time.time()
     model = decoder.build_random_model(cfg, spec, seed=1234, rank=rank, nranks=world, layers=args.layers)
@@ -399,6 +404,7 @@ def main():
     gen = torch.Generator().manual_seed(7)
     ids = torch.randint(0, cfg.vocab, (batch,), generator=gen)
     sess.set_state(ids, [SEQ_LEN] * batch)
+    distinct_experts = sess.count_distinct_experts() if cfg.moe is not None else None
     t_build = time.time() - t_build
 
     def barrier():
@@ -468,12 +474,22 @@ def main():
         "ar_overlap": bool(getattr(sess, "ar_overlap", False)),        # all-reduce on a side stream + weight prefetch beside it
         "build_s": round(t_build, 1),
         "last_ids": last_ids[:4],
+        **({"distinct_routed_experts_per_layer": distinct_experts} if distinct_experts is not None else {}),
     }
     if args.layers is not None:
         out["invalid"] = "debug run with a truncated layer stack"
 
+    if rank == 0 and cfg.moe is not None:
+        out["roofline"] = {"bound": "hbm", "kernel": "whole decode step (the routed experts' slot GEMVs dominate: dihip::gemv_stream_kernel<8, 2, 1, 0, *, 0, true>; "
+                                                       "their block alone is --workload moe_layer)",
+                           "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
+                           "traffic": None, "traffic_source": None,
+                           "note": "algorithmic bytes count every DISTINCT routed expert of a layer once per step; the slot kernels stream an "
+                                   "expert once per token that picked it"}
     if rank == 0:
         try:
+            if cfg.moe is not None:
+                raise StopIteration  # the per-kernel breakdown below is the dense layer's
             kb = kernel_breakdown(sess, torch, ops)
             dom = kb["gate_up_swiglu"]
             gpt = 1 if (group > 0 and group == (128 if wbits == 4 else 64)) else 0
@@ -492,6 +508,8 @@ def main():
                                "traffic": traffic, "traffic_source": traffic_source,
                                "avg_launch_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["bytes"]}
             out["kernels"] = kb
+        except StopIteration:
+            pass
         except Exception as e:  # never lose the headline number to the breakdown
             out["roofline_error"] = repr(e)
         if world == 1 and not args.no_cpu_baseline and args.workload in ("int4_b1", "int8_b1", "int4_b32_u4kv"):  # the CPU graph below is Qwen2-7B's

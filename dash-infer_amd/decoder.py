@@ -79,6 +79,7 @@ class LayerWeights:
     exp_up: Optional[ops.PackedExperts] = None
     exp_down: Optional[ops.PackedExperts] = None
     ep: Optional[tuple] = None                       # (first expert, count) of this rank
+    expert_bytes: int = 0                            # packed bytes of ONE routed expert (gate + up + down, with scales / zeros)
 
 
 @dataclass
@@ -205,7 +206,8 @@ def build_random_model(cfg: ModelConfig, spec: QuantSpec, seed=1234, device="cud
             # streamed per token: the router, top_k experts, the shared expert (already counted) and its gate
             per_expert = (lw.exp_gate.w.numel() + lw.exp_gate.sz.numel() + lw.exp_up.w.numel() + lw.exp_up.sz.numel()
                           + lw.exp_down.w.numel() + lw.exp_down.sz.numel()) // per
-            wbytes += lw.router.nbytes + lw.shared_sig.nbytes + mc.top_k * per_expert // nranks
+            wbytes += lw.router.nbytes + lw.shared_sig.nbytes   # the routed experts a step touches depend on the routing:
+            lw.expert_bytes = per_expert                         # DecodeSession.count_distinct_experts() measures them
             if fp is not None:
                 fp[li]["moe"] = {"router": w_router, "shared_gate_w": w_sig, "top_k": mc.top_k,
                                  "experts_gate": [q for _, q in eq["gate"]], "experts_up": [q for _, q in eq["up"]],
@@ -672,6 +674,8 @@ class DecodeSession:
         ops.rmsnorm_rows(self.h, lw.ln2, cfg.eps, out=self.moe_xn)
         ops.gemm_dense(self.moe_xn, lw.router, out=self.moe_logits, scratch=self.moe_dense_scratch)
         ops.moe_route(self.moe_logits, cfg.moe.top_k, ep=lw.ep, scores=self.moe_scores, experts=self.moe_experts)
+        if getattr(self, "_expert_log", None) is not None:
+            self._expert_log.append(self.moe_experts.clone())
         ops.moe_experts(self.moe_xn, self.moe_experts, self.moe_scores, lw.exp_gate, lw.exp_up, lw.exp_down, ws=self.moe_ws, out=self.moe_out)
         ops.prenorm_swiglu(self.moe_xn, lw.gate, lw.up, sc, B, out=self.moe_act)
         ops.gemm_lowp(self.moe_act, lw.down, scratch=sc, out=self.moe_shared)
@@ -755,4 +759,21 @@ class DecodeSession:
         cfg = self.model.cfg
         kvb = {"none": self.H * 2, "i8": self.H + 8, "u4": self.H // 2 + 8}[self.kv_mode]
         kv = len(self.model.layers) * self.B * 2 * self.g_loc * seq_len * kvb
-        return self.model.weight_bytes + kv
+        return self.model.weight_bytes + kv + getattr(self, "routed_expert_bytes", 0)
+
+    def count_distinct_experts(self):
+        """Mixture-of-experts models: one eager step on a copy of the state that records, per layer, how many DISTINCT local
+        experts the batch selected -- each is streamed once per token that picked it by the slot kernels, but algorithmically
+        once per step.  Sets self.routed_expert_bytes (added to algorithmic_bytes_per_step) and returns the per-layer counts."""
+        assert self.model.cfg.moe is not None
+        ids0, old0, new0 = self.ids.clone(), self.old_lens.clone(), self.new_lens.clone()
+        self._expert_log = []
+        self.step()
+        torch.cuda.synchronize()
+        counts = [int((e[e >= 0]).unique().numel()) for e in self._expert_log]
+        self._expert_log = None
+        self.ids.copy_(ids0)
+        self.old_lens.copy_(old0)
+        self.new_lens.copy_(new0)
+        self.routed_expert_bytes = sum(c * lw.expert_bytes for c, lw in zip(counts, self.model.layers))
+        return counts

@@ -18,7 +18,7 @@ d = json.load(open("$OUT/bench_int4_b1.json"))
 print("int4_b1", d["value"], d["ms_per_step"], d["step_hbm"]["frac_of_peak"], d["roofline"]["frac"], {k: v["avg_us"] for k, v in d["kernels"].items()})
 print("cpu_baseline", d.get("cpu_baseline"))
 PY
-for w in int8_b1 int4_b32_u4kv cfg3_rank moe_layer; do
+for w in int8_b1 int4_b32_u4kv cfg3_rank moe_layer cfg5_moe; do
   timeout 300 python bench.py --workload $w --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err
   python - <<PY
 import json
