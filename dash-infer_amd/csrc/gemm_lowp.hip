@@ -438,7 +438,9 @@ static KslicePlan make_kslice_plan(int wbits, int M, int N, int K, int group_siz
 // One launch of M = 1 GEMVs over (token, expert-rank) slots (mixture-of-experts, moe.hip): slot s streams expert
 // slot_expert[s] of a stack of equally shaped packed weights, reads activation row s / x_div, writes row s.
 int run_gemv_slots(hipStream_t stream, int wbits, int epi, const void* x, int ldx, int x_div, const void* w0, const void* sz0,
-                   const void* w1, const void* sz1, void* y, int N, int K, int group_size, const int* slot_expert, int nslots) {
+                   const void* w1, const void* sz1, void* y, int N, int K, int group_size, const int* slot_expert, int nslots,
+                   const int* group_rows, const int* group_nrows) {
+  const bool grouped = group_rows != nullptr;  // slot_expert / nslots then enumerate groups of <= 4 slots (moe.hip)
   const bool dual = epi == EPI_SWIGLU;
   const LowpDims d = lowp_dims(wbits, N, K, group_size);
   DIHIP_REQUIRE(K == d.Kp && (d.group == 0 || d.group % d.KTILE == 0), DIHIP_PARAM_ERROR,
@@ -447,7 +449,7 @@ int run_gemv_slots(hipStream_t stream, int wbits, int epi, const void* x, int ld
   int ncu = cached_num_cus();
   if (ncu <= 0) ncu = 256;
   const int want = std::max((d.NTILES + 7) / 8, (ncu + nslots - 1) / nslots);
-  const GemvPlan gp = make_gemv_plan(wbits, 1, N, K, group_size, dual, want);
+  const GemvPlan gp = make_gemv_plan(wbits, grouped ? 4 : 1, N, K, group_size, dual, want);
   DIHIP_REQUIRE(gp.ok && gp.lds_bytes <= 64 * 1024, DIHIP_PARAM_ERROR, "moe: unsupported expert shape N=%d K=%d", N, K);
   GemvArgs g{};
   g.w0 = reinterpret_cast<const u32x4_t*>(w0);
@@ -460,7 +462,9 @@ int run_gemv_slots(hipStream_t stream, int wbits, int epi, const void* x, int ld
   g.ldy = N;
   g.alpha = 1.f;
   g.act = DIHIP_ACT_NONE;
-  g.M = 1;
+  g.M = grouped ? 4 : 1;
+  g.slot_rows = group_rows;
+  g.slot_nrows = group_nrows;
   g.N = N;
   g.K = K;
   g.KT = d.KT;
@@ -481,8 +485,10 @@ int run_gemv_slots(hipStream_t stream, int wbits, int epi, const void* x, int ld
   g.nslots = nslots;
   const bool gpt = gp.ktpg == 1;
   hipError_t e = hipErrorInvalidValue;
-#define SLOT_GO(W_, EPI_, G_) \
-  if (wbits == W_ && epi == EPI_ && (int)gpt == G_) e = launch_gemv_slots<W_, DIHIP_BF16, EPI_, G_>(g, gp.blocks, gp.lds_bytes, stream);
+#define SLOT_GO(W_, EPI_, G_)                                                                                          \
+  if (wbits == W_ && epi == EPI_ && (int)gpt == G_)                                                                    \
+    e = grouped ? launch_gemv_slots<W_, DIHIP_BF16, EPI_, G_, 4>(g, gp.blocks, gp.lds_bytes, stream)                   \
+                : launch_gemv_slots<W_, DIHIP_BF16, EPI_, G_, 1>(g, gp.blocks, gp.lds_bytes, stream);
   SLOT_GO(8, EPI_SWIGLU, 0) SLOT_GO(8, EPI_STD, 0) SLOT_GO(8, EPI_SWIGLU, 1) SLOT_GO(8, EPI_STD, 1)
   SLOT_GO(4, EPI_SWIGLU, 0) SLOT_GO(4, EPI_STD, 0) SLOT_GO(4, EPI_SWIGLU, 1) SLOT_GO(4, EPI_STD, 1)
 #undef SLOT_GO

@@ -130,6 +130,11 @@ struct GemvArgs {
   size_t w_estride, sz_estride;  // u32x4 / u32 elements between consecutive experts' packed tensors
   int x_div;                     // activation row of slot s = s / x_div
   int nslots;
+  // SLOT with MR > 1 (grouped slots): gridDim.y enumerates GROUPS of up to 4 slots that picked the same expert; group g
+  // streams expert slot_expert[g] once for its slot_nrows[g] rows, reads activation rows slot_rows[4g + r] / x_div and
+  // writes rows slot_rows[4g + r]
+  const int* slot_rows;
+  const int* slot_nrows;
   // PUB (fused decode-step launch): publication counters and the head geometry that maps a column tile to its KV group
   unsigned* front_counter;
   int front_n, front_g, front_hpg;
@@ -177,9 +182,24 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
     p_sz0 = a.sz0 + (size_t)e_ * a.sz_estride;
     if (a.w1) p_w1 = a.w1 + (size_t)e_ * a.w_estride;
     if (a.sz1) p_sz1 = a.sz1 + (size_t)e_ * a.sz_estride;
-    p_x = reinterpret_cast<const uint16_t*>(a.x) + (size_t)(s_ / a.x_div) * a.ldx;
-    p_y = reinterpret_cast<uint16_t*>(a.y) + (size_t)s_ * a.ldy;
+    if constexpr (MR == 1) {
+      p_x = reinterpret_cast<const uint16_t*>(a.x) + (size_t)(s_ / a.x_div) * a.ldx;
+      p_y = reinterpret_cast<uint16_t*>(a.y) + (size_t)s_ * a.ldy;
+    } else {
+      // row 0 of the group: the early activation loads take their base from p_x (rows > 0: x_row below)
+      const int r0_ = __builtin_amdgcn_readfirstlane(a.slot_rows[(size_t)s_ * 4]);
+      p_x = reinterpret_cast<const uint16_t*>(a.x) + (size_t)(r0_ / a.x_div) * a.ldx;
+    }
   }
+  // activation row r of this workgroup's rows (wave-uniform: feeds the "s" base of the asm loads)
+  auto x_row = [&](int r) -> const uint16_t* {
+    if constexpr (SLOT && MR > 1) {
+      const int sr_ = __builtin_amdgcn_readfirstlane(a.slot_rows[(size_t)blockIdx.y * 4 + r]);
+      return reinterpret_cast<const uint16_t*>(a.x) + (size_t)(sr_ / a.x_div) * a.ldx;
+    } else {
+      return reinterpret_cast<const uint16_t*>(p_x) + (size_t)r * a.ldx;
+    }
+  };
   using WT = WTraits<WBITS>;
   using EX = ExpandV<WBITS, FT>;
   constexpr int KSTEPS = WT::KSTEPS;
@@ -189,7 +209,7 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
   constexpr int D = GEMV_RING;
   constexpr int LPC = QUANT ? 2 : 1;  // loads per chunk
 
-  const int rows = MR == 1 ? 1 : a.M;  // <= 16
+  const int rows = MR == 1 ? 1 : (SLOT ? __builtin_amdgcn_readfirstlane(a.slot_nrows[blockIdx.y]) : a.M);  // <= 16
   uint16_t* xs = reinterpret_cast<uint16_t*>(smem + 256);
   float* xsum_tab = reinterpret_cast<float*>(smem + 256 + gemv_xs_bytes(rows, a.RS));
   float* red = xsum_tab + (size_t)a.KT * 16;
@@ -274,7 +294,7 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
         stream_load_plain_b128(V[2 * j + 1], hrow, i * 32u + 16u);
         stream_load_plain_b128(G[j], a.gamma, i * 16u);
       } else {
-        stream_load_plain_b128(V[j], reinterpret_cast<const uint16_t*>(p_x) + (size_t)r * a.ldx, i * 16u);
+        stream_load_plain_b128(V[j], x_row(r), i * 16u);
       }
     }
     stream_wait<0>();
@@ -635,15 +655,17 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
       const float* p2 = p + (size_t)a.WK * rows * 16;
       for (int s = 0; s < a.WK; ++s) v2 += p2[(size_t)s * rows * 16];
     }
+    size_t yrow = (size_t)m * a.ldy;  // grouped slots: the row's slot
+    if constexpr (SLOT && MR > 1) yrow = (size_t)a.slot_rows[(size_t)blockIdx.y * 4 + m] * a.ldy;
     if constexpr (EPI == EPI_STD) {
       v = __fmul_rn(a.alpha, v);
       if (a.bias) v = __fadd_rn(v, load_ft<FT>(a.bias, n));
       v = apply_act(v, a.act);
-      if (a.residual) v = ft_round<FT>(v) + load_ft<FT>(a.residual, (size_t)m * a.ldy + n);
-      if constexpr (PUB) store_ft_wt<FT>(p_y, (size_t)m * a.ldy + n, v);
-      else store_ft<FT>(p_y, (size_t)m * a.ldy + n, v);
+      if (a.residual) v = ft_round<FT>(v) + load_ft<FT>(a.residual, yrow + n);
+      if constexpr (PUB) store_ft_wt<FT>(p_y, yrow + n, v);
+      else store_ft<FT>(p_y, yrow + n, v);
     } else if constexpr (EPI == EPI_SWIGLU) {
-      store_ft<FT>(p_y, (size_t)m * a.ldy + n, (v / (1.f + expf(-v))) * v2);
+      store_ft<FT>(p_y, yrow + n, (v / (1.f + expf(-v))) * v2);
     } else {
       const float base = a.h_res ? a.h_res[(size_t)m * a.N + n] : 0.f;
       a.h_out[(size_t)m * a.N + n] = __fadd_rn(base, __fmul_rn(a.alpha, v));
@@ -677,13 +699,13 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArg
 
 template <int WBITS, int FT, int MR, int PRO, int EPI, int GPT>
 hipError_t launch_gemv_stream(const GemvArgs& a, int blocks, size_t lds_bytes, hipStream_t stream);
-template <int WBITS, int FT, int EPI, int GPT>
+template <int WBITS, int FT, int EPI, int GPT, int MR>
 hipError_t launch_gemv_slots(const GemvArgs& a, int blocks, size_t lds_bytes, hipStream_t stream);
 
-#define DIHIP_DEFINE_GEMV_SLOT_LAUNCH(WBITS, FT, EPI, GPT)                                                       \
+#define DIHIP_DEFINE_GEMV_SLOT_LAUNCH(WBITS, FT, EPI, GPT, MR)                                                   \
   template <>                                                                                                    \
-  hipError_t launch_gemv_slots<WBITS, FT, EPI, GPT>(const GemvArgs& a, int blocks, size_t lds_bytes, hipStream_t s) { \
-    auto kern = gemv_stream_kernel<WBITS, FT, 1, PRO_PLAIN, EPI, GPT, true>;                                     \
+  hipError_t launch_gemv_slots<WBITS, FT, EPI, GPT, MR>(const GemvArgs& a, int blocks, size_t lds_bytes, hipStream_t s) { \
+    auto kern = gemv_stream_kernel<WBITS, FT, MR, PRO_PLAIN, EPI, GPT, true>;                                    \
     hipLaunchKernelGGL(kern, dim3(blocks, a.nslots), dim3(GEMV_THREADS), lds_bytes, s, a);                       \
     return hipGetLastError();                                                                                    \
   }

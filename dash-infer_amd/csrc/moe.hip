@@ -21,7 +21,8 @@
 namespace dihip {
 
 int run_gemv_slots(hipStream_t stream, int wbits, int epi, const void* x, int ldx, int x_div, const void* w0, const void* sz0,
-                   const void* w1, const void* sz1, void* y, int N, int K, int group_size, const int* slot_expert, int nslots);
+                   const void* w1, const void* sz1, void* y, int N, int K, int group_size, const int* slot_expert, int nslots,
+                   const int* group_rows, const int* group_nrows);
 constexpr int MOE_EPI_STD = 0, MOE_EPI_SWIGLU = 1;  // EPI_STD / EPI_SWIGLU of gemm_lowp_kernel.hpp
 
 struct ScoreIdx {
@@ -125,6 +126,49 @@ __global__ __launch_bounds__(256) void moe_shared_combine_kernel(float* __restri
   h_out[i] = (base + load_ft<FT>(moe_out, i)) + calc;
 }
 
+// Slots that picked the same expert, gathered into groups of up to 4 (one workgroup; slots <= a few thousand): a group streams
+// its expert ONCE for all its rows (gemv_stream_kernel<.., MR = 4, SLOT>), where the per-slot launch streams it once per token
+// that picked it -- at 16 tokens x top-8 of 64 experts that is 128 expert reads for ~57 distinct experts.  The reference gets
+// the same effect from its reorder / pad / batched-GEMM machinery (moe_op.cpp:395-452).  Deterministic: expert e's slots keep
+// their order, groups are numbered by (expert, chunk).  Outputs for `nslots` group entries (unused ones: expert -1).
+__global__ __launch_bounds__(256) void moe_group_kernel(int* __restrict__ group_expert, int* __restrict__ group_rows,
+                                                        int* __restrict__ group_nrows, const int* __restrict__ experts, int nslots) {
+  __shared__ int s_groups[256], s_off[256];
+  const int e = threadIdx.x;
+  int cnt = 0;
+  for (int s = 0; s < nslots; ++s) cnt += experts[s] == e ? 1 : 0;
+  s_groups[e] = (cnt + 3) >> 2;
+  __syncthreads();
+  if (e == 0) {
+    int acc = 0;
+    for (int i = 0; i < 256; ++i) {
+      s_off[i] = acc;
+      acc += s_groups[i];
+    }
+  }
+  __syncthreads();
+  int g = s_off[e], r = 0;
+  for (int s = 0; s < nslots && cnt > 0; ++s) {
+    if (experts[s] != e) continue;
+    if (r == 0) {
+      group_expert[g] = e;
+      group_nrows[g] = 0;
+    }
+    group_rows[(size_t)g * 4 + r] = s;
+    group_nrows[g] = r + 1;
+    if (++r == 4) {
+      r = 0;
+      ++g;
+    }
+  }
+  // entries past the last group
+  const int total = s_off[255] + s_groups[255];
+  for (int i = total + e; i < nslots; i += 256) {
+    group_expert[i] = -1;
+    group_nrows[i] = 0;
+  }
+}
+
 // CalcExpert (csrc/core/kernel/cuda/calc_expert.cu:27-35): out[t, c] = in[t, c] * expert_weight[t]
 template <int FT>
 __global__ __launch_bounds__(256) void calc_expert_kernel(void* __restrict__ out, const void* __restrict__ in,
@@ -170,7 +214,7 @@ int dihip_moe_route_ep(void* stream, const void* router_logits, int num_tokens, 
 size_t dihip_moe_workspace_bytes(int num_tokens, int top_k, int hidden, int proj) {
   if (num_tokens <= 0 || top_k <= 0 || hidden <= 0 || proj <= 0) return 0;
   const size_t slots = (size_t)num_tokens * top_k;
-  return (slots * proj * 2 + 255) / 256 * 256 + slots * hidden * 2 + 256;
+  return (slots * proj * 2 + 255) / 256 * 256 + (slots * hidden * 2 + 255) / 256 * 256 + slots * 6 * sizeof(int) + 256;  // + group tables
 }
 
 int dihip_moe_experts(void* stream, int wbits, const void* x, const int32_t* experts, const float* scores,
@@ -190,11 +234,30 @@ int dihip_moe_experts(void* stream, int wbits, const void* x, const int32_t* exp
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   char* act = reinterpret_cast<char*>(ws);                                   // [slots, proj]  SiLU(gate) * up
   char* ys = act + (slots * proj * 2 + 255) / 256 * 256;                     // [slots, hidden] expert outputs
+  int* group_expert = reinterpret_cast<int*>(ys + (slots * hidden * 2 + 255) / 256 * 256);  // [slots] (+ rows [slots][4], nrows [slots])
+  int* group_rows = group_expert + slots;
+  int* group_nrows = group_rows + slots * 4;
+  // more than one token: slots of the same expert share one pass over its weights (moe_group_kernel); a single token's
+  // top-k experts are distinct, the per-slot launch is the same work without the grouping launch
+  static int group_on = -1;  // DIHIP_MOE_GROUP=0: per-slot launches (diagnostics)
+  if (group_on < 0) {
+    const char* e = getenv("DIHIP_MOE_GROUP");
+    group_on = (e && e[0] == '0') ? 0 : 1;
+  }
+  const bool grouped = group_on && num_tokens > 1;
+  const int* slot_expert = experts;
+  const int *rows = nullptr, *nrows = nullptr;
+  if (grouped) {
+    hipLaunchKernelGGL(moe_group_kernel, dim3(1), dim3(256), 0, s, group_expert, group_rows, group_nrows, experts, (int)slots);
+    slot_expert = group_expert;
+    rows = group_rows;
+    nrows = group_nrows;
+  }
   int st = run_gemv_slots(s, wbits, MOE_EPI_SWIGLU, x, hidden, top_k, gate_packed, gate_sz, up_packed, up_sz, act, proj, hidden,
-                          group_size, experts, (int)slots);
+                          group_size, slot_expert, (int)slots, rows, nrows);
   if (st) return st;
   st = run_gemv_slots(s, wbits, MOE_EPI_STD, act, proj, 1, down_packed, down_sz, nullptr, nullptr, ys, hidden, proj, group_size,
-                      experts, (int)slots);
+                      slot_expert, (int)slots, rows, nrows);
   if (st) return st;
   hipLaunchKernelGGL(moe_finalize_kernel<DIHIP_BF16>, dim3((hidden + 511) / 512, num_tokens), dim3(256), 0, s, out, ys, scores, experts,
                      top_k, hidden);
