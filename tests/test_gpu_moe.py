@@ -156,3 +156,39 @@ def test_experts_tensor_parallel_split(ops, wbits, G, nranks):
         acc += out_r.float().cpu().numpy()
     ref = full.float().cpu().numpy()
     np.testing.assert_allclose(acc, ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("wbits,G,T,E,k", [(8, -1, 16, 4, 2), (4, 128, 9, 6, 3), (8, 128, 5, 5, 1), (8, -1, 32, 64, 8)])
+def test_grouped_experts_equal_the_per_token_calls(ops, wbits, G, T, E, k):
+    """More than one token: slots that picked the same expert are gathered into groups of up to 4 rows that stream the expert
+    once (moe_group_kernel + the MR = 4 slot GEMV).  A one-token call takes the per-slot launches: row t of the T-token call
+    must equal the call on token t alone up to the f32 summation order of the K split (the launch plan -- units per
+    workgroup, waves across K -- follows the slot count, so the two calls may split K differently) -- with few experts
+    (every expert hit by many tokens: full groups, partial last groups), with skipped slots (expert parallelism: -1), and
+    with every slot's expert distinct per token (top-k of one token never repeats an expert)."""
+    rng = np.random.default_rng(T * 7 + E + k)
+    hidden, proj = 256, 384
+    gate = pack(ops, *make_experts(rng, E, proj, hidden, G, wbits), G, wbits)
+    up = pack(ops, *make_experts(rng, E, proj, hidden, G, wbits), G, wbits)
+    down = pack(ops, *make_experts(rng, E, hidden, proj, G, wbits), G, wbits)
+    x = dev(bf16_round(rng.normal(0, 1, (T, hidden)).astype(np.float32)), torch.bfloat16)
+    logits = dev(bf16_round(rng.normal(0, 2, (T, E)).astype(np.float32)), torch.bfloat16)
+    scores, experts = ops.moe_route(logits, k)
+    for ep in (None, (0, max(1, E // 2))):          # whole stack / expert-parallel window (slots outside it are skipped)
+        if ep is not None:
+            scores, experts = ops.moe_route(logits, k, ep=ep)
+            if int((experts >= 0).sum()) == 0:
+                continue
+            # the window's experts are the first E/2 of the same stacks: positions coincide with global ids
+        whole = ops.moe_experts(x, experts, scores, gate, up, down)
+        torch.cuda.synchronize()
+        for t in range(T):
+            one = ops.moe_experts(x[t:t + 1].contiguous(), experts[t:t + 1].contiguous(), scores[t:t + 1].contiguous(), gate, up, down)
+            torch.cuda.synchronize()
+            a, b = whole[t].float(), one[0].float()
+            tol = 2.0 ** -7 * max(float(b.abs().max()), 1e-3)   # two bf16 roundings (expert output, combine) of sums in another order
+            assert float((a - b).abs().max()) <= tol, f"token {t} (ep={ep}): max diff {(a - b).abs().max()} > {tol}"
+    # run-to-run determinism of the grouped path
+    again = ops.moe_experts(x, experts, scores, gate, up, down)
+    torch.cuda.synchronize()
+    assert torch.equal(again, whole)
