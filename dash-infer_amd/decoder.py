@@ -413,7 +413,8 @@ def make_comm(rank, nranks, device, backend=None, allow_labelled_fallback=False)
         for _ in range(3):  # repeated: the one-shot protocol alternates two slot sets
             probe.fill_(float(rank + 1))
             c.allreduce_(probe)
-            torch.cuda.synchronize()
+            if torch.device(device).type == "cuda":
+                torch.cuda.synchronize()
             if abs(float(probe[0]) - nranks * (nranks + 1) / 2) > 1e-3 or abs(float(probe[-1]) - nranks * (nranks + 1) / 2) > 1e-3:
                 raise RuntimeError(f"[rank {rank}] all-reduce backend {c.backend} returned a wrong sum ({float(probe[0])})")
     return c
