@@ -40,6 +40,9 @@ _SIGS = {
     "dihip_gemm_lowp_prefers_frag": (i32, [i32, i32, i32, i32, i32, i32]),
     "dihip_moe_route": (i32, [vp, vp, i32, i32, i32, vp, vp, i32]),
     "dihip_rmsnorm_rows": (i32, [vp, vp, vp, vp, f32, i32, i32, i32]),
+    "dihip_decode_mid_sync_bytes": (sz, []),
+    "dihip_decode_mid_supported": (i32, [i32, i32, i32, i32, i32]),
+    "dihip_decode_mid": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, i32]),
     "dihip_moe_route_ep": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32]),
     "dihip_calc_expert": (i32, [vp, vp, vp, vp, i32, i32, i32]),
     "dihip_moe_shared_combine": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32]),

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(GEMV_THREADS, 2) void decode_front_kernel(const Gem
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int bid = (int)blockIdx.x;
   if (bid < gemv_blocks) {
-    gemv_stream_body<WBITS, DIHIP_BF16, MR, PRO_RMSNORM, EPI_STD, GPT, false, true>(g, bid, gemv_blocks, smem);
+    gemv_stream_body<WBITS, DIHIP_BF16, MR, PRO_RMSNORM, EPI_STD, GPT, false, GEMV_SYNC_PUB>(g, bid, gemv_blocks, smem);
   } else {
     if (threadIdx.x >= ATTN_THREADS) return;  // the attention body is a 4-wave workgroup (barriers count live waves only)
     const int i = bid - gemv_blocks;

@@ -495,6 +495,14 @@ class DecodeSession:
             self.front_ws = torch.empty(int(lib().dihip_decode_front_workspace_bytes(batch, self.n_loc, self.g_loc, max_len)),
                                         dtype=torch.uint8, device=device)
             self.front_sync = torch.zeros(int(lib().dihip_decode_front_sync_bytes(batch, self.g_loc)), dtype=torch.uint8, device=device)
+        # batch 1: the o-projection (+ residual) and RMSNorm + gate / up + SwiGLU of a layer as ONE launch (dihip_decode_mid: the
+        # second GEMV's workgroups fill their weight ring while the first streams, then wait for its completion counters).
+        # Experiment switch DIHIP_DECODER_MID=1.
+        l0m = model.layers[0]
+        self.mid = (batch == 1 and dt == torch.bfloat16 and cfg.moe is None and os.environ.get("DIHIP_DECODER_MID", "0") == "1"
+                    and ops.decode_mid_supported(l0m.o, l0m.gate))
+        if self.mid:
+            self.mid_sync = torch.zeros(int(lib().dihip_decode_mid_sync_bytes()), dtype=torch.uint8, device=device)
         # weights of the following launches touched by idle CUs during the attention launch: measured SLOWER end to end
         # (606 vs 627 tokens/s, profiles/r02_attn_merge_fold.txt: the prefetch traffic delays the attention's own,
         # latency-bound loads more than the warmer GEMVs gain) -- kept as an experiment switch, off by default
@@ -645,9 +653,12 @@ class DecodeSession:
                 else:
                     self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag)  # lm_head applies the final norm itself
                 continue
-            self._proj_residual(self.attn, lw.o, tp_on, frag=self.attn_frag, next_weights=(lw.gate.w, lw.up.w))
-            ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act,
-                                  y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
+            if self.mid and not tp_on:
+                ops.decode_mid(self.attn, lw.o, self.h, self.h, lw.ln2, cfg.eps, lw.gate, lw.up, self.act, self.mid_sync)
+            else:
+                self._proj_residual(self.attn, lw.o, tp_on, frag=self.attn_frag, next_weights=(lw.gate.w, lw.up.w))
+                ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act,
+                                      y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
             nxt = m.layers[li + 1].qkv if li + 1 < len(m.layers) else m.lm_head
             self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag, next_weights=(nxt.w,))
         ops.lm_head(self.h, m.final_norm, cfg.eps, m.lm_head, sc, out=self.logits)

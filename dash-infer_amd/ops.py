@@ -408,6 +408,18 @@ def decode_front(h, gamma, eps, pw, bias, kv, old_lens_dev, rope_tab, n, g, H, m
     return attn_out
 
 
+def decode_mid_supported(po, pg):
+    return bool(lib().dihip_decode_mid_supported(po.wbits, po.N, po.K, pg.N, po.group))
+
+
+def decode_mid(attn, po, h_res, h_out, gamma, eps, pg, pu, act, sync):
+    """o-projection (+ residual into the f32 hidden row) and RMSNorm + gate / up GEMV + SwiGLU as ONE launch (M = 1)."""
+    check(lib().dihip_decode_mid(cur_stream(), po.wbits, ptr(attn), ptr(po.w), ptr(po.sz), ptr(h_res), ptr(h_out), ptr(gamma), float(eps),
+                                 ptr(pg.w), ptr(pg.sz), ptr(pu.w), ptr(pu.sz), ptr(act), po.N, po.K, pg.N, po.group, ptr(sync),
+                                 sync.numel(), dt_code(attn)), "dihip_decode_mid")
+    return act
+
+
 def span_attn_set_next_prefetch(tensors):
     """Up to 4 device tensors whose lines the next decode-step attention launch pulls into the Infinity Cache."""
     tensors = [t for t in tensors if t is not None][:4]

@@ -306,6 +306,20 @@ int dihip_span_attn_decode_fused(void* stream, void* output, const void* qkv, vo
                                  int head_size, int span_len, int n_spans_per_request, int max_seq_len,
                                  int kv_mode, int dtype, float qk_scale, void* ws, size_t ws_bytes);
 
+/* 3e. Two consecutive GEMVs of a decode layer in ONE launch (experiment; csrc/decode_mid.hip): the o-projection with its
+ * residual  h_out = h_res + attn . Wo  and  act = SiLU(norm(h_out) . Wgate) * (norm(h_out) . Wup).  Replaces
+ * dihip_fused_gemm_addto followed by dihip_fused_norm_swiglu at M = 1, bit-identically: the second GEMV's workgroups ramp and
+ * fill their weight ring while the first streams, then wait for its completion counters and read the row coherently.
+ *   attn FT [1, k_attn]; h_res / h_out f32 [1, hidden] (in place allowed); act FT [1, inter]
+ *   sync: >= dihip_decode_mid_sync_bytes(), zero-initialised ONCE (every launch leaves it zeroed)
+ * dihip_decode_mid_supported: both shapes on the decode GEMV with at most one workgroup per CU each. */
+size_t dihip_decode_mid_sync_bytes(void);
+int dihip_decode_mid_supported(int wbits, int hidden, int k_attn, int inter, int group_size);
+int dihip_decode_mid(void* stream, int wbits, const void* attn, const void* wo_packed, const void* wo_sz,
+                     const float* h_res, float* h_out, const void* gamma, float eps, const void* wg_packed,
+                     const void* wg_sz, const void* wu_packed, const void* wu_sz, void* act, int hidden,
+                     int k_attn, int inter, int group_size, void* sync, size_t sync_bytes, int dtype);
+
 /* Cache prefetch riding on the NEXT decode-step attention launch of the calling thread (3b with the 16-bit cache):
  * the launch gets extra workgroups -- on the CUs the attention leaves idle -- that touch every 128-byte line of up to 4
  * device buffers, pulling them into the 256 MB Infinity Cache while HBM is otherwise idle.  Meant for the weights of

@@ -27,6 +27,10 @@ import sys
 import tempfile
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+# kernels that run one of two already audited bodies by block index: the compiler joins the bodies through a scalar flag, the
+# path-insensitive walk then follows paths from one body into the other that cannot execute.  Their bodies are audited as
+# stand-alone kernels (decode_mid.hip: *_audit_kernel; decode_front's GEMV body: the gemv_stream_kernel instantiations).
+FUSED_KERNELS = ("decode_mid_kernel",)
 REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
 WAIT = re.compile(r"vmcnt\((\d+)\)")
 
@@ -122,7 +126,6 @@ def audit_loads_forward(name, blocks, order, findings):
         ring loads a read ends the walk instead: the unrolled main loop has paths that cannot execute (the compiler keeps "real
         refill or dummy" in a scalar flag tested two blocks later), on which the counted waits look too weak; their
         consumption is straight-line `wait, consume, refill` code, which rule (1) checks exactly."""
-    succ = successors(blocks, order)
     for lab in order:
         for n, (mn, ops) in enumerate(blocks[lab]):
             # the hand-issued loads all use the scalar-base form `vDst, vOff, s[base]`; a load the compiler emits with `off`
@@ -138,12 +141,18 @@ def audit_loads_forward(name, blocks, order, findings):
                 b, start, c, dest = work.pop()
                 closed = False
                 ins = blocks[b]
+                targets = []  # branches BEHIND the starting point (a label-to-label block can hold one in its middle)
                 for k in range(start, len(ins)):
                     m2, o2 = ins[k]
                     if m2 == "s_waitcnt":
                         w = WAIT.search(o2)
                         if w and int(w.group(1)) <= c:
                             closed = True
+                            break
+                        continue
+                    if m2 == "s_branch" or m2.startswith("s_cbranch"):
+                        targets.append(o2.strip())
+                        if m2 == "s_branch":
                             break
                         continue
                     parts = o2.split(",", 1)
@@ -167,14 +176,22 @@ def audit_loads_forward(name, blocks, order, findings):
                             break
                     if is_vmem(m2):
                         c += 1
-                    if m2 == "s_endpgm":
+                    if m2 in ("s_endpgm", "s_setpc_b64"):
                         closed = True
                         break
                 if closed:
                     continue
-                for t in succ[b]:
+                # every exit of the block leaves with the state at its END: the compiler keeps "real chunk or dummy" of a ring
+                # slot in a scalar flag and branches around the arm not taken from the middle of a block -- counting only the
+                # loads in front of such a branch would follow paths that cannot execute (both arms issue the same number)
+                last = ins[-1][0] if ins else ""
+                if last != "s_branch" and last not in ("s_endpgm", "s_setpc_b64"):
+                    i = order.index(b)
+                    if i + 1 < len(order):
+                        targets.append(order[i + 1])
+                for t in targets:
                     key = (t, c, dest)
-                    if key not in seen and len(seen) < 20000:
+                    if t in blocks and key not in seen and len(seen) < 20000:
                         seen.add(key)
                         work.append((t, 0, c, dest))
 
@@ -196,7 +213,8 @@ def audit_kernel(name, blocks, order):
     return findings
 
 
-def audit(obj, only=None):
+def audit(obj, only=None, skip=()):
+    """skip: substrings of kernel names to leave out (kernels that join two audited bodies through a scalar flag)"""
     text = disassemble(obj)
     findings, kernels = [], 0
     head = re.compile(r"^[0-9a-f]+ <(.+)>:$")
@@ -205,7 +223,7 @@ def audit(obj, only=None):
 
     def flush():
         nonlocal kernels
-        if name and order and (only is None or only in name):
+        if name and order and (only is None or only in name) and not any(x in name for x in skip):
             kernels += 1
             findings.extend(sorted(audit_kernel(name, blocks, order)))
 
@@ -231,7 +249,7 @@ def audit(obj, only=None):
 def main(argv):
     bad = 0
     for obj in argv:
-        kernels, findings = audit(obj)
+        kernels, findings = audit(obj, skip=FUSED_KERNELS)
         print("%s: %d kernels, %d findings" % (os.path.basename(obj), kernels, len(findings)))
         for f in findings[:40]:
             print("  " + f)
