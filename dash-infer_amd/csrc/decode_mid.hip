@@ -37,6 +37,22 @@ __global__ __launch_bounds__(GEMV_THREADS, 2) void decode_mid_kernel(const GemvA
     gemv_stream_body<WBITS, DIHIP_BF16, 1, PRO_RMSNORM, EPI_SWIGLU, GPT, false, GEMV_SYNC_HWAIT>(gg, bid - blocks_o, blocks_g, smem);
 }
 
+// Sequential form (DIHIP_MID_MODE=seq): max(blocks_o, blocks_g) workgroups, one per CU; a workgroup runs its share of the
+// producer, requests the consumer's weight ring, waits for all producers and runs its share of the consumer -- no second
+// streaming workgroup on the CU, the hand-over wait overlaps the ring's first round trip.
+template <int WBITS, int GPT>
+__global__ __launch_bounds__(GEMV_THREADS, 2) void decode_mid_seq_kernel(const GemvArgs go, const GemvArgs gg, const int blocks_o,
+                                                                      const int blocks_g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int bid = (int)blockIdx.x;
+  if (bid < blocks_o) {
+    gemv_stream_body<WBITS, DIHIP_BF16, 1, PRO_PLAIN, EPI_ADDTO, GPT, false, GEMV_SYNC_HPUB>(go, bid, blocks_o, smem);
+    __syncthreads();  // the LDS carve-up changes hands
+  }
+  if (bid < blocks_g)
+    gemv_stream_body<WBITS, DIHIP_BF16, 1, PRO_RMSNORM, EPI_SWIGLU, GPT, false, GEMV_SYNC_HWAIT>(gg, bid, blocks_g, smem);
+}
+
 // The two bodies as kernels of their own.  Never launched: they exist so that tools/audit_asm_loads.py can walk each body's
 // control flow by itself -- in the fused kernel the compiler joins the two bodies through a scalar flag, which a
 // path-insensitive walk cannot follow (tests/test_asm_audit.py skips decode_mid_kernel and audits these).
@@ -58,8 +74,18 @@ MID_AUDIT(4, 1) MID_AUDIT(4, 0) MID_AUDIT(8, 1) MID_AUDIT(8, 0)
 
 template <int WBITS, int GPT>
 static hipError_t launch_mid(const GemvArgs& go, const GemvArgs& gg, int blocks_o, int blocks_g, size_t lds, hipStream_t s) {
-  auto kern = decode_mid_kernel<WBITS, GPT>;
-  hipLaunchKernelGGL(kern, dim3(blocks_o + blocks_g), dim3(GEMV_THREADS), lds, s, go, gg, blocks_o, blocks_g);
+  static int seq = -1;  // DIHIP_MID_MODE=seq: the sequential form (one workgroup per CU runs both)
+  if (seq < 0) {
+    const char* e = getenv("DIHIP_MID_MODE");
+    seq = (e && std::string(e) == "seq") ? 1 : 0;
+  }
+  if (seq) {
+    auto kern = decode_mid_seq_kernel<WBITS, GPT>;
+    hipLaunchKernelGGL(kern, dim3(std::max(blocks_o, blocks_g)), dim3(GEMV_THREADS), lds, s, go, gg, blocks_o, blocks_g);
+  } else {
+    auto kern = decode_mid_kernel<WBITS, GPT>;
+    hipLaunchKernelGGL(kern, dim3(blocks_o + blocks_g), dim3(GEMV_THREADS), lds, s, go, gg, blocks_o, blocks_g);
+  }
   return hipGetLastError();
 }
 

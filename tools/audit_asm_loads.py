@@ -30,7 +30,7 @@ OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 # kernels that run one of two already audited bodies by block index: the compiler joins the bodies through a scalar flag, the
 # path-insensitive walk then follows paths from one body into the other that cannot execute.  Their bodies are audited as
 # stand-alone kernels (decode_mid.hip: *_audit_kernel; decode_front's GEMV body: the gemv_stream_kernel instantiations).
-FUSED_KERNELS = ("decode_mid_kernel",)
+FUSED_KERNELS = ("decode_mid_kernel", "decode_mid_seq_kernel")
 REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
 WAIT = re.compile(r"vmcnt\((\d+)\)")
 
