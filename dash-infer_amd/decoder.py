@@ -386,26 +386,28 @@ def make_comm(rank, nranks, device, backend=None, allow_labelled_fallback=False)
     if backend == "torch":
         c = TorchComm(rank, nranks)
     elif backend in ("rccl", "p2p", "auto"):
+        import sys
         try:
             c = RcclComm(rank, nranks, device)
-            if backend == "p2p":
-                c = P2PComm(rank, nranks, device, c)
-            elif backend == "auto":
-                try:
-                    c = P2PComm(rank, nranks, device, c, guarded=True)
-                except P2PUnavailable as e:
-                    import sys
-                    print(f"[rank {rank}] peer-to-peer all-reduce unavailable ({e}); RCCL all-reduce instead (recorded in comm_backend)",
-                          file=sys.stderr)
-                    c.backend = f"rccl (p2p-oneshot unavailable: {str(e)[:120]})"
         except Exception as e:  # noqa: BLE001
             if not allow_labelled_fallback:
                 raise
-            import sys
-            print(f"[rank {rank}] C-ABI communicator ({backend}) could not be created: {e}; torch.distributed collectives instead "
+            print(f"[rank {rank}] C-ABI RCCL communicator could not be created: {e}; torch.distributed collectives instead "
                   "(recorded in comm_backend)", file=sys.stderr)
             c = TorchComm(rank, nranks)
-            c.backend = f"torch.distributed (labelled fallback: {backend} communicator failed: {type(e).__name__})"
+            c.backend = f"torch.distributed (labelled fallback: rccl communicator failed: {type(e).__name__})"
+        base = c  # also serves the peer-to-peer communicator's all-gather and its over-long messages
+        if backend == "p2p":
+            c = P2PComm(rank, nranks, device, base)
+        elif backend == "auto":
+            try:
+                c = P2PComm(rank, nranks, device, base, guarded=True)
+                if base.backend != "rccl":
+                    c.backend = f"p2p-oneshot (all-gather / long messages: {base.backend})"
+            except P2PUnavailable as e:
+                print(f"[rank {rank}] peer-to-peer all-reduce unavailable ({e}); {base.backend} instead (recorded in comm_backend)",
+                      file=sys.stderr)
+                c.backend = f"{base.backend} (p2p-oneshot unavailable: {str(e)[:120]})"
     else:
         raise ValueError(f"unknown tensor-parallel all-reduce backend {backend!r}")
     for dt, n in ((torch.float32, 8), (torch.bfloat16, 3584)):

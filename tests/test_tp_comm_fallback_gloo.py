@@ -80,6 +80,10 @@ def _worker(rank, world, port, fail, q):
     fake = FakeLib(rank, fail)
     decoder.lib = lambda: fake
     decoder.RcclComm = FakeRccl
+    if fail is not None and fail[0] == "rccl":   # the C-ABI RCCL communicator cannot be created (on every rank)
+        def broken(*a, **k):
+            raise RuntimeError("ncclCommInitRank failed")
+        decoder.RcclComm = broken
     # the fake "device" all-reduce involves no host collective (like the real kernels: a rank that left the probe early does
     # not pair up with the others' later calls -- theirs time out in probe mode); every tensor here is full of rank + 1
     decoder.P2PComm.allreduce_ = lambda self, t: t.fill_(world * (world + 1) / 2)
@@ -92,7 +96,8 @@ def _worker(rank, world, port, fail, q):
 
 
 @pytest.mark.parametrize("fail,expect", [(None, "p2p-oneshot"), (("open", 1), "rccl (p2p-oneshot unavailable"),
-                                         (("probe", 0), "rccl (p2p-oneshot unavailable"), (("alloc", 1), "rccl (p2p-oneshot unavailable")])
+                                         (("probe", 0), "rccl (p2p-oneshot unavailable"), (("alloc", 1), "rccl (p2p-oneshot unavailable"),
+                                         (("rccl", -1), "p2p-oneshot (all-gather / long messages: torch.distributed")])
 def test_guarded_p2p_setup_ends_in_the_same_backend_on_every_rank(pkg, fail, expect):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
