@@ -688,12 +688,7 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
                          int span_len, int n_spans_per_request, int max_seq_len, int kv_mode, int dtype, float qk_scale, void* ws,
                          size_t ws_bytes, bool* handled) {
   *handled = false;
-  static int enabled = -1;  // DIHIP_ATTN_FUSED_MFMA=0: keep the one-wave-per-head kernel (diagnostics)
-  if (enabled < 0) {
-    const char* e = getenv("DIHIP_ATTN_FUSED_MFMA");
-    enabled = (e && e[0] == '0') ? 0 : 1;
-  }
-  if (!enabled || kv_mode != DIHIP_KV_NONE || !attn_use_mfma(kv_mode, dtype)) return DIHIP_SUCCESS;
+  if (kv_mode != DIHIP_KV_NONE || !attn_use_mfma(kv_mode, dtype)) return DIHIP_SUCCESS;
   const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true);
   if (p.nsplits > 1 && (ws == nullptr || ws_bytes < p.partial_bytes)) return DIHIP_SUCCESS;  // caller's kernels size their own
   *handled = true;

@@ -24,52 +24,8 @@
 
 namespace dihip {
 
-// one workgroup (128 threads = head dims) per (request, head).  All partial loads of a batch of 16
-// splits are issued together: max, weights and the weighted sum of the batch cost one round trip.
-template <int FT>
-__global__ __launch_bounds__(128) void span_attn_merge_kernel(void* out, const float* partials, const uint32_t* old_lens,
-                                                              int n, int nsplits, int tps) {
-  constexpr int H = 128;
-  const int bh = blockIdx.x, d = threadIdx.x;
-  (void)old_lens;
-  (void)n;
-  (void)tps;
-  const int ns = nsplits;  // dead splits hold neutral records (max = -inf, sum = 0, o = 0)
-  const float* base = partials + (size_t)bh * nsplits * ATTN_PSTRIDE;
-  float mm = -INFINITY, ll = 0.f, oo = 0.f;
-  constexpr int MB = 72;  // splits per batch: all loads of a batch are in flight together
-  for (int sb = 0; sb < ns; sb += MB) {
-    float mv[MB], lv[MB], ov[MB];
-#pragma unroll
-    for (int j = 0; j < MB; ++j) {
-      const bool in = sb + j < ns;
-      const float* rec = base + (size_t)(in ? sb + j : 0) * ATTN_PSTRIDE;
-      mv[j] = rec[H];
-      lv[j] = rec[H + 1];
-      ov[j] = rec[d];
-      if (!in) {
-        mv[j] = -INFINITY;
-        lv[j] = 0.f;
-        ov[j] = 0.f;
-      }
-    }
-    float bm = mm;
-#pragma unroll
-    for (int j = 0; j < MB; ++j) bm = fmaxf(bm, mv[j]);
-    const float carry = safe_exp_diff(mm, bm);
-    ll *= carry;
-    oo *= carry;
-#pragma unroll
-    for (int j = 0; j < MB; ++j) {
-      const float c = safe_exp_diff(mv[j], bm);
-      ll = fmaf(lv[j], c, ll);
-      oo = fmaf(ov[j], c, oo);
-    }
-    mm = bm;
-  }
-  store_ft<FT>(out, (size_t)bh * H + d, ll > 0.f ? oo / ll : 0.f);
-}
-
+// cos / sin per (position, dim pair): the table dihip_span_attn_decode_fused and dihip_decode_front read (same arithmetic as
+// dihip_rope_qk: rope_sincos)
 __global__ void rope_table_kernel(float* tab, const float* inv_freq, int max_pos, int half) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= max_pos * half) return;
