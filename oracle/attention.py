@@ -13,8 +13,8 @@ the k-sum order of sgemm is not reproduced; sums here are float64.
 import numpy as np
 
 
-def softmax_rows(s):
-    s = np.asarray(s, np.float64)
+def softmax_rows(s, dtype=np.float64):
+    s = np.asarray(s, dtype)
     m = s.max(axis=-1, keepdims=True)
     e = np.exp(s - m)
     return e / e.sum(axis=-1, keepdims=True)
@@ -36,23 +36,25 @@ def decode_attention(q, k, v, alpha):
     return out.astype(np.float32)
 
 
-def prefill_attention(q, k, v, alpha, causal=True):
-    """q [Lq,n,H]; k,v [Lk,g,H] -> [Lq,n,H] float32."""
-    q = np.asarray(q, np.float64)
-    k = np.asarray(k, np.float64)
-    v = np.asarray(v, np.float64)
+def prefill_attention(q, k, v, alpha, causal=True, dtype=np.float64):
+    """q [Lq,n,H]; k,v [Lk,g,H] -> [Lq,n,H] float32.  dtype: accumulation type of the two contractions and the softmax
+    (float64 by default; float32 = what cblas_sgemm + the f32 softmax of the x86 path carry, used by the full-depth
+    comparisons where a float64 pass over 28 layers x 2k tokens would take minutes)."""
+    q = np.asarray(q, dtype)
+    k = np.asarray(k, dtype)
+    v = np.asarray(v, dtype)
     Lq, n, H = q.shape
     Lk, g, _ = k.shape
     hpg = n // g
     off = Lk - Lq
-    out = np.empty((Lq, n, H), np.float64)
+    out = np.empty((Lq, n, H), dtype)
     mask = None
     if causal:
         mask = np.arange(Lk)[None, :] > (np.arange(Lq)[:, None] + off)
     for h in range(n):
         grp = h // hpg
-        s = alpha * (q[:, h, :] @ k[:, grp, :].T)
+        s = dtype(alpha) * (q[:, h, :] @ k[:, grp, :].T)
         if mask is not None:
-            s = np.where(mask, -np.inf, s)
-        out[:, h, :] = softmax_rows(s) @ v[:, grp, :]
+            s[mask] = -np.inf
+        out[:, h, :] = softmax_rows(s, dtype) @ v[:, grp, :]
     return out.astype(np.float32)

@@ -18,15 +18,42 @@ from .numerics import bf16_round, ft_round
 from .quant import unpack_u4
 
 
-def dequant(q, scales, zeros, group, wbits, N=None):
-    """q: int8 [K,N] (wbits 8) or packed u8 [K,ceil(N/2)] (wbits 4). Returns f32 [K,N]."""
+def dequant(q, scales, zeros, group, wbits, N=None, threads=1):
+    """q: int8 [K,N] (wbits 8) or packed u8 [K,ceil(N/2)] (wbits 4). Returns f32 [K,N].
+    threads > 1: row blocks (whole groups) on a thread pool -- the same per-element expression, for the full-depth
+    comparisons that dequantise 28 layers of 7B-width matrices (numpy releases the GIL inside these array passes)."""
     scales = np.asarray(scales, np.float32)
     zeros = np.asarray(zeros, np.float32)
     N = scales.shape[-1] if N is None else N
+    K0 = q.shape[0]
+    g0 = K0 if group in (-1, None, 0) else int(group)
+    if threads > 1 and K0 >= 2 * threads and (g0 == K0 or K0 % g0 == 0):
+        from concurrent.futures import ThreadPoolExecutor
+        unit = 1 if g0 == K0 else g0
+        per = -(-(K0 // unit) // threads) * unit
+        per = max(unit, min(per, (max(1, (1 << 21) // max(N, 1)) // unit) * unit))  # blocks of <= 2M elements stay cache-sized
+        out = np.empty((K0, N), np.float32)
+
+        def job(k0):
+            k1 = min(K0, k0 + per)
+            if g0 == K0:
+                out[k0:k1] = dequant(q[k0:k1], scales, zeros, -1, wbits, N)
+            else:
+                out[k0:k1] = dequant(q[k0:k1], scales[k0 // g0:k1 // g0], zeros[k0 // g0:k1 // g0], g0, wbits, N)
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(job, range(0, K0, per)))
+        return out
     if wbits == 4:
         q = unpack_u4(q, N)
     K = q.shape[0]
     g = K if group in (-1, None, 0) else int(group)
+    if K % g == 0 and zeros.ndim == 2 and zeros.shape[0] == K // g:
+        # the same f32 expression per element, broadcast per group instead of through [K, N] gathers of the parameters
+        # (a 7B-width matrix is 68M elements: the full-depth comparisons dequantise 28 layers of them)
+        w = q.astype(np.float32).reshape(K // g, g, q.shape[1])
+        w -= zeros[:, None, :]
+        w *= scales[:, None, :]
+        return w.reshape(K, q.shape[1])
     idx = np.arange(K) // g
     return ((q.astype(np.float32) - zeros[idx]).astype(np.float32) * scales[idx]).astype(np.float32)
 

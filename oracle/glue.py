@@ -15,7 +15,7 @@ import numpy as np
 def rmsnorm(x, gamma, eps=1e-6):
     x = np.asarray(x, np.float32)
     gamma = np.asarray(gamma, np.float32)
-    var = (x.astype(np.float64) ** 2).sum(axis=-1, keepdims=True) / x.shape[-1]
+    var = np.einsum("...k,...k->...", x, x, dtype=np.float64)[..., None] / x.shape[-1]   # sum of squares in f64
     rstd = (1.0 / np.sqrt(var.astype(np.float32) + np.float32(eps))).astype(np.float32)
     return ((gamma * x).astype(np.float32) * rstd).astype(np.float32)
 
@@ -38,9 +38,11 @@ def rope(x, pos, inv_freq):
     return out
 
 
-def silu(x):
+def silu(x, dtype=np.float64):
+    """dtype: the type exp / the division run in (float32 for the full-depth comparisons: 40M elements per layer)."""
     x = np.asarray(x, np.float32)
-    return (x / (1.0 + np.exp(-x.astype(np.float64)))).astype(np.float32)
+    xd = x.astype(dtype, copy=False)
+    return (xd / (dtype(1.0) + np.exp(-xd))).astype(np.float32, copy=False)
 
 
 def greedy(logits):

@@ -11,7 +11,16 @@ Two sets of rounding points (`rounding=`):
              attention output are rounded to the GPU cache's FT (bf16), because the product's KV cache is FT.
   "ft_graph" the CUDA bf16 graph of the reference (qwen_v15.py:296-346 with FT = bf16): every operator output is an FT
              tensor -- the residual ADD results, Gemm(gate)+SiLU, Gemm(up), their MUL, the o / down GEMM outputs.
-tests/test_gpu_decoder.py reports the product's error against both (say which rounding points differ).
+  "x86_pure_bf16" the x86 path itself under matmul_precision=medium_bf16 (gemm_op_cpu.cpp:75-126, gemm_op_x86_spr.cpp:55-69):
+             every tensor between operators is f32 -- qkv, the rotated q / k, the KV cache (BatchMQAOp's contiguous f32
+             cache, batch_mqa_op.cpp:140-179) and the attention output (cblas_sgemm + f32 softmax) included; inside a matmul
+             the src is converted to bf16 and the weight is the bf16 reorder of the dequantised (q - z) * s (x86 has
+             no weight-only GEMM, the quantised configs run on dequantised weights), f32 accumulation and output.
+  "x86_pure_f32"  the same path under the default matmul precision: f32 src and f32 dequantised weights, nothing rounded.
+  "x86_pure_bf16_exactw"  ablation: medium_bf16's src conversion but the unrounded (q - z) * s -- what separates the product's
+             A16Wx arithmetic (bf16 activations into the GEMM, exact integer weights x f32 scale) from "x86_pure_bf16" is the
+             weight rounding, from "x86" the FT rounding of qkv / cache / attention output.
+tests/test_gpu_decoder.py reports the product's error against these (say which rounding points differ).
 
 Two evaluation orders of the same function, which must agree (tests/test_oracle_model.py): `step()` decodes token by
 token against a growing cache (what the product path does), `last_logits_from_scratch()` recomputes a whole sequence with
@@ -21,6 +30,33 @@ import numpy as np
 
 from . import attention, gemm_ref, glue, kv_codec, moe
 from .numerics import bf16_round
+
+
+class Rounding:
+    """Where one evaluation of the decoder graph rounds (see the module docstring)."""
+
+    def __init__(self, name, op_out_ft, gemm_src_ft, w_bf16, qkv_ft, attn_ft):
+        self.name = name
+        self.op_out_ft = op_out_ft      # every operator output is an FT tensor (the CUDA bf16 graph)
+        self.gemm_src_ft = gemm_src_ft  # a matmul takes its src as bf16 (A16Wx kernels; oneDNN under medium_bf16)
+        self.w_bf16 = w_bf16            # the matmul's weight is the bf16 rounding of the dequantised value
+        self.qkv_ft = qkv_ft            # qkv GEMM output, rotated q / k and the cache rows are FT
+        self.attn_ft = attn_ft          # the attention output is FT
+
+    def __eq__(self, other):            # `oracle.rounding == "ft_graph"` keeps working
+        return self.name == (other.name if isinstance(other, Rounding) else other)
+
+    def __repr__(self):
+        return f"Rounding({self.name})"
+
+
+ROUNDINGS = {r.name: r for r in (
+    Rounding("x86", False, True, False, True, True),
+    Rounding("ft_graph", True, True, False, True, True),
+    Rounding("x86_pure_bf16", False, True, True, False, False),
+    Rounding("x86_pure_bf16_exactw", False, True, False, False, False),
+    Rounding("x86_pure_f32", False, False, False, False, False),
+)}
 
 
 class DecoderOracle:
@@ -33,29 +69,58 @@ class DecoderOracle:
         self.wbits, self.group, self.eps, self.kv_mode = wbits, group, eps, kv_mode
         self.inv_freq = glue.rope_inv_freq(head_dim, rope_theta)
         self.cache = None
-        assert rounding in ("x86", "ft_graph")
         self.rounding = rounding
+        self.acc = np.float64           # accumulation type of the matmuls / attention (np.float32: the full-depth comparisons)
         self._wcache = {} if cache_weights else None  # id(q) -> dequantised f64 [K, N] (large models: dequantise once)
         self._lm64 = None
 
+    @property
+    def rounding(self):
+        return self._rounding
+
+    @rounding.setter
+    def rounding(self, r):
+        self._rounding = r if isinstance(r, Rounding) else ROUNDINGS[r]
+
     # -- pieces --------------------------------------------------------------------------------
-    def linear(self, x, w, ft, bias=None):
+    def dequantised(self, w):
+        """The matmul's weight matrix [K, N] in the accumulation type: (q - z) * s in f32 (bit-exact restatement of the
+        reference's host loop), rounded to bf16 where the x86 path holds bf16 weights."""
         q, s, z = w
-        if self._wcache is None:
-            return gemm_ref.gemm_a16wx(x, q, s, z, self.group, self.wbits, bias=bias, ft=ft)
-        # same arithmetic as gemm_ref.gemm_a16wx(mode="exact"), with the dequantised matrix kept
-        w64 = self._wcache.get(id(q))
-        if w64 is None:
-            w64 = self._wcache[id(q)] = gemm_ref.dequant(q, s, z, self.group, self.wbits).astype(np.float64)
-        v = np.asarray(x, np.float32).astype(np.float64) @ w64
+        w32 = gemm_ref.dequant(q, s, z, self.group, self.wbits)
+        if self.rounding.w_bf16:
+            w32 = bf16_round(w32)
+        return w32.astype(self.acc, copy=False)
+
+    def linear(self, x, w, ft, bias=None, W=None):
+        """x . W (+ bias), rounded to `ft`.  W: the matrix already dequantised for this rounding (lockstep evaluation of
+        several oracles over one dequantisation, `teacher_forced_logits`), else taken from / put into the weight cache."""
+        q = w[0]
+        if W is None and self._wcache is not None:
+            W = self._wcache.get((id(q), self.rounding.w_bf16))
+            if W is None:
+                W = self._wcache[(id(q), self.rounding.w_bf16)] = self.dequantised(w)
+        if W is None:
+            W = self.dequantised(w)
+        v = np.asarray(x, np.float32).astype(self.acc, copy=False) @ W
         if bias is not None:
-            v = v + np.asarray(bias, np.float64)[None, :]
+            v = v + np.asarray(bias, self.acc)[None, :]
         from .numerics import ft_round
-        return ft_round(v.astype(np.float32), ft)
+        return ft_round(v.astype(np.float32, copy=False), ft)
+
+    def _src(self, x):
+        """What a matmul reads: bf16 under medium_bf16 / the A16Wx kernels, the f32 tensor itself otherwise."""
+        return bf16_round(x) if self.rounding.gemm_src_ft else np.asarray(x, np.float32)
+
+    def _qkv_ft(self):
+        return "bf16" if self.rounding.qkv_ft else "f32"
+
+    def _attn_out(self, v):
+        return bf16_round(v) if self.rounding.attn_ft else np.asarray(v, np.float32)
 
     def _ft(self, v):
         """An operator output under the bf16 graph of the reference; f32 (no rounding) under x86 semantics."""
-        return bf16_round(v) if self.rounding == "ft_graph" else v
+        return bf16_round(v) if self.rounding.op_out_ft else v
 
     def _residual(self, h, y):
         return self._ft(self._ft(h) + self._ft(y))
@@ -69,19 +134,21 @@ class DecoderOracle:
 
     def _qkv_heads(self, row, pos):
         n, g, H = self.n, self.g, self.H
-        q = bf16_round(glue.rope(row[: n * H].reshape(n, H), pos, self.inv_freq))
-        k = bf16_round(glue.rope(row[n * H:(n + g) * H].reshape(g, H), pos, self.inv_freq))
+        rq = bf16_round if self.rounding.qkv_ft else (lambda t: t)
+        q = rq(glue.rope(row[: n * H].reshape(n, H), pos, self.inv_freq))
+        k = rq(glue.rope(row[n * H:(n + g) * H].reshape(g, H), pos, self.inv_freq))
         v = row[(n + g) * H:].reshape(g, H)
         return q, k, v
 
-    def _mlp(self, h, lw):
+    def _mlp(self, h, lw, W=None):
         if "moe" in lw:
             return self._moe_mlp(h, lw)
-        xn = bf16_round(glue.rmsnorm(h, lw["ln2"], self.eps))
-        gate = self._ft(glue.silu(self.linear(xn, lw["gate"], "f32")))
-        up = self._ft(self.linear(xn, lw["up"], "f32"))
-        act = bf16_round(gate * up)
-        return self._residual(h, self.linear(act, lw["down"], "f32"))
+        W = W or {}
+        xn = self._src(glue.rmsnorm(h, lw["ln2"], self.eps))
+        gate = self._ft(glue.silu(self.linear(xn, lw["gate"], "f32", W=W.get("gate")), dtype=self.acc))
+        up = self._ft(self.linear(xn, lw["up"], "f32", W=W.get("up")))
+        act = self._src(gate * up)
+        return self._residual(h, self.linear(act, lw["down"], "f32", W=W.get("down")))
 
     def _moe_mlp(self, h, lw):
         """The mixture-of-experts layer of python/pyhie/allspark/model/qwen_v20_moe.py:318-382: router Gemm -> MOE (softmax,
@@ -106,13 +173,16 @@ class DecoderOracle:
             return bf16_round(bf16_round(moe_out + calc) + bf16_round(h))                              # expert_add, final_add
         return ((h + moe_out) + calc).astype(np.float32)
 
-    def _logits(self, h):
-        xn = bf16_round(glue.rmsnorm(h, self.final_norm, self.eps))
-        if self._wcache is not None:
-            if self._lm64 is None:
-                self._lm64 = self.lm_head.astype(np.float64)
-            return (xn.astype(np.float64) @ self._lm64).astype(np.float32)
-        return (xn.astype(np.float64) @ self.lm_head.astype(np.float64)).astype(np.float32)
+    def _logits(self, h, lm=None):
+        xn = self._src(glue.rmsnorm(h, self.final_norm, self.eps))
+        if lm is None:
+            if self._wcache is not None:
+                if self._lm64 is None or self._lm64.dtype != self.acc:
+                    self._lm64 = self.lm_head.astype(self.acc)
+                lm = self._lm64
+            else:
+                lm = self.lm_head.astype(self.acc)
+        return (xn.astype(self.acc, copy=False) @ lm).astype(np.float32)
 
     # -- incremental decode ------------------------------------------------------------------------
     def step(self, ids):
@@ -123,18 +193,30 @@ class DecoderOracle:
             self.cache = [[([], []) for _ in range(B)] for _ in self.layers]
         h = self.embed[np.asarray(ids)].astype(np.float32)
         for li, lw in enumerate(self.layers):
-            xn = bf16_round(glue.rmsnorm(h, lw["ln1"], self.eps))
-            qkv = self.linear(xn, lw["qkv"], "bf16", bias=lw["qkv_bias"])
+            xn = self._src(glue.rmsnorm(h, lw["ln1"], self.eps))
+            qkv = self.linear(xn, lw["qkv"], self._qkv_ft(), bias=lw["qkv_bias"])
             attn = np.empty((B, n * H), np.float32)
             for b in range(B):
                 ks, vs = self.cache[li][b]
                 q, k, v = self._qkv_heads(qkv[b], len(ks))
                 ks.append(self.kv_store(k))
                 vs.append(self.kv_store(v))
-                attn[b] = bf16_round(attention.decode_attention(q, np.stack(ks), np.stack(vs), 1.0 / np.sqrt(H))).reshape(-1)
-            h = self._residual(h, self.linear(attn, lw["o"], "f32"))
+                attn[b] = self._attn_out(attention.decode_attention(q, np.stack(ks), np.stack(vs), 1.0 / np.sqrt(H))).reshape(-1)
+            h = self._residual(h, self.linear(self._src(attn), lw["o"], "f32"))
             h = self._mlp(h, lw)
         return self._logits(h)
+
+    def _context_qkv(self, h, lw, L, W=None):
+        """q [L, n, H], k, v [L, g, H] of a whole prompt (positions 0 .. L-1) as the attention sees them."""
+        n, g, H = self.n, self.g, self.H
+        xn = self._src(glue.rmsnorm(h, lw["ln1"], self.eps))
+        qkv = self.linear(xn, lw["qkv"], self._qkv_ft(), bias=lw["qkv_bias"], W=(W or {}).get("qkv"))
+        pos = np.arange(L, dtype=np.int32)
+        rq = bf16_round if self.rounding.qkv_ft else (lambda t: t)
+        q = rq(glue.rope(qkv[:, : n * H].reshape(L, n, H), pos, self.inv_freq))
+        k = rq(glue.rope(qkv[:, n * H:(n + g) * H].reshape(L, g, H), pos, self.inv_freq))
+        v = qkv[:, (n + g) * H:].reshape(L, g, H)
+        return q, k, v
 
     # -- context phase: fills the cache of every request, returns the logits after each prompt's last token --------
     def prefill(self, seqs):
@@ -148,21 +230,15 @@ class DecoderOracle:
             L = len(seq)
             h = self.embed[np.asarray(seq)].astype(np.float32)
             for li, lw in enumerate(self.layers):
-                xn = bf16_round(glue.rmsnorm(h, lw["ln1"], self.eps))
-                qkv = self.linear(xn, lw["qkv"], "bf16", bias=lw["qkv_bias"])
-                pos = np.arange(L, dtype=np.int32)
-                g = self.g
-                q = bf16_round(glue.rope(qkv[:, : n * H].reshape(L, n, H), pos, self.inv_freq))
-                k = bf16_round(glue.rope(qkv[:, n * H:(n + g) * H].reshape(L, g, H), pos, self.inv_freq))
-                v = qkv[:, (n + g) * H:].reshape(L, g, H)
+                q, k, v = self._context_qkv(h, lw, L)
                 ks, vs = self.cache[li][b]
                 for t in range(L):
                     ks.append(self.kv_store(k[t]))
                     vs.append(self.kv_store(v[t]))
                 # the context phase attends over the fresh (unquantised) K / V of the prompt (span_attn_op_cuda.cpp:
                 # runContext: xformer_prefill_attention on the qkv rows; the cache copy is a side output)
-                attn = bf16_round(attention.prefill_attention(q, k, v, 1.0 / np.sqrt(H), True))
-                h = self._residual(h, self.linear(attn.reshape(L, n * H), lw["o"], "f32"))
+                attn = self._attn_out(attention.prefill_attention(q, k, v, 1.0 / np.sqrt(H), True, dtype=self.acc))
+                h = self._residual(h, self.linear(self._src(attn.reshape(L, n * H)), lw["o"], "f32"))
                 h = self._mlp(h, lw)
             out.append(self._logits(h[-1:])[0])
         return np.stack(out)
@@ -174,15 +250,55 @@ class DecoderOracle:
         L = len(seq)
         h = self.embed[np.asarray(seq)].astype(np.float32)
         for lw in self.layers:
-            xn = bf16_round(glue.rmsnorm(h, lw["ln1"], self.eps))
-            qkv = self.linear(xn, lw["qkv"], "bf16", bias=lw["qkv_bias"])
+            xn = self._src(glue.rmsnorm(h, lw["ln1"], self.eps))
+            qkv = self.linear(xn, lw["qkv"], self._qkv_ft(), bias=lw["qkv_bias"])
             qs, ks, vs = [], [], []
             for t in range(L):
                 q, k, v = self._qkv_heads(qkv[t], t)
                 qs.append(q)
                 ks.append(self.kv_store(k))
                 vs.append(self.kv_store(v))
-            attn = bf16_round(attention.prefill_attention(np.stack(qs), np.stack(ks), np.stack(vs), 1.0 / np.sqrt(H), True))
-            h = self._residual(h, self.linear(attn.reshape(L, n * H), lw["o"], "f32"))
+            attn = self._attn_out(attention.prefill_attention(np.stack(qs), np.stack(ks), np.stack(vs), 1.0 / np.sqrt(H), True))
+            h = self._residual(h, self.linear(self._src(attn.reshape(L, n * H)), lw["o"], "f32"))
             h = self._mlp(h, lw)
         return self._logits(h[-1:])
+
+    def scratch_layer(self, h, lw, W=None):
+        """One decoder layer over ALL positions of one sequence (h [L, hidden]); 16-bit / f32 cache only (the cache returns
+        what was written).  W: {"qkv" | "o" | "gate" | "up" | "down": matrix dequantised for this rounding} or None."""
+        assert self.kv_mode == "none"
+        L = h.shape[0]
+        q, k, v = self._context_qkv(h, lw, L, W)
+        attn = self._attn_out(attention.prefill_attention(q, k, v, 1.0 / np.sqrt(self.H), True, dtype=self.acc))
+        h = self._residual(h, self.linear(self._src(attn.reshape(L, self.n * self.H)), lw["o"], "f32", W=(W or {}).get("o")))
+        return self._mlp(h, lw, W)
+
+
+def teacher_forced_logits(oracles, layers, seq, n_last, progress=None, threads=1):
+    """Logits [n_last, V] of the last n_last positions of `seq` for each oracle (same weights, different Rounding), all
+    positions computed together with the causal attention oracle -- for a greedy run that is fed the tokens the product
+    chose, this is the same function as prefill + step() token by token (tests/test_oracle_model.py) at one pass over
+    the weights: every layer is dequantised ONCE (twice when some oracle wants the bf16 weight rounding of the x86 path)
+    and applied to every oracle's hidden rows before the next layer is touched, so a 28-layer model at Qwen2-7B widths
+    needs one layer's matrices in host memory at a time.  `layers`: a sequence of layer dicts (may build each on access)."""
+    hs = [o.embed[np.asarray(seq)].astype(np.float32) for o in oracles]
+    o0 = oracles[0]
+    for li in range(len(layers)):
+        lw = layers[li]
+        mats = {}
+        for name in ("qkv", "o", "gate", "up", "down"):
+            w32 = gemm_ref.dequant(*lw[name], o0.group, o0.wbits, threads=threads)
+            mats[name] = {False: w32}
+            if any(o.rounding.w_bf16 for o in oracles):
+                mats[name][True] = bf16_round(w32, threads=threads)
+        for i, o in enumerate(oracles):
+            W = {name: mats[name][o.rounding.w_bf16].astype(o.acc, copy=False) for name in mats}
+            hs[i] = o.scratch_layer(hs[i], lw, W)
+        del mats, lw
+        if progress:
+            progress(li)
+    out = []
+    for o, h in zip(oracles, hs):
+        lm = o.lm_head.astype(o.acc, copy=False)
+        out.append(o._logits(h[-n_last:], lm=lm))
+    return out

@@ -7,16 +7,30 @@ the upper 16 bits, NaN quieted): csrc/common/bfloat16_impl.hpp
 import numpy as np
 
 
-def bf16_round(x):
-    """Round an array to bfloat16 (RNE) and return it as float32."""
+def bf16_round(x, threads=1):
+    """Round an array to bfloat16 (RNE) and return it as float32.  threads > 1: row blocks of a 2-D array on a thread pool."""
     x = np.ascontiguousarray(x, dtype=np.float32)
-    u = x.view(np.uint32).astype(np.uint64)
+    if threads > 1 and x.ndim == 2 and x.shape[0] >= 2 * threads:
+        from concurrent.futures import ThreadPoolExecutor
+        out = np.empty_like(x)
+        per = max(1, min(-(-x.shape[0] // threads), (1 << 21) // max(x.shape[1], 1)))  # cache-sized blocks
+
+        def job(r0):
+            out[r0:r0 + per] = bf16_round(x[r0:r0 + per])
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(job, range(0, x.shape[0], per)))
+        return out
+    u = x.view(np.uint32)
+    # u + 0x7FFF + lsb in 32 bits: it can only wrap for bit patterns >= 0xFFFF8000, which are NaNs (patched below)
+    r = (u >> 16) & np.uint32(1)
+    r += np.uint32(0x7FFF)
+    with np.errstate(over="ignore"):
+        r += u
+    r &= np.uint32(0xFFFF0000)
+    out = r.view(np.float32)
     nan = np.isnan(x)
-    lsb = (u >> 16) & 1
-    r = ((u + 0x7FFF + lsb) >> 16) << 16
-    r = r.astype(np.uint32)
-    out = r.view(np.float32).copy()
-    out[nan] = np.nan
+    if nan.any():
+        out[nan] = np.nan
     return out.reshape(x.shape)
 
 

@@ -118,3 +118,45 @@ def test_moe_layers_incremental_equals_full_recompute_and_route_through_the_expe
     whole, a, b = m._moe_mlp(h, lw) - h, m._moe_mlp(h, routed_only) - h, m._moe_mlp(h, shared_only) - h
     np.testing.assert_allclose(whole, a + b, rtol=0, atol=1e-5)
     assert np.abs(a).max() > 1e-3 and np.abs(b).max() > 1e-3
+
+
+@pytest.mark.parametrize("rounding", ["x86", "ft_graph", "x86_pure_bf16", "x86_pure_bf16_exactw", "x86_pure_f32"])
+def test_teacher_forced_pass_equals_prefill_then_steps(rounding):
+    """oracle.model.teacher_forced_logits (what the full-depth GPU comparison uses: one pass over the weights, all positions
+    at once, several roundings in lockstep) gives the logits of prefill + step() fed the same tokens, for every rounding
+    mode -- including the pure x86 ones (f32 qkv / cache / attention output; bf16 weight reorder under medium_bf16)."""
+    rng = np.random.default_rng(23)
+    a = make_oracle(rng, 4, 128, "none")
+    a.rounding = rounding
+    seq = [int(t) for t in rng.integers(0, 64, 11)]
+    L, n_last = 7, 5
+    ref = [a.prefill([seq[:L]])[0]]
+    for t in range(L, L + n_last - 1):
+        ref.append(a.step([seq[t]])[0])
+    others = [make_oracle(np.random.default_rng(23), 4, 128, "none") for _ in range(2)]
+    others[0].rounding, others[1].rounding = rounding, "x86_pure_f32"
+    got = omodel.teacher_forced_logits(others, others[0].layers, seq[:L + n_last - 1], n_last)
+    np.testing.assert_allclose(got[0], np.stack(ref), rtol=0, atol=2e-5 * max(1.0, float(np.abs(np.stack(ref)).max())))
+    # f32 accumulation (the full-depth setting): the same function up to the summation order -- which, through bf16
+    # roundings that flip, already moves a logit by several 1e-3 on this two-layer model (the noise floor every
+    # "logits within 1e-2" statement about a bf16 graph sits on)
+    for o in others:
+        o.acc = np.float32
+    got32 = omodel.teacher_forced_logits(others, others[0].layers, seq[:L + n_last - 1], n_last)
+    np.testing.assert_allclose(got32[0], got[0], rtol=0, atol=1e-2 * max(1.0, float(np.abs(got[0]).max())))
+
+
+def test_pure_x86_rounding_modes_differ_where_they_should():
+    """The rounding specs are not aliases: the bf16 weight reorder, the FT cache and the f32-everything path give different
+    logits on the same model, at the size of the roundings they add / remove (sanity for the ablation in DESIGN section 0)."""
+    rng = np.random.default_rng(29)
+    ms = {}
+    for r in ("x86", "x86_pure_bf16", "x86_pure_bf16_exactw", "x86_pure_f32"):
+        ms[r] = make_oracle(np.random.default_rng(29), 4, 128, "none")
+        ms[r].rounding = r
+    seq = [int(t) for t in rng.integers(0, 64, 9)]
+    lo = dict(zip(ms, omodel.teacher_forced_logits(list(ms.values()), ms["x86"].layers, seq, 1)))
+    d = lambda a, b: float(np.abs(lo[a] - lo[b]).max())
+    assert 0 < d("x86", "x86_pure_bf16_exactw") < 5e-2       # FT rounding of qkv / cache / attention output
+    assert 0 < d("x86_pure_bf16", "x86_pure_bf16_exactw") < 5e-2   # weight rounding
+    assert 0 < d("x86_pure_f32", "x86_pure_bf16_exactw") < 5e-2    # src rounding
