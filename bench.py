@@ -299,16 +299,11 @@ def kernel_breakdown(sess, torch, ops, iters=5):
     timed("qkv_norm_gemv", l0.qkv.nbytes + act_b(l0.qkv),
           lambda li, lw: ops.fused_norm_gemm(sess.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sc, out=sess.qkv))
     kvb = {"none": sess.H * 2, "i8": sess.H + 8, "u4": sess.H // 2 + 8}[sess.kv_mode]
-    if getattr(sess, "front", False):
-        # the front half as the step runs it: RMSNorm + qkv GEMV + Rotary + append + attention in one launch, + the split merge
-        timed("front_qkv_attention", l0.qkv.nbytes + act_b(l0.qkv) + B * 2 * sess.g_loc * SEQ_LEN * kvb,
-              lambda li, lw: ops.decode_front(sess.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sess.kv[li], sess.old_lens, sess.rope_tab,
-                                              sess.n_loc, sess.g_loc, sess.H, sess.max_len, sess.scale, sess.front_ws, sess.front_sync,
-                                              sess.qkv, sess.attn))
     if sess.fused_attention:
         timed("rope_append_span_attention", B * 2 * sess.g_loc * SEQ_LEN * kvb,
               lambda li, lw: ops.span_attn_decode_fused(sess.qkv, sess.kv[li], sess.old_lens, sess.rope_tab, sess.n_loc, sess.g_loc,
-                                                        sess.H, sess.max_len, sess.scale, sess.attn_ws, out=sess.attn))
+                                                        sess.H, sess.max_len, sess.scale, sess.attn_ws, out=sess.attn,
+                                                        sync=sess.attn_sync if sess.attn_merge_in_launch else None))
     else:
         def sep(li, lw):
             ops.rope_kv_append(sess.kv[li], sess.q, sess.qkv, sess.old_lens, sess.inv_freq, sess.n_loc, sess.g_loc, sess.H)

@@ -40,9 +40,6 @@ _SIGS = {
     "dihip_gemm_lowp_prefers_frag": (i32, [i32, i32, i32, i32, i32, i32]),
     "dihip_moe_route": (i32, [vp, vp, i32, i32, i32, vp, vp, i32]),
     "dihip_rmsnorm_rows": (i32, [vp, vp, vp, vp, f32, i32, i32, i32]),
-    "dihip_decode_mid_sync_bytes": (sz, []),
-    "dihip_decode_mid_supported": (i32, [i32, i32, i32, i32, i32]),
-    "dihip_decode_mid": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, i32]),
     "dihip_moe_route_ep": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32]),
     "dihip_calc_expert": (i32, [vp, vp, vp, vp, i32, i32, i32]),
     "dihip_moe_shared_combine": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32]),
@@ -70,13 +67,8 @@ _SIGS = {
     "dihip_rope_table": (i32, [vp, vp, vp, i32, i32]),
     "dihip_span_attn_fused_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "dihip_span_attn_decode_fused": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz]),
-    "dihip_span_attn_set_next_prefetch": (i32, [C.POINTER(vp), C.POINTER(sz), i32]),
+    "dihip_span_attn_decode_fused_sync": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp, sz]),
     "dihip_span_attn_merge_partials": (i32, [vp, vp, vp, i32, i32, i32, i32]),
-    "dihip_decode_front_sync_bytes": (sz, [i32, i32]),
-    "dihip_decode_front_workspace_bytes": (sz, [i32, i32, i32, i32]),
-    "dihip_decode_front_supported": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, i32, i32]),
-    "dihip_decode_front": (i32, [vp, i32, vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
-                                 i32, f32, vp, sz, vp, sz]),
     "dihip_prefill_attn": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32]),
     "dihip_rmsnorm": (i32, [vp, vp, vp, vp, f32, i32, i32, i32]),
     "dihip_rope_qk": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32]),

@@ -496,113 +496,6 @@ int run_gemv_slots(hipStream_t stream, int wbits, int epi, const void* x, int ld
   return DIHIP_SUCCESS;
 }
 
-// GemvArgs + launch geometry of the fused RMSNorm + qkv GEMV as the decode GEMV would run it (decode_front.hip builds its
-// fused launch from it); false when the call is not served by gemv_stream_kernel (M > 4, odd alignment, ...)
-bool gemv_front_plan(int wbits, const float* h, const void* gamma, float eps, const void* w_packed, const void* sz_packed,
-                     const void* bias, void* y, int M, int N, int K, int group_size, GemvArgs* g_out, int* blocks, size_t* lds_bytes,
-                     int* mr, int* gpt) {
-  if (!gemv_stream_enabled() || wbits == 16 || M < 1) return false;
-  const LowpDims d = lowp_dims(wbits, N, K, group_size);
-  if (K != d.Kp || K % 8 != 0 || (reinterpret_cast<uintptr_t>(h) % 16) || (reinterpret_cast<uintptr_t>(gamma) % 16)) return false;
-  const GemvPlan gp = make_gemv_plan(wbits, M, N, K, group_size, false);
-  if (!gp.ok) return false;
-  GemvArgs g{};
-  g.w0 = reinterpret_cast<const u32x4_t*>(w_packed);
-  g.sz0 = reinterpret_cast<const uint32_t*>(sz_packed);
-  g.x = h;
-  g.ldx = K;
-  g.gamma = gamma;
-  g.eps = eps;
-  g.bias = bias;
-  g.y = y;
-  g.ldy = N;
-  g.alpha = 1.f;
-  g.act = DIHIP_ACT_NONE;
-  g.M = M;
-  g.N = N;
-  g.K = K;
-  g.KT = d.KT;
-  g.NTILES = d.NTILES;
-  g.Gp = lowp_dims(4, N, K, group_size).Gp;
-  g.ktpg = gp.ktpg;
-  g.kgroups = gp.kgroups;
-  g.upb = gp.upb;
-  g.nu_q = d.NTILES / gp.blocks;
-  g.nu_r = d.NTILES % gp.blocks;
-  g.WK = gp.WK;
-  g.WN = gp.WN;
-  g.RS = gp.RS;
-  *g_out = g;
-  *blocks = gp.blocks;
-  *lds_bytes = gp.lds_bytes;
-  *mr = gp.MR;
-  *gpt = gp.ktpg == 1 ? 1 : 0;
-  return true;
-}
-
-// GemvArgs + launch geometry of two consecutive decode GEMVs of a layer as the launch chain would run them (decode_mid.hip
-// fuses them into one launch): the residual projection  h_out = h_res + x . W  (PRO_PLAIN, EPI_ADDTO) and the gated MLP
-// input  act = SiLU(norm(h_out) . Wg) * (norm(h_out) . Wu)  (PRO_RMSNORM, EPI_SWIGLU).  false when either is not served
-// by gemv_stream_kernel at M = 1.
-bool gemv_mid_plan(int wbits, const void* x, const void* wo, const void* szo, const float* h_res, float* h_out, int No, int Ko,
-                   const void* gamma, float eps, const void* wg, const void* szg, const void* wu, const void* szu, void* act,
-                   int Ni, int group_size, GemvArgs* go, int* blocks_o, size_t* lds_o, GemvArgs* gg, int* blocks_g, size_t* lds_g,
-                   int* gpt) {
-  if (!gemv_stream_enabled() || wbits == 16) return false;
-  const LowpDims d_o = lowp_dims(wbits, No, Ko, group_size);
-  const LowpDims dg = lowp_dims(wbits, Ni, No, group_size);
-  if (Ko != d_o.Kp || No != dg.Kp || Ko % 8 || No % 8) return false;
-  if ((reinterpret_cast<uintptr_t>(x) % 16) || (reinterpret_cast<uintptr_t>(h_out) % 16) || (reinterpret_cast<uintptr_t>(gamma) % 16)) return false;
-  const GemvPlan po = make_gemv_plan(wbits, 1, No, Ko, group_size, false);
-  const GemvPlan pg = make_gemv_plan(wbits, 1, Ni, No, group_size, true);
-  if (!po.ok || !pg.ok || (po.ktpg == 1) != (pg.ktpg == 1)) return false;
-  auto fill = [&](GemvArgs& g, const GemvPlan& gp, const LowpDims& d, int N, int K) {
-    g.alpha = 1.f;
-    g.act = DIHIP_ACT_NONE;
-    g.M = 1;
-    g.N = N;
-    g.K = K;
-    g.ldx = K;
-    g.ldy = N;
-    g.KT = d.KT;
-    g.NTILES = d.NTILES;
-    g.Gp = lowp_dims(4, N, K, group_size).Gp;
-    g.ktpg = gp.ktpg;
-    g.kgroups = gp.kgroups;
-    g.upb = gp.upb;
-    g.nu_q = d.NTILES / gp.blocks;
-    g.nu_r = d.NTILES % gp.blocks;
-    g.WK = gp.WK;
-    g.WN = gp.WN;
-    g.RS = gp.RS;
-  };
-  GemvArgs a{};
-  a.w0 = reinterpret_cast<const u32x4_t*>(wo);
-  a.sz0 = reinterpret_cast<const uint32_t*>(szo);
-  a.x = x;
-  a.h_res = h_res;
-  a.h_out = h_out;
-  fill(a, po, d_o, No, Ko);
-  GemvArgs b{};
-  b.w0 = reinterpret_cast<const u32x4_t*>(wg);
-  b.sz0 = reinterpret_cast<const uint32_t*>(szg);
-  b.w1 = reinterpret_cast<const u32x4_t*>(wu);
-  b.sz1 = reinterpret_cast<const uint32_t*>(szu);
-  b.x = h_out;
-  b.gamma = gamma;
-  b.eps = eps;
-  b.y = act;
-  fill(b, pg, dg, Ni, No);
-  *go = a;
-  *gg = b;
-  *blocks_o = po.blocks;
-  *blocks_g = pg.blocks;
-  *lds_o = po.lds_bytes;
-  *lds_g = pg.lds_bytes;
-  *gpt = po.ktpg == 1 ? 1 : 0;
-  return true;
-}
-
 static int run_gemm(hipStream_t stream, const GemmCall& c) {
   DIHIP_REQUIRE(c.M >= 0 && c.N > 0 && c.K > 0, DIHIP_PARAM_ERROR, "gemm_lowp: bad shape M=%d N=%d K=%d",
                 c.M, c.N, c.K);

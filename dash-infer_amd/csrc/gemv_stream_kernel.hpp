@@ -36,6 +36,16 @@ namespace dihip {
 constexpr int GEMV_WAVES = 8;
 constexpr int GEMV_THREADS = GEMV_WAVES * 64;
 constexpr int GEMV_RING = 8;  // 1 KiB chunks in flight per wave
+// Slots of the ring filled BEFORE the activation prologue; the rest are requested when the prologue's last barrier is
+// reached.  A CU holds ~32 KiB of outstanding misses: 8 waves x 8 chunks asked for at once is twice that, and the second
+// half of the workgroup's waves sat in the issue queue ~0.8 us behind the first (profiles/r02_gemv_wave_timeline.txt: ring
+// issued at 1.5 vs 2.3 us), reached the prologue's barriers late and finished the main loop ~1.1 us after waves 0-3.
+// 4 + 4 asks for exactly the capacity up front and tops the ring up once the activations are staged.
+#ifndef DIHIP_GEMV_RING_EARLY
+#define DIHIP_GEMV_RING_EARLY 4
+#endif
+constexpr int GEMV_RING_EARLY = DIHIP_GEMV_RING_EARLY;
+static_assert(GEMV_RING_EARLY >= 1 && GEMV_RING_EARLY <= GEMV_RING, "early slots: 1 .. ring");
 
 // ---- hand-scheduled weight stream ------------------------------------------------------------
 // The ring loads are issued through inline asm so that hipcc's waitcnt pass does not see them:
@@ -48,10 +58,6 @@ __device__ __forceinline__ void stream_load_b128(u32x4_t& dst, const void* sbase
 }
 __device__ __forceinline__ void stream_load_b32(uint32_t& dst, const void* sbase, uint32_t voff) {
   asm volatile("global_load_dword %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase));
-}
-// a row another workgroup of the SAME launch wrote (write-through): read past this XCD's L2
-__device__ __forceinline__ void stream_load_coherent_b128(u32x4_t& dst, const void* sbase, uint32_t voff) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 sc0 sc1" : "=&v"(dst) : "v"(voff), "s"(sbase));
 }
 // a second load into the SAME register (read-write operand: the register's current value is not dead)
 __device__ __forceinline__ void stream_reload_b32(uint32_t& dst, const void* sbase, uint32_t voff) {
@@ -139,16 +145,6 @@ struct GemvArgs {
   // writes rows slot_rows[4g + r]
   const int* slot_rows;
   const int* slot_nrows;
-  // PUB (fused decode-step launch): publication counters and the head geometry that maps a column tile to its KV group
-  unsigned* front_counter;
-  int front_n, front_g, front_hpg;
-  // HPUB / HWAIT (decode_mid.hip: two GEMVs of one launch that hand the f32 hidden row over): completion counters
-  // (chain_replicas copies, one 128-byte line each: a consumer polls copy bid % replicas), the number of producer
-  // workgroups a consumer waits for, the consumers' pass counter (the last one through zeroes everything for the next
-  // launch) and the pause before the first poll (s_sleep(127) repetitions)
-  unsigned* chain_counter;
-  unsigned* chain_done;
-  int chain_replicas, chain_target, chain_consumers, chain_presleep;
   int WK, WN;  // wave grid inside the workgroup, WK * WN == GEMV_WAVES, both powers of two (SwiGLU: WN >= 2)
   int RS;      // LDS activation row stride in elements (KT * KTILE + 8)
   unsigned long long* trace;  // diagnostics (dihip_debug_set_trace): [block][wave][8] wall-clock stamps, or null
@@ -165,22 +161,7 @@ __host__ __device__ inline size_t gemv_lds_bytes(int rows, int RS, int KT, int u
 // GPT: every k-tile is one quantisation group (W4 g128, W8 g64): no accumulator carry between chunks
 // SLOT (mixture-of-experts): gridDim.y enumerates (token, expert-rank) slots; slot s streams the weights of expert
 // slot_expert[s] (all experts have one shape: base + expert * stride), reads activation row s / x_div and writes row s.
-// PUB (decode_front.hip): this GEMV produces the fused qkv row for attention workgroups of the SAME launch: the row is stored
-// write-through (agent scope) and, once a workgroup's stores have left, it adds its column tiles to the publication counter
-// of the KV group(s) they belong to (a.front_counter[m * front_g + group], one count per 16-column tile and row).
-template <int FT>
-__device__ __forceinline__ void store_ft_wt(void* p, size_t i, float v) {  // FT store that another CU may read in this launch
-  static_assert(FT == DIHIP_BF16 || FT == DIHIP_F16, "16-bit rows");
-  unsigned short* q = reinterpret_cast<unsigned short*>(p) + i;
-  const unsigned bits = f32_to_ft_bits<FT>(v);
-  asm volatile("global_store_short %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(q), "v"(bits) : "memory");
-}
-
-// SYNC: 0 plain | GEMV_SYNC_PUB (decode_front: publishes the qkv row per KV group) | GEMV_SYNC_HPUB (decode_mid producer:
-// the f32 hidden row is stored write-through, then the workgroup is counted) | GEMV_SYNC_HWAIT (decode_mid consumer: no
-// early activation loads; the weight ring is filled, then the workgroup waits for the producers and reads the row coherently)
-enum { GEMV_SYNC_NONE = 0, GEMV_SYNC_PUB = 1, GEMV_SYNC_HPUB = 2, GEMV_SYNC_HWAIT = 3 };
-template <int WBITS, int FT, int MR, int PRO, int EPI, int GPT, bool SLOT = false, int SYNC = GEMV_SYNC_NONE>
+template <int WBITS, int FT, int MR, int PRO, int EPI, int GPT, bool SLOT = false>
 __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bid, const int nblocks, unsigned char* smem) {
   // the tensors of this launch (SLOT: of this slot's expert / activation row); everything else is read from `a`
   const u32x4_t* p_w0 = a.w0;
@@ -267,12 +248,7 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
   constexpr int NV = PRO == PRO_RMSNORM ? 2 * NE : NE, NG = PRO == PRO_RMSNORM ? NE : 1;
   u32x4_t ev[NV];
   u32x4_t eg[NG];
-  if constexpr (SYNC == GEMV_SYNC_HWAIT) {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) ev[j] = u32x4_t{0u, 0u, 0u, 0u};  // loaded after the wait (fetch_hidden_row below)
-#pragma unroll
-    for (int j = 0; j < NG; ++j) eg[j] = u32x4_t{0u, 0u, 0u, 0u};
-  } else {
+  {
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
       // sub-batches entirely beyond the row are skipped (wave-uniform); a partial one is clamped
@@ -403,8 +379,9 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
       stream_load_b128(wb[SLOT], dummy_w, 0u); /* no scale word */   \
     }                                                                \
   } while (0)
+  constexpr int DE = GEMV_RING_EARLY;
 #pragma unroll
-  for (int j = 0; j < D; ++j) {
+  for (int j = 0; j < DE; ++j) {
     if (to_issue > 0) {
       DIHIP_GEMV_ISSUE(j);
       --to_issue;
@@ -436,40 +413,7 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
       if ((i & (KTILE / 8 - 1)) == 0) xsum_tab[(i / (KTILE / 8)) * 16 + r] = sum;
     }
   };
-  if constexpr (SYNC == GEMV_SYNC_HWAIT) {
-    static_assert(PRO == PRO_RMSNORM && MR == 1, "HWAIT: the consumer is the single-row RMSNorm GEMV");
-    // The weight ring is in flight (it does not depend on the row).  One lane waits for the producers: every producer
-    // workgroup adds 1 to each counter copy once its write-through stores have been acknowledged.
-    if (tid == 0) {
-      const unsigned* cnt = a.chain_counter + (size_t)(bid % a.chain_replicas) * 32;
-      for (int i = 0; i < a.chain_presleep; ++i) __builtin_amdgcn_s_sleep(127);  // ~3.9 us each: no poll before it can be done
-      unsigned long long spins = 0;
-      while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.chain_target) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1ull << 22)) __builtin_trap();  // seconds without the producers: fail loudly, never hang the box
-      }
-      // the last consumer through leaves the counters zeroed for the next launch (launches of a stream do not overlap)
-      const unsigned t = __hip_atomic_fetch_add(a.chain_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t == (unsigned)a.chain_consumers - 1u) {
-        for (int r = 0; r < a.chain_replicas; ++r)
-          __hip_atomic_store(a.chain_counter + (size_t)r * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.chain_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    __syncthreads();
-    // the row, read past the L2 (the producers ran on other XCDs), waited for on the spot
-#pragma unroll
-    for (int j = 0; j < NE; ++j) {
-      if (j > 0 && j * GEMV_THREADS >= nvec) continue;  // (ev / eg of skipped sub-batches stay zero)
-      const uint32_t i = (uint32_t)min(j * GEMV_THREADS + tid, nvec - 1);
-      stream_load_coherent_b128(ev[2 * j], p_x, i * 32u);
-      stream_load_coherent_b128(ev[2 * j + 1], p_x, i * 32u + 16u);
-      stream_load_plain_b128(eg[j], a.gamma, i * 16u);
-    }
-    stream_wait<0>();
-  } else {
-    stream_wait<D * LPC>();  // everything older than the ring fill has landed: the early batch
-  }
+  stream_wait<DE * LPC>();  // everything older than the (early part of the) ring fill has landed: the early batch
 #pragma unroll
   for (int j = 0; j < NV; ++j) early_landed(ev[j]);
 #pragma unroll
@@ -558,6 +502,16 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
       u32x4_t lv[NV], lg[NG];
       fetch_batch(r, 0, lv, lg);
       plain_row(r, lv);
+    }
+  }
+  // the rest of the ring (see GEMV_RING_EARLY): in flight while the workgroup meets at the barrier
+#pragma unroll
+  for (int j = DE; j < D; ++j) {
+    if (to_issue > 0) {
+      DIHIP_GEMV_ISSUE(j);
+      --to_issue;
+    } else {
+      DIHIP_GEMV_DUMMY(j);
     }
   }
   __syncthreads();
@@ -715,42 +669,13 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
       if (a.bias) v = __fadd_rn(v, load_ft<FT>(a.bias, n));
       v = apply_act(v, a.act);
       if (a.residual) v = ft_round<FT>(v) + load_ft<FT>(a.residual, yrow + n);
-      if constexpr (SYNC == GEMV_SYNC_PUB) store_ft_wt<FT>(p_y, yrow + n, v);
-      else store_ft<FT>(p_y, yrow + n, v);
+      store_ft<FT>(p_y, yrow + n, v);
     } else if constexpr (EPI == EPI_SWIGLU) {
       store_ft<FT>(p_y, yrow + n, (v / (1.f + expf(-v))) * v2);
     } else {
       const float base = a.h_res ? a.h_res[(size_t)m * a.N + n] : 0.f;
       const float hv = __fadd_rn(base, __fmul_rn(a.alpha, v));
-      if constexpr (SYNC == GEMV_SYNC_HPUB) {
-        float* q_ = a.h_out + (size_t)m * a.N + n;
-        asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(q_), "v"(hv) : "memory");  // written through: read in this launch
-      } else {
-        a.h_out[(size_t)m * a.N + n] = hv;
-      }
-    }
-  }
-  if constexpr (SYNC == GEMV_SYNC_HPUB) {
-    // every store of this workgroup has been acknowledged (vmcnt(0) per wave, then the barrier): count it on every copy
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid < a.chain_replicas)
-      __hip_atomic_fetch_add(a.chain_counter + (size_t)tid * 32, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if constexpr (SYNC == GEMV_SYNC_PUB) {
-    // publish: all write-through stores of this workgroup have been acknowledged (vmcnt(0) per wave, then the barrier), then one
-    // lane adds the workgroup's tiles to their groups' counters.  Column tile t = 8 tiles per head of 128: heads [0, n) are
-    // query heads (group = head / hpg), [n, n + g) K heads, [n + g, n + 2g) V heads.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      for (int u = 0; u < nu; ++u) {
-        const int head = (u0 + u * NB) >> 3;
-        const int grp = head < a.front_n ? head / a.front_hpg : (head < a.front_n + a.front_g ? head - a.front_n : head - a.front_n - a.front_g);
-        for (int m = 0; m < rows; ++m)
-          __hip_atomic_fetch_add(a.front_counter + ((size_t)m * a.front_g + grp) * 32 /* FRONT_SYNC_STRIDE */, 1u, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
-      }
+      a.h_out[(size_t)m * a.N + n] = hv;
     }
   }
   DIHIP_GEMV_STAMP(6);
@@ -760,7 +685,7 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
 template <int WBITS, int FT, int MR, int PRO, int EPI, int GPT, bool SLOT = false>
 __global__ __launch_bounds__(GEMV_THREADS) void gemv_stream_kernel(const GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  gemv_stream_body<WBITS, FT, MR, PRO, EPI, GPT, SLOT, GEMV_SYNC_NONE>(a, (int)blockIdx.x, (int)gridDim.x, smem);
+  gemv_stream_body<WBITS, FT, MR, PRO, EPI, GPT, SLOT>(a, (int)blockIdx.x, (int)gridDim.x, smem);
 }
 
 template <int WBITS, int FT, int MR, int PRO, int EPI, int GPT>

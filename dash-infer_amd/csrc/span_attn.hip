@@ -635,49 +635,6 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
   return DIHIP_SA_SUCCESS;
 }
 
-// ---- cache prefetch riding on the decode-step attention launch (AttnArgs::pf_ptr) -----------------------------------
-struct PendingPrefetch {
-  const void* ptr[4];
-  size_t bytes[4];
-  int n;
-};
-static thread_local PendingPrefetch g_pending_pf = {};
-
-// fills a.pf_* from the pending list (consumed), returns the extra grid rows (blockIdx.y) to launch
-static int take_prefetch_rows(AttnArgs& a, int nsplits, int attn_rows, int batch) {
-  for (int i = 0; i < 4; ++i) {
-    a.pf_ptr[i] = nullptr;
-    a.pf_lines[i] = 0;
-  }
-  PendingPrefetch p = g_pending_pf;
-  g_pending_pf.n = 0;
-  static int enabled = -1;  // DIHIP_ATTN_PREFETCH=0: ignore the list (A/B)
-  if (enabled < 0) {
-    const char* e = getenv("DIHIP_ATTN_PREFETCH");
-    enabled = (e && e[0] == '0') ? 0 : 1;
-  }
-  if (!enabled || p.n <= 0) return 0;
-  size_t lines = 0;
-  for (int i = 0; i < p.n && i < 4; ++i) {
-    a.pf_ptr[i] = reinterpret_cast<const unsigned*>(p.ptr[i]);
-    a.pf_lines[i] = (unsigned)std::min<size_t>(p.bytes[i] / 128, 0x7fffffffu);
-    lines += a.pf_lines[i];
-  }
-  if (lines == 0) return 0;
-  int ncu = cached_num_cus();
-  if (ncu <= 0) ncu = 256;
-  static int want_wgs = -1;  // DIHIP_ATTN_PREFETCH_WGS: prefetch workgroups (default: the CUs the attention leaves idle)
-  if (want_wgs < 0) {
-    const char* e = getenv("DIHIP_ATTN_PREFETCH_WGS");
-    want_wgs = e ? std::max(1, atoi(e)) : 0;
-  }
-  const int used = nsplits * attn_rows * batch;
-  int wgs = want_wgs > 0 ? want_wgs : std::max(32, ncu - used);
-  wgs = (int)std::min<size_t>((size_t)wgs, (lines + ATTN_THREADS - 1) / ATTN_THREADS);
-  const int per_row = nsplits * batch;
-  return std::max(1, (wgs + per_row - 1) / per_row);
-}
-
 // decode-step form (Rotary + cache append folded in) for the 16-bit cache: span_attn_ft_mfma_kernel<FT, NONE, true>
 size_t span_attn_fused_mfma_workspace_bytes(int batch, int n_heads, int n_groups, int max_seq_len) {
   return attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true).partial_bytes;
@@ -686,7 +643,7 @@ size_t span_attn_fused_mfma_workspace_bytes(int batch, int n_heads, int n_groups
 int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* const* k_span_array, void* const* v_span_array,
                          const uint32_t* old_seq_lens_dev, const float* rope_table, int batch, int n_heads, int n_groups,
                          int span_len, int n_spans_per_request, int max_seq_len, int kv_mode, int dtype, float qk_scale, void* ws,
-                         size_t ws_bytes, bool* handled) {
+                         size_t ws_bytes, bool* handled, void* sync, size_t sync_bytes) {
   *handled = false;
   if (kv_mode != DIHIP_KV_NONE || !attn_use_mfma(kv_mode, dtype)) return DIHIP_SUCCESS;
   const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true);
@@ -710,13 +667,29 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
   a.nchunks = p.nchunks;
   a.scale = qk_scale;
   a.rope_tab = rope_table;
-  const int pf_rows = take_prefetch_rows(a, p.nsplits, n_groups * p.nchunks, batch);
-  const dim3 grid(p.nsplits, n_groups * p.nchunks + pf_rows, batch);
+  a.partial_bytes = p.partial_bytes;
+  // split width fixed from max_seq_len (AttnArgs::tps_static); DIHIP_ATTN_STATIC_TPS=0: from the request's length (A/B)
+  static int static_tps = -1, merge_mode = -1;
+  if (static_tps < 0) {
+    const char* e = getenv("DIHIP_ATTN_STATIC_TPS");
+    static_tps = (e && e[0] == '0') ? 0 : 1;
+    const char* m = getenv("DIHIP_ATTN_MERGE");  // "launch": the split merge as a second launch also when a sync buffer is given (A/B)
+    merge_mode = (m && m[0] == 'l') ? 0 : 1;
+  }
+  if (static_tps) a.tps_static = ((max_seq_len + p.nsplits - 1) / p.nsplits + 31) & ~31;
+  // in-launch merge: needs the caller's zero-initialised ticket words (dihip_span_attn_decode_fused_sync)
+  const bool merge_wt = merge_mode == 1 && p.nsplits > 1 && sync != nullptr &&
+                        sync_bytes >= (size_t)batch * n_groups * p.nchunks * sizeof(unsigned) && p.partial_bytes < (1ull << 31);
+  if (merge_wt) {
+    a.counters = reinterpret_cast<unsigned*>(sync);
+    a.merge_wt = 1;
+  }
+  const dim3 grid(p.nsplits, n_groups * p.nchunks, batch);
   if (dtype == DIHIP_BF16)
     hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_NONE, true>), grid, dim3(ATTN_THREADS), 0, s, a);
   else
     hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_F16, DIHIP_KV_NONE, true>), grid, dim3(ATTN_THREADS), 0, s, a);
-  if (p.nsplits > 1) {
+  if (p.nsplits > 1 && !merge_wt) {
     const dim3 mg(batch * n_heads), mb(128);
     if (dtype == DIHIP_BF16)
       hipLaunchKernelGGL(span_attn_split_merge_kernel<DIHIP_BF16>, mg, mb, 0, s, output, a.partials, n_heads, p.nsplits, 0);
@@ -726,33 +699,11 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
   return launch_status();
 }
 
-// plan of the decode-step MFMA attention for the fused front launch (decode_front.hip): 0 = not covered
-int span_attn_front_plan(int batch, int n_heads, int n_groups, int max_seq_len, int kv_mode, int dtype, int* nsplits, int* nchunks,
-                         size_t* partial_bytes) {
-  if (kv_mode != DIHIP_KV_NONE || dtype != DIHIP_BF16 || !attn_use_mfma(kv_mode, dtype) || n_heads % n_groups) return 0;
-  const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true);
-  *nsplits = p.nsplits;
-  *nchunks = p.nchunks;
-  *partial_bytes = (size_t)batch * n_heads * p.nsplits * ATTN_PSTRIDE * sizeof(float);  // partial records are always written
-  return 1;
-}
-
 }  // namespace dihip
 
 using namespace dihip;
 
 extern "C" {
-
-int dihip_span_attn_set_next_prefetch(const void* const* ptrs, const size_t* bytes, int count) {
-  DIHIP_REQUIRE(count >= 0 && count <= 4 && (count == 0 || (ptrs && bytes)), DIHIP_PARAM_ERROR,
-                "span_attn_set_next_prefetch: 0..4 buffers");
-  g_pending_pf.n = count;
-  for (int i = 0; i < count; ++i) {
-    g_pending_pf.ptr[i] = ptrs[i];
-    g_pending_pf.bytes[i] = ptrs[i] ? bytes[i] : 0;
-  }
-  return DIHIP_SUCCESS;
-}
 
 int dihip_span_attn_merge_partials(void* stream, void* output, const float* partials, int batch, int n_heads, int nsplits,
                                    int dtype) {

@@ -8,7 +8,6 @@ namespace dihip {
 constexpr int ATTN_THREADS = 256;
 constexpr int ATTN_TB = 2;              // tokens per lane slot per iteration
 constexpr int ATTN_TOK_PER_ITER = 32;  // 4 waves x 4 token slots x ATTN_TB tokens
-constexpr int FRONT_SYNC_STRIDE = 32;  // unsigned words between the per-(request, group) sync counters: one 128-byte line each
 constexpr int ATTN_PSTRIDE = 132;      // floats per partial record: o[128], m, l, pad
 
 struct AttnArgs {
@@ -25,20 +24,16 @@ struct AttnArgs {
   // decode-step form (Rotary + DecoderCacheAppend folded in): q points at the fused pre-Rotary qkv rows
   // [B, (n + 2g) * H], seq_lens holds the tokens ALREADY cached (position of the new token)
   const float* rope_tab;  // [max_pos][64] {cos, sin}; non-null selects the decode-step form
-  // decode-step form: workgroups with blockIdx.y >= g * nchunks do not attend; they touch one dword per 128-byte line of up
-  // to 4 buffers (the weights of the launches that follow: o-projection, next layer's qkv), which pulls them into the
-  // 256 MB Infinity Cache while the attention -- 4 MB of KV on a fraction of the CUs -- leaves HBM idle.  The small
-  // GEMVs are first-byte-latency bound: on cache-resident weights they measured 1.4-1.6 us shorter (profiles/r02*).
-  const unsigned* pf_ptr[4];
-  unsigned pf_lines[4];
-  // fused decode-step launch (decode_front.hip): qkv-publication counters [B * g], see span_attn_ft_mfma_body<.., FRONT>
-  unsigned* front_counter;
-  unsigned* front_done;
-  unsigned front_target;
-  int front_presleep;     // s_sleep(127) repetitions before the first poll (the GEMV cannot be done earlier)
   int len_bias;           // sequence length = seq_lens[b] + len_bias (decode step on the op-boundary kernels: lengths BEFORE the append, + 1)
-  int force_partials;     // write the block's partial record even for a single split and leave the merge to the consumer
-                          // (decode_front.hip launches dihip_span_attn_merge_partials itself)
+  int force_partials;     // write the block's partial record even for a single split and leave the merge to the caller
+  int tps_static;         // decode-step form: tokens per split fixed by the host from max_seq_len (0: from the request's
+                          // length, as the op-boundary kernels).  A split's token range -- and with it the span-table
+                          // entries of a wave's first tiles -- then depends on the kernel arguments alone: the pointer loads
+                          // go out together with the length load instead of one round trip behind it.
+  int merge_wt;           // in-launch merge of the split partials (a.counters != null): records stored write-through,
+                          // arrival ticket, the last workgroup of a (request, group) reads all records past its L1 and
+                          // writes the output -- no release / acquire fences, no second launch
+  size_t partial_bytes;   // size of `partials` (buffer-resource range of the write-through stores / loads)
 };
 
 // decode-step form on the matrix cores (span_attn.hip); returns a DIHIP status, DIHIP_PARAM_ERROR with
@@ -46,7 +41,7 @@ struct AttnArgs {
 int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* const* k_span_array, void* const* v_span_array,
                          const uint32_t* old_seq_lens_dev, const float* rope_table, int batch, int n_heads, int n_groups,
                          int span_len, int n_spans_per_request, int max_seq_len, int kv_mode, int dtype, float qk_scale, void* ws,
-                         size_t ws_bytes, bool* handled);
+                         size_t ws_bytes, bool* handled, void* sync = nullptr, size_t sync_bytes = 0);
 size_t span_attn_fused_mfma_workspace_bytes(int batch, int n_heads, int n_groups, int max_seq_len);
 // the op-boundary decode kernels (span_attn.hip: run_decode) on lengths seq_lens[b] + len_bias; returns a DIHIP status
 int span_attn_decode_biased(void* stream, void* output, const void* query, const void* const* k_span_array,

@@ -1,6 +1,5 @@
-// span_attn_ft_mfma.hpp -- the MFMA decode attention over 16-bit / int8 caches as a device function (plus the block epilogue it
-// shares with the other decode kernels), so that it can run as a kernel of its own (span_attn.hip) or as the attention
-// workgroups of the fused decode-step launch (decode_front.hip).
+// span_attn_ft_mfma.hpp -- the MFMA decode attention over 16-bit / int8 caches (plus the block epilogues it shares with the
+// other decode kernels of span_attn.hip).
 #pragma once
 #include "span_attn_common.hpp"
 
@@ -111,6 +110,96 @@ __device__ __forceinline__ void attn_block_epilogue(const AttnArgs& a, float* ld
   }
 }
 
+// In-launch merge of the split partials without fences (AttnArgs::merge_wt; MI355X guide, Guideline 16 form R1): the 4 waves
+// have left their (o[128], m, l) records in `lds`.  The block record goes to `partials` with 16-byte WRITE-THROUGH stores
+// (sc1: the line leaves this XCD's L2), every wave drains its stores, one lane takes an arrival ticket (relaxed agent-scope
+// atomic), and the workgroup that arrives last for its (request, group, head chunk) reads all nsplits records with sc1
+// loads -- which are served past this CU's L1, and the writers' lines are not in any other L2 -- merges them in split order
+// (the arithmetic of span_attn_split_merge_kernel) and writes the FT output.  The ticket word is left at zero for the
+// next launch.  Thread -> (head h = e / 32, dims (e % 32) * 4 .. + 3).
+template <int FT, int HC>
+__device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float* lds, unsigned* flag_lds, int b, int h0, int nh,
+                                                       int split, unsigned* counter) {
+  constexpr int H = 128;
+  const int tid = threadIdx.x;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.partials, 0, (int)a.partial_bytes, 0x00020000);
+  __syncthreads();
+  for (int e = tid; e < nh * 32; e += ATTN_THREADS) {
+    const int h = e >> 5, dq = e & 31;
+    float mm = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) mm = fmaxf(mm, lds[(w * HC + h) * ATTN_PSTRIDE + H]);
+    float ll = 0.f;
+    f32x4_t oo = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* rec = lds + (w * HC + h) * ATTN_PSTRIDE;
+      const float c = safe_exp_diff(rec[H], mm);
+      ll += rec[H + 1] * c;
+      const f32x4_t ov = *reinterpret_cast<const f32x4_t*>(rec + dq * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) oo[j] += ov[j] * c;
+    }
+    const uint32_t roff = (uint32_t)((((size_t)b * a.n + h0 + h) * a.nsplits + split) * ATTN_PSTRIDE * sizeof(float));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, oo), rsrc, roff + dq * 16, 0, 16 /* sc1 */);
+    if (dq == 0) {
+      const u32x2_t ml = {__float_as_uint(mm), __float_as_uint(ll)};
+      __builtin_amdgcn_raw_buffer_store_b64(ml, rsrc, roff + H * 4, 0, 16);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its write-through stores are acknowledged
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = t == (unsigned)a.nsplits - 1u;
+    if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // launches of a stream do not overlap
+    *flag_lds = last ? 1u : 0u;
+  }
+  __syncthreads();
+  if (*flag_lds == 0u) return;
+  for (int e = tid; e < nh * 32; e += ATTN_THREADS) {
+    const int h = e >> 5, dq = e & 31;
+    const uint32_t hoff = (uint32_t)(((size_t)b * a.n + h0 + h) * a.nsplits * ATTN_PSTRIDE * sizeof(float));
+    float mm = -INFINITY, ll = 0.f;
+    f32x4_t oo = {0.f, 0.f, 0.f, 0.f};
+    constexpr int MB = 32;  // records per batch: all loads of a batch in flight together
+    for (int sb = 0; sb < a.nsplits; sb += MB) {
+      u32x4_t ov[MB];
+      u32x2_t mv[MB];
+#pragma unroll
+      for (int j = 0; j < MB; ++j) {
+        const uint32_t ro = hoff + (uint32_t)(min(sb + j, a.nsplits - 1) * (ATTN_PSTRIDE * (int)sizeof(float)));
+        ov[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ro + dq * 16, 0, 16 /* sc1 */);
+        mv[j] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, ro + H * 4, 0, 16);
+      }
+      float bm = mm;
+#pragma unroll
+      for (int j = 0; j < MB; ++j)
+        if (sb + j < a.nsplits) bm = fmaxf(bm, __uint_as_float(mv[j][0]));
+      const float carry = safe_exp_diff(mm, bm);
+      ll *= carry;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) oo[q] *= carry;
+#pragma unroll
+      for (int j = 0; j < MB; ++j) {
+        if (sb + j < a.nsplits) {
+          const float c = safe_exp_diff(__uint_as_float(mv[j][0]), bm);
+          ll = fmaf(__uint_as_float(mv[j][1]), c, ll);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) oo[q] = fmaf(__uint_as_float(ov[j][q]), c, oo[q]);
+        }
+      }
+      mm = bm;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int d = dq * 4 + q;
+      const size_t idx = a.out_frag_mt ? act_frag_index(b, (h0 + h) * H + d, a.out_frag_mt) : ((size_t)b * a.n + h0 + h) * H + d;
+      store_ft<FT>(a.out, idx, ll > 0.f ? oo[q] / ll : 0.f);
+    }
+  }
+}
+
 constexpr int MF_HC = 16;   // query heads per workgroup chunk (MFMA N)
 constexpr int MF_TOK = 32;  // tokens per wave iteration
 
@@ -139,73 +228,58 @@ __device__ __forceinline__ f32x4_t mfma_ft(const u32x4_t& a_, const u32x4_t& b_,
 // the SAME lane); the workgroup whose range holds the new token rotates / rounds this step's K head and takes its V
 // head, one wave writes both into the span (byte-identical to DecoderCacheAppend), and every lane whose (clamped)
 // token is the new one uses the register copy -- the span row itself may not be written yet.
-// FRONT (decode_front.hip): the attention workgroups of the fused decode-step launch.  The fused qkv row (a.q) is produced
-// by GEMV workgroups of the SAME launch: K / V tile loads and all address work go first, then the workgroup waits until
-// the GEMV workgroups have published every column tile of its KV group (a.front_counter[b * g + grp] == a.front_target;
-// the row was stored write-through), and reads q / k / v of this step with agent-scope loads (they must not come from
-// this CU's L1 or a stale line).  The last attention workgroup of a (request, group) to pass the wait clears both
-// counters: the launch leaves the sync words as it found them (graph-replay safe).
 constexpr int FT_MFMA_EPI_BYTES = (4 * MF_HC * ATTN_PSTRIDE + 4) * 4;
 constexpr int FT_MFMA_VT_BYTES = 4 * MF_TOK * MF_VPITCH;
 constexpr int FT_MFMA_SMEM_BYTES = FT_MFMA_EPI_BYTES > FT_MFMA_VT_BYTES ? FT_MFMA_EPI_BYTES : FT_MFMA_VT_BYTES;
 
-template <bool FRONT>
-__device__ __forceinline__ u32x4_t ld_qkv16(const uint16_t* p) {  // 16 bytes of the fused qkv row
-  if constexpr (FRONT) {
-    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return u32x4_t{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
-  } else {
-    return *reinterpret_cast<const u32x4_t*>(p);
-  }
-}
+__device__ __forceinline__ u32x4_t ld_qkv16(const uint16_t* p) { return *reinterpret_cast<const u32x4_t*>(p); }  // 16 bytes of the fused qkv row
 
-template <int FT, int MODE, bool FUSED, bool FRONT = false>
+template <int FT, int MODE, bool FUSED>
 __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const int bx, const int by, const int bz, const int gx,
                                                        const int gy, const int gz, unsigned char* smem) {
   constexpr int H = 128;
   constexpr int HC = MF_HC;
   constexpr bool Q8 = MODE == DIHIP_KV_I8;
   static_assert(!FUSED || MODE == DIHIP_KV_NONE, "the decode-step form covers the 16-bit cache");
-  static_assert(!FRONT || FUSED, "FRONT is a decode-step form");
   constexpr int ROWB = Q8 ? H : H * 2;  // bytes per token-head row in the span
   // the per-wave V tiles and the epilogue records share one buffer (a barrier separates the two uses): FT_MFMA_SMEM_BYTES
   float* lds = reinterpret_cast<float*>(smem);
   unsigned* flag_lds = reinterpret_cast<unsigned*>(lds + 4 * HC * ATTN_PSTRIDE);
 
   const int tid = threadIdx.x, lane = tid & 63;
-  if constexpr (FUSED) {
-    if (by >= a.g * a.nchunks) {  // cache-prefetch workgroup (see AttnArgs::pf_ptr); workgroup-uniform exit
-      const unsigned pw = ((bz * (gy - a.g * a.nchunks) + (by - a.g * a.nchunks)) * gx + bx);
-      const unsigned npw = gz * (gy - a.g * a.nchunks) * gx;
-      unsigned acc = 0;
-#pragma unroll
-      for (int bi = 0; bi < 4; ++bi) {
-        const unsigned* p = a.pf_ptr[bi];
-        const unsigned lines = a.pf_lines[bi];
-        for (unsigned i = pw * ATTN_THREADS + tid; i < lines; i += npw * ATTN_THREADS) acc ^= gload<unsigned>(p + (size_t)i * 32);
-      }
-      if (acc == 0x9E3779B9u && a.partials) a.partials[0] = 0.f;  // practically never: keeps the loads alive
-      return;
-    }
-  }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kb = lane >> 4, ni = lane & 15;
   const int split = bx;
-  const int grp = by / a.nchunks, hc = by % a.nchunks;
+  const int grp = a.nchunks == 1 ? by : by / a.nchunks, hc = a.nchunks == 1 ? 0 : by % a.nchunks;
   const int b = bz;
   const int h0 = grp * a.hpg + hc * HC;
   const int nh = min(HC, a.hpg - hc * HC);
   unsigned char* vt = smem + wave * (MF_TOK * MF_VPITCH);
-
-  const int len = (int)a.seq_lens[b] + (FUSED ? 1 : a.len_bias);
-  const int newpos = len - 1;  // FUSED: position of this step's token
-  const int tps = ((len + a.nsplits - 1) / a.nsplits + 31) & ~31;
-  const int t0 = split * tps;
-  const int t1 = min(len, t0 + tps);
+  const int lgS = 31 - __builtin_clz((unsigned)a.S);  // span lengths are powers of two (16 .. 128): shifts, not the ~25-instruction scalar division
   const void* const* ksp = a.kspans + (size_t)b * a.span_stride;
   const void* const* vsp = a.vspans + (size_t)b * a.span_stride;
+  // decode-step form with a host-fixed split width: the span-table entries of this wave's first tile pair depend on the
+  // kernel arguments alone -- requested here, beside the length (one round trip instead of two before the K / V loads)
+  const bool spec = FUSED && a.tps_static > 0;
+  int spu[2] = {0, 0};
+  const void* kpu[2] = {nullptr, nullptr};
+  const void* vpu[2] = {nullptr, nullptr};
+  if constexpr (FUSED) {
+    if (spec) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        spu[c] = min((split * a.tps_static + wave * MF_TOK + c * 16) >> lgS, a.span_stride - 1);
+        kpu[c] = ksp[spu[c]];
+        vpu[c] = vsp[spu[c]];
+      }
+    }
+  }
+  // (a request longer than its span table cannot be served: the length is clamped, the new token's store below is skipped)
+  const int len = min((int)a.seq_lens[b] + (FUSED ? 1 : a.len_bias), a.span_stride * a.S);
+  const int newpos = (int)a.seq_lens[b] + (FUSED ? 1 : a.len_bias) - 1;  // FUSED: position of this step's token
+  const int tps = spec ? a.tps_static : (((len + a.nsplits - 1) / a.nsplits + 31) & ~31);
+  const int t0 = split * tps;
+  const int t1 = min(len, t0 + tps);
   const size_t par_off = (size_t)a.g * a.S * ROWB;  // int8: (zero, scale) pairs follow the data of all groups
 
   // K: tile c.  FT rows: k-step ks = dims ks*32 + kb*8.. (4 x 16 B per token);  int8 rows: dims kb*32.. (2 x 16 B)
@@ -218,17 +292,17 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   auto tile_base = [&](int tb, int c, int& row0, int& last) {
     int base = tb + c * 16;
     base = base < t1 ? base : ((t1 - 1) & ~15);
-    const int sp = __builtin_amdgcn_readfirstlane(base / a.S);
-    row0 = grp * a.S + (base - sp * a.S);
+    const int sp = __builtin_amdgcn_readfirstlane(base >> lgS);
+    row0 = grp * a.S + (base - (sp << lgS));
     last = min(15, t1 - 1 - base);  // last valid token of the tile, relative
     return sp;
   };
-  auto load_k = [&](int tb) {
+  auto load_k = [&](int tb, bool first = false) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       int row0, last;
       const int sp = tile_base(tb, c, row0, last);
-      const unsigned char* kbase = reinterpret_cast<const unsigned char*>(ksp[sp]);
+      const unsigned char* kbase = reinterpret_cast<const unsigned char*>(first && spec && sp == spu[c] ? kpu[c] : ksp[sp]);
       const unsigned char* kd = kbase + (size_t)row0 * ROWB;
       if constexpr (Q8) {
         const uint32_t off = (uint32_t)(min(ni, last) * ROWB + kb * 32);
@@ -244,12 +318,12 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
       }
     }
   };
-  auto load_v = [&](int tb) {
+  auto load_v = [&](int tb, bool first = false) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       int row0, last;
       const int sp = tile_base(tb, c, row0, last);
-      const unsigned char* vbase = reinterpret_cast<const unsigned char*>(vsp[sp]);
+      const unsigned char* vbase = reinterpret_cast<const unsigned char*>(first && spec && sp == spu[c] ? vpu[c] : vsp[sp]);
       const unsigned char* vd = vbase + (size_t)row0 * ROWB;
       if constexpr (Q8) {
 #pragma unroll
@@ -281,8 +355,8 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   const int tb0 = t0 + wave * MF_TOK;
   const bool active = tb0 < t1;
   if (active) {
-    load_v(tb0);
-    load_k(tb0);
+    load_v(tb0, true);
+    load_k(tb0, true);
   }
 
   // rotate-half on a lane's fragments: dims ks*32 + kb*8 + e (ks = 0, 1) pair with ks + 2; table row = position.
@@ -320,27 +394,12 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   float qsum = 0.f;
   const size_t qrow_stride = FUSED ? (size_t)(a.n + 2 * a.g) * H : (size_t)a.n * H;
   const float* cs_row = FUSED ? a.rope_tab + (size_t)newpos * 128 : nullptr;
-  if constexpr (FRONT) {
-    // everything above needs only the cache: the K / V tiles of this wave are in flight.  Now the qkv row.
-    // one poller per workgroup, one 128-byte line per counter, and no poll before the GEMV can possibly be done: every poll is
-    // a device-scope access to a line that the producers' atomics also need (a hot line serialises at its home channel)
-    unsigned* cnt = a.front_counter + ((size_t)b * a.g + grp) * FRONT_SYNC_STRIDE;
-    if (tid == 0) {
-      unsigned long long spins = 0;
-      for (int i = 0; i < a.front_presleep; ++i) __builtin_amdgcn_s_sleep(127);  // 127 x 64 clk ~ 3.9 us each at 2.1 GHz
-      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.front_target) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1ull << 22)) __builtin_trap();  // the producer workgroups are gone: fail loudly instead of hanging the GPU
-      }
-    }
-    __syncthreads();
-  }
   {
     const bool hv = ni < nh;
     const uint16_t* qrow = reinterpret_cast<const uint16_t*>(a.q) + (size_t)b * qrow_stride + (size_t)(h0 + (hv ? ni : 0)) * H;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      qf[ks] = ld_qkv16<FRONT>(qrow + (Q8 ? kb * 32 + ks * 8 : ks * 32 + kb * 8));
+      qf[ks] = ld_qkv16(qrow + (Q8 ? kb * 32 + ks * 8 : ks * 32 + kb * 8));
       if constexpr (Q8) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) qsum += hv ? ft_bits_to_f32<FT>(qf[ks][j] & 0xFFFFu) + ft_bits_to_f32<FT>(qf[ks][j] >> 16) : 0.f;
@@ -362,11 +421,12 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
       const uint16_t* krow = reinterpret_cast<const uint16_t*>(a.q) + (size_t)b * qrow_stride + (size_t)(a.n + grp) * H;
       const uint16_t* vrow = krow + (size_t)a.g * H;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) knew[ks] = ld_qkv16<FRONT>(krow + ks * 32 + kb * 8);
+      for (int ks = 0; ks < 4; ++ks) knew[ks] = ld_qkv16(krow + ks * 32 + kb * 8);
       rotate(knew, cs_row);
-      vnew = ld_qkv16<FRONT>(vrow + (lane & 15) * 8);
-      if (hc == 0 && wave == 0) {  // one writer per (request, group): DecoderCacheAppend
-        const int sp = min(newpos / a.S, a.span_stride - 1), pos = newpos - (newpos / a.S) * a.S;  // clamped: never past the span table
+      vnew = ld_qkv16(vrow + (lane & 15) * 8);
+      if (hc == 0 && wave == 0 && (newpos >> lgS) < a.span_stride) {  // one writer per (request, group): DecoderCacheAppend; a token
+        // past the span table is dropped, as kv_append_kernel does (span_cache.hip) -- never written over a cached one
+        const int sp = newpos >> lgS, pos = newpos - (sp << lgS);
         unsigned char* kd = reinterpret_cast<unsigned char*>(const_cast<void*>(ksp[sp])) + ((size_t)grp * a.S + pos) * ROWB;
         unsigned char* vd = reinterpret_cast<unsigned char*>(const_cast<void*>(vsp[sp])) + ((size_t)grp * a.S + pos) * ROWB;
         if (ni == 0) {
@@ -378,19 +438,6 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
     }
   }
 
-  if constexpr (FRONT) {
-    // every read of the qkv row by this workgroup is issued above and consumed below; the workgroup that is the last of its
-    // (request, group) to get here clears the two sync words for the next launch
-    __syncthreads();
-    if (tid == 0) {
-      unsigned* done = a.front_done + ((size_t)b * a.g + grp) * FRONT_SYNC_STRIDE;
-      const unsigned t = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t == (unsigned)(gx * a.nchunks) - 1u) {
-        __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.front_counter + ((size_t)b * a.g + grp) * FRONT_SYNC_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
   const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, l = 0.f, czero = 0.f;
   f32x4_t o[8];  // O^T tile dt: rows (dims) dt*16 + kb*4 + r, column = head ni
@@ -543,6 +590,12 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
       rec[H + 1] = l;
     }
   }
+  if constexpr (FUSED) {
+    if (a.merge_wt) {
+      attn_block_epilogue_wt<FT, HC>(a, lds, flag_lds, b, h0, nh, split, a.counters + ((size_t)b * a.g + grp) * a.nchunks + hc);
+      return;
+    }
+  }
   attn_block_epilogue<FT, HC>(a, lds, flag_lds, b, h0, nh, split);
 }
 
@@ -550,7 +603,7 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
 template <int FT, int MODE, bool FUSED>
 __global__ __launch_bounds__(ATTN_THREADS, 2) void span_attn_ft_mfma_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[FT_MFMA_SMEM_BYTES];
-  span_attn_ft_mfma_body<FT, MODE, FUSED, false>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z, smem);
+  span_attn_ft_mfma_body<FT, MODE, FUSED>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z, smem);
 }
 
 }  // namespace dihip

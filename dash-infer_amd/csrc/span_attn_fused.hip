@@ -24,7 +24,7 @@
 
 namespace dihip {
 
-// cos / sin per (position, dim pair): the table dihip_span_attn_decode_fused and dihip_decode_front read (same arithmetic as
+// cos / sin per (position, dim pair): the table dihip_span_attn_decode_fused reads (same arithmetic as
 // dihip_rope_qk: rope_sincos)
 __global__ void rope_table_kernel(float* tab, const float* inv_freq, int max_pos, int half) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -69,6 +69,16 @@ int dihip_span_attn_decode_fused(void* stream, void* output, const void* qkv, vo
                                  int batch, int n_heads, int n_groups, int head_size, int span_len,
                                  int n_spans_per_request, int max_seq_len, int kv_mode, int dtype, float qk_scale, void* ws,
                                  size_t ws_bytes) {
+  return dihip_span_attn_decode_fused_sync(stream, output, qkv, k_span_array, v_span_array, old_seq_lens_dev, rope_table, batch,
+                                           n_heads, n_groups, head_size, span_len, n_spans_per_request, max_seq_len, kv_mode, dtype,
+                                           qk_scale, ws, ws_bytes, nullptr, 0);
+}
+
+int dihip_span_attn_decode_fused_sync(void* stream, void* output, const void* qkv, void* const* k_span_array,
+                                      void* const* v_span_array, const uint32_t* old_seq_lens_dev, const float* rope_table,
+                                      int batch, int n_heads, int n_groups, int head_size, int span_len,
+                                      int n_spans_per_request, int max_seq_len, int kv_mode, int dtype, float qk_scale, void* ws,
+                                      size_t ws_bytes, void* sync, size_t sync_bytes) {
   DIHIP_REQUIRE(batch >= 0 && n_heads > 0 && n_groups > 0 && n_spans_per_request > 0 && max_seq_len > 0, DIHIP_PARAM_ERROR,
                 "span_attn_decode_fused: invalid parameter");
   DIHIP_REQUIRE(output && qkv && k_span_array && v_span_array && old_seq_lens_dev && rope_table, DIHIP_PARAM_ERROR,
@@ -89,7 +99,7 @@ int dihip_span_attn_decode_fused(void* stream, void* output, const void* qkv, vo
     bool handled = false;
     const int st = span_attn_fused_mfma(stream, output, qkv, k_span_array, v_span_array, old_seq_lens_dev, rope_table, batch,
                                         n_heads, n_groups, span_len, n_spans_per_request, max_seq_len, kv_mode, dtype, qk_scale,
-                                        ws, ws_bytes, &handled);
+                                        ws, ws_bytes, &handled, sync, sync_bytes);
     DIHIP_REQUIRE(handled, DIHIP_MEMORY_ERROR, "span_attn_decode_fused: workspace too small (%zu bytes; dihip_span_attn_fused_workspace_bytes)",
                   ws_bytes);
     return st;

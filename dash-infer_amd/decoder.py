@@ -486,29 +486,9 @@ class DecodeSession:
         # cores, at every batch size.  Quantised caches: the quantising append launch, then the matrix-core decode kernels
         # (dihip_span_attn_decode_fused would issue the same two launches; the explicit pair also has the FRAG32 output).
         self.fused_attention = kv_mode == "none"
-        # batch <= 4, 16-bit cache: RMSNorm + qkv GEMV and Rotary + append + attention of a layer as ONE launch (the attention
-        # workgroups resolve addresses and pull K / V while the GEMV streams, then wait for the qkv row): dihip_decode_front.
-        # Bit-identical to the two calls and measured SLOWER (22.2 us vs 18.8 us per layer, 608 vs 640 tokens/s: the
-        # attention's dependent loads run at loaded latency while the GEMV streams; profiles/r02_attn_merge_fold.txt) --
-        # an experiment switch, DIHIP_DECODER_FRONT=1.  It needs all of its workgroups co-resident (one decode stream per GPU).
-        self.front = (batch <= 4 and kv_mode == "none" and dt == torch.bfloat16 and os.environ.get("DIHIP_DECODER_FRONT", "0") == "1" and cfg.moe is None
-                      and ops.decode_front_supported(model.layers[0].qkv, batch, self.n_loc, self.g_loc, H, max_len, kv_mode, dt))
-        if self.front:
-            self.front_ws = torch.empty(int(lib().dihip_decode_front_workspace_bytes(batch, self.n_loc, self.g_loc, max_len)),
-                                        dtype=torch.uint8, device=device)
-            self.front_sync = torch.zeros(int(lib().dihip_decode_front_sync_bytes(batch, self.g_loc)), dtype=torch.uint8, device=device)
-        # batch 1: the o-projection (+ residual) and RMSNorm + gate / up + SwiGLU of a layer as ONE launch (dihip_decode_mid: the
-        # second GEMV's workgroups fill their weight ring while the first streams, then wait for its completion counters).
-        # Experiment switch DIHIP_DECODER_MID=1.
-        l0m = model.layers[0]
-        self.mid = (batch == 1 and dt == torch.bfloat16 and cfg.moe is None and os.environ.get("DIHIP_DECODER_MID", "0") == "1"
-                    and ops.decode_mid_supported(l0m.o, l0m.gate))
-        if self.mid:
-            self.mid_sync = torch.zeros(int(lib().dihip_decode_mid_sync_bytes()), dtype=torch.uint8, device=device)
-        # weights of the following launches touched by idle CUs during the attention launch: measured SLOWER end to end
-        # (606 vs 627 tokens/s, profiles/r02_attn_merge_fold.txt: the prefetch traffic delays the attention's own,
-        # latency-bound loads more than the warmer GEMVs gain) -- kept as an experiment switch, off by default
-        self.attn_prefetch = batch <= 4 and os.environ.get("DIHIP_DECODER_ATTN_PREFETCH", "0") == "1"
+        # split sequences: the partial records are merged inside the attention launch (arrival tickets in attn_sync, zeroed
+        # once) instead of by a second launch; DIHIP_DECODER_ATTN_MERGE=launch restores the two-launch form (A/B)
+        self.attn_merge_in_launch = os.environ.get("DIHIP_DECODER_ATTN_MERGE", "ticket") != "launch"
         if not self.fused_attention and batch <= 32 and ops.prefers_frag(model.layers[0].o, batch):
             self.attn_frag = True
             self.attn = torch.zeros(ops.act_frag_numel(batch, self.n_loc * H), dtype=dt, device=device)
@@ -575,7 +555,8 @@ class DecodeSession:
         n, g, H, dev = self.n_loc, self.g_loc, self.H, self.h.device
         Lmax = max(len(s) for s in seqs)
         l0, wb, gsz = m.layers[0], m.quant.wbits, m.quant.group
-        need = max(ops.lowp_workspace_bytes(wb, Lmax, p.N, p.K, gsz) for p in (l0.qkv, l0.o, l0.gate, l0.down))
+        # per prompt length: a shorter prompt can take a split-K plan with a larger slab than the longest one
+        need = max(ops.lowp_workspace_bytes(wb, L, p.N, p.K, gsz) for L in {len(s) for s in seqs} for p in (l0.qkv, l0.o, l0.gate, l0.down))
         need = max(need, int(lib().dihip_dense_workspace_bytes(1, m.lm_head.N, m.lm_head.K)))
         sc = ops.Scratch(need, dev)
         logits = torch.empty(self.B, m.vocab_local, dtype=torch.float32, device=dev) if return_logits else None
@@ -613,26 +594,14 @@ class DecodeSession:
         tp_on = self.comm is not None and m.nranks > 1
         nf = self.norm_fuse and not tp_on
         for li, lw in enumerate(m.layers):
-            if self.front:
-                ops.decode_front(self.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, self.kv[li], self.old_lens, self.rope_tab, self.n_loc,
-                                 self.g_loc, self.H, self.max_len, self.scale, self.front_ws, self.front_sync, self.qkv, self.attn)
-                self._proj_residual(self.attn, lw.o, tp_on, frag=False, next_weights=(lw.gate.w, lw.up.w))
-                ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act,
-                                      y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
-                nxt = m.layers[li + 1].qkv if li + 1 < len(m.layers) else m.lm_head
-                self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag, next_weights=(nxt.w,))
-                continue
             if nf and li > 0:
                 ops.prenorm_gemm(self.xn1, lw.qkv, lw.qkv_bias, sc, self.B, x_layout=self.xn1_layout, out=self.qkv)
             else:
                 ops.fused_norm_gemm(self.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sc, out=self.qkv)
-            if self.attn_prefetch and self.kv_mode == "none" and self.fused_attention:
-                # weights of the launches that follow, pulled into the Infinity Cache by the CUs the attention leaves idle
-                nxt = m.layers[li + 1].qkv if li + 1 < len(m.layers) else None
-                ops.span_attn_set_next_prefetch([lw.o.w, lw.o.sz] + ([nxt.w, nxt.sz] if nxt is not None else []))
             if self.fused_attention:
                 ops.span_attn_decode_fused(self.qkv, self.kv[li], self.old_lens, self.rope_tab, self.n_loc, self.g_loc, self.H,
-                                           self.max_len, self.scale, self.attn_ws, out=self.attn)
+                                           self.max_len, self.scale, self.attn_ws, out=self.attn,
+                                           sync=self.attn_sync if self.attn_merge_in_launch else None)
             else:
                 ops.rope_kv_append(self.kv[li], self.q, self.qkv, self.old_lens, self.inv_freq, self.n_loc, self.g_loc, self.H)
                 ops.span_attn_decode(self.q, self.kv[li], self.new_lens, self.n_loc, self.g_loc, self.H, self.max_len,
@@ -655,12 +624,9 @@ class DecodeSession:
                 else:
                     self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag)  # lm_head applies the final norm itself
                 continue
-            if self.mid and not tp_on:
-                ops.decode_mid(self.attn, lw.o, self.h, self.h, lw.ln2, cfg.eps, lw.gate, lw.up, self.act, self.mid_sync)
-            else:
-                self._proj_residual(self.attn, lw.o, tp_on, frag=self.attn_frag, next_weights=(lw.gate.w, lw.up.w))
-                ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act,
-                                      y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
+            self._proj_residual(self.attn, lw.o, tp_on, frag=self.attn_frag, next_weights=(lw.gate.w, lw.up.w))
+            ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act,
+                                  y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
             nxt = m.layers[li + 1].qkv if li + 1 < len(m.layers) else m.lm_head
             self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag, next_weights=(nxt.w,))
         ops.lm_head(self.h, m.final_norm, cfg.eps, m.lm_head, sc, out=self.logits)

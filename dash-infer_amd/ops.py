@@ -382,51 +382,22 @@ def span_attn_fused_workspace(batch, n, g, H, max_len):
     return int(lib().dihip_span_attn_fused_workspace_bytes(batch, n, g, H, max_len))
 
 
-def span_attn_decode_fused(qkv, kv, old_lens_dev, rope_tab, n, g, H, max_len, scale, ws, out=None):
-    """Rotary + cache append + paged decode attention of one step from the fused qkv rows."""
+def span_attn_decode_fused(qkv, kv, old_lens_dev, rope_tab, n, g, H, max_len, scale, ws, out=None, sync=None):
+    """Rotary + cache append + paged decode attention of one step from the fused qkv rows.  sync (zeroed once,
+    dihip_span_attn_sync_bytes): the split partials are merged inside the launch instead of by a second one."""
     B = qkv.shape[0]
     out = out if out is not None else torch.empty(B, n * H, dtype=qkv.dtype, device=qkv.device)
     pool = kv.pool
+    if sync is not None:
+        check(lib().dihip_span_attn_decode_fused_sync(cur_stream(), ptr(out), ptr(qkv), ptr(kv.k_ptrs), ptr(kv.v_ptrs), ptr(old_lens_dev),
+                                                      ptr(rope_tab), B, n, g, H, pool.S, kv.max_spans, max_len, capi.KV[pool.mode],
+                                                      dt_code(qkv), float(scale), ptr(ws), ws.numel(), ptr(sync), sync.numel()),
+              "dihip_span_attn_decode_fused_sync")
+        return out
     check(lib().dihip_span_attn_decode_fused(cur_stream(), ptr(out), ptr(qkv), ptr(kv.k_ptrs), ptr(kv.v_ptrs), ptr(old_lens_dev),
                                              ptr(rope_tab), B, n, g, H, pool.S, kv.max_spans, max_len, capi.KV[pool.mode],
                                              dt_code(qkv), float(scale), ptr(ws), ws.numel()), "dihip_span_attn_decode_fused")
     return out
-
-
-def decode_front_supported(pw, M, n, g, H, max_len, mode, dtype):
-    return bool(lib().dihip_decode_front_supported(pw.wbits, M, pw.K, pw.group, n, g, H, max_len, capi.KV[mode], dt_code(dtype)))
-
-
-def decode_front(h, gamma, eps, pw, bias, kv, old_lens_dev, rope_tab, n, g, H, max_len, scale, ws, sync, qkv_out, attn_out):
-    """RMSNorm + qkv GEMV(+bias) + Rotary + cache append + paged decode attention of one layer: one launch + the split merge."""
-    M = h.shape[0]
-    pool = kv.pool
-    check(lib().dihip_decode_front(cur_stream(), pw.wbits, ptr(h), ptr(gamma), float(eps), ptr(pw.w), ptr(pw.sz), ptr(bias), ptr(qkv_out),
-                                   ptr(attn_out), M, pw.K, pw.group, ptr(kv.k_ptrs), ptr(kv.v_ptrs), ptr(old_lens_dev), ptr(rope_tab), n, g, H,
-                                   pool.S, kv.max_spans, max_len, capi.KV[pool.mode], dt_code(qkv_out), float(scale), ptr(ws), ws.numel(),
-                                   ptr(sync), sync.numel()), "dihip_decode_front")
-    return attn_out
-
-
-def decode_mid_supported(po, pg):
-    return bool(lib().dihip_decode_mid_supported(po.wbits, po.N, po.K, pg.N, po.group))
-
-
-def decode_mid(attn, po, h_res, h_out, gamma, eps, pg, pu, act, sync):
-    """o-projection (+ residual into the f32 hidden row) and RMSNorm + gate / up GEMV + SwiGLU as ONE launch (M = 1)."""
-    check(lib().dihip_decode_mid(cur_stream(), po.wbits, ptr(attn), ptr(po.w), ptr(po.sz), ptr(h_res), ptr(h_out), ptr(gamma), float(eps),
-                                 ptr(pg.w), ptr(pg.sz), ptr(pu.w), ptr(pu.sz), ptr(act), po.N, po.K, pg.N, po.group, ptr(sync),
-                                 sync.numel(), dt_code(attn)), "dihip_decode_mid")
-    return act
-
-
-def span_attn_set_next_prefetch(tensors):
-    """Up to 4 device tensors whose lines the next decode-step attention launch pulls into the Infinity Cache."""
-    tensors = [t for t in tensors if t is not None][:4]
-    n = len(tensors)
-    ptrs = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in tensors])
-    sizes = (C.c_size_t * max(n, 1))(*[t.numel() * t.element_size() for t in tensors])
-    check(lib().dihip_span_attn_set_next_prefetch(ptrs, sizes, n), "dihip_span_attn_set_next_prefetch")
 
 
 def span_attn_merge_partials(partials, batch, n, nsplits, dtype=torch.bfloat16):

@@ -305,55 +305,23 @@ int dihip_span_attn_decode_fused(void* stream, void* output, const void* qkv, vo
                                  const float* rope_table, int batch, int n_heads, int n_groups,
                                  int head_size, int span_len, int n_spans_per_request, int max_seq_len,
                                  int kv_mode, int dtype, float qk_scale, void* ws, size_t ws_bytes);
+/* The same with the split partials merged INSIDE the launch (16-bit cache, split sequences): `sync` = at least
+ * dihip_span_attn_sync_bytes(batch, n_heads) bytes that the caller zeroes ONCE; every call leaves them zeroed (arrival
+ * tickets: the workgroup that arrives last for a (request, KV group) merges all split records and writes the output --
+ * records stored write-through, read past the L1, no fences).  Bit-identical output; one launch instead of two.
+ * sync = NULL (or the quantised caches): as dihip_span_attn_decode_fused.  Calls sharing one `sync` buffer must be
+ * ordered on one stream.  Replaces the reference's reduce kernel (span_attention.hpp:145-211).  */
+int dihip_span_attn_decode_fused_sync(void* stream, void* output, const void* qkv, void* const* k_span_array,
+                                      void* const* v_span_array, const uint32_t* old_seq_lens_dev,
+                                      const float* rope_table, int batch, int n_heads, int n_groups,
+                                      int head_size, int span_len, int n_spans_per_request, int max_seq_len,
+                                      int kv_mode, int dtype, float qk_scale, void* ws, size_t ws_bytes,
+                                      void* sync, size_t sync_bytes);
 
-/* 3e. Two consecutive GEMVs of a decode layer in ONE launch (experiment; csrc/decode_mid.hip): the o-projection with its
- * residual  h_out = h_res + attn . Wo  and  act = SiLU(norm(h_out) . Wgate) * (norm(h_out) . Wup).  Replaces
- * dihip_fused_gemm_addto followed by dihip_fused_norm_swiglu at M = 1, bit-identically: the second GEMV's workgroups ramp and
- * fill their weight ring while the first streams, then wait for its completion counters and read the row coherently.
- *   attn FT [1, k_attn]; h_res / h_out f32 [1, hidden] (in place allowed); act FT [1, inter]
- *   sync: >= dihip_decode_mid_sync_bytes(), zero-initialised ONCE (every launch leaves it zeroed)
- * dihip_decode_mid_supported: both shapes on the decode GEMV with at most one workgroup per CU each. */
-size_t dihip_decode_mid_sync_bytes(void);
-int dihip_decode_mid_supported(int wbits, int hidden, int k_attn, int inter, int group_size);
-int dihip_decode_mid(void* stream, int wbits, const void* attn, const void* wo_packed, const void* wo_sz,
-                     const float* h_res, float* h_out, const void* gamma, float eps, const void* wg_packed,
-                     const void* wg_sz, const void* wu_packed, const void* wu_sz, void* act, int hidden,
-                     int k_attn, int inter, int group_size, void* sync, size_t sync_bytes, int dtype);
-
-/* Cache prefetch riding on the NEXT decode-step attention launch of the calling thread (3b with the 16-bit cache):
- * the launch gets extra workgroups -- on the CUs the attention leaves idle -- that touch every 128-byte line of up to 4
- * device buffers, pulling them into the 256 MB Infinity Cache while HBM is otherwise idle.  Meant for the weights of
- * the launches that follow (o-projection, the next layer's qkv): those GEMVs are bound by first-byte latency.  The
- * list is consumed by that launch (kernel arguments: captured into a hipGraph like any other); count = 0 clears it.
- * Purely a performance hint: results do not change.  */
-int dihip_span_attn_set_next_prefetch(const void* const* ptrs, const size_t* bytes, int count);
 /* merge of the per-split partial records  f32 [batch * n_heads][nsplits][132] = { o[128] (unnormalised), m, l, pad }  of a
- * decode attention launch into the FT [batch, n_heads * 128] output (the second launch of 3b / 3d) */
+ * decode attention launch into the FT [batch, n_heads * 128] output (the second launch of 3b) */
 int dihip_span_attn_merge_partials(void* stream, void* output, const float* partials, int batch, int n_heads,
                                    int nsplits, int dtype);
-/* 3d. The front half of a decode layer in ONE launch (+ the split merge): RMSNorm + qkv GEMV (+bias) and Rotary + cache
- * append + paged attention -- replaces dihip_fused_norm_gemm + dihip_span_attn_decode_fused, i.e. the reference's
- * Gemm[A16W8|A16W4](qkv) + Rotary + DecOptMQA operators of one layer (qwen_v15.py:218-262, span_attn_op.cpp:90-169).
- * The attention workgroups ride in the GEMV's launch: they resolve lengths / span pointers and pull their K / V tiles while
- * the GEMV workgroups stream the weights, wait for the qkv row on a per-(request, KV group) counter and finish.  Results
- * are bit-identical to the two calls it replaces (qkv row, span bytes, attention output).
- *   h [M, K] f32 hidden stream, gamma FT [K]; w / sz packed qkv weight [(n + 2g) * 128 columns]; bias FT or NULL
- *   qkv (out) FT [M, (n + 2g) * 128]; attn_out FT [M, n * 128]
- *   ws >= dihip_decode_front_workspace_bytes (split partials); sync >= dihip_decode_front_sync_bytes, zeroed ONCE by the
- *   caller (the launch leaves it zero)
- * Covered (dihip_decode_front_supported == 1): M <= 4, bf16, 16-bit cache, head size 128, K a multiple of the k-tile, and a
- * grid that is resident at once; otherwise the call returns DIHIP_PARAM_ERROR and the caller uses the two calls.  */
-size_t dihip_decode_front_sync_bytes(int batch, int n_groups);
-size_t dihip_decode_front_workspace_bytes(int batch, int n_heads, int n_groups, int max_seq_len);
-int dihip_decode_front_supported(int wbits, int M, int K, int group_size, int n_heads, int n_groups, int head_size,
-                                 int max_seq_len, int kv_mode, int dtype);
-int dihip_decode_front(void* stream, int wbits, const float* h, const void* gamma, float eps, const void* w_packed,
-                       const void* sz_packed, const void* bias, void* qkv, void* attn_out, int M, int K,
-                       int group_size, void* const* k_span_array, void* const* v_span_array,
-                       const uint32_t* old_seq_lens_dev, const float* rope_table, int n_heads, int n_groups,
-                       int head_size, int span_len, int n_spans_per_request, int max_seq_len, int kv_mode,
-                       int dtype, float qk_scale, void* ws, size_t ws_bytes, void* sync, size_t sync_bytes);
-
 /* =============================================================================================
  * 4. Prefill attention (replaces xformer_prefill_attention,
  *    csrc/core/kernel/cuda/xformer_mha/xformer_mha.h:26-41): causal softmax(alpha Q K^T) V, GQA.

@@ -36,10 +36,11 @@ def decode_attention(q, k, v, alpha):
     return out.astype(np.float32)
 
 
-def prefill_attention(q, k, v, alpha, causal=True, dtype=np.float64):
+def prefill_attention(q, k, v, alpha, causal=True, dtype=np.float64, threads=1):
     """q [Lq,n,H]; k,v [Lk,g,H] -> [Lq,n,H] float32.  dtype: accumulation type of the two contractions and the softmax
     (float64 by default; float32 = what cblas_sgemm + the f32 softmax of the x86 path carry, used by the full-depth
-    comparisons where a float64 pass over 28 layers x 2k tokens would take minutes)."""
+    comparisons where a float64 pass over 28 layers x 2k tokens would take minutes).  threads > 1: heads on a thread pool
+    (BLAS held to one thread per call meanwhile): the same per-head arithmetic up to the summation order of BLAS's blocking."""
     q = np.asarray(q, dtype)
     k = np.asarray(k, dtype)
     v = np.asarray(v, dtype)
@@ -51,10 +52,22 @@ def prefill_attention(q, k, v, alpha, causal=True, dtype=np.float64):
     mask = None
     if causal:
         mask = np.arange(Lk)[None, :] > (np.arange(Lq)[:, None] + off)
-    for h in range(n):
+    def head(h):
         grp = h // hpg
         s = dtype(alpha) * (q[:, h, :] @ k[:, grp, :].T)
         if mask is not None:
             s[mask] = -np.inf
         out[:, h, :] = softmax_rows(s, dtype) @ v[:, grp, :]
+    if threads > 1 and n > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            from threadpoolctl import threadpool_limits
+        except ImportError:  # plain loop: concurrent multi-threaded BLAS calls would only fight over one pool
+            threadpool_limits = None
+        if threadpool_limits is not None:
+            with threadpool_limits(limits=1, user_api="blas"), ThreadPoolExecutor(min(threads, n)) as ex:
+                list(ex.map(head, range(n)))
+            return out.astype(np.float32)
+    for h in range(n):
+        head(h)
     return out.astype(np.float32)

@@ -71,6 +71,7 @@ class DecoderOracle:
         self.cache = None
         self.rounding = rounding
         self.acc = np.float64           # accumulation type of the matmuls / attention (np.float32: the full-depth comparisons)
+        self.threads = 1                # thread pool width of the per-head attention loop (full-depth comparisons)
         self._wcache = {} if cache_weights else None  # id(q) -> dequantised f64 [K, N] (large models: dequantise once)
         self._lm64 = None
 
@@ -237,7 +238,7 @@ class DecoderOracle:
                     vs.append(self.kv_store(v[t]))
                 # the context phase attends over the fresh (unquantised) K / V of the prompt (span_attn_op_cuda.cpp:
                 # runContext: xformer_prefill_attention on the qkv rows; the cache copy is a side output)
-                attn = self._attn_out(attention.prefill_attention(q, k, v, 1.0 / np.sqrt(H), True, dtype=self.acc))
+                attn = self._attn_out(attention.prefill_attention(q, k, v, 1.0 / np.sqrt(H), True, dtype=self.acc, threads=self.threads))
                 h = self._residual(h, self.linear(self._src(attn.reshape(L, n * H)), lw["o"], "f32"))
                 h = self._mlp(h, lw)
             out.append(self._logits(h[-1:])[0])
@@ -269,7 +270,7 @@ class DecoderOracle:
         assert self.kv_mode == "none"
         L = h.shape[0]
         q, k, v = self._context_qkv(h, lw, L, W)
-        attn = self._attn_out(attention.prefill_attention(q, k, v, 1.0 / np.sqrt(self.H), True, dtype=self.acc))
+        attn = self._attn_out(attention.prefill_attention(q, k, v, 1.0 / np.sqrt(self.H), True, dtype=self.acc, threads=self.threads))
         h = self._residual(h, self.linear(self._src(attn.reshape(L, self.n * self.H)), lw["o"], "f32", W=(W or {}).get("o")))
         return self._mlp(h, lw, W)
 
@@ -283,6 +284,8 @@ def teacher_forced_logits(oracles, layers, seq, n_last, progress=None, threads=1
     needs one layer's matrices in host memory at a time.  `layers`: a sequence of layer dicts (may build each on access)."""
     hs = [o.embed[np.asarray(seq)].astype(np.float32) for o in oracles]
     o0 = oracles[0]
+    for o in oracles:
+        o.threads = max(o.threads, threads)
     for li in range(len(layers)):
         lw = layers[li]
         mats = {}

@@ -311,11 +311,23 @@ def test_fused_rope_append_attention_matches_separate_ops(ops, n, g, S, lens, mo
     tab = ops.rope_table(inv_d, max_len + 3, H)
     ws2 = torch.empty(ops.span_attn_fused_workspace(B, n, g, H, max_len), dtype=torch.uint8, device="cuda")
     ws2.fill_(0x7F)
-    # the cache-prefetch hint rides on this launch (extra workgroups touching two buffers): results must not change
-    junk = torch.ones(3 * 1024 * 1024 + 40, dtype=torch.uint8, device="cuda")
-    ops.span_attn_set_next_prefetch([junk, tab])
     out = ops.span_attn_decode_fused(dev(qkv, ft), kv2, old, tab, n, g, H, max_len, scale, ws2)
     torch.cuda.synchronize()
+    # the same call with the split partials merged INSIDE the launch (dihip_span_attn_decode_fused_sync: write-through records,
+    # arrival tickets): bit-identical output and spans, ticket words left at zero -- three times in a row on one sync buffer
+    pool3, kv3, _, _ = build_batch(ops, np.random.default_rng(n + S + len(mode)), lens, n, g, H, S, mode, ft, extra_tokens=1)
+    tickets = torch.zeros(int(ops.lib().dihip_span_attn_sync_bytes(B, n)), dtype=torch.uint8, device="cuda")
+    for rep in range(3):
+        ws3 = torch.empty_like(ws2)
+        ws3.fill_(0x7F if rep == 0 else 0xC3)
+        out3 = ops.span_attn_decode_fused(dev(qkv, ft), kv3, old, tab, n, g, H, max_len, scale, ws3, sync=tickets)
+        torch.cuda.synchronize()
+        assert torch.equal(out3, out), f"in-launch merge differs from the two-launch form (repetition {rep})"
+        assert int(tickets.view(torch.int32).abs().sum()) == 0, "ticket words must be zero after the launch"
+    for b in range(B):
+        for i in range(len(kv2.k_idx[b])):
+            assert torch.equal(pool3.span_view(kv3.k_idx[b][i]), pool2.span_view(kv2.k_idx[b][i])), f"K span {b}/{i} (in-launch merge)"
+            assert torch.equal(pool3.span_view(kv3.v_idx[b][i]), pool2.span_view(kv2.v_idx[b][i])), f"V span {b}/{i} (in-launch merge)"
     for b in range(B):
         for i in range(len(kv.k_idx[b])):
             assert torch.equal(pool.span_view(kv.k_idx[b][i]), pool2.span_view(kv2.k_idx[b][i])), f"K span {b}/{i}"
@@ -406,55 +418,3 @@ def test_span_attention_long_context(ops, L, mode):
     ref = cbind.span_attn_decode(q[0], [kb[i] for i in range(nspans)], [vb[i] for i in range(nspans)], L, n, g, H, S, mode, ft, scale)
     # averaging 10^5 random rows leaves outputs of 1e-2 ... 2e-1: the bound is relative to the output scale
     np.testing.assert_allclose(out[0], ref, rtol=2e-2, atol=1e-2 * float(np.abs(ref).max()))
-
-
-# ------------------------------------------- front half of a decode layer in one launch (3d) -----
-@pytest.mark.gpu
-@pytest.mark.parametrize("wbits,group", [(4, 128), (8, -1)])
-@pytest.mark.parametrize("n,g,S,lens,K", [(28, 4, 128, [2048], 3584), (28, 4, 128, [2111], 3584), (14, 2, 32, [0, 1, 31, 500], 896),
-                                          (8, 8, 16, [77, 300], 1024), (4, 1, 64, [1000, 5, 64], 1024), (3, 1, 16, [5, 0], 384)])
-def test_decode_front_equals_the_two_calls_it_replaces(ops, n, g, S, lens, K, wbits, group):
-    """dihip_decode_front (RMSNorm + qkv GEMV + Rotary + append + attention in one launch: attention workgroups wait for the
-    GEMV workgroups of the same launch) == dihip_fused_norm_gemm + dihip_span_attn_decode_fused, BIT for bit: qkv row, span
-    bytes, attention output; repeated launches on the same sync words (they must be left zero); and both agree with the
-    oracle through the separate-call tests above."""
-    from oracle import glue, quant
-    rng = np.random.default_rng(n + S + len(lens) + wbits)
-    H, ft, mode = 128, "bf16", "none"
-    B = len(lens)
-    N = (n + 2 * g) * H
-    pool, kv, _, _ = build_batch(ops, rng, lens, n, g, H, S, mode, ft, extra_tokens=3)
-    pool2, kv2, _, _ = build_batch(ops, np.random.default_rng(n + S + len(lens) + wbits), lens, n, g, H, S, mode, ft, extra_tokens=3)
-    W = bf16_round(rng.normal(0, 0.05, (K, N)).astype(np.float32))
-    qw, sw, zw = (quant.iq_quantize_a16w8 if wbits == 8 else quant.iq_quantize_a16w4)(W, group, ft)
-    pw = ops.pack_lowp(torch.from_numpy(qw).cuda(), dev(sw, ft), dev(zw, ft), group, wbits)
-    bias = dev(bf16_round(rng.normal(0, 0.1, N).astype(np.float32)), ft)
-    gamma = dev(bf16_round(1 + rng.normal(0, 0.1, K).astype(np.float32)), ft)
-    inv_d = torch.from_numpy(glue.rope_inv_freq(H, 1000000.0)).cuda()
-    max_len = max(lens) + 4
-    tab = ops.rope_table(inv_d, max_len + 3, H)
-    scale = 1.0 / np.sqrt(H)
-    assert ops.decode_front_supported(pw, B, n, g, H, max_len, mode, torch.bfloat16)
-    sc = ops.Scratch(ops.lowp_workspace_bytes(wbits, B, N, K, group))
-    ws = torch.empty(ops.span_attn_fused_workspace(B, n, g, H, max_len), dtype=torch.uint8, device="cuda")
-    ws2 = torch.empty(int(ops.lib().dihip_decode_front_workspace_bytes(B, n, g, max_len)), dtype=torch.uint8, device="cuda")
-    sync = torch.zeros(int(ops.lib().dihip_decode_front_sync_bytes(B, g)), dtype=torch.uint8, device="cuda")
-    old = torch.tensor(lens, dtype=torch.int32, device="cuda")
-    old2 = old.clone()
-    for step in range(3):
-        h = torch.from_numpy(rng.normal(0, 1, (B, K)).astype(np.float32)).cuda()
-        qkv_ref = ops.fused_norm_gemm(h, gamma, 1e-6, pw, bias, sc)
-        out_ref = ops.span_attn_decode_fused(qkv_ref, kv, old, tab, n, g, H, max_len, scale, ws)
-        qkv = torch.full((B, N), float("nan"), dtype=torch.bfloat16, device="cuda")
-        out = torch.full((B, n * H), float("nan"), dtype=torch.bfloat16, device="cuda")
-        ops.decode_front(h, gamma, 1e-6, pw, bias, kv2, old2, tab, n, g, H, max_len, scale, ws2, sync, qkv, out)
-        torch.cuda.synchronize()
-        assert torch.equal(qkv.view(torch.int16), qkv_ref.view(torch.int16)), f"step {step}: qkv row differs"
-        assert torch.equal(out.view(torch.int16), out_ref.view(torch.int16)), f"step {step}: attention output differs"
-        assert int(sync.view(torch.int32).abs().sum()) == 0, "the launch must leave its sync words zero"
-        for b in range(B):
-            for i in range(len(kv.k_idx[b])):
-                assert torch.equal(pool.span_view(kv.k_idx[b][i]), pool2.span_view(kv2.k_idx[b][i])), f"K span {b}/{i}"
-                assert torch.equal(pool.span_view(kv.v_idx[b][i]), pool2.span_view(kv2.v_idx[b][i])), f"V span {b}/{i}"
-        old += 1
-        old2 += 1

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static check of the hand-counted `s_waitcnt vmcnt(N)` code (gemv_stream_kernel.hpp, decode_front.hip).
+"""Static check of the hand-counted `s_waitcnt vmcnt(N)` code (gemv_stream_kernel.hpp).
 
 The streaming GEMV issues its loads from inline asm and waits with literal vmcnt values; the compiler does
 not know the destination registers are in flight, so nothing stops it from reading or copying one of them
@@ -27,10 +27,8 @@ import sys
 import tempfile
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-# kernels that run one of two already audited bodies by block index: the compiler joins the bodies through a scalar flag, the
-# path-insensitive walk then follows paths from one body into the other that cannot execute.  Their bodies are audited as
-# stand-alone kernels (decode_mid.hip: *_audit_kernel; decode_front's GEMV body: the gemv_stream_kernel instantiations).
-FUSED_KERNELS = ("decode_mid_kernel", "decode_mid_seq_kernel")
+# kernels to skip (none today; the fused two-body launches of round 2, which the path-insensitive walk could not follow, are gone)
+FUSED_KERNELS = ()
 REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
 WAIT = re.compile(r"vmcnt\((\d+)\)")
 
