@@ -402,6 +402,25 @@ def main():
     distinct_experts = sess.count_distinct_experts() if cfg.moe is not None else None
     t_build = time.time() - t_build
 
+    # The one-shot peer-to-peer all-reduce has never run across xGMI on the box it was developed on: before it is timed,
+    # two whole decode steps run eagerly with EVERY peer-to-peer sum checked against RCCL's on a copy (same addends, real
+    # load, all message sizes of the step).  Any rank seeing a difference beyond summation-order ulps sends ALL ranks to
+    # RCCL, and the JSON line says so -- a wrong sum can cost a run its fast path, never its correctness.
+    if world > 1 and isinstance(comm, decoder.P2PComm):
+        comm.start_verification()
+        for _ in range(2):
+            sess.step()
+        torch.cuda.synchronize()
+        ok, summary = comm.finish_verification(torch.device("cuda", local_rank))
+        if ok:
+            comm.backend = f"{comm.backend} (verified against rccl: {summary})"
+        else:
+            base = comm.rccl
+            base.backend = f"{base.backend} (p2p-oneshot FAILED verification against rccl: {summary})"
+            print(f"[rank {rank}] {base.backend}", file=sys.stderr)
+            sess.comm = comm = base
+        sess.set_state(ids, [SEQ_LEN] * batch)
+
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -439,6 +458,49 @@ def main():
         elapsed = float(t.item())
     last_ids = sess.ids.tolist()
 
+    # share of the step spent in the tensor-parallel all-reduces: the step's collectives alone (2 per layer on the hidden rows,
+    # same backend, same message), captured into a graph and replayed between events -- every rank takes part
+    ar_info = None
+    if world > 1:
+        try:
+            n_ar = 2 * len(model.layers)
+            buf = torch.zeros_like(sess.h)
+            def ar_only():
+                for _ in range(n_ar):
+                    comm.allreduce_(buf)
+            s_ar = torch.cuda.Stream()
+            s_ar.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s_ar):
+                ar_only()
+            torch.cuda.current_stream().wait_stream(s_ar)
+            barrier()
+            if graph_on:
+                g_ar = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_ar):
+                    ar_only()
+                run_ar = g_ar.replay
+            else:
+                run_ar = ar_only
+            run_ar()
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                run_ar()
+            e1.record()
+            barrier()
+            ar_ms = e0.elapsed_time(e1) / 5
+            import torch.distributed as dist
+            t_ar = torch.tensor([ar_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t_ar, op=dist.ReduceOp.MAX)
+            ar_ms = float(t_ar.item())
+            ar_info = {"count_per_step": n_ar, "bytes_each": int(buf.numel() * buf.element_size()),
+                       "us_per_step": round(ar_ms * 1e3, 1), "us_each": round(ar_ms * 1e3 / n_ar, 2),
+                       "share_of_step": round(ar_ms / (elapsed / args.steps * 1e3), 4),
+                       "note": "the step's hidden-row all-reduces alone, back to back (max over ranks); inside the step they also wait for the slowest rank's GEMV"}
+        except Exception as e:  # noqa: BLE001 -- never lose the headline number to a diagnostic
+            ar_info = {"error": repr(e)}
+
     ms_per_step = elapsed / args.steps * 1e3
     tokens_per_s = batch * args.steps / elapsed
     # whole-step algorithmic bytes: this rank's packed weights + scales/zeros + lm_head + KV read
@@ -467,6 +529,8 @@ def main():
                      "frac_of_peak": round(step_gbs / HBM_PEAK_GBS, 4)},
         "comm_backend": (comm.backend if comm is not None else None),  # which all-reduce ran: never a silent substitute
         "ar_overlap": bool(getattr(sess, "ar_overlap", False)),        # all-reduce on a side stream + weight prefetch beside it
+        "allreduce": ar_info,                                          # TP > 1: time of the step's all-reduces alone and their share
+        "lm_head_split": getattr(model, "lm_split", "vocab") if world > 1 else None,
         "build_s": round(t_build, 1),
         "last_ids": last_ids[:4],
         **({"distinct_routed_experts_per_layer": distinct_experts} if distinct_experts is not None else {}),

@@ -20,10 +20,18 @@
 // The epoch lives in device memory and is advanced by the last workgroup of each launch, so a captured launch replays
 // correctly (nothing in the kernel arguments changes from call to call).
 //
+// The receive buffer (slots + flags) is FINE-GRAINED / uncached device memory (hipExtMallocWithFlags, as RCCL allocates its
+// own flag and LL buffers): peers write it over xGMI while the owner's kernel polls and reads it in the same launch, and
+// coarse-grained memory (plain hipMalloc) is only coherent at kernel boundaries -- the owner's L2 may keep a line of
+// epoch e - 2 whatever scope the load names.  An allocation that cannot be made that way is an error, never a
+// silent coarse-grained substitute.
+//
 // Bounded: messages up to P2P_MAX_BYTES; a poll that sees no progress for tens of seconds traps (a lost peer must not hang the
-// GPU silently).  Developed on a one-GPU box: ranks as host threads on separate streams exercise the protocol
-// (tests/test_gpu_tp_loopback.py); it has NOT run across xGMI yet -- bench.py selects it only with DIHIP_TP_ALLREDUCE=p2p.
+// GPU silently).  Developed on a one-GPU box: ranks as host threads / processes on one GPU exercise the protocol
+// (tests/test_gpu_tp_loopback.py, test_gpu_p2p_processes.py); it has NOT run across xGMI yet -- bench.py therefore verifies
+// every all-reduce of its warm-up steps against RCCL before it times this path (decoder.P2PComm.verify).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "device_utils.h"
@@ -166,8 +174,21 @@ size_t dihip_p2p_ar_max_bytes(void) { return P2P_MAX_BYTES; }
 int dihip_p2p_ar_alloc(void** buf) {
   DIHIP_REQUIRE(buf, DIHIP_PARAM_ERROR, "p2p_ar_alloc: null pointer");
   void* p = nullptr;
-  hipError_t e = hipMalloc(&p, P2P_BUFFER_BYTES);  // its own allocation: an IPC handle names a whole allocation
-  DIHIP_REQUIRE(e == hipSuccess, DIHIP_MEMORY_ERROR, "p2p_ar_alloc: hipMalloc: %s", hipGetErrorString(e));
+  // its own allocation (an IPC handle names a whole allocation), uncached: never held in this GPU's L2, so a peer's write
+  // is what the next load returns.  Fine-grained is the fallback spelling of the same property on runtimes without the
+  // uncached flag.  DIHIP_P2P_COARSE=1 (diagnostics on a one-GPU box only) takes plain hipMalloc.
+  hipError_t e = hipErrorUnknown;
+  const char* coarse = getenv("DIHIP_P2P_COARSE");
+  if (coarse && coarse[0] == '1') {
+    e = hipMalloc(&p, P2P_BUFFER_BYTES);
+  } else {
+    e = hipExtMallocWithFlags(&p, P2P_BUFFER_BYTES, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      e = hipExtMallocWithFlags(&p, P2P_BUFFER_BYTES, hipDeviceMallocFinegrained);
+    }
+  }
+  DIHIP_REQUIRE(e == hipSuccess, DIHIP_MEMORY_ERROR, "p2p_ar_alloc: uncached / fine-grained device allocation failed: %s", hipGetErrorString(e));
   e = hipMemset(p, 0, P2P_BUFFER_BYTES);
   DIHIP_REQUIRE(e == hipSuccess, DIHIP_RUNTIME_ERROR, "p2p_ar_alloc: hipMemset: %s", hipGetErrorString(e));
   *buf = p;

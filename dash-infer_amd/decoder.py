@@ -136,7 +136,7 @@ def _pack(q, s, z, spec, rows=None, cols=None, n_full=None):
 
 
 def build_random_model(cfg: ModelConfig, spec: QuantSpec, seed=1234, device="cuda", rank=0, nranks=1,
-                       dtype=torch.bfloat16, layers: Optional[int] = None, keep_fp=False):
+                       dtype=torch.bfloat16, layers: Optional[int] = None, keep_fp=False, lm_head_split=None):
     """Synthetic weights per SURVEY 8(d): W ~ N(0, 0.02^2) in FT with
     Generator(seed + 1000*layer + idx), InstantQuant-quantised on the FULL matrix (as the reference
     converter does before the TP split), then sliced for this rank and packed."""
@@ -216,18 +216,35 @@ def build_random_model(cfg: ModelConfig, spec: QuantSpec, seed=1234, device="cud
         del w_qkv, w_o, w_gate, w_up, w_down, qs
     embed = rand((cfg.vocab, cfg.hidden), seed + 900001)
     final_norm = (1.0 + rand((cfg.hidden,), seed + 900002, 0.1).float()).to(dtype)
-    # lm_head stays unquantised FT (qwen_v15.py:153-164); vocabulary-parallel slice for TP
+    # lm_head stays unquantised FT (qwen_v15.py:153-164).  Under TP, two splits (lm_head_split, default $DIHIP_TP_LMHEAD or "vocab"):
+    #   "vocab"  vocabulary-parallel slice + arg-max pair all-gather: 1/nranks of the logits per rank, 8 bytes per request on the
+    #            wire -- right for greedy decoding, but no rank ever holds the full logits row;
+    #   "k"      the reference's own graph (model_base.py:690-703: Gemm with attribute splitk, lm_head.weight HSPLIT, then
+    #            AllReduce "all_reduce_lmhead"; gemm_op.cpp:95-98: lda = k * nranks): every rank multiplies its K slice of the
+    #            normalised row with its row block of the weight, the partial logits are summed by an all-reduce, and every rank
+    #            holds the FULL f32 logits row (top-k / top-p sampling, logprobs, the logits parity check under TP).
+    lm_split = (lm_head_split or os.environ.get("DIHIP_TP_LMHEAD", "vocab")) if nranks > 1 else "vocab"
+    assert lm_split in ("vocab", "k"), f"unknown lm_head split {lm_split!r}"
     vloc = cfg.vocab // nranks
     assert cfg.vocab % nranks == 0
     w_lm = rand((cfg.hidden, cfg.vocab), seed + 900003)
     if fp is not None:
         fp["embed"], fp["final_norm"], fp["lm_head"] = embed, final_norm, w_lm
-    lm = ops.pack_dense(w_lm[:, rank * vloc:(rank + 1) * vloc].contiguous())
+    if lm_split == "k":
+        assert cfg.hidden % (32 * nranks) == 0, "K-split lm_head: hidden must split into whole 32-row k-tiles per rank"
+        kloc = cfg.hidden // nranks
+        lm = ops.pack_dense(w_lm[rank * kloc:(rank + 1) * kloc, :].contiguous())
+    else:
+        lm = ops.pack_dense(w_lm[:, rank * vloc:(rank + 1) * vloc].contiguous())
     wbytes += lm.nbytes
     del w_lm
     torch.cuda.synchronize()
-    mw = ModelWeights(cfg, spec, rank, nranks, me, embed, out_layers, final_norm, lm, rank * vloc, vloc, wbytes)
+    if lm_split == "k":
+        mw = ModelWeights(cfg, spec, rank, nranks, me, embed, out_layers, final_norm, lm, 0, cfg.vocab, wbytes)
+    else:
+        mw = ModelWeights(cfg, spec, rank, nranks, me, embed, out_layers, final_norm, lm, rank * vloc, vloc, wbytes)
     mw.fp = fp
+    mw.lm_split = lm_split
     return mw
 
 
@@ -359,13 +376,42 @@ class P2PComm:
                 check(l.dihip_p2p_ar_set_timeout(self.handle, 1 << 24, 1), "dihip_p2p_ar_set_timeout")
             stage("probe exchange", probe)
 
+    verify = False   # set by bench.py around its eager verification steps: every peer-to-peer sum is checked against RCCL
+
     def allreduce_(self, t):
         nbytes = t.numel() * t.element_size()
         if nbytes > self.max_bytes or nbytes % 8:
             return self.rccl.allreduce_(t)
+        ref = None
+        if self.verify:
+            ref = t.clone()
+            self.rccl.allreduce_(ref)
+        self._device_sum(t)
+        if ref is not None:
+            # (not under graph capture: it synchronises.)  Same addends, another summation order: a few ulps of the result type.
+            r32, t32 = ref.float(), t.float()
+            diff = float((t32 - r32).abs().max())
+            scale = float(r32.abs().max())
+            ulp = 2.0 ** -7 if t.dtype in (torch.bfloat16,) else (2.0 ** -10 if t.dtype == torch.float16 else 2.0 ** -20)
+            self.verify_log.append((diff, scale, diff <= 4 * ulp * max(scale, 1e-6) * max(1, self.nranks // 2)))
+        return t
+
+    def _device_sum(self, t):
         check(lib().dihip_p2p_allreduce_sum(self.handle, ops.cur_stream(), ops.ptr(t), ops.ptr(t), t.numel(), ops.dt_code(t)),
               "dihip_p2p_allreduce_sum")
-        return t
+
+    def start_verification(self):
+        self.verify, self.verify_log = True, []
+
+    def finish_verification(self, device):
+        """Ends a verification phase; every rank learns whether ALL ranks saw every peer-to-peer sum agree with RCCL's.
+        Returns (ok, summary string)."""
+        self.verify = False
+        log = getattr(self, "verify_log", [])
+        bad = [x for x in log if not x[2]]
+        ok = _all_ranks_ok(len(bad) == 0 and len(log) > 0, device)
+        worst = max((d / max(sc, 1e-6) for d, sc, _ in log), default=0.0)
+        return ok, f"{len(log)} all-reduces checked against rccl, worst relative difference {worst:.2e}, {len(bad)} outside 4 ulp on this rank"
 
     def allgather(self, src, dst):
         return self.rccl.allgather(src, dst)
@@ -472,6 +518,11 @@ class DecodeSession:
         else:
             self.act = torch.empty(batch, l0_.gate.N, dtype=dt, device=device)
         self.logits = torch.empty(batch, model.vocab_local, dtype=f32, device=device)
+        self.lm_ksplit = getattr(model, "lm_split", "vocab") == "k" and model.nranks > 1
+        if self.lm_ksplit:
+            self.lm_xn = torch.empty(batch, cfg.hidden, dtype=dt, device=device)
+            kloc = cfg.hidden // model.nranks
+            self.lm_xs = torch.empty(batch, kloc, dtype=dt, device=device)
         self.partial = torch.zeros(batch, cfg.hidden, dtype=f32, device=device)
         l0, wb, gsz = model.layers[0], model.quant.wbits, model.quant.group
         need = max(ops.lowp_workspace_bytes(wb, batch, p.N, p.K, gsz) for p in (l0.qkv, l0.o, l0.gate, l0.down))
@@ -629,6 +680,16 @@ class DecodeSession:
                                   y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
             nxt = m.layers[li + 1].qkv if li + 1 < len(m.layers) else m.lm_head
             self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag, next_weights=(nxt.w,))
+        if self.lm_ksplit and tp_on:
+            # the reference's lm_head under TP (model_base.py:690-703): final norm -> this rank's K slice of the row times its row
+            # block of the weight -> all-reduce of the partial logits: every rank ends with the full f32 logits row
+            ops.rmsnorm_rows(self.h, m.final_norm, cfg.eps, out=self.lm_xn)
+            kloc = self.lm_xs.shape[1]
+            self.lm_xs.copy_(self.lm_xn[:, m.rank * kloc:(m.rank + 1) * kloc])
+            ops.fused_gemm_addto(self.lm_xs, m.lm_head, None, sc, out=self.logits, M=self.B)
+            self._allreduce(self.logits)
+            ops.argmax(self.logits, ws=self.argmax_ws, out=self.ids, advance=(self.old_lens, self.new_lens))
+            return
         ops.lm_head(self.h, m.final_norm, cfg.eps, m.lm_head, sc, out=self.logits)
         if tp_on:
             check(lib().dihip_argmax_partial(ops.cur_stream(), ops.ptr(self.pair), ops.ptr(self.logits), self.B,

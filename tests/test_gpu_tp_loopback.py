@@ -44,6 +44,10 @@ def test_p2p_allreduce_between_rank_threads(pkg, nranks):
     (2, "i8", 3, 8, -1, "host", True),
     (2, "none", 2, 8, -1, "host-moe", False),  # mixture-of-experts layers under expert parallelism (4 of 8 experts per rank)
     (4, "none", 1, 4, 128, "host-moe", False),
+    # the reference-shaped lm_head under TP: K-split Gemm + all-reduce of the partial logits (model_base.py:690-703,
+    # gemm_op.cpp:95-98) -- every rank holds the FULL f32 logits row, equal to the single rank's
+    (2, "none", 2, 4, 128, "host-ksplit", False),
+    (4, "i8", 1, 8, -1, "host-ksplit", False),
 ])
 def test_tp_decode_matches_single_rank(pkg, monkeypatch, nranks, kv_mode, batch, wbits, group, comm_kind, overlap):
     if comm_kind == "p2p":
@@ -52,4 +56,5 @@ def test_tp_decode_matches_single_rank(pkg, monkeypatch, nranks, kv_mode, batch,
     from tests import tp_loopback_lib
     monkeypatch.setenv("DIHIP_TP_OVERLAP", "1" if overlap else "0")
     moe = comm_kind.endswith("-moe")
-    tp_loopback_lib.run_tp_decode(nranks, kv_mode, batch, wbits, group, comm_kind.split("-")[0], overlap, moe=moe)
+    tp_loopback_lib.run_tp_decode(nranks, kv_mode, batch, wbits, group, comm_kind.split("-")[0], overlap, moe=moe,
+                                  lm_head_split="k" if comm_kind.endswith("-ksplit") else None)

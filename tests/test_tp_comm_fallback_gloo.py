@@ -113,3 +113,50 @@ def test_guarded_p2p_setup_ends_in_the_same_backend_on_every_rank(pkg, fail, exp
     assert all(g[1].startswith(expect) for g in got), got
     assert got[0][1] == got[1][1] or expect.startswith("rccl")   # the same decision (the message names the failing rank's view)
     assert all(g[2] == 3.0 for g in got)
+
+
+def _verify_worker(rank, world, port, corrupt_rank, q):
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from __graft_entry__ import _load_pkg
+    _load_pkg()
+    from dash_infer_amd import decoder
+    decoder.lib = lambda: FakeLib(rank, None)
+    decoder.RcclComm = FakeRccl
+    calls = {"n": 0}
+
+    def device_sum(self, t):   # the "peer-to-peer kernel": a correct sum, except for one stale word on one rank every third call
+        dist.all_reduce(t)
+        calls["n"] += 1
+        if rank == corrupt_rank and calls["n"] % 3 == 0:
+            t.view(-1)[5] += 0.75
+    decoder.P2PComm._device_sum = device_sum
+    comm = decoder.make_comm(rank, world, torch.device("cpu"), backend="auto", allow_labelled_fallback=True)
+    assert comm.backend.startswith("p2p-oneshot")
+    comm.start_verification()
+    for i in range(7):
+        comm.allreduce_(torch.full((3584,), float(rank + 1) * (i + 1), dtype=torch.bfloat16 if i % 2 else torch.float32))
+    ok, summary = comm.finish_verification(torch.device("cpu"))
+    q.put((rank, ok, summary))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("corrupt_rank", [-1, 1])
+def test_p2p_verification_phase_reaches_one_verdict_on_every_rank(pkg, corrupt_rank):
+    """bench.py's verification of the peer-to-peer all-reduce (every sum of two eager decode steps checked against RCCL): a
+    stale word seen by ONE rank makes EVERY rank report failure (and fall back together); clean sums pass on both."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_verify_worker, args=(r, 2, port, corrupt_rank, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [g[1] for g in got] == [corrupt_rank < 0] * 2, got
+    assert all("7 all-reduces checked" in g[2] for g in got), got

@@ -144,7 +144,7 @@ def run_p2p_allreduce(nranks):
             assert torch.equal(results[r][k][3], y0), f"rank {r} differs (case {ci}, repetition {rep})"
 
 
-def run_tp_decode(nranks, kv_mode, batch, wbits, group, comm_kind, overlap, moe=False):
+def run_tp_decode(nranks, kv_mode, batch, wbits, group, comm_kind, overlap, moe=False, lm_head_split=None):
     import os
     from dash_infer_amd import decoder
     os.environ["DIHIP_TP_OVERLAP"] = "1" if overlap else "0"
@@ -180,7 +180,7 @@ def run_tp_decode(nranks, kv_mode, batch, wbits, group, comm_kind, overlap, moe=
     def worker(rank):
         try:
             torch.cuda.set_device(0)
-            model = decoder.build_random_model(cfg, spec, seed=99, rank=rank, nranks=nranks)
+            model = decoder.build_random_model(cfg, spec, seed=99, rank=rank, nranks=nranks, lm_head_split=lm_head_split)
             comm = (LoopbackP2PComm if p2p else LoopbackComm)(shared, rank, nranks)
             # P2P: the ranks' kernels wait for one another, so every rank needs a stream of its own
             st = torch.cuda.Stream() if p2p else torch.cuda.current_stream()
@@ -222,7 +222,14 @@ def run_tp_decode(nranks, kv_mode, batch, wbits, group, comm_kind, overlap, moe=
         # one of the whole sum.  Measured 0.6e-2 ... 1.3e-2 on logits of magnitude ~3.
         tol = 2.5e-2
     for t in range(steps):
-        logits = np.concatenate([results[r][t][0] for r in range(nranks)], axis=1)  # vocabulary-parallel slices
+        if lm_head_split == "k":
+            # the reference's K-split lm_head + logits all-reduce (model_base.py:690-703): EVERY rank holds the full logits row
+            logits = results[0][t][0]
+            assert logits.shape[1] == cfg.vocab
+            for r in range(1, nranks):
+                assert np.array_equal(results[r][t][0], logits), f"rank {r}: the all-reduced logits row differs from rank 0's"
+        else:
+            logits = np.concatenate([results[r][t][0] for r in range(nranks)], axis=1)  # vocabulary-parallel slices
         ids_tp = results[0][t][1]
         for r in range(1, nranks):
             assert np.array_equal(results[r][t][1], ids_tp)            # every rank holds the same next token
