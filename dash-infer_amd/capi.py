@@ -74,6 +74,11 @@ _SIGS = {
     "dihip_rope_qk": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32]),
     "dihip_binary_add": (i32, [vp, vp, vp, vp, sz, i32]),
     "dihip_silu_mul": (i32, [vp, vp, vp, vp, sz, i32]),
+    "dihip_binary_mul": (i32, [vp, vp, vp, vp, sz, i32]),
+    "dihip_unary": (i32, [vp, vp, vp, sz, i32, i32]),
+    "dihip_unary_glu": (i32, [vp, vp, vp, sz, sz, i32, i32]),
+    "dihip_embedding_ft": (i32, [vp, vp, vp, vp, i32, i32, i32, i32]),
+    "dihip_cast_to_f32": (i32, [vp, vp, vp, sz, i32]),
     "dihip_dense_packed_weight_bytes": (sz, [i32, i32]),
     "dihip_dense_pack": (i32, [vp, vp, i32, i32, i32, vp]),
     "dihip_dense_workspace_bytes": (sz, [i32, i32, i32]),

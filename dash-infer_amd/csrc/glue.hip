@@ -60,6 +60,47 @@ __global__ __launch_bounds__(256) void binary_kernel(void* __restrict__ y, const
   }
 }
 
+// Binary MUL / Unary / UnaryGLU of the reference graph as stand-alone operators (csrc/core/kernel/cuda/binary.cu, unary.cu:120-133):
+// the fused decode step never launches them (they ride in GEMV epilogues); the operator layer needs them so that an
+// unmodified model graph resolves on DeviceType::HIP.  f32 arithmetic, one FT rounding of the result.
+template <int FT>
+__global__ __launch_bounds__(256) void binary_mul_kernel(void* __restrict__ y, const void* __restrict__ a,
+                                                         const void* __restrict__ b, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
+    store_ft<FT>(y, i, load_ft<FT>(a, i) * load_ft<FT>(b, i));
+}
+template <int FT>
+__global__ __launch_bounds__(256) void unary_kernel(void* __restrict__ y, const void* __restrict__ x, size_t count, int act) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
+    store_ft<FT>(y, i, apply_act(load_ft<FT>(x, i), act));
+}
+// out[row, col] = f(in[row, col]) * in[row, inner + col]  (unary_glu_kernel, unary.cu:120-133; f's result rounded to FT first)
+template <int FT>
+__global__ __launch_bounds__(256) void unary_glu_kernel(void* __restrict__ y, const void* __restrict__ x, size_t outer, size_t inner,
+                                                        int act) {
+  const size_t count = outer * inner;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / inner, col = i - row * inner;
+    float f = apply_act(load_ft<FT>(x, row * inner * 2 + col), act);
+    if constexpr (FT != DIHIP_F32) f = ft_round<FT>(f);
+    store_ft<FT>(y, i, f * load_ft<FT>(x, row * inner * 2 + inner + col));
+  }
+}
+// EmbeddingT5 with an FT output (embeddingT5.cu): out[m, :] = table[clamp(ids[m]), :]
+template <int FT>
+__global__ __launch_bounds__(256) void embedding_ft_kernel(void* __restrict__ out, const int64_t* __restrict__ ids,
+                                                           const void* __restrict__ table, int K, int vocab) {
+  const int m = blockIdx.x;
+  int64_t id = ids[m];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const size_t row = (size_t)id * K;
+  for (int k = threadIdx.x; k < K; k += 256) store_ft<FT>(out, (size_t)m * K + k, load_ft<FT>(table, row + k));
+}
+template <int FT>
+__global__ __launch_bounds__(256) void cast_to_f32_kernel(float* __restrict__ y, const void* __restrict__ x, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) y[i] = load_ft<FT>(x, i);
+}
+
 // ---- greedy argmax (GenerateOp top_k = 1): lowest index wins ties --------------------------------
 struct ArgPair {
   float v;
@@ -223,6 +264,52 @@ int dihip_silu_mul(void* stream, void* y, const void* gate, const void* up, size
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int blocks = (int)std::min<size_t>((count + 255) / 256, 2048);
   FT_SWITCH(dtype, hipLaunchKernelGGL((binary_kernel<FT, 1>), dim3(blocks), dim3(256), 0, s, y, gate, up, count));
+  return launch_status();
+}
+
+int dihip_binary_mul(void* stream, void* y, const void* a, const void* b, size_t count, int dtype) {
+  DIHIP_REQUIRE(y && a && b, DIHIP_PARAM_ERROR, "binary_mul: null pointer");
+  if (count == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int blocks = (int)std::min<size_t>((count + 255) / 256, 2048);
+  FT_SWITCH(dtype, hipLaunchKernelGGL((binary_mul_kernel<FT>), dim3(blocks), dim3(256), 0, s, y, a, b, count));
+  return launch_status();
+}
+
+int dihip_unary(void* stream, void* y, const void* x, size_t count, int act, int dtype) {
+  DIHIP_REQUIRE(y && x, DIHIP_PARAM_ERROR, "unary: null pointer");
+  DIHIP_REQUIRE(act >= DIHIP_ACT_NONE && act <= DIHIP_ACT_SIGMOID, DIHIP_PARAM_ERROR, "unary: unknown UnaryType %d", act);
+  if (count == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int blocks = (int)std::min<size_t>((count + 255) / 256, 2048);
+  FT_SWITCH(dtype, hipLaunchKernelGGL((unary_kernel<FT>), dim3(blocks), dim3(256), 0, s, y, x, count, act));
+  return launch_status();
+}
+
+int dihip_unary_glu(void* stream, void* y, const void* x, size_t outer, size_t inner, int act, int dtype) {
+  DIHIP_REQUIRE(y && x, DIHIP_PARAM_ERROR, "unary_glu: null pointer");
+  DIHIP_REQUIRE(act >= DIHIP_ACT_NONE && act <= DIHIP_ACT_SIGMOID, DIHIP_PARAM_ERROR, "unary_glu: unknown UnaryType %d", act);
+  if (outer * inner == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int blocks = (int)std::min<size_t>((outer * inner + 255) / 256, 2048);
+  FT_SWITCH(dtype, hipLaunchKernelGGL((unary_glu_kernel<FT>), dim3(blocks), dim3(256), 0, s, y, x, outer, inner, act));
+  return launch_status();
+}
+
+int dihip_embedding_ft(void* stream, void* out, const int64_t* ids, const void* table, int M, int K, int vocab, int dtype) {
+  DIHIP_REQUIRE(M >= 0 && K > 0 && vocab > 0 && out && ids && table, DIHIP_PARAM_ERROR, "embedding_ft: bad argument");
+  if (M == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  FT_SWITCH(dtype, hipLaunchKernelGGL((embedding_ft_kernel<FT>), dim3(M), dim3(256), 0, s, out, ids, table, K, vocab));
+  return launch_status();
+}
+
+int dihip_cast_to_f32(void* stream, float* y, const void* x, size_t count, int dtype) {
+  DIHIP_REQUIRE(y && x, DIHIP_PARAM_ERROR, "cast_to_f32: null pointer");
+  if (count == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int blocks = (int)std::min<size_t>((count + 255) / 256, 2048);
+  FT_SWITCH(dtype, hipLaunchKernelGGL((cast_to_f32_kernel<FT>), dim3(blocks), dim3(256), 0, s, y, x, count));
   return launch_status();
 }
 

@@ -77,7 +77,8 @@ const char* dihost_last_error(void) { return g_err.c_str(); }
 const char* dihost_registered_ops(void) {
   static std::string s;
   s.clear();
-  for (const char* t : {"GemmA16W8", "GemmA16W4", "DecOptMHA", "DecOptMQA", "AllReduce", "AllGather", "MOEA16W8", "CalcExpert", "Gemm", "Rotary"}) {
+  for (const char* t : {"GemmA16W8", "GemmA16W4", "DecOptMHA", "DecOptMQA", "AllReduce", "AllGather", "MOEA16W8", "CalcExpert", "Gemm", "Rotary",
+                        "LayerNormNoBeta", "Binary", "Unary", "UnaryGLU", "EmbeddingT5", "GetLastLine", "GenerateOp", "TransMask", "RichEmbedding"}) {
     try {
       (void)OpFactory::getInstance().GetOperator({t, DeviceType::HIP});
       s += (s.empty() ? "" : ",");

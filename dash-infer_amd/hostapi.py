@@ -8,7 +8,7 @@ from . import REPO_ROOT
 from .capi import lib as _devlib
 
 OPS_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdashinfer_hip_ops.so")
-DT = {"f32": 1, "f16": 2, "i8": 3, "i32": 5, "bf16": 9, "u8": 10}
+DT = {"f32": 1, "f16": 2, "i8": 3, "i32": 5, "i64": 6, "bf16": 9, "u8": 10}
 vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
 _SIGS = {
     "dihost_model_create": (i32, [C.POINTER(vp), vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),

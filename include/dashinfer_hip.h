@@ -349,6 +349,19 @@ int dihip_rope_qk(void* stream, void* qkv, const uint32_t* positions, const floa
 /* Binary ADD / MUL and SiLU*MUL on FT tensors */
 int dihip_binary_add(void* stream, void* y, const void* a, const void* b, size_t count, int dtype);
 int dihip_silu_mul(void* stream, void* y, const void* gate, const void* up, size_t count, int dtype);
+/* The remaining elementwise operators of the reference layer graph as stand-alone calls (the fused decode step never
+ * launches them; the operator layer needs them so that an unmodified graph resolves on DeviceType::HIP):
+ *   Binary MUL  (csrc/core/operator/general/binary/binary_op.cpp, BinaryType MUL = 2)
+ *   Unary       (unary_op.cpp; act = allspark UnaryType, DIHIP_ACT_*)
+ *   UnaryGLU    (unary_glu_op.cpp; kernel unary.cu:120-133): y[row, col] = act(x[row, col]) * x[row, inner + col], x [outer, 2 * inner]
+ *   EmbeddingT5 with an FT output (embeddingT5_op.cpp): out[m, :] = table[ids[m], :], ids clamped to [0, vocab)
+ *   cast FT -> f32 (greedy GenerateOp over FT logits)                                              */
+int dihip_binary_mul(void* stream, void* y, const void* a, const void* b, size_t count, int dtype);
+int dihip_unary(void* stream, void* y, const void* x, size_t count, int act, int dtype);
+int dihip_unary_glu(void* stream, void* y, const void* x, size_t outer, size_t inner, int act, int dtype);
+int dihip_embedding_ft(void* stream, void* out, const int64_t* ids, const void* table, int M, int K, int vocab,
+                       int dtype);
+int dihip_cast_to_f32(void* stream, float* y, const void* x, size_t count, int dtype);
 /* Unquantised 16-bit weights run through the same MFMA kernel family as the weight-only GEMM:
  * the [K, N] weight is re-laid-out once into dihip tile-major order (dihip_dense_pack).
  *   dihip_gemm_a16w16 : op type "Gemm" semantics, y = act(alpha x.W + bias) (+ residual)
