@@ -37,7 +37,13 @@ WORKLOADS = {
     # BASELINE configs[4] as a whole decode step on ONE GPU: Qwen2-57B-A14B int8 per-channel (attention, router, 64 routed experts
     # top-8, shared expert behind its sigmoid gate; 28 layers, ~57 GB of int8 weights), batch 16, 1024 cached tokens ("prefix")
     "cfg5_moe":      (8, -1, "none", 16, False),
+    # the CONTEXT phase of the headline model (north star: "MFMA utilisation for prefill shown against gfx950 peaks"): one
+    # "step" = the product's DecodeSession.prefill of ONE 2048-token prompt through all 28 layers (qkv GEMM, Rotary, ContextSpanCopy,
+    # MFMA prefill attention, o / gate-up / down GEMMs, lm_head on the last row); value = prompt tokens / s; roofline = the
+    # prefill attention kernel against the dense bf16 MFMA peak
+    "prefill_2048":  (4, 128, "none", 1, True),
 }
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / f16 MFMA
 SEQ_LEN = 2048
 SEQ_LEN_OF = {"cfg3_rank": 4096, "cfg5_moe": 1024}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -104,7 +110,7 @@ def cpu_baseline(wbits, group, cores_hint=None):
                       f"max {passes[-1] * 1e3:.1f})"}
 
 
-def cpu_baseline_torch(wbits, group, seq_len=SEQ_LEN, budget_s=15.0):
+def cpu_baseline_torch(wbits, group, seq_len=SEQ_LEN, budget_s=15.0, weights="bf16"):
     """the reference's x86 path cannot be built here (oneDNN / MKL / intel_gemm are LFS stubs), so the
     SAME decode graph is timed through PyTorch-CPU (oneDNN + MKL, the libraries the reference's x86 operators call:
     csrc/core/operator/general/gemm/gemm_op_cpu.cpp:75-126, generate_opt/batch_mqa/batch_mqa_op.cpp:140-179) on this box's
@@ -118,8 +124,10 @@ def cpu_baseline_torch(wbits, group, seq_len=SEQ_LEN, budget_s=15.0):
     hid, n, g, H, inter, vocab, L = 3584, 28, 4, 128, 18944, 152064, 28
     cores = os.cpu_count() or 1
 
-    def mk(K, N):  # a dequantised weight as the x86 path would hold it: bf16 [K, N]
-        return (torch.randn(K, N, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+    wdt = torch.bfloat16 if weights == "bf16" else torch.float32
+
+    def mk(K, N):  # a dequantised weight as the x86 path would hold it: bf16 (medium_bf16) or f32 [K, N]
+        return (torch.randn(K, N, dtype=torch.float32) * 0.02).to(wdt)
 
     nrot = 4
     layers = [dict(qkv=mk(hid, (n + 2 * g) * H), qkv_b=torch.zeros((n + 2 * g) * H), o=mk(n * H, hid), gate=mk(hid, inter),
@@ -131,7 +139,7 @@ def cpu_baseline_torch(wbits, group, seq_len=SEQ_LEN, budget_s=15.0):
     cos, sin = torch.cos(ang), torch.sin(ang)
 
     def lin(x, w):
-        return torch.mm(x.to(torch.bfloat16), w).float()
+        return torch.mm(x.to(wdt), w).float()
 
     def rms(x, gam):
         return (gam * x) * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-6)
@@ -183,13 +191,80 @@ def cpu_baseline_torch(wbits, group, seq_len=SEQ_LEN, budget_s=15.0):
                 break
     except OSError:
         cpu_model = platform.processor()
-    return {"value": round(1.0 / med, 3), "unit": "tokens/s", "cores": best[1], "kind": "oneDNN-stand-in",
+    return {"value": round(1.0 / med, 3), "unit": "tokens/s", "cores": best[1], "kind": "oneDNN-stand-in", "weights": weights,
             "library": f"PyTorch-CPU {torch.__version__} (oneDNN / MKL), torch.set_num_threads({best[1]}) of {cores} logical CPUs; {cpu_model}",
             "sample": f"whole Qwen2-7B decode step at batch 1, seq {seq_len}: 28 x [RMSNorm, qkv bf16 GEMV + bias, RoPE, GQA attention over "
                       f"{seq_len + 1} cached tokens (f32), o GEMV + residual, RMSNorm, gate/up GEMV + SwiGLU, down GEMV + residual] over "
-                      f"{nrot} distinct layers' bf16 weights in rotation + final norm + bf16 lm_head + argmax; median of {len(ts)} steps in "
+                      f"{nrot} distinct layers' {weights} weights in rotation + final norm + {weights} lm_head + argmax; median of {len(ts)} steps in "
                       f"{time.perf_counter() - t_start:.1f} s ({med * 1e3:.1f} ms/token; min {ts[0] * 1e3:.1f}, max {ts[-1] * 1e3:.1f}); "
-                      f"weights dequantised to bf16 as the x86 path holds them (int{wbits} g{group} on the GPU)"}
+                      f"weights dequantised to {weights} as the x86 path holds them (int{wbits} g{group} on the GPU)"}
+
+
+def prefill_bench(args, torch, decoder, ops):
+    """--workload prefill_2048 (see WORKLOADS).  Timed with HIP events on the launch stream around whole prefill calls (eager
+    launches: the context phase is not graph-captured); the attention kernel alone is timed the same way over all layers' calls."""
+    wbits, group, kv_mode, batch, gptq = WORKLOADS["prefill_2048"]
+    cfg = decoder.QWEN2_7B
+    L = 2048
+    t0 = time.time()
+    model = decoder.build_random_model(cfg, decoder.QuantSpec(wbits, group, gptq_like_zeros=gptq), seed=1234, layers=args.layers)
+    sess = decoder.DecodeSession(model, 1, max_len=L + 16, span_len=128, kv_mode=kv_mode)
+    gen = torch.Generator().manual_seed(11)
+    prompt = [int(t) for t in torch.randint(0, cfg.vocab, (L,), generator=gen)]
+    t_build = time.time() - t0
+    nl = len(model.layers)
+    for _ in range(max(1, args.warmup)):
+        sess.prefill([prompt])
+    torch.cuda.synchronize()
+    steps = max(1, args.steps)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t_wall = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        sess.prefill([prompt])
+    e1.record()
+    torch.cuda.synchronize()
+    t_wall = (time.perf_counter() - t_wall) / steps
+    ms = e0.elapsed_time(e1) / steps
+    # the attention kernel alone: all layers' calls on resident fused qkv rows
+    n, g, H = cfg.n_heads, cfg.n_kv, cfg.head_dim
+    qkv = (torch.randn(L, (n + 2 * g) * H, device="cuda") * 0.5).to(torch.bfloat16)
+    out = torch.empty(L, n * H, dtype=torch.bfloat16, device="cuda")
+    def attn_all():
+        for _ in range(nl):
+            ops.prefill_attn(qkv[:, : n * H], qkv[:, n * H:(n + g) * H], qkv[:, (n + g) * H:], n, g, H, sess.scale, out=out)
+    attn_all()
+    torch.cuda.synchronize()
+    a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a0.record()
+    for _ in range(5):
+        attn_all()
+    a1.record()
+    torch.cuda.synchronize()
+    attn_us = a0.elapsed_time(a1) / (5 * nl) * 1e3
+    flops = 4.0 * n * H * L * L / 2.0   # causal: QK^T and PV, half the square
+    tflops = flops / (attn_us * 1e-6) / 1e12
+    # GEMM flops of the step (2 M N K per projection) for the record
+    gemm_flops = 2.0 * L * sum(p.N * p.K for lw in model.layers for p in (lw.qkv, lw.o, lw.gate, lw.up, lw.down))
+    out_d = {
+        "metric": "prefill (context phase) tokens/sec, Qwen2-7B weight-only quantized, one 2048-token prompt",
+        "value": round(L / (ms * 1e-3), 1), "unit": "tokens/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic (random-init InstantQuant weights of the Qwen2-7B shapes, random prompt)",
+        "config": {"workload": f"Qwen2-7B prefill_2048: int{wbits} weight-only group {group}, 16-bit KV spans, batch 1, prompt {L} tokens, "
+                               f"{nl} layers, eager launches (DecodeSession.prefill)", "global_batch": 1, "seq_len": L, "parallelism": "tp1",
+                   "layers": nl},
+        "roofline": {"bound": "mfma", "kernel": "dihip::prefill_attn_kernel (causal flash attention, 28 query / 4 KV heads, head 128)",
+                     "achieved": round(tflops, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "traffic": None, "avg_launch_us": round(attn_us, 2), "algorithmic_flops_per_launch": flops},
+        "context_phase": {"attention_share": round(attn_us * nl / (ms * 1e3), 4), "gemm_tflops_if_rest_were_gemm": round(
+            gemm_flops / max(1e-9, (ms * 1e-3 - attn_us * nl * 1e-6)) / 1e12, 1), "host_wall_ms": round(t_wall * 1e3, 3)},
+        "build_s": round(t_build, 1),
+    }
+    if args.layers is not None:
+        out_d["invalid"] = "debug run with a truncated layer stack"
+    return out_d
 
 
 def moe_layer_bench(args, torch, ops):
@@ -325,6 +400,19 @@ def kernel_breakdown(sess, torch, ops, iters=5):
     return res
 
 
+def csrc_tree_hash():
+    """sha256 over the kernel sources (dash-infer_amd/csrc/*.hip, *.hpp, *.h, Makefile) in name order: stamps a PMC summary with
+    the code it was collected on (tools/gpu_pmc.sh writes it, pmc_traffic() compares)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "dash-infer_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hpp")) + glob.glob(os.path.join(d, "*.h")) + [os.path.join(d, "Makefile")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary
     (profiles/*_pmc_hbm_traffic.csv, written by tools/gpu_pmc.sh: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE)."""
@@ -335,9 +423,15 @@ def pmc_traffic(kernel_substr):
         return None, None
     key = kernel_substr.rstrip(">")  # template argument lists may have grown a defaulted tail
     tot = 0
+    stamp = None
     for r in csv.DictReader(open(files[-1])):
+        stamp = r.get("csrc_hash") or stamp
         if key in r["kernel"]:
             tot += int(r["avg_bytes_corrected"])
+    # a summary collected on other kernel sources says nothing about this build: refuse it (VERDICT r2 housekeeping)
+    if stamp != csrc_tree_hash():
+        return None, "STALE: profiles/%s was collected on kernel sources %s, this tree is %s -- re-run tools/gpu_pmc.sh" % (
+            os.path.basename(files[-1]), stamp or "(unstamped)", csrc_tree_hash())
     # not measured by THIS run: counters need their own rocprofv3 passes (tools/gpu_pmc.sh); the summary read here is named
     return (tot or None), "committed PMC summary profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, " \
                           "gfx950 FETCH_SIZE x2 correction); not collected by this run" % os.path.basename(files[-1])
@@ -375,6 +469,10 @@ def main():
                                  allow_labelled_fallback=True)
 
     wbits, group, kv_mode, batch, gptq = WORKLOADS[args.workload]
+    if args.workload == "prefill_2048":
+        assert world == 1, "prefill_2048 is a one-GPU workload"
+        print(json.dumps(prefill_bench(args, torch, decoder, ops)), flush=True)
+        return
     if args.workload == "moe_layer":
         assert world == 1, "moe_layer is a one-GPU workload"
         out = moe_layer_bench(args, torch, ops)
@@ -573,9 +671,13 @@ def main():
             out["roofline_error"] = repr(e)
         if world == 1 and not args.no_cpu_baseline and args.workload in ("int4_b1", "int8_b1", "int4_b32_u4kv"):  # the CPU graph below is Qwen2-7B's
             try:
-                out["cpu_baseline"] = cpu_baseline_torch(wbits, group)
+                out["cpu_baseline"] = cpu_baseline_torch(wbits, group, budget_s=12.0)
             except Exception as e:
                 out["cpu_baseline_error"] = repr(e)
+            try:  # the same graph with f32 weights (the x86 path's default matmul precision): MKL sgemv, bandwidth bound
+                out["cpu_baseline_f32"] = cpu_baseline_torch(wbits, group, budget_s=10.0, weights="f32")
+            except Exception as e:
+                out["cpu_baseline_f32_error"] = repr(e)
             try:  # second figure: the plain-C oracle loop (the restated CPU_SubC_Ref), linear layers only
                 out["cpu_baseline_port"] = cpu_baseline(wbits, group)
             except Exception as e:

@@ -153,10 +153,20 @@ __device__ __forceinline__ float rows_sum(float v) {  // (r0 + r1) + (r2 + r3): 
   const auto r2 = __builtin_amdgcn_permlane32_swap(um, um, false, false);
   return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
 }
+// Sum over the 64 lanes, result in every lane.  DPP moves inside the 16-lane rows (pairs, quads, 8s, 16s: after each level
+// every lane of a group holds the group's sum, so which lane of the partner group is read does not matter), then the two
+// cross-row exchanges of rows_sum: VALU only.  (__shfl_xor is six dependent ds_bpermute round trips through the LDS pipe:
+// ~0.25 us of the RMSNorm prologue every decode GEMV runs.)  One fixed tree: every norm path of the library sums through here.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f32(float v) {  // DPP move, all rows / banks enabled
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov_f32<0x141>(v);  // row_half_mirror: the other quad of the 8
+  v += dpp_mov_f32<0x140>(v);  // row_mirror: the other half of the 16
+  return rows_sum(v);
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

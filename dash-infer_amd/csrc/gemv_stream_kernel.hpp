@@ -446,7 +446,7 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
           for (int q = 0; q < 4; ++q) {
             const float ga = ft_bits_to_f32<FT>(G[j][q] & 0xFFFFu), gb = ft_bits_to_f32<FT>(G[j][q] >> 16);
             const float xa = q < 2 ? h0[2 * q] : h1[2 * q - 4], xb = q < 2 ? h0[2 * q + 1] : h1[2 * q - 3];
-            o[q] = f32_to_ft_bits<FT>((ga * xa) * rstd) | (f32_to_ft_bits<FT>((gb * xb) * rstd) << 16);
+            o[q] = pack_ft2<FT>((ga * xa) * rstd, (gb * xb) * rstd);  // (one packed convert: same round-to-nearest-even bits)
           }
           stage_vector(r, i, o);
         }

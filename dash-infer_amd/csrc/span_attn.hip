@@ -685,6 +685,7 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
     a.merge_wt = 1;
   }
   const dim3 grid(p.nsplits, n_groups * p.nchunks, batch);
+  a.trace = debug_trace_buffer((size_t)p.nsplits * n_groups * p.nchunks * batch * 32 * sizeof(unsigned long long));
   if (dtype == DIHIP_BF16)
     hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_NONE, true>), grid, dim3(ATTN_THREADS), 0, s, a);
   else

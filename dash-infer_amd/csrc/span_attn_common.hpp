@@ -34,6 +34,7 @@ struct AttnArgs {
                           // arrival ticket, the last workgroup of a (request, group) reads all records past its L1 and
                           // writes the output -- no release / acquire fences, no second launch
   size_t partial_bytes;   // size of `partials` (buffer-resource range of the write-through stores / loads)
+  unsigned long long* trace;  // diagnostics (`make trace` build + dihip_debug_set_trace): [workgroup][wave][8] wall-clock stamps, or null
 };
 
 // decode-step form on the matrix cores (span_attn.hip); returns a DIHIP status, DIHIP_PARAM_ERROR with

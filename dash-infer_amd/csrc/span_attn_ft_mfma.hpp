@@ -110,59 +110,17 @@ __device__ __forceinline__ void attn_block_epilogue(const AttnArgs& a, float* ld
   }
 }
 
-// In-launch merge of the split partials without fences (AttnArgs::merge_wt; MI355X guide, Guideline 16 form R1): the 4 waves
-// have left their (o[128], m, l) records in `lds`.  The block record goes to `partials` with 16-byte WRITE-THROUGH stores
-// (sc1: the line leaves this XCD's L2), every wave drains its stores, one lane takes an arrival ticket (relaxed agent-scope
-// atomic), and the workgroup that arrives last for its (request, group, head chunk) reads all nsplits records with sc1
-// loads -- which are served past this CU's L1, and the writers' lines are not in any other L2 -- merges them in split order
-// (the arithmetic of span_attn_split_merge_kernel) and writes the FT output.  The ticket word is left at zero for the
-// next launch.  Thread -> (head h = e / 32, dims (e % 32) * 4 .. + 3).
-template <int FT, int HC>
-__device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float* lds, unsigned* flag_lds, int b, int h0, int nh,
-                                                       int split, unsigned* counter) {
+// the last-arriving workgroup's part of attn_block_epilogue_wt: all nsplits records of its heads, read past the L1 (sc1),
+// merged in split order, output written.  MB = records per load batch.
+template <int FT, int MB, typename RSRC>
+__device__ __forceinline__ void merge_split_records(const AttnArgs& a, RSRC rsrc, int b, int h0, int nh, unsigned long long* tr) {
   constexpr int H = 128;
   const int tid = threadIdx.x;
-  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.partials, 0, (int)a.partial_bytes, 0x00020000);
-  __syncthreads();
-  for (int e = tid; e < nh * 32; e += ATTN_THREADS) {
-    const int h = e >> 5, dq = e & 31;
-    float mm = -INFINITY;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) mm = fmaxf(mm, lds[(w * HC + h) * ATTN_PSTRIDE + H]);
-    float ll = 0.f;
-    f32x4_t oo = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float* rec = lds + (w * HC + h) * ATTN_PSTRIDE;
-      const float c = safe_exp_diff(rec[H], mm);
-      ll += rec[H + 1] * c;
-      const f32x4_t ov = *reinterpret_cast<const f32x4_t*>(rec + dq * 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) oo[j] += ov[j] * c;
-    }
-    const uint32_t roff = (uint32_t)((((size_t)b * a.n + h0 + h) * a.nsplits + split) * ATTN_PSTRIDE * sizeof(float));
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, oo), rsrc, roff + dq * 16, 0, 16 /* sc1 */);
-    if (dq == 0) {
-      const u32x2_t ml = {__float_as_uint(mm), __float_as_uint(ll)};
-      __builtin_amdgcn_raw_buffer_store_b64(ml, rsrc, roff + H * 4, 0, 16);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its write-through stores are acknowledged
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool last = t == (unsigned)a.nsplits - 1u;
-    if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // launches of a stream do not overlap
-    *flag_lds = last ? 1u : 0u;
-  }
-  __syncthreads();
-  if (*flag_lds == 0u) return;
   for (int e = tid; e < nh * 32; e += ATTN_THREADS) {
     const int h = e >> 5, dq = e & 31;
     const uint32_t hoff = (uint32_t)(((size_t)b * a.n + h0 + h) * a.nsplits * ATTN_PSTRIDE * sizeof(float));
     float mm = -INFINITY, ll = 0.f;
     f32x4_t oo = {0.f, 0.f, 0.f, 0.f};
-    constexpr int MB = 32;  // records per batch: all loads of a batch in flight together
     for (int sb = 0; sb < a.nsplits; sb += MB) {
       u32x4_t ov[MB];
       u32x2_t mv[MB];
@@ -191,13 +149,87 @@ __device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float*
       }
       mm = bm;
     }
+#if defined(DIHIP_GEMV_TRACE) && DIHIP_GEMV_TRACE
+    if (tr) tr[6] = wall_clock64();
+#endif
+    float r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = ll > 0.f ? oo[q] / ll : 0.f;
+    if constexpr (FT != DIHIP_F32) {
+      if (!a.out_frag_mt) {  // row-major output: the lane's 4 dims are one 8-byte store (same round-to-nearest-even bits as store_ft)
+        const u32x2_t pk = {pack_ft2<FT>(r[0], r[1]), pack_ft2<FT>(r[2], r[3])};
+        *reinterpret_cast<u32x2_t*>(reinterpret_cast<uint16_t*>(a.out) + ((size_t)b * a.n + h0 + h) * H + dq * 4) = pk;
+        continue;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int d = dq * 4 + q;
       const size_t idx = a.out_frag_mt ? act_frag_index(b, (h0 + h) * H + d, a.out_frag_mt) : ((size_t)b * a.n + h0 + h) * H + d;
-      store_ft<FT>(a.out, idx, ll > 0.f ? oo[q] / ll : 0.f);
+      store_ft<FT>(a.out, idx, r[q]);
     }
   }
+}
+
+// In-launch merge of the split partials without fences (AttnArgs::merge_wt; MI355X guide, Guideline 16 form R1): the 4 waves
+// have left their (o[128], m, l) records in `lds`.  The block record goes to `partials` with 16-byte WRITE-THROUGH stores
+// (sc1: the line leaves this XCD's L2), every wave drains its stores, one lane takes an arrival ticket (relaxed agent-scope
+// atomic), and the workgroup that arrives last for its (request, group, head chunk) reads all nsplits records with sc1
+// loads -- which are served past this CU's L1, and the writers' lines are not in any other L2 -- merges them in split order
+// (the arithmetic of span_attn_split_merge_kernel) and writes the FT output.  The ticket word is left at zero for the
+// next launch.  Thread -> (head h = e / 32, dims (e % 32) * 4 .. + 3).
+template <int FT, int HC>
+__device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float* lds, unsigned* flag_lds, int b, int h0, int nh,
+                                                       int split, unsigned* counter, unsigned long long* tr = nullptr) {
+  constexpr int H = 128;
+  const int tid = threadIdx.x;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.partials, 0, (int)a.partial_bytes, 0x00020000);
+  __syncthreads();
+  for (int e = tid; e < nh * 32; e += ATTN_THREADS) {
+    const int h = e >> 5, dq = e & 31;
+    float mm = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) mm = fmaxf(mm, lds[(w * HC + h) * ATTN_PSTRIDE + H]);
+    float ll = 0.f;
+    f32x4_t oo = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* rec = lds + (w * HC + h) * ATTN_PSTRIDE;
+      const float c = safe_exp_diff(rec[H], mm);
+      ll += rec[H + 1] * c;
+      const f32x4_t ov = *reinterpret_cast<const f32x4_t*>(rec + dq * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) oo[j] += ov[j] * c;
+    }
+    const uint32_t roff = (uint32_t)((((size_t)b * a.n + h0 + h) * a.nsplits + split) * ATTN_PSTRIDE * sizeof(float));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, oo), rsrc, roff + dq * 16, 0, 16 /* sc1 */);
+    if (dq == 0) {
+      const u32x2_t ml = {__float_as_uint(mm), __float_as_uint(ll)};
+      __builtin_amdgcn_raw_buffer_store_b64(ml, rsrc, roff + H * 4, 0, 16);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its write-through stores are acknowledged
+#if defined(DIHIP_GEMV_TRACE) && DIHIP_GEMV_TRACE
+  if (tr) tr[4] = wall_clock64();
+#endif
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = t == (unsigned)a.nsplits - 1u;
+    if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // launches of a stream do not overlap
+    *flag_lds = last ? 1u : 0u;
+  }
+  __syncthreads();
+#if defined(DIHIP_GEMV_TRACE) && DIHIP_GEMV_TRACE
+  if (tr) tr[5] = wall_clock64();
+#endif
+  if (*flag_lds == 0u) return;
+  // records per batch: all loads of a batch are in flight together.  The batch width follows the split count (8 / 16 / 24 /
+  // 32), so that a 17-split plan issues 24 record loads per lane, not 32 (the excess re-reads the last record)
+  if (a.nsplits <= 8) merge_split_records<FT, 8>(a, rsrc, b, h0, nh, tr);
+  else if (a.nsplits <= 16) merge_split_records<FT, 16>(a, rsrc, b, h0, nh, tr);
+  else if (a.nsplits <= 24) merge_split_records<FT, 24>(a, rsrc, b, h0, nh, tr);
+  else merge_split_records<FT, 32>(a, rsrc, b, h0, nh, tr);
 }
 
 constexpr int MF_HC = 16;   // query heads per workgroup chunk (MFMA N)
@@ -234,6 +266,16 @@ constexpr int FT_MFMA_SMEM_BYTES = FT_MFMA_EPI_BYTES > FT_MFMA_VT_BYTES ? FT_MFM
 
 __device__ __forceinline__ u32x4_t ld_qkv16(const uint16_t* p) { return *reinterpret_cast<const u32x4_t*>(p); }  // 16 bytes of the fused qkv row
 
+// per-wave wall-clock stamps (tools/attn_bench on the `make trace` build); absent from the product build
+#if defined(DIHIP_GEMV_TRACE) && DIHIP_GEMV_TRACE
+#define DIHIP_ATTN_STAMP(I)                                                                                          \
+  do {                                                                                                               \
+    if (a.trace) a.trace[(((size_t)bz * gy + by) * gx + bx) * 32 + (threadIdx.x >> 6) * 8 + (I)] = wall_clock64();    \
+  } while (0)
+#else
+#define DIHIP_ATTN_STAMP(I) do { } while (0)
+#endif
+
 template <int FT, int MODE, bool FUSED>
 __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const int bx, const int by, const int bz, const int gx,
                                                        const int gy, const int gz, unsigned char* smem) {
@@ -247,6 +289,7 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   unsigned* flag_lds = reinterpret_cast<unsigned*>(lds + 4 * HC * ATTN_PSTRIDE);
 
   const int tid = threadIdx.x, lane = tid & 63;
+  DIHIP_ATTN_STAMP(0);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kb = lane >> 4, ni = lane & 15;
   const int split = bx;
@@ -358,6 +401,7 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
     load_v(tb0, true);
     load_k(tb0, true);
   }
+  DIHIP_ATTN_STAMP(1);
 
   // rotate-half on a lane's fragments: dims ks*32 + kb*8 + e (ks = 0, 1) pair with ks + 2; table row = position.
   // Same arithmetic and rounding as dihip_rope_qk / the Rotary op: two products, one add, rounded to FT.
@@ -438,6 +482,7 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
     }
   }
 
+  DIHIP_ATTN_STAMP(2);
   const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, l = 0.f, czero = 0.f;
   f32x4_t o[8];  // O^T tile dt: rows (dims) dt*16 + kb*4 + r, column = head ni
@@ -576,6 +621,7 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   if constexpr (Q8) {
     czero = rows_sum(czero);
   }
+  DIHIP_ATTN_STAMP(3);
   __syncthreads();  // every wave is done with its V tile: the buffer now holds the epilogue records
   if (ni < nh) {
     float* rec = lds + (wave * HC + ni) * ATTN_PSTRIDE;
@@ -592,11 +638,14 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   }
   if constexpr (FUSED) {
     if (a.merge_wt) {
-      attn_block_epilogue_wt<FT, HC>(a, lds, flag_lds, b, h0, nh, split, a.counters + ((size_t)b * a.g + grp) * a.nchunks + hc);
+      attn_block_epilogue_wt<FT, HC>(a, lds, flag_lds, b, h0, nh, split, a.counters + ((size_t)b * a.g + grp) * a.nchunks + hc,
+                                     a.trace ? a.trace + (((size_t)bz * gy + by) * gx + bx) * 32 + (threadIdx.x >> 6) * 8 : nullptr);
+      DIHIP_ATTN_STAMP(7);
       return;
     }
   }
   attn_block_epilogue<FT, HC>(a, lds, flag_lds, b, h0, nh, split);
+  DIHIP_ATTN_STAMP(7);
 }
 
 

@@ -49,6 +49,7 @@ class GemmLowpHIP : public AsOperator {
     if (WBITS == 4 && (w->GetDataType() != UINT8 || (int)w->GetShape()[1] != (n_ + 1) / 2)) return AsStatus::ALLSPARK_PARAM_ERROR;
     ftype_ = weights_[1]->GetDataType();
     if (ftype_ != FLOAT16 && ftype_ != BFLOAT16) return AsStatus::ALLSPARK_PARAM_ERROR;
+    tensor_map_->at(out_names_[0])->SetDataType(ftype_);  // type inference at Init: the next operator's Init reads it
     // re-layout once (gemm_a16w8_gpu.cpp:421-473 does the same job for the CUDA kernels)
     const HIPContext& hctx = static_cast<const HIPContext&>(ctx);
     packed_w_ = std::make_unique<AsTensor>(op_name_ + ".packed_w", DeviceType::HIP, INT8,

@@ -74,6 +74,8 @@ class RotaryHIP : public AsOperator {
   explicit RotaryHIP(const std::string& t = "") : AsOperator(t) {}
   AsStatus Init(const OperatorProto& op_proto, const DeviceContext& ctx, const TensorMap& weights_map, TensorMap* tensor_map) override {
     AS_CHECK_STATUS(AsOperator::Init(op_proto, ctx, weights_map, tensor_map));
+    // type inference at Init, as every reference operator does it (rotary_op.cpp:90-91): the NEXT operator's Init reads it
+    tensor_map_->at(out_names_[0])->SetDataType(tensor_map_->at(in_names_[0])->GetDataType());
     const char* p = attr_ptr(op_proto, "num_heads");
     if (!p) return AsStatus::ALLSPARK_PARAM_ERROR;  // rotary_op.cpp:94-98
     num_heads_ = *(const int*)p;

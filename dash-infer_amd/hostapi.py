@@ -52,7 +52,8 @@ def lib():
 
 class HostError(RuntimeError):
     def __init__(self, code, what):
-        super().__init__(f"{what}: AsStatus {code}: {lib().dihost_last_error().decode()}")
+        dev = _devlib().dihip_last_error()
+        super().__init__(f"{what}: AsStatus {code}: {lib().dihost_last_error().decode()} (device library: {dev.decode() if dev else ''})")
         self.code = code
 
 
@@ -95,6 +96,8 @@ class Model:
         oid = i32()
         _ck(lib().dihost_op_create(self.h, C.byref(oid), op_type.encode(), op_name.encode(), ",".join(inputs).encode(),
                                    ",".join(outputs).encode(), ",".join(weights).encode(), attrs.encode()), "create " + op_type)
+        self._names = getattr(self, "_names", {})
+        self._names[oid.value] = f"{op_type} {op_name}"
         return oid.value
 
     def set_runtime(self, is_context, steps, k_spans, v_spans):
@@ -110,10 +113,10 @@ class Model:
         _ck(lib().dihost_set_prefix_len(self.h, request, prefix_len), "set_prefix_len")
 
     def reshape(self, op):
-        _ck(lib().dihost_op_reshape(self.h, op), "CallReshape")
+        _ck(lib().dihost_op_reshape(self.h, op), f"CallReshape [{self._names.get(op, op)}]")
 
     def alloc(self, op):
-        _ck(lib().dihost_op_alloc(self.h, op), "CallAlloc")
+        _ck(lib().dihost_op_alloc(self.h, op), f"CallAlloc [{self._names.get(op, op)}]")
 
     def forward(self, op):
-        _ck(lib().dihost_op_forward(self.h, op), "CallForward")
+        _ck(lib().dihost_op_forward(self.h, op), f"CallForward [{self._names.get(op, op)}]")

@@ -63,7 +63,9 @@ class DecoderOracle:
     def __init__(self, layers, embed, final_norm, lm_head, n_heads, n_kv, head_dim, wbits, group, eps=1e-6,
                  rope_theta=1000000.0, kv_mode="none", rounding="x86", cache_weights=False):
         """layers: list of dicts with 'qkv', 'o', 'gate', 'up', 'down' = (q, scales, zeros) in the formats of
-        gemm_ref.gemm_a16wx, plus 'qkv_bias', 'ln1', 'ln2' (float arrays); embed [V, hidden], lm_head [hidden, V]."""
+        gemm_ref.gemm_a16wx -- or a plain FT-valued float array [K, N] for an UNQUANTISED layer (op type Gemm: BASELINE
+        configs[0], Qwen2-0.5B bf16 on the x86 path; wbits = 16) --, plus 'qkv_bias', 'ln1', 'ln2' (float arrays);
+        embed [V, hidden], lm_head [hidden, V].  Any head size (Qwen2-0.5B: 64)."""
         self.layers, self.embed, self.final_norm, self.lm_head = layers, embed, final_norm, lm_head
         self.n, self.g, self.H = n_heads, n_kv, head_dim
         self.wbits, self.group, self.eps, self.kv_mode = wbits, group, eps, kv_mode
@@ -87,6 +89,8 @@ class DecoderOracle:
     def dequantised(self, w):
         """The matmul's weight matrix [K, N] in the accumulation type: (q - z) * s in f32 (bit-exact restatement of the
         reference's host loop), rounded to bf16 where the x86 path holds bf16 weights."""
+        if isinstance(w, np.ndarray):   # unquantised FT weight (already bf16-valued: the bf16 reorder is the identity)
+            return np.asarray(w, np.float32).astype(self.acc, copy=False)
         q, s, z = w
         w32 = gemm_ref.dequant(q, s, z, self.group, self.wbits)
         if self.rounding.w_bf16:
@@ -96,7 +100,7 @@ class DecoderOracle:
     def linear(self, x, w, ft, bias=None, W=None):
         """x . W (+ bias), rounded to `ft`.  W: the matrix already dequantised for this rounding (lockstep evaluation of
         several oracles over one dequantisation, `teacher_forced_logits`), else taken from / put into the weight cache."""
-        q = w[0]
+        q = w if isinstance(w, np.ndarray) else w[0]
         if W is None and self._wcache is not None:
             W = self._wcache.get((id(q), self.rounding.w_bf16))
             if W is None:
@@ -290,7 +294,8 @@ def teacher_forced_logits(oracles, layers, seq, n_last, progress=None, threads=1
         lw = layers[li]
         mats = {}
         for name in ("qkv", "o", "gate", "up", "down"):
-            w32 = gemm_ref.dequant(*lw[name], o0.group, o0.wbits, threads=threads)
+            w32 = (np.asarray(lw[name], np.float32) if isinstance(lw[name], np.ndarray)
+                   else gemm_ref.dequant(*lw[name], o0.group, o0.wbits, threads=threads))
             mats[name] = {False: w32}
             if any(o.rounding.w_bf16 for o in oracles):
                 mats[name][True] = bf16_round(w32, threads=threads)

@@ -4,7 +4,7 @@ oracle -- two evaluation orders of one function, built from pieces that are pinn
 import numpy as np
 import pytest
 
-from oracle import model as omodel, quant
+from oracle import glue, model as omodel, quant
 from oracle.numerics import bf16_round
 
 
@@ -160,3 +160,43 @@ def test_pure_x86_rounding_modes_differ_where_they_should():
     assert 0 < d("x86", "x86_pure_bf16_exactw") < 5e-2       # FT rounding of qkv / cache / attention output
     assert 0 < d("x86_pure_bf16", "x86_pure_bf16_exactw") < 5e-2   # weight rounding
     assert 0 < d("x86_pure_f32", "x86_pure_bf16_exactw") < 5e-2    # src rounding
+
+
+# BASELINE configs[0]: "Qwen2-0.5B bf16 greedy decode, batch 1, x86 CPU reference path (plumbing, no GPU)".  The reference's
+# CPU engine entry is switched off in this version and its x86 libraries are LFS stubs (F4): the path exists
+# here as the oracle's unquantised form -- op type Gemm with bf16 weights (gemm_op_cpu.cpp:75-126), head size 64, 14 query /
+# 2 KV heads, f32 tensors between operators.  Qwen2-0.5B widths, a few layers, a small vocabulary (CPU seconds).
+def make_dense_oracle(rng, rounding, hidden=896, n=14, g=2, H=64, inter=4864, vocab=512, nlayers=3):
+    w = lambda K, N, std=0.02: bf16_round(rng.normal(0, std, (K, N)).astype(np.float32))
+    layers = [dict(qkv=w(hidden, (n + 2 * g) * H), o=w(n * H, hidden), gate=w(hidden, inter), up=w(hidden, inter), down=w(inter, hidden),
+                   qkv_bias=bf16_round(rng.normal(0, 0.05, (n + 2 * g) * H).astype(np.float32)),
+                   ln1=bf16_round(1 + rng.normal(0, 0.1, hidden).astype(np.float32)),
+                   ln2=bf16_round(1 + rng.normal(0, 0.1, hidden).astype(np.float32))) for _ in range(nlayers)]
+    embed = bf16_round(rng.normal(0, 1.0, (vocab, hidden)).astype(np.float32))
+    fn = bf16_round(1 + rng.normal(0, 0.1, hidden).astype(np.float32))
+    lm = w(hidden, vocab, 0.05)
+    return omodel.DecoderOracle(layers, embed, fn, lm, n, g, H, 16, -1, kv_mode="none", rounding=rounding)
+
+
+@pytest.mark.parametrize("rounding", ["x86_pure_bf16", "x86_pure_f32"])
+def test_config0_unquantised_bf16_model_incremental_decode_equals_full_recompute(rounding):
+    """configs[0] plumbing: greedy decoding of an unquantised Qwen2-0.5B-shaped model on the x86 semantics (medium_bf16 and the
+    default f32 matmul precision), token by token against the growing f32 cache == recomputing the whole sequence (prefill
+    attention oracle) == the one-pass teacher-forced evaluation; greedy ids identical along all three."""
+    rng = np.random.default_rng(64)
+    m = make_dense_oracle(rng, rounding)
+    prompt = [int(t) for t in rng.integers(0, 512, 6)]
+    lo = m.prefill([prompt])
+    seq, step_logits = list(prompt), [lo[0]]
+    for _ in range(5):
+        nxt = int(glue.greedy(step_logits[-1][None, :])[0])
+        seq.append(nxt)
+        step_logits.append(m.step([nxt])[0])
+    m2 = make_dense_oracle(np.random.default_rng(64), rounding)
+    for L in (len(prompt), len(prompt) + 2, len(seq)):
+        full = m2.last_logits_from_scratch(seq[:L])[0]
+        want = step_logits[L - len(prompt)]
+        np.testing.assert_allclose(want, full, rtol=0, atol=3e-5 * max(1.0, float(np.abs(full).max())))
+        assert int(np.argmax(want)) == int(np.argmax(full))
+    tf = omodel.teacher_forced_logits([m2], m2.layers, seq, len(step_logits))[0]
+    np.testing.assert_allclose(tf, np.stack(step_logits), rtol=0, atol=3e-5 * max(1.0, float(np.abs(tf).max())))

@@ -28,9 +28,11 @@ int main(int argc, char** argv) {
   float *inv, *tab; CK(hipMalloc(&inv, H * 2)); CK(hipMemcpy(inv, hf.data(), H * 2, hipMemcpyHostToDevice)); CK(hipMalloc(&tab, (size_t)(max_len + 1) * H * 4));
   if (dihip_rope_table(st, tab, inv, max_len + 1, H)) { printf("rope_table: %s\n", dihip_last_error()); return 1; }
   size_t wsb = dihip_span_attn_fused_workspace_bytes(B, n, g, H, max_len); void* ws; CK(hipMalloc(&ws, wsb));
+  size_t syb = dihip_span_attn_sync_bytes(B, n); void* sync; CK(hipMalloc(&sync, syb)); CK(hipMemset(sync, 0, syb));
+  const bool in_launch = !(getenv("MERGE") && getenv("MERGE")[0] == 'l');   // MERGE=launch: the two-launch form
   auto launch = [&](int layer) {
-    int rc = dihip_span_attn_decode_fused(st, out, qkv, dk + (size_t)layer * B * spr, dv + (size_t)layer * B * spr, lens, tab, B, n, g, H, S, spr, max_len, mode, DIHIP_BF16,
-                                          0.0883883f, ws, wsb);
+    int rc = dihip_span_attn_decode_fused_sync(st, out, qkv, dk + (size_t)layer * B * spr, dv + (size_t)layer * B * spr, lens, tab, B, n, g, H, S, spr, max_len, mode, DIHIP_BF16,
+                                               0.0883883f, ws, wsb, in_launch ? sync : nullptr, in_launch ? syb : 0);
     if (rc) { printf("status %d: %s\n", rc, dihip_last_error()); exit(1); }
   };
   for (int l = 0; l < layers; ++l) launch(l);
@@ -45,7 +47,8 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 10; ++i) CK(hipGraphLaunch(ge, st));
   CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-  printf("fused attention + merge, B=%d L=%d kv_mode=%d: %.2f us per layer (graph of %d layers)\n", B, L, mode, ms * 1e3 / (10 * layers), layers);
+  printf("fused attention (%s merge), B=%d L=%d kv_mode=%d: %.2f us per layer (graph of %d layers)\n", in_launch ? "in-launch" : "second-launch", B, L, mode,
+         ms * 1e3 / (10 * layers), layers);
   // timeline of one launch
   size_t tb = (size_t)64 << 20; unsigned long long* tr; CK(hipMalloc(&tr, tb)); CK(hipMemset(tr, 0, tb));
   for (int l = 0; l < 3; ++l) launch(l);
@@ -55,9 +58,9 @@ int main(int argc, char** argv) {
   std::vector<unsigned long long> ht(tb / 8 / 64); CK(hipMemcpy(ht.data(), tr, ht.size() * 8, hipMemcpyDeviceToHost));
   unsigned long long t0 = ~0ull; size_t nw = 0;
   for (size_t w = 0; w < ht.size() / 8; ++w) if (ht[w * 8]) { t0 = std::min(t0, ht[w * 8]); nw = w + 1; }
-  const char* names[7] = {"entry", "kv loads issued", "q rotated", "new token done", "token loop done", "block merged", "end"};
+  const char* names[8] = {"entry", "kv loads issued", "q + new token", "token loop done", "records drained", "ticket known", "merged (last)", "end"};
   printf("  %zu waves; stamps (us after first wave start) min / median / max\n", nw);
-  for (int s = 0; s < 7; ++s) {
+  for (int s = 0; s < 8; ++s) {
     std::vector<double> v; for (size_t w = 0; w < nw; ++w) if (ht[w * 8 + s]) v.push_back((double)(ht[w * 8 + s] - t0) * 0.01);
     if (v.empty()) continue; std::sort(v.begin(), v.end());
     printf("    %-16s %7.2f %7.2f %7.2f\n", names[s], v.front(), v[v.size() / 2], v.back());

@@ -10,6 +10,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   echo "$ctr exit $?"
   ls $OUT/$ctr | head
 done
+HASH=$(cd $GRAFT_REPO_ROOT && python -c "import bench; print(bench.csrc_tree_hash())")
 python - <<PY
 # per-kernel averages -> $OUT/pmc_hbm_traffic.csv (the schema bench.py's pmc_traffic() reads from profiles/)
 import csv, glob, collections
@@ -26,9 +27,9 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             a = acc[r["Kernel_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
     for k, (n, v) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
         kb = v / n   # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB
-        rows.append((ctr, k, n, round(kb, 1), int(kb * 1024 * (2 if ctr == "FETCH_SIZE" else 1)), NOTE[ctr]))
+        rows.append((ctr, k, n, round(kb, 1), int(kb * 1024 * (2 if ctr == "FETCH_SIZE" else 1)), NOTE[ctr], "$HASH"))
         print("%-10s %-80s n=%5d  avg %.1f KB" % (ctr, k[:80], n, kb))
 with open("$OUT/pmc_hbm_traffic.csv", "w", newline="") as f:
-    w = csv.writer(f); w.writerow(["counter", "kernel", "dispatches", "avg_counter_KB_raw", "avg_bytes_corrected", "note"]); w.writerows(rows)
+    w = csv.writer(f); w.writerow(["counter", "kernel", "dispatches", "avg_counter_KB_raw", "avg_bytes_corrected", "note", "csrc_hash"]); w.writerows(rows)
 PY
 find $OUT -name "*.csv" -size +8M -delete
