@@ -45,6 +45,7 @@ constexpr int GEMV_RING = 8;  // 1 KiB chunks in flight per wave
 #define DIHIP_GEMV_RING_EARLY 4
 #endif
 constexpr int GEMV_RING_EARLY = DIHIP_GEMV_RING_EARLY;
+
 static_assert(GEMV_RING_EARLY >= 1 && GEMV_RING_EARLY <= GEMV_RING, "early slots: 1 .. ring");
 
 // ---- hand-scheduled weight stream ------------------------------------------------------------
@@ -609,6 +610,9 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
   }
   // Consume slot j -- everything older than the D-1 refills issued after it has landed -- and
   // refill it.  Steady state: every refill is a real chunk.
+  // (The second-dispatched half of the workgroup streams ~13 % slower than the first -- the two waves of a SIMD are
+  // arbitrated by age -- and finishes ~1.2 us later on the 72 MB launch.  Alternating s_setprio between the halves once
+  // per ring revolution did not change that: 14.95 vs 14.96 us, profiles/r03b_*; removed.)
   int c = 0;
   while (to_issue >= D) {
 #pragma unroll
@@ -621,6 +625,7 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
     to_issue -= D;
     c += D;
   }
+
   // last real refills, then dummies
   for (; c < total; c += D) {
 #pragma unroll

@@ -678,8 +678,8 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
   }
   if (static_tps) a.tps_static = ((max_seq_len + p.nsplits - 1) / p.nsplits + 31) & ~31;
   // in-launch merge: needs the caller's zero-initialised ticket words (dihip_span_attn_decode_fused_sync)
-  const bool merge_wt = merge_mode == 1 && p.nsplits > 1 && sync != nullptr &&
-                        sync_bytes >= (size_t)batch * n_groups * p.nchunks * sizeof(unsigned) && p.partial_bytes < (1ull << 31);
+  const bool merge_wt = merge_mode >= 1 && p.nsplits > 1 && sync != nullptr &&
+                        sync_bytes >= (size_t)batch * n_groups * p.nchunks * 128 && p.partial_bytes < (1ull << 31);
   if (merge_wt) {
     a.counters = reinterpret_cast<unsigned*>(sync);
     a.merge_wt = 1;
@@ -736,7 +736,8 @@ extern "C" {
 
 size_t dihip_span_attn_sync_bytes(int batch, int n_heads) {
   if (batch <= 0 || n_heads <= 0) return 0;
-  return ((size_t)batch * n_heads * sizeof(unsigned) + 255) & ~(size_t)255;
+  // one 128-byte line per (request, KV group, head chunk) -- at most one per head -- for the in-launch merge's arrival words
+  return (size_t)batch * n_heads * 128;
 }
 
 size_t dihip_span_attn_decode_workspace_bytes(int batch, int n_heads, int head_size, int max_seq_len, int num_cus) {

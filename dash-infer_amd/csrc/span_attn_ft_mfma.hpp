@@ -178,6 +178,10 @@ __device__ __forceinline__ void merge_split_records(const AttnArgs& a, RSRC rsrc
 // loads -- which are served past this CU's L1, and the writers' lines are not in any other L2 -- merges them in split order
 // (the arithmetic of span_attn_split_merge_kernel) and writes the FT output.  The ticket word is left at zero for the
 // next launch.  Thread -> (head h = e / 32, dims (e % 32) * 4 .. + 3).
+// (Measured alternatives, profiles/r03_attn_timeline.txt: "designated mergers" -- the workgroup of split s waits for all
+// arrivals and merges head s, so that a group's heads merge on 7 CUs in parallel -- shorten the merge reads from 2.6 to 1.2 us
+// but see the last arrival 1.4 us late through their poll: 10.6 vs 10.2 us per layer, removed; the hand-off as a whole
+// costs ~3 us (store drain ~1, ticket ~0.5, reads of freshly handed-off records ~1.5-2.5) either way.)
 template <int FT, int HC>
 __device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float* lds, unsigned* flag_lds, int b, int h0, int nh,
                                                        int split, unsigned* counter, unsigned long long* tr = nullptr) {
@@ -638,7 +642,8 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   }
   if constexpr (FUSED) {
     if (a.merge_wt) {
-      attn_block_epilogue_wt<FT, HC>(a, lds, flag_lds, b, h0, nh, split, a.counters + ((size_t)b * a.g + grp) * a.nchunks + hc,
+      attn_block_epilogue_wt<FT, HC>(a, lds, flag_lds, b, h0, nh, split,
+                                     a.counters + (((size_t)b * a.g + grp) * a.nchunks + hc) * 32,  // one 128-byte line each
                                      a.trace ? a.trace + (((size_t)bz * gy + by) * gx + bx) * 32 + (threadIdx.x >> 6) * 8 : nullptr);
       DIHIP_ATTN_STAMP(7);
       return;
