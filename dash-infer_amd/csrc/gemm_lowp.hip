@@ -7,6 +7,7 @@
 
 #include "gemm_lowp_launch.hpp"
 #include "gemv_stream_kernel.hpp"
+#include "gemm_prefill_kernel.hpp"
 #include "gemv_batch_kernel.hpp"
 #include "gemm_kslice_kernel.hpp"
 #include "gemm_panel_kernel.hpp"
@@ -721,6 +722,52 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
   }
   DIHIP_REQUIRE(!want_frag, DIHIP_PARAM_ERROR,
                 "gemm_lowp: the FRAG32 activation layout needs the small-batch kernel (see dihip_gemm_lowp_prefers_frag)");
+  // context phase (M >= 64 rows): 128 x 256 workgroup tiles, A through LDS, every weight byte read once per 128 rows
+  // (gemm_prefill_kernel.hpp).  DIHIP_GEMM_PREFILL=0 keeps the general kernel (A/B, diagnostics).
+  static int prefill_on = -1;
+  if (prefill_on < 0) {
+    const char* e = getenv("DIHIP_GEMM_PREFILL");
+    prefill_on = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (prefill_on && c.dtype == DIHIP_BF16 && c.pro == PRO_PLAIN && c.M >= 64 && (c.wbits == 4 || c.wbits == 8) && gemv_aligned &&
+      (d.group == 0 || d.group % d.KTILE == 0) && (c.epi != EPI_SWIGLU || (c.w1 && c.sz1))) {
+    PrefillArgs g{};
+    g.w0 = reinterpret_cast<const u32x4_t*>(c.w0);
+    g.w1 = reinterpret_cast<const u32x4_t*>(c.w1);
+    g.sz0 = reinterpret_cast<const uint32_t*>(c.sz0);
+    g.sz1 = reinterpret_cast<const uint32_t*>(c.sz1);
+    g.x = c.x;
+    g.ldx = c.ldx;
+    g.bias = c.bias;
+    g.residual = c.residual;
+    g.y = c.y;
+    g.ldy = c.N;
+    g.h_res = c.h_res;
+    g.h_out = c.h_out;
+    g.alpha = c.alpha;
+    g.act = c.act;
+    g.M = c.M;
+    g.N = c.N;
+    g.KT = d.KT;
+    g.NTILES = d.NTILES;
+    g.Gp = lowp_dims(4, c.N, c.K, c.group_size).Gp;
+    g.ktpg = d.group ? d.group / d.KTILE : (1 << 28);
+    const int tiles_per_block = dual ? PF_WAVES : PF_WAVES * PF_CW;
+    g.col_blocks = (d.NTILES + tiles_per_block - 1) / tiles_per_block;
+    const int blocks = g.col_blocks * ((c.M + PF_BM - 1) / PF_BM);
+    const bool gpt = g.ktpg == 1;
+    hipError_t e = hipErrorInvalidValue;
+#define PREFILL_GO(W_, EPI_, G_) \
+    if (c.wbits == W_ && c.epi == EPI_ && (int)gpt == G_) e = launch_gemm_prefill<W_, DIHIP_BF16, EPI_, G_>(g, blocks, stream);
+#define PREFILL_ALL(W_) PREFILL_GO(W_, EPI_STD, 0) PREFILL_GO(W_, EPI_STD, 1) PREFILL_GO(W_, EPI_SWIGLU, 0) PREFILL_GO(W_, EPI_SWIGLU, 1) \
+    PREFILL_GO(W_, EPI_ADDTO, 0) PREFILL_GO(W_, EPI_ADDTO, 1)
+    PREFILL_ALL(4) PREFILL_ALL(8)
+#undef PREFILL_ALL
+#undef PREFILL_GO
+    DIHIP_REQUIRE(e == hipSuccess, DIHIP_RUNTIME_ERROR, "gemm_prefill: launch failed (wbits=%d M=%d epi=%d): %s", c.wbits, c.M, c.epi,
+                  hipGetErrorString(e));
+    return DIHIP_SUCCESS;
+  }
   const GemmPlan p = make_plan(c.wbits, c.M, c.N, c.K, c.group_size, dual);
   DIHIP_REQUIRE((size_t)p.col_blocks * p.m_blocks * sizeof(unsigned) <= GEMM_SYNC_BYTES, DIHIP_EXCEED_LIMIT_ERROR,
                 "gemm_lowp: too many tiles for the sync buffer");

@@ -1,0 +1,280 @@
+// gemm_prefill_kernel.hpp -- weight-only (A16W8 / A16W4) GEMM for the CONTEXT phase (M >= 64 rows) on gfx950.
+//
+// The general kernel (gemm_lowp_kernel.hpp) keeps at most 32 activation rows per workgroup: a 2048-token prompt walks every
+// weight matrix 64 times and the context phase of Qwen2-7B ran at 9 % of the dense bf16 MFMA peak (profiles/r03f_bench_prefill_2048.json:
+// 119 ms, of which the attention is 1.5).  This kernel is the large-M member of the family -- replaces, for prefill shapes,
+// the reference's dequantise + cuBLAS fall-back and its 16816 tensor-core kernels (gemm_a16w8_kernel.h:239-331,
+// hgemm_a16w4_subc_32x256x32, gemm_a16w4_subc_kernel.cu:466-815):
+//
+//   * workgroup tile 128 rows x 256 columns (8 waves side by side in N, each 128 x 32 = 8 row tiles x 2 column tiles of
+//     v_mfma_f32_16x16x32: 16 accumulators), K walked in packed k-tiles (W4: 128 k, W8: 64 k);
+//   * A (activations, FT row-major) goes global -> registers -> LDS once per workgroup and k-tile, stored as the MFMA A
+//     fragments (one fragment = one contiguous 1 KiB: conflict-free ds_write_b128 / ds_read_b128), double-buffered: the loads of
+//     k-tile t + 1 are in flight while t is multiplied, ONE barrier per k-tile; every wave reads all 8 row tiles;
+//   * B (weights) never touches LDS: "dihip tile-major" packing makes a lane's 16-byte load the B fragment of its own column
+//     tile (x KSTEPS), and no two waves share a column tile;
+//   * the same exact-integer arithmetic as the decode kernels: q expands to 128 + q in FT with the magic-number trick, the MFMA
+//     sums exact products, and per quantisation group  y += s * (acc - (z + 128) * sum_k x)  on the f32 accumulator, with
+//     sum_k x per (row, k-tile) taken while A is staged (8-element partials, cross-lane adds over the 4 k-blocks of a row);
+//   * epilogues as everywhere: STD (alpha, bias, UnaryType activation, FT residual), SwiGLU over a gate / up pair (a wave's two
+//     column tiles are then the SAME 16 columns of the two matrices: 128 output columns per workgroup), f32 hidden-stream update.
+//
+// Host contract (gemm_lowp.hip: run_gemm): bf16 / f16 activations row-major with ldx % 8 == 0, 16-byte aligned; K a multiple of
+// the k-tile; group_size a multiple of the k-tile or per-channel.  Rows >= M are clamped on load and masked on store.
+#pragma once
+#include "gemm_lowp_kernel.hpp"
+#include "gemv_stream_kernel.hpp"  // ExpandV: the 128 + q expansion of the decode kernels
+
+namespace dihip {
+
+constexpr int PF_WAVES = 8;
+constexpr int PF_THREADS = PF_WAVES * 64;
+constexpr int PF_BM = 128;           // rows per workgroup (8 row tiles)
+constexpr int PF_RT = PF_BM / 16;    // row tiles
+constexpr int PF_CW = 2;             // column tiles per wave
+
+struct PrefillArgs {
+  const u32x4_t* w0;
+  const u32x4_t* w1;    // EPI_SWIGLU: "up" weight
+  const uint32_t* sz0;  // [NTILES][Gp][16] (scale | zero << 16)
+  const uint32_t* sz1;
+  const void* x;        // FT [M, ldx]
+  int ldx;
+  const void* bias;
+  const void* residual;  // FT [M, ldy]
+  void* y;               // FT [M, ldy]
+  int ldy;
+  const float* h_res;  // EPI_ADDTO
+  float* h_out;
+  float alpha;
+  int act;
+  int M, N;
+  int KT;      // k-tiles
+  int NTILES;  // 16-column tiles
+  int Gp;      // (scale, zero) groups stored per tile
+  int ktpg;    // k-tiles per quantisation group (per-channel: >= KT)
+  int col_blocks;
+};
+
+template <int WBITS>
+constexpr size_t prefill_lds_bytes() {
+  // 2 x A tile (PF_RT x KSTEPS fragments of 1 KiB) + 2 x 128 row sums
+  return (size_t)2 * PF_RT * WTraits<WBITS>::KSTEPS * 1024 + 2 * PF_BM * sizeof(float);
+}
+
+// (GPT -- one k-tile per quantisation group -- is a compile-time copy of the same code: the group test folds away)
+template <int WBITS, int FT, int EPI, int GPT>
+__global__ __launch_bounds__(PF_THREADS, 2) void gemm_prefill_kernel(const PrefillArgs a) {
+  using WT = WTraits<WBITS>;
+  using EX = ExpandV<WBITS, FT>;
+  constexpr int KSTEPS = WT::KSTEPS;
+  constexpr int KTILE = WT::KTILE;
+  constexpr bool DUAL = EPI == EPI_SWIGLU;
+  constexpr size_t ABYTES = (size_t)PF_RT * KSTEPS * 1024;  // one A tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* xsum = reinterpret_cast<float*>(smem + 2 * ABYTES);  // [2][PF_BM]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ni = lane & 15, kb = lane >> 4;
+  // consecutive workgroups share a column block (its weights stay hot in the L2s) and walk the rows
+  const int mblocks = (a.M + PF_BM - 1) / PF_BM;
+  const int cb = blockIdx.x / mblocks, mb = blockIdx.x - cb * mblocks;
+  const int m0 = mb * PF_BM;
+
+  // ---- this wave's column tiles -------------------------------------------------------------------
+  // STD / ADDTO: tiles cb * 16 + wave * 2 + {0, 1} of the one matrix;  SwiGLU: tile cb * 8 + wave of gate (c = 0) and up (c = 1)
+  int tile[PF_CW];
+  bool tile_ok[PF_CW];
+  const u32x4_t* wp[PF_CW];
+  const uint32_t* szp[PF_CW];
+#pragma unroll
+  for (int c = 0; c < PF_CW; ++c) {
+    const int t = DUAL ? cb * PF_WAVES + wave : (cb * PF_WAVES + wave) * PF_CW + c;
+    tile_ok[c] = t < a.NTILES;
+    tile[c] = min(t, a.NTILES - 1);
+    const bool second = DUAL && c == 1;
+    wp[c] = (second ? a.w1 : a.w0) + (size_t)tile[c] * a.KT * 64 + lane;
+    szp[c] = (second ? a.sz1 : a.sz0) + (size_t)tile[c] * a.Gp * 16 + ni;
+  }
+
+  // ---- A staging: wave w stages row tile w (all KSTEPS fragments of the k-tile): lane (kb, r) <- 16 bytes of row m0 + 16 w + r
+  const int arow = min(m0 + wave * 16 + ni, a.M - 1);  // rows past M re-read the last row (masked on store)
+  const char* xrow = reinterpret_cast<const char*>(a.x) + ((size_t)arow * a.ldx + kb * 8) * 2;
+  u32x4_t areg[KSTEPS];
+  u32x4_t wreg[PF_CW];
+  uint32_t szreg[PF_CW] = {0u, 0u};
+  auto load_a = [&](int kt) {
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) areg[ks] = *reinterpret_cast<const u32x4_t*>(xrow + ((size_t)kt * KTILE + ks * 32) * 2);
+  };
+  auto load_b = [&](int kt) {
+#pragma unroll
+    for (int c = 0; c < PF_CW; ++c) wreg[c] = __builtin_nontemporal_load(wp[c] + (size_t)kt * 64);
+  };
+  // stages the loaded k-tile into A buffer `buf`; its row sums go into (or are added to) the row-sum table of its quantisation
+  // group, `gbuf` = group parity (the lane with kb == 0 of a row's 4 k-block lanes owns that row's entry: no race)
+  auto stage_a = [&](int buf, int gbuf, bool group_start) {
+    unsigned char* dst = smem + buf * ABYTES + ((size_t)wave * KSTEPS * 64 + lane) * 16;
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      *reinterpret_cast<u32x4_t*>(dst + ks * 1024) = areg[ks];
+      float e[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        e[2 * q] = ft_bits_to_f32<FT>(areg[ks][q] & 0xFFFFu);
+        e[2 * q + 1] = ft_bits_to_f32<FT>(areg[ks][q] >> 16);
+      }
+      part += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+    }
+    part = rows_sum(part);  // over the 4 k-blocks of the row: the row's sum over this k-tile
+    if (kb == 0) {
+      float* p = xsum + gbuf * PF_BM + wave * 16 + ni;
+      *p = group_start ? part : *p + part;
+    }
+  };
+
+  // acc: exact integer products of the running quantisation group (MFMA); tot: the scaled result
+  f32x4_t acc[PF_RT][PF_CW], tot[PF_RT][PF_CW];
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int rt = 0; rt < PF_RT; ++rt)
+#pragma unroll
+    for (int c = 0; c < PF_CW; ++c) acc[rt][c] = tot[rt][c] = zero4;
+  uint32_t ex_mask = 0x000F000Fu, ex_magic = FT == DIHIP_BF16 ? 0x43004300u : 0x64006400u;
+  asm volatile("" : "+v"(ex_mask), "+v"(ex_magic));
+
+  // ---- prologue: k-tile 0 into buffer 0 ----------------------------------------------------------------
+  load_a(0);
+  load_b(0);
+#pragma unroll
+  for (int c = 0; c < PF_CW; ++c) szreg[c] = szp[c][0];
+  stage_a(0, 0, true);
+  __syncthreads();
+
+  int gl = 0;   // k-tiles of the running group done
+  int grp = 0;  // running group
+  for (int kt = 0; kt < a.KT; ++kt) {
+    const int buf = kt & 1;
+    u32x4_t wcur[PF_CW];
+#pragma unroll
+    for (int c = 0; c < PF_CW; ++c) wcur[c] = wreg[c];
+    const bool more = kt + 1 < a.KT;
+    if (more) {  // (uniform) the loads of the next k-tile fly while this one is multiplied
+      load_a(kt + 1);
+      load_b(kt + 1);
+    }
+    // ---- multiply: every wave reads all row tiles of the A tile
+    const unsigned char* abase = smem + buf * ABYTES + (size_t)lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      u32x4_t bf[PF_CW];
+#pragma unroll
+      for (int c = 0; c < PF_CW; ++c) bf[c] = EX::frag(wcur[c], ks, ex_mask, ex_magic);
+#pragma unroll
+      for (int rt = 0; rt < PF_RT; ++rt) {
+        const u32x4_t af = *reinterpret_cast<const u32x4_t*>(abase + ((size_t)rt * KSTEPS + ks) * 1024);
+#pragma unroll
+        for (int c = 0; c < PF_CW; ++c) acc[rt][c] = mfma16<FT>(af, bf[c], acc[rt][c]);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // the fragment reads of one k-step at a time: 32 live registers, not 128
+    }
+    // ---- at the group's end: scale / zero-point on the f32 accumulators, with the group's row sums
+    ++gl;
+    const bool gend = GPT || gl == a.ktpg || !more;
+    if (gend) {  // (uniform)
+      const float* xs = xsum + (grp & 1) * PF_BM + kb * 4;
+      float s_[PF_CW], nz_[PF_CW];
+#pragma unroll
+      for (int c = 0; c < PF_CW; ++c) {
+        s_[c] = ft_bits_to_f32<FT>(szreg[c] & 0xFFFFu);
+        nz_[c] = -(ft_bits_to_f32<FT>(szreg[c] >> 16) + EX::OFFSET);
+      }
+#pragma unroll
+      for (int rt = 0; rt < PF_RT; ++rt) {
+        const f32x4_t xv = *reinterpret_cast<const f32x4_t*>(xs + rt * 16);
+#pragma unroll
+        for (int c = 0; c < PF_CW; ++c) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tot[rt][c][r] = fmaf(s_[c], fmaf(nz_[c], xv[r], acc[rt][c][r]), tot[rt][c][r]);
+          acc[rt][c] = zero4;
+        }
+      }
+      gl = 0;
+      ++grp;
+      if (more) {
+#pragma unroll
+        for (int c = 0; c < PF_CW; ++c) szreg[c] = szp[c][(size_t)min(grp, a.Gp - 1) * 16];
+      }
+    }
+    // ---- the next A tile into the other buffer (its last readers passed the previous barrier); its row sums belong to
+    // group `grp` (already advanced when this k-tile closed one): that group's table was last read two groups ago
+    if (more) stage_a(buf ^ 1, grp & 1, gl == 0);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane (kb, ni) holds rows rt * 16 + kb * 4 + r of column tile c, column ni --------------------
+#pragma unroll
+  for (int rt = 0; rt < PF_RT; ++rt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + rt * 16 + kb * 4 + r;
+      if (m >= a.M) continue;
+      if constexpr (DUAL) {
+        const int n = tile[0] * 16 + ni;
+        if (tile_ok[0] && n < a.N) {
+          const float g = tot[rt][0][r], u = tot[rt][1][r];
+          store_ft<FT>(a.y, (size_t)m * a.ldy + n, (g / (1.f + expf(-g))) * u);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < PF_CW; ++c) {
+          const int n = tile[c] * 16 + ni;
+          if (!tile_ok[c] || n >= a.N) continue;
+          float v = tot[rt][c][r];
+          if constexpr (EPI == EPI_STD) {
+            v = a.alpha * v;
+            if (a.bias) v += load_ft<FT>(a.bias, n);
+            v = apply_act(v, a.act);
+            if (a.residual) v = ft_round<FT>(v) + load_ft<FT>(a.residual, (size_t)m * a.ldy + n);
+            store_ft<FT>(a.y, (size_t)m * a.ldy + n, v);
+          } else {
+            const float base = a.h_res ? a.h_res[(size_t)m * a.N + n] : 0.f;
+            a.h_out[(size_t)m * a.N + n] = base + a.alpha * v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int WBITS, int FT, int EPI, int GPT>
+hipError_t launch_gemm_prefill(const PrefillArgs& a, int blocks, hipStream_t stream);
+
+#define DIHIP_DEFINE_PREFILL_LAUNCH(WBITS, FT, EPI, GPT)                                                           \
+  template <>                                                                                                      \
+  hipError_t launch_gemm_prefill<WBITS, FT, EPI, GPT>(const PrefillArgs& a, int blocks, hipStream_t s) {           \
+    auto kern = gemm_prefill_kernel<WBITS, FT, EPI, GPT>;                                                          \
+    constexpr size_t lds = prefill_lds_bytes<WBITS>();                                                             \
+    if (lds > 64 * 1024) {                                                                                         \
+      static bool granted = false;                                                                                 \
+      if (!granted) {                                                                                              \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                             \
+        granted = true;                                                                                            \
+      }                                                                                                            \
+    }                                                                                                              \
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(PF_THREADS), lds, s, a);                                           \
+    return hipGetLastError();                                                                                      \
+  }
+
+#define DIHIP_DEFINE_PREFILL_LAUNCH_SET(WBITS, FT)          \
+  DIHIP_DEFINE_PREFILL_LAUNCH(WBITS, FT, EPI_STD, 0)        \
+  DIHIP_DEFINE_PREFILL_LAUNCH(WBITS, FT, EPI_STD, 1)        \
+  DIHIP_DEFINE_PREFILL_LAUNCH(WBITS, FT, EPI_SWIGLU, 0)     \
+  DIHIP_DEFINE_PREFILL_LAUNCH(WBITS, FT, EPI_SWIGLU, 1)     \
+  DIHIP_DEFINE_PREFILL_LAUNCH(WBITS, FT, EPI_ADDTO, 0)      \
+  DIHIP_DEFINE_PREFILL_LAUNCH(WBITS, FT, EPI_ADDTO, 1)
+
+}  // namespace dihip

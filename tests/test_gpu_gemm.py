@@ -594,3 +594,36 @@ def test_residual_gemm_with_fused_norm(ops, wbits, G, M):
                 y0 = ops.fused_norm_gemm(ref_h, gamma, 1e-6, p1, bias, sc)
                 y1 = ops.prenorm_gemm(xn, p1, bias, sc, M, x_layout=clay)
             assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Context-phase GEMM (gemm_prefill_kernel.hpp: M >= 64 rows, 128 x 256 workgroup tiles, A through LDS): every epilogue, ragged M
+# (rows past M clamped on load, masked on store), ragged N (last column tile / last workgroup partly outside), groups of one
+# k-tile (W4 g128, W8 g64), wider groups (W4 g256, W8 g128) and per-channel, against the oracle.
+@pytest.mark.gpu
+@pytest.mark.parametrize("wbits,G", [(4, 128), (4, 256), (4, -1), (8, -1), (8, 64), (8, 128)])
+@pytest.mark.parametrize("M,N,K", [(64, 512, 512), (200, 261, 1024), (999, 1056, 768), (2048, 640, 3584)])
+def test_prefill_gemm_all_epilogues(ops, M, N, K, wbits, G):
+    rng = np.random.default_rng(M + N + K + wbits + abs(G))
+    x, q, s, z = make_case(rng, M, N, K, G, wbits, "bf16", style="iq")
+    pw = ops.pack_lowp(to_dev(q), to_dev(s, "bf16"), to_dev(z, "bf16"), G, wbits)
+    xd = to_dev(x, "bf16")
+    sc = ops.Scratch(ops.lowp_workspace_bytes(wbits, M, N, K, G))
+    # STD: alpha, bias, activation, FT residual
+    bias = bf16_round(rng.normal(0, 0.3, N).astype(np.float32))
+    res = bf16_round(rng.normal(0, 1, (M, N)).astype(np.float32))
+    y = ops.gemm_lowp(xd, pw, bias=to_dev(bias, "bf16"), residual=to_dev(res, "bf16"), act="silu", alpha=0.5, scratch=sc)
+    pre = gemm_ref.gemm_a16wx(x, q, s, z, G, wbits, alpha=0.5, bias=bias, act="silu", ft="bf16")
+    assert_close(y.float().cpu().numpy(), bf16_round(pre + res), "bf16", what=f"prefill STD M{M} N{N} K{K}", pre=pre)
+    # f32 hidden-stream update
+    h = rng.normal(0, 1.5, (M, N)).astype(np.float32)
+    h2 = ops.fused_gemm_addto(xd, pw, to_dev(h), sc, M=M)
+    ref = h + gemm_ref.gemm_a16wx(x, q, s, z, G, wbits, round_out=False)
+    np.testing.assert_allclose(h2.cpu().numpy(), ref, rtol=2e-5, atol=3e-5 * np.abs(ref).max())
+    # SwiGLU over a gate / up pair (prenorm entry: PRO_PLAIN on normalised rows)
+    _, qu, su, zu = make_case(rng, 1, N, K, G, wbits, "bf16", style="iq")
+    pu = ops.pack_lowp(to_dev(qu), to_dev(su, "bf16"), to_dev(zu, "bf16"), G, wbits)
+    act = ops.prenorm_swiglu(xd, pw, pu, sc, M)
+    g = gemm_ref.gemm_a16wx(x, q, s, z, G, wbits, round_out=False).astype(np.float64)
+    u = gemm_ref.gemm_a16wx(x, qu, su, zu, G, wbits, round_out=False).astype(np.float64)
+    assert_close(act.float().cpu().numpy(), bf16_round(((g / (1 + np.exp(-g))) * u).astype(np.float32)), "bf16", what="prefill SwiGLU")
