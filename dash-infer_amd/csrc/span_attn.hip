@@ -551,7 +551,6 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
     return DIHIP_SA_PARAM_ERROR;
   }
   const AttnPlan p = attn_plan(batch, n, g, max_seq_len, num_cus, attn_use_mfma(mode, dtype));
-  (void)counters;  // kept in the signature: earlier versions merged in-kernel with arrival counters
   if (p.nsplits > 1 && (ws == nullptr || ws_bytes < p.partial_bytes)) {
     set_last_error("span_attn: workspace too small (%zu < %zu)", ws_bytes, p.partial_bytes);
     return DIHIP_SA_PARAM_ERROR;
@@ -564,13 +563,19 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
   a.seq_lens = seq_lens_dev;
   a.len_bias = len_bias;
   a.partials = reinterpret_cast<float*>(ws);
-  static int ticket_max = -1;  // DIHIP_ATTN_TICKET_MAX_WGS: in-kernel last-arriver merge up to this many workgroups (0 = never)
-  if (ticket_max < 0) {
-    const char* e = getenv("DIHIP_ATTN_TICKET_MAX_WGS");
-    ticket_max = e ? atoi(e) : 0;
+  // Split sequences: with the caller's ticket words (`sync`: dihip_span_attn_sync_bytes, zeroed once, one 128-byte line per
+  // (request, group, head chunk)) the partial records are merged INSIDE the launch -- write-through records, arrival ticket,
+  // the last workgroup merges (attn_block_epilogue_wt, round 3; the fenced last-arriver form of round 1 cost ~20 us per layer
+  // at batch 32 and is gone) -- else by span_attn_split_merge_kernel as a second launch.  DIHIP_ATTN_MERGE=launch: always the latter.
+  static int merge_in_launch = -1;
+  if (merge_in_launch < 0) {
+    const char* e = getenv("DIHIP_ATTN_MERGE");
+    merge_in_launch = (e && e[0] == 'l') ? 0 : 1;
   }
-  const bool ticket = counters != nullptr && p.nsplits > 1 && (long)p.nsplits * g * p.nchunks * batch <= ticket_max;
+  const bool ticket = merge_in_launch && counters != nullptr && p.nsplits > 1 && p.partial_bytes < (1ull << 31);
   a.counters = ticket ? counters : nullptr;
+  a.merge_wt = ticket ? 1 : 0;
+  a.partial_bytes = p.partial_bytes;
   a.B = batch;
   a.n = n;
   a.g = g;

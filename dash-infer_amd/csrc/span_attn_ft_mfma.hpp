@@ -9,10 +9,18 @@ namespace dihip {
 // `lds` ([wave][HC] records of ATTN_PSTRIDE floats).  Combines them and writes the output, or, for split
 // sequences, the block's partial record for span_attn_split_merge_kernel.
 template <int FT, int HC>
+__device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float* lds, unsigned* flag_lds, int b, int h0, int nh,
+                                                       int split, unsigned* counter, unsigned long long* tr);
+
+template <int FT, int HC>
 __device__ __forceinline__ void attn_block_epilogue(const AttnArgs& a, float* lds, unsigned* flag_lds, int b, int h0, int nh,
                                                     int split) {
   constexpr int H = 128;
   const int tid = threadIdx.x;
+  if (a.merge_wt) {  // in-launch merge of the split partials (ticket words from the caller): see attn_block_epilogue_wt
+    attn_block_epilogue_wt<FT, HC>(a, lds, flag_lds, b, h0, nh, split, a.counters + ((size_t)b * gridDim.y + blockIdx.y) * 32, nullptr);
+    return;
+  }
   __syncthreads();
   // thread -> (head, dim) pairs of the block result; kept in registers for the epilogue
   constexpr int PER_THREAD = (HC * H + ATTN_THREADS - 1) / ATTN_THREADS;
@@ -56,48 +64,7 @@ __device__ __forceinline__ void attn_block_epilogue(const AttnArgs& a, float* ld
         }
       }
     }
-    // The split partials are normally merged by span_attn_split_merge_kernel (next launch).  An in-kernel hand-off
-    // to the last-arriving workgroup needs an agent-scope release/acquire per workgroup (L2 write-back +
-    // invalidate): measured ~20 us per layer at batch 32 against ~3 us for the extra launch.  a.counters != null
-    // selects the hand-off (small grids only, see run_decode).
-    if (a.counters == nullptr) return;
-    unsigned* counter = a.counters + (size_t)b * gridDim.y + blockIdx.y;
-    if (!arrive_and_check_last(counter, (unsigned)a.nsplits, flag_lds)) return;
-#pragma unroll
-    for (int e = 0; e < PER_THREAD; ++e) {
-      const int idx = tid + e * ATTN_THREADS;
-      const int h = idx / H, d = idx - h * H;
-      if (h < nh) {
-        const float* base = a.partials + ((size_t)b * a.n + h0 + h) * a.nsplits * ATTN_PSTRIDE;
-        float mm = -INFINITY, ll = 0.f, oo = 0.f;
-        for (int sb = 0; sb < a.nsplits; sb += 16) {
-          float mv[16], lv[16], ov[16];
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const bool in = sb + j < a.nsplits;
-            const float* rec = base + (size_t)(in ? sb + j : 0) * ATTN_PSTRIDE;
-            mv[j] = in ? rec[H] : -INFINITY;
-            lv[j] = in ? rec[H + 1] : 0.f;
-            ov[j] = in ? rec[d] : 0.f;
-          }
-          float bmx = mm;
-#pragma unroll
-          for (int j = 0; j < 16; ++j) bmx = fmaxf(bmx, mv[j]);
-          const float carry = safe_exp_diff(mm, bmx);
-          ll *= carry;
-          oo *= carry;
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const float c = safe_exp_diff(mv[j], bmx);
-            ll = fmaf(lv[j], c, ll);
-            oo = fmaf(ov[j], c, oo);
-          }
-          mm = bmx;
-        }
-        bo[e] = oo;
-        bl[e] = ll;
-      }
-    }
+    return;  // merged by span_attn_split_merge_kernel (next launch)
   }
 #pragma unroll
   for (int e = 0; e < PER_THREAD; ++e) {
@@ -184,7 +151,7 @@ __device__ __forceinline__ void merge_split_records(const AttnArgs& a, RSRC rsrc
 // costs ~3 us (store drain ~1, ticket ~0.5, reads of freshly handed-off records ~1.5-2.5) either way.)
 template <int FT, int HC>
 __device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float* lds, unsigned* flag_lds, int b, int h0, int nh,
-                                                       int split, unsigned* counter, unsigned long long* tr = nullptr) {
+                                                       int split, unsigned* counter, unsigned long long* tr) {
   constexpr int H = 128;
   const int tid = threadIdx.x;
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.partials, 0, (int)a.partial_bytes, 0x00020000);
