@@ -325,7 +325,8 @@ def moe_layer_bench(args, torch, ops):
                                "not in this workload), hipGraph=on", "global_batch": T, "parallelism": "tp1", "layers": L},
         "step_hbm": {"algorithmic_bytes_per_rank": int(bytes_step), "achieved_GBps_per_gpu": round(gbs, 1),
                      "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4), "distinct_experts_per_step": distinct},
-        "roofline": {"bound": "hbm", "kernel": "dihip::gemv_stream_kernel<8, 2, 1, 0, *, 0, true> (expert GEMVs over (token, expert) slots)",
+        "roofline": {"bound": "hbm", "kernel": "dihip::gemv_stream_kernel<8, 2, 4, 0, *, 0, true> (expert GEMVs over GROUPS of up to 4 (token, expert) slots that picked "
+                               "the same expert; DIHIP_MOE_GROUP=0: <8, 2, 1, ...>, one slot per launch row)",
                      "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                      "traffic": None, "note": "whole-block figure: route + gate/up + down + combine launches"},
         "build_s": round(t_build, 1),
@@ -637,12 +638,12 @@ def main():
         out["invalid"] = "debug run with a truncated layer stack"
 
     if rank == 0 and cfg.moe is not None:
-        out["roofline"] = {"bound": "hbm", "kernel": "whole decode step (the routed experts' slot GEMVs dominate: dihip::gemv_stream_kernel<8, 2, 1, 0, *, 0, true>; "
+        out["roofline"] = {"bound": "hbm", "kernel": "whole decode step (the routed experts' grouped slot GEMVs dominate: dihip::gemv_stream_kernel<8, 2, 4, 0, *, 0, true>; "
                                                        "their block alone is --workload moe_layer)",
                            "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
                            "traffic": None, "traffic_source": None,
                            "note": "algorithmic bytes count every DISTINCT routed expert of a layer once per step; the slot kernels stream an "
-                                   "expert once per token that picked it"}
+                                   "expert once per GROUP of up to 4 slots that picked it (once per slot with DIHIP_MOE_GROUP=0)"}
     if rank == 0:
         try:
             if cfg.moe is not None:

@@ -244,7 +244,9 @@ int dihip_moe_experts(void* stream, int wbits, const void* x, const int32_t* exp
     const char* e = getenv("DIHIP_MOE_GROUP");
     group_on = (e && e[0] == '0') ? 0 : 1;
   }
-  const bool grouped = group_on && num_tokens > 1;
+  // (the grouping kernel is ONE workgroup scanning the slot list: fine for decode batches, a long serial launch for prefill-sized
+  // calls -- beyond 2048 slots the per-slot launches run instead)
+  const bool grouped = group_on && num_tokens > 1 && slots <= 2048;
   const int* slot_expert = experts;
   const int *rows = nullptr, *nrows = nullptr;
   if (grouped) {

@@ -804,7 +804,7 @@ class DecodeSession:
 
     def count_distinct_experts(self):
         """Mixture-of-experts models: one eager step on a copy of the state that records, per layer, how many DISTINCT local
-        experts the batch selected -- each is streamed once per token that picked it by the slot kernels, but algorithmically
+        experts the batch selected -- each is streamed once per group of up to 4 slots that picked it, but algorithmically
         once per step.  Sets self.routed_expert_bytes (added to algorithmic_bytes_per_step) and returns the per-layer counts."""
         assert self.model.cfg.moe is not None
         ids0, old0, new0 = self.ids.clone(), self.old_lens.clone(), self.new_lens.clone()
