@@ -245,8 +245,35 @@ def prefill_bench(args, torch, decoder, ops):
     attn_us = a0.elapsed_time(a1) / (5 * nl) * 1e3
     flops = 4.0 * n * H * L * L / 2.0   # causal: QK^T and PV, half the square
     tflops = flops / (attn_us * 1e-6) / 1e12
+    # every GEMM of a layer alone, the same way: layer 0's weights on resident activations, the product's own calls
+    lw = model.layers[0]
+    sc = ops.Scratch(max(ops.lowp_workspace_bytes(wbits, L, p.N, p.K, group) for p in (lw.qkv, lw.o, lw.gate, lw.down)), "cuda")
+    h = torch.randn(L, cfg.hidden, device="cuda") * 0.5
+    attn_in = (torch.randn(L, n * H, device="cuda") * 0.5).to(torch.bfloat16)
+    act_in = (torch.randn(L, lw.down.K, device="cuda") * 0.5).to(torch.bfloat16)
+    calls = {
+        "qkv_norm_gemm": (lambda: ops.fused_norm_gemm(h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sc), lw.qkv.N * lw.qkv.K),
+        "o_gemm_addto": (lambda: ops.fused_gemm_addto(attn_in, lw.o, h, sc, M=L), lw.o.N * lw.o.K),
+        "gate_up_swiglu_gemm": (lambda: ops.fused_norm_swiglu(h, lw.ln2, cfg.eps, lw.gate, lw.up, sc), 2 * lw.gate.N * lw.gate.K),
+        "down_gemm_addto": (lambda: ops.fused_gemm_addto(act_in, lw.down, h, sc, M=L), lw.down.N * lw.down.K),
+    }
+    gemms = {}
+    for name, (fn, nk) in calls.items():
+        fn()
+        torch.cuda.synchronize()
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record()
+        for _ in range(20):
+            fn()
+        g1.record()
+        torch.cuda.synchronize()
+        us = g0.elapsed_time(g1) / 20 * 1e3
+        gemms[name] = {"avg_us": round(us, 2), "tflops": round(2.0 * L * nk / (us * 1e-6) / 1e12, 1),
+                       "share_of_step": round(us * nl / (ms * 1e3), 4)}
     # GEMM flops of the step (2 M N K per projection) for the record
-    gemm_flops = 2.0 * L * sum(p.N * p.K for lw in model.layers for p in (lw.qkv, lw.o, lw.gate, lw.up, lw.down))
+    gemm_flops = 2.0 * L * sum(p.N * p.K for lw_ in model.layers for p in (lw_.qkv, lw_.o, lw_.gate, lw_.up, lw_.down))
+    dom = gemms["gate_up_swiglu_gemm"]
+    dom_flops = 2.0 * L * 2 * lw.gate.N * lw.gate.K
     out_d = {
         "metric": "prefill (context phase) tokens/sec, Qwen2-7B weight-only quantized, one 2048-token prompt",
         "value": round(L / (ms * 1e-3), 1), "unit": "tokens/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
@@ -255,9 +282,14 @@ def prefill_bench(args, torch, decoder, ops):
         "config": {"workload": f"Qwen2-7B prefill_2048: int{wbits} weight-only group {group}, 16-bit KV spans, batch 1, prompt {L} tokens, "
                                f"{nl} layers, eager launches (DecodeSession.prefill)", "global_batch": 1, "seq_len": L, "parallelism": "tp1",
                    "layers": nl},
-        "roofline": {"bound": "mfma", "kernel": "dihip::prefill_attn_kernel (causal flash attention, 28 query / 4 KV heads, head 128)",
-                     "achieved": round(tflops, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4),
-                     "traffic": None, "avg_launch_us": round(attn_us, 2), "algorithmic_flops_per_launch": flops},
+        # the kernel the context phase spends most of its time in (the launch includes the RMSNorm kernel in front of it)
+        "roofline": {"bound": "mfma", "kernel": "dihip::gemm_prefill_kernel<4, bf16, SwiGLU> (RMSNorm + gate/up weight-only GEMM + SwiGLU, M = 2048)",
+                     "achieved": dom["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(dom["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "traffic": None, "avg_launch_us": dom["avg_us"], "algorithmic_flops_per_launch": dom_flops},
+        "attention": {"kernel": "dihip::prefill_attn_kernel (causal flash attention, 28 query / 4 KV heads, head 128)", "tflops": round(tflops, 1),
+                      "frac_of_mfma_peak": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), "avg_launch_us": round(attn_us, 2),
+                      "algorithmic_flops_per_launch": flops},
+        "gemms": gemms,
         "context_phase": {"attention_share": round(attn_us * nl / (ms * 1e3), 4), "gemm_tflops_if_rest_were_gemm": round(
             gemm_flops / max(1e-9, (ms * 1e-3 - attn_us * nl * 1e-6)) / 1e12, 1), "host_wall_ms": round(t_wall * 1e3, 3)},
         "build_s": round(t_build, 1),

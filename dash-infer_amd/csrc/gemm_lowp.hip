@@ -752,7 +752,7 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
     g.NTILES = d.NTILES;
     g.Gp = lowp_dims(4, c.N, c.K, c.group_size).Gp;
     g.ktpg = d.group ? d.group / d.KTILE : (1 << 28);
-    const int tiles_per_block = dual ? PF_WAVES : PF_WAVES * PF_CW;
+    const int tiles_per_block = dual ? PF_WN * PF_CW / 2 : PF_WN * PF_CW;
     g.col_blocks = (d.NTILES + tiles_per_block - 1) / tiles_per_block;
     const int blocks = g.col_blocks * ((c.M + PF_BM - 1) / PF_BM);
     const bool gpt = g.ktpg == 1;

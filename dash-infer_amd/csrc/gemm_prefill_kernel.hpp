@@ -15,12 +15,26 @@
 //     tile (x KSTEPS), and no two waves share a column tile;
 //   * the same exact-integer arithmetic as the decode kernels: q expands to 128 + q in FT with the magic-number trick, the MFMA
 //     sums exact products, and per quantisation group  y += s * (acc - (z + 128) * sum_k x)  on the f32 accumulator, with
-//     sum_k x per (row, k-tile) taken while A is staged (8-element partials, cross-lane adds over the 4 k-blocks of a row);
+//     sum_k x per (row, k-tile) taken while A is staged -- four MFMAs against a fragment of ones per wave and k-tile (the VALU
+//     form cost 72 instructions per wave and k-tile: +3 % tokens/s);
 //   * epilogues as everywhere: STD (alpha, bias, UnaryType activation, FT residual), SwiGLU over a gate / up pair (a wave's two
 //     column tiles are then the SAME 16 columns of the two matrices: 128 output columns per workgroup), f32 hidden-stream update.
 //
 // Host contract (gemm_lowp.hip: run_gemm): bf16 / f16 activations row-major with ldx % 8 == 0, 16-byte aligned; K a multiple of
 // the k-tile; group_size a multiple of the k-tile or per-channel.  Rows >= M are clamped on load and masked on store.
+//
+// Where the time goes (round 3, SQ counters of the SwiGLU launch, profiles/r03_prefill_gemm_sq_counters.txt): 244 registers mean
+// one workgroup = two waves per SIMD; per wave and k-tile 68 MFMAs (16 cycles of the matrix pipe each) + 193 other VALU + 45 LDS +
+// 32 scalar instructions.  MFMA and VALU share the SIMD's one VALU-class issue slot per 4 cycles, so the two waves need
+// 2 x 261 x 4 = 2088 issue cycles next to 2176 cycles of matrix pipe: the loop only runs at the MFMA rate if every gap of every
+// MFMA carries exactly its three VALU instructions.  Measured: matrix pipe busy 39 % of the kernel (790-870 TFLOP/s), waves
+// issuing 31 %, issue-stalled 44 %, parked at waitcnt / barrier 25 %.  Tried and measured, none better than +-3 %: the loop
+// without per-k-step scheduling fences (kept, +3 % with s_setprio around the multiply), an explicit sched_group_barrier
+// interleave with software-pipelined expansion, a 2 x 4 wave grid (half the LDS reads, twice the expansions: -10 %), a ping-pong
+// schedule (two groups of four waves half a k-tile period apart so that each SIMD always has one multiplying wave: -7 %, or
+// -2 % with scalar instead of SLP-packed FMAs), scalar FMAs alone (-2 %).  The instruction mix is the limit: the fix-up
+// (2 FMA per accumulator element and group) and the 4-bit expansion (7 VALU per 8 weights) are inherent to multiplying the
+// integer weights in place; getting past ~35 % needs weights dequantised ahead of the GEMM (the reference's own large-M route).
 #pragma once
 #include "gemm_lowp_kernel.hpp"
 #include "gemv_stream_kernel.hpp"  // ExpandV: the 128 + q expansion of the decode kernels
@@ -30,8 +44,12 @@ namespace dihip {
 constexpr int PF_WAVES = 8;
 constexpr int PF_THREADS = PF_WAVES * 64;
 constexpr int PF_BM = 128;           // rows per workgroup (8 row tiles)
-constexpr int PF_RT = PF_BM / 16;    // row tiles
-constexpr int PF_CW = 2;             // column tiles per wave
+constexpr int PF_WM = 1;             // waves along M (a 2 x 4 grid with 4 x 4 tiles per wave measured 10 % slower: twice the expansions)
+constexpr int PF_WN = PF_WAVES / PF_WM;
+constexpr int PF_TR = PF_BM / 16;    // row tiles of the workgroup (= waves: wave w stages row tile w)
+constexpr int PF_RT = PF_TR / PF_WM; // row tiles per wave
+constexpr int PF_CW = 2 * PF_WM;     // column tiles per wave (the workgroup covers 256 columns either way)
+static_assert(PF_TR == PF_WAVES, "one staged row tile per wave");
 
 struct PrefillArgs {
   const u32x4_t* w0;
@@ -58,8 +76,8 @@ struct PrefillArgs {
 
 template <int WBITS>
 constexpr size_t prefill_lds_bytes() {
-  // 2 x A tile (PF_RT x KSTEPS fragments of 1 KiB) + 2 x 128 row sums
-  return (size_t)2 * PF_RT * WTraits<WBITS>::KSTEPS * 1024 + 2 * PF_BM * sizeof(float);
+  // 2 x A tile (PF_TR x KSTEPS fragments of 1 KiB) + 2 x 128 row sums
+  return (size_t)2 * PF_TR * WTraits<WBITS>::KSTEPS * 1024 + 2 * PF_BM * sizeof(float);
 }
 
 // (GPT -- one k-tile per quantisation group -- is a compile-time copy of the same code: the group test folds away)
@@ -70,30 +88,32 @@ __global__ __launch_bounds__(PF_THREADS, 2) void gemm_prefill_kernel(const Prefi
   constexpr int KSTEPS = WT::KSTEPS;
   constexpr int KTILE = WT::KTILE;
   constexpr bool DUAL = EPI == EPI_SWIGLU;
-  constexpr size_t ABYTES = (size_t)PF_RT * KSTEPS * 1024;  // one A tile
+  constexpr size_t ABYTES = (size_t)PF_TR * KSTEPS * 1024;  // one A tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* xsum = reinterpret_cast<float*>(smem + 2 * ABYTES);  // [2][PF_BM]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ni = lane & 15, kb = lane >> 4;
+  const int wm = wave / PF_WN, wn = wave - wm * PF_WN;  // this wave's place in the PF_WM x PF_WN grid
   // consecutive workgroups share a column block (its weights stay hot in the L2s) and walk the rows
   const int mblocks = (a.M + PF_BM - 1) / PF_BM;
   const int cb = blockIdx.x / mblocks, mb = blockIdx.x - cb * mblocks;
   const int m0 = mb * PF_BM;
 
   // ---- this wave's column tiles -------------------------------------------------------------------
-  // STD / ADDTO: tiles cb * 16 + wave * 2 + {0, 1} of the one matrix;  SwiGLU: tile cb * 8 + wave of gate (c = 0) and up (c = 1)
+  // STD / ADDTO: PF_CW consecutive tiles of the one matrix;  SwiGLU: PF_CW / 2 tiles of gate (c < PF_CW / 2) and the same of up
+  constexpr int HCW = PF_CW / 2;
   int tile[PF_CW];
   bool tile_ok[PF_CW];
   const u32x4_t* wp[PF_CW];
   const uint32_t* szp[PF_CW];
 #pragma unroll
   for (int c = 0; c < PF_CW; ++c) {
-    const int t = DUAL ? cb * PF_WAVES + wave : (cb * PF_WAVES + wave) * PF_CW + c;
+    const int t = DUAL ? (cb * PF_WN + wn) * HCW + (c % HCW) : (cb * PF_WN + wn) * PF_CW + c;
     tile_ok[c] = t < a.NTILES;
     tile[c] = min(t, a.NTILES - 1);
-    const bool second = DUAL && c == 1;
+    const bool second = DUAL && c >= HCW;
     wp[c] = (second ? a.w1 : a.w0) + (size_t)tile[c] * a.KT * 64 + lane;
     szp[c] = (second ? a.sz1 : a.sz0) + (size_t)tile[c] * a.Gp * 16 + ni;
   }
@@ -103,7 +123,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void gemm_prefill_kernel(const Prefi
   const char* xrow = reinterpret_cast<const char*>(a.x) + ((size_t)arow * a.ldx + kb * 8) * 2;
   u32x4_t areg[KSTEPS];
   u32x4_t wreg[PF_CW];
-  uint32_t szreg[PF_CW] = {0u, 0u};
+  uint32_t szreg[PF_CW] = {};
   auto load_a = [&](int kt) {
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) areg[ks] = *reinterpret_cast<const u32x4_t*>(xrow + ((size_t)kt * KTILE + ks * 32) * 2);
@@ -116,22 +136,23 @@ __global__ __launch_bounds__(PF_THREADS, 2) void gemm_prefill_kernel(const Prefi
   // group, `gbuf` = group parity (the lane with kb == 0 of a row's 4 k-block lanes owns that row's entry: no race)
   auto stage_a = [&](int buf, int gbuf, bool group_start) {
     unsigned char* dst = smem + buf * ABYTES + ((size_t)wave * KSTEPS * 64 + lane) * 16;
-    float part = 0.f;
+    // A = the staged fragment, B = ones: every column of the result tile is the row sum (lane (kb, ni): rows kb * 4 + r)
+    const u32x4_t ones = FT == DIHIP_BF16 ? u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}
+                                    : u32x4_t{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+    f32x4_t sx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       *reinterpret_cast<u32x4_t*>(dst + ks * 1024) = areg[ks];
-      float e[8];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        e[2 * q] = ft_bits_to_f32<FT>(areg[ks][q] & 0xFFFFu);
-        e[2 * q + 1] = ft_bits_to_f32<FT>(areg[ks][q] >> 16);
-      }
-      part += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+      sx = mfma16<FT>(areg[ks], ones, sx);
     }
-    part = rows_sum(part);  // over the 4 k-blocks of the row: the row's sum over this k-tile
-    if (kb == 0) {
-      float* p = xsum + gbuf * PF_BM + wave * 16 + ni;
-      *p = group_start ? part : *p + part;
+    if (ni == 0) {
+      f32x4_t* p = reinterpret_cast<f32x4_t*>(xsum + gbuf * PF_BM + wave * 16 + kb * 4);
+      if (group_start) {
+        *p = sx;
+      } else {
+        const f32x4_t o = *p;
+        *p = f32x4_t{o[0] + sx[0], o[1] + sx[1], o[2] + sx[2], o[3] + sx[3]};
+      }
     }
   };
 
@@ -167,6 +188,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void gemm_prefill_kernel(const Prefi
     }
     // ---- multiply: every wave reads all row tiles of the A tile
     const unsigned char* abase = smem + buf * ABYTES + (size_t)lane * 16;
+    __builtin_amdgcn_s_setprio(1);  // the multiplying wave wins the issue arbitration against its SIMD neighbour's VALU phase
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       u32x4_t bf[PF_CW];
@@ -174,17 +196,17 @@ __global__ __launch_bounds__(PF_THREADS, 2) void gemm_prefill_kernel(const Prefi
       for (int c = 0; c < PF_CW; ++c) bf[c] = EX::frag(wcur[c], ks, ex_mask, ex_magic);
 #pragma unroll
       for (int rt = 0; rt < PF_RT; ++rt) {
-        const u32x4_t af = *reinterpret_cast<const u32x4_t*>(abase + ((size_t)rt * KSTEPS + ks) * 1024);
+        const u32x4_t af = *reinterpret_cast<const u32x4_t*>(abase + ((size_t)(wm * PF_RT + rt) * KSTEPS + ks) * 1024);
 #pragma unroll
         for (int c = 0; c < PF_CW; ++c) acc[rt][c] = mfma16<FT>(af, bf[c], acc[rt][c]);
       }
-      __builtin_amdgcn_sched_barrier(0);  // the fragment reads of one k-step at a time: 32 live registers, not 128
     }
+    __builtin_amdgcn_s_setprio(0);
     // ---- at the group's end: scale / zero-point on the f32 accumulators, with the group's row sums
     ++gl;
     const bool gend = GPT || gl == a.ktpg || !more;
     if (gend) {  // (uniform)
-      const float* xs = xsum + (grp & 1) * PF_BM + kb * 4;
+      const float* xs = xsum + (grp & 1) * PF_BM + wm * PF_RT * 16 + kb * 4;
       float s_[PF_CW], nz_[PF_CW];
 #pragma unroll
       for (int c = 0; c < PF_CW; ++c) {
@@ -219,13 +241,16 @@ __global__ __launch_bounds__(PF_THREADS, 2) void gemm_prefill_kernel(const Prefi
   for (int rt = 0; rt < PF_RT; ++rt) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = m0 + rt * 16 + kb * 4 + r;
+      const int m = m0 + (wm * PF_RT + rt) * 16 + kb * 4 + r;
       if (m >= a.M) continue;
       if constexpr (DUAL) {
-        const int n = tile[0] * 16 + ni;
-        if (tile_ok[0] && n < a.N) {
-          const float g = tot[rt][0][r], u = tot[rt][1][r];
-          store_ft<FT>(a.y, (size_t)m * a.ldy + n, (g / (1.f + expf(-g))) * u);
+#pragma unroll
+        for (int c = 0; c < HCW; ++c) {
+          const int n = tile[c] * 16 + ni;
+          if (tile_ok[c] && n < a.N) {
+            const float g = tot[rt][c][r], u = tot[rt][HCW + c][r];
+            store_ft<FT>(a.y, (size_t)m * a.ldy + n, (g / (1.f + expf(-g))) * u);
+          }
         }
       } else {
 #pragma unroll

@@ -1,14 +1,14 @@
 #!/bin/bash
 # One gpurun call for the end of a round: the GPU test suite, the bench line of every workload, the rocprofv3 kernel summary of
 # the headline bench and the PMC traffic passes.  Everything lands under gpurun_out/$TAG; copy what is to be judged to profiles/.
-#   gpurun --timeout 1500 -- 'TAG=r02z bash tools/gpu_round_end.sh'
+#   gpurun --timeout 2400 -- 'TAG=r03z bash tools/gpu_round_end.sh'
 TAG=${TAG:-rend}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 if [ -z "$SKIP_TESTS" ]; then
-  timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $OUT/pytest_gpu.log
+  DIHIP_FULL_DEPTH_ABLATION=${ABLATION:-0} timeout 1500 python -m pytest tests -m gpu -q -s 2>&1 | grep -E "FULL DEPTH|configs\[|7B-width|operator graph|passed|failed|error" | cut -c1-900 > $OUT/pytest_gpu.log
   tail -3 $OUT/pytest_gpu.log
 fi
 timeout 400 python bench.py > $OUT/bench_int4_b1.json 2> $OUT/bench_int4_b1.err
@@ -18,7 +18,7 @@ d = json.load(open("$OUT/bench_int4_b1.json"))
 print("int4_b1", d["value"], d["ms_per_step"], d["step_hbm"]["frac_of_peak"], d["roofline"]["frac"], {k: v["avg_us"] for k, v in d["kernels"].items()})
 print("cpu_baseline", d.get("cpu_baseline"))
 PY
-for w in int8_b1 int4_b32_u4kv cfg3_rank moe_layer cfg5_moe; do
+for w in int8_b1 int4_b32_u4kv cfg3_rank moe_layer cfg5_moe prefill_2048; do
   timeout 300 python bench.py --workload $w --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err
   python - <<PY
 import json
