@@ -755,6 +755,7 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
     const int tiles_per_block = dual ? PF_WN * PF_CW / 2 : PF_WN * PF_CW;
     g.col_blocks = (d.NTILES + tiles_per_block - 1) / tiles_per_block;
     const int blocks = g.col_blocks * ((c.M + PF_BM - 1) / PF_BM);
+    g.trace = debug_trace_buffer((size_t)blocks * PF_WAVES * 4 * 8 * sizeof(unsigned long long));
     const bool gpt = g.ktpg == 1;
     hipError_t e = hipErrorInvalidValue;
 #define PREFILL_GO(W_, EPI_, G_) \

@@ -72,6 +72,7 @@ struct PrefillArgs {
   int Gp;      // (scale, zero) groups stored per tile
   int ktpg;    // k-tiles per quantisation group (per-channel: >= KT)
   int col_blocks;
+  unsigned long long* trace;  // per-wave cycle stamps (library built with -DDIHIP_PF_TRACE, tools/prefill_trace.py)
 };
 
 template <int WBITS>
@@ -174,10 +175,21 @@ __global__ __launch_bounds__(PF_THREADS, 2) void gemm_prefill_kernel(const Prefi
   stage_a(0, 0, true);
   __syncthreads();
 
+#ifdef DIHIP_PF_TRACE
+  // k-tiles 8..11 of every workgroup: 8 stamps per k-tile (loop top, after each k-step, after the fix-up, after staging, after the barrier)
+#define DIHIP_PF_STAMP(I)                                                                                                \
+  do {                                                                                                                   \
+    if (a.trace && lane == 0 && kt >= 8 && kt < 12)                                                                       \
+      a.trace[(((size_t)blockIdx.x * PF_WAVES + wave) * 4 + (kt - 8)) * 8 + (I)] = __builtin_readcyclecounter();         \
+  } while (0)
+#else
+#define DIHIP_PF_STAMP(I) do { } while (0)
+#endif
   int gl = 0;   // k-tiles of the running group done
   int grp = 0;  // running group
   for (int kt = 0; kt < a.KT; ++kt) {
     const int buf = kt & 1;
+    DIHIP_PF_STAMP(0);
     u32x4_t wcur[PF_CW];
 #pragma unroll
     for (int c = 0; c < PF_CW; ++c) wcur[c] = wreg[c];
@@ -200,6 +212,12 @@ __global__ __launch_bounds__(PF_THREADS, 2) void gemm_prefill_kernel(const Prefi
 #pragma unroll
         for (int c = 0; c < PF_CW; ++c) acc[rt][c] = mfma16<FT>(af, bf[c], acc[rt][c]);
       }
+#ifdef DIHIP_PF_TRACE
+      if (ks == 0) DIHIP_PF_STAMP(1);
+      if (ks == 1) DIHIP_PF_STAMP(2);
+      if (ks == 2) DIHIP_PF_STAMP(3);
+      if (ks == 3) DIHIP_PF_STAMP(4);
+#endif
     }
     __builtin_amdgcn_s_setprio(0);
     // ---- at the group's end: scale / zero-point on the f32 accumulators, with the group's row sums
@@ -232,9 +250,13 @@ __global__ __launch_bounds__(PF_THREADS, 2) void gemm_prefill_kernel(const Prefi
     }
     // ---- the next A tile into the other buffer (its last readers passed the previous barrier); its row sums belong to
     // group `grp` (already advanced when this k-tile closed one): that group's table was last read two groups ago
+    DIHIP_PF_STAMP(5);
     if (more) stage_a(buf ^ 1, grp & 1, gl == 0);
+    DIHIP_PF_STAMP(6);
     __syncthreads();
+    DIHIP_PF_STAMP(7);
   }
+#undef DIHIP_PF_STAMP
 
   // ---- epilogue: lane (kb, ni) holds rows rt * 16 + kb * 4 + r of column tile c, column ni --------------------
 #pragma unroll
