@@ -168,16 +168,14 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_mov_f32<0x140>(v);  // row_mirror: the other half of the 16
   return rows_sum(v);
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+__device__ __forceinline__ float wave_max(float v) {  // same moves as wave_sum (max is order-independent: same bits as any tree)
+  v = fmaxf(v, dpp_mov_f32<0xB1>(v));
+  v = fmaxf(v, dpp_mov_f32<0x4E>(v));
+  v = fmaxf(v, dpp_mov_f32<0x141>(v));
+  v = fmaxf(v, dpp_mov_f32<0x140>(v));
+  return rows_max(v);
 }
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
-}
+__device__ __forceinline__ float wave_min(float v) { return -wave_max(-v); }  // min(a, b) = -max(-a, -b) bit for bit (no NaNs here)
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {  // allspark UnaryType

@@ -314,6 +314,14 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
   const int tb0 = t0 + wave * MF_TOK;
   const bool active = tb0 < t1;
   Buf ba, bb;
+#if defined(DIHIP_GEMV_TRACE) && DIHIP_GEMV_TRACE
+  unsigned long long* const trw = a.trace ? a.trace + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + wave * 8) : nullptr;
+#define DIHIP_U4_STAMP(I) do { if (trw) trw[I] = wall_clock64(); } while (0)
+#else
+  unsigned long long* const trw = nullptr;
+#define DIHIP_U4_STAMP(I) do { } while (0)
+#endif
+  DIHIP_U4_STAMP(0);  // entry (lengths and span table base read)
   if (active) issue(ba, tb0);
 
   // ---- Q as the B operand: lane (kb, head ni) holds dims kb*32 + ks*8 + e in the order the nibble expansion
@@ -433,15 +441,18 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
     }
   };
 
+  DIHIP_U4_STAMP(1);  // first loads issued, q fragments built
   if (active) {
     constexpr int STEP = 4 * MF_TOK;  // the 4 waves interleave 32-token blocks
     for (int tb = tb0; tb < t1; tb += 2 * STEP) {
       issue(bb, tb + STEP);  // unconditional (clamped inside): see the note in the VALU kernel
       process(ba, tb);
+      if (tb == tb0) DIHIP_U4_STAMP(2);  // first 32 tokens done
       issue(ba, tb + 2 * STEP);
       if (tb + STEP < t1) process(bb, tb + STEP);
     }
   }
+  DIHIP_U4_STAMP(3);  // token loop done
   // ---- totals of the head over the 4 token rows (kb), then the record the shared epilogue expects
   l = rows_sum(l);
   czero = rows_sum(czero);
@@ -463,7 +474,9 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
       rec[H + 1] = l;
     }
   }
-  attn_block_epilogue<DIHIP_BF16, HC>(a, lds, flag_lds, b, h0, nh, split);
+  attn_block_epilogue<DIHIP_BF16, HC>(a, lds, flag_lds, b, h0, nh, split, trw);
+  DIHIP_U4_STAMP(7);
+#undef DIHIP_U4_STAMP
 }
 
 // ---- 16-bit KV cache (bf16 / f16, the default cache mode) on the matrix cores -----------------------------
@@ -593,6 +606,7 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
     a.out_frag_mt = batch > 16 ? 2 : 1;
   }
   const dim3 grid(p.nsplits, g * p.nchunks, batch);
+  a.trace = debug_trace_buffer((size_t)p.nsplits * g * p.nchunks * batch * 32 * sizeof(unsigned long long));
   bool ok = true;
   if (p.mfma && mode == DIHIP_KV_U4) {
     hipLaunchKernelGGL(span_attn_u4_mfma_kernel, grid, dim3(ATTN_THREADS), 0, s, a);

@@ -14,11 +14,11 @@ __device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float*
 
 template <int FT, int HC>
 __device__ __forceinline__ void attn_block_epilogue(const AttnArgs& a, float* lds, unsigned* flag_lds, int b, int h0, int nh,
-                                                    int split) {
+                                                    int split, unsigned long long* tr = nullptr) {
   constexpr int H = 128;
   const int tid = threadIdx.x;
   if (a.merge_wt) {  // in-launch merge of the split partials (ticket words from the caller): see attn_block_epilogue_wt
-    attn_block_epilogue_wt<FT, HC>(a, lds, flag_lds, b, h0, nh, split, a.counters + ((size_t)b * gridDim.y + blockIdx.y) * 32, nullptr);
+    attn_block_epilogue_wt<FT, HC>(a, lds, flag_lds, b, h0, nh, split, a.counters + ((size_t)b * gridDim.y + blockIdx.y) * 32, tr);
     return;
   }
   __syncthreads();

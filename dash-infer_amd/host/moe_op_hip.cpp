@@ -131,12 +131,22 @@ class MoeA16W8HIP : public AsOperator {
     AsTensor* wsp = tensor_map_->at("workspace").get();
     if (x->GetDataType() != ftype_) return AsStatus::ALLSPARK_PARAM_ERROR;
     hipStream_t s = static_cast<const HIPContext*>(ctx_)->GetStream();
-    AS_CHECK_STATUS(FromDihip(dihip_moe_route_ep(s, lg->GetDataPtr(), total_token_, num_expert_, top_k_, (float*)experts_score_->GetDataPtr(),
-                                                 (int32_t*)topk_indice_->GetDataPtr(), DihipDtype(lg->GetDataType()), ep_first_, ep_num_)));
-    return FromDihip(dihip_moe_experts(s, 8, x->GetDataPtr(), (const int32_t*)topk_indice_->GetDataPtr(), (const float*)experts_score_->GetDataPtr(),
-                                       gate_w_->GetDataPtr(), gate_sz_->GetDataPtr(), up_w_->GetDataPtr(), up_sz_->GetDataPtr(),
-                                       down_w_->GetDataPtr(), down_sz_->GetDataPtr(), total_token_, top_k_, hidden_, proj_, group_size_,
-                                       y->GetDataPtr(), wsp->GetDataPtr(), wsp->GetSizeInByte(), DihipDtype(ftype_)));
+    // decode batches: routing and the same-expert slot grouping in one launch (dihip_moe_route_grouped); the operator has one
+    // output tensor, so the finalize-routing launch stays (the fused decode step folds it into its combine, dihip_moe_combine)
+    const bool one_launch_route = total_token_ > 1 && (int64_t)total_token_ * top_k_ <= 2048 && lg->GetDataType() != FLOAT32;
+    if (one_launch_route) {
+      AS_CHECK_STATUS(FromDihip(dihip_moe_route_grouped(s, lg->GetDataPtr(), total_token_, num_expert_, top_k_, (float*)experts_score_->GetDataPtr(),
+                                                        (int32_t*)topk_indice_->GetDataPtr(), DihipDtype(lg->GetDataType()), ep_first_, ep_num_,
+                                                        hidden_, proj_, wsp->GetDataPtr(), wsp->GetSizeInByte())));
+    } else {
+      AS_CHECK_STATUS(FromDihip(dihip_moe_route_ep(s, lg->GetDataPtr(), total_token_, num_expert_, top_k_, (float*)experts_score_->GetDataPtr(),
+                                                   (int32_t*)topk_indice_->GetDataPtr(), DihipDtype(lg->GetDataType()), ep_first_, ep_num_)));
+    }
+    return FromDihip(dihip_moe_experts_ex(s, 8, x->GetDataPtr(), (const int32_t*)topk_indice_->GetDataPtr(), (const float*)experts_score_->GetDataPtr(),
+                                          gate_w_->GetDataPtr(), gate_sz_->GetDataPtr(), up_w_->GetDataPtr(), up_sz_->GetDataPtr(),
+                                          down_w_->GetDataPtr(), down_sz_->GetDataPtr(), total_token_, top_k_, hidden_, proj_, group_size_,
+                                          y->GetDataPtr(), wsp->GetDataPtr(), wsp->GetSizeInByte(), DihipDtype(ftype_),
+                                          one_launch_route ? DIHIP_MOE_PREGROUPED : 0));
   }
 
  private:

@@ -158,17 +158,44 @@ def moe_shared_combine(h_out, h_res, moe_out, shared_out, shared_gate):
     return h_out
 
 
-def moe_experts(x, experts, scores, gate, up, down, ws=None, out=None):
+MOE_PREGROUPED, MOE_NO_FINALIZE = 1, 2
+MOE_GROUP_MAX_SLOTS = 2048
+
+
+def moe_experts(x, experts, scores, gate, up, down, ws=None, out=None, flags=0):
+    """flags: MOE_PREGROUPED (the group tables in `ws` come from moe_route_grouped), MOE_NO_FINALIZE (the slot outputs stay in
+    `ws` for moe_combine; nothing is written to `out`)."""
     T, hidden = x.shape
     top_k = experts.shape[1]
     proj = gate.N
     need = int(lib().dihip_moe_workspace_bytes(T, top_k, hidden, proj))
     ws = ws if ws is not None else torch.empty(need, dtype=torch.uint8, device=x.device)
-    out = out if out is not None else torch.empty(T, hidden, dtype=x.dtype, device=x.device)
-    check(lib().dihip_moe_experts(cur_stream(), gate.wbits, ptr(x), ptr(experts), ptr(scores), ptr(gate.w), ptr(gate.sz), ptr(up.w),
-                                  ptr(up.sz), ptr(down.w), ptr(down.sz), T, top_k, hidden, proj, gate.group, ptr(out), ptr(ws),
-                                  ws.numel(), dt_code(x)), "dihip_moe_experts")
+    if not flags & MOE_NO_FINALIZE:
+        out = out if out is not None else torch.empty(T, hidden, dtype=x.dtype, device=x.device)
+    check(lib().dihip_moe_experts_ex(cur_stream(), gate.wbits, ptr(x), ptr(experts), ptr(scores), ptr(gate.w), ptr(gate.sz), ptr(up.w),
+                                     ptr(up.sz), ptr(down.w), ptr(down.sz), T, top_k, hidden, proj, gate.group, ptr(out), ptr(ws),
+                                     ws.numel(), dt_code(x), int(flags)), "dihip_moe_experts_ex")
     return out
+
+
+def moe_route_grouped(logits, top_k, hidden, proj, ws, ep=None, scores=None, experts=None):
+    """moe_route + the slot grouping of moe_experts in one launch (decode batches: 1 < T, T * top_k <= MOE_GROUP_MAX_SLOTS);
+    follow with moe_experts(..., ws=ws, flags=MOE_PREGROUPED)."""
+    T, E = logits.shape
+    scores = scores if scores is not None else torch.empty(T, top_k, dtype=torch.float32, device=logits.device)
+    experts = experts if experts is not None else torch.empty(T, top_k, dtype=torch.int32, device=logits.device)
+    first, count = ep if ep is not None else (0, E)
+    check(lib().dihip_moe_route_grouped(cur_stream(), ptr(logits), T, E, top_k, ptr(scores), ptr(experts), dt_code(logits), first, count,
+                                        hidden, proj, ptr(ws), ws.numel()), "dihip_moe_route_grouped")
+    return scores, experts
+
+
+def moe_combine(h_out, h_res, ws, scores, experts, shared_out, shared_gate, proj):
+    """finalize-routing over the slot outputs moe_experts(..., flags=MOE_NO_FINALIZE) left in `ws` + moe_shared_combine's tail."""
+    T, hidden = shared_out.shape
+    check(lib().dihip_moe_combine(cur_stream(), ptr(h_out), ptr(h_res), ptr(ws), ptr(scores), ptr(experts), ptr(shared_out),
+                                  ptr(shared_gate), T, experts.shape[1], hidden, proj, dt_code(shared_out)), "dihip_moe_combine")
+    return h_out
 
 
 ACT_ROWMAJOR, ACT_FRAG32 = 0, 1

@@ -202,6 +202,22 @@ int dihip_calc_expert(void* stream, void* out, const void* in, const void* exper
 int dihip_moe_shared_combine(void* stream, float* h_out, const float* h_res, const void* moe_out,
                              const void* shared_out, const void* shared_gate, int num_tokens, int hidden,
                              int dtype);
+/* The decode block in fewer launches (bit-identical to the calls above; at most 2048 (token, expert) slots, more than one token):
+ *   dihip_moe_route_grouped : dihip_moe_route_ep + the (expert, <= 4 slots) grouping dihip_moe_experts would launch, in one
+ *                             workgroup; the tables go to `ws` (>= dihip_moe_workspace_bytes) where dihip_moe_experts_ex expects them
+ *   dihip_moe_experts_ex    : flags DIHIP_MOE_PREGROUPED (skip the grouping launch), DIHIP_MOE_NO_FINALIZE (leave the slot
+ *                             outputs in `ws`; `out` may be NULL)
+ *   dihip_moe_combine       : finalize-routing (sum_k score * slot output, rounded to FT) + dihip_moe_shared_combine's tail */
+#define DIHIP_MOE_PREGROUPED 1
+#define DIHIP_MOE_NO_FINALIZE 2
+int dihip_moe_route_grouped(void* stream, const void* router_logits, int num_tokens, int num_experts, int top_k, float* scores,
+                            int32_t* experts, int dtype, int ep_first, int ep_count, int hidden, int proj, void* ws, size_t ws_bytes);
+int dihip_moe_experts_ex(void* stream, int wbits, const void* x, const int32_t* experts, const float* scores,
+                         const void* gate_packed, const void* gate_sz, const void* up_packed, const void* up_sz,
+                         const void* down_packed, const void* down_sz, int num_tokens, int top_k, int hidden, int proj,
+                         int group_size, void* out, void* ws, size_t ws_bytes, int dtype, int flags);
+int dihip_moe_combine(void* stream, float* h_out, const float* h_res, const void* ws, const float* scores, const int32_t* experts,
+                      const void* shared_out, const void* shared_gate, int num_tokens, int top_k, int hidden, int proj, int dtype);
 
 /* =============================================================================================
  * 2. KV span writers (replace csrc/core/kernel/cuda/cuda_kernel_span_cache.h:12-41)

@@ -192,3 +192,45 @@ def test_grouped_experts_equal_the_per_token_calls(ops, wbits, G, T, E, k):
     again = ops.moe_experts(x, experts, scores, gate, up, down)
     torch.cuda.synchronize()
     assert torch.equal(again, whole)
+
+
+@pytest.mark.parametrize("wbits,G,T,E,k", [(8, -1, 16, 64, 8), (4, 128, 9, 6, 3), (8, 128, 2, 5, 1), (8, -1, 33, 64, 8)])
+def test_fewer_launch_block_is_bit_identical(ops, wbits, G, T, E, k):
+    """dihip_moe_route_grouped + dihip_moe_experts_ex(PREGROUPED | NO_FINALIZE) + dihip_moe_combine against the separate calls
+    (route, experts with its own grouping launch and finalize kernel, shared_combine): the same scores / expert ids, the same
+    group tables, and the same f32 hidden rows bit for bit -- whole stack and an expert-parallel window, with and without the
+    residual rows (ranks > 0 pass none)."""
+    rng = np.random.default_rng(T * 11 + E + k)
+    hidden, proj = 256, 384
+    gate = pack(ops, *make_experts(rng, E, proj, hidden, G, wbits), G, wbits)
+    up = pack(ops, *make_experts(rng, E, proj, hidden, G, wbits), G, wbits)
+    down = pack(ops, *make_experts(rng, E, hidden, proj, G, wbits), G, wbits)
+    x = dev(bf16_round(rng.normal(0, 1, (T, hidden)).astype(np.float32)), torch.bfloat16)
+    logits = dev(bf16_round(rng.normal(0, 2, (T, E)).astype(np.float32)), torch.bfloat16)
+    shared = dev(bf16_round(rng.normal(0, 1, (T, hidden)).astype(np.float32)), torch.bfloat16)
+    sig = dev(bf16_round(rng.uniform(0, 1, (T, 1)).astype(np.float32)), torch.bfloat16)
+    h = dev(rng.normal(0, 1, (T, hidden)).astype(np.float32), torch.float32)
+    nbytes = int(ops.lib().dihip_moe_workspace_bytes(T, k, hidden, proj))
+    for ep in (None, (0, max(1, E // 2))):
+        for with_res in (True, False):
+            s0, e0 = ops.moe_route(logits, k, ep=ep)
+            moe_out = ops.moe_experts(x, e0, s0, gate, up, down)
+            ref = torch.empty_like(h)
+            ops.moe_shared_combine(ref, h if with_res else None, moe_out, shared, sig)
+            ws = torch.full((nbytes,), 0xAB, dtype=torch.uint8, device="cuda")
+            s1, e1 = ops.moe_route_grouped(logits, k, hidden, proj, ws, ep=ep)
+            assert torch.equal(s0, s1) and torch.equal(e0, e1)
+            assert ops.moe_experts(x, e1, s1, gate, up, down, ws=ws, flags=ops.MOE_PREGROUPED | ops.MOE_NO_FINALIZE) is None
+            got = torch.empty_like(h)
+            ops.moe_combine(got, h if with_res else None, ws, s1, e1, shared, sig, proj)
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref), f"ep={ep} residual={with_res}: max diff {(got - ref).abs().max()}"
+
+
+def test_fewer_launch_block_rejects_what_it_does_not_serve(ops):
+    logits = torch.zeros(1, 8, dtype=torch.bfloat16, device="cuda")
+    ws = torch.zeros(int(ops.lib().dihip_moe_workspace_bytes(300, 8, 64, 64)), dtype=torch.uint8, device="cuda")
+    with pytest.raises(Exception):
+        ops.moe_route_grouped(logits, 2, 64, 64, ws)                       # one token: its top-k experts are distinct, no groups
+    with pytest.raises(Exception):
+        ops.moe_route_grouped(torch.zeros(300, 8, dtype=torch.bfloat16, device="cuda"), 8, 64, 64, ws)   # 2400 slots > 2048
