@@ -158,6 +158,10 @@ static GemmPlan make_plan(int wbits, int M, int N, int K, int group_size, bool d
   const int units = (d.KT + granule - 1) / granule;
   int want = (int)std::max<long>(1, target_blocks / std::max<long>(1, (long)p.col_blocks * p.m_blocks));
   want = std::min(want, units);
+  // a skinny unquantised matrix (the MoE router, hidden -> 64 experts; the shared expert's gate, hidden -> 1) is ONE column block:
+  // its last-arriving workgroup sums every split's partial tile alone -- 112 splits of one k-tile took 19.8 us (profiles/r03u),
+  // most of it that serial sum
+  if (wbits == 16 && (long)p.col_blocks * p.m_blocks <= 2) want = std::min(want, 16);
   int units_per_split = (units + want - 1) / want;
   p.ktiles_per_split = units_per_split * granule;
   p.splitk = (d.KT + p.ktiles_per_split - 1) / p.ktiles_per_split;
