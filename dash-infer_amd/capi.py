@@ -48,6 +48,7 @@ _SIGS = {
     "dihip_moe_experts_ex": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, sz, i32, i32]),
     "dihip_moe_route_grouped": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp, sz]),
     "dihip_moe_combine": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32]),
+    "dihip_moe_router_gate": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
     "dihip_act_frag_bytes": (sz, [i32, i32]),
     "dihip_act_to_frag": (i32, [vp, vp, vp, i32, i32, i32]),
     "dihip_act_from_frag": (i32, [vp, vp, vp, i32, i32, i32]),

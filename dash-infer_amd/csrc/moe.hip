@@ -17,6 +17,7 @@
 #include <algorithm>
 
 #include "device_utils.h"
+#include "gemm_lowp_kernel.hpp"  // mfma16
 
 namespace dihip {
 
@@ -259,6 +260,64 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(float* __restrict__ h_
   h_out[i] = (base + ft_round<FT>(a0)) + calc;
 }
 
+// The two unquantised skinny GEMMs of the MoE layer graph in ONE launch (qwen_v20_moe.py:330-338, 360-365): router logits
+// = FT(xn . W_router) [T, E] and the shared expert's gate = FT(sigmoid(xn . w_gate)) [T, 1].  One workgroup of 16 waves per
+// 16-column tile (E / 16 router tiles + the gate's tile); the waves split K (k-steps w, w + 16, ...: A fragment straight from
+// the activation rows, B fragment = the packed chunk), meet in LDS and wave 0 sums the 16 partial tiles in fixed order.  The
+// general kernel needs a split-K slab and a last-arriver reduction for such a shape: 2 x 9.0 us per layer (profiles/r03w).
+template <int FT>
+__global__ __launch_bounds__(1024) void moe_router_gate_kernel(void* __restrict__ logits, void* __restrict__ gate_out,
+                                                                const void* __restrict__ xn, const u32x4_t* __restrict__ w_router,
+                                                                const u32x4_t* __restrict__ w_gate, int T, int E, int K, int KT,
+                                                                int router_tiles) {
+  __shared__ f32x4_t part[16][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int ni = lane & 15, kb = lane >> 4;
+  const int tile = blockIdx.x;
+  const bool is_gate = tile >= router_tiles;
+  const u32x4_t* wp = (is_gate ? w_gate : w_router + (size_t)tile * KT * 64) + lane;
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  for (int m0 = 0; m0 < T; m0 += 16) {
+    const int row = min(m0 + ni, T - 1);  // rows past T re-read the last one (masked on store)
+    const char* xr = reinterpret_cast<const char*>(xn) + ((size_t)row * K + kb * 8) * 2;
+    f32x4_t acc = zero4;
+    for (int ks = wave; ks < KT; ks += 16) {
+      const u32x4_t af = *reinterpret_cast<const u32x4_t*>(xr + (size_t)ks * 64);
+      const u32x4_t bf = wp[(size_t)ks * 64];
+      acc = mfma16<FT>(af, bf, acc);
+    }
+    // compiler trap: the loop ends in the MFMA and hipcc puts the ds_write of its result straight behind the loop exit -- no
+    // wait states for the matrix pipe's write-back across the block boundary (MFMA -> LDS read of the result is a software
+    // hazard; MFMA -> VALU is interlocked): three of the four accumulator registers reached LDS without the last k-step.
+    // Explicit wait states (24 >= the 19 a 16-pass MFMA needs) close it.
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+      f32x4_t v = part[0][lane];
+#pragma unroll
+      for (int w = 1; w < 16; ++w) {
+        const f32x4_t t = part[w][lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += t[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + kb * 4 + r;
+        if (m >= T) continue;
+        if (is_gate) {
+          if (ni == 0) store_ft<FT>(gate_out, m, apply_act(v[r], DIHIP_ACT_SIGMOID));
+        } else {
+          const int n = tile * 16 + ni;
+          if (n < E) store_ft<FT>(logits, (size_t)m * E + n, v[r]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // CalcExpert (csrc/core/kernel/cuda/calc_expert.cu:27-35): out[t, c] = in[t, c] * expert_weight[t]
 template <int FT>
 __global__ __launch_bounds__(256) void calc_expert_kernel(void* __restrict__ out, const void* __restrict__ in,
@@ -416,6 +475,27 @@ int dihip_moe_combine(void* stream, float* h_out, const float* h_res, const void
   const MoeWs w = moe_ws_layout(const_cast<void*>(ws), (size_t)num_tokens * top_k, hidden, proj);
   hipLaunchKernelGGL(moe_combine_kernel<DIHIP_BF16>, dim3((hidden + 255) / 256, num_tokens), dim3(256), 0, s, h_out, h_res, w.ys, scores,
                      experts, shared_out, shared_gate, top_k, hidden);
+  return launch_status();
+}
+
+int dihip_moe_router_gate(void* stream, const void* xn, const void* w_router_packed, const void* w_gate_packed, void* router_logits,
+                          void* shared_gate, int num_tokens, int num_experts, int hidden, int dtype) {
+  DIHIP_REQUIRE(num_tokens >= 0 && num_experts > 0 && hidden > 0 && hidden % 32 == 0, DIHIP_PARAM_ERROR,
+                "moe_router_gate: hidden must be a multiple of 32 (the packed k-step)");
+  DIHIP_REQUIRE(xn && w_router_packed && w_gate_packed && router_logits && shared_gate, DIHIP_PARAM_ERROR, "moe_router_gate: null pointer");
+  if (num_tokens == 0) return DIHIP_SUCCESS;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int rt = (num_experts + 15) / 16, KT = hidden / 32;
+  const u32x4_t* wr = reinterpret_cast<const u32x4_t*>(w_router_packed);
+  const u32x4_t* wg = reinterpret_cast<const u32x4_t*>(w_gate_packed);
+  if (dtype == DIHIP_BF16)
+    hipLaunchKernelGGL(moe_router_gate_kernel<DIHIP_BF16>, dim3(rt + 1), dim3(1024), 0, s, router_logits, shared_gate, xn, wr, wg, num_tokens,
+                       num_experts, hidden, KT, rt);
+  else if (dtype == DIHIP_F16)
+    hipLaunchKernelGGL(moe_router_gate_kernel<DIHIP_F16>, dim3(rt + 1), dim3(1024), 0, s, router_logits, shared_gate, xn, wr, wg, num_tokens,
+                       num_experts, hidden, KT, rt);
+  else
+    DIHIP_REQUIRE(false, DIHIP_PARAM_ERROR, "moe_router_gate: 16-bit activations only (dtype %d)", dtype);
   return launch_status();
 }
 

@@ -713,9 +713,12 @@ class DecodeSession:
         the residual (rank 0) are added first and the f32 hidden rows are all-reduced once -- the same sum."""
         cfg, m, sc, B = self.model.cfg, self.model, self.scratch, self.B
         ops.rmsnorm_rows(self.h, lw.ln2, cfg.eps, out=self.moe_xn)
-        ops.gemm_dense(self.moe_xn, lw.router, out=self.moe_logits, scratch=self.moe_dense_scratch)
-        # decode batches: routing + slot grouping in one launch, finalize-routing folded into the combine (9 launches per block
-        # instead of 11, bit-identical; DIHIP_MOE_FUSED=0: the separate calls)
+        if fused_dense := os.environ.get("DIHIP_MOE_FUSED", "1") != "0":   # router + shared-expert gate Gemms in one launch
+            ops.moe_router_gate(self.moe_xn, lw.router, lw.shared_sig, logits=self.moe_logits, sig=self.moe_sig)
+        else:
+            ops.gemm_dense(self.moe_xn, lw.router, out=self.moe_logits, scratch=self.moe_dense_scratch)
+        # decode batches: routing + slot grouping in one launch, finalize-routing folded into the combine (with the fused dense
+        # pair: 8 launches per block instead of 11; DIHIP_MOE_FUSED=0: the separate calls)
         fused = B > 1 and B * cfg.moe.top_k <= ops.MOE_GROUP_MAX_SLOTS and os.environ.get("DIHIP_MOE_FUSED", "1") != "0"
         if fused:
             ops.moe_route_grouped(self.moe_logits, cfg.moe.top_k, cfg.hidden, lw.exp_gate.N, self.moe_ws, ep=lw.ep,
@@ -728,7 +731,8 @@ class DecodeSession:
                         flags=(ops.MOE_PREGROUPED | ops.MOE_NO_FINALIZE) if fused else 0)
         ops.prenorm_swiglu(self.moe_xn, lw.gate, lw.up, sc, B, out=self.moe_act)
         ops.gemm_lowp(self.moe_act, lw.down, scratch=sc, out=self.moe_shared)
-        ops.gemm_dense(self.moe_xn, lw.shared_sig, act="sigmoid", out=self.moe_sig, scratch=self.moe_dense_scratch)
+        if not fused_dense:
+            ops.gemm_dense(self.moe_xn, lw.shared_sig, act="sigmoid", out=self.moe_sig, scratch=self.moe_dense_scratch)
         h_res = self.h if (not tp_on or m.rank == 0) else None
         if fused:
             ops.moe_combine(self.h, h_res, self.moe_ws, self.moe_scores, self.moe_experts, self.moe_shared, self.moe_sig, lw.exp_gate.N)

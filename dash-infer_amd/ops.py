@@ -190,6 +190,18 @@ def moe_route_grouped(logits, top_k, hidden, proj, ws, ep=None, scores=None, exp
     return scores, experts
 
 
+def moe_router_gate(xn, router, gate, logits=None, sig=None):
+    """The router Gemm (xn . W_router -> FT [T, E]) and the shared expert's gate Gemm with SIGMOID (-> FT [T, 1]) in one launch;
+    router / gate: pack_dense of [hidden, E] / [hidden, 1]."""
+    T, hidden = xn.shape
+    logits = logits if logits is not None else torch.empty(T, router.N, dtype=xn.dtype, device=xn.device)
+    sig = sig if sig is not None else torch.empty(T, 1, dtype=xn.dtype, device=xn.device)
+    assert router.K == hidden and gate.K == hidden and gate.N == 1
+    check(lib().dihip_moe_router_gate(cur_stream(), ptr(xn), ptr(router.w), ptr(gate.w), ptr(logits), ptr(sig), T, router.N, hidden,
+                                      dt_code(xn)), "dihip_moe_router_gate")
+    return logits, sig
+
+
 def moe_combine(h_out, h_res, ws, scores, experts, shared_out, shared_gate, proj):
     """finalize-routing over the slot outputs moe_experts(..., flags=MOE_NO_FINALIZE) left in `ws` + moe_shared_combine's tail."""
     T, hidden = shared_out.shape

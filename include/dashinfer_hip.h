@@ -218,6 +218,11 @@ int dihip_moe_experts_ex(void* stream, int wbits, const void* x, const int32_t* 
                          int group_size, void* out, void* ws, size_t ws_bytes, int dtype, int flags);
 int dihip_moe_combine(void* stream, float* h_out, const float* h_res, const void* ws, const float* scores, const int32_t* experts,
                       const void* shared_out, const void* shared_gate, int num_tokens, int top_k, int hidden, int proj, int dtype);
+/* The layer graph's two unquantised skinny Gemm operators on the normalised rows in one launch (qwen_v20_moe.py:330-338 "mlp.gate",
+ * :360-365 "shared_expert_gate" with activation SIGMOID): router_logits FT [T, E] = FT(xn . W_router), shared_gate FT [T] =
+ * FT(sigmoid(xn . w_gate)); both weights packed by dihip_dense_pack ([hidden, E] and [hidden, 1]). */
+int dihip_moe_router_gate(void* stream, const void* xn, const void* w_router_packed, const void* w_gate_packed, void* router_logits,
+                          void* shared_gate, int num_tokens, int num_experts, int hidden, int dtype);
 
 /* =============================================================================================
  * 2. KV span writers (replace csrc/core/kernel/cuda/cuda_kernel_span_cache.h:12-41)

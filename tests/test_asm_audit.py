@@ -73,3 +73,44 @@ def test_no_register_is_read_while_its_load_is_in_flight(obj):
     kernels, findings = audit_asm_loads.audit(obj, skip=audit_asm_loads.FUSED_KERNELS)
     assert kernels > 0
     assert not findings, "\n".join(findings[:20])
+
+
+# ---- MFMA results read too early (tools/audit_mfma_hazard.py) -----------------------------------------------------------------
+spec2 = importlib.util.spec_from_file_location("audit_mfma_hazard", os.path.join(ROOT, "tools", "audit_mfma_hazard.py"))
+audit_mfma_hazard = importlib.util.module_from_spec(spec2)
+spec2.loader.exec_module(audit_mfma_hazard)
+
+
+def test_the_mfma_audit_flags_a_store_right_behind_a_loop_of_mfmas(tmp_path):
+    """the form hipcc produced for moe_router_gate_kernel: the loop ends in the MFMA, the ds_write of the accumulator follows the
+    loop exit after two scalar instructions -- and the form with the wait states the kernel now carries"""
+    body = ".LBB0_1:\n\tglobal_load_dwordx4 v[8:11], v[4:5], off\n\tv_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[12:15], v[0:3]\n\ts_cbranch_scc0 .LBB0_1\n"
+    bad = tmp_path / "bad.s"
+    bad.write_text("k:\n" + body + "\ts_and_b64 vcc, exec, s[20:21]\n\tds_write_b128 v76, v[0:3]\n\ts_endpgm\n")
+    good = tmp_path / "good.s"
+    good.write_text("k:\n" + body + "\ts_nop 15\n\ts_nop 7\n\ts_and_b64 vcc, exec, s[20:21]\n\tds_write_b128 v76, v[0:3]\n\ts_endpgm\n")
+    assert len(audit_mfma_hazard.audit(str(bad))) == 1
+    assert audit_mfma_hazard.audit(str(good)) == []
+    # chained accumulation and a VALU read after hipcc's own s_nop are fine
+    chain = tmp_path / "chain.s"
+    chain.write_text("k:\n\tv_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[12:15], v[0:3]\n\tv_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[16:19], v[0:3]\n"
+                     "\ts_nop 6\n\tv_add_f32_e32 v20, v0, v1\n\ts_endpgm\n")
+    assert audit_mfma_hazard.audit(str(chain)) == []
+
+
+@pytest.mark.parametrize("src", ["moe.hip", "gemv_batch_inst_w4_g1.hip"])
+def test_no_kernel_reads_an_mfma_result_without_wait_states(src, tmp_path):
+    """compiles the file to device assembly (no GPU needed) and audits it: MoE kernels (where the bug was) and the small-batch
+    GEMM whose waves combine MFMA tiles through LDS"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "dash-infer_amd", "csrc")
+    out = tmp_path / (src + ".s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+                    "-fno-gpu-rdc", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", str(out), os.path.join(csrc, src)],
+                   check=True, capture_output=True, timeout=600)
+    found = audit_mfma_hazard.audit(str(out))
+    assert not found, found[:3]

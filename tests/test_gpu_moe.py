@@ -234,3 +234,33 @@ def test_fewer_launch_block_rejects_what_it_does_not_serve(ops):
         ops.moe_route_grouped(logits, 2, 64, 64, ws)                       # one token: its top-k experts are distinct, no groups
     with pytest.raises(Exception):
         ops.moe_route_grouped(torch.zeros(300, 8, dtype=torch.bfloat16, device="cuda"), 8, 64, 64, ws)   # 2400 slots > 2048
+
+
+@pytest.mark.parametrize("T,E,hidden,dt", [(16, 64, 3584, torch.bfloat16), (1, 64, 3584, torch.bfloat16), (33, 60, 512, torch.bfloat16),
+                                           (7, 8, 256, torch.float16)])
+def test_router_and_gate_in_one_launch(ops, T, E, hidden, dt):
+    """dihip_moe_router_gate against the two Gemm operators it replaces (dihip_gemm_a16w16, the second with SIGMOID) and against
+    float64: the same products summed in another fixed order (16 waves x k-steps, then 16 partial tiles) -- within one FT
+    rounding of each other, run-to-run identical."""
+    rng = np.random.default_rng(T * 3 + E)
+    ft = "bf16" if dt == torch.bfloat16 else "f16"
+    from oracle.numerics import ft_round
+    xn = ft_round(rng.normal(0, 1, (T, hidden)).astype(np.float32), ft)
+    wr = ft_round(rng.normal(0, 0.05, (hidden, E)).astype(np.float32), ft)
+    wg = ft_round(rng.normal(0, 0.05, (hidden, 1)).astype(np.float32), ft)
+    xd = dev(xn, dt)
+    pr, pg = ops.pack_dense(dev(wr, dt)), ops.pack_dense(dev(wg, dt))
+    logits, sig = ops.moe_router_gate(xd, pr, pg)
+    ref_l = ops.gemm_dense(xd, pr)
+    ref_s = ops.gemm_dense(xd, pg, act="sigmoid")
+    torch.cuda.synchronize()
+    exact_l = xn.astype(np.float64) @ wr.astype(np.float64)
+    exact_s = 1.0 / (1.0 + np.exp(-(xn.astype(np.float64) @ wg.astype(np.float64))))
+    ulp = 2.0 ** -8 if ft == "bf16" else 2.0 ** -11
+    assert np.abs(logits.float().cpu().numpy() - exact_l).max() <= ulp * max(1.0, np.abs(exact_l).max())
+    assert np.abs(sig.float().cpu().numpy() - exact_s).max() <= ulp
+    assert float((logits.float() - ref_l.float()).abs().max()) <= 2 * ulp * max(1.0, float(ref_l.float().abs().max()))
+    assert float((sig.float() - ref_s.float()).abs().max()) <= 2 * ulp
+    l2, s2 = ops.moe_router_gate(xd, pr, pg)
+    torch.cuda.synchronize()
+    assert torch.equal(l2, logits) and torch.equal(s2, sig)
