@@ -846,11 +846,11 @@ static bool batch_kernel_shape(int wbits, int M, int N, int K, int group_size, b
 // f32 hidden rows -> FT normalised rows (used by the fused entry points when M > 4); frag_mt > 0: FRAG32 output.
 // One workgroup per row, the row stays in registers (one 16-byte load per 4 columns, all in flight together):
 // a single round trip instead of two dependent passes over h.  cols % 4 == 0, cols <= 256 * 4 * VPT.
-template <int FT, int VPT>
-__global__ __launch_bounds__(256) void rmsnorm_f32_to_ft_kernel(uint16_t* __restrict__ y, const float* __restrict__ h,
+template <int FT, int VPT, int THREADS>
+__global__ __launch_bounds__(THREADS) void rmsnorm_f32_to_ft_kernel(uint16_t* __restrict__ y, const float* __restrict__ h,
                                                                 const void* __restrict__ gamma, float eps, int cols,
                                                                 int frag_mt) {
-  __shared__ float red[4];
+  __shared__ float red[THREADS / 64];
   const int row = blockIdx.x, tid = threadIdx.x;
   const f32x4_t* hr = reinterpret_cast<const f32x4_t*>(h + (size_t)row * cols);
   const int nvec = cols >> 2;
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256) void rmsnorm_f32_to_ft_kernel(uint16_t* __rest
   u32x2_t gm[VPT];
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const int c = tid + i * 256;
+    const int c = tid + i * THREADS;
     v[i] = c < nvec ? hr[c] : f32x4_t{0.f, 0.f, 0.f, 0.f};
     gm[i] = c < nvec ? reinterpret_cast<const u32x2_t*>(gamma)[c] : u32x2_t{0u, 0u};
   }
@@ -868,10 +868,13 @@ __global__ __launch_bounds__(256) void rmsnorm_f32_to_ft_kernel(uint16_t* __rest
   ss = wave_sum(ss);
   if ((tid & 63) == 0) red[tid >> 6] = ss;
   __syncthreads();
-  const float rstd = 1.f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)cols + eps);
+  float tot = red[0];
+#pragma unroll
+  for (int w = 1; w < THREADS / 64; ++w) tot += red[w];
+  const float rstd = 1.f / sqrtf(tot / (float)cols + eps);
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const int c = tid + i * 256;
+    const int c = tid + i * THREADS;
     if (c < nvec) {
       const float g0 = ft_bits_to_f32<FT>(gm[i][0] & 0xFFFFu), g1 = ft_bits_to_f32<FT>(gm[i][0] >> 16);
       const float g2 = ft_bits_to_f32<FT>(gm[i][1] & 0xFFFFu), g3 = ft_bits_to_f32<FT>(gm[i][1] >> 16);
@@ -1034,9 +1037,9 @@ static int launch_rmsnorm_rows(hipStream_t s, const float* h, const void* gamma,
   const bool vec = K % 4 == 0 && (reinterpret_cast<uintptr_t>(h) % 16 == 0) && (reinterpret_cast<uintptr_t>(gamma) % 8 == 0);
   uint16_t* xo = reinterpret_cast<uint16_t*>(out);
   if (vec && K <= 4096)
-    hipLaunchKernelGGL((rmsnorm_f32_to_ft_kernel<DIHIP_BF16, 4>), dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, frag_mt);
-  else if (vec && K <= 8192)
-    hipLaunchKernelGGL((rmsnorm_f32_to_ft_kernel<DIHIP_BF16, 8>), dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, frag_mt);
+    hipLaunchKernelGGL((rmsnorm_f32_to_ft_kernel<DIHIP_BF16, 4, 256>), dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, frag_mt);
+  else if (vec && K <= 8192)  // wide rows: 1024 threads, two vectors each (256 threads took 6.8 us for 16 rows of 8192)
+    hipLaunchKernelGGL((rmsnorm_f32_to_ft_kernel<DIHIP_BF16, 2, 1024>), dim3(M), dim3(1024), 0, s, xo, h, gamma, eps, K, frag_mt);
   else
     hipLaunchKernelGGL(rmsnorm_f32_to_ft_wide_kernel<DIHIP_BF16>, dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, frag_mt);
   return launch_status();

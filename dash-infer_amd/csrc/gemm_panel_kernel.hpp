@@ -286,10 +286,11 @@ __global__ __launch_bounds__(256) void gemm_panel_reduce_kernel(const PanelArgs 
 // row keeps the finished f32 row in registers (slices summed in the fixed order of gemm_panel_reduce_kernel, residual
 // added as in panel_epilogue), writes h_out, and normalises straight into the next GEMM's activation layout -- the
 // arithmetic of rmsnorm_f32_to_ft_kernel (gemm_lowp.hip), one launch and one pass over the row less.
-// N % 4 == 0, N <= 1024 * VPT.
-template <int FT, int VPT>
-__global__ __launch_bounds__(256) void gemm_reduce_addto_norm_kernel(const PanelArgs a) {
-  __shared__ float red[4];
+// N % 4 == 0, N <= 4 * THREADS * VPT.  Rows wider than 4096 take 1024 threads (a 256-thread block walked a row of 8192 in eight
+// dependent steps: 9.0 us at 16 rows, profiles/r03z cfg3_rank).
+template <int FT, int VPT, int THREADS>
+__global__ __launch_bounds__(THREADS) void gemm_reduce_addto_norm_kernel(const PanelArgs a) {
+  __shared__ float red[THREADS / 64];
   const int row = blockIdx.x, tid = threadIdx.x;
   const int nvec = a.N >> 2;
   const size_t total = (size_t)a.M * a.N;
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_addto_norm_kernel(const Panel
   f32x4_t base[VPT];
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const int c = min(tid + i * 256, nvec - 1);  // clamped: lanes past the row re-load its last vector and store nothing
+    const int c = min(tid + i * THREADS, nvec - 1);  // clamped: lanes past the row re-load its last vector and store nothing
     const size_t e = (size_t)row * a.N + (size_t)c * 4;
     v[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     gm[i] = reinterpret_cast<const u32x2_t*>(a.n_gamma)[c];
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_addto_norm_kernel(const Panel
       const int sj = min(s0 + j, a.nslices - 1);
 #pragma unroll
       for (int i = 0; i < VPT; ++i) {
-        const int c = min(tid + i * 256, nvec - 1);
+        const int c = min(tid + i * THREADS, nvec - 1);
         t[j][i] = *reinterpret_cast<const f32x4_t*>(a.slab + (size_t)sj * total + (size_t)row * a.N + (size_t)c * 4);
       }
     }
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_addto_norm_kernel(const Panel
   }
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const int c = tid + i * 256;
+    const int c = tid + i * THREADS;
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[i][r] = c < nvec ? __fadd_rn(base[i][r], __fmul_rn(a.alpha, v[i][r])) : 0.f;
     if (c < nvec) *reinterpret_cast<f32x4_t*>(a.h_out + (size_t)row * a.N + (size_t)c * 4) = v[i];
@@ -341,11 +342,14 @@ __global__ __launch_bounds__(256) void gemm_reduce_addto_norm_kernel(const Panel
   ss = wave_sum(ss);
   if ((tid & 63) == 0) red[tid >> 6] = ss;
   __syncthreads();
-  const float rstd = 1.f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)a.N + a.n_eps);
+  float tot = red[0];
+#pragma unroll
+  for (int w = 1; w < THREADS / 64; ++w) tot += red[w];  // ((r0 + r1) + r2) + ...: the order of rmsnorm_f32_to_ft_kernel
+  const float rstd = 1.f / sqrtf(tot / (float)a.N + a.n_eps);
   uint16_t* y = reinterpret_cast<uint16_t*>(a.n_out);
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const int c = tid + i * 256;
+    const int c = tid + i * THREADS;
     if (c < nvec) {
       const float g0 = ft_bits_to_f32<FT>(gm[i][0] & 0xFFFFu), g1 = ft_bits_to_f32<FT>(gm[i][0] >> 16);
       const float g2 = ft_bits_to_f32<FT>(gm[i][1] & 0xFFFFu), g3 = ft_bits_to_f32<FT>(gm[i][1] >> 16);
@@ -363,8 +367,8 @@ template <int FT, int EPI>
 inline void launch_slab_reduce(const PanelArgs& a, int mt_tiles, hipStream_t s) {
   if constexpr (EPI == EPI_ADDTO) {
     if (a.n_gamma) {  // host contract (run_gemm): N % 4 == 0, N <= 8192, 16-byte aligned rows
-      if (a.N <= 4096) hipLaunchKernelGGL((gemm_reduce_addto_norm_kernel<FT, 4>), dim3(a.M), dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((gemm_reduce_addto_norm_kernel<FT, 8>), dim3(a.M), dim3(256), 0, s, a);
+      if (a.N <= 4096) hipLaunchKernelGGL((gemm_reduce_addto_norm_kernel<FT, 4, 256>), dim3(a.M), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gemm_reduce_addto_norm_kernel<FT, 2, 1024>), dim3(a.M), dim3(1024), 0, s, a);
       return;
     }
   }
