@@ -524,6 +524,13 @@ static AttnPlan attn_plan(int batch, int n_heads, int n_groups, int max_seq_len,
   }
   const long max_splits = std::max(1, (max_seq_len + min_tps - 1) / min_tps);  // >= 128 tokens per split
   p.nsplits = (int)std::max<long>(1, std::min<long>(std::min<long>(want, max_splits), split_cap));
+  // two workgroups per CU only while a split keeps >= 256 tokens: below that the second workgroup buys no bandwidth and every
+  // extra split is another record to merge (one TP = 8 rank of Qwen2-72B, batch 16 x 1 KV head x 4096 tokens: 16 splits 15.4 us,
+  // 32 splits 18.4; the 57B MoE step at batch 16 x 4 x 1024: 4 splits = 8 + 0.4 %; profiles/r03ab)
+  if (per_cu > 1 && p.nsplits * base > num_cus && (max_seq_len + p.nsplits - 1) / p.nsplits < 256) {
+    const long one_per_cu = std::max<long>(1, (num_cus + base - 1) / base);
+    p.nsplits = (int)std::max<long>(1, std::min<long>(p.nsplits, one_per_cu));
+  }
   static int force_splits = -1;  // DIHIP_ATTN_NSPLITS: diagnostics
   if (force_splits < 0) {
     const char* e = getenv("DIHIP_ATTN_NSPLITS");
