@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 3, call H: bench lines of the secondary workloads after the decode-step changes (profiles/r03h_*)
 ROOT=${GRAFT_REPO_ROOT:-$PWD}; OUT=$ROOT/gpurun_out/r3h; mkdir -p $OUT; cd $ROOT
 for w in int4_b32_u4kv cfg3_rank int8_b1 cfg5_moe; do
   timeout 400 python bench.py --workload $w --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err
