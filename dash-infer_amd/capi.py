@@ -116,6 +116,7 @@ _SIGS = {
     "dihip_p2p_ar_error": (i32, [vp, vp]),
     "dihip_p2p_allreduce_sum": (i32, [vp, vp, vp, vp, sz, i32]),
     "dihip_debug_set_trace": (i32, [vp, sz]),
+    "dihip_debug_attn_plan": (i32, [i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),
     "dihip_debug_gemv_plan": (i32, [i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32),
                               C.POINTER(sz)]),
 }

@@ -17,18 +17,23 @@ void set_last_error(const char* fmt, ...) {
 }
 
 int cached_num_cus() {
-  static int cus = -1;
-  if (cus < 0) {
+  static const int cus = [] {
     int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
-      cus = n;
-    else {
-      (void)hipGetLastError();
-      cus = 0;
-    }
-  }
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+      return n;
+    (void)hipGetLastError();
+    return 0;
+  }();
   return cus;
+}
+
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+bool env_off(const char* name) {
+  const char* e = getenv(name);
+  return e && e[0] == '0';
 }
 
 static unsigned long long* g_trace = nullptr;

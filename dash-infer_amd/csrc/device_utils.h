@@ -40,6 +40,10 @@ inline int launch_status(int code = DIHIP_RUNTIME_ERROR) {
 int cached_num_cus();
 // diagnostics: the buffer set by dihip_debug_set_trace if it holds at least `bytes`, else null
 unsigned long long* debug_trace_buffer(size_t bytes);
+// environment switches: read once into a function-local `static const` (C++11 static initialisation is thread-safe; the rank
+// threads of a loop-back TP group used to race on hand-rolled `static int x = -1` caches)
+int env_int(const char* name, int dflt);          // atoi of the variable, or dflt when unset
+bool env_off(const char* name);                   // set and starting with '0'
 void debug_set_trace(void* buf, size_t bytes);
 
 // ---------------------------------------------------------------- device side --------------

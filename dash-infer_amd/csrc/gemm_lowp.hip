@@ -256,11 +256,9 @@ static GemvPlan make_gemv_plan(int wbits, int M, int N, int K, int group_size, b
   GemvPlan p{};
   const LowpDims d = lowp_dims(wbits, N, K, group_size);
   p.ok = false;
-  static int max_m = -1;  // DIHIP_GEMV_STREAM_MAXM: largest batch served by the LDS-resident kernel
-  if (max_m < 0) {
-    const char* e = getenv("DIHIP_GEMV_STREAM_MAXM");
-    max_m = e ? std::max(1, std::min(16, atoi(e))) : 4;  // beyond 4 rows the per-workgroup x staging (M x K into LDS) costs more than the small-batch kernel
-  }
+  // DIHIP_GEMV_STREAM_MAXM: largest batch served by the LDS-resident kernel (beyond 4 rows the per-workgroup x staging, M x K
+  // into LDS, costs more than the small-batch kernel)
+  static const int max_m = std::max(1, std::min(16, env_int("DIHIP_GEMV_STREAM_MAXM", 4)));
   if (M < 1 || M > max_m) return p;
   if (d.group && d.group % d.KTILE != 0) return p;  // groups smaller than a k-tile: general kernel
   p.ktpg = d.group ? d.group / d.KTILE : (1 << 28);
@@ -272,17 +270,9 @@ static GemvPlan make_gemv_plan(int wbits, int M, int N, int K, int group_size, b
   // never more workgroups than CUs (a second round starts ~2 us late, measured on the qkv shape):
   // one tile per workgroup up to the CU count, ceil(tiles / CUs) beyond
   p.upb = units <= num_cus ? 1 : (units + num_cus - 1) / num_cus;
-  static int upb_override = -1;  // experiments: DIHIP_GEMV_UPB=<units per workgroup> for the multi-unit shapes
-  if (upb_override < 0) {
-    const char* e = getenv("DIHIP_GEMV_UPB");
-    upb_override = e ? atoi(e) : 0;
-  }
+  static const int upb_override = env_int("DIHIP_GEMV_UPB", 0);  // experiments: units per workgroup for the multi-unit shapes
   if (upb_override > 0 && p.upb > 1) p.upb = upb_override;
-  static int upb_small = -1;  // experiments: DIHIP_GEMV_UPB_SMALL=<units per workgroup> for shapes with units in (CUs, 1.5 CUs]
-  if (upb_small < 0) {
-    const char* e = getenv("DIHIP_GEMV_UPB_SMALL");
-    upb_small = e ? atoi(e) : 0;
-  }
+  static const int upb_small = env_int("DIHIP_GEMV_UPB_SMALL", 0);  // experiments: units per workgroup for shapes with units in (CUs, 1.5 CUs]
   if (upb_small > 0 && p.upb == 1 && units > num_cus) p.upb = upb_small;
   if (want_blocks > 0) p.upb = std::max(1, (units + want_blocks - 1) / want_blocks);
   p.blocks = (units + p.upb - 1) / p.upb;
@@ -347,13 +337,9 @@ static hipError_t dispatch_gemv_f16(const GemvPlan& p, const GemvArgs& a, hipStr
              : launch_gemv_stream<WBITS, DIHIP_F16, 4, PRO_PLAIN, EPI_STD, 0>(a, p.blocks, p.lds_bytes, s);
 }
 
-static int g_force_general = -1;  // DIHIP_GEMV_STREAM=0 routes everything to the general kernel
-static bool gemv_stream_enabled() {
-  if (g_force_general < 0) {
-    const char* e = getenv("DIHIP_GEMV_STREAM");
-    g_force_general = (e && e[0] == '0') ? 1 : 0;
-  }
-  return g_force_general == 0;
+static bool gemv_stream_enabled() {  // DIHIP_GEMV_STREAM=0 routes everything to the general kernel
+  static const bool on = !env_off("DIHIP_GEMV_STREAM");
+  return on;
 }
 
 // ---- batched decode, FRAG32 activations (gemm_panel_kernel.hpp) ----------------------------------------
@@ -365,24 +351,14 @@ struct PanelPlan {
 
 static PanelPlan make_panel_plan(int wbits, int M, int N, int K, int group_size, bool dual) {
   PanelPlan p{};
-  static int enabled = -1;  // DIHIP_GEMM_PANEL=0: keep the whole-column kernel (diagnostics)
-  if (enabled < 0) {
-    const char* e = getenv("DIHIP_GEMM_PANEL");
-    enabled = (e && e[0] == '0') ? 0 : 1;
-  }
+  static const bool enabled = !env_off("DIHIP_GEMM_PANEL");  // =0: keep the whole-column kernel (diagnostics)
   if (!enabled) return p;
   const LowpDims d = lowp_dims(wbits, N, K, group_size);
   int ncu = cached_num_cus();
   if (ncu <= 0) ncu = 256;
   p.panels = (d.NTILES + PANEL_WAVES - 1) / PANEL_WAVES;
   const int ktpg = d.group ? std::max(1, d.group / d.KTILE) : 1;  // slices hold whole quantisation groups
-  static int target = -1, one_frac = -1;  // diagnostics: DIHIP_PANEL_TARGET_WGS, DIHIP_PANEL_ONE_SLICE_PCT
-  if (target < 0) {
-    const char* e1 = getenv("DIHIP_PANEL_TARGET_WGS");
-    const char* e2 = getenv("DIHIP_PANEL_ONE_SLICE_PCT");
-    target = e1 ? atoi(e1) : 0;
-    one_frac = e2 ? atoi(e2) : 50;
-  }
+  static const int target = env_int("DIHIP_PANEL_TARGET_WGS", 0), one_frac = env_int("DIHIP_PANEL_ONE_SLICE_PCT", 50);  // diagnostics
   const int tgt = target > 0 ? target : ncu;
   if (100 * p.panels >= one_frac * ncu) {
     p.nslices = 1;  // enough panels to keep the HBM queue full from every second CU on
@@ -428,11 +404,7 @@ static KslicePlan make_kslice_plan(int wbits, int M, int N, int K, int group_siz
   p.waves = std::min(KSL_WAVES, nsl);
   p.nslices = (nsl + KSL_WAVES - 1) / KSL_WAVES;
   p.nunits = d.NTILES;
-  static int target = -1;  // DIHIP_KSLICE_TARGET_WGS: diagnostics
-  if (target < 0) {
-    const char* e = getenv("DIHIP_KSLICE_TARGET_WGS");
-    target = e ? atoi(e) : 0;
-  }
+  static const int target = env_int("DIHIP_KSLICE_TARGET_WGS", 0);  // diagnostics
   const int tgt = target > 0 ? target : ncu;  // one 8-wave workgroup per CU (64 KB LDS, ~250 registers)
   p.groups = std::max(1, std::min(p.nunits, tgt / p.nslices));
   p.slab_bytes = p.nslices > 1 ? (size_t)p.nslices * (dual ? 2 : 1) * M * N * sizeof(float) : 0;
@@ -698,13 +670,7 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
     g.yfrag = c.y_layout == DIHIP_ACT_FRAG32;
     // at most one workgroup per CU; a workgroup with several units walks them two at a time so that
     // one pass over the activations (L2 -> registers) feeds two column tiles
-    static int env_upb = -1, env_nt = -1;  // diagnostics: DIHIP_GEMB_UPB / DIHIP_GEMB_NT
-    if (env_upb < 0) {
-      const char* e1 = getenv("DIHIP_GEMB_UPB");
-      const char* e2 = getenv("DIHIP_GEMB_NT");
-      env_upb = e1 ? atoi(e1) : 0;
-      env_nt = e2 ? atoi(e2) : 0;
-    }
+    static const int env_upb = env_int("DIHIP_GEMB_UPB", 0), env_nt = env_int("DIHIP_GEMB_NT", 0);  // diagnostics
     int ncu = cached_num_cus();
     if (ncu <= 0) ncu = 256;
     g.upb = env_upb > 0 ? env_upb : (d.NTILES <= ncu ? 1 : (d.NTILES + ncu - 1) / ncu);
@@ -728,11 +694,7 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
                 "gemm_lowp: the FRAG32 activation layout needs the small-batch kernel (see dihip_gemm_lowp_prefers_frag)");
   // context phase (M >= 64 rows): 128 x 256 workgroup tiles, A through LDS, every weight byte read once per 128 rows
   // (gemm_prefill_kernel.hpp).  DIHIP_GEMM_PREFILL=0 keeps the general kernel (A/B, diagnostics).
-  static int prefill_on = -1;
-  if (prefill_on < 0) {
-    const char* e = getenv("DIHIP_GEMM_PREFILL");
-    prefill_on = (e && e[0] == '0') ? 0 : 1;
-  }
+  static const bool prefill_on = !env_off("DIHIP_GEMM_PREFILL");
   if (prefill_on && c.dtype == DIHIP_BF16 && c.pro == PRO_PLAIN && c.M >= 64 && (c.wbits == 4 || c.wbits == 8) && gemv_aligned &&
       (d.group == 0 || d.group % d.KTILE == 0) && (c.epi != EPI_SWIGLU || (c.w1 && c.sz1))) {
     PrefillArgs g{};

@@ -304,13 +304,10 @@ hipError_t launch_gemm_prefill(const PrefillArgs& a, int blocks, hipStream_t str
   hipError_t launch_gemm_prefill<WBITS, FT, EPI, GPT>(const PrefillArgs& a, int blocks, hipStream_t s) {           \
     auto kern = gemm_prefill_kernel<WBITS, FT, EPI, GPT>;                                                          \
     constexpr size_t lds = prefill_lds_bytes<WBITS>();                                                             \
-    if (lds > 64 * 1024) {                                                                                         \
-      static bool granted = false;                                                                                 \
-      if (!granted) {                                                                                              \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e != hipSuccess) return e;                                                                             \
-        granted = true;                                                                                            \
-      }                                                                                                            \
+    if (lds > 64 * 1024) {  /* granted once (thread-safe static initialisation) */                               \
+      static const hipError_t granted =                                                                            \
+          hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (granted != hipSuccess) return granted;                                                                   \
     }                                                                                                              \
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(PF_THREADS), lds, s, a);                                           \
     return hipGetLastError();                                                                                      \

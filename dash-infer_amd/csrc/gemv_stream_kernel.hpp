@@ -29,6 +29,7 @@
 // Host-side contract (gemm_lowp.hip: run_gemm / make_gemv_plan): M <= 16, K % KTILE == 0,
 // ldx % 8 == 0, x and gamma 16-byte aligned, group_size % KTILE == 0 or per-channel, LDS budget.
 #pragma once
+#include <atomic>
 #include "gemm_lowp_kernel.hpp"
 
 namespace dihip {
@@ -712,13 +713,13 @@ hipError_t launch_gemv_slots(const GemvArgs& a, int blocks, size_t lds_bytes, hi
                                                               size_t lds_bytes, hipStream_t s) {  \
     auto kern = gemv_stream_kernel<WBITS, FT, MR, PRO, EPI, GPT>;                                 \
     if (lds_bytes > 64 * 1024) {                                                                  \
-      static size_t granted = 0;                                                                  \
-      if (lds_bytes > granted) {                                                                  \
+      static std::atomic<size_t> granted{0}; /* rank threads may race here: a second grant is harmless */ \
+      if (lds_bytes > granted.load(std::memory_order_relaxed)) {                                  \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
                                            hipFuncAttributeMaxDynamicSharedMemorySize,            \
                                            (int)lds_bytes);                                       \
         if (e != hipSuccess) return e;                                                            \
-        granted = lds_bytes;                                                                      \
+        granted.store(lds_bytes, std::memory_order_relaxed);                                      \
       }                                                                                           \
     }                                                                                             \
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(GEMV_THREADS), lds_bytes, s, a);                  \

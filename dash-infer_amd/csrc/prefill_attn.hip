@@ -339,21 +339,13 @@ extern "C" int dihip_prefill_attn(void* stream, void* out, const void* q, const 
   DIHIP_REQUIRE(q_stride % 8 == 0 && kv_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(q) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(k) & 15) == 0 && (reinterpret_cast<uintptr_t>(v) & 15) == 0,
                 DIHIP_PARAM_ERROR, "prefill_attn: rows must be 16-byte aligned");
-  static int force_mt = -1;  // DIHIP_PREFILL_MT: diagnostics
-  if (force_mt < 0) {
-    const char* e = getenv("DIHIP_PREFILL_MT");
-    force_mt = e ? atoi(e) : 0;
-  }
+  static const int force_mt = env_int("DIHIP_PREFILL_MT", 0);  // diagnostics
   int ncu = cached_num_cus();
   if (ncu <= 0) ncu = 256;
   // 128-row query tiles read every K / V fragment once per two MFMAs; 64-row tiles double the workgroup count.
   // Two workgroups fit a CU: take the small tile while the large one would fill less than 1.5 slots (measured).
   auto wgs = [&](int rows) { return (long)((seq_q + rows - 1) / rows) * n_heads; };
-  static int force_ng = -1;  // DIHIP_PREFILL_NG: diagnostics
-  if (force_ng < 0) {
-    const char* e = getenv("DIHIP_PREFILL_NG");
-    force_ng = e ? atoi(e) : 0;
-  }
+  static const int force_ng = env_int("DIHIP_PREFILL_NG", 0);  // diagnostics
   // While all 128-row workgroups are resident at once (2 per CU) the longest one sets the time: two key groups per
   // workgroup halve its chain of key tiles (same 8 waves per CU).  Measured: +12 % at 2048 tokens (448 workgroups);
   // below one workgroup per CU the 64-row tiles are faster still, above two per CU the greedy dispatch balances already
@@ -362,11 +354,7 @@ extern "C" int dihip_prefill_attn(void* stream, void* out, const void* q, const 
   const int mt = ng == 2 ? 2 : force_mt > 0 ? std::min(force_mt, 2) : (2 * wgs(128) >= 3L * ncu ? 2 : 1);
   const int rows = 64 * mt;
   const int nqt = (seq_q + rows - 1) / rows;
-  static int force_prio = -2;  // DIHIP_PREFILL_PRIO: diagnostics
-  if (force_prio == -2) {
-    const char* e = getenv("DIHIP_PREFILL_PRIO");
-    force_prio = e ? atoi(e) : -1;
-  }
+  static const int force_prio = env_int("DIHIP_PREFILL_PRIO", -1);  // diagnostics
   // raised issue priority for the MFMA phases: +9..11 % once the grid exceeds the resident workgroups (2 per CU), +2 % at
   // 16384, but -4 % while every workgroup is resident from the start (measured, A/B in one process)
   const int prio = force_prio >= 0 ? force_prio : ((long)nqt * n_heads > (ng == 2 ? 1L : 2L) * ncu ? 1 : 0);

@@ -490,11 +490,7 @@ struct AttnPlan {
 };
 
 static bool attn_use_mfma(int mode, int dtype) {
-  static int enabled = -1;  // DIHIP_ATTN_MFMA=0: keep the VALU kernel for the u4 cache (diagnostics)
-  if (enabled < 0) {
-    const char* e = getenv("DIHIP_ATTN_MFMA");
-    enabled = (e && e[0] == '0') ? 0 : 1;
-  }
+  static const bool enabled = !env_off("DIHIP_ATTN_MFMA");  // =0: keep the VALU kernel for the u4 cache (diagnostics)
   if (!enabled || dtype == DIHIP_F32) return false;
   return mode == DIHIP_KV_U4 ? dtype == DIHIP_BF16 : (mode == DIHIP_KV_NONE || mode == DIHIP_KV_I8);
 }
@@ -509,19 +505,11 @@ static AttnPlan attn_plan(int batch, int n_heads, int n_groups, int max_seq_len,
   if (num_cus <= 0) num_cus = cached_num_cus();
   if (num_cus <= 0) num_cus = 256;
   const long base = (long)batch * n_groups * p.nchunks;
-  static int wgs_per_cu = -1;  // DIHIP_ATTN_WGS_PER_CU: workgroups (4 waves) the split count aims at per CU
-  if (wgs_per_cu < 0) {
-    const char* e = getenv("DIHIP_ATTN_WGS_PER_CU");
-    wgs_per_cu = e ? std::max(1, atoi(e)) : 0;
-  }
+  static const int wgs_per_cu = std::max(0, env_int("DIHIP_ATTN_WGS_PER_CU", 0));  // workgroups (4 waves) the split count aims at per CU
   // the MFMA kernel hides latency with two co-resident workgroups per CU; the VALU kernel measured best with one
   const int per_cu = wgs_per_cu > 0 ? wgs_per_cu : (mfma ? 2 : 1);
   long want = ((long)num_cus * per_cu + base - 1) / base;
-  static int min_tps = -1;  // DIHIP_ATTN_SPLIT_TOKENS: fewest tokens per split (diagnostics)
-  if (min_tps < 0) {
-    const char* e = getenv("DIHIP_ATTN_SPLIT_TOKENS");
-    min_tps = e ? std::max(32, atoi(e)) : 128;
-  }
+  static const int min_tps = std::max(32, env_int("DIHIP_ATTN_SPLIT_TOKENS", 128));  // fewest tokens per split (diagnostics)
   const long max_splits = std::max(1, (max_seq_len + min_tps - 1) / min_tps);  // >= 128 tokens per split
   p.nsplits = (int)std::max<long>(1, std::min<long>(std::min<long>(want, max_splits), split_cap));
   // two workgroups per CU only while a split keeps >= 256 tokens: below that the second workgroup buys no bandwidth and every
@@ -531,11 +519,7 @@ static AttnPlan attn_plan(int batch, int n_heads, int n_groups, int max_seq_len,
     const long one_per_cu = std::max<long>(1, (num_cus + base - 1) / base);
     p.nsplits = (int)std::max<long>(1, std::min<long>(p.nsplits, one_per_cu));
   }
-  static int force_splits = -1;  // DIHIP_ATTN_NSPLITS: diagnostics
-  if (force_splits < 0) {
-    const char* e = getenv("DIHIP_ATTN_NSPLITS");
-    force_splits = e ? atoi(e) : 0;
-  }
+  static const int force_splits = env_int("DIHIP_ATTN_NSPLITS", 0);  // diagnostics
   if (force_splits > 0) p.nsplits = (int)std::min<long>(std::min<long>(force_splits, max_splits), split_cap);
   p.partial_bytes = p.nsplits > 1 ? (size_t)batch * n_heads * p.nsplits * ATTN_PSTRIDE * sizeof(float) : 0;
   return p;
@@ -587,11 +571,10 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
   // (request, group, head chunk)) the partial records are merged INSIDE the launch -- write-through records, arrival ticket,
   // the last workgroup merges (attn_block_epilogue_wt, round 3; the fenced last-arriver form of round 1 cost ~20 us per layer
   // at batch 32 and is gone) -- else by span_attn_split_merge_kernel as a second launch.  DIHIP_ATTN_MERGE=launch: always the latter.
-  static int merge_in_launch = -1;
-  if (merge_in_launch < 0) {
+  static const bool merge_in_launch = [] {
     const char* e = getenv("DIHIP_ATTN_MERGE");
-    merge_in_launch = (e && e[0] == 'l') ? 0 : 1;
-  }
+    return !(e && e[0] == 'l');
+  }();
   const bool ticket = merge_in_launch && counters != nullptr && p.nsplits > 1 && p.partial_bytes < (1ull << 31);
   a.counters = ticket ? counters : nullptr;
   a.merge_wt = ticket ? 1 : 0;
@@ -695,13 +678,11 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
   a.rope_tab = rope_table;
   a.partial_bytes = p.partial_bytes;
   // split width fixed from max_seq_len (AttnArgs::tps_static); DIHIP_ATTN_STATIC_TPS=0: from the request's length (A/B)
-  static int static_tps = -1, merge_mode = -1;
-  if (static_tps < 0) {
-    const char* e = getenv("DIHIP_ATTN_STATIC_TPS");
-    static_tps = (e && e[0] == '0') ? 0 : 1;
-    const char* m = getenv("DIHIP_ATTN_MERGE");  // "launch": the split merge as a second launch also when a sync buffer is given (A/B)
-    merge_mode = (m && m[0] == 'l') ? 0 : 1;
-  }
+  static const bool static_tps = !env_off("DIHIP_ATTN_STATIC_TPS");
+  static const int merge_mode = [] {  // "launch": the split merge as a second launch also when a sync buffer is given (A/B)
+    const char* m = getenv("DIHIP_ATTN_MERGE");
+    return (m && m[0] == 'l') ? 0 : 1;
+  }();
   if (static_tps) a.tps_static = ((max_seq_len + p.nsplits - 1) / p.nsplits + 31) & ~31;
   // in-launch merge: needs the caller's zero-initialised ticket words (dihip_span_attn_decode_fused_sync)
   const bool merge_wt = merge_mode >= 1 && p.nsplits > 1 && sync != nullptr &&
@@ -937,6 +918,16 @@ int dihip_span_attn_run(void* output, const void* query, const void* const* k_sp
                     handle->n_groups, handle->head_size, handle->span_len, handle->n_spans, handle->max_len,
                     handle->kv_mode, handle->dtype, qk_scale, partials, handle->partial_bytes, counters,
                     handle->num_cus);
+}
+
+int dihip_debug_attn_plan(int batch, int n_heads, int n_groups, int max_seq_len, int kv_mode, int dtype, int num_cus, int* nsplits,
+                          int* mfma) {
+  if (batch <= 0 || n_heads <= 0 || n_groups <= 0 || n_heads % n_groups || max_seq_len <= 0) return DIHIP_SA_PARAM_ERROR;
+  const bool m = attn_use_mfma(kv_mode, dtype);
+  const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, num_cus, m);
+  if (nsplits) *nsplits = p.nsplits;
+  if (mfma) *mfma = m ? 1 : 0;
+  return DIHIP_SUCCESS;
 }
 
 }  // extern "C"

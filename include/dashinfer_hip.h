@@ -483,6 +483,9 @@ int dihip_debug_set_trace(void* buf, size_t bytes);
 /* launch plan of the decode GEMV for a shape (DIHIP_PARAM_ERROR when the general kernel is used) */
 int dihip_debug_gemv_plan(int wbits, int M, int N, int K, int group_size, int dual, int* blocks,
                           int* upb, int* wk, int* wn, size_t* lds_bytes);
+/* split plan of the decode attention for a shape on `num_cus` CUs (0: this device's count, 256 without a device) */
+int dihip_debug_attn_plan(int batch, int n_heads, int n_groups, int max_seq_len, int kv_mode, int dtype, int num_cus,
+                          int* nsplits, int* mfma);
 
 #ifdef __cplusplus
 }
