@@ -34,7 +34,14 @@
 // schedule (two groups of four waves half a k-tile period apart so that each SIMD always has one multiplying wave: -7 %, or
 // -2 % with scalar instead of SLP-packed FMAs), scalar FMAs alone (-2 %).  The instruction mix is the limit: the fix-up
 // (2 FMA per accumulator element and group) and the 4-bit expansion (7 VALU per 8 weights) are inherent to multiplying the
-// integer weights in place; getting past ~35 % needs weights dequantised ahead of the GEMM (the reference's own large-M route).
+// integer weights in place.
+// Where the rest goes (per-wave cycle stamps + tools/gemm_skeleton_bench, same profile): the multiply phase itself runs at the
+// rate of the bare skeleton -- LDS fragment reads + MFMAs + barrier with nothing else reach 70 % of the matrix peak in this
+// tile shape, 82 % with the reads of k-step s + 1 issued ahead of the MFMAs of s (2 657 / 2 454 cycles per k-tile; the kernel's
+// two waves multiply for 2 620-3 312) -- and then ~1 600 cycles per k-tile pass with the pipe idle: fix-up 564, staging 408,
+// barrier 628.  Next: stage A with direct global -> LDS loads (no staging phase, 16 registers back; the row-sum MFMAs move to
+// the multiply, which reads those fragments anyway), spend the registers on pipelined fragment reads, and slide the fix-up under
+// the first k-step of the next tile.  (A one-wave-per-SIMD 128 x 128 wave tile measured WORSE as a bare skeleton: 54 %.)
 #pragma once
 #include "gemm_lowp_kernel.hpp"
 #include "gemv_stream_kernel.hpp"  // ExpandV: the 128 + q expansion of the decode kernels
