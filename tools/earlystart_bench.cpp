@@ -1,5 +1,12 @@
-// earlystart_bench.cpp -- experiment for DESIGN.md section 8, item 1 (NOT yet run: written at the end of round 1 when the
-// GPU budget was spent; compile-checked only).
+// earlystart_bench.cpp -- experiment for DESIGN.md section 8, item 1.  Run at the end of round 3 (one MI355X, 56 dependent stages):
+//     MB per stage   plain boundaries   early start (two streams)   pure stream at 6.7 TB/s
+//          8              4.17 us              21.0 us                     1.25 us
+//         16              5.32                 36.1                        2.50
+//         36              8.27                 39.4                        5.63
+//         72             13.75                 46.7                       11.27
+// -> the two-stream early start is a dead end (each hand-over between the streams costs 17-30 us); the "boundaries" column is the
+// floor of a chain of bare streaming kernels: 2.5-2.9 us per stage on top of the bytes.  The product's four GEMVs per layer (8.8, 6.4,
+// 72 and 36 MB: 5.44 + 4.31 + 15.05 + 9.29 = 34.1 us) sit within 13 % of that chain (4.2 + 4.0 + 13.75 + 8.27 = 30.2 us).
 //
 // Question: a decode layer is a chain of dependent weight-streaming kernels, and each launch spends 3-5 us not
 // streaming (ramp, first-byte latency, tail) -- `tools/ldsdma_bench` shows the transport itself reaches 6.4-6.9 TB/s.
