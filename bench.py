@@ -200,6 +200,90 @@ def cpu_baseline_torch(wbits, group, seq_len=SEQ_LEN, budget_s=15.0, weights="bf
                       f"weights dequantised to {weights} as the x86 path holds them (int{wbits} g{group} on the GPU)"}
 
 
+def timed_blocks(run_n, steps, blocks, world=1, device=None, sync=None, before_block=None):
+    """`blocks` timed blocks of EXACTLY `steps` steps each.  A block is bracketed by barrier + synchronize on both sides; its time
+    is the MAXIMUM over the ranks (all-reduce MAX on `device`: the GPU under RCCL, the CPU under gloo in the tests).  before_block runs
+    untimed in front of each block (rewinding the sequences: every block then decodes the same positions).  The reported
+    time is the MEDIAN block (one clock ramp or a noisy neighbour cannot move the headline); min / max ride
+    along.  -> (median_s, [block seconds, max over ranks])"""
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+    if sync is None:
+        sync = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)
+
+    def barrier():
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
+
+    times = []
+    for _ in range(max(1, blocks)):
+        if before_block is not None:   # untimed: e.g. rewind the sequences so that every block decodes the same positions
+            before_block()
+        barrier()
+        t0 = time.perf_counter()
+        run_n(steps)
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=device if device is not None else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        times.append(el)
+    srt = sorted(times)
+    return srt[len(srt) // 2], times
+
+
+def blocks_summary(times, steps):
+    srt = sorted(times)
+    return {"count": len(times), "steps_each": steps, "ms_per_step_median": round(srt[len(srt) // 2] / steps * 1e3, 4),
+            "ms_per_step_min": round(srt[0] / steps * 1e3, 4), "ms_per_step_max": round(srt[-1] / steps * 1e3, 4),
+            "spread": round((srt[-1] - srt[0]) / srt[len(srt) // 2], 4)}
+
+
+def host_runner_bench(args, torch, decoder, ops, model, sess, batch, max_len, kv_mode, fuse, graph, steps, blocks):
+    """The SAME decode step through the C++ operator layer (dash-infer_amd/host): the reference's Qwen2 operator list
+    (tests/ref_graph.py: qwen_v15.py:187-388) -> fusion pass (host/fusion_pass.cpp; fuse=False: the list as it is, fourteen launches
+    per layer) -> OpFactory -> HipModelRunner (host/model_runner.cpp: Alloc -> Forward per operator per step, model.cpp:1248-1325),
+    the fused step captured once as a hipGraph and replayed.  The requests adopt the Python session's cache spans (same random
+    history); the weights are the same quantised tensors, re-laid-out by the operators' own InitV2."""
+    from dash_infer_amd import hostapi
+    from tests import ref_graph
+    cfg = model.cfg
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    kvc = {"none": 0, "i8": 1, "u4": 2}[kv_mode]
+    with torch.cuda.stream(stream):
+        m = hostapi.Model(ops.cur_stream(), cfg.n_heads, cfg.n_kv, cfg.head_dim, sess.pool.S, kvc, max_batch=batch, max_len=max_len)
+        try:
+            ref_graph.register_weights(m, model)
+            g = ref_graph.qwen2_graph(len(model.layers), model.quant.wbits, model.quant.group, cfg.eps, cfg.n_heads, cfg.n_kv, cfg.rope_theta)
+            ref_graph.add_graph(m, g)
+            rep = m.graph_build(fuse=fuse)
+            gen = torch.Generator().manual_seed(7)
+            ids = torch.randint(0, cfg.vocab, (batch,), generator=gen).tolist()
+            for b in range(batch):
+                ks = [[int(p) for p in sess.kv[li].k_host[b].tolist()] for li in range(len(model.layers))]
+                vs = [[int(p) for p in sess.kv[li].v_host[b].tolist()] for li in range(len(model.layers))]
+                m.request_adopt(SEQ_LEN, ids[b], ks, vs)
+            m.decode_steps(max(2, args.warmup), graph=graph)
+            m.sync_ids()
+
+            def run_n(n):
+                m.decode_steps(n, graph=graph)
+
+            med, times = timed_blocks(run_n, steps, blocks, sync=stream.synchronize, before_block=lambda: m.requests_rewind(SEQ_LEN))
+            last = m.sync_ids()
+        finally:
+            m.close()
+    return {"tokens_per_s": round(batch * steps / med, 2), "ms_per_step": round(med / steps * 1e3, 4), "blocks": blocks_summary(times, steps),
+            "fused": rep["fused"], "operators": f"{rep['ops']} ({len(rep['types'])} operators run per step)", "hipGraph": bool(graph),
+            "why_unfused": rep["why"] if not rep["fused"] else None, "last_ids": last[:4]}
+
+
 def prefill_bench(args, torch, decoder, ops):
     """--workload prefill_2048 (see WORKLOADS).  Timed with HIP events on the launch stream around whole prefill calls (eager
     launches: the context phase is not graph-captured); the attention kernel alone is timed the same way over all layers' calls."""
@@ -433,6 +517,129 @@ def kernel_breakdown(sess, torch, ops, iters=5):
     return res
 
 
+def allreduce_alone(torch, comm, sess, n_layers, graph_on, step_ms, world):
+    """Time of the step's hidden-row all-reduces alone (2 per layer), back to back, max over ranks."""
+    import torch.distributed as dist
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+    try:
+        n_ar = 2 * n_layers
+        buf = torch.zeros_like(sess.h)
+
+        def ar_only():
+            for _ in range(n_ar):
+                comm.allreduce_(buf)
+        s_ar = torch.cuda.Stream()
+        s_ar.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_ar):
+            ar_only()
+        torch.cuda.current_stream().wait_stream(s_ar)
+        barrier()
+        if graph_on:
+            g_ar = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_ar):
+                ar_only()
+            run_ar = g_ar.replay
+        else:
+            run_ar = ar_only
+        run_ar()
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            run_ar()
+        e1.record()
+        barrier()
+        ar_ms = e0.elapsed_time(e1) / 5
+        t_ar = torch.tensor([ar_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t_ar, op=dist.ReduceOp.MAX)
+        ar_ms = float(t_ar.item())
+        return {"count_per_step": n_ar, "bytes_each": int(buf.numel() * buf.element_size()),
+                "us_per_step": round(ar_ms * 1e3, 1), "us_each": round(ar_ms * 1e3 / n_ar, 2),
+                "share_of_step": round(ar_ms / step_ms, 4),
+                "note": "the step's hidden-row all-reduces alone, back to back (max over ranks); inside the step they also wait for the slowest rank's GEMV"}
+    except Exception as e:  # noqa: BLE001 -- never lose the headline number to a diagnostic
+        return {"error": repr(e)}
+
+
+def tp_ab_runs(args, torch, decoder, model, comm, batch, max_len, kv_mode, ids, rank, world, local_rank, blocks=3):
+    """TP > 1: the decode step under {rccl, p2p-oneshot} x {all-reduce on the compute stream, on a side stream beside the next
+    GEMV's weight prefetch}, each its own DecodeSession + hipGraph over the SAME sharded model, `blocks` blocks of --steps steps
+    (median, max over ranks).  Every rank walks the same list in the same order (collectives inside)."""
+    dev = torch.device("cuda", local_rank)
+    comms = []
+    rccl = comm.rccl if isinstance(comm, decoder.P2PComm) else comm
+    comms.append(("rccl", rccl))
+    if isinstance(comm, decoder.P2PComm):
+        comms.append(("p2p-oneshot", comm))
+    else:
+        comms.append(("p2p-oneshot", None))   # unavailable / failed verification on this node: recorded as such
+    res = []
+    for name, c in comms:
+        for overlap in (False, True):
+            row = {"allreduce": name, "overlap": overlap}
+            if c is None:
+                row["skipped"] = f"not available here: {getattr(comm, 'backend', None)}"
+                res.append(row)
+                continue
+            try:
+                sv = decoder.DecodeSession(model, batch, max_len, span_len=128, kv_mode=kv_mode, comm=c, ar_overlap=overlap)
+                sv.fill_cache_random(SEQ_LEN)
+                sv.set_state(ids, [SEQ_LEN] * batch)
+                try:
+                    sv.capture(warmup=1)
+                    run_n, graph_on = sv.replay_steps, True
+                except Exception as e:  # noqa: BLE001
+                    row["capture_error"] = repr(e)[:200]
+                    torch.cuda.synchronize()
+                    sv.set_state(ids, [SEQ_LEN] * batch)
+                    graph_on = False
+
+                    def run_n(n, sv=sv):
+                        for _ in range(n):
+                            sv.step()
+                run_n(max(2, args.warmup))
+                med, times = timed_blocks(run_n, args.steps, blocks, world, dev,
+                                          before_block=lambda sv=sv: sv.set_state(ids, [SEQ_LEN + args.warmup] * batch))
+                row.update(tokens_per_s=round(batch * args.steps / med, 2), ms_per_step=round(med / args.steps * 1e3, 4), hipGraph=graph_on,
+                           blocks=blocks_summary(times, args.steps), backend_label=c.backend)
+                if not overlap:
+                    a = allreduce_alone(torch, c, sv, len(model.layers), graph_on, med / args.steps * 1e3, world)
+                    row["allreduce_alone"] = {k: a.get(k) for k in ("us_each", "us_per_step", "share_of_step", "error") if k in a}
+                del sv
+            except Exception as e:  # noqa: BLE001
+                row["error"] = repr(e)[:300]
+            res.append(row)
+    return res
+
+
+def secondary_workloads(names=("int4_b32_u4kv", "int8_b1", "prefill_2048"), steps=10, warmup=3, timeout=420):
+    import subprocess
+    res = []
+    for w in names:
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", str(steps if w != "prefill_2048" else 3),
+               "--warmup", str(warmup if w != "prefill_2048" else 1), "--blocks", "3", "--no-cpu-baseline", "--no-extra"]
+        t0 = time.time()
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not line:
+                res.append({"workload": w, "error": f"rc {p.returncode}: {(p.stderr or p.stdout)[-400:]}"})
+                continue
+            d = json.loads(line[-1])
+            keep = {k: d.get(k) for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "step_hbm", "roofline",
+                                          "blocks", "attention", "gemms", "kernels") if k in d}
+            keep["workload"] = w
+            keep["wall_s"] = round(time.time() - t0, 1)
+            res.append(keep)
+        except Exception as e:  # noqa: BLE001
+            res.append({"workload": w, "error": repr(e)})
+    return res
+
+
 def csrc_tree_hash():
     """sha256 over the kernel sources (dash-infer_amd/csrc/*.hip, *.hpp, *.h, Makefile) in name order: stamps a PMC summary with
     the code it was collected on (tools/gpu_pmc.sh writes it, pmc_traffic() compares)."""
@@ -481,6 +688,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="debug: eager launches instead of hipGraph replay")
     ap.add_argument("--steps-per-graph", type=int, default=1,
                     help="consecutive decode steps captured per hipGraph (measured: 1 is fastest, back-to-back replays already pipeline)")
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each; the median block is reported")
+    ap.add_argument("--runner", default="python", choices=["python", "host"],
+                    help="whose step `value` is: decoder.DecodeSession (Python + ctypes) or the C++ operator layer (fused list, hipGraph)")
+    ap.add_argument("--no-extra", action="store_true", help="headline only: no host-runner figures, no secondary workloads, no TP A/B")
     args = ap.parse_args()
 
     import torch
@@ -523,7 +734,12 @@ def main():
         cfg, model_name = decoder.QWEN2_57B_A14B, "Qwen2-57B-A14B"
     spec = decoder.QuantSpec(wbits, group, gptq_like_zeros=gptq)
     t_build = time.time()
-    model = decoder.build_random_model(cfg, spec, seed=1234, rank=rank, nranks=world, layers=args.layers)
+    # the C++ operator layer is measured beside the Python runner on the dense one-GPU workloads (its operators re-lay-out the
+    # unpacked quantised tensors themselves: keep them)
+    host_leg = world == 1 and cfg.moe is None and (args.runner == "host" or not args.no_extra)
+    model = decoder.build_random_model(cfg, spec, seed=1234, rank=rank, nranks=world, layers=args.layers, keep_fp=host_leg)
+    blocks = max(1, args.blocks)
+    # (kept tight: the decode attention's split width is fixed from max_len; the blocks rewind to SEQ_LEN instead of growing it)
     max_len = SEQ_LEN + args.steps + args.warmup + 16
     sess = decoder.DecodeSession(model, batch, max_len, span_len=128, kv_mode=kv_mode, comm=comm)
     sess.fill_cache_random(SEQ_LEN)
@@ -577,60 +793,37 @@ def main():
     else:
         run_n = run_eager
     run_n(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run_n(args.steps)  # exactly K decode steps (graphs of --steps-per-graph consecutive steps + single-step graphs)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # exactly K decode steps per block (graphs of --steps-per-graph consecutive steps + single-step graphs), barrier + synchronize
+    # on both sides, max over ranks; the median of --blocks blocks is the reported time
+    elapsed, block_times = timed_blocks(run_n, args.steps, blocks, world, torch.device("cuda", local_rank),
+                                        before_block=lambda: sess.set_state(ids, [SEQ_LEN + args.warmup] * batch))
     last_ids = sess.ids.tolist()
+    python_runner = {"tokens_per_s": round(batch * args.steps / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 4)}
+    host_runner = None
+    if host_leg:
+        try:
+            host_runner = {"fused_graph": host_runner_bench(args, torch, decoder, ops, model, sess, batch, max_len, kv_mode, True, True,
+                                                            args.steps, blocks)}
+            if not args.no_extra:   # the reference's own operator list, one launch per operator, eager: what fusion + capture buy
+                host_runner["unfused_eager"] = host_runner_bench(args, torch, decoder, ops, model, sess, batch, max_len, kv_mode, False,
+                                                                 False, max(4, args.steps // 4), min(blocks, 3))
+            host_runner["fused_graph_vs_python_runner"] = round(host_runner["fused_graph"]["tokens_per_s"] / python_runner["tokens_per_s"], 4)
+        except Exception as e:  # noqa: BLE001 -- never lose the headline number to the second runner
+            if args.runner == "host":
+                raise
+            host_runner = {"error": repr(e)}
+    if args.runner == "host":
+        elapsed = host_runner["fused_graph"]["ms_per_step"] * 1e-3 * args.steps
+        block_times = None
 
     # share of the step spent in the tensor-parallel all-reduces: the step's collectives alone (2 per layer on the hidden rows,
     # same backend, same message), captured into a graph and replayed between events -- every rank takes part
-    ar_info = None
-    if world > 1:
-        try:
-            n_ar = 2 * len(model.layers)
-            buf = torch.zeros_like(sess.h)
-            def ar_only():
-                for _ in range(n_ar):
-                    comm.allreduce_(buf)
-            s_ar = torch.cuda.Stream()
-            s_ar.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s_ar):
-                ar_only()
-            torch.cuda.current_stream().wait_stream(s_ar)
-            barrier()
-            if graph_on:
-                g_ar = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_ar):
-                    ar_only()
-                run_ar = g_ar.replay
-            else:
-                run_ar = ar_only
-            run_ar()
-            barrier()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                run_ar()
-            e1.record()
-            barrier()
-            ar_ms = e0.elapsed_time(e1) / 5
-            import torch.distributed as dist
-            t_ar = torch.tensor([ar_ms], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t_ar, op=dist.ReduceOp.MAX)
-            ar_ms = float(t_ar.item())
-            ar_info = {"count_per_step": n_ar, "bytes_each": int(buf.numel() * buf.element_size()),
-                       "us_per_step": round(ar_ms * 1e3, 1), "us_each": round(ar_ms * 1e3 / n_ar, 2),
-                       "share_of_step": round(ar_ms / (elapsed / args.steps * 1e3), 4),
-                       "note": "the step's hidden-row all-reduces alone, back to back (max over ranks); inside the step they also wait for the slowest rank's GEMV"}
-        except Exception as e:  # noqa: BLE001 -- never lose the headline number to a diagnostic
-            ar_info = {"error": repr(e)}
+    ar_info = allreduce_alone(torch, comm, sess, len(model.layers), graph_on, elapsed / args.steps * 1e3, world) if world > 1 else None
+    # one SCALE invocation answers DESIGN section 4's open questions: RCCL vs the one-shot peer-to-peer all-reduce, each with the
+    # all-reduce on the compute stream and overlapped on a side stream beside a weight prefetch -- the SAME model, same process
+    tp_ab = None
+    if world > 1 and not args.no_extra:
+        tp_ab = tp_ab_runs(args, torch, decoder, model, comm, batch, max_len, kv_mode, ids, rank, world, local_rank)
 
     ms_per_step = elapsed / args.steps * 1e3
     tokens_per_s = batch * args.steps / elapsed
@@ -658,9 +851,15 @@ def main():
                    "layers": len(model.layers)},
         "step_hbm": {"algorithmic_bytes_per_rank": int(step_bytes), "achieved_GBps_per_gpu": round(step_gbs, 1),
                      "frac_of_peak": round(step_gbs / HBM_PEAK_GBS, 4)},
+        "runner": ("python: decoder.DecodeSession over the C-ABI (hipGraph replay)" if args.runner == "python" else
+                   "host: C++ operator layer, fused operator list behind the allspark operator API, hipGraph replay"),
+        "blocks": blocks_summary(block_times, args.steps) if block_times else (host_runner or {}).get("fused_graph", {}).get("blocks"),
+        "python_runner": python_runner,
+        "host_runner": host_runner,   # host_runner.fused_graph.tokens_per_s = the operator-API figure; .unfused_eager = op by op
         "comm_backend": (comm.backend if comm is not None else None),  # which all-reduce ran: never a silent substitute
         "ar_overlap": bool(getattr(sess, "ar_overlap", False)),        # all-reduce on a side stream + weight prefetch beside it
         "allreduce": ar_info,                                          # TP > 1: time of the step's all-reduces alone and their share
+        "tp_ab": tp_ab,                                                # TP > 1: rccl / p2p-oneshot x overlap off / on, same run
         "lm_head_split": getattr(model, "lm_split", "vocab") if world > 1 else None,
         "build_s": round(t_build, 1),
         "last_ids": last_ids[:4],
@@ -715,6 +914,10 @@ def main():
                 out["cpu_baseline_port"] = cpu_baseline(wbits, group)
             except Exception as e:
                 out["cpu_baseline_port_error"] = repr(e)
+        # the secondary workloads of the north star (batch 32 + uint4 KV, int8, the context phase) in the SAME driver-run line,
+        # short: each in its own process (own model, own allocator), its JSON line attached under extra.workloads
+        if world == 1 and args.workload == "int4_b1" and not args.no_extra and args.layers is None:
+            out["extra"] = {"workloads": secondary_workloads()}
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -67,6 +67,7 @@ _SIGS = {
     "dihip_span_attn_decode_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "dihip_span_attn_decode": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp]),
     "dihip_span_attn_decode_ex": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp, i32]),
+    "dihip_span_attn_decode_sync": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp, sz, i32]),
     "dihip_span_attn_sync_bytes": (sz, [i32, i32]),
     "dihip_rope_table": (i32, [vp, vp, vp, i32, i32]),
     "dihip_span_attn_fused_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),

@@ -43,6 +43,7 @@
 // the multiply, which reads those fragments anyway), spend the registers on pipelined fragment reads, and slide the fix-up under
 // the first k-step of the next tile.  (A one-wave-per-SIMD 128 x 128 wave tile measured WORSE as a bare skeleton: 54 %.)
 #pragma once
+#include <atomic>
 #include "gemm_lowp_kernel.hpp"
 #include "gemv_stream_kernel.hpp"  // ExpandV: the 128 + q expansion of the decode kernels
 
@@ -311,10 +312,18 @@ hipError_t launch_gemm_prefill(const PrefillArgs& a, int blocks, hipStream_t str
   hipError_t launch_gemm_prefill<WBITS, FT, EPI, GPT>(const PrefillArgs& a, int blocks, hipStream_t s) {           \
     auto kern = gemm_prefill_kernel<WBITS, FT, EPI, GPT>;                                                          \
     constexpr size_t lds = prefill_lds_bytes<WBITS>();                                                             \
-    if (lds > 64 * 1024) {  /* granted once (thread-safe static initialisation) */                               \
-      static const hipError_t granted =                                                                            \
-          hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      if (granted != hipSuccess) return granted;                                                                   \
+    if (lds > 64 * 1024) {  /* the grant is per DEVICE: once per device of this process */           \
+      static std::atomic<unsigned> granted_mask[4];  /* 128 device ids */                                          \
+      int dev = 0;                                                                                                 \
+      if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();                                              \
+      const unsigned bit = 1u << (dev & 31);                                                                       \
+      std::atomic<unsigned>* word = dev >= 0 && dev < 128 ? &granted_mask[dev >> 5] : nullptr;                     \
+      if (!word || !(word->load(std::memory_order_acquire) & bit)) {                                               \
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+        if (e != hipSuccess) return e;                                                                             \
+        if (word) word->fetch_or(bit, std::memory_order_release);                                                  \
+      }                                                                                                            \
     }                                                                                                              \
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(PF_THREADS), lds, s, a);                                           \
     return hipGetLastError();                                                                                      \

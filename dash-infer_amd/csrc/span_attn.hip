@@ -541,7 +541,7 @@ static bool span_len_valid(int S) { return S == 16 || S == 32 || S == 64 || S ==
 static int run_decode(hipStream_t s, void* out, const void* q, const void* const* ks, const void* const* vs,
                       const uint32_t* seq_lens_dev, int batch, int n, int g, int H, int S, int span_stride,
                       int max_seq_len, int mode, int dtype, float scale, void* ws, size_t ws_bytes, unsigned* counters,
-                      int num_cus, int out_layout = DIHIP_ACT_ROWMAJOR, int len_bias = 0) {
+                      int num_cus, int out_layout = DIHIP_ACT_ROWMAJOR, int len_bias = 0, size_t counter_bytes = 0) {
   if (H != 128) {
     set_last_error("span_attn: unsupported head size %d (only 128, dispatch.hpp:45-57)", H);
     return DIHIP_SA_PARAM_ERROR;
@@ -575,7 +575,10 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
     const char* e = getenv("DIHIP_ATTN_MERGE");
     return !(e && e[0] == 'l');
   }();
-  const bool ticket = merge_in_launch && counters != nullptr && p.nsplits > 1 && p.partial_bytes < (1ull << 31);
+  //  the ticket words are only used when the caller states their size and it covers one 128-byte line per
+  // (request, KV group, head chunk): the legacy entry points pass 0 and keep the two-launch merge
+  const bool ticket = merge_in_launch && counters != nullptr && p.nsplits > 1 && p.partial_bytes < (1ull << 31) &&
+                      counter_bytes >= (size_t)batch * g * p.nchunks * 128;
   a.counters = ticket ? counters : nullptr;
   a.merge_wt = ticket ? 1 : 0;
   a.partial_bytes = p.partial_bytes;
@@ -794,6 +797,17 @@ int dihip_span_attn_decode_ex(void* stream, void* output, const void* query, con
                               int n_groups, int head_size, int span_len, int n_spans_per_request, int max_seq_len,
                               int kv_mode, int dtype, float qk_scale, void* ws, size_t ws_bytes, void* sync,
                               int out_layout) {
+  (void)sync;  // legacy signature: never touched (two-launch merge), as the header promises
+  return dihip_span_attn_decode_sync(stream, output, query, k_span_array, v_span_array, seq_lens_dev, batch, n_heads, n_groups,
+                                     head_size, span_len, n_spans_per_request, max_seq_len, kv_mode, dtype, qk_scale, ws, ws_bytes,
+                                     nullptr, 0, out_layout);
+}
+
+int dihip_span_attn_decode_sync(void* stream, void* output, const void* query, const void* const* k_span_array,
+                                const void* const* v_span_array, const uint32_t* seq_lens_dev, int batch, int n_heads,
+                                int n_groups, int head_size, int span_len, int n_spans_per_request, int max_seq_len,
+                                int kv_mode, int dtype, float qk_scale, void* ws, size_t ws_bytes, void* sync,
+                                size_t sync_bytes, int out_layout) {
   DIHIP_REQUIRE(out_layout == DIHIP_ACT_ROWMAJOR || out_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR,
                 "span_attn_decode: bad out_layout");
   DIHIP_REQUIRE(batch >= 0 && n_heads > 0 && n_groups > 0 && head_size > 0 && n_spans_per_request > 0 &&
@@ -804,7 +818,7 @@ int dihip_span_attn_decode_ex(void* stream, void* output, const void* query, con
   if (batch == 0) return DIHIP_SUCCESS;
   int st = run_decode(reinterpret_cast<hipStream_t>(stream), output, query, k_span_array, v_span_array, seq_lens_dev,
                       batch, n_heads, n_groups, head_size, span_len, n_spans_per_request, max_seq_len, kv_mode, dtype,
-                      qk_scale, ws, ws_bytes, reinterpret_cast<unsigned*>(sync), 0, out_layout);
+                      qk_scale, ws, ws_bytes, reinterpret_cast<unsigned*>(sync), 0, out_layout, 0, sync ? sync_bytes : 0);
   if (st == DIHIP_SA_SUCCESS) return DIHIP_SUCCESS;
   return st == DIHIP_SA_PARAM_ERROR ? DIHIP_PARAM_ERROR : DIHIP_RUNTIME_ERROR;
 }
@@ -917,7 +931,7 @@ int dihip_span_attn_run(void* output, const void* query, const void* const* k_sp
   return run_decode(s, output, query, k_span_array, v_span_array, lens_dev, handle->batch, handle->n_heads,
                     handle->n_groups, handle->head_size, handle->span_len, handle->n_spans, handle->max_len,
                     handle->kv_mode, handle->dtype, qk_scale, partials, handle->partial_bytes, counters,
-                    handle->num_cus);
+                    handle->num_cus, DIHIP_ACT_ROWMAJOR, 0, handle->counter_bytes);
 }
 
 int dihip_debug_attn_plan(int batch, int n_heads, int n_groups, int max_seq_len, int kv_mode, int dtype, int num_cus, int* nsplits,

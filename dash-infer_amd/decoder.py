@@ -135,11 +135,28 @@ def _pack(q, s, z, spec, rows=None, cols=None, n_full=None):
     return ops.pack_lowp(qq, ss.contiguous(), zz.contiguous(), spec.group, spec.wbits)
 
 
+def decisive_permutation(vocab, seed):
+    """The next-token map of a `decisive` synthetic model: a fixed random permutation of the vocabulary (host generator:
+    the same on every box and device)."""
+    g = torch.Generator()
+    g.manual_seed(int(seed) + 900004)
+    return torch.randperm(vocab, generator=g)
+
+
 def build_random_model(cfg: ModelConfig, spec: QuantSpec, seed=1234, device="cuda", rank=0, nranks=1,
-                       dtype=torch.bfloat16, layers: Optional[int] = None, keep_fp=False, lm_head_split=None):
+                       dtype=torch.bfloat16, layers: Optional[int] = None, keep_fp=False, lm_head_split=None,
+                       decisive: Optional[float] = None):
     """Synthetic weights per SURVEY 8(d): W ~ N(0, 0.02^2) in FT with
     Generator(seed + 1000*layer + idx), InstantQuant-quantised on the FULL matrix (as the reference
-    converter does before the TP split), then sliced for this rank and packed."""
+    converter does before the TP split), then sliced for this rank and packed.
+
+    decisive = s (tests only): a model whose greedy choice is DECISIVE, like a trained model's and unlike
+    N(0, 0.02) weights (whose top-2 logit margins of 1e-3 .. 6e-2 sit below any bf16 graph's own rounding noise, so that
+    "bit-exact greedy ids" cannot be asserted on them).  The embedding rows are drawn with standard deviation s (the 28 random
+    layers add ~ N(0, 2.3^2) per element each to the residual stream, so s = 2 leaves the embedding ~ 3 % of the final hidden
+    state's energy) and the lm_head column of token pi(t) is 0.02 x the embedding row of t, pi = decisive_permutation: the
+    logit of pi(current token) stands ~ 2 x above the best of the other 152k -- a margin tens of times the accumulated
+    rounding error of the hidden state -- while every layer's output still moves every logit.  Everything else is unchanged."""
     H, n, g = cfg.head_dim, cfg.n_heads, cfg.n_kv
     shards = tp.shard_heads(n, g, nranks)
     me = shards[rank]
@@ -214,7 +231,7 @@ def build_random_model(cfg: ModelConfig, spec: QuantSpec, seed=1234, device="cud
                                  "experts_down": [q for _, q in eq["down"]]}
         out_layers.append(lw)
         del w_qkv, w_o, w_gate, w_up, w_down, qs
-    embed = rand((cfg.vocab, cfg.hidden), seed + 900001)
+    embed = rand((cfg.vocab, cfg.hidden), seed + 900001, std=0.02 if decisive is None else float(decisive))
     final_norm = (1.0 + rand((cfg.hidden,), seed + 900002, 0.1).float()).to(dtype)
     # lm_head stays unquantised FT (qwen_v15.py:153-164).  Under TP, two splits (lm_head_split, default $DIHIP_TP_LMHEAD or "vocab"):
     #   "vocab"  vocabulary-parallel slice + arg-max pair all-gather: 1/nranks of the logits per rank, 8 bytes per request on the
@@ -227,7 +244,15 @@ def build_random_model(cfg: ModelConfig, spec: QuantSpec, seed=1234, device="cud
     assert lm_split in ("vocab", "k"), f"unknown lm_head split {lm_split!r}"
     vloc = cfg.vocab // nranks
     assert cfg.vocab % nranks == 0
-    w_lm = rand((cfg.hidden, cfg.vocab), seed + 900003)
+    if decisive is None:
+        w_lm = rand((cfg.hidden, cfg.vocab), seed + 900003)
+    else:
+        perm = decisive_permutation(cfg.vocab, seed).to(device)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(cfg.vocab, device=device)
+        # column v = 0.02 x the embedding row of the token whose successor v is (FT rounding of the product)
+        w_lm = (embed.float() * 0.02).to(dtype)[inv].t().contiguous()
+        del perm, inv
     if fp is not None:
         fp["embed"], fp["final_norm"], fp["lm_head"] = embed, final_norm, w_lm
     if lm_split == "k":
@@ -472,7 +497,7 @@ class DecodeSession:
     """Buffers + KV spans for a fixed batch; `step()` enqueues one decode step."""
 
     def __init__(self, model: ModelWeights, batch, max_len, span_len=128, kv_mode="none", comm: Optional[RcclComm] = None,
-                 device="cuda"):
+                 device="cuda", ar_overlap: Optional[bool] = None):
         cfg = model.cfg
         self.model, self.B, self.max_len, self.comm = model, batch, max_len, comm
         self.kv_mode = kv_mode
@@ -564,7 +589,8 @@ class DecodeSession:
         # -- the collective on a side HIP stream between two events (record after the producing GEMV -> side stream waits ->
         # all-reduce -> record -> compute stream waits), while the compute stream pulls the weights of the NEXT GEMV into
         # the Infinity Cache (the only work of the decode chain that does not depend on the reduced row).
-        self.ar_overlap = comm is not None and model.nranks > 1 and os.environ.get("DIHIP_TP_OVERLAP", "0") == "1"
+        want_overlap = os.environ.get("DIHIP_TP_OVERLAP", "0") == "1" if ar_overlap is None else bool(ar_overlap)
+        self.ar_overlap = comm is not None and model.nranks > 1 and want_overlap
         self.side_stream = torch.cuda.Stream(device=device) if self.ar_overlap else None
         self.argmax_ws = torch.empty(batch * 64 * 8, dtype=torch.uint8, device=device)
         nr = model.nranks
@@ -645,46 +671,64 @@ class DecodeSession:
 
     # -- one decode step -------------------------------------------------------------------
     def step(self):
-        m, cfg, sc = self.model, self.model.cfg, self.scratch
+        m = self.model
         ops.embedding(self.ids, m.embed, out=self.h)
+        L = len(m.layers)
+        for li in range(L):
+            self._layer(li, first=li == 0, last=li + 1 == L)
+        self._head()
+
+    def run_single_layer(self, li):
+        """Layer li alone on the f32 hidden rows in self.h (in place), against the cache state (old_lens) as it is: the
+        per-layer teacher-forced drift test feeds the oracle's layer input here (tests/test_gpu_parity_depth.py).  Same
+        launches as the layer inside step(), in the forms the first layer (norm from h) and the last layer (no norm handed
+        on) take -- bit-identical to the mid-layer forms (tests/test_gpu_gemm.py)."""
+        self._layer(li, first=True, last=True)
+
+    def _layer(self, li, first, last):
+        m, cfg, sc = self.model, self.model.cfg, self.scratch
+        lw = m.layers[li]
         tp_on = self.comm is not None and m.nranks > 1
         nf = self.norm_fuse and not tp_on
-        for li, lw in enumerate(m.layers):
-            if nf and li > 0:
-                ops.prenorm_gemm(self.xn1, lw.qkv, lw.qkv_bias, sc, self.B, x_layout=self.xn1_layout, out=self.qkv)
+        if nf and not first:
+            ops.prenorm_gemm(self.xn1, lw.qkv, lw.qkv_bias, sc, self.B, x_layout=self.xn1_layout, out=self.qkv)
+        else:
+            ops.fused_norm_gemm(self.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sc, out=self.qkv)
+        if self.fused_attention:
+            ops.span_attn_decode_fused(self.qkv, self.kv[li], self.old_lens, self.rope_tab, self.n_loc, self.g_loc, self.H,
+                                       self.max_len, self.scale, self.attn_ws, out=self.attn,
+                                       sync=self.attn_sync if self.attn_merge_in_launch else None)
+        else:
+            ops.rope_kv_append(self.kv[li], self.q, self.qkv, self.old_lens, self.inv_freq, self.n_loc, self.g_loc, self.H)
+            ops.span_attn_decode(self.q, self.kv[li], self.new_lens, self.n_loc, self.g_loc, self.H, self.max_len,
+                                 self.scale, self.attn_ws, self.attn_sync, out=self.attn,
+                                 out_layout=ops.ACT_FRAG32 if self.attn_frag else ops.ACT_ROWMAJOR)
+        if cfg.moe is not None:
+            self._proj_residual(self.attn, lw.o, tp_on, frag=self.attn_frag)
+            self._moe_block(lw, tp_on)
+            return
+        if nf:
+            ops.fused_gemm_addto_norm(self.attn, lw.o, self.h, sc, lw.ln2, cfg.eps, self.xn2, out=self.h,
+                                      x_layout=ops.ACT_FRAG32 if self.attn_frag else ops.ACT_ROWMAJOR,
+                                      xnorm_layout=self.xn2_layout, M=self.B)
+            ops.prenorm_swiglu(self.xn2, lw.gate, lw.up, sc, self.B, x_layout=self.xn2_layout, out=self.act,
+                               y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
+            if not last:
+                ops.fused_gemm_addto_norm(self.act, lw.down, self.h, sc, m.layers[li + 1].ln1, cfg.eps, self.xn1, out=self.h,
+                                          x_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR,
+                                          xnorm_layout=self.xn1_layout, M=self.B)
             else:
-                ops.fused_norm_gemm(self.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, sc, out=self.qkv)
-            if self.fused_attention:
-                ops.span_attn_decode_fused(self.qkv, self.kv[li], self.old_lens, self.rope_tab, self.n_loc, self.g_loc, self.H,
-                                           self.max_len, self.scale, self.attn_ws, out=self.attn,
-                                           sync=self.attn_sync if self.attn_merge_in_launch else None)
-            else:
-                ops.rope_kv_append(self.kv[li], self.q, self.qkv, self.old_lens, self.inv_freq, self.n_loc, self.g_loc, self.H)
-                ops.span_attn_decode(self.q, self.kv[li], self.new_lens, self.n_loc, self.g_loc, self.H, self.max_len,
-                                     self.scale, self.attn_ws, self.attn_sync, out=self.attn,
-                                     out_layout=ops.ACT_FRAG32 if self.attn_frag else ops.ACT_ROWMAJOR)
-            if cfg.moe is not None:
-                self._proj_residual(self.attn, lw.o, tp_on, frag=self.attn_frag)
-                self._moe_block(lw, tp_on)
-                continue
-            if nf:
-                ops.fused_gemm_addto_norm(self.attn, lw.o, self.h, sc, lw.ln2, cfg.eps, self.xn2, out=self.h,
-                                          x_layout=ops.ACT_FRAG32 if self.attn_frag else ops.ACT_ROWMAJOR,
-                                          xnorm_layout=self.xn2_layout, M=self.B)
-                ops.prenorm_swiglu(self.xn2, lw.gate, lw.up, sc, self.B, x_layout=self.xn2_layout, out=self.act,
-                                   y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
-                if li + 1 < len(m.layers):
-                    ops.fused_gemm_addto_norm(self.act, lw.down, self.h, sc, m.layers[li + 1].ln1, cfg.eps, self.xn1, out=self.h,
-                                              x_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR,
-                                              xnorm_layout=self.xn1_layout, M=self.B)
-                else:
-                    self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag)  # lm_head applies the final norm itself
-                continue
-            self._proj_residual(self.attn, lw.o, tp_on, frag=self.attn_frag, next_weights=(lw.gate.w, lw.up.w))
-            ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act,
-                                  y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
-            nxt = m.layers[li + 1].qkv if li + 1 < len(m.layers) else m.lm_head
-            self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag, next_weights=(nxt.w,))
+                self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag)  # lm_head applies the final norm itself
+            return
+        self._proj_residual(self.attn, lw.o, tp_on, frag=self.attn_frag, next_weights=(lw.gate.w, lw.up.w))
+        ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act,
+                              y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
+        nxt = m.layers[li + 1].qkv if li + 1 < len(m.layers) else m.lm_head
+        self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag, next_weights=(nxt.w,))
+
+    def _head(self):
+        m, cfg, sc = self.model, self.model.cfg, self.scratch
+        tp_on = self.comm is not None and m.nranks > 1
         if self.lm_ksplit and tp_on:
             # the reference's lm_head under TP (model_base.py:690-703): final norm -> this rank's K slice of the row times its row
             # block of the weight -> all-reduce of the partial logits: every rank ends with the full f32 logits row

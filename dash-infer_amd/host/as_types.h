@@ -156,6 +156,14 @@ class DeviceContext {
   AsCacheMode cache_mode_ = AsCacheMode::AsCacheDefault;
 };
 
+// A consumer GEMM's shape, advertised at Init for the tensor it reads, so that the PRODUCER of that tensor can decide at
+// Reshape (when the row count is known) whether to write it in the MFMA-fragment layout the small-batch kernels load
+// fastest (DIHIP_ACT_FRAG32, include/dashinfer_hip.h section 1) -- the decision decoder.DecodeSession takes with
+// ops.prefers_frag().  Backend-private graph annotation: nothing of it crosses the operator interface.
+struct ActLayoutPref {
+  int wbits = 0, n = 0, k = 0, group = -1, dual = 0;
+};
+
 class HIPContext : public DeviceContext {
  public:
   DeviceType GetDeviceType() const override { return DeviceType::HIP; }
@@ -164,9 +172,29 @@ class HIPContext : public DeviceContext {
   void* GetRCCLComm() const { return comm_; }
   void SetRCCLComm(void* c) { comm_ = c; }
 
+  // ---- annotations of the fused decode graph (host/fused_ops_hip.cpp; written at Init / Reshape, read at Forward) ----
+  void AdvertiseLayoutPref(const std::string& tensor, const ActLayoutPref& p) const { layout_pref_[tensor] = p; }
+  const ActLayoutPref* LayoutPref(const std::string& tensor) const {
+    auto it = layout_pref_.find(tensor);
+    return it == layout_pref_.end() ? nullptr : &it->second;
+  }
+  void SetActLayout(const std::string& tensor, int layout) const { act_layout_[tensor] = layout; }
+  int ActLayout(const std::string& tensor) const {
+    auto it = act_layout_.find(tensor);
+    return it == act_layout_.end() ? 0 : it->second;
+  }
+  // The model runner keeps the per-request sequence lengths ON THE DEVICE (tensors "dihip.old_seq_lens" / "dihip.new_seq_lens",
+  // advanced by the greedy sampling launch) so that a captured decode step replays with nothing changing on the host; without a
+  // runner (a plain Alloc -> Forward loop over the operators) every attention operator uploads the lengths itself per step.
+  bool LensOnDevice() const { return lens_on_device_; }
+  void SetLensOnDevice(bool v) const { lens_on_device_ = v; }
+
  private:
   hipStream_t stream_ = nullptr;
   void* comm_ = nullptr;
+  mutable std::map<std::string, ActLayoutPref> layout_pref_;
+  mutable std::map<std::string, int> act_layout_;
+  mutable bool lens_on_device_ = false;
 };
 
 // VirtualCache (csrc/runtime/cache/virtual_cache.h:93-139): the per-request paged cache of all layers, as the span
@@ -182,10 +210,21 @@ class VirtualCache {
   virtual int GetLayerNum() const = 0;
 };
 
+// the sampling half of GenerateConfig (csrc/interface/allspark.h GenerateConfig: top_k / top_p / temperature / seed, the
+// fields GenerateOp reads per request, generate_op.cpp:60-140)
+struct GenerateConfig {
+  int top_k = 1;            // 0: the whole vocabulary (then top_p decides); 1: greedy
+  float top_p = 1.0f;       // 0 or >= 1: off
+  float temperature = 1.0f;
+  unsigned long long seed = 0;
+};
+
 // per-request generation state (generate_context.h:32-70): step = tokens already in the cache
 struct GenerateContext {
   int step = 0;
   int prefix_len = 0;
+  GenerateConfig gen_cfg;
+  unsigned long long sample_calls = 0;   // draws taken so far (the per-request random stream's position)
   std::shared_ptr<VirtualCache> virtual_k_cache, virtual_v_cache;  // generate_context.h:60-61
 };
 

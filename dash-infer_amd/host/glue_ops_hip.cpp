@@ -72,6 +72,10 @@ REGISTER_OP(LayerNormNoBeta, HIP, LayerNormNoBetaHIP)
 class RotaryHIP : public AsOperator {
  public:
   explicit RotaryHIP(const std::string& t = "") : AsOperator(t) {}
+  ~RotaryHIP() override {
+    if (pos_host_) (void)hipHostFree(pos_host_);
+    if (staged_) (void)hipEventDestroy(staged_);
+  }
   AsStatus Init(const OperatorProto& op_proto, const DeviceContext& ctx, const TensorMap& weights_map, TensorMap* tensor_map) override {
     AS_CHECK_STATUS(AsOperator::Init(op_proto, ctx, weights_map, tensor_map));
     // type inference at Init, as every reference operator does it (rotary_op.cpp:90-91): the NEXT operator's Init reads it
@@ -120,19 +124,30 @@ class RotaryHIP : public AsOperator {
     AsTensor* y = tensor_map_->at(out_names_[0]).get();
     const int rows = batch_ * seq_len_;
     if (rows == 0) return AsStatus::ALLSPARK_SUCCESS;
-    std::vector<uint32_t> pos(rows);
+    // positions staged in pinned memory, guarded by an event (a pageable copy + hipStreamSynchronize per layer per step
+    // serialised the stream); the reference stages them once per step through its layer cache manager (rotary_op.cpp:315-338)
+    if ((size_t)rows > pos_cap_) {
+      if (pos_host_) (void)hipHostFree(pos_host_);
+      pos_cap_ = std::max<size_t>(rows, 256);
+      if (hipHostMalloc((void**)&pos_host_, pos_cap_ * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return AsStatus::ALLSPARK_MEMORY_ERROR;
+    }
+    if (!staged_ && hipEventCreateWithFlags(&staged_, hipEventDisableTiming) != hipSuccess) return AsStatus::ALLSPARK_RUNTIME_ERROR;
+    if (hipEventSynchronize(staged_) != hipSuccess) return AsStatus::ALLSPARK_RUNTIME_ERROR;  // the previous copy has left the buffer
+    uint32_t* pos = pos_host_;
     if (rt->is_context) {
       if (batch_ != 1) return AsStatus::ALLSPARK_RUNTIME_ERROR;  // rotary_op.cpp:301-306
       const GenerateContext* g = rt->GetContextGenCtx();
-      for (int t = 0; t < seq_len_; ++t) pos[t] = (uint32_t)(g->step + g->prefix_len + t);
+      // model.cpp:532 sets gen_ctx->step = prefix_len for a prefill over a cached prefix, and the kernel rotates row t at
+      // seq_pos + step (rotary.cu:133): the prefix enters ONCE, through step (step + prefix_len counted it twice)
+      for (int t = 0; t < seq_len_; ++t) pos[t] = (uint32_t)(g->step + t);
     } else {
       if (rt->GetGenCtxListSize() != batch_ || seq_len_ != 1) return AsStatus::ALLSPARK_RUNTIME_ERROR;
       for (int b = 0; b < batch_; ++b) pos[b] = (uint32_t)rt->GetGenCtx(b)->step;  // rotary_op.cpp:379-389
     }
     hipStream_t s = stream_of(ctx_);
-    if (hipMemcpyAsync(positions_->GetDataPtr(), pos.data(), rows * sizeof(uint32_t), hipMemcpyHostToDevice, s) != hipSuccess)
+    if (hipMemcpyAsync(positions_->GetDataPtr(), pos, rows * sizeof(uint32_t), hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipEventRecord(staged_, s) != hipSuccess)
       return AsStatus::ALLSPARK_RUNTIME_ERROR;
-    if (hipStreamSynchronize(s) != hipSuccess) return AsStatus::ALLSPARK_RUNTIME_ERROR;  // `pos` is a stack-lifetime pageable buffer
     if (y->GetDataPtr() != x->GetDataPtr() &&
         hipMemcpyAsync(y->GetDataPtr(), x->GetDataPtr(), x->GetSizeInByte(), hipMemcpyDeviceToDevice, s) != hipSuccess)
       return AsStatus::ALLSPARK_RUNTIME_ERROR;
@@ -144,6 +159,9 @@ class RotaryHIP : public AsOperator {
   int num_heads_ = 0, group_num_ = 0, size_per_head_ = 0, hidden_ = 0, kv_stride_ = 0, batch_ = 0, seq_len_ = 0;
   float base_ = 10000.f;
   std::unique_ptr<AsTensor> inv_freq_, positions_;
+  uint32_t* pos_host_ = nullptr;
+  size_t pos_cap_ = 0;
+  hipEvent_t staged_ = nullptr;
 };
 REGISTER_OP(Rotary, HIP, RotaryHIP)
 

@@ -5,6 +5,7 @@
 #include <sstream>
 #include <thread>
 
+#include "model_runner.h"
 #include "operator.h"
 
 using namespace allspark;
@@ -32,6 +33,13 @@ class ListVirtualCache : public VirtualCache {
     ++calls_;
     return *views_[layer];
   }
+  void Rewind(size_t len) {  // benchmarks: the cache is taken back to `len` tokens (its spans stay assigned)
+    std::lock_guard<std::mutex> g(mu_);
+    for (size_t l = 0; l < len_.size(); ++l) {
+      len_[l] = len;
+      refresh(l);
+    }
+  }
   size_t GetSeqLength(int layer) const override {
     std::lock_guard<std::mutex> g(mu_);
     return layer >= 0 && layer < (int)len_.size() ? len_[layer] : 0;
@@ -57,6 +65,9 @@ struct dihost_model {
   TensorMap tensors, weights, weights_buffer;
   RuntimeContext rt;
   std::vector<std::unique_ptr<AsOperator>> ops;
+  std::vector<OperatorProto> graph;          // dihost_graph_add_op
+  std::unique_ptr<HipModelRunner> runner;    // dihost_graph_build
+  std::string text;
 };
 static thread_local std::string g_err;
 
@@ -78,7 +89,9 @@ const char* dihost_registered_ops(void) {
   static std::string s;
   s.clear();
   for (const char* t : {"GemmA16W8", "GemmA16W4", "DecOptMHA", "DecOptMQA", "AllReduce", "AllGather", "MOEA16W8", "CalcExpert", "Gemm", "Rotary",
-                        "LayerNormNoBeta", "Binary", "Unary", "UnaryGLU", "EmbeddingT5", "GetLastLine", "GenerateOp", "TransMask", "RichEmbedding"}) {
+                        "LayerNormNoBeta", "Binary", "Unary", "UnaryGLU", "EmbeddingT5", "GetLastLine", "GenerateOp", "TransMask", "RichEmbedding",
+                        "PreProcessId", "UpdateId", "PostProcessId", "DihipEmbedding", "DihipNormGemm", "DihipRopeSpanAttn", "DihipGemmAddTo",
+                        "DihipNormSwiGLU", "DihipLMHead", "DihipGreedy", "DihipSample"}) {
     try {
       (void)OpFactory::getInstance().GetOperator({t, DeviceType::HIP});
       s += (s.empty() ? "" : ",");
@@ -135,9 +148,33 @@ int dihost_get_tensor(dihost_model_t m, const char* name, int* dtype, int* ndim,
   return 0;
 }
 
+static int parse_proto(OperatorProto& proto, const char* op_type, const char* op_name, const char* inputs, const char* outputs,
+                       const char* weights, const char* attrs);
+
 int dihost_op_create(dihost_model_t m, int* op_id, const char* op_type, const char* op_name, const char* inputs,
                      const char* outputs, const char* weights, const char* attrs) {
   OperatorProto proto;
+  const int prc = parse_proto(proto, op_type, op_name, inputs, outputs, weights, attrs);
+  if (prc) return prc;
+  std::unique_ptr<AsOperator> op;
+  try {
+    op = OpFactory::getInstance().GetOperator({proto.op_type, DeviceType::HIP})();
+  } catch (const AsException& e) {
+    g_err = e.what();
+    return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  }
+  const AsStatus st = op->CallInit(proto, m->ctx, m->weights, m->weights_buffer, &m->tensors, &m->rt);
+  if (st != AsStatus::ALLSPARK_SUCCESS) {
+    g_err = "CallInit failed";
+    return (int)st;
+  }
+  m->ops.push_back(std::move(op));
+  if (op_id) *op_id = (int)m->ops.size() - 1;
+  return 0;
+}
+
+static int parse_proto(OperatorProto& proto, const char* op_type, const char* op_name, const char* inputs, const char* outputs,
+                       const char* weights, const char* attrs) {
   proto.op_type = op_type ? op_type : "";
   proto.op_name = op_name ? op_name : "";
   proto.inputs = split(inputs, ',');
@@ -163,20 +200,6 @@ int dihost_op_create(dihost_model_t m, int* op_id, const char* op_type, const ch
     }
     proto.attr[key] = bytes;
   }
-  std::unique_ptr<AsOperator> op;
-  try {
-    op = OpFactory::getInstance().GetOperator({proto.op_type, DeviceType::HIP})();
-  } catch (const AsException& e) {
-    g_err = e.what();
-    return (int)AsStatus::ALLSPARK_PARAM_ERROR;
-  }
-  const AsStatus st = op->CallInit(proto, m->ctx, m->weights, m->weights_buffer, &m->tensors, &m->rt);
-  if (st != AsStatus::ALLSPARK_SUCCESS) {
-    g_err = "CallInit failed";
-    return (int)st;
-  }
-  m->ops.push_back(std::move(op));
-  if (op_id) *op_id = (int)m->ops.size() - 1;
   return 0;
 }
 
@@ -239,6 +262,126 @@ long dihost_cache_seq_len(dihost_model_t m, int request, int layer) {
 int dihost_op_forward(dihost_model_t m, int id) {
   AsOperator* op = get_op(m, id);
   return op ? (int)op->CallForward(&m->rt) : (int)AsStatus::ALLSPARK_PARAM_ERROR;
+}
+
+// ---- the model runner (host/model_runner.h): the reference's operator LIST, optionally rewritten by the fusion pass ----------
+int dihost_graph_add_op(dihost_model_t m, const char* op_type, const char* op_name, const char* inputs, const char* outputs,
+                        const char* weights, const char* attrs) {
+  OperatorProto proto;
+  const int rc = parse_proto(proto, op_type, op_name, inputs, outputs, weights, attrs);
+  if (rc) return rc;
+  m->graph.push_back(std::move(proto));
+  return 0;
+}
+int dihost_graph_build(dihost_model_t m, int fuse) {
+  m->runner = std::make_unique<HipModelRunner>(&m->ctx, &m->tensors, &m->weights, &m->weights_buffer);
+  const AsStatus st = m->runner->Build(m->graph, fuse != 0);
+  if (st != AsStatus::ALLSPARK_SUCCESS) g_err = m->runner->last_error();
+  return (int)st;
+}
+// "fused=<0|1>;layers=<n>;ops=<before>-><after>;why=<text>;types=<comma-separated operator types of the built list>"
+const char* dihost_graph_report(dihost_model_t m) {
+  if (!m->runner) return "";
+  const FusionReport& r = m->runner->fusion();
+  std::string t = "fused=" + std::to_string(r.fused ? 1 : 0) + ";layers=" + std::to_string(r.layers) + ";ops=" + std::to_string(r.ops_before) +
+                  "->" + std::to_string(r.ops_after) + ";why=" + r.why + ";types=";
+  for (size_t i = 0; i < m->runner->protos().size(); ++i) t += (i ? "," : "") + m->runner->protos()[i].op_type;
+  m->text = t;
+  return m->text.c_str();
+}
+// the fusion pass alone on the recorded list (no operator is created: runs without a GPU); same report format
+const char* dihost_graph_fuse_dry(dihost_model_t m) {
+  FusionReport r;
+  const std::vector<OperatorProto> out = FuseDecoderGraph(m->graph, m->ctx, &r);
+  std::string t = "fused=" + std::to_string(r.fused ? 1 : 0) + ";layers=" + std::to_string(r.layers) + ";ops=" + std::to_string(r.ops_before) +
+                  "->" + std::to_string(r.ops_after) + ";why=" + r.why + ";types=";
+  for (size_t i = 0; i < out.size(); ++i) t += (i ? "," : "") + out[i].op_type;
+  t += ";wiring=";
+  for (size_t i = 0; i < out.size(); ++i) {
+    t += (i ? "|" : "") + out[i].op_type + "(";
+    for (size_t j = 0; j < out[i].inputs.size(); ++j) t += (j ? "," : "") + out[i].inputs[j];
+    t += ")->(";
+    for (size_t j = 0; j < out[i].outputs.size(); ++j) t += (j ? "," : "") + out[i].outputs[j];
+    t += ")[";
+    for (size_t j = 0; j < out[i].weights.size(); ++j) t += (j ? "," : "") + out[i].weights[j];
+    t += "]";
+  }
+  m->text = t;
+  return m->text.c_str();
+}
+static std::shared_ptr<GenerateContext> make_request(dihost_model_t m, int step, int prefix_len, int top_k, float top_p, float temperature,
+                                                     unsigned long long seed, int n_layers, int spans_per_req, void* const* k_spans,
+                                                     void* const* v_spans, int cached_len) {
+  auto gc = std::make_shared<GenerateContext>();
+  gc->step = step;
+  gc->prefix_len = prefix_len;
+  gc->gen_cfg.top_k = top_k;
+  gc->gen_cfg.top_p = top_p;
+  gc->gen_cfg.temperature = temperature;
+  gc->gen_cfg.seed = seed;
+  std::vector<std::vector<void*>> ks(n_layers), vs(n_layers);
+  for (int l = 0; l < n_layers; ++l)
+    for (int i = 0; i < spans_per_req; ++i) {
+      ks[l].push_back(k_spans[(size_t)l * spans_per_req + i]);
+      vs[l].push_back(v_spans[(size_t)l * spans_per_req + i]);
+    }
+  gc->virtual_k_cache = std::make_shared<ListVirtualCache>(std::move(ks), m->ctx.GetCacheSpanSize(), (size_t)cached_len);
+  gc->virtual_v_cache = std::make_shared<ListVirtualCache>(std::move(vs), m->ctx.GetCacheSpanSize(), (size_t)cached_len);
+  return gc;
+}
+int dihost_request_start(dihost_model_t m, const int64_t* prompt_host, int len, int prefix_len, int top_k, float top_p, float temperature,
+                         unsigned long long seed, int n_layers, int spans_per_req, void* const* k_spans, void* const* v_spans,
+                         int64_t* first_id) {
+  if (!m->runner) return (int)AsStatus::ALLSPARK_INVALID_CALL_ERROR;
+  auto gc = make_request(m, prefix_len, prefix_len, top_k, top_p, temperature, seed, n_layers, spans_per_req, k_spans, v_spans, prefix_len);
+  const AsStatus st = m->runner->StartRequest(gc, prompt_host, len, first_id);
+  if (st != AsStatus::ALLSPARK_SUCCESS) g_err = m->runner->last_error();
+  return (int)st;
+}
+int dihost_request_adopt(dihost_model_t m, int cached_len, int64_t next_id, int n_layers, int spans_per_req, void* const* k_spans,
+                         void* const* v_spans) {
+  if (!m->runner) return (int)AsStatus::ALLSPARK_INVALID_CALL_ERROR;
+  auto gc = make_request(m, cached_len, 0, 1, 1.0f, 1.0f, 0, n_layers, spans_per_req, k_spans, v_spans, cached_len);
+  const AsStatus st = m->runner->AdoptRequest(gc, next_id);
+  if (st != AsStatus::ALLSPARK_SUCCESS) g_err = m->runner->last_error();
+  return (int)st;
+}
+int dihost_request_stop(dihost_model_t m, int index) {
+  if (!m->runner) return (int)AsStatus::ALLSPARK_INVALID_CALL_ERROR;
+  const AsStatus st = m->runner->StopRequest(index);
+  if (st != AsStatus::ALLSPARK_SUCCESS) g_err = m->runner->last_error();
+  return (int)st;
+}
+int dihost_decode_steps(dihost_model_t m, int n, int use_graph) {
+  if (!m->runner) return (int)AsStatus::ALLSPARK_INVALID_CALL_ERROR;
+  const AsStatus st = m->runner->DecodeSteps(n, use_graph != 0);
+  if (st != AsStatus::ALLSPARK_SUCCESS) g_err = m->runner->last_error();
+  return (int)st;
+}
+int dihost_sync_ids(dihost_model_t m, int64_t* ids_host, int capacity) {
+  if (!m->runner) return -1;
+  std::vector<int64_t> ids;
+  const AsStatus st = m->runner->Sync(&ids);
+  if (st != AsStatus::ALLSPARK_SUCCESS) {
+    g_err = m->runner->last_error();
+    return -(int)st;
+  }
+  for (int i = 0; i < (int)ids.size() && i < capacity; ++i) ids_host[i] = ids[i];
+  return (int)ids.size();
+}
+int dihost_running_batch(dihost_model_t m) { return m->runner ? m->runner->batch() : 0; }
+int dihost_requests_rewind(dihost_model_t m, int cached_len) {
+  if (!m->runner) return (int)AsStatus::ALLSPARK_INVALID_CALL_ERROR;
+  for (auto& gc : m->runner->running()) {
+    auto* k = dynamic_cast<ListVirtualCache*>(gc->virtual_k_cache.get());
+    auto* v = dynamic_cast<ListVirtualCache*>(gc->virtual_v_cache.get());
+    if (!k || !v) return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+    k->Rewind((size_t)cached_len);
+    v->Rewind((size_t)cached_len);
+  }
+  const AsStatus st = m->runner->Rewind(cached_len);
+  if (st != AsStatus::ALLSPARK_SUCCESS) g_err = m->runner->last_error();
+  return (int)st;
 }
 
 }  // extern "C"

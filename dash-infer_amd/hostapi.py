@@ -24,6 +24,18 @@ _SIGS = {
     "dihost_op_forward": (i32, [vp, i32]),
     "dihost_ops_alloc_concurrent": (i32, [vp, C.POINTER(i32), i32]),
     "dihost_cache_seq_len": (C.c_long, [vp, i32, i32]),
+    "dihost_graph_add_op": (i32, [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+    "dihost_graph_build": (i32, [vp, i32]),
+    "dihost_graph_report": (C.c_char_p, [vp]),
+    "dihost_graph_fuse_dry": (C.c_char_p, [vp]),
+    "dihost_request_start": (i32, [vp, C.POINTER(C.c_int64), i32, i32, i32, C.c_float, C.c_float, C.c_ulonglong, i32, i32, C.POINTER(vp),
+                                   C.POINTER(vp), C.POINTER(C.c_int64)]),
+    "dihost_request_adopt": (i32, [vp, i32, C.c_int64, i32, i32, C.POINTER(vp), C.POINTER(vp)]),
+    "dihost_request_stop": (i32, [vp, i32]),
+    "dihost_decode_steps": (i32, [vp, i32, i32]),
+    "dihost_sync_ids": (i32, [vp, C.POINTER(C.c_int64), i32]),
+    "dihost_running_batch": (i32, [vp]),
+    "dihost_requests_rewind": (i32, [vp, i32]),
     "dihost_last_error": (C.c_char_p, []),
     "dihost_registered_ops": (C.c_char_p, []),
 }
@@ -120,3 +132,63 @@ class Model:
 
     def forward(self, op):
         _ck(lib().dihost_op_forward(self.h, op), f"CallForward [{self._names.get(op, op)}]")
+
+    # ---- the model runner: the reference's operator list, optionally fused, driven like AsModel's decode loop ----------------
+    def graph_add_op(self, op_type, op_name, inputs, outputs, weights=(), attrs=""):
+        _ck(lib().dihost_graph_add_op(self.h, op_type.encode(), op_name.encode(), ",".join(inputs).encode(), ",".join(outputs).encode(),
+                                      ",".join(weights).encode(), attrs.encode()), "graph_add_op " + op_type)
+
+    @staticmethod
+    def _report(text):
+        out = {}
+        for item in text.decode().split(";"):
+            k, _, v = item.partition("=")
+            out[k] = v
+        out["fused"] = out.get("fused") == "1"
+        out["layers"] = int(out.get("layers", 0))
+        out["types"] = [t for t in out.get("types", "").split(",") if t]
+        return out
+
+    def graph_build(self, fuse=True):
+        _ck(lib().dihost_graph_build(self.h, int(fuse)), "graph_build")
+        return self._report(lib().dihost_graph_report(self.h))
+
+    def graph_fuse_dry(self):
+        return self._report(lib().dihost_graph_fuse_dry(self.h))
+
+    @staticmethod
+    def _spans(k_spans, v_spans):
+        nl = len(k_spans)
+        spr = len(k_spans[0]) if nl else 0
+        flat = lambda a: (vp * (nl * spr))(*[p for l in a for p in l])
+        return nl, spr, flat(k_spans), flat(v_spans)
+
+    def request_start(self, prompt, k_spans, v_spans, prefix_len=0, top_k=1, top_p=1.0, temperature=1.0, seed=0):
+        """k_spans / v_spans: [layer][span] device pointers of this request's cache.  -> the first generated id."""
+        nl, spr, ks, vs = self._spans(k_spans, v_spans)
+        ids = (C.c_int64 * len(prompt))(*[int(t) for t in prompt])
+        first = C.c_int64()
+        _ck(lib().dihost_request_start(self.h, ids, len(prompt), prefix_len, top_k, top_p, temperature, seed, nl, spr, ks, vs, C.byref(first)),
+            "request_start")
+        return first.value
+
+    def request_adopt(self, cached_len, next_id, k_spans, v_spans):
+        nl, spr, ks, vs = self._spans(k_spans, v_spans)
+        _ck(lib().dihost_request_adopt(self.h, cached_len, int(next_id), nl, spr, ks, vs), "request_adopt")
+
+    def request_stop(self, index):
+        _ck(lib().dihost_request_stop(self.h, index), "request_stop")
+
+    def decode_steps(self, n=1, graph=False):
+        _ck(lib().dihost_decode_steps(self.h, n, int(graph)), "decode_steps")
+
+    def sync_ids(self):
+        cap = max(1, lib().dihost_running_batch(self.h))
+        buf = (C.c_int64 * cap)()
+        n = lib().dihost_sync_ids(self.h, buf, cap)
+        if n < 0:
+            raise HostError(-n, "sync_ids")
+        return [int(buf[i]) for i in range(n)]
+
+    def requests_rewind(self, cached_len):
+        _ck(lib().dihost_requests_rewind(self.h, int(cached_len)), "requests_rewind")

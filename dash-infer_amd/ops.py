@@ -393,10 +393,10 @@ def span_attn_decode(q, kv, seq_lens_dev, n, g, H, max_len, scale, ws, sync, out
         out = (torch.zeros(act_frag_numel(B, n * H), dtype=q.dtype, device=q.device) if out_layout
                else torch.empty(B, n * H, dtype=q.dtype, device=q.device))
     pool = kv.pool
-    check(lib().dihip_span_attn_decode_ex(cur_stream(), ptr(out), ptr(q), ptr(kv.k_ptrs), ptr(kv.v_ptrs), ptr(seq_lens_dev),
-                                          B, n, g, H, pool.S, kv.max_spans, max_len, capi.KV[pool.mode], dt_code(q),
-                                          float(scale), ptr(ws), ws.numel() if ws is not None else 0, ptr(sync),
-                                          int(out_layout)), "dihip_span_attn_decode_ex")
+    check(lib().dihip_span_attn_decode_sync(cur_stream(), ptr(out), ptr(q), ptr(kv.k_ptrs), ptr(kv.v_ptrs), ptr(seq_lens_dev),
+                                            B, n, g, H, pool.S, kv.max_spans, max_len, capi.KV[pool.mode], dt_code(q),
+                                            float(scale), ptr(ws), ws.numel() if ws is not None else 0, ptr(sync),
+                                            sync.numel() if sync is not None else 0, int(out_layout)), "dihip_span_attn_decode_sync")
     return out
 
 

@@ -306,6 +306,16 @@ int dihip_span_attn_decode_ex(void* stream, void* output, const void* query,
                               int kv_mode, int dtype, float qk_scale, void* ws, size_t ws_bytes,
                               void* sync, int out_layout);
 size_t dihip_span_attn_sync_bytes(int batch, int n_heads);
+/* The same with the split partials merged INSIDE the launch: `sync` = at least dihip_span_attn_sync_bytes(batch, n_heads) bytes
+ * (one 128-byte line of arrival words per request and head) that the caller zeroes ONCE; every call leaves them zeroed; calls
+ * sharing one buffer must be ordered on one stream.  sync == NULL or sync_bytes too small: the two-launch merge of
+ * dihip_span_attn_decode_ex (never an out-of-bounds ticket).  Bit-identical output either way.                      */
+int dihip_span_attn_decode_sync(void* stream, void* output, const void* query,
+                                const void* const* k_span_array, const void* const* v_span_array,
+                                const uint32_t* seq_lens_dev, int batch, int n_heads, int n_groups,
+                                int head_size, int span_len, int n_spans_per_request, int max_seq_len,
+                                int kv_mode, int dtype, float qk_scale, void* ws, size_t ws_bytes,
+                                void* sync, size_t sync_bytes, int out_layout);
 
 /* 3b. Decode-step form with Rotary and DecoderCacheAppend folded in: replaces the
  * Rotary op (csrc/core/kernel/cpu/rotary.cpp:22-106 semantics, rotate-half, position = old_seq_lens[b])

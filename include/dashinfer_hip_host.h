@@ -45,6 +45,36 @@ int dihost_op_forward(dihost_model_t m, int op_id);
 int dihost_ops_alloc_concurrent(dihost_model_t m, const int* op_ids, int count);
 /* VirtualCache::GetSeqLength of a request's K cache for one layer (-1: unknown request) */
 long dihost_cache_seq_len(dihost_model_t m, int request, int layer);
+
+/* ---- the model runner (dash-infer_amd/host/model_runner.h): AsModel's decode loop over an operator LIST ------------------------
+ * dihost_graph_add_op records one OperatorProto of the reference graph (same argument format as dihost_op_create);
+ * dihost_graph_build runs the fusion pass (fuse != 0; host/fusion_pass.h) and creates + initialises every operator through the
+ * OpFactory.  dihost_graph_report / dihost_graph_fuse_dry (the pass alone, works without a GPU):
+ *   "fused=<0|1>;layers=<n>;ops=<before>-><after>;why=<text>;types=<operator types, comma-separated>[;wiring=<op(in)->(out)[weights]|...>]" */
+int dihost_graph_add_op(dihost_model_t m, const char* op_type, const char* op_name, const char* inputs, const char* outputs,
+                        const char* weights, const char* attrs);
+int dihost_graph_build(dihost_model_t m, int fuse);
+const char* dihost_graph_report(dihost_model_t m);
+const char* dihost_graph_fuse_dry(dihost_model_t m);
+/* A request enters through its context phase (prompt ids on the host; its cache claims the spans k_spans / v_spans
+ * [n_layers][spans_per_req] in order, the first prefix_len tokens already present) and joins the running batch; *first_id = the
+ * token sampled after the prompt.  top_k = 1: greedy.  dihost_request_adopt: a request whose cache already holds cached_len tokens
+ * joins with next_id as its next input (benchmarks).  dihost_request_stop removes running request `index` (the others move up). */
+int dihost_request_start(dihost_model_t m, const int64_t* prompt_host, int len, int prefix_len, int top_k, float top_p, float temperature,
+                         unsigned long long seed, int n_layers, int spans_per_req, void* const* k_spans, void* const* v_spans,
+                         int64_t* first_id);
+int dihost_request_adopt(dihost_model_t m, int cached_len, int64_t next_id, int n_layers, int spans_per_req, void* const* k_spans,
+                         void* const* v_spans);
+int dihost_request_stop(dihost_model_t m, int index);
+/* n decoder steps of the running batch (Alloc -> Forward per operator per step, csrc/core/model/model.cpp:1248-1325);
+ * use_graph != 0: the step is captured once as a hipGraph and replayed (fused list only; the context stream must not be NULL) */
+int dihost_decode_steps(dihost_model_t m, int n, int use_graph);
+/* synchronises the stream; ids generated by the last step, one per running request -> count (negative AsStatus on error) */
+int dihost_sync_ids(dihost_model_t m, int64_t* ids_host, int capacity);
+int dihost_running_batch(dihost_model_t m);
+/* benchmarks: every running request (and its cache) back to cached_len tokens; spans, shapes and the captured step are kept */
+int dihost_requests_rewind(dihost_model_t m, int cached_len);
+
 const char* dihost_last_error(void);
 /* "GemmA16W8,GemmA16W4,DecOptMHA,DecOptMQA,AllReduce": op types registered for DeviceType::HIP */
 const char* dihost_registered_ops(void);

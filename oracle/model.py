@@ -310,3 +310,86 @@ def teacher_forced_logits(oracles, layers, seq, n_last, progress=None, threads=1
         lm = o.lm_head.astype(o.acc, copy=False)
         out.append(o._logits(h[-n_last:], lm=lm))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Layer-major evaluation of whole teacher-forced runs (full depth, any cache mode, a batch of ragged requests).
+def _layer_sequences(o, hs, lw, W, prompt_lens, want_kv=False):
+    """One decoder layer over ALL positions of several independent sequences under oracle `o`'s rounding and cache mode.
+    hs[b]: f32 [L_b, hidden].  Rows below prompt_lens[b] are CONTEXT-phase rows: causal attention over the fresh (unquantised)
+    K / V of the prompt (SpanAttnOp::runContext attends over the qkv rows; the cache copy is a side output).  Rows from
+    prompt_lens[b] on are DECODER-phase rows: row t attends over what the cache returns for rows 0 .. t (kv_store: the codec
+    image for the int8 / uint4 caches) -- exactly step() after prefill(), evaluated layer by layer.
+    -> (list of f32 [L_b, hidden] outputs; with want_kv a list of (k, v, k_image, v_image), each [L_b, g, H]: the FT-valued rows
+    written to the cache and what the cache returns for them -- the same arrays for the 16-bit cache)."""
+    n, g, H = o.n, o.g, o.H
+    W = W or {}
+    rows = np.concatenate(hs)
+    xn = o._src(glue.rmsnorm(rows, lw["ln1"], o.eps))
+    qkv = o.linear(xn, lw["qkv"], o._qkv_ft(), bias=lw["qkv_bias"], W=W.get("qkv"))
+    rq = bf16_round if o.rounding.qkv_ft else (lambda t: t)
+    alpha = 1.0 / np.sqrt(H)
+    attn_rows, kvs, off = [], [], 0
+    for b, h in enumerate(hs):
+        L, P = h.shape[0], int(prompt_lens[b])
+        r = qkv[off:off + L]
+        off += L
+        pos = np.arange(L, dtype=np.int32)
+        q = rq(glue.rope(r[:, : n * H].reshape(L, n, H), pos, o.inv_freq))
+        k = rq(glue.rope(r[:, n * H:(n + g) * H].reshape(L, g, H), pos, o.inv_freq))
+        v = r[:, (n + g) * H:].reshape(L, g, H)
+        out = np.empty((L, n, H), np.float32)
+        if P > 0:
+            out[:P] = attention.prefill_attention(q[:P], k[:P], v[:P], alpha, True, dtype=o.acc, threads=o.threads)
+        if o.kv_mode == "none":
+            kc, vc = k, v
+        else:
+            zk, sk = kv_codec.quant_params(k, o.kv_mode)
+            zv, sv = kv_codec.quant_params(v, o.kv_mode)
+            kc = kv_codec.dequantize(kv_codec.quantize(k, zk, sk, o.kv_mode), zk, sk)
+            vc = kv_codec.dequantize(kv_codec.quantize(v, zv, sv, o.kv_mode), zv, sv)
+        if L > P:
+            # decoder row t sees the cache's image of rows 0 .. t: the last L - P rows of one causal pass over it
+            out[P:] = attention.prefill_attention(q[P:], kc, vc, alpha, True, dtype=o.acc, threads=o.threads)
+        attn_rows.append(o._attn_out(out).reshape(L, n * H))
+        if want_kv:
+            kvs.append((k, v, kc, vc))
+    h2 = o._residual(rows, o.linear(o._src(np.concatenate(attn_rows)), lw["o"], "f32", W=W.get("o")))
+    h3 = o._mlp(h2, lw, W)
+    outs, off = [], 0
+    for h in hs:
+        outs.append(h3[off:off + h.shape[0]])
+        off += h.shape[0]
+    return outs, kvs
+
+
+def teacher_forced_trace(o, layers, seqs, prompt_lens, on_layer=None, threads=1, want_kv=False, on_logits=None):
+    """Teacher-forced evaluation of a batch of requests at full depth, one pass over the weights (each layer dequantised once
+    and applied to every row of every request before the next layer is touched).  seqs[b] = prompt tokens followed by the
+    tokens fed at the decode steps; prompt_lens[b] = how many of them were the context phase.  Any cache mode.
+    on_layer(li, h_in, h_out, kvs): per layer, the lists of f32 [L_b, hidden] layer inputs / outputs and (with want_kv) each
+    request's (k, v, k_image, v_image) -- the per-layer drift test feeds these to the GPU layer.
+    -> list of f32 logits [L_b - prompt_lens[b] + 1, V]: after the prompt's last token, then after every decode step;
+    with on_logits(b, logits_b) each request's block is handed over and dropped instead (batch 32 x 65 rows x 152k columns)."""
+    o.threads = max(o.threads, threads)
+    hs = [o.embed[np.asarray(s)].astype(np.float32) for s in seqs]
+    for li in range(len(layers)):
+        lw = layers[li]
+        mats = {}
+        for name in ("qkv", "o", "gate", "up", "down"):
+            w32 = (np.asarray(lw[name], np.float32) if isinstance(lw[name], np.ndarray)
+                   else gemm_ref.dequant(*lw[name], o.group, o.wbits, threads=threads))
+            if o.rounding.w_bf16:
+                w32 = bf16_round(w32, threads=threads)
+            mats[name] = w32.astype(o.acc, copy=False)
+        outs, kvs = _layer_sequences(o, hs, lw, mats, prompt_lens, want_kv=want_kv)
+        if on_layer is not None:
+            on_layer(li, hs, outs, kvs)
+        hs = outs
+        del mats, lw
+    lm = o.lm_head.astype(o.acc, copy=False)
+    if on_logits is not None:
+        for b, (h, P) in enumerate(zip(hs, prompt_lens)):
+            on_logits(b, o._logits(h[int(P) - 1:], lm=lm))
+        return None
+    return [o._logits(h[int(P) - 1:], lm=lm) for h, P in zip(hs, prompt_lens)]

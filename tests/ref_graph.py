@@ -1,0 +1,75 @@
+"""The reference's Qwen2 operator list (python/pyhie/allspark/model/qwen_v15.py:187-388 in its weight-only-quantised form --
+dynamic quantisation switches the Gemm's fused binary ADD off, qwen_v15.py:175-178 -- and the tail of model_base.py:690-703) as
+plain tuples (op_type, op_name, inputs, outputs, weights, attrs), for the host-layer tests and bench.py --runner host.  Pure
+Python: the CPU tests of the fusion pass use it without a GPU."""
+
+
+def qwen2_graph(n_layers, wbits, group, eps, n_heads, n_kv, rope_theta, tp_allreduce=False):
+    gemm = "GemmA16W4" if wbits == 4 else "GemmA16W8"
+    gattr = f"GroupSize=i:{group}" if group and group > 0 else ""
+
+    def lowp(name, inp, out, act=0, bias=False):
+        w = [name + ".weight", name + ".weight.scales", name + ".weight.zeros"] + ([name + ".bias"] if bias else [])
+        attrs = ";".join(a for a in (gattr, f"activation=i:{act}" if act else "", "alpha=f:1.0") if a)
+        return (gemm, name, [inp], [out], w, attrs)
+
+    g = [("EmbeddingT5", "embedding", ["input_ids"], ["embedding.out"], ["embedding.word_embeddings"], "token_embedding=b:0")]
+    prev = "embedding.out"
+    for li in range(n_layers):
+        p = f"decoder.layer.{li}."
+        g.append(("LayerNormNoBeta", p + "attention.layernorm", [prev], [p + "attention.layernorm.out"], [p + "attention.layernorm.gamma"], f"eps=f:{eps}"))
+        g.append(lowp(p + "attention.self", p + "attention.layernorm.out", p + "attention.self.out", bias=True))
+        g.append(("Rotary", p + "rotary", [p + "attention.self.out"], [p + "rotary.out"], [],
+                  f"num_heads=i:{n_heads};multi_query_group_num=i:{n_kv};rotary_base=f:{rope_theta}"))
+        g.append(("DecOptMQA", p + "attention", [p + "rotary.out"], [p + "attention.out"], [], ""))
+        g.append(lowp(p + "attention.output.dense", p + "attention.out", p + "attention.output.dense.out"))
+        o_out = p + "attention.output.dense.out"
+        if tp_allreduce:
+            g.append(("AllReduce", p + "attention.all_reduce", [o_out], [o_out], [], ""))
+        g.append(("Binary", p + "attention_add", [o_out, prev], [p + "attention_add.out"], [], "binary_type=i:1"))
+        g.append(("LayerNormNoBeta", p + "ffn.layernorm", [p + "attention_add.out"], [p + "ffn.layernorm.out"], [p + "ffn.layernorm.gamma"], f"eps=f:{eps}"))
+        g.append(lowp(p + "ffn.intermediate.dense", p + "ffn.layernorm.out", p + "ffn.intermediate.dense.out", act=5))
+        g.append(lowp(p + "ffn.linear.dense", p + "ffn.layernorm.out", p + "ffn.linear.dense.out"))
+        g.append(("Binary", p + "ffn.mul", [p + "ffn.intermediate.dense.out", p + "ffn.linear.dense.out"], [p + "ffn.mul.out"], [], "binary_type=i:2"))
+        g.append(lowp(p + "ffn.output.dense", p + "ffn.mul.out", p + "ffn.output.dense.out"))
+        d_out = p + "ffn.output.dense.out"
+        if tp_allreduce:
+            g.append(("AllReduce", p + "ffn.all_reduce", [d_out], [d_out], [], ""))
+        g.append(("Binary", p + "final_add", [d_out, p + "attention_add.out"], [p + "final_add.out"], [], "binary_type=i:1"))
+        prev = p + "final_add.out"
+    g.append(("LayerNormNoBeta", "final.layernorm", [prev], ["last_hidden_state"], ["final.layernorm.gamma"], f"eps=f:{eps}"))
+    g.append(("GetLastLine", "get_last_line", ["last_hidden_state"], ["get_last_line.out"], [], ""))
+    g.append(("Gemm", "lm_head", ["get_last_line.out"], ["logits"], ["lm_head.weight"], "with_bias=b:0"))
+    g.append(("GenerateOp", "generate", ["logits"], ["generated_ids"], [], "top_k=i:1"))
+    return g
+
+
+def register_weights(m, model):
+    """The product model's unpacked quantised weights (decoder.build_random_model(keep_fp=True)) under the reference's names."""
+    fp = model.fp
+    qdt = "u8" if model.quant.wbits == 4 else "i8"
+
+    def lowp(name, key, li):
+        q, s, z = fp[li][key]
+        m.set_weight(name + ".weight", q, qdt)
+        m.set_weight(name + ".weight.scales", s, "bf16")
+        m.set_weight(name + ".weight.zeros", z, "bf16")
+
+    m.set_weight("embedding.word_embeddings", fp["embed"], "bf16")
+    for li in range(len(model.layers)):
+        p = f"decoder.layer.{li}."
+        m.set_weight(p + "attention.layernorm.gamma", fp[li]["ln1"], "bf16")
+        m.set_weight(p + "ffn.layernorm.gamma", fp[li]["ln2"], "bf16")
+        lowp(p + "attention.self", "qkv", li)
+        m.set_weight(p + "attention.self.bias", fp[li]["qkv_bias"], "bf16")
+        lowp(p + "attention.output.dense", "o", li)
+        lowp(p + "ffn.intermediate.dense", "gate", li)
+        lowp(p + "ffn.linear.dense", "up", li)
+        lowp(p + "ffn.output.dense", "down", li)
+    m.set_weight("final.layernorm.gamma", fp["final_norm"], "bf16")
+    m.set_weight("lm_head.weight", fp["lm_head"], "bf16")
+
+
+def add_graph(m, graph):
+    for t, name, inputs, outputs, weights, attrs in graph:
+        m.graph_add_op(t, name, inputs, outputs, weights, attrs)

@@ -1,0 +1,78 @@
+"""The fusion pass of the HIP operator layer (dash-infer_amd/host/fusion_pass.cpp) on CPU: it rewrites the reference's Qwen2
+operator list (tests/ref_graph.py: python/pyhie/allspark/model/qwen_v15.py:187-388) into the fused decode-step operators, follows
+tensors by name, threads the handed-on norm from layer to layer, keeps the AllReduce behind a row-parallel projection, and leaves
+a list it does not fully understand UNCHANGED with the first misfit named."""
+import pytest
+
+from tests import ref_graph
+
+
+@pytest.fixture()
+def model(pkg):
+    from dash_infer_amd import hostapi
+    m = hostapi.Model(None, 4, 2, 128, 16)
+    yield m
+    m.close()
+
+
+def test_two_layer_graph_is_fused_five_operators_per_layer(model):
+    g = ref_graph.qwen2_graph(2, 4, 128, 1e-6, 4, 2, 1000000.0)
+    ref_graph.add_graph(model, g)
+    r = model.graph_fuse_dry()
+    assert r["fused"] and r["layers"] == 2, r["why"]
+    per_layer = ["DihipNormGemm", "DihipRopeSpanAttn", "DihipGemmAddTo", "DihipNormSwiGLU", "DihipGemmAddTo"]
+    assert r["types"] == ["DihipEmbedding"] + per_layer * 2 + ["DihipLMHead", "DihipGreedy"]
+    assert r["ops"] == f"{len(g)}->13"
+    w = r["wiring"].split("|")
+    # layer 0 reads the hidden rows only; its down projection hands the next layer's norm on; layer 1 takes it; the last does not
+    assert w[1].startswith("DihipNormGemm(embedding.out)->(decoder.layer.0.attention.self.out)[decoder.layer.0.attention.layernorm.gamma,")
+    assert "decoder.layer.0.attention.self.bias]" in w[1]
+    assert w[2] == "DihipRopeSpanAttn(decoder.layer.0.attention.self.out)->(decoder.layer.0.attention.out)[]"
+    assert w[3].startswith("DihipGemmAddTo(decoder.layer.0.attention.out,embedding.out)->(decoder.layer.0.attention_add.out,decoder.layer.0.attention.output.dense.dihip_xnorm)")
+    assert w[3].endswith("decoder.layer.0.ffn.layernorm.gamma]")
+    assert w[4].startswith("DihipNormSwiGLU(decoder.layer.0.attention_add.out,decoder.layer.0.attention.output.dense.dihip_xnorm)->(decoder.layer.0.ffn.mul.out)")
+    assert w[5].startswith("DihipGemmAddTo(decoder.layer.0.ffn.mul.out,decoder.layer.0.attention_add.out)->(decoder.layer.0.final_add.out,decoder.layer.0.ffn.output.dense.dihip_xnorm)")
+    assert w[5].endswith("decoder.layer.1.attention.layernorm.gamma]")
+    assert w[6].startswith("DihipNormGemm(decoder.layer.0.final_add.out,decoder.layer.0.ffn.output.dense.dihip_xnorm)->")
+    assert w[10].startswith("DihipGemmAddTo(decoder.layer.1.ffn.mul.out,decoder.layer.1.attention_add.out)->(decoder.layer.1.final_add.out)[")
+    assert w[10].endswith("decoder.layer.1.ffn.output.dense.weight.zeros]")
+    assert w[11] == "DihipLMHead(decoder.layer.1.final_add.out)->(logits)[final.layernorm.gamma,lm_head.weight]"
+    assert w[12] == "DihipGreedy(logits)->(generated_ids)[]"
+
+
+def test_allreduce_stays_behind_the_row_parallel_projections(pkg):
+    from dash_infer_amd import hostapi
+    m = hostapi.Model(None, 4, 2, 128, 16, rank=1, nranks=2)
+    ref_graph.add_graph(m, ref_graph.qwen2_graph(1, 8, -1, 1e-6, 4, 2, 1e6, tp_allreduce=True))
+    r = m.graph_fuse_dry()
+    # the tensor-parallel lm_head is outside the fused head: the whole list stays as it is
+    assert not r["fused"] and "single-rank" in r["why"]
+    m.close()
+    m = hostapi.Model(None, 4, 2, 128, 16)   # the same list on one rank: the AllReduce operators are kept (they copy)
+    ref_graph.add_graph(m, ref_graph.qwen2_graph(1, 8, -1, 1e-6, 4, 2, 1e6, tp_allreduce=True))
+    r = m.graph_fuse_dry()
+    assert r["fused"], r["why"]
+    assert r["types"] == ["DihipEmbedding", "DihipNormGemm", "DihipRopeSpanAttn", "DihipGemmAddTo", "AllReduce", "DihipNormSwiGLU",
+                          "DihipGemmAddTo", "AllReduce", "DihipLMHead", "DihipGreedy"]
+    w = r["wiring"].split("|")
+    assert w[4] == "AllReduce(decoder.layer.0.attention_add.out)->(decoder.layer.0.attention_add.out)[]"   # in place on the f32 rows
+    m.close()
+
+
+@pytest.mark.parametrize("mutate,needle", [
+    (lambda g: g.__setitem__(3, ("Rotary", g[3][1], g[3][2], g[3][3], [], g[3][5] + ";rotary_type=i:2")), "Rotary variant"),
+    (lambda g: g.__setitem__(5, (g[5][0], g[5][1], g[5][2], g[5][3], g[5][4] + ["x.bias"], g[5][5])), "unexpected weights"),
+    (lambda g: g.__setitem__(8, (g[8][0], g[8][1], g[8][2], g[8][3], g[8][4], "GroupSize=i:128;alpha=f:1.0")), "unexpected activation"),
+    (lambda g: g.__setitem__(6, ("Binary", g[6][1], [g[6][2][0], "something.else"], g[6][3], [], g[6][5])), "does not combine"),
+    (lambda g: g.insert(4, ("Unary", "extra", ["decoder.layer.0.rotary.out"], ["decoder.layer.0.rotary.out"], [], "unary_type=i:4")), "DecOptMQA"),
+    (lambda g: g.__setitem__(len(g) - 2, ("Gemm", "lm_head", ["get_last_line.out"], ["logits"], ["lm_head.weight"], "splitk=b:1")), "lm_head"),
+    (lambda g: g.pop(0), "EmbeddingT5"),
+])
+def test_a_list_that_does_not_fit_is_left_unchanged(model, mutate, needle):
+    g = ref_graph.qwen2_graph(1, 4, 128, 1e-6, 4, 2, 1e6)
+    mutate(g)
+    ref_graph.add_graph(model, g)
+    r = model.graph_fuse_dry()
+    assert not r["fused"]
+    assert needle in r["why"], r["why"]
+    assert r["types"] == [t[0] for t in g]          # unchanged, operator by operator

@@ -16,8 +16,12 @@ def test_op_registry(pkg):
     ops = hostapi.lib().dihost_registered_ops().decode().split(",")
     # every op type of the Qwen2 layer graph (qwen_v15.py:187-388, model_base.py:690-703) resolves for DeviceType::HIP; the
     # graph-head / id-processing ops that only shuffle engine state are not registered
-    assert sorted(ops) == sorted(["GemmA16W8", "GemmA16W4", "DecOptMHA", "DecOptMQA", "AllReduce", "AllGather", "MOEA16W8", "CalcExpert",
-                                  "Gemm", "Rotary", "LayerNormNoBeta", "Binary", "Unary", "UnaryGLU", "EmbeddingT5", "GetLastLine", "GenerateOp"])
+    reference_types = ["GemmA16W8", "GemmA16W4", "DecOptMHA", "DecOptMQA", "AllReduce", "AllGather", "MOEA16W8", "CalcExpert",
+                       "Gemm", "Rotary", "LayerNormNoBeta", "Binary", "Unary", "UnaryGLU", "EmbeddingT5", "GetLastLine", "GenerateOp"]
+    # + the fused decode-step operators the fusion pass rewrites that graph into (host/fused_ops_hip.cpp)
+    fused_types = ["DihipEmbedding", "DihipNormGemm", "DihipRopeSpanAttn", "DihipGemmAddTo", "DihipNormSwiGLU", "DihipLMHead", "DihipGreedy"]
+    assert sorted(t for t in ops if not t.startswith("Dihip")) == sorted(reference_types)
+    assert sorted(t for t in ops if t.startswith("Dihip")) == sorted(fused_types)
 
 
 def test_unknown_op_type_is_rejected(pkg):

@@ -200,3 +200,40 @@ def test_config0_unquantised_bf16_model_incremental_decode_equals_full_recompute
         assert int(np.argmax(want)) == int(np.argmax(full))
     tf = omodel.teacher_forced_logits([m2], m2.layers, seq, len(step_logits))[0]
     np.testing.assert_allclose(tf, np.stack(step_logits), rtol=0, atol=3e-5 * max(1.0, float(np.abs(tf).max())))
+
+
+@pytest.mark.parametrize("kv_mode,rounding", [("none", "x86"), ("u4", "x86"), ("i8", "ft_graph")])
+def test_layer_major_trace_equals_prefill_then_steps(kv_mode, rounding):
+    """teacher_forced_trace (every layer applied to all rows of all requests before the next layer is touched; context rows
+    attend over the fresh K / V, decoder rows over the cache's codec image) is the same function as prefill() followed by
+    step() token by token -- for ragged batches and the quantised caches too.  Its per-layer hook sees each layer's inputs,
+    outputs and the cache image of K / V (what the per-layer drift test of tests/test_gpu_parity_depth.py feeds the GPU)."""
+    rng = np.random.default_rng(21)
+    a = make_oracle(rng, 4, 128, kv_mode, nlayers=3)
+    b = make_oracle(np.random.default_rng(21), 4, 128, kv_mode, nlayers=3)
+    a.rounding = b.rounding = rounding
+    prompts = [[int(t) for t in rng.integers(0, 64, n)] for n in (6, 3)]
+    fed = [[int(t) for t in rng.integers(0, 64, 4)] for _ in prompts]       # the tokens fed at 4 decode steps
+    want = [b.prefill(prompts)]
+    for t in range(4):
+        want.append(b.step([f[t] for f in fed]))
+    seen = []
+    def hook(li, h_in, h_out, kvs):
+        seen.append(li)
+        assert [h.shape for h in h_in] == [h.shape for h in h_out] == [(10, 256), (7, 256)]
+        assert kvs[0][0].shape == (10, 1, 128) and kvs[1][1].shape == (7, 1, 128)
+        if li == 0:   # the cache image of the trace is what step() stored
+            np.testing.assert_array_equal(kvs[0][2][7], b.cache[0][0][0][7])
+            np.testing.assert_array_equal(kvs[1][3][2], b.cache[0][1][1][2])
+            if kv_mode == "none":
+                assert kvs[0][0] is kvs[0][2]
+            else:   # the written rows are FT-valued, their image is the codec's
+                np.testing.assert_array_equal(kvs[0][0], bf16_round(kvs[0][0]))
+                assert np.abs(kvs[0][0] - kvs[0][2]).max() > 0
+    got = omodel.teacher_forced_trace(a, a.layers, [p + f for p, f in zip(prompts, fed)], [6, 3], on_layer=hook, want_kv=True)
+    assert seen == [0, 1, 2]
+    for bi in range(2):
+        assert got[bi].shape == (5, 64)
+        for t in range(5):
+            ref = want[t][bi]
+            np.testing.assert_allclose(got[bi][t], ref, rtol=0, atol=3e-5 * max(1.0, float(np.abs(ref).max())))
