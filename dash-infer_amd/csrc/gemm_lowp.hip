@@ -251,6 +251,43 @@ struct GemvPlan {
   size_t lds_bytes;
 };
 
+// K-slice boundaries of a plan (GemvArgs::kcut) and the wave mapping.  Even split: kcut[i] = kgroups * i / WK (the former
+// in-kernel formula).  DIHIP_GEMV_KSKEW = s (per cent): the k-slices held by the first-dispatched half of the workgroup's waves
+// get (1 + s/100) shares, the others (1 - s/100) -- the two waves of a SIMD are arbitrated by age and the younger half streams
+// ~13 % slower (profiles/r03_gemv_wave_timeline.txt); boundaries rounded to whole split units, every slice keeps >= 1 unit when
+// there are enough.  DIHIP_GEMV_WMAP = 1: consecutive waves differ in wn, so that the k-slices ARE ordered by age also for the
+// WK 4 x WN 2 plans (gate / up pair: without it waves 0-3 stream the gate matrix and 4-7 the up matrix, and no K split can
+// balance them).
+static void fill_kcut(GemvArgs& g) {
+  static const int skew = std::max(0, std::min(60, env_int("DIHIP_GEMV_KSKEW", 0)));
+  static const int wmap_env = env_int("DIHIP_GEMV_WMAP", 0);
+  g.wmap = (wmap_env && g.WN > 1 && g.WK > 1) ? 1 : 0;
+  const int WK = g.WK, G = g.kgroups;
+  // which k-slices sit on the older half of the waves
+  auto older = [&](int wk) {
+    if (WK == 1) return true;
+    if (g.WN == 1) return wk < WK / 2;           // wave == wk
+    return g.wmap ? wk < WK / 2 : true;           // wmap 0 with WN > 1: every k-slice has waves of both halves
+  };
+  const bool skewed = skew > 0 && (g.WN == 1 || g.wmap) && WK >= 2 && G >= 2 * WK;
+  double tot = 0;
+  double w[GEMV_WAVES];
+  for (int i = 0; i < WK; ++i) {
+    w[i] = skewed ? (older(i) ? 100.0 + skew : 100.0 - skew) : 100.0;
+    tot += w[i];
+  }
+  g.kcut[0] = 0;
+  double acc = 0;
+  for (int i = 0; i < WK; ++i) {
+    acc += w[i];
+    int c = skewed ? (int)(G * acc / tot + 0.5) : (int)(((long)G * (i + 1)) / WK);
+    c = std::max(c, g.kcut[i]);
+    g.kcut[i + 1] = std::min(c, G);
+  }
+  g.kcut[WK] = G;
+  for (int i = WK + 1; i <= GEMV_WAVES; ++i) g.kcut[i] = G;
+}
+
 // want_blocks > 0 (expert slots: gridDim.y multiplies the grid): aim at that many workgroups instead of one per CU
 static GemvPlan make_gemv_plan(int wbits, int M, int N, int K, int group_size, bool dual, int want_blocks = 0) {
   GemvPlan p{};
@@ -455,6 +492,7 @@ int run_gemv_slots(hipStream_t stream, int wbits, int epi, const void* x, int ld
   g.WK = gp.WK;
   g.WN = gp.WN;
   g.RS = gp.RS;
+  fill_kcut(g);
   g.slot_expert = slot_expert;
   g.w_estride = (size_t)d.NTILES * d.KT * 64;       // u32x4 per expert
   g.sz_estride = (size_t)d.NTILES * g.Gp * 16;      // u32 per expert
@@ -522,6 +560,7 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
       g.WK = gp.WK;
       g.WN = gp.WN;
       g.RS = gp.RS;
+      fill_kcut(g);
       g.trace = debug_trace_buffer((size_t)gp.blocks * GEMV_WAVES * 64);
       hipError_t e = hipErrorInvalidValue;
       if (f16_std) e = c.wbits == 4 ? dispatch_gemv_f16<4>(gp, g, stream) : dispatch_gemv_f16<8>(gp, g, stream);

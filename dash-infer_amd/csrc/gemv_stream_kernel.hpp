@@ -148,6 +148,10 @@ struct GemvArgs {
   const int* slot_rows;
   const int* slot_nrows;
   int WK, WN;  // wave grid inside the workgroup, WK * WN == GEMV_WAVES, both powers of two (SwiGLU: WN >= 2)
+  // K-slice boundaries in split units (k-groups), kcut[0] = 0 .. kcut[WK] = kgroups: host-computed, so that the slices need not
+  // be equal (the second-dispatched half of a workgroup streams slower: gemm_lowp.hip fill_kcut)
+  int kcut[GEMV_WAVES + 1];
+  int wmap;    // wave -> (wk, wn): 0: wk = wave % WK, wn = wave / WK;  1: wn = wave % WN, wk = wave / WN (k-slices ordered by wave age)
   int RS;      // LDS activation row stride in elements (KT * KTILE + 8)
   unsigned long long* trace;  // diagnostics (dihip_debug_set_trace): [block][wave][8] wall-clock stamps, or null
 };
@@ -218,7 +222,7 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
   const int lane = tid & 63;
   const int ni = lane & 15, kb = lane >> 4;
   const int lgWK = __builtin_ctz(a.WK), lgWN = __builtin_ctz(a.WN);
-  const int wk = wave & (a.WK - 1), wn = wave >> lgWK;
+  const int wk = a.wmap ? wave >> lgWN : wave & (a.WK - 1), wn = a.wmap ? wave & (a.WN - 1) : wave >> lgWK;
 
   // per-wave wall-clock stamps (tools/gemv_bench TRACE=1): compiled in only with -DDIHIP_GEMV_TRACE=1 (`make trace` ->
   // lib/trace/libdashinfer_hip.so).  In the product build they are absent: each one is an exec-masked branch that splits
@@ -314,9 +318,9 @@ __device__ __forceinline__ void gemv_stream_body(const GemvArgs& a, const int bi
   const bool subc = QUANT && a.ktpg < a.KT;
   const int gsz = subc ? a.ktpg : 1;
   const int gcount = subc ? a.ktpg : (1 << 30);  // group countdown start (per-channel: never expires)
-  const int g_lo = (a.kgroups * wk) >> lgWK;
+  const int g_lo = __builtin_amdgcn_readfirstlane(a.kcut[wk]);
   const int k_lo = min(a.KT, g_lo * gsz);
-  const int k_hi = min(a.KT, ((a.kgroups * (wk + 1)) >> lgWK) * gsz);
+  const int k_hi = min(a.KT, __builtin_amdgcn_readfirstlane(a.kcut[wk + 1]) * gsz);
   const int nk = k_hi - k_lo;
   const int nvw = wn < nv ? (nv - wn + a.WN - 1) >> lgWN : 0;  // half-units v = wn, wn + WN, ...
   const int total = __builtin_amdgcn_readfirstlane(nvw * nk);

@@ -217,6 +217,26 @@ struct GenerateConfig {
   float top_p = 1.0f;       // 0 or >= 1: off
   float temperature = 1.0f;
   unsigned long long seed = 0;
+  // the stop conditions UpdateIdOp checks (update_id_op.cpp:42-75)
+  int max_length = 0;       // 0: unbounded here (the engine always sets it)
+  bool early_stopping = true;
+  int eos_token_id = -1;
+  std::vector<std::vector<int64_t>> stop_words_ids;
+};
+
+// csrc/common/request.h:25-40, the slice the id-processing operators touch: the request's input tensors, its intermediate
+// tensors ("generated_ids" on the host, "generated_ids_gpu" / "new_input_ids_gpu" on the device) and the queue of generated
+// tokens the engine drains (moodycamel::ConcurrentQueue in the reference; single producer / single consumer here)
+struct Request {
+  std::string request_id;
+  std::map<std::string, std::shared_ptr<class AsTensor>> inputs, interim;
+  std::vector<int64_t> generated_ids_queue;
+  std::mutex queue_mu;
+  bool finish = false;
+  void enqueue(int64_t t) {
+    std::lock_guard<std::mutex> g(queue_mu);
+    generated_ids_queue.push_back(t);
+  }
 };
 
 // per-request generation state (generate_context.h:32-70): step = tokens already in the cache
@@ -225,6 +245,13 @@ struct GenerateContext {
   int prefix_len = 0;
   GenerateConfig gen_cfg;
   unsigned long long sample_calls = 0;   // draws taken so far (the per-request random stream's position)
+  // generate_context.h:32-55: what UpdateIdOp / PreProcessIdOp read
+  int in_length_bias = 0;
+  bool finish = false;
+  int generate_method = 0;               // sample = 0 (beam search = 1 is refused, generate_op.cpp:655-660)
+  bool gen_over[1] = {false};
+  int engine_max_length = 0;
+  std::shared_ptr<Request> request;
   std::shared_ptr<VirtualCache> virtual_k_cache, virtual_v_cache;  // generate_context.h:60-61
 };
 

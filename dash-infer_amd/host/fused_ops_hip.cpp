@@ -29,6 +29,7 @@
 
 #include "dashinfer_hip.h"
 #include "operator.h"
+#include "sampling_host.h"
 #include "span_attn_op_hip.h"
 
 namespace allspark {
@@ -594,10 +595,11 @@ class DihipLMHeadOp : public AsOperator {
 REGISTER_OP(DihipLMHead, HIP, DihipLMHeadOp)
 
 // ======================================================================================================== DihipGreedy
-// GenerateOp for greedy requests (generate_op.cpp:325-453 with top_k = 1) over f32 logits: ids[b] = argmax, lowest index on
-// ties; in the decoder phase with device-resident lengths the same launch advances "dihip.old_seq_lens" / "dihip.new_seq_lens"
-// (the decode step then needs nothing from the host: it replays as a hipGraph).  A request that asks for sampling is refused here
-// -- the sampling form of GenerateOp is host/sampling_ops_hip.cpp.
+// GenerateOp over f32 logits (generate_op.cpp:325-600).  All requests greedy (top_k = 1): ids[b] = argmax, lowest index on ties.
+// Any request sampling: dihip_sample with the per-request top_k / top_p / temperature / seed of gen_cfg, the random stream keyed
+// by the DEVICE-resident position of the sampled token.  In the decoder phase with device-resident lengths the same launch
+// advances "dihip.old_seq_lens" / "dihip.new_seq_lens": the decode step needs nothing from the host and replays as a hipGraph --
+// sampling included.
 class DihipGreedyOp : public AsOperator {
  public:
   explicit DihipGreedyOp(const std::string& t = "") : AsOperator(t) {}
@@ -612,10 +614,7 @@ class DihipGreedyOp : public AsOperator {
     if (s.size() < 2 || x->GetDataType() != FLOAT32) return AsStatus::ALLSPARK_PARAM_ERROR;
     vocab_ = (int)s.back();
     rows_ = (int)(x->Count() / vocab_);
-    for (int i = 0; rt && i < rt->GetGenCtxListSize(); ++i) {
-      const GenerateConfig& g = rt->GetGenCtx(i)->gen_cfg;
-      if (g.top_k != 1) return AsStatus::ALLSPARK_PARAM_ERROR;  // never decode a sampling request greedily in silence
-    }
+    if (rt && rt->GetGenCtxListSize() > 0) AS_CHECK_STATUS(params_.Gather(rt, rows_, stream_of(ctx_)));
     AsTensor* y = tensor_map_->at(out_names_[0]).get();
     y->SetDataType(INT64);
     AS_CHECK_STATUS(y->SetShape(Shape{rows_, 1}));
@@ -626,9 +625,26 @@ class DihipGreedyOp : public AsOperator {
     AsTensor* x = tensor_map_->at(in_names_[0]).get();
     AsTensor* y = tensor_map_->at(out_names_[0]).get();
     hipStream_t s = stream_of(ctx_);
-    if (!rt->is_context && hip_ctx(ctx_).LensOnDevice()) {
+    const bool on_dev = !rt->is_context && hip_ctx(ctx_).LensOnDevice();
+    uint32_t *ca = nullptr, *cb = nullptr;
+    if (on_dev) {
       auto o = tensor_map_->find("dihip.old_seq_lens"), n = tensor_map_->find("dihip.new_seq_lens");
       if (o == tensor_map_->end() || n == tensor_map_->end()) return AsStatus::ALLSPARK_INVALID_CALL_ERROR;
+      ca = (uint32_t*)o->second->GetDataPtr();
+      cb = (uint32_t*)n->second->GetDataPtr();
+    }
+    if (params_.any_sampling()) {
+      // position of the sampled token = tokens in the sequence after this step: new_seq_lens on the device, else staged
+      const uint32_t* pos = cb;
+      if (!on_dev) {
+        AS_CHECK_STATUS(params_.StagePositions(rt, rt->is_context ? seq_ : 1, s));
+        pos = params_.dev_pos();
+      }
+      return FromDihip(dihip_sample(s, (int64_t*)y->GetDataPtr(), (const float*)x->GetDataPtr(), rows_, vocab_, params_.top_k(), params_.top_p(),
+                                    params_.temperature(), params_.seed(), pos, ca, cb, nullptr, nullptr));
+    }
+    if (on_dev) {
+      auto o = tensor_map_->find("dihip.old_seq_lens"), n = tensor_map_->find("dihip.new_seq_lens");
       return FromDihip(dihip_argmax_advance(s, (int64_t*)y->GetDataPtr(), (const float*)x->GetDataPtr(), rows_, vocab_, ws_->GetDataPtr(),
                                             ws_->GetSizeInByte(), (uint32_t*)o->second->GetDataPtr(), (uint32_t*)n->second->GetDataPtr()));
     }
@@ -636,8 +652,9 @@ class DihipGreedyOp : public AsOperator {
   }
 
  private:
-  int rows_ = 0, vocab_ = 0;
+  int rows_ = 0, vocab_ = 0, seq_ = 1;
   std::unique_ptr<AsTensor> ws_;
+  SamplingParams params_;
 };
 REGISTER_OP(DihipGreedy, HIP, DihipGreedyOp)
 

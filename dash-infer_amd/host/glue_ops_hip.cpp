@@ -8,8 +8,10 @@
 //   Unary / UnaryGLU general/unary/unary_op.cpp, general/unary_glu/unary_glu_op.cpp  (attr unary_type)
 //   EmbeddingT5      general/embeddingT5/embeddingT5_op.cpp  (weights [word_embeddings]; ids INT64 [batch, seq])
 //   GetLastLine      general/get_last_line/get_last_line.cpp
-//   GenerateOp       generate_opt/generate/generate_op.cpp -- GREEDY ONLY (top_k = 1): the sampling machinery of the reference
-//                    (top-k / top-p, repetition penalties, logprobs, formatters) is engine territory
+//   GenerateOp       generate_opt/generate/generate_op.cpp -- greedy (top_k = 1: arg-max) and the sampling half (per-request
+//                    top_k / top_p / temperature / seed from gen_cfg, generate_op.cpp:325-372,472-600 -> dihip_sample); the
+//                    logits processors (repetition / presence / frequency penalties, no-repeat n-grams, min length), logprobs
+//                    and the json formatter stay the engine's
 // Every operator binds tensors by name, infers its output type / shape like the reference op and only enqueues C-ABI calls
 // (include/dashinfer_hip.h section 5) on the context's stream.  The decode step of the product (decoder.py, bench.py)
 // never runs these as separate launches -- they ride in GEMV prologues / epilogues there; this file is the drop-in
@@ -19,6 +21,7 @@
 
 #include "dashinfer_hip.h"
 #include "operator.h"
+#include "sampling_host.h"
 
 namespace allspark {
 
@@ -319,46 +322,57 @@ class GenerateOpHIP : public AsOperator {
   explicit GenerateOpHIP(const std::string& t = "") : AsOperator(t) {}
   AsStatus Init(const OperatorProto& op_proto, const DeviceContext& ctx, const TensorMap& weights_map, TensorMap* tensor_map) override {
     AS_CHECK_STATUS(AsOperator::Init(op_proto, ctx, weights_map, tensor_map));
-    // attributes of the sampling path are accepted only where they mean greedy
-    if (const char* p = attr_ptr(op_proto, "top_k"))
-      if (*(const int*)p != 1) return AsStatus::ALLSPARK_PARAM_ERROR;
+    // (the graph's own top_k attribute is a default the per-request gen_cfg overrides: generate_op.cpp:336-343)
     tensor_map_->at(out_names_[0])->SetDataType(INT64);
     return AsStatus::ALLSPARK_SUCCESS;
   }
-  AsStatus Reshape(RuntimeContext*) override {
+  AsStatus Reshape(RuntimeContext* rt) override {
     AsTensor* x = tensor_map_->at(in_names_[0]).get();
     const Shape& s = x->GetShape();
     if (s.size() < 2) return AsStatus::ALLSPARK_PARAM_ERROR;
     vocab_ = (int)s.back();
     rows_ = (int)(x->Count() / vocab_);
+    // GenerateOp::Reshape: [batch, seq, vocab], the last row of each request is sampled (generate_op.cpp:326-332,476-477)
+    seq_ = s.size() >= 3 ? (int)s[s.size() - 2] : 1;
+    rows_ = (int)(x->Count() / vocab_) / std::max(seq_, 1);
     AsTensor* y = tensor_map_->at(out_names_[0]).get();
     y->SetDataType(INT64);
     AS_CHECK_STATUS(y->SetShape(Shape{rows_, 1}));
+    if (rt && rt->GetGenCtxListSize() > 0) AS_CHECK_STATUS(params_.Gather(rt, rows_, stream_of(ctx_)));
     // scratch: f32 copy of FT logits + the arg-max partials (64 pairs per row)
     const int64_t need = (x->GetDataType() == FLOAT32 ? 0 : (int64_t)rows_ * vocab_ * 4) + (int64_t)rows_ * 64 * 8 + 256;
     AsTensor* wsp = tensor_map_->at("workspace").get();
     if (wsp->GetSizeInByte() < (size_t)need) AS_CHECK_STATUS(wsp->SetShape(Shape{need}));
     return AsStatus::ALLSPARK_SUCCESS;
   }
-  AsStatus Forward(RuntimeContext*) override {
+  AsStatus Forward(RuntimeContext* rt) override {
     AsTensor* x = tensor_map_->at(in_names_[0]).get();
     AsTensor* y = tensor_map_->at(out_names_[0]).get();
     AsTensor* wsp = tensor_map_->at("workspace").get();
     hipStream_t s = stream_of(ctx_);
     char* ws = (char*)wsp->GetDataPtr();
-    const float* logits = (const float*)x->GetDataPtr();
+    if (seq_ > 1 && rows_ != 1) return AsStatus::ALLSPARK_PARAM_ERROR;  // several rows per request only in the context phase (one request)
+    const size_t es = SizeofType(x->GetDataType());
+    const char* last = (const char*)x->GetDataPtr() + (size_t)(std::max(seq_, 1) - 1) * vocab_ * es;  // in_ptr, generate_op.cpp:476-477
+    const float* logits = (const float*)last;
     size_t off = 0;
     if (x->GetDataType() != FLOAT32) {
       if (!is_ft(x->GetDataType())) return AsStatus::ALLSPARK_PARAM_ERROR;
-      AS_CHECK_STATUS(FromDihip(dihip_cast_to_f32(s, (float*)ws, x->GetDataPtr(), (size_t)rows_ * vocab_, DihipDtype(x->GetDataType()))));
+      AS_CHECK_STATUS(FromDihip(dihip_cast_to_f32(s, (float*)ws, last, (size_t)rows_ * vocab_, DihipDtype(x->GetDataType()))));
       logits = (const float*)ws;
       off = ((size_t)rows_ * vocab_ * 4 + 255) & ~(size_t)255;
+    }
+    if (rt && rt->GetGenCtxListSize() > 0 && params_.any_sampling()) {
+      AS_CHECK_STATUS(params_.StagePositions(rt, rt->is_context ? seq_ : 1, s));
+      return FromDihip(dihip_sample(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, params_.top_k(), params_.top_p(), params_.temperature(),
+                                    params_.seed(), params_.dev_pos(), nullptr, nullptr, nullptr, nullptr));
     }
     return FromDihip(dihip_argmax(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, ws + off, wsp->GetSizeInByte() - off));
   }
 
  private:
-  int rows_ = 0, vocab_ = 0;
+  int rows_ = 0, vocab_ = 0, seq_ = 1;
+  SamplingParams params_;
 };
 REGISTER_OP(GenerateOp, HIP, GenerateOpHIP)
 

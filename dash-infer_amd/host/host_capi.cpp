@@ -1,6 +1,7 @@
 // host_capi.cpp -- C test harness of the operator layer (include/dashinfer_hip_host.h).
 #include "dashinfer_hip_host.h"
 
+#include <cstring>
 #include <mutex>
 #include <sstream>
 #include <thread>
@@ -368,6 +369,65 @@ int dihost_sync_ids(dihost_model_t m, int64_t* ids_host, int capacity) {
   }
   for (int i = 0; i < (int)ids.size() && i < capacity; ++i) ids_host[i] = ids[i];
   return (int)ids.size();
+}
+// ---- the Request slice of a runtime-context request (id-processing operators: PreProcessId / UpdateId / PostProcessId) -------
+// attaches a Request with inputs["input_ids"] = ids [1, len] (host) to request `index` of the runtime context set by
+// dihost_set_runtime, with the stop conditions UpdateId checks; stop_words: `n_words` sequences of `word_len` ids each
+int dihost_request_attach(dihost_model_t m, int index, const int64_t* ids, int len, int max_length, int early_stopping, int eos_token_id,
+                          const int64_t* stop_words, int n_words, int word_len, int in_length_bias) {
+  if (index < 0 || index >= (int)m->rt.gen_ctx_list.size() || !ids || len <= 0) return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  auto& gc = m->rt.gen_ctx_list[index];
+  auto rq = std::make_shared<Request>();
+  rq->request_id = "request-" + std::to_string(index);
+  auto t = std::make_shared<AsTensor>("input_ids", DeviceType::CPU, INT64, Shape{1, len});
+  std::memcpy(t->GetDataPtr(), ids, (size_t)len * sizeof(int64_t));
+  rq->inputs["input_ids"] = t;
+  gc->request = rq;
+  gc->gen_cfg.max_length = max_length;
+  gc->gen_cfg.early_stopping = early_stopping != 0;
+  gc->gen_cfg.eos_token_id = eos_token_id;
+  gc->gen_cfg.stop_words_ids.clear();
+  for (int w = 0; w < n_words; ++w) gc->gen_cfg.stop_words_ids.emplace_back(stop_words + (size_t)w * word_len, stop_words + (size_t)(w + 1) * word_len);
+  gc->in_length_bias = in_length_bias;
+  gc->finish = false;
+  gc->gen_over[0] = false;
+  gc->engine_max_length = m->ctx.GetModelMaxLength();
+  return 0;
+}
+// what GenerateOp's fill_generated_ids does after sampling (generate_impl_cpu.hpp:176-200): token -> generated_ids[position], shape grown
+int dihost_request_put_token(dihost_model_t m, int index, int position, int64_t token) {
+  if (index < 0 || index >= (int)m->rt.gen_ctx_list.size() || !m->rt.gen_ctx_list[index]->request) return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  auto& interim = m->rt.gen_ctx_list[index]->request->interim;
+  auto it = interim.find("generated_ids");
+  if (it == interim.end()) return (int)AsStatus::ALLSPARK_INVALID_CALL_ERROR;
+  AsTensor& t = *it->second;
+  if (position < 0) return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  if (position >= t.Count() && t.SetShape(Shape{1, (int64_t)position + 1}) != AsStatus::ALLSPARK_SUCCESS) return (int)AsStatus::ALLSPARK_EXCEED_LIMIT_ERROR;
+  static_cast<int64_t*>(t.GetDataPtr())[position] = token;
+  return 0;
+}
+int dihost_set_phase(dihost_model_t m, int is_context) {  // the same requests, the other phase (context <-> decoder)
+  m->rt.is_context = is_context != 0;
+  return 0;
+}
+int dihost_request_set_step(dihost_model_t m, int index, int step, int in_length_bias) {
+  if (index < 0 || index >= (int)m->rt.gen_ctx_list.size()) return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  m->rt.gen_ctx_list[index]->step = step;
+  m->rt.gen_ctx_list[index]->in_length_bias = in_length_bias;
+  return 0;
+}
+// -> number of queued tokens copied (the queue is drained), *finish = the request's stop verdict; negative AsStatus on error
+int dihost_request_poll(dihost_model_t m, int index, int64_t* tokens, int capacity, int* finish, int* n_interim) {
+  if (index < 0 || index >= (int)m->rt.gen_ctx_list.size() || !m->rt.gen_ctx_list[index]->request) return -(int)AsStatus::ALLSPARK_PARAM_ERROR;
+  auto& gc = m->rt.gen_ctx_list[index];
+  std::lock_guard<std::mutex> g(gc->request->queue_mu);
+  auto& q = gc->request->generated_ids_queue;
+  const int n = std::min((int)q.size(), capacity);
+  for (int i = 0; i < n; ++i) tokens[i] = q[i];
+  q.erase(q.begin(), q.begin() + n);
+  if (finish) *finish = gc->finish ? 1 : 0;
+  if (n_interim) *n_interim = (int)gc->request->interim.size();
+  return n;
 }
 int dihost_running_batch(dihost_model_t m) { return m->runner ? m->runner->batch() : 0; }
 int dihost_requests_rewind(dihost_model_t m, int cached_len) {

@@ -34,6 +34,11 @@ _SIGS = {
     "dihost_request_stop": (i32, [vp, i32]),
     "dihost_decode_steps": (i32, [vp, i32, i32]),
     "dihost_sync_ids": (i32, [vp, C.POINTER(C.c_int64), i32]),
+    "dihost_request_attach": (i32, [vp, i32, C.POINTER(C.c_int64), i32, i32, i32, i32, C.POINTER(C.c_int64), i32, i32, i32]),
+    "dihost_request_put_token": (i32, [vp, i32, i32, C.c_int64]),
+    "dihost_request_set_step": (i32, [vp, i32, i32, i32]),
+    "dihost_set_phase": (i32, [vp, i32]),
+    "dihost_request_poll": (i32, [vp, i32, C.POINTER(C.c_int64), i32, C.POINTER(i32), C.POINTER(i32)]),
     "dihost_running_batch": (i32, [vp]),
     "dihost_requests_rewind": (i32, [vp, i32]),
     "dihost_last_error": (C.c_char_p, []),
@@ -192,3 +197,29 @@ class Model:
 
     def requests_rewind(self, cached_len):
         _ck(lib().dihost_requests_rewind(self.h, int(cached_len)), "requests_rewind")
+
+    # ---- the Request slice behind PreProcessId / UpdateId / PostProcessId -------------------------------------------------
+    def request_attach(self, index, ids, max_length=0, early_stopping=True, eos=-1, stop_words=(), in_length_bias=0):
+        arr = (C.c_int64 * len(ids))(*[int(t) for t in ids])
+        wl = len(stop_words[0]) if stop_words else 0
+        assert all(len(w) == wl for w in stop_words)
+        flat = [int(t) for w in stop_words for t in w]
+        sw = (C.c_int64 * max(1, len(flat)))(*flat)
+        _ck(lib().dihost_request_attach(self.h, index, arr, len(ids), max_length, int(early_stopping), eos, sw, len(stop_words), wl,
+                                        in_length_bias), "request_attach")
+
+    def request_put_token(self, index, position, token):
+        _ck(lib().dihost_request_put_token(self.h, index, position, int(token)), "request_put_token")
+
+    def request_set_step(self, index, step, in_length_bias=0):
+        _ck(lib().dihost_request_set_step(self.h, index, step, in_length_bias), "request_set_step")
+
+    def request_poll(self, index, capacity=64):
+        buf, fin, ni = (C.c_int64 * capacity)(), i32(), i32()
+        n = lib().dihost_request_poll(self.h, index, buf, capacity, C.byref(fin), C.byref(ni))
+        if n < 0:
+            raise HostError(-n, "request_poll")
+        return [int(buf[i]) for i in range(n)], bool(fin.value), ni.value
+
+    def set_phase(self, is_context):
+        _ck(lib().dihost_set_phase(self.h, int(is_context)), "set_phase")

@@ -514,3 +514,23 @@ def prefetch(tensors, stream=None, workgroups=0):
 def increment_u32_(v):
     check(lib().dihip_increment_u32(cur_stream(), ptr(v), v.numel()), "dihip_increment_u32")
     return v
+
+
+def sample(logits, top_k, top_p, temperature, seed, position=None, advance=(), want_probs=False):
+    """The sampling half of GenerateOp (dihip_sample): logits f32 [M, N]; top_k / top_p / temperature / seed per row (lists or
+    tensors); position: u32 device tensor [M] (the index of the token being sampled) or None.  -> ids [M] (and, with want_probs,
+    the final probabilities / candidate indices [M, 1024] of the sorted candidates)."""
+    M, N = logits.shape
+    dev = logits.device
+    tk = torch.as_tensor(top_k, dtype=torch.int32).to(dev)
+    tp = torch.as_tensor(top_p, dtype=torch.float32).to(dev)
+    tt = torch.as_tensor(temperature, dtype=torch.float32).to(dev)
+    sd = torch.as_tensor([int(s) & 0x7FFFFFFFFFFFFFFF for s in seed] if not isinstance(seed, torch.Tensor) else seed, dtype=torch.int64).to(dev)
+    ids = torch.empty(M, dtype=torch.int64, device=dev)
+    probs = torch.zeros(M, 1024, dtype=torch.float32, device=dev) if want_probs else None
+    cand = torch.full((M, 1024), -1, dtype=torch.int32, device=dev) if want_probs else None
+    a = advance[0] if len(advance) > 0 else None
+    b = advance[1] if len(advance) > 1 else None
+    check(lib().dihip_sample(cur_stream(), ptr(ids), ptr(logits), M, N, ptr(tk), ptr(tp), ptr(tt), ptr(sd), ptr(position), ptr(a), ptr(b),
+                             ptr(probs), ptr(cand)), "dihip_sample")
+    return (ids, probs, cand) if want_probs else ids

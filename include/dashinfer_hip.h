@@ -414,6 +414,18 @@ int dihip_argmax(void* stream, int64_t* ids, const float* logits, int M, int N, 
  * advance by one in the same launch: the decode step needs no separate length-update kernels */
 int dihip_argmax_advance(void* stream, int64_t* ids, const float* logits, int M, int N, void* ws,
                          size_t ws_bytes, uint32_t* counters_a, uint32_t* counters_b);
+/* The sampling half of GenerateOp (generate_op.cpp:472-600; arithmetic of its x86 path, generate_impl_cpu.hpp:120-170): per row
+ *   top-k (k largest logits, descending; top_k <= 0 or > 1024 -> 1024, the reference's CONFIG_SAMPLE_CONSTRAIN_MAX_K limit) ->
+ *   softmax(logit / T) -> top-p (shortest prefix whose cumulated probability EXCEEDS p; p <= 1e-7: off, kernel/cpu/topp.cpp) ->
+ *   softmax(logit / T) over the prefix -> exponential race prob_i / -log1p(-u_i), first maximum wins (kernel/cpu/sample.cpp:42-68).
+ * top_k / top_p / temperature / seed: device arrays [M].  The random stream is the backend's own, a pure function of
+ * (seed[m], position[m], candidate rank): position = device-resident index of the token being sampled (NULL: 0), so that a
+ * captured step replays; counters_a / _b (may be NULL) advance by one per row like dihip_argmax_advance.  probs_out / cand_out
+ * (tests, may be NULL): [M, 1024] final probabilities / candidate indices in sorted order (0 / -1 beyond the kept prefix / k). */
+int dihip_sample(void* stream, int64_t* ids, const float* logits, int M, int N, const int* top_k,
+                 const float* top_p, const float* temperature, const unsigned long long* seed,
+                 const uint32_t* position, uint32_t* counters_a, uint32_t* counters_b, float* probs_out,
+                 int* cand_out);
 /* vocabulary-parallel greedy sampling for TP: one {f32 value, i32 global index} pair per row
  * from this rank's logits slice [M, N] (global index = local + index_offset); after an
  * all-gather of the pairs ([nparts][M]) every rank merges them to the same ids.                */

@@ -71,6 +71,16 @@ int dihost_request_stop(dihost_model_t m, int index);
 int dihost_decode_steps(dihost_model_t m, int n, int use_graph);
 /* synchronises the stream; ids generated by the last step, one per running request -> count (negative AsStatus on error) */
 int dihost_sync_ids(dihost_model_t m, int64_t* ids_host, int capacity);
+/* the Request slice behind the id-processing operators (PreProcessId / UpdateId / PostProcessId, host/id_ops_hip.cpp):
+ * attach: request `index` of the runtime context gets inputs["input_ids"] = ids [1, len] and the stop conditions UpdateId checks
+ * (stop_words: n_words sequences of word_len ids); put_token: what GenerateOp's fill_generated_ids writes after sampling;
+ * poll: drains the request's queue of generated tokens -> count, *finish = stop verdict, *n_interim = interim tensors */
+int dihost_request_attach(dihost_model_t m, int index, const int64_t* ids, int len, int max_length, int early_stopping, int eos_token_id,
+                          const int64_t* stop_words, int n_words, int word_len, int in_length_bias);
+int dihost_request_put_token(dihost_model_t m, int index, int position, int64_t token);
+int dihost_request_set_step(dihost_model_t m, int index, int step, int in_length_bias);
+int dihost_set_phase(dihost_model_t m, int is_context);
+int dihost_request_poll(dihost_model_t m, int index, int64_t* tokens, int capacity, int* finish, int* n_interim);
 int dihost_running_batch(dihost_model_t m);
 /* benchmarks: every running request (and its cache) back to cached_len tokens; spans, shapes and the captured step are kept */
 int dihost_requests_rewind(dihost_model_t m, int cached_len);

@@ -467,3 +467,44 @@ def test_allgather_operator_single_rank_and_row_transpose(env):
         check(lib().dihip_gather_rows_transpose(ops.cur_stream(), ops.ptr(out), ops.ptr(tmp), nr, rows, rb), "gather_rows_transpose")
         torch.cuda.synchronize()
         assert torch.equal(out, tmp.view(nr, rows, rb).transpose(0, 1).reshape(-1)), (nr, rows, rb)
+
+
+def test_preprocess_id_and_update_id_follow_a_request_through_its_stop_conditions(env):
+    """PreProcessId (preprocess_id_op.cpp:32-80) copies the request's input ids into its host and device "generated_ids"; after
+    every step GenerateOp writes the new token there (fill_generated_ids) and UpdateId (update_id_op.cpp:42-156) queues it and
+    applies the stop conditions: eos (early_stopping), stop words, the length limit -- positions per the reference's table
+    (context: step + in_length_bias, decoder: step)."""
+    from dash_infer_amd import hostapi, ops
+    m = hostapi.Model(ops.cur_stream(), 4, 2, 128, 16, max_batch=3, max_len=64)
+    pre = m.create_op("PreProcessId", "preprocess_id", ["input_ids"], ["pre.out"])
+    upd = m.create_op("UpdateId", "update_id", ["generated_ids"], ["upd.out"])
+    prompt = [101, 102, 103, 104]
+    L = len(prompt)
+    scripts = {   # tokens GenerateOp "samples" per step (context step first) and the step after which the request must be finished
+        "eos":   dict(toks=[5, 6, 99, 7], kw=dict(max_length=64, eos=99, stop_words=[]), done_after=2),
+        "words": dict(toks=[5, 7, 8, 9], kw=dict(max_length=64, eos=-1, stop_words=[[7, 8], [1, 2]]), done_after=2),
+        "limit": dict(toks=[5, 6, 7, 8], kw=dict(max_length=L + 3, eos=-1, stop_words=[]), done_after=2),
+    }
+    for name, sc in scripts.items():
+        # ---- context phase: step = 0 (no prefix); PreProcessId; GenerateOp's token lands at position L; UpdateId with in_length_bias = L
+        m.set_runtime(True, [0], [[[]]], [[[]]])
+        m.request_attach(0, prompt, early_stopping=True, in_length_bias=0, **sc["kw"])
+        m.forward(pre)
+        _, _, n_interim = m.request_poll(0)
+        assert n_interim == 2                                 # generated_ids + generated_ids_gpu
+        m.request_set_step(0, 0, in_length_bias=L)
+        m.request_put_token(0, L, sc["toks"][0])
+        m.forward(upd)
+        got, finish, _ = m.request_poll(0)
+        assert got == [sc["toks"][0]] and not finish, name
+        # ---- decoder phase: step = tokens in the cache = position of the token fed; the new token lands at step + 1 ... the
+        # reference reads generated_ids[step] AFTER AsModel advanced step (model.cpp:1320): emulate that order
+        m.set_phase(False)
+        for t, tok in enumerate(sc["toks"][1:], start=1):
+            m.request_put_token(0, L + t, tok)
+            m.request_set_step(0, L + t, in_length_bias=0)
+            m.forward(upd)
+            got, finish, _ = m.request_poll(0)
+            assert got == [tok], (name, t)
+            assert finish == (t >= sc["done_after"]), (name, t, finish)
+    m.close()
