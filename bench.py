@@ -653,12 +653,13 @@ def csrc_tree_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary
-    (profiles/*_pmc_hbm_traffic.csv, written by tools/gpu_pmc.sh: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE)."""
+def pmc_traffic(kernel_substr, workload="int4_b1"):
+    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary of this workload
+    (profiles/*_pmc_hbm_traffic[_<workload>].csv, written by tools/gpu_pmc.sh: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE)."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.csv")))
+    suffix = "" if workload == "int4_b1" else "_" + workload
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic%s.csv" % suffix)))
     if not files:
         return None, None
     key = kernel_substr.rstrip(">")  # template argument lists may have grown a defaulted tail
@@ -689,8 +690,10 @@ def main():
     ap.add_argument("--steps-per-graph", type=int, default=1,
                     help="consecutive decode steps captured per hipGraph (measured: 1 is fastest, back-to-back replays already pipeline)")
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each; the median block is reported")
-    ap.add_argument("--runner", default="python", choices=["python", "host"],
-                    help="whose step `value` is: decoder.DecodeSession (Python + ctypes) or the C++ operator layer (fused list, hipGraph)")
+    ap.add_argument("--runner", default="auto", choices=["auto", "python", "host"],
+                    help="whose step `value` is: the C++ operator layer (host: reference operator list -> fusion pass -> OpFactory -> "
+                         "model runner, hipGraph replay) or decoder.DecodeSession (python: the same C-ABI calls from Python).  auto = host "
+                         "where it applies (one GPU, dense model), python otherwise; both figures are always in the line")
     ap.add_argument("--no-extra", action="store_true", help="headline only: no host-runner figures, no secondary workloads, no TP A/B")
     args = ap.parse_args()
 
@@ -736,7 +739,9 @@ def main():
     t_build = time.time()
     # the C++ operator layer is measured beside the Python runner on the dense one-GPU workloads (its operators re-lay-out the
     # unpacked quantised tensors themselves: keep them)
-    host_leg = world == 1 and cfg.moe is None and (args.runner == "host" or not args.no_extra)
+    host_leg = world == 1 and cfg.moe is None and args.runner != "python"
+    if args.runner == "host" and not host_leg:
+        raise SystemExit("--runner host: the operator-layer runner covers the dense one-GPU workloads")
     model = decoder.build_random_model(cfg, spec, seed=1234, rank=rank, nranks=world, layers=args.layers, keep_fp=host_leg)
     blocks = max(1, args.blocks)
     # (kept tight: the decode attention's split width is fixed from max_len; the blocks rewind to SEQ_LEN instead of growing it)
@@ -812,7 +817,8 @@ def main():
             if args.runner == "host":
                 raise
             host_runner = {"error": repr(e)}
-    if args.runner == "host":
+    value_from_host = host_leg and isinstance(host_runner, dict) and "fused_graph" in host_runner and host_runner["fused_graph"].get("fused")
+    if value_from_host:
         elapsed = host_runner["fused_graph"]["ms_per_step"] * 1e-3 * args.steps
         block_times = None
 
@@ -851,8 +857,8 @@ def main():
                    "layers": len(model.layers)},
         "step_hbm": {"algorithmic_bytes_per_rank": int(step_bytes), "achieved_GBps_per_gpu": round(step_gbs, 1),
                      "frac_of_peak": round(step_gbs / HBM_PEAK_GBS, 4)},
-        "runner": ("python: decoder.DecodeSession over the C-ABI (hipGraph replay)" if args.runner == "python" else
-                   "host: C++ operator layer, fused operator list behind the allspark operator API, hipGraph replay"),
+        "runner": ("host: C++ operator layer -- reference operator list -> fusion pass -> OpFactory(HIP) -> model runner, hipGraph replay"
+                   if value_from_host else "python: decoder.DecodeSession over the C-ABI (hipGraph replay)"),
         "blocks": blocks_summary(block_times, args.steps) if block_times else (host_runner or {}).get("fused_graph", {}).get("blocks"),
         "python_runner": python_runner,
         "host_runner": host_runner,   # host_runner.fused_graph.tokens_per_s = the operator-API figure; .unfused_eager = op by op
@@ -890,7 +896,7 @@ def main():
                 fam = "gemm_panel_kernel" if os.environ.get("DIHIP_GEMM_KSLICE", "1") == "0" else "gemm_kslice_kernel"
                 kname = "%s<%d, 2, %d, 1, %d>" % (fam, wbits, 2 if batch > 16 else 1, gpt)
                 kdesc = " (gate/up small-batch GEMM + SwiGLU; the timed launch pair includes the RMSNorm kernel)"
-            traffic, traffic_source = pmc_traffic(kname) if (args.workload == "int4_b1" and world == 1) else (None, None)  # PMC pass: TP=1 shapes
+            traffic, traffic_source = pmc_traffic(kname, args.workload) if world == 1 else (None, None)  # PMC passes: TP=1 shapes
             out["roofline"] = {"bound": "hbm", "kernel": "dihip::" + kname + kdesc,
                                "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4),

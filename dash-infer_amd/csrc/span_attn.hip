@@ -684,11 +684,11 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
   static const bool static_tps = !env_off("DIHIP_ATTN_STATIC_TPS");
   static const int merge_mode = [] {  // "launch": the split merge as a second launch also when a sync buffer is given (A/B)
     const char* m = getenv("DIHIP_ATTN_MERGE");
-    return (m && m[0] == 'l') ? 0 : 1;
+    return (m && m[0] == 'l') ? 0 : (m && m[0] == 'n') ? 2 : 1;  // "none" (timing experiments only): partials written, never merged
   }();
   if (static_tps) a.tps_static = ((max_seq_len + p.nsplits - 1) / p.nsplits + 31) & ~31;
   // in-launch merge: needs the caller's zero-initialised ticket words (dihip_span_attn_decode_fused_sync)
-  const bool merge_wt = merge_mode >= 1 && p.nsplits > 1 && sync != nullptr &&
+  const bool merge_wt = merge_mode == 1 && p.nsplits > 1 && sync != nullptr &&
                         sync_bytes >= (size_t)batch * n_groups * p.nchunks * 128 && p.partial_bytes < (1ull << 31);
   if (merge_wt) {
     a.counters = reinterpret_cast<unsigned*>(sync);
@@ -700,7 +700,7 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
     hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_NONE, true>), grid, dim3(ATTN_THREADS), 0, s, a);
   else
     hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_F16, DIHIP_KV_NONE, true>), grid, dim3(ATTN_THREADS), 0, s, a);
-  if (p.nsplits > 1 && !merge_wt) {
+  if (p.nsplits > 1 && !merge_wt && merge_mode != 2) {
     const dim3 mg(batch * n_heads), mb(128);
     if (dtype == DIHIP_BF16)
       hipLaunchKernelGGL(span_attn_split_merge_kernel<DIHIP_BF16>, mg, mb, 0, s, output, a.partials, n_heads, p.nsplits, 0);

@@ -309,9 +309,11 @@ def test_qwen7b_full_depth_decode_vs_oracle(pkg, wbits, group, gptq, roundings):
     # What holds on every box.  The literal "1e-2 absolute" of the north star does not exist at this depth for ANY pair of
     # evaluations of the graph: two oracles that differ in nothing but the summation precision are already further apart
     # (the @f64 twin of the ablation run; DESIGN.md section 0 has the measured table).  Asserted: the product stays within
-    # 4e-2 of the logit scale of the hybrid rounding, is closer to it than the reference's own x86 variants are to each other,
+    # 3e-2 of the logit scale of the hybrid rounding (measured 2.2e-2; the clause itself is asserted on a DECISIVE model and per
+    # layer in tests/test_gpu_parity_depth.py -- this random N(0, 0.02) model is kept as the explanation of why it has to be), is
+    # closer to it than the reference's own x86 variants are to each other,
     # and a greedy id differs from an oracle's only inside that oracle's genuine near-tie.
-    assert max(errs) <= 4e-2 * max(1.0, scale), f"logits differ by {max(errs):.3e} at max |logit| {scale:.2f}"
+    assert max(errs) <= 3e-2 * max(1.0, scale), f"logits differ by {max(errs):.3e} at max |logit| {scale:.2f}"
     if ("x86_pure_bf16", "x86_pure_f32") in dist:
         assert max(errs) <= dist[("x86_pure_bf16", "x86_pure_f32")], "further from the hybrid oracle than the two x86 precisions are from each other"
     for r in rep:

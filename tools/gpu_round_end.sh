@@ -8,10 +8,10 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 if [ -z "$SKIP_TESTS" ]; then
-  DIHIP_FULL_DEPTH_ABLATION=${ABLATION:-0} timeout 1500 python -m pytest tests -m gpu -q -s 2>&1 | grep -E "FULL DEPTH|configs\[|7B-width|operator graph|passed|failed|error" | cut -c1-900 > $OUT/pytest_gpu.log
+  DIHIP_FULL_DEPTH_ABLATION=${ABLATION:-0} timeout 2400 python -m pytest tests -m gpu -q -s 2>&1 | grep -E "FULL DEPTH|configs\[|7B-width|operator graph|\[int4_b1\]|\[int4_b32_u4kv\]|\[cfg3_rank\]|passed|failed|error" | cut -c1-900 > $OUT/pytest_gpu.log
   tail -3 $OUT/pytest_gpu.log
 fi
-timeout 400 python bench.py > $OUT/bench_int4_b1.json 2> $OUT/bench_int4_b1.err
+timeout 900 python bench.py > $OUT/bench_int4_b1.json 2> $OUT/bench_int4_b1.err
 python - <<PY
 import json
 d = json.load(open("$OUT/bench_int4_b1.json"))
@@ -31,12 +31,14 @@ PY
 done
 export TMPDIR=/tmp
 cd /tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o int4_b1 -- python $ROOT/bench.py --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof_bench.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o int4_b1 -- python $ROOT/bench.py --no-cpu-baseline --no-extra > $OUT/prof_bench.json 2> $OUT/prof_bench.err
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" $OUT/bench_int4_b1_kernel_stats.csv && head -12 $OUT/bench_int4_b1_kernel_stats.csv | cut -c1-160
 find $OUT/prof -name "*.csv" -size +4M -delete
 cd $ROOT
 if [ -z "$SKIP_PMC" ]; then
-  bash tools/gpu_pmc.sh $TAG/pmc > $OUT/pmc.log 2>&1
-  tail -12 $OUT/pmc.log | cut -c1-160
+  for w in int4_b1 int4_b32_u4kv cfg3_rank int8_b1; do   # (counters for every workload, not the headline alone)
+    bash tools/gpu_pmc.sh $TAG/pmc $w > $OUT/pmc_$w.log 2>&1
+    tail -8 $OUT/pmc_$w.log | cut -c1-160
+  done
 fi
