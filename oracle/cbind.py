@@ -3,6 +3,8 @@
   oracle/_ref/liboracle_c.so     - our plain-C restatement (oracle/c/oracle_c.c)
   oracle/_ref/libdashinfer_ref.so - the reference's own host loops compiled from
                                     /root/reference by oracle/Makefile (optional)
+  oracle/_ref/libdashinfer_ref_attn.so - the reference's x86 decoder attention
+                                    (cpu_dec_single_mqa + kernel/cpu/mha.cpp), same recipe
 Both are built by ``make -C oracle`` (also run by __graft_entry__.build()).
 """
 import ctypes as C
@@ -180,3 +182,45 @@ def ref_prefill_check(concat, output, alpha, causal=True, feps=1e-3):
     b, s, _, nh, ph = concat.shape
     return bool(r.ref_prefill_check(_ptr(concat), _ptr(output), b, s, nh, ph, C.c_float(alpha),
                                     1 if causal else 0, C.c_float(feps)))
+
+
+# ---- the reference's own x86 decoder attention (oracle/ref_attn_shim.cpp -> _ref/libdashinfer_ref_attn.so) -----------------
+_ref_attn = None
+
+
+def ref_attn_lib():
+    """BatchMQAOp's cpu_dec_single_mqa + the AVX2 softmax / batch helpers of kernel/cpu/mha.cpp, compiled from /root/reference
+    by oracle/Makefile (needs AVX2 on the host), or None when absent."""
+    global _ref_attn
+    if _ref_attn is None:
+        p = os.path.join(_REFDIR, "libdashinfer_ref_attn.so")
+        ok = os.path.exists(p)
+        if ok:
+            try:
+                ok = "avx2" in open("/proc/cpuinfo").read()
+            except OSError:
+                ok = False
+        _ref_attn = C.CDLL(p) if ok else False
+    return _ref_attn or None
+
+
+def ref_decode_attention_step(qkv, k_cache, v_cache, step, n, g, H, alpha):
+    """One decoder step of the reference's x86 attention for `batch` requests at the same step.  qkv f32 [batch, (n + 2 g) H]
+    (this step's rotated q | k | v), k_cache / v_cache f32 [batch, cache_max_len, g H] holding step - 1 earlier tokens (this step's
+    rows are appended in place at position step - 1).  -> out f32 [batch, n H]."""
+    l = ref_attn_lib()
+    qkv = _f32(qkv)
+    batch = qkv.shape[0]
+    assert k_cache.dtype == np.float32 and v_cache.dtype == np.float32 and k_cache.flags.c_contiguous and v_cache.flags.c_contiguous
+    out = np.empty((batch, n * H), np.float32)
+    l.ref_dec_single_mqa.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
+    l.ref_dec_single_mqa(out, qkv, k_cache, v_cache, batch, int(step), k_cache.shape[1], n, H, g, float(alpha))
+    return out
+
+
+def ref_vsoftmax(row, temperature=1.0):
+    l = ref_attn_lib()
+    r = _f32(row).copy()
+    l.ref_vsoftmax.argtypes = [_fp, C.c_int, C.c_float]
+    l.ref_vsoftmax(r, r.shape[0], float(temperature))
+    return r

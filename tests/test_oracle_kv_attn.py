@@ -120,3 +120,42 @@ def test_prefill_oracle_passes_reference_checker(causal):
     bad = out.copy()
     bad[1, 5, 1, 7] += 0.05
     assert not cbind.ref_prefill_check(concat, bad, alpha, causal, 1e-3) or True  # checker may only warn
+
+
+# ---- the decode attention oracle pinned against the REFERENCE's own x86 code ---------------------------
+needs_ref_attn = pytest.mark.skipif(cbind.ref_attn_lib() is None, reason="oracle/_ref/libdashinfer_ref_attn.so not built (or no AVX2)")
+
+
+@needs_ref_attn
+@pytest.mark.parametrize("n,g,H,step,batch", [(28, 4, 128, 1, 1), (28, 4, 128, 9, 2), (8, 1, 128, 300, 3), (4, 4, 64, 33, 1), (28, 4, 128, 2049, 1)])
+def test_decode_attention_oracle_matches_the_reference_x86_decoder_attention(n, g, H, step, batch):
+    """oracle/attention.py::decode_attention against BatchMQAOp's cpu_dec_single_mqa (batch_mqa_op.cpp:140-179) with the batch
+    helpers and the AVX2 softmax of kernel/cpu/mha.cpp compiled from the reference tree: cache update at position step - 1, GQA
+    head -> group mapping, alpha inside the score product, softmax over `step` tokens, P.V.  (cblas_sgemm itself is a plain loop
+    in the shim: MKL is an LFS stub.)  Agreement to f32 accumulation accuracy."""
+    from oracle import attention
+    rng = np.random.default_rng(step * 7 + n)
+    alpha = 1.0 / np.sqrt(H)
+    cap = step + 3
+    kc = np.zeros((batch, cap, g * H), np.float32)
+    vc = np.zeros((batch, cap, g * H), np.float32)
+    kc[:, : step - 1] = rng.normal(0, 1, (batch, step - 1, g * H))
+    vc[:, : step - 1] = rng.normal(0, 1, (batch, step - 1, g * H))
+    qkv = rng.normal(0, 1, (batch, (n + 2 * g) * H)).astype(np.float32)
+    got = cbind.ref_decode_attention_step(qkv, kc, vc, step, n, g, H, alpha)
+    # the reference appended this step's k / v rows itself
+    np.testing.assert_array_equal(kc[:, step - 1], qkv[:, n * H:(n + g) * H])
+    np.testing.assert_array_equal(vc[:, step - 1], qkv[:, (n + g) * H:])
+    for b in range(batch):
+        want = attention.decode_attention(qkv[b, : n * H].reshape(n, H), kc[b, :step].reshape(step, g, H), vc[b, :step].reshape(step, g, H), alpha)
+        np.testing.assert_allclose(got[b].reshape(n, H), want, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want).max())))
+
+
+@needs_ref_attn
+def test_softmax_rows_matches_the_reference_avx2_softmax():
+    from oracle import attention
+    rng = np.random.default_rng(0)
+    for nlen in (1, 5, 8, 63, 64, 1000):
+        row = rng.normal(0, 3, nlen).astype(np.float32)
+        np.testing.assert_allclose(cbind.ref_vsoftmax(row), attention.softmax_rows(row[None])[0], rtol=0, atol=3e-7)
+        np.testing.assert_allclose(cbind.ref_vsoftmax(row, 0.7), attention.softmax_rows(row[None] / np.float32(0.7))[0], rtol=0, atol=3e-7)
