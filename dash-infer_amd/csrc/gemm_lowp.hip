@@ -188,7 +188,7 @@ static hipError_t dispatch(const GemmPlan& p, int pro, int epi, const GemmArgs& 
   CASE(1, 4, PRO_PLAIN, EPI_STD)
   CASE(2, 2, PRO_PLAIN, EPI_STD)
   CASE(2, 4, PRO_PLAIN, EPI_STD)
-  if constexpr (FT == DIHIP_BF16) {
+  {  // fused decode-step forms: bf16 and (round 4) f16
     CASE(1, 2, PRO_RMSNORM, EPI_STD)
     CASE(1, 4, PRO_RMSNORM, EPI_STD)
     CASE(1, 4, PRO_RMSNORM, EPI_SWIGLU)
@@ -364,9 +364,9 @@ static hipError_t dispatch_gemv(const GemvPlan& p, int pro, int epi, const GemvA
   return hipErrorInvalidValue;
 }
 
-// f16 activations: the op-boundary form only (PRO_PLAIN / EPI_STD); the fused decode-step forms are bf16
+// (round 3: f16 activations had the op-boundary form only; round 4 instantiates every form for f16 -- dispatch_gemv<WBITS, DIHIP_F16>)
 template <int WBITS>
-static hipError_t dispatch_gemv_f16(const GemvPlan& p, const GemvArgs& a, hipStream_t s) {
+[[maybe_unused]] static hipError_t dispatch_gemv_f16(const GemvPlan& p, const GemvArgs& a, hipStream_t s) {
   const bool gpt = p.ktpg == 1;
   if (p.MR == 1) return gpt ? launch_gemv_stream<WBITS, DIHIP_F16, 1, PRO_PLAIN, EPI_STD, 1>(a, p.blocks, p.lds_bytes, s)
                             : launch_gemv_stream<WBITS, DIHIP_F16, 1, PRO_PLAIN, EPI_STD, 0>(a, p.blocks, p.lds_bytes, s);
@@ -524,7 +524,7 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
   const LowpDims d = lowp_dims(c.wbits, c.N, c.K, c.group_size);
   const bool gemv_aligned = (c.K == d.Kp) && (c.ldx % 8 == 0) && (reinterpret_cast<uintptr_t>(c.x) % 16 == 0) &&
                             (c.pro == PRO_PLAIN || reinterpret_cast<uintptr_t>(c.gamma) % 16 == 0);
-  const bool f16_std = c.dtype == DIHIP_F16 && c.pro == PRO_PLAIN && c.epi == EPI_STD && c.wbits != 16;
+  const bool f16_std = c.dtype == DIHIP_F16;  // every form of the decode GEMV exists for f16 as well
   const bool want_frag = c.x_layout == DIHIP_ACT_FRAG32 || c.y_layout == DIHIP_ACT_FRAG32;  // small-batch kernel only
   if ((c.dtype == DIHIP_BF16 || f16_std) && gemv_stream_enabled() && gemv_aligned && !want_frag) {
     const GemvPlan gp = make_gemv_plan(c.wbits, c.M, c.N, c.K, c.group_size, dual);
@@ -563,7 +563,9 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
       fill_kcut(g);
       g.trace = debug_trace_buffer((size_t)gp.blocks * GEMV_WAVES * 64);
       hipError_t e = hipErrorInvalidValue;
-      if (f16_std) e = c.wbits == 4 ? dispatch_gemv_f16<4>(gp, g, stream) : dispatch_gemv_f16<8>(gp, g, stream);
+      if (f16_std && c.wbits == 4) e = dispatch_gemv<4, DIHIP_F16>(gp, c.pro, c.epi, g, stream);
+      else if (f16_std && c.wbits == 8) e = dispatch_gemv<8, DIHIP_F16>(gp, c.pro, c.epi, g, stream);
+      else if (f16_std && c.wbits == 16) e = dispatch_gemv<16, DIHIP_F16>(gp, c.pro, c.epi, g, stream);
       else if (c.wbits == 4) e = dispatch_gemv<4, DIHIP_BF16>(gp, c.pro, c.epi, g, stream);
       else if (c.wbits == 8) e = dispatch_gemv<8, DIHIP_BF16>(gp, c.pro, c.epi, g, stream);
       else if (c.wbits == 16) e = dispatch_gemv<16, DIHIP_BF16>(gp, c.pro, c.epi, g, stream);
@@ -1034,15 +1036,22 @@ int dihip_gemm_a16w4(void* stream, const void* x, const void* w_packed, const vo
 }
 
 // RMSNorm of M rows of the f32 hidden stream into FT rows (row-major or FRAG32)
-static int launch_rmsnorm_rows(hipStream_t s, const float* h, const void* gamma, float eps, int M, int K, void* out, int frag_mt) {
+static int launch_rmsnorm_rows(hipStream_t s, const float* h, const void* gamma, float eps, int M, int K, void* out, int frag_mt,
+                               int dtype = DIHIP_BF16) {
   const bool vec = K % 4 == 0 && (reinterpret_cast<uintptr_t>(h) % 16 == 0) && (reinterpret_cast<uintptr_t>(gamma) % 8 == 0);
   uint16_t* xo = reinterpret_cast<uint16_t*>(out);
-  if (vec && K <= 4096)
-    hipLaunchKernelGGL((rmsnorm_f32_to_ft_kernel<DIHIP_BF16, 4, 256>), dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, frag_mt);
-  else if (vec && K <= 8192)  // wide rows: 1024 threads, two vectors each (256 threads took 6.8 us for 16 rows of 8192)
-    hipLaunchKernelGGL((rmsnorm_f32_to_ft_kernel<DIHIP_BF16, 2, 1024>), dim3(M), dim3(1024), 0, s, xo, h, gamma, eps, K, frag_mt);
-  else
-    hipLaunchKernelGGL(rmsnorm_f32_to_ft_wide_kernel<DIHIP_BF16>, dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, frag_mt);
+#define DIHIP_RMS_ROWS(FT_)                                                                                                        \
+  do {                                                                                                                             \
+    if (vec && K <= 4096)                                                                                                          \
+      hipLaunchKernelGGL((rmsnorm_f32_to_ft_kernel<FT_, 4, 256>), dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, frag_mt);         \
+    else if (vec && K <= 8192) /* wide rows: 1024 threads, two vectors each (256 threads took 6.8 us for 16 rows of 8192) */       \
+      hipLaunchKernelGGL((rmsnorm_f32_to_ft_kernel<FT_, 2, 1024>), dim3(M), dim3(1024), 0, s, xo, h, gamma, eps, K, frag_mt);       \
+    else                                                                                                                           \
+      hipLaunchKernelGGL(rmsnorm_f32_to_ft_wide_kernel<FT_>, dim3(M), dim3(256), 0, s, xo, h, gamma, eps, K, frag_mt);              \
+  } while (0)
+  if (dtype == DIHIP_F16) DIHIP_RMS_ROWS(DIHIP_F16);
+  else DIHIP_RMS_ROWS(DIHIP_BF16);
+#undef DIHIP_RMS_ROWS
   return launch_status();
 }
 
@@ -1059,20 +1068,20 @@ static int norm_to_ws(hipStream_t s, const float* h, const void* gamma, float ep
     slab = std::max(slab, make_kslice_plan(wbits, M, N, K, group_size, dual, true).slab_bytes);
   }
   const size_t off = (slab + 255) & ~(size_t)255;
-  const bool frag = force_frag || batch_kernel_shape(wbits, M, N, K, group_size, dual);
+  const bool frag = dtype == DIHIP_BF16 && (force_frag || batch_kernel_shape(wbits, M, N, K, group_size, dual));  // the small-batch kernels are bf16
   const int mt = M > 16 ? 2 : 1;
   const size_t xbytes = frag ? (size_t)mt * 16 * K * 2 : (size_t)M * K * 2;
   DIHIP_REQUIRE(ws && ws_bytes >= off + xbytes, DIHIP_MEMORY_ERROR, "fused gemm: workspace too small");
   *xnorm = reinterpret_cast<char*>(ws) + off;
   *ws_left = off;
   *x_layout = frag ? DIHIP_ACT_FRAG32 : DIHIP_ACT_ROWMAJOR;
-  return launch_rmsnorm_rows(s, h, gamma, eps, M, K, *xnorm, frag ? mt : 0);
+  return launch_rmsnorm_rows(s, h, gamma, eps, M, K, *xnorm, frag ? mt : 0, dtype);
 }
 
 int dihip_fused_norm_gemm(void* stream, int wbits, const float* h, const void* gamma, float eps, const void* w_packed,
                           const void* sz_packed, const void* bias, void* y, int M, int N, int K, int group_size,
                           int act, void* ws, size_t ws_bytes, void* sync, int dtype) {
-  DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "fused path is bf16 only");
+  DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16, DIHIP_PARAM_ERROR, "fused path: bf16 or f16 activations");
   DIHIP_REQUIRE(sync != nullptr, DIHIP_PARAM_ERROR, "fused path needs a sync buffer");
   if (M == 0) return DIHIP_SUCCESS;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1124,10 +1133,10 @@ int dihip_fused_norm_swiglu_ex(void* stream, int wbits, const float* h, const vo
                                const void* wg_packed, const void* szg_packed, const void* wu_packed,
                                const void* szu_packed, void* y, int M, int N, int K, int group_size, void* ws,
                                size_t ws_bytes, void* sync, int dtype, int y_layout) {
-  DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "fused path is bf16 only");
+  DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16, DIHIP_PARAM_ERROR, "fused path: bf16 or f16 activations");
   DIHIP_REQUIRE(y_layout == DIHIP_ACT_ROWMAJOR || y_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "fused swiglu: bad y_layout");
-  DIHIP_REQUIRE(y_layout == DIHIP_ACT_ROWMAJOR || (M > 4 && batch_kernel_eligible(wbits, M, N, K, group_size)), DIHIP_PARAM_ERROR,
-                "fused swiglu: FRAG32 output needs the small-batch kernel (4 < M <= 32, K a multiple of the k-tile)");
+  DIHIP_REQUIRE(y_layout == DIHIP_ACT_ROWMAJOR || (dtype == DIHIP_BF16 && M > 4 && batch_kernel_eligible(wbits, M, N, K, group_size)), DIHIP_PARAM_ERROR,
+                "fused swiglu: FRAG32 output needs the small-batch kernel (bf16, 4 < M <= 32, K a multiple of the k-tile)");
   DIHIP_REQUIRE(sync != nullptr, DIHIP_PARAM_ERROR, "fused path needs a sync buffer");
   if (M == 0) return DIHIP_SUCCESS;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1204,7 +1213,7 @@ int dihip_act_from_frag(void* stream, const void* x_frag, void* x_rowmajor, int 
 int dihip_fused_gemm_addto_ex(void* stream, int wbits, const void* x, const void* w_packed, const void* sz_packed,
                               const float* h_res, float* h_out, int M, int N, int K, int group_size, void* ws,
                               size_t ws_bytes, void* sync, int dtype, int x_layout) {
-  DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "fused path is bf16 only");
+  DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16, DIHIP_PARAM_ERROR, "fused path: bf16 or f16 activations");
   DIHIP_REQUIRE(x_layout == DIHIP_ACT_ROWMAJOR || x_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "fused addto: bad x_layout");
   // h_res may be NULL: then h_out = x . W (row-parallel TP ranks other than 0, gemm_op.cpp:133-137)
   DIHIP_REQUIRE(sync != nullptr && h_out, DIHIP_PARAM_ERROR, "fused addto: null pointer");
@@ -1235,7 +1244,7 @@ int dihip_fused_gemm_addto_norm(void* stream, int wbits, const void* x, const vo
                                 const float* h_res, float* h_out, int M, int N, int K, int group_size, void* ws,
                                 size_t ws_bytes, void* sync, int dtype, int x_layout, const void* gamma, float eps,
                                 void* xnorm, int xnorm_layout) {
-  DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "fused path is bf16 only");
+  DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16, DIHIP_PARAM_ERROR, "fused path: bf16 or f16 activations");
   DIHIP_REQUIRE(x_layout == DIHIP_ACT_ROWMAJOR || x_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "fused addto: bad x_layout");
   DIHIP_REQUIRE(xnorm_layout == DIHIP_ACT_ROWMAJOR || (xnorm_layout == DIHIP_ACT_FRAG32 && M <= 32 && N % 32 == 0),
                 DIHIP_PARAM_ERROR, "fused addto + norm: FRAG32 output needs M <= 32 and N %% 32 == 0");
@@ -1270,21 +1279,21 @@ int dihip_fused_gemm_addto_norm(void* stream, int wbits, const void* x, const vo
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int st = run_gemm(s, c);
   if (st || done) return st;
-  return launch_rmsnorm_rows(s, h_out, gamma, eps, M, N, xnorm, c.n_frag_mt);  // this plan has no slab reduction to ride on
+  return launch_rmsnorm_rows(s, h_out, gamma, eps, M, N, xnorm, c.n_frag_mt, dtype);  // this plan has no slab reduction to ride on
 }
 
 // LayerNormNoBeta of the f32 hidden rows into FT rows, on its own (the MoE layer feeds four consumers from it)
 int dihip_rmsnorm_rows(void* stream, void* xnorm, const float* h, const void* gamma, float eps, int M, int K, int dtype) {
   DIHIP_REQUIRE(M >= 0 && K > 0 && xnorm && h && gamma, DIHIP_PARAM_ERROR, "rmsnorm_rows: bad argument");
-  DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "rmsnorm_rows: bf16 rows only");
+  DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16, DIHIP_PARAM_ERROR, "rmsnorm_rows: 16-bit rows only");
   if (M == 0) return DIHIP_SUCCESS;
-  return launch_rmsnorm_rows(reinterpret_cast<hipStream_t>(stream), h, gamma, eps, M, K, xnorm, 0);
+  return launch_rmsnorm_rows(reinterpret_cast<hipStream_t>(stream), h, gamma, eps, M, K, xnorm, 0, dtype);
 }
 
 int dihip_prenorm_gemm(void* stream, int wbits, const void* xnorm, int x_layout, const void* w_packed, const void* sz_packed,
                        const void* bias, void* y, int M, int N, int K, int group_size, int act, void* ws, size_t ws_bytes,
                        void* sync, int dtype) {
-  DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "fused path is bf16 only");
+  DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16, DIHIP_PARAM_ERROR, "fused path: bf16 or f16 activations");
   DIHIP_REQUIRE(x_layout == DIHIP_ACT_ROWMAJOR || x_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "prenorm gemm: bad x_layout");
   DIHIP_REQUIRE(sync != nullptr && xnorm && y, DIHIP_PARAM_ERROR, "prenorm gemm: null pointer");
   GemmCall c{};
@@ -1314,7 +1323,7 @@ int dihip_prenorm_gemm(void* stream, int wbits, const void* xnorm, int x_layout,
 int dihip_prenorm_swiglu(void* stream, int wbits, const void* xnorm, int x_layout, const void* wg_packed,
                          const void* szg_packed, const void* wu_packed, const void* szu_packed, void* y, int M, int N, int K,
                          int group_size, void* ws, size_t ws_bytes, void* sync, int dtype, int y_layout) {
-  DIHIP_REQUIRE(dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "fused path is bf16 only");
+  DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16, DIHIP_PARAM_ERROR, "fused path: bf16 or f16 activations");
   DIHIP_REQUIRE(x_layout == DIHIP_ACT_ROWMAJOR || x_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "prenorm swiglu: bad x_layout");
   DIHIP_REQUIRE(y_layout == DIHIP_ACT_ROWMAJOR || y_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "prenorm swiglu: bad y_layout");
   DIHIP_REQUIRE(sync != nullptr && xnorm && y, DIHIP_PARAM_ERROR, "prenorm swiglu: null pointer");
@@ -1416,7 +1425,7 @@ int dihip_lm_head(void* stream, float* logits, const float* h, const void* gamma
   c.alpha = 1.f;
   c.sync = sync;
   c.ldx = K;
-  if (gamma != nullptr && M <= 4 && dtype == DIHIP_BF16) {
+  if (gamma != nullptr && M <= 4) {
     c.pro = PRO_RMSNORM;
     c.x = h;
     c.gamma = gamma;
@@ -1424,7 +1433,7 @@ int dihip_lm_head(void* stream, float* logits, const float* h, const void* gamma
     c.ws = ws;
     c.ws_bytes = ws_bytes;
   } else {
-    DIHIP_REQUIRE(gamma != nullptr && dtype == DIHIP_BF16, DIHIP_PARAM_ERROR, "lm_head: needs gamma, bf16");
+    DIHIP_REQUIRE(gamma != nullptr, DIHIP_PARAM_ERROR, "lm_head: needs gamma");
     void* xn;
     size_t left;
     int st = norm_to_ws(s, h, gamma, eps, M, K, dtype, ws, ws_bytes, 16, N, -1, false, &xn, &left, &c.x_layout);

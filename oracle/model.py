@@ -29,7 +29,7 @@ the prefill attention oracle.
 import numpy as np
 
 from . import attention, gemm_ref, glue, kv_codec, moe
-from .numerics import bf16_round
+from .numerics import bf16_round, ft_round as _ft_round
 
 
 class Rounding:
@@ -61,7 +61,7 @@ ROUNDINGS = {r.name: r for r in (
 
 class DecoderOracle:
     def __init__(self, layers, embed, final_norm, lm_head, n_heads, n_kv, head_dim, wbits, group, eps=1e-6,
-                 rope_theta=1000000.0, kv_mode="none", rounding="x86", cache_weights=False):
+                 rope_theta=1000000.0, kv_mode="none", rounding="x86", cache_weights=False, ft="bf16"):
         """layers: list of dicts with 'qkv', 'o', 'gate', 'up', 'down' = (q, scales, zeros) in the formats of
         gemm_ref.gemm_a16wx -- or a plain FT-valued float array [K, N] for an UNQUANTISED layer (op type Gemm: BASELINE
         configs[0], Qwen2-0.5B bf16 on the x86 path; wbits = 16) --, plus 'qkv_bias', 'ln1', 'ln2' (float arrays);
@@ -69,6 +69,7 @@ class DecoderOracle:
         self.layers, self.embed, self.final_norm, self.lm_head = layers, embed, final_norm, lm_head
         self.n, self.g, self.H = n_heads, n_kv, head_dim
         self.wbits, self.group, self.eps, self.kv_mode = wbits, group, eps, kv_mode
+        self.ft = ft                    # the activation type "FT" of the graph: bf16 (default) or f16
         self.inv_freq = glue.rope_inv_freq(head_dim, rope_theta)
         self.cache = None
         self.rounding = rounding
@@ -84,6 +85,10 @@ class DecoderOracle:
     @rounding.setter
     def rounding(self, r):
         self._rounding = r if isinstance(r, Rounding) else ROUNDINGS[r]
+
+    def _r(self, x, threads=1):
+        """round to FT (the 16-bit activation type of this model)"""
+        return bf16_round(x, threads=threads) if self.ft == "bf16" else _ft_round(x, self.ft)
 
     # -- pieces --------------------------------------------------------------------------------
     def dequantised(self, w):
@@ -115,17 +120,17 @@ class DecoderOracle:
 
     def _src(self, x):
         """What a matmul reads: bf16 under medium_bf16 / the A16Wx kernels, the f32 tensor itself otherwise."""
-        return bf16_round(x) if self.rounding.gemm_src_ft else np.asarray(x, np.float32)
+        return self._r(x) if self.rounding.gemm_src_ft else np.asarray(x, np.float32)
 
     def _qkv_ft(self):
-        return "bf16" if self.rounding.qkv_ft else "f32"
+        return self.ft if self.rounding.qkv_ft else "f32"
 
     def _attn_out(self, v):
-        return bf16_round(v) if self.rounding.attn_ft else np.asarray(v, np.float32)
+        return self._r(v) if self.rounding.attn_ft else np.asarray(v, np.float32)
 
     def _ft(self, v):
         """An operator output under the bf16 graph of the reference; f32 (no rounding) under x86 semantics."""
-        return bf16_round(v) if self.rounding.op_out_ft else v
+        return self._r(v) if self.rounding.op_out_ft else v
 
     def _residual(self, h, y):
         return self._ft(self._ft(h) + self._ft(y))
@@ -139,7 +144,7 @@ class DecoderOracle:
 
     def _qkv_heads(self, row, pos):
         n, g, H = self.n, self.g, self.H
-        rq = bf16_round if self.rounding.qkv_ft else (lambda t: t)
+        rq = self._r if self.rounding.qkv_ft else (lambda t: t)
         q = rq(glue.rope(row[: n * H].reshape(n, H), pos, self.inv_freq))
         k = rq(glue.rope(row[n * H:(n + g) * H].reshape(g, H), pos, self.inv_freq))
         v = row[(n + g) * H:].reshape(g, H)
@@ -217,7 +222,7 @@ class DecoderOracle:
         xn = self._src(glue.rmsnorm(h, lw["ln1"], self.eps))
         qkv = self.linear(xn, lw["qkv"], self._qkv_ft(), bias=lw["qkv_bias"], W=(W or {}).get("qkv"))
         pos = np.arange(L, dtype=np.int32)
-        rq = bf16_round if self.rounding.qkv_ft else (lambda t: t)
+        rq = self._r if self.rounding.qkv_ft else (lambda t: t)
         q = rq(glue.rope(qkv[:, : n * H].reshape(L, n, H), pos, self.inv_freq))
         k = rq(glue.rope(qkv[:, n * H:(n + g) * H].reshape(L, g, H), pos, self.inv_freq))
         v = qkv[:, (n + g) * H:].reshape(L, g, H)
@@ -327,7 +332,7 @@ def _layer_sequences(o, hs, lw, W, prompt_lens, want_kv=False):
     rows = np.concatenate(hs)
     xn = o._src(glue.rmsnorm(rows, lw["ln1"], o.eps))
     qkv = o.linear(xn, lw["qkv"], o._qkv_ft(), bias=lw["qkv_bias"], W=W.get("qkv"))
-    rq = bf16_round if o.rounding.qkv_ft else (lambda t: t)
+    rq = o._r if o.rounding.qkv_ft else (lambda t: t)
     alpha = 1.0 / np.sqrt(H)
     attn_rows, kvs, off = [], [], 0
     for b, h in enumerate(hs):

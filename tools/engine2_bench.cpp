@@ -43,12 +43,15 @@ constexpr int SPIN_MAX = 1 << 20;    // bounded polls (x s_sleep): ~ a second
 #ifndef CONS_SLEEP
 #define CONS_SLEEP 4                 // s_sleep argument of the consumers' poll of the landed counter (0: spin)
 #endif
+#ifndef NLOAD
+#define NLOAD 1                      // loader waves per CU (slot s belongs to loader s % NLOAD)
+#endif
 #ifndef USE_COUNTER
 #define USE_COUNTER 1                // 1: one arrival counter polled by one lane, then a single sweep; 0: tag-spinning sweeps only
 #endif
 
 struct Ctl {                         // LDS control block
-  unsigned landed;                   // slots 0 .. landed-1 of the stream are in the ring
+  unsigned landed[4];                // per loader: its slots 0 .. landed-1 (local index s / NLOAD) are in the ring
   unsigned freed[NSLOT];             // how often each ring slot has been released
   unsigned bar;                      // consumer barrier counter
   unsigned giveup;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(512) void engine(const Args a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int cu = blockIdx.x, ncu = gridDim.x;
-  const int NCONS = (int)(blockDim.x >> 6) - 1;  // consumer waves: 3 (the guide's geometry) or 7 (one per remaining wave slot)
+  const int NCONS = (int)(blockDim.x >> 6) - NLOAD;  // consumer waves: 3 (the guide's geometry) or 7 (one per remaining wave slot)
   if (threadIdx.x < (int)(sizeof(Ctl) / 4)) reinterpret_cast<unsigned*>(ctl)[threadIdx.x] = 0u;
   __syncthreads();
   unsigned long long* st = a.stamps ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
@@ -92,9 +95,10 @@ __global__ __launch_bounds__(512) void engine(const Args a) {
   const unsigned char* wa = a.w + (size_t)cu * a.a_slots * SLOT_BYTES;
   const unsigned char* wb = a.w + (size_t)ncu * a.a_slots * SLOT_BYTES + (size_t)cu * a.b_slots * SLOT_BYTES;
 
-  if (wave == 0) {
-    // ------------------------------------------------------------------------------------------------ loader
-    for (long s = 0; s < total; ++s) {
+  if (wave < NLOAD) {
+    // ------------------------------------------------------------------------------------------------ loader(s)
+    long mine = 0;  // local index of this loader's next slot
+    for (long s = wave; s < total; s += NLOAD, ++mine) {
       const int slot = (int)(s % NSLOT);
       if (s >= NSLOT) {  // wait until the ring slot has been released (s / NSLOT) times
         int spins = 0;
@@ -114,22 +118,22 @@ __global__ __launch_bounds__(512) void engine(const Args a) {
       // two fills stay in flight; everything older has landed
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_LAG) : "memory");
       constexpr int BEHIND = VM_LAG / 16;  // fills that may still be in flight
-      if (s >= BEHIND && lane == 0) __hip_atomic_store(&ctl->landed, (unsigned)(s - BEHIND + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (mine >= BEHIND && lane == 0) __hip_atomic_store(&ctl->landed[wave], (unsigned)(mine - BEHIND + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(&ctl->landed, (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_store(&ctl->landed[wave], (unsigned)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (st && lane == 0) st[6] = wclk();
     return;
   }
 
   // -------------------------------------------------------------------------------------------------- consumers
-  const int cw = wave - 1;
+  const int cw = wave - NLOAD;
   u32x4 acc = {0u, 0u, 0u, 0u};
   float f0 = (float)lane, f1 = f0 + 1.f, f2 = f0 + 2.f, f3 = f0 + 3.f;
   auto consume = [&](long s0, long s1) {
     for (long s = s0 + cw; s < s1; s += NCONS) {
       int spins = 0;
-      while (lds_load(&ctl->landed) <= (unsigned)s) {
+      while (lds_load(&ctl->landed[s % NLOAD]) <= (unsigned)(s / NLOAD)) {
         if (CONS_SLEEP) __builtin_amdgcn_s_sleep(CONS_SLEEP);
         if (++spins > SPIN_MAX * 8) {
           ctl->giveup = 1;
@@ -281,7 +285,7 @@ int main(int argc, char** argv) {
   unsigned arrived = 0;  // host mirror of the counter: every A (phase 0 or 1) adds ncu
   const size_t lds = NSLOT * SLOT_BYTES + 256 + (size_t)ncu * gpc * 4 + 64;
   CK(hipFuncSetAttribute((const void*)engine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  printf("VM_LAG %d CONS_SLEEP %d USE_COUNTER %d | ", VM_LAG, CONS_SLEEP, USE_COUNTER);
+  printf("NLOAD %d VM_LAG %d CONS_SLEEP %d USE_COUNTER %d | ", NLOAD, VM_LAG, CONS_SLEEP, USE_COUNTER);
   printf("%d CUs; per CU %ld + %ld slots of 16 KiB (%.1f + %.1f MB per layer), %d granules per CU (%.1f KB gathered per CU), LDS %zu B\n", ncu, a_slots,
          b_slots, ncu * a_slots * SLOT_BYTES / 1e6, ncu * b_slots * SLOT_BYTES / 1e6, gpc, ncu * gpc * 8 / 1e3, lds);
   hipEvent_t e0, e1;
@@ -321,13 +325,13 @@ int main(int argc, char** argv) {
     }
     unsigned g = 0;
     CK(hipMemcpy(&g, gave, 4, hipMemcpyDeviceToHost));
-    printf("1 loader + %d consumers, work %3d FMA per lane per KiB: two launches %6.2f us | one persistent launch %6.2f us | ratio %.3f | pure stream at 6.5 TB/s %.2f us | gave up %u\n",
-           threads / 64 - 1, work, us[0], us[1], us[1] / us[0], per_layer / 6.5e12 * 1e6, g);
+    printf("%d loader(s) + %d consumers, work %3d FMA per lane per KiB: two launches %6.2f us | one persistent launch %6.2f us | ratio %.3f | pure stream at 6.5 TB/s %.2f us | gave up %u\n",
+           NLOAD, threads / 64 - NLOAD, work, us[0], us[1], us[1] / us[0], per_layer / 6.5e12 * 1e6, g);
   }
   // timeline of ONE fused launch: per CU stamps relative to the earliest start
   for (int cfg = 0; cfg < 3; ++cfg) {
     const int tl_threads = cfg == 0 ? 256 : 512, tl_work = cfg == 2 ? 40 : 0;
-    printf("timeline of one persistent launch, 1 loader + %d consumers, work %d:\n", tl_threads / 64 - 1, tl_work);
+    printf("timeline of one persistent launch, %d loader(s) + %d consumers, work %d:\n", NLOAD, tl_threads / 64 - NLOAD, tl_work);
     CK(hipMemset(stamps, 0, (size_t)ncu * 64));
     arrived += (unsigned)ncu;
     Args a{w + per_layer * (cfg + 1), a_slots, b_slots, gran, gpc, epoch++, out, gave, arrivals, arrived, 0, tl_work, stamps};
