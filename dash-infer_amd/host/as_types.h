@@ -161,7 +161,7 @@ class DeviceContext {
 // fastest (DIHIP_ACT_FRAG32, include/dashinfer_hip.h section 1) -- the decision decoder.DecodeSession takes with
 // ops.prefers_frag().  Backend-private graph annotation: nothing of it crosses the operator interface.
 struct ActLayoutPref {
-  int wbits = 0, n = 0, k = 0, group = -1, dual = 0;
+  int wbits = 0, n = 0, k = 0, group = -1, dual = 0, bf16 = 1;
 };
 
 class HIPContext : public DeviceContext {

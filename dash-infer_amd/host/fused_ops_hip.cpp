@@ -95,10 +95,13 @@ struct PackedLowp {
     return FromDihip(dihip_gemm_lowp_pack(s, wbits, wq->GetDataPtr(), scales->GetDataPtr(), zeros->GetDataPtr(), n, k, group,
                                           DihipDtype(ft), w->GetDataPtr(), sz->GetDataPtr()));
   }
-  ActLayoutPref pref(int dual) const { return ActLayoutPref{wbits, n, k, group, dual}; }
-  bool prefers_frag(int m, int dual) const { return dihip_gemm_lowp_prefers_frag(wbits, m, n, k, group, dual) != 0; }
+  ActLayoutPref pref(int dual) const { return ActLayoutPref{wbits, n, k, group, dual, ft == BFLOAT16 ? 1 : 0}; }
+  // (the small-batch kernels, and with them the FRAG32 layout, are bf16: f16 activations stay row-major)
+  bool prefers_frag(int m, int dual) const { return ft == BFLOAT16 && dihip_gemm_lowp_prefers_frag(wbits, m, n, k, group, dual) != 0; }
 };
-bool pref_frag(const ActLayoutPref* p, int m) { return p && dihip_gemm_lowp_prefers_frag(p->wbits, m, p->n, p->k, p->group, p->dual) != 0; }
+bool pref_frag(const ActLayoutPref* p, int m) {
+  return p && p->bf16 && dihip_gemm_lowp_prefers_frag(p->wbits, m, p->n, p->k, p->group, p->dual) != 0;
+}
 
 std::unique_ptr<AsTensor> zeroed(const std::string& name, size_t bytes, hipStream_t s) {
   auto t = std::make_unique<AsTensor>(name, DeviceType::HIP, INT8, Shape{(int64_t)bytes});

@@ -216,6 +216,8 @@ ACT_ROWMAJOR, ACT_FRAG32 = 0, 1
 def prefers_frag(pw, M, dual=False):
     """True when a [M, pw.N, pw.K] call runs on the small-batch kernel, which reads / writes the FRAG32
     activation layout (include/dashinfer_hip.h) faster than row-major."""
+    if pw.dtype != torch.bfloat16:   # the small-batch kernels (and with them the FRAG32 layout) are bf16; f16 takes the general kernel
+        return False
     return bool(lib().dihip_gemm_lowp_prefers_frag(pw.wbits, int(M), pw.N, pw.K, pw.group, int(dual)))
 
 

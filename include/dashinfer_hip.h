@@ -106,7 +106,7 @@ int dihip_gemm_a16w4(void* stream, const void* x, const void* w_packed, const vo
 
 /* Fused decode-step variants (the glue the reference runs as separate
  * LayerNormNoBeta / Binary / Unary ops, python/pyhie/allspark/model/qwen_v15.py:210-381).
- * hidden stream `h` is f32 [M, K]; all use bf16 weights metadata; M <= 32.
+ * hidden stream `h` is f32 [M, K]; FT = bf16 or f16 (dtype; the FRAG32 layouts and the small-batch kernels behind them are bf16).
  *   norm_gemm   : y = act(rmsnorm(h; gamma, eps) . W + bias)                 y: FT [M,N]
  *   norm_swiglu : y = FT(silu(rmsnorm(h).Wg)) * FT(rmsnorm(h).Wu)            y: FT [M,N]
  *   gemm_addto  : h_out[M,N] (f32) = h_res + x . W   (f32, no rounding)           x: FT [M,K]   */

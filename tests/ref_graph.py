@@ -44,7 +44,7 @@ def qwen2_graph(n_layers, wbits, group, eps, n_heads, n_kv, rope_theta, tp_allre
     return g
 
 
-def register_weights(m, model):
+def register_weights(m, model, ft="bf16"):
     """The product model's unpacked quantised weights (decoder.build_random_model(keep_fp=True)) under the reference's names."""
     fp = model.fp
     qdt = "u8" if model.quant.wbits == 4 else "i8"
@@ -52,22 +52,22 @@ def register_weights(m, model):
     def lowp(name, key, li):
         q, s, z = fp[li][key]
         m.set_weight(name + ".weight", q, qdt)
-        m.set_weight(name + ".weight.scales", s, "bf16")
-        m.set_weight(name + ".weight.zeros", z, "bf16")
+        m.set_weight(name + ".weight.scales", s, ft)
+        m.set_weight(name + ".weight.zeros", z, ft)
 
-    m.set_weight("embedding.word_embeddings", fp["embed"], "bf16")
+    m.set_weight("embedding.word_embeddings", fp["embed"], ft)
     for li in range(len(model.layers)):
         p = f"decoder.layer.{li}."
-        m.set_weight(p + "attention.layernorm.gamma", fp[li]["ln1"], "bf16")
-        m.set_weight(p + "ffn.layernorm.gamma", fp[li]["ln2"], "bf16")
+        m.set_weight(p + "attention.layernorm.gamma", fp[li]["ln1"], ft)
+        m.set_weight(p + "ffn.layernorm.gamma", fp[li]["ln2"], ft)
         lowp(p + "attention.self", "qkv", li)
-        m.set_weight(p + "attention.self.bias", fp[li]["qkv_bias"], "bf16")
+        m.set_weight(p + "attention.self.bias", fp[li]["qkv_bias"], ft)
         lowp(p + "attention.output.dense", "o", li)
         lowp(p + "ffn.intermediate.dense", "gate", li)
         lowp(p + "ffn.linear.dense", "up", li)
         lowp(p + "ffn.output.dense", "down", li)
-    m.set_weight("final.layernorm.gamma", fp["final_norm"], "bf16")
-    m.set_weight("lm_head.weight", fp["lm_head"], "bf16")
+    m.set_weight("final.layernorm.gamma", fp["final_norm"], ft)
+    m.set_weight("lm_head.weight", fp["lm_head"], ft)
 
 
 def add_graph(m, graph):

@@ -25,16 +25,17 @@ KV = {"none": 0, "i8": 1, "u4": 2}
 class Host:
     """hostapi.Model + the reference graph + a span pool, on its own stream (a captured step needs a non-NULL stream)."""
 
-    def __init__(self, model, batch, max_len, span, kv_mode, fuse=True):
+    def __init__(self, model, batch, max_len, span, kv_mode, fuse=True, ft="bf16"):
         from dash_infer_amd import hostapi, ops
         cfg = model.cfg
         self.cfg, self.nl, self.spr = cfg, len(model.layers), (max_len + span - 1) // span
         self.stream = torch.cuda.Stream()
         torch.cuda.synchronize()
-        self.pool = ops.SpanPool(2 * batch * self.nl * self.spr + 4, cfg.n_kv, span, cfg.head_dim, kv_mode, torch.bfloat16)
+        self.pool = ops.SpanPool(2 * batch * self.nl * self.spr + 4, cfg.n_kv, span, cfg.head_dim, kv_mode,
+                                 torch.float16 if ft == "f16" else torch.bfloat16)
         with torch.cuda.stream(self.stream):
             self.m = hostapi.Model(ops.cur_stream(), cfg.n_heads, cfg.n_kv, cfg.head_dim, span, KV[kv_mode], max_batch=batch, max_len=max_len)
-            ref_graph.register_weights(self.m, model)
+            ref_graph.register_weights(self.m, model, ft)
             self.graph = ref_graph.qwen2_graph(self.nl, model.quant.wbits, model.quant.group, cfg.eps, cfg.n_heads, cfg.n_kv, cfg.rope_theta)
             ref_graph.add_graph(self.m, self.graph)
             self.report = self.m.graph_build(fuse=fuse)
@@ -98,6 +99,34 @@ def test_fused_operator_list_is_bit_identical_to_decode_session(pkg, shape, wbit
         ids = h.steps(1, graph=True)          # step 0 captures, the others replay
         assert ids == want[t][1], f"step {t}: ids differ"
         assert torch.equal(h.logits(), want[t][0]), f"step {t}: logits are not bit-identical to DecodeSession"
+    h.close()
+
+
+def test_fused_operator_list_f16_is_bit_identical_to_decode_session(pkg):
+    """the same with f16 activations (scales / zeros / embedding / lm_head in f16): the fused operators carry the weights' FT"""
+    from dash_infer_amd import decoder
+    cfg = decoder.ModelConfig("runner-test-f16", **SMALL)
+    model = decoder.build_random_model(cfg, decoder.QuantSpec(4, 128), seed=77, keep_fp=True, dtype=torch.float16)
+    span, max_len, steps, batch = 16, 64, 4, 2
+    rng = np.random.default_rng(2)
+    prompts = [[int(t) for t in rng.integers(0, cfg.vocab, n)] for n in (9, 20)]
+    sess = decoder.DecodeSession(model, batch, max_len=max_len, span_len=span, kv_mode="none")
+    lo0 = sess.prefill(prompts).clone()
+    ids0 = sess.ids.cpu().tolist()
+    want = []
+    for _ in range(steps):
+        sess.step()
+        torch.cuda.synchronize()
+        want.append((sess.logits.clone(), sess.ids.cpu().tolist()))
+    h = Host(model, batch, max_len, span, "none", ft="f16")
+    assert h.report["fused"], h.report["why"]
+    for b, pr in enumerate(prompts):
+        k, v = h.spans()
+        assert h.start(pr, k, v) == ids0[b]
+        assert torch.equal(h.logits()[0], lo0[b])
+    for t in range(steps):
+        assert h.steps(1, graph=True) == want[t][1]
+        assert torch.equal(h.logits(), want[t][0]), f"step {t}"
     h.close()
 
 
