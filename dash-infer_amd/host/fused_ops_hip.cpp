@@ -541,6 +541,46 @@ class DihipRopeSpanAttnOp : public SpanAttnOpHIP {
 };
 REGISTER_OP(DihipRopeSpanAttn, HIP, DihipRopeSpanAttnOp)
 
+// ===================================================================================================== DihipFinalNorm
+// LayerNormNoBeta of the f32 hidden rows into FT rows (dihip_rmsnorm_rows): the seam between the fused layers and a tail that stays
+// on the reference's own operators (tensor-parallel lm_head: GetLastLine -> Gemm(splitk) -> AllReduce -> GenerateOp).
+class DihipFinalNormOp : public AsOperator {
+ public:
+  explicit DihipFinalNormOp(const std::string& t = "") : AsOperator(t) {}
+  AsStatus Init(const OperatorProto& op_proto, const DeviceContext& ctx, const TensorMap& weights_map, TensorMap* tensor_map) override {
+    AS_CHECK_STATUS(AsOperator::Init(op_proto, ctx, weights_map, tensor_map));
+    if (weights_.size() != 1) return AsStatus::ALLSPARK_PARAM_ERROR;
+    const char* e = attr_ptr(op_proto, "eps");
+    if (!e) return AsStatus::ALLSPARK_PARAM_ERROR;
+    eps_ = *(const float*)e;
+    ft_ = weights_[0]->GetDataType();
+    if (ft_ != BFLOAT16 && ft_ != FLOAT16) return AsStatus::ALLSPARK_PARAM_ERROR;
+    hidden_ = (int)weights_[0]->GetShape()[0];
+    tensor_map_->at(out_names_[0])->SetDataType(ft_);
+    return AsStatus::ALLSPARK_SUCCESS;
+  }
+  AsStatus Reshape(RuntimeContext*) override {
+    AsTensor* h = tensor_map_->at(in_names_[0]).get();
+    Shape s = h->GetShape();
+    if (s.empty() || (int)s.back() != hidden_ || h->GetDataType() != FLOAT32) return AsStatus::ALLSPARK_PARAM_ERROR;
+    rows_ = (int)(h->Count() / hidden_);
+    AsTensor* y = tensor_map_->at(out_names_[0]).get();
+    y->SetDataType(ft_);
+    return y->SetShape(std::move(s));
+  }
+  AsStatus Forward(RuntimeContext*) override {
+    return FromDihip(dihip_rmsnorm_rows(stream_of(ctx_), tensor_map_->at(out_names_[0])->GetDataPtr(),
+                                        (const float*)tensor_map_->at(in_names_[0])->GetDataPtr(), weights_[0]->GetDataPtr(), eps_, rows_,
+                                        hidden_, DihipDtype(ft_)));
+  }
+
+ private:
+  int hidden_ = 0, rows_ = 0;
+  float eps_ = 1e-6f;
+  DataType ft_ = BFLOAT16;
+};
+REGISTER_OP(DihipFinalNorm, HIP, DihipFinalNormOp)
+
 // ======================================================================================================== DihipLMHead
 // logits (f32) = RMSNorm(h_last; gamma, eps) . W_lm: final LayerNormNoBeta + GetLastLine + the lm_head Gemm
 // (model_base.py:690-703; qwen_v15.py:383-388).  weights [gamma, lm_head.weight FT [hidden, vocab]]; one rank.

@@ -207,14 +207,37 @@ std::vector<OperatorProto> FuseDecoderGraph(const std::vector<OperatorProto>& gr
   // tail: LayerNormNoBeta(h) , GetLastLine , Gemm(lm_head.weight) , GenerateOp
   const OperatorProto *lnf = m.peek(), *gll, *lm, *gen;
   ++m.i;
-  if (!m.typed(gll, "GetLastLine", lnf->outputs[0])) return refuse("");
-  if (!m.typed(lm, "Gemm", gll->outputs[0])) return refuse("");
-  if (lm->weights.size() != 1 || attr_bool(*lm, "splitk") || attr_bool(*lm, "with_bias") || attr_int(*lm, "activation", 0) != 0 ||
-      attr_float(*lm, "alpha", 1.0f) != 1.0f || attr_int(*lm, "binary_type", 0) != 0 || lm->inputs.size() != 1)
-    return refuse("an lm_head Gemm the fused head does not implement (" + lm->op_name + ")");
-  if (ctx.GetNranks() > 1) return refuse("tensor-parallel lm_head: the fused head is single-rank");
-  if (!m.typed(gen, "GenerateOp", lm->outputs[0])) return refuse("");
-  if (m.i != graph.size()) return refuse(m.fail("operators after GenerateOp") ? "" : "");
+  const size_t tail_at = m.i;
+  auto simple_tail = [&]() -> bool {
+    if (!m.typed(gll, "GetLastLine", lnf->outputs[0])) return false;
+    if (!m.typed(lm, "Gemm", gll->outputs[0])) return false;
+    if (lm->weights.size() != 1 || attr_bool(*lm, "splitk") || attr_bool(*lm, "with_bias") || attr_int(*lm, "activation", 0) != 0 ||
+        attr_float(*lm, "alpha", 1.0f) != 1.0f || attr_int(*lm, "binary_type", 0) != 0 || lm->inputs.size() != 1)
+      return m.fail("an lm_head Gemm the fused head does not implement");
+    if (ctx.GetNranks() > 1) return m.fail("tensor-parallel lm_head: the fused head is single-rank");
+    if (!m.typed(gen, "GenerateOp", lm->outputs[0])) return false;
+    if (m.i != graph.size()) return m.fail("operators after GenerateOp");
+    return true;
+  };
+  if (!simple_tail()) {
+    // the tail as it is, behind a DihipFinalNorm: every remaining operator must be one the HIP backend registers and that reads FT rows
+    const std::string why_simple = m.why;
+    for (size_t j = tail_at; j < graph.size(); ++j) {
+      const std::string& t = graph[j].op_type;
+      if (t != "GetLastLine" && t != "Gemm" && t != "AllReduce" && t != "AllGather" && t != "GenerateOp")
+        return refuse(why_simple + ", and the tail holds " + t + " (" + graph[j].op_name + "), which cannot stay behind DihipFinalNorm");
+    }
+    if (tail_at >= graph.size() || graph.back().op_type != "GenerateOp") return refuse(why_simple + ", and the list does not end in GenerateOp");
+    OperatorProto f_norm = make("DihipFinalNorm", lnf->op_name, {h}, lnf->outputs, lnf->weights);
+    copy_attr(f_norm, *lnf, "eps");
+    out.push_back(std::move(f_norm));
+    for (size_t j = tail_at; j < graph.size(); ++j) out.push_back(graph[j]);
+    rep.fused = true;
+    rep.device_resident = false;
+    rep.why = "layers fused, the tail runs on the reference's own operators (" + why_simple + ")";
+    rep.ops_after = (int)out.size();
+    return out;
+  }
   OperatorProto f_lm = make("DihipLMHead", lm->op_name, {h}, lm->outputs, {lnf->weights[0], lm->weights[0]});
   copy_attr(f_lm, *lnf, "eps");
   out.push_back(std::move(f_lm));
@@ -222,6 +245,7 @@ std::vector<OperatorProto> FuseDecoderGraph(const std::vector<OperatorProto>& gr
   f_gen.attr = gen->attr;
   out.push_back(std::move(f_gen));
   rep.fused = true;
+  rep.device_resident = true;
   rep.ops_after = (int)out.size();
   return out;
 }

@@ -11,6 +11,11 @@ namespace allspark {
 
 struct FusionReport {
   bool fused = false;   // false: the list is returned unchanged, `why` names the first operator that did not fit
+  // true: the tail is fused as well (DihipLMHead + DihipGreedy), so a decoder step keeps its whole state on the device (sequence
+  // lengths advanced by the sampling launch) and may be captured as a hipGraph.  false with fused == true: the layers are fused
+  // but the reference's own tail operators run behind a DihipFinalNorm (tensor-parallel lm_head: Gemm with splitk + AllReduce);
+  // lengths are then staged from the host per step like the unfused operators do.
+  bool device_resident = false;
   int layers = 0;
   int ops_before = 0, ops_after = 0;
   std::string why;
@@ -23,7 +28,9 @@ struct FusionReport {
 //   LayerNormNoBeta(h') , GemmA16Wx(.; SILU) , GemmA16Wx(.) , Binary MUL -> DihipNormSwiGLU(h' [, xnorm])
 //   GemmA16Wx(.) , [AllReduce] , Binary ADD(., h')                   -> DihipGemmAddTo(+ gamma of the next layer's first norm) [, AllReduce]
 // head / tail: EmbeddingT5 -> DihipEmbedding ;  LayerNormNoBeta , GetLastLine , Gemm(lm_head) -> DihipLMHead ; GenerateOp -> DihipGreedy
-// Anything else (another rotary variant, a bias on o / down, alpha != 1, a split-K lm_head, ...) leaves the WHOLE list unfused.
+// any other tail made of GetLastLine / Gemm / AllReduce / GenerateOp (the tensor-parallel lm_head of model_base.py:690-703: Gemm with
+// splitk + AllReduce) keeps those operators behind  LayerNormNoBeta -> DihipFinalNorm  (f32 hidden rows -> FT rows).
+// Anything else (another rotary variant, a bias on o / down, alpha != 1, ...) leaves the WHOLE list unfused.
 std::vector<OperatorProto> FuseDecoderGraph(const std::vector<OperatorProto>& graph, const DeviceContext& ctx, FusionReport* report);
 
 }  // namespace allspark

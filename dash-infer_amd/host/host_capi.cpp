@@ -92,7 +92,7 @@ const char* dihost_registered_ops(void) {
   for (const char* t : {"GemmA16W8", "GemmA16W4", "DecOptMHA", "DecOptMQA", "AllReduce", "AllGather", "MOEA16W8", "CalcExpert", "Gemm", "Rotary",
                         "LayerNormNoBeta", "Binary", "Unary", "UnaryGLU", "EmbeddingT5", "GetLastLine", "GenerateOp", "TransMask", "RichEmbedding",
                         "PreProcessId", "UpdateId", "PostProcessId", "DihipEmbedding", "DihipNormGemm", "DihipRopeSpanAttn", "DihipGemmAddTo",
-                        "DihipNormSwiGLU", "DihipLMHead", "DihipGreedy", "DihipSample"}) {
+                        "DihipNormSwiGLU", "DihipLMHead", "DihipGreedy", "DihipFinalNorm"}) {
     try {
       (void)OpFactory::getInstance().GetOperator({t, DeviceType::HIP});
       s += (s.empty() ? "" : ",");
@@ -284,8 +284,8 @@ int dihost_graph_build(dihost_model_t m, int fuse) {
 const char* dihost_graph_report(dihost_model_t m) {
   if (!m->runner) return "";
   const FusionReport& r = m->runner->fusion();
-  std::string t = "fused=" + std::to_string(r.fused ? 1 : 0) + ";layers=" + std::to_string(r.layers) + ";ops=" + std::to_string(r.ops_before) +
-                  "->" + std::to_string(r.ops_after) + ";why=" + r.why + ";types=";
+  std::string t = "fused=" + std::to_string(r.fused ? 1 : 0) + ";device_resident=" + std::to_string(r.device_resident ? 1 : 0) + ";layers=" +
+                  std::to_string(r.layers) + ";ops=" + std::to_string(r.ops_before) + "->" + std::to_string(r.ops_after) + ";why=" + r.why + ";types=";
   for (size_t i = 0; i < m->runner->protos().size(); ++i) t += (i ? "," : "") + m->runner->protos()[i].op_type;
   m->text = t;
   return m->text.c_str();
@@ -294,8 +294,8 @@ const char* dihost_graph_report(dihost_model_t m) {
 const char* dihost_graph_fuse_dry(dihost_model_t m) {
   FusionReport r;
   const std::vector<OperatorProto> out = FuseDecoderGraph(m->graph, m->ctx, &r);
-  std::string t = "fused=" + std::to_string(r.fused ? 1 : 0) + ";layers=" + std::to_string(r.layers) + ";ops=" + std::to_string(r.ops_before) +
-                  "->" + std::to_string(r.ops_after) + ";why=" + r.why + ";types=";
+  std::string t = "fused=" + std::to_string(r.fused ? 1 : 0) + ";device_resident=" + std::to_string(r.device_resident ? 1 : 0) + ";layers=" +
+                  std::to_string(r.layers) + ";ops=" + std::to_string(r.ops_before) + "->" + std::to_string(r.ops_after) + ";why=" + r.why + ";types=";
   for (size_t i = 0; i < out.size(); ++i) t += (i ? "," : "") + out[i].op_type;
   t += ";wiring=";
   for (size_t i = 0; i < out.size(); ++i) {

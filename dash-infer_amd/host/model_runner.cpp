@@ -42,7 +42,7 @@ AsStatus HipModelRunner::Build(const std::vector<OperatorProto>& graph, bool fus
     fusion_.ops_before = fusion_.ops_after = (int)graph.size();
     fusion_.why = "fusion not requested";
   }
-  fused_ = fusion_.fused;
+  fused_ = fusion_.fused && fusion_.device_resident;  // device-resident step state (and graph replay) needs the fused tail
   ids_in_name_ = protos_.front().inputs[0];
   ids_out_name_ = protos_.back().outputs[0];
   const int64_t mb = std::max(1, ctx_->GetModelMaxBatch());

@@ -150,6 +150,7 @@ class Model:
             k, _, v = item.partition("=")
             out[k] = v
         out["fused"] = out.get("fused") == "1"
+        out["device_resident"] = out.get("device_resident") == "1"
         out["layers"] = int(out.get("layers", 0))
         out["types"] = [t for t in out.get("types", "").split(",") if t]
         return out

@@ -4,7 +4,7 @@ plain tuples (op_type, op_name, inputs, outputs, weights, attrs), for the host-l
 Python: the CPU tests of the fusion pass use it without a GPU."""
 
 
-def qwen2_graph(n_layers, wbits, group, eps, n_heads, n_kv, rope_theta, tp_allreduce=False):
+def qwen2_graph(n_layers, wbits, group, eps, n_heads, n_kv, rope_theta, tp_allreduce=False, tp_lm_head=False):
     gemm = "GemmA16W4" if wbits == 4 else "GemmA16W8"
     gattr = f"GroupSize=i:{group}" if group and group > 0 else ""
 
@@ -39,7 +39,11 @@ def qwen2_graph(n_layers, wbits, group, eps, n_heads, n_kv, rope_theta, tp_allre
         prev = p + "final_add.out"
     g.append(("LayerNormNoBeta", "final.layernorm", [prev], ["last_hidden_state"], ["final.layernorm.gamma"], f"eps=f:{eps}"))
     g.append(("GetLastLine", "get_last_line", ["last_hidden_state"], ["get_last_line.out"], [], ""))
-    g.append(("Gemm", "lm_head", ["get_last_line.out"], ["logits"], ["lm_head.weight"], "with_bias=b:0"))
+    if tp_lm_head:   # model_base.py:690-703: K-split lm_head (Gemm with splitk, lm_head.weight HSPLIT) + AllReduce of the logits
+        g.append(("Gemm", "lm_head", ["get_last_line.out"], ["lm_head.out"], ["lm_head.weight"], "with_bias=b:0;splitk=b:1"))
+        g.append(("AllReduce", "all_reduce_lmhead", ["lm_head.out"], ["logits"], [], ""))
+    else:
+        g.append(("Gemm", "lm_head", ["get_last_line.out"], ["logits"], ["lm_head.weight"], "with_bias=b:0"))
     g.append(("GenerateOp", "generate", ["logits"], ["generated_ids"], [], "top_k=i:1"))
     return g
 

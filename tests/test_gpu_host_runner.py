@@ -259,3 +259,53 @@ def test_prefill_over_a_cached_prefix_matches_a_prefill_from_scratch(pkg, fuse):
     ids = h.steps(3, graph=fuse)
     assert ids[1] == ids[2]
     h.close()
+
+
+def test_layers_fused_behind_the_reference_tail(pkg):
+    """A list whose tail the fused head does not cover (the tensor-parallel form: Gemm with splitk + AllReduce, here on one rank
+    where the AllReduce copies) still gets its LAYERS fused, with the reference's own tail operators behind a DihipFinalNorm; the
+    step state is then staged from the host per step (no graph replay).  Logits (FT, from the Gemm operator) agree with the fully
+    fused list to the FT rounding of the logits."""
+    from dash_infer_amd import decoder, hostapi, ops
+    cfg = decoder.ModelConfig("runner-test", **SMALL)
+    model = decoder.build_random_model(cfg, decoder.QuantSpec(4, 128), seed=31, keep_fp=True)
+    span, max_len, B = 16, 64, 2
+    rng = np.random.default_rng(8)
+    prompts = [[int(t) for t in rng.integers(0, cfg.vocab, n)] for n in (13, 6)]
+    full = Host(model, B, max_len, span, "none")
+    want = []
+    for pr in prompts:
+        k, v = full.spans()
+        full.start(pr, k, v)
+    for _ in range(3):
+        ids = full.steps(1, graph=True)
+        want.append((full.logits().float().clone(), ids))
+    full.close()
+
+    h = Host.__new__(Host)
+    h.cfg, h.nl, h.spr = cfg, len(model.layers), (max_len + span - 1) // span
+    h.stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    h.pool = ops.SpanPool(2 * B * h.nl * h.spr + 4, cfg.n_kv, span, cfg.head_dim, "none", torch.bfloat16)
+    with torch.cuda.stream(h.stream):
+        h.m = hostapi.Model(ops.cur_stream(), cfg.n_heads, cfg.n_kv, cfg.head_dim, span, 0, max_batch=B, max_len=max_len)
+        ref_graph.register_weights(h.m, model)
+        ref_graph.add_graph(h.m, ref_graph.qwen2_graph(h.nl, 4, 128, cfg.eps, cfg.n_heads, cfg.n_kv, cfg.rope_theta, tp_lm_head=True))
+        h.report = h.m.graph_build(fuse=True)
+    h.stream.synchronize()
+    assert h.report["fused"] and not h.report["device_resident"]
+    assert "DihipFinalNorm" in h.report["types"] and "DihipRopeSpanAttn" in h.report["types"] and "LayerNormNoBeta" not in h.report["types"]
+    h.report["fused"] = False      # (Host.logits(): the tail's Gemm writes FT logits)
+    for pr in prompts:
+        k, v = h.spans()
+        h.start(pr, k, v)
+    with pytest.raises(hostapi.HostError):
+        h.steps(1, graph=True)      # no device-resident state: replay is refused
+    scale = max(1.0, float(want[0][0].abs().max()))
+    for t in range(3):
+        ids = h.steps(1, graph=False)
+        lo = h.logits().float()
+        assert float((lo - want[t][0]).abs().max()) <= 2 ** -7 * scale, f"step {t}"
+        if ids != want[t][1]:
+            break                   # a near-tie decided differently by the FT logits: later steps see other inputs
+    h.close()

@@ -19,7 +19,7 @@ def test_two_layer_graph_is_fused_five_operators_per_layer(model):
     g = ref_graph.qwen2_graph(2, 4, 128, 1e-6, 4, 2, 1000000.0)
     ref_graph.add_graph(model, g)
     r = model.graph_fuse_dry()
-    assert r["fused"] and r["layers"] == 2, r["why"]
+    assert r["fused"] and r["device_resident"] and r["layers"] == 2, r["why"]
     per_layer = ["DihipNormGemm", "DihipRopeSpanAttn", "DihipGemmAddTo", "DihipNormSwiGLU", "DihipGemmAddTo"]
     assert r["types"] == ["DihipEmbedding"] + per_layer * 2 + ["DihipLMHead", "DihipGreedy"]
     assert r["ops"] == f"{len(g)}->13"
@@ -43,15 +43,21 @@ def test_two_layer_graph_is_fused_five_operators_per_layer(model):
 def test_allreduce_stays_behind_the_row_parallel_projections(pkg):
     from dash_infer_amd import hostapi
     m = hostapi.Model(None, 4, 2, 128, 16, rank=1, nranks=2)
-    ref_graph.add_graph(m, ref_graph.qwen2_graph(1, 8, -1, 1e-6, 4, 2, 1e6, tp_allreduce=True))
+    ref_graph.add_graph(m, ref_graph.qwen2_graph(1, 8, -1, 1e-6, 4, 2, 1e6, tp_allreduce=True, tp_lm_head=True))
     r = m.graph_fuse_dry()
-    # the tensor-parallel lm_head is outside the fused head: the whole list stays as it is
-    assert not r["fused"] and "single-rank" in r["why"]
+    # tensor parallel: the layers are fused (AllReduce kept behind the row-parallel projections), the K-split lm_head + its
+    # AllReduce stay the reference's own operators behind a DihipFinalNorm, and the step state is staged from the host
+    assert r["fused"] and not r["device_resident"], r["why"]
+    assert r["types"] == ["DihipEmbedding", "DihipNormGemm", "DihipRopeSpanAttn", "DihipGemmAddTo", "AllReduce", "DihipNormSwiGLU",
+                          "DihipGemmAddTo", "AllReduce", "DihipFinalNorm", "GetLastLine", "Gemm", "AllReduce", "GenerateOp"]
+    w = r["wiring"].split("|")
+    assert w[8] == "DihipFinalNorm(decoder.layer.0.final_add.out)->(last_hidden_state)[final.layernorm.gamma]"
+    assert "single-rank" in r["why"] or "splitk" in r["why"] or "lm_head" in r["why"]
     m.close()
     m = hostapi.Model(None, 4, 2, 128, 16)   # the same list on one rank: the AllReduce operators are kept (they copy)
     ref_graph.add_graph(m, ref_graph.qwen2_graph(1, 8, -1, 1e-6, 4, 2, 1e6, tp_allreduce=True))
     r = m.graph_fuse_dry()
-    assert r["fused"], r["why"]
+    assert r["fused"] and r["device_resident"], r["why"]
     assert r["types"] == ["DihipEmbedding", "DihipNormGemm", "DihipRopeSpanAttn", "DihipGemmAddTo", "AllReduce", "DihipNormSwiGLU",
                           "DihipGemmAddTo", "AllReduce", "DihipLMHead", "DihipGreedy"]
     w = r["wiring"].split("|")
@@ -65,7 +71,6 @@ def test_allreduce_stays_behind_the_row_parallel_projections(pkg):
     (lambda g: g.__setitem__(8, (g[8][0], g[8][1], g[8][2], g[8][3], g[8][4], "GroupSize=i:128;alpha=f:1.0")), "unexpected activation"),
     (lambda g: g.__setitem__(6, ("Binary", g[6][1], [g[6][2][0], "something.else"], g[6][3], [], g[6][5])), "does not combine"),
     (lambda g: g.insert(4, ("Unary", "extra", ["decoder.layer.0.rotary.out"], ["decoder.layer.0.rotary.out"], [], "unary_type=i:4")), "DecOptMQA"),
-    (lambda g: g.__setitem__(len(g) - 2, ("Gemm", "lm_head", ["get_last_line.out"], ["logits"], ["lm_head.weight"], "splitk=b:1")), "lm_head"),
     (lambda g: g.pop(0), "EmbeddingT5"),
 ])
 def test_a_list_that_does_not_fit_is_left_unchanged(model, mutate, needle):
@@ -76,3 +81,20 @@ def test_a_list_that_does_not_fit_is_left_unchanged(model, mutate, needle):
     assert not r["fused"]
     assert needle in r["why"], r["why"]
     assert r["types"] == [t[0] for t in g]          # unchanged, operator by operator
+
+
+def test_a_tail_with_an_unknown_operator_is_refused(model):
+    g = ref_graph.qwen2_graph(1, 4, 128, 1e-6, 4, 2, 1e6)
+    g.insert(len(g) - 1, ("Unary", "logit_scale", ["logits"], ["logits"], [], "unary_type=i:4"))
+    ref_graph.add_graph(model, g)
+    r = model.graph_fuse_dry()
+    assert not r["fused"] and "Unary" in r["why"]
+    assert r["types"] == [t[0] for t in g]
+
+
+def test_split_k_lm_head_on_one_rank_keeps_the_reference_tail(model):
+    g = ref_graph.qwen2_graph(1, 4, 128, 1e-6, 4, 2, 1e6, tp_lm_head=True)
+    ref_graph.add_graph(model, g)
+    r = model.graph_fuse_dry()
+    assert r["fused"] and not r["device_resident"]
+    assert r["types"][-5:] == ["DihipFinalNorm", "GetLastLine", "Gemm", "AllReduce", "GenerateOp"]
