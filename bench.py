@@ -246,7 +246,7 @@ def blocks_summary(times, steps):
 
 def host_runner_bench(args, torch, decoder, ops, model, sess, batch, max_len, kv_mode, fuse, graph, steps, blocks):
     """The SAME decode step through the C++ operator layer (dash-infer_amd/host): the reference's Qwen2 operator list
-    (tests/ref_graph.py: qwen_v15.py:187-388) -> fusion pass (host/fusion_pass.cpp; fuse=False: the list as it is, fourteen launches
+    (tests/ref_graph.py: qwen_v15.py:187-388; the MoE layers of qwen_v20_moe.py:318-391 for cfg5_moe) -> fusion pass (host/fusion_pass.cpp; fuse=False: the list as it is, fourteen launches
     per layer) -> OpFactory -> HipModelRunner (host/model_runner.cpp: Alloc -> Forward per operator per step, model.cpp:1248-1325),
     the fused step captured once as a hipGraph and replayed.  The requests adopt the Python session's cache spans (same random
     history); the weights are the same quantised tensors, re-laid-out by the operators' own InitV2."""
@@ -260,7 +260,8 @@ def host_runner_bench(args, torch, decoder, ops, model, sess, batch, max_len, kv
         m = hostapi.Model(ops.cur_stream(), cfg.n_heads, cfg.n_kv, cfg.head_dim, sess.pool.S, kvc, max_batch=batch, max_len=max_len)
         try:
             ref_graph.register_weights(m, model)
-            g = ref_graph.qwen2_graph(len(model.layers), model.quant.wbits, model.quant.group, cfg.eps, cfg.n_heads, cfg.n_kv, cfg.rope_theta)
+            g = ref_graph.qwen2_graph(len(model.layers), model.quant.wbits, model.quant.group, cfg.eps, cfg.n_heads, cfg.n_kv, cfg.rope_theta,
+                                      moe=(cfg.moe.num_experts, cfg.moe.top_k) if cfg.moe is not None else None)
             ref_graph.add_graph(m, g)
             rep = m.graph_build(fuse=fuse)
             gen = torch.Generator().manual_seed(7)
@@ -737,11 +738,11 @@ def main():
         cfg, model_name = decoder.QWEN2_57B_A14B, "Qwen2-57B-A14B"
     spec = decoder.QuantSpec(wbits, group, gptq_like_zeros=gptq)
     t_build = time.time()
-    # the C++ operator layer is measured beside the Python runner on the dense one-GPU workloads (its operators re-lay-out the
-    # unpacked quantised tensors themselves: keep them)
-    host_leg = world == 1 and cfg.moe is None and args.runner != "python"
+    # the C++ operator layer is measured beside the Python runner on the one-GPU workloads, the mixture-of-experts one included
+    # (its operators re-lay-out the unpacked quantised tensors themselves: keep them)
+    host_leg = world == 1 and args.runner != "python"
     if args.runner == "host" and not host_leg:
-        raise SystemExit("--runner host: the operator-layer runner covers the dense one-GPU workloads")
+        raise SystemExit("--runner host: the operator-layer runner covers the one-GPU workloads")
     model = decoder.build_random_model(cfg, spec, seed=1234, rank=rank, nranks=world, layers=args.layers, keep_fp=host_leg)
     blocks = max(1, args.blocks)
     # (kept tight: the decode attention's split width is fixed from max_len; the blocks rewind to SEQ_LEN instead of growing it)

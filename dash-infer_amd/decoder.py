@@ -657,6 +657,9 @@ class DecodeSession:
                 ops.kv_context_copy(kv.v_ptrs[b], qkv[:, (n + g) * H:], stride, L, 0, g, H, self.pool.S, self.kv_mode)
                 attn = ops.prefill_attn(qkv[:, : n * H], qkv[:, n * H:(n + g) * H], qkv[:, (n + g) * H:], n, g, H, self.scale)
                 h = ops.fused_gemm_addto(attn, lw.o, h, sc, M=L)
+                if cfg.moe is not None:
+                    h = self._moe_rows(h, lw, sc)
+                    continue
                 act = ops.fused_norm_swiglu(h, lw.ln2, cfg.eps, lw.gate, lw.up, sc)
                 h = ops.fused_gemm_addto(act, lw.down, h, sc, M=L)
             if return_logits:
@@ -668,6 +671,27 @@ class DecodeSession:
         else:
             self.set_state(torch.zeros(self.B, dtype=torch.int64), lens)
         return logits
+
+    def _moe_rows(self, h, lw, sc):
+        """The mixture-of-experts block (_moe_block below) over the T rows of a prompt, on fresh tensors, single rank."""
+        cfg, mc = self.model.cfg, self.model.cfg.moe
+        T, proj = h.shape[0], lw.exp_gate.N
+        xn = ops.rmsnorm_rows(h, lw.ln2, cfg.eps)
+        logits, sig = ops.moe_router_gate(xn, lw.router, lw.shared_sig)
+        ws = torch.empty(int(lib().dihip_moe_workspace_bytes(T, mc.top_k, cfg.hidden, mc.moe_inter)), dtype=torch.uint8, device=h.device)
+        grouped = T > 1 and T * mc.top_k <= ops.MOE_GROUP_MAX_SLOTS and os.environ.get("DIHIP_MOE_FUSED", "1") != "0"
+        if grouped:
+            scores, experts = ops.moe_route_grouped(logits, mc.top_k, cfg.hidden, proj, ws, ep=lw.ep)
+        else:
+            scores, experts = ops.moe_route(logits, mc.top_k, ep=lw.ep)
+        out = ops.moe_experts(xn, experts, scores, lw.exp_gate, lw.exp_up, lw.exp_down, ws=ws,
+                              out=torch.empty(T, cfg.hidden, dtype=xn.dtype, device=h.device),
+                              flags=(ops.MOE_PREGROUPED | ops.MOE_NO_FINALIZE) if grouped else 0)
+        act = ops.prenorm_swiglu(xn, lw.gate, lw.up, sc, T)
+        shared = ops.gemm_lowp(act, lw.down, scratch=sc)
+        if grouped:
+            return ops.moe_combine(h, h, ws, scores, experts, shared, sig, proj)
+        return ops.moe_shared_combine(h, h, out, shared, sig)
 
     # -- one decode step -------------------------------------------------------------------
     def step(self):

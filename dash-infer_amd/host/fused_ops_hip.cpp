@@ -17,6 +17,7 @@
 //   DihipRopeSpanAttn   <- Rotary + DecOptMQA|DecOptMHA                   (class derived from SpanAttnOpHIP)
 //   DihipGemmAddTo      <- GemmA16Wx + [AllReduce] + Binary ADD           [4 < M <= 32: + the LayerNormNoBeta that follows]
 //   DihipNormSwiGLU     <- LayerNormNoBeta + GemmA16Wx(SILU) + GemmA16Wx + Binary MUL
+//   DihipMoeBlock       <- the mixture-of-experts feed-forward block of qwen_v20_moe.py:318-382 (twelve operators)
 //   DihipLMHead         <- LayerNormNoBeta + GetLastLine + Gemm(lm_head)  f32 logits
 //   DihipGreedy         <- GenerateOp (greedy requests); advances the device-resident length counters in the same launch
 //
@@ -28,6 +29,7 @@
 #include <cstdlib>
 
 #include "dashinfer_hip.h"
+#include "moe_op_hip.h"
 #include "operator.h"
 #include "sampling_host.h"
 #include "span_attn_op_hip.h"
@@ -540,6 +542,169 @@ class DihipRopeSpanAttnOp : public SpanAttnOpHIP {
   std::unique_ptr<AsTensor> pos_dev_;
 };
 REGISTER_OP(DihipRopeSpanAttn, HIP, DihipRopeSpanAttnOp)
+
+// ====================================================================================================== DihipMoeBlock
+// The feed-forward block of a mixture-of-experts layer (python/pyhie/allspark/model/qwen_v20_moe.py:318-382), twelve operators
+// in the reference graph:
+//   LayerNormNoBeta -> Gemm "mlp.gate" (router) -> MOE -> [AllReduce] -> GemmA16Wx "shared_expert.gate_up_proj" -> UnaryGLU ->
+//   GemmA16Wx "shared_expert.down_proj" ; Gemm "shared_expert_gate" (SIGMOID) -> CalcExpert -> [AllReduce] -> Binary ADD -> Binary ADD
+// as the launches of decoder.DecodeSession._moe_block: norm -> router + shared gate in one launch -> routing (+ slot grouping) ->
+// expert GEMVs -> shared expert SwiGLU pair -> shared down projection -> combine (finalize-routing + CalcExpert + both adds) on
+// the f32 hidden rows.  Under expert / tensor parallelism the rank adds its partial sums (and, on rank 0, the residual) first;
+// the fusion pass leaves ONE AllReduce of the f32 rows behind the operator -- the same sum as the reference's two.
+//   inputs  [h f32 [.., hidden]]      outputs [h_out f32]
+//   weights [ffn gamma, mlp.gate W [hidden, E], experts gate_up W/scales/zeros, experts down W/scales/zeros (the MOEA16W8 stacks),
+//            shared gate_up W/scales/zeros ([hidden, 2 I], columns [gate | up]), shared down W/scales/zeros, shared_expert_gate W [hidden, 1]]
+//   attrs   eps, num_experts, num_experts_per_tok, [use_ep], [GroupSize] (experts), wbits / [shared.GroupSize] (shared expert)
+class DihipMoeBlockOp : public MoeA16W8HIP {
+ public:
+  explicit DihipMoeBlockOp(const std::string& t = "") : MoeA16W8HIP(t) {}
+  AsStatus InitV2(const OperatorProto& op_proto, const DeviceContext& ctx, const TensorMap& weights_map, TensorMap& weights_buffer,
+                  TensorMap* tensor_map, RuntimeContext* runtime_ctx) override {
+    (void)weights_buffer;
+    (void)runtime_ctx;
+    AS_CHECK_STATUS(AsOperator::Init(op_proto, ctx, weights_map, tensor_map));
+    if (ctx.GetDeviceType() != DeviceType::HIP || weights_.size() != 15 || in_names_.size() != 1) return AsStatus::ALLSPARK_PARAM_ERROR;
+    const char* e = attr_ptr(op_proto, "eps");
+    if (!e) return AsStatus::ALLSPARK_PARAM_ERROR;
+    eps_ = *(const float*)e;
+    AS_CHECK_STATUS(ParseMoeAttrs(op_proto, ctx));
+    AS_CHECK_STATUS(PackExperts(weights_.data() + 2, ctx));
+    hipStream_t s = stream_of(&ctx);
+    // the two unquantised skinny weights
+    const AsTensor *router = weights_[1], *sig = weights_[14];
+    if (router->GetShape().size() != 2 || (int)router->GetShape()[0] != hidden_ || (int)router->GetShape()[1] != num_expert_ ||
+        router->GetDataType() != ftype_)
+      return AsStatus::ALLSPARK_PARAM_ERROR;
+    if (sig->Count() != hidden_ || sig->GetDataType() != ftype_) return AsStatus::ALLSPARK_PARAM_ERROR;
+    if ((int)weights_[0]->GetShape()[0] != hidden_ || weights_[0]->GetDataType() != ftype_) return AsStatus::ALLSPARK_PARAM_ERROR;
+    router_ = std::make_unique<AsTensor>(op_name_ + ".router_packed", DeviceType::HIP, INT8, Shape{(int64_t)dihip_dense_packed_weight_bytes(num_expert_, hidden_)});
+    sig_ = std::make_unique<AsTensor>(op_name_ + ".shared_gate_packed", DeviceType::HIP, INT8, Shape{(int64_t)dihip_dense_packed_weight_bytes(1, hidden_)});
+    if (!router_->GetDataPtr() || !sig_->GetDataPtr()) return AsStatus::ALLSPARK_MEMORY_ERROR;
+    AS_CHECK_STATUS(FromDihip(dihip_dense_pack(s, router->GetDataPtr(), num_expert_, hidden_, DihipDtype(ftype_), router_->GetDataPtr())));
+    AS_CHECK_STATUS(FromDihip(dihip_dense_pack(s, sig->GetDataPtr(), 1, hidden_, DihipDtype(ftype_), sig_->GetDataPtr())));
+    // the shared expert: column halves of gate_up_proj become the gate and the up tensor (UnaryGLU, unary.cu:122-132)
+    const int wb = read_wbits(op_proto);
+    const char* sg = attr_ptr(op_proto, "shared.GroupSize");
+    const int grp = sg ? *(const int*)sg : -1;
+    const AsTensor *gu = weights_[8], *gus = weights_[9], *guz = weights_[10];
+    if (gu->GetShape().size() != 2 || gus->GetShape().size() != 2 || (int)gu->GetShape()[0] != hidden_ || gus->GetDataType() != ftype_ ||
+        (gus->GetShape()[1] % 4))
+      return AsStatus::ALLSPARK_PARAM_ERROR;
+    const int inter = (int)gus->GetShape()[1] / 2, G = (int)gus->GetShape()[0];
+    const size_t wrow = wb == 4 ? (size_t)inter / 2 : (size_t)inter;  // bytes of one half of a weight row
+    AsTensor tw(op_name_ + ".tmp_w", DeviceType::HIP, gu->GetDataType(), Shape{hidden_, (int64_t)wrow});
+    AsTensor ts(op_name_ + ".tmp_s", DeviceType::HIP, ftype_, Shape{G, inter}), tz(op_name_ + ".tmp_z", DeviceType::HIP, ftype_, Shape{G, inter});
+    if (!tw.GetDataPtr() || !ts.GetDataPtr() || !tz.GetDataPtr()) return AsStatus::ALLSPARK_MEMORY_ERROR;
+    for (int half = 0; half < 2; ++half) {
+      if (hipMemcpy2DAsync(tw.GetDataPtr(), wrow, (const char*)gu->GetDataPtr() + half * wrow, 2 * wrow, wrow, hidden_, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+          hipMemcpy2DAsync(ts.GetDataPtr(), (size_t)inter * 2, (const char*)gus->GetDataPtr() + (size_t)half * inter * 2, (size_t)inter * 4, (size_t)inter * 2, G,
+                           hipMemcpyDeviceToDevice, s) != hipSuccess ||
+          hipMemcpy2DAsync(tz.GetDataPtr(), (size_t)inter * 2, (const char*)guz->GetDataPtr() + (size_t)half * inter * 2, (size_t)inter * 4, (size_t)inter * 2, G,
+                           hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return AsStatus::ALLSPARK_RUNTIME_ERROR;
+      AS_CHECK_STATUS((half ? su_ : sg_).Pack(op_name_ + (half ? ".shared_up" : ".shared_gate"), wb, grp, &tw, &ts, &tz, s));
+    }
+    AS_CHECK_STATUS(sd_.Pack(op_name_ + ".shared_down", wb, grp, weights_[11], weights_[12], weights_[13], s));
+    if (sg_.n != inter || sg_.k != hidden_ || sd_.k != inter || sd_.n != hidden_ || sd_.ft != ftype_) return AsStatus::ALLSPARK_PARAM_ERROR;
+    sync_ = zeroed(op_name_ + ".sync", dihip_gemm_lowp_sync_bytes(), s);
+    if (!sync_) return AsStatus::ALLSPARK_MEMORY_ERROR;
+    if (hipStreamSynchronize(s) != hipSuccess) return AsStatus::ALLSPARK_RUNTIME_ERROR;  // the staging tensors die here
+    tensor_map_->at(out_names_[0])->SetDataType(FLOAT32);
+    return AsStatus::ALLSPARK_SUCCESS;
+  }
+
+  AsStatus Reshape(RuntimeContext* rt) override {
+    AsTensor* h = tensor_map_->at(in_names_[0]).get();
+    Shape s = h->GetShape();
+    if (s.empty() || (int)s.back() != hidden_ || h->GetDataType() != FLOAT32) return AsStatus::ALLSPARK_PARAM_ERROR;
+    total_token_ = (int)(h->Count() / hidden_);
+    const int t = std::max(total_token_, 1);
+    AsTensor* y = tensor_map_->at(out_names_[0]).get();
+    y->SetDataType(FLOAT32);
+    AS_CHECK_STATUS(y->SetShape(std::move(s)));
+    static const bool fuse_on = env_on("DIHIP_MOE_FUSED", true), frag_on = env_on("DIHIP_MOE_ACT_FRAG", true);
+    grouped_ = fuse_on && total_token_ > 1 && (int64_t)total_token_ * top_k_ <= 2048;  // decoder.DecodeSession._moe_block
+    act_frag_ = frag_on && rt && !rt->is_context && total_token_ > 4 && total_token_ <= 32 && sg_.n % 32 == 0;
+    // scratch rows shared by the layers' blocks (one block runs at a time)
+    struct Need { const char* name; DataType dt; int64_t count; AsTensor** slot; };
+    const size_t act_bytes = act_frag_ ? dihip_act_frag_bytes(total_token_, sg_.n) : (size_t)t * sg_.n * 2;
+    const Need needs[] = {{"dihip.moe_xn", ftype_, (int64_t)t * hidden_, &xn_},      {"dihip.moe_logits", ftype_, (int64_t)t * num_expert_, &logits_},
+                          {"dihip.moe_sig", ftype_, (int64_t)t, &sigv_},              {"dihip.moe_scores", FLOAT32, (int64_t)t * top_k_, &scores_},
+                          {"dihip.moe_experts", INT32, (int64_t)t * top_k_, &idx_},   {"dihip.moe_out", ftype_, (int64_t)t * hidden_, &moe_out_},
+                          {"dihip.moe_shared", ftype_, (int64_t)t * hidden_, &shared_}, {"dihip.moe_ws", INT8, (int64_t)dihip_moe_workspace_bytes(t, top_k_, hidden_, proj_), &mws_}};
+    for (const Need& n : needs) {
+      auto it = tensor_map_->find(n.name);
+      if (it == tensor_map_->end()) it = tensor_map_->emplace(n.name, std::make_shared<AsTensor>(n.name, DeviceType::HIP, n.dt, Shape{n.count})).first;
+      if (it->second->Count() < n.count) AS_CHECK_STATUS(it->second->SetShape(Shape{n.count}));
+      if (!it->second->GetDataPtr()) return AsStatus::ALLSPARK_MEMORY_ERROR;
+      *n.slot = it->second.get();
+    }
+    {  // SiLU(gate) * up of the shared expert: FRAG32 for small decode batches (zero padding rows), row-major otherwise
+      auto it = tensor_map_->find("dihip.moe_act");
+      if (it == tensor_map_->end()) it = tensor_map_->emplace("dihip.moe_act", std::make_shared<AsTensor>("dihip.moe_act", DeviceType::HIP, ftype_, Shape{0})).first;
+      act_ = it->second.get();
+      if (act_->GetSizeInByte() < act_bytes || hip_ctx(ctx_).ActLayout("dihip.moe_act") != (act_frag_ ? DIHIP_ACT_FRAG32 : DIHIP_ACT_ROWMAJOR)) {
+        AS_CHECK_STATUS(act_->SetShape(Shape{(int64_t)((std::max(act_bytes, act_->GetSizeInByte()) + 1) / 2)}));
+        if (hipMemsetAsync(act_->GetDataPtr(), 0, act_->GetSizeInByte(), stream_of(ctx_)) != hipSuccess) return AsStatus::ALLSPARK_RUNTIME_ERROR;
+        hip_ctx(ctx_).SetActLayout("dihip.moe_act", act_frag_ ? DIHIP_ACT_FRAG32 : DIHIP_ACT_ROWMAJOR);
+      }
+    }
+    const size_t ws = std::max(dihip_gemm_lowp_workspace_bytes(sg_.wbits, t, sg_.n, sg_.k, sg_.group),
+                               dihip_gemm_lowp_workspace_bytes(sd_.wbits, t, sd_.n, sd_.k, sd_.group));
+    return grow_workspace(tensor_map_, ws);
+  }
+
+  AsStatus Forward(RuntimeContext*) override {
+    const float* h = (const float*)tensor_map_->at(in_names_[0])->GetDataPtr();
+    float* y = (float*)tensor_map_->at(out_names_[0])->GetDataPtr();
+    AsTensor* wsp = tensor_map_->at("workspace").get();
+    hipStream_t s = stream_of(ctx_);
+    const int T = total_token_, dt = DihipDtype(ftype_);
+    AS_CHECK_STATUS(FromDihip(dihip_rmsnorm_rows(s, xn_->GetDataPtr(), h, weights_[0]->GetDataPtr(), eps_, T, hidden_, dt)));
+    AS_CHECK_STATUS(FromDihip(dihip_moe_router_gate(s, xn_->GetDataPtr(), router_->GetDataPtr(), sig_->GetDataPtr(), logits_->GetDataPtr(),
+                                                    sigv_->GetDataPtr(), T, num_expert_, hidden_, dt)));
+    float* scores = (float*)scores_->GetDataPtr();
+    int32_t* idx = (int32_t*)idx_->GetDataPtr();
+    if (grouped_) {
+      AS_CHECK_STATUS(FromDihip(dihip_moe_route_grouped(s, logits_->GetDataPtr(), T, num_expert_, top_k_, scores, idx, dt, ep_first_, ep_num_, hidden_,
+                                                        proj_, mws_->GetDataPtr(), mws_->GetSizeInByte())));
+    } else {
+      AS_CHECK_STATUS(FromDihip(dihip_moe_route_ep(s, logits_->GetDataPtr(), T, num_expert_, top_k_, scores, idx, dt, ep_first_, ep_num_)));
+    }
+    AS_CHECK_STATUS(FromDihip(dihip_moe_experts_ex(s, 8, xn_->GetDataPtr(), idx, scores, gate_w_->GetDataPtr(), gate_sz_->GetDataPtr(), up_w_->GetDataPtr(),
+                                                   up_sz_->GetDataPtr(), down_w_->GetDataPtr(), down_sz_->GetDataPtr(), T, top_k_, hidden_, proj_,
+                                                   group_size_, moe_out_->GetDataPtr(), mws_->GetDataPtr(), mws_->GetSizeInByte(), dt,
+                                                   grouped_ ? (DIHIP_MOE_PREGROUPED | DIHIP_MOE_NO_FINALIZE) : 0)));
+    const int lay = act_frag_ ? DIHIP_ACT_FRAG32 : DIHIP_ACT_ROWMAJOR;
+    AS_CHECK_STATUS(FromDihip(dihip_prenorm_swiglu(s, sg_.wbits, xn_->GetDataPtr(), DIHIP_ACT_ROWMAJOR, sg_.w->GetDataPtr(), sg_.sz->GetDataPtr(),
+                                                   su_.w->GetDataPtr(), su_.sz->GetDataPtr(), act_->GetDataPtr(), T, sg_.n, sg_.k, sg_.group,
+                                                   wsp->GetDataPtr(), wsp->GetSizeInByte(), sync_->GetDataPtr(), dt, lay)));
+    if (act_frag_) {
+      AS_CHECK_STATUS(FromDihip(dihip_prenorm_gemm(s, sd_.wbits, act_->GetDataPtr(), DIHIP_ACT_FRAG32, sd_.w->GetDataPtr(), sd_.sz->GetDataPtr(), nullptr,
+                                                   shared_->GetDataPtr(), T, sd_.n, sd_.k, sd_.group, 0, wsp->GetDataPtr(), wsp->GetSizeInByte(),
+                                                   sync_->GetDataPtr(), dt)));
+    } else {
+      auto gemm = sd_.wbits == 8 ? dihip_gemm_a16w8 : dihip_gemm_a16w4;
+      AS_CHECK_STATUS(FromDihip(gemm(s, act_->GetDataPtr(), sd_.w->GetDataPtr(), sd_.sz->GetDataPtr(), nullptr, nullptr, shared_->GetDataPtr(), T, sd_.n,
+                                     sd_.k, sd_.group, 0, 1.0f, wsp->GetDataPtr(), wsp->GetSizeInByte(), sync_->GetDataPtr(), dt)));
+    }
+    const float* h_res = (ctx_->GetNranks() <= 1 || ctx_->GetRank() == 0) ? h : nullptr;  // the residual rides on rank 0 (gemm_op.cpp:133-137)
+    if (grouped_)
+      return FromDihip(dihip_moe_combine(s, y, h_res, mws_->GetDataPtr(), scores, idx, shared_->GetDataPtr(), sigv_->GetDataPtr(), T, top_k_, hidden_,
+                                         proj_, dt));
+    return FromDihip(dihip_moe_shared_combine(s, y, h_res, moe_out_->GetDataPtr(), shared_->GetDataPtr(), sigv_->GetDataPtr(), T, hidden_, dt));
+  }
+
+ private:
+  float eps_ = 1e-6f;
+  bool grouped_ = false, act_frag_ = false;
+  PackedLowp sg_, su_, sd_;
+  std::unique_ptr<AsTensor> router_, sig_, sync_;
+  AsTensor *xn_ = nullptr, *logits_ = nullptr, *sigv_ = nullptr, *scores_ = nullptr, *idx_ = nullptr, *moe_out_ = nullptr, *shared_ = nullptr,
+           *mws_ = nullptr, *act_ = nullptr;
+};
+REGISTER_OP(DihipMoeBlock, HIP, DihipMoeBlockOp)
 
 // ===================================================================================================== DihipFinalNorm
 // LayerNormNoBeta of the f32 hidden rows into FT rows (dihip_rmsnorm_rows): the seam between the fused layers and a tail that stays

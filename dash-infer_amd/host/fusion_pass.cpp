@@ -48,6 +48,18 @@ struct Matcher {
     ++i;
     return true;
   }
+  // an unquantised Gemm on `in` with one weight (no bias), the given activation, plain alpha / layout
+  bool dense(const OperatorProto*& out, const std::string& in, int act) {
+    const OperatorProto* p = peek();
+    if (!p || p->op_type != "Gemm") return fail("expected Gemm");
+    if (p->inputs.size() != 1 || p->inputs[0] != in || p->outputs.size() != 1 || p->weights.size() != 1) return fail("Gemm with unexpected inputs / weights");
+    if (attr_int(*p, "activation", 0) != act || attr_bool(*p, "with_bias") || attr_bool(*p, "splitk") || attr_float(*p, "alpha", 1.0f) != 1.0f ||
+        attr_bool(*p, "transB") || attr_int(*p, "binary_type", 0) != 0)
+      return fail("Gemm attributes");
+    out = p;
+    ++i;
+    return true;
+  }
   bool typed(const OperatorProto*& out, const char* type, const std::string& in) {
     const OperatorProto* p = peek();
     if (!p || p->op_type != type) return fail(std::string("expected ") + type);
@@ -148,6 +160,75 @@ std::vector<OperatorProto> FuseDecoderGraph(const std::vector<OperatorProto>& gr
     const std::string o_sum = m.maybe_allreduce(ar1, o->outputs[0]);
     if (!m.binary(add1, 1, o_sum, h)) return refuse("");
     if (!m.typed(ln2, "LayerNormNoBeta", add1->outputs[0]) || ln2->weights.size() != 1 || !attr_ptr(*ln2, "eps")) return refuse(m.why.empty() ? "ffn LayerNormNoBeta" : "");
+    const OperatorProto* after_ln2 = m.peek();
+    const bool moe_layer = after_ln2 && after_ln2->op_type == "Gemm";
+
+    OperatorProto f_qkv = make("DihipNormGemm", qkv->op_name, {h}, qkv->outputs, {ln1->weights[0]});
+    if (!xnorm_in.empty()) f_qkv.inputs.push_back(xnorm_in);
+    f_qkv.weights.insert(f_qkv.weights.end(), qkv->weights.begin(), qkv->weights.end());
+    copy_attr(f_qkv, *ln1, "eps");
+    lowp_attrs(f_qkv, *qkv);
+    out.push_back(std::move(f_qkv));
+
+    OperatorProto f_att = make("DihipRopeSpanAttn", att->op_name, {qkv->outputs[0]}, att->outputs, {});
+    f_att.attr = rot->attr;
+    for (const auto& kv : att->attr) f_att.attr[kv.first] = kv.second;
+    out.push_back(std::move(f_att));
+    xnorm_in.clear();
+
+    if (moe_layer) {
+      // the mixture-of-experts feed-forward block (qwen_v20_moe.py:318-382) -> one DihipMoeBlock
+      const OperatorProto *router, *moe, *ar_moe, *sgu, *glu, *sdown, *sgate, *calc, *ar_sh, *eadd;
+      if (!m.dense(router, ln2->outputs[0], 0)) return refuse("");
+      {
+        const OperatorProto* p = m.peek();
+        if (!p || p->op_type != "MOEA16W8" || p->inputs.size() != 2 || p->inputs[0] != ln2->outputs[0] || p->inputs[1] != router->outputs[0] ||
+            p->outputs.size() != 1 || p->weights.size() != 6)
+          return refuse(m.fail("expected MOEA16W8(ffn rows, router logits)") ? "" : "");
+        moe = p;
+        ++m.i;
+      }
+      (void)m.maybe_allreduce(ar_moe, moe->outputs[0]);
+      if (!m.lowp(sgu, ln2->outputs[0], 0, false)) return refuse("");
+      if (!m.typed(glu, "UnaryGLU", sgu->outputs[0])) return refuse("");
+      if (attr_int(*glu, "unary_type", 0) != (int)SILU) return refuse("a UnaryGLU activation the fused shared expert does not implement (" + glu->op_name + ")");
+      if (!m.lowp(sdown, glu->outputs[0], 0, false)) return refuse("");
+      if (lowp_bits(*sgu) != lowp_bits(*sdown) || attr_int(*sgu, "GroupSize", -1) != attr_int(*sdown, "GroupSize", -1))
+        return refuse("shared expert projections quantised differently (" + sgu->op_name + ")");
+      if (!m.dense(sgate, ln2->outputs[0], (int)SIGMOID)) return refuse("");
+      {
+        const OperatorProto* p = m.peek();
+        if (!p || p->op_type != "CalcExpert" || p->inputs.size() != 2 || p->inputs[0] != sdown->outputs[0] || p->inputs[1] != sgate->outputs[0] ||
+            p->outputs.size() != 1)
+          return refuse(m.fail("expected CalcExpert(shared expert rows, shared expert gate)") ? "" : "");
+        calc = p;
+        ++m.i;
+      }
+      (void)m.maybe_allreduce(ar_sh, calc->outputs[0]);
+      if (!m.binary(eadd, 1, moe->outputs[0], calc->outputs[0])) return refuse("");
+      if (!m.binary(add2, 1, eadd->outputs[0], add1->outputs[0])) return refuse("");
+
+      OperatorProto f_o = make("DihipGemmAddTo", o->op_name, {att->outputs[0], h}, {add1->outputs[0]}, o->weights);
+      lowp_attrs(f_o, *o);
+      out.push_back(std::move(f_o));
+      if (ar1) out.push_back(make("AllReduce", ar1->op_name, {add1->outputs[0]}, {add1->outputs[0]}, {}));
+
+      OperatorProto f_moe = make("DihipMoeBlock", moe->op_name, {add1->outputs[0]}, {add2->outputs[0]}, {ln2->weights[0], router->weights[0]});
+      for (const OperatorProto* src : {moe, sgu, sdown}) f_moe.weights.insert(f_moe.weights.end(), src->weights.begin(), src->weights.end());
+      f_moe.weights.push_back(sgate->weights[0]);
+      copy_attr(f_moe, *ln2, "eps");
+      for (const char* k : {"num_experts", "num_experts_per_tok", "use_ep", "GroupSize"}) copy_attr(f_moe, *moe, k);
+      f_moe.attr["wbits"] = bytes_of(lowp_bits(*sgu));
+      if (attr_ptr(*sgu, "GroupSize")) f_moe.attr["shared.GroupSize"] = sgu->attr.at("GroupSize");
+      out.push_back(std::move(f_moe));
+      // the reference all-reduces the MOE rows and the CalcExpert rows, the block adds them (and the residual on rank 0) first:
+      // one all-reduce of the f32 hidden rows, the same sum
+      if (ar_moe || ar_sh) out.push_back(make("AllReduce", (ar_moe ? ar_moe : ar_sh)->op_name, {add2->outputs[0]}, {add2->outputs[0]}, {}));
+      h = add2->outputs[0];
+      ++rep.layers;
+      continue;
+    }
+
     if (!m.lowp(gate, ln2->outputs[0], (int)SILU, false)) return refuse("");
     if (!m.lowp(up, ln2->outputs[0], 0, false)) return refuse("");
     if (lowp_bits(*gate) != lowp_bits(*up) || attr_int(*gate, "GroupSize", -1) != attr_int(*up, "GroupSize", -1))
@@ -161,18 +242,6 @@ std::vector<OperatorProto> FuseDecoderGraph(const std::vector<OperatorProto>& gr
     const OperatorProto* next_gemm = m.peek(1);
     const bool hand_on = next_ln && next_ln->op_type == "LayerNormNoBeta" && next_ln->inputs.size() == 1 && next_ln->inputs[0] == add2->outputs[0] &&
                          next_ln->weights.size() == 1 && attr_ptr(*next_ln, "eps") && next_gemm && lowp_bits(*next_gemm);
-
-    OperatorProto f_qkv = make("DihipNormGemm", qkv->op_name, {h}, qkv->outputs, {ln1->weights[0]});
-    if (!xnorm_in.empty()) f_qkv.inputs.push_back(xnorm_in);
-    f_qkv.weights.insert(f_qkv.weights.end(), qkv->weights.begin(), qkv->weights.end());
-    copy_attr(f_qkv, *ln1, "eps");
-    lowp_attrs(f_qkv, *qkv);
-    out.push_back(std::move(f_qkv));
-
-    OperatorProto f_att = make("DihipRopeSpanAttn", att->op_name, {qkv->outputs[0]}, att->outputs, {});
-    f_att.attr = rot->attr;
-    for (const auto& kv : att->attr) f_att.attr[kv.first] = kv.second;
-    out.push_back(std::move(f_att));
 
     const std::string xn2 = o->op_name + ".dihip_xnorm";
     OperatorProto f_o = make("DihipGemmAddTo", o->op_name, {att->outputs[0], h}, {add1->outputs[0], xn2}, o->weights);
@@ -191,7 +260,6 @@ std::vector<OperatorProto> FuseDecoderGraph(const std::vector<OperatorProto>& gr
 
     OperatorProto f_down = make("DihipGemmAddTo", down->op_name, {mul->outputs[0], add1->outputs[0]}, {add2->outputs[0]}, down->weights);
     lowp_attrs(f_down, *down);
-    xnorm_in.clear();
     if (hand_on) {
       xnorm_in = down->op_name + ".dihip_xnorm";
       f_down.outputs.push_back(xnorm_in);

@@ -92,7 +92,7 @@ const char* dihost_registered_ops(void) {
   for (const char* t : {"GemmA16W8", "GemmA16W4", "DecOptMHA", "DecOptMQA", "AllReduce", "AllGather", "MOEA16W8", "CalcExpert", "Gemm", "Rotary",
                         "LayerNormNoBeta", "Binary", "Unary", "UnaryGLU", "EmbeddingT5", "GetLastLine", "GenerateOp", "TransMask", "RichEmbedding",
                         "PreProcessId", "UpdateId", "PostProcessId", "DihipEmbedding", "DihipNormGemm", "DihipRopeSpanAttn", "DihipGemmAddTo",
-                        "DihipNormSwiGLU", "DihipLMHead", "DihipGreedy", "DihipFinalNorm"}) {
+                        "DihipNormSwiGLU", "DihipLMHead", "DihipGreedy", "DihipFinalNorm", "DihipMoeBlock"}) {
     try {
       (void)OpFactory::getInstance().GetOperator({t, DeviceType::HIP});
       s += (s.empty() ? "" : ",");

@@ -4,7 +4,9 @@ plain tuples (op_type, op_name, inputs, outputs, weights, attrs), for the host-l
 Python: the CPU tests of the fusion pass use it without a GPU."""
 
 
-def qwen2_graph(n_layers, wbits, group, eps, n_heads, n_kv, rope_theta, tp_allreduce=False, tp_lm_head=False):
+def qwen2_graph(n_layers, wbits, group, eps, n_heads, n_kv, rope_theta, tp_allreduce=False, tp_lm_head=False, moe=None):
+    """moe = (num_experts, top_k[, use_ep]): the feed-forward half of every layer is the mixture-of-experts block of
+    python/pyhie/allspark/model/qwen_v20_moe.py:318-391 (MOE in its weight-only form MOEA16W8)."""
     gemm = "GemmA16W4" if wbits == 4 else "GemmA16W8"
     gattr = f"GroupSize=i:{group}" if group and group > 0 else ""
 
@@ -28,6 +30,27 @@ def qwen2_graph(n_layers, wbits, group, eps, n_heads, n_kv, rope_theta, tp_allre
             g.append(("AllReduce", p + "attention.all_reduce", [o_out], [o_out], [], ""))
         g.append(("Binary", p + "attention_add", [o_out, prev], [p + "attention_add.out"], [], "binary_type=i:1"))
         g.append(("LayerNormNoBeta", p + "ffn.layernorm", [p + "attention_add.out"], [p + "ffn.layernorm.out"], [p + "ffn.layernorm.gamma"], f"eps=f:{eps}"))
+        if moe is not None:
+            xn, ex = p + "ffn.layernorm.out", p + "mlp.experts"
+            g.append(("Gemm", p + "mlp.gate", [xn], [p + "mlp.gate.out"], [p + "mlp.gate.weight"], "with_bias=b:0"))
+            mattr = f"num_experts=i:{moe[0]};num_experts_per_tok=i:{moe[1]}" + (";use_ep=b:1" if len(moe) > 2 and moe[2] else "") + (";" + gattr if gattr else "")
+            g.append(("MOEA16W8", ex, [xn, p + "mlp.gate.out"], [ex + ".out"],
+                      [ex + ".gate_up_proj.weight", ex + ".gate_up_proj.weight.scale", ex + ".gate_up_proj.weight.zero_point",
+                       ex + ".down_proj.weight", ex + ".down_proj.weight.scale", ex + ".down_proj.weight.zero_point"], mattr))
+            if tp_allreduce:
+                g.append(("AllReduce", p + "attention.all_reduce_moe", [ex + ".out"], [ex + ".out"], [], ""))
+            g.append(lowp(p + "shared_expert.gate_up_proj", xn, p + "shared_expert.gate_up_proj.out"))
+            g.append(("UnaryGLU", p + "shared_expert_act_mul", [p + "shared_expert.gate_up_proj.out"], [p + "shared_expert_act_mul.out"], [], "unary_type=i:5"))
+            g.append(lowp(p + "shared_expert.down_proj", p + "shared_expert_act_mul.out", p + "shared_expert.down_proj.out"))
+            g.append(("Gemm", p + "shared_expert_gate", [xn], [p + "shared_expert_gate.out"], [p + "shared_expert_gate.weight"], "with_bias=b:0;activation=i:6"))
+            g.append(("CalcExpert", p + "shared_calc_expert", [p + "shared_expert.down_proj.out", p + "shared_expert_gate.out"], [p + "shared_calc_expert.out"], [],
+                      "num_experts=i:1"))
+            if tp_allreduce:
+                g.append(("AllReduce", p + "all_reduce_shared_expert", [p + "shared_calc_expert.out"], [p + "shared_calc_expert.out"], [], ""))
+            g.append(("Binary", p + "expert_add", [ex + ".out", p + "shared_calc_expert.out"], [p + "expert_add.out"], [], "binary_type=i:1"))
+            g.append(("Binary", p + "final_add", [p + "expert_add.out", p + "attention_add.out"], [p + "final_add.out"], [], "binary_type=i:1"))
+            prev = p + "final_add.out"
+            continue
         g.append(lowp(p + "ffn.intermediate.dense", p + "ffn.layernorm.out", p + "ffn.intermediate.dense.out", act=5))
         g.append(lowp(p + "ffn.linear.dense", p + "ffn.layernorm.out", p + "ffn.linear.dense.out"))
         g.append(("Binary", p + "ffn.mul", [p + "ffn.intermediate.dense.out", p + "ffn.linear.dense.out"], [p + "ffn.mul.out"], [], "binary_type=i:2"))
@@ -67,6 +90,21 @@ def register_weights(m, model, ft="bf16"):
         lowp(p + "attention.self", "qkv", li)
         m.set_weight(p + "attention.self.bias", fp[li]["qkv_bias"], ft)
         lowp(p + "attention.output.dense", "o", li)
+        if "moe" in fp[li]:
+            import torch
+            mo, ex = fp[li]["moe"], p + "mlp.experts"
+            m.set_weight(p + "mlp.gate.weight", mo["router"], ft)
+            m.set_weight(p + "shared_expert_gate.weight", mo["shared_gate_w"], ft)
+            cat = lambda a, b: [torch.cat([x, y], dim=1).contiguous() for x, y in zip(a, b)]      # columns [gate | up] (unary.cu:122-132)
+            gq, gs, gz = cat(fp[li]["gate"], fp[li]["up"])
+            for name, t, dt in ((".weight", gq, qdt), (".weight.scales", gs, ft), (".weight.zeros", gz, ft)):
+                m.set_weight(p + "shared_expert.gate_up_proj" + name, t, dt)
+            lowp(p + "shared_expert.down_proj", "down", li)
+            gu = [cat(g_, u_) for g_, u_ in zip(mo["experts_gate"], mo["experts_up"])]
+            for j, suffix in enumerate((".weight", ".weight.scale", ".weight.zero_point")):
+                m.set_weight(ex + ".gate_up_proj" + suffix, torch.stack([e[j] for e in gu]).contiguous(), qdt if j == 0 else ft)
+                m.set_weight(ex + ".down_proj" + suffix, torch.stack([e[j] for e in mo["experts_down"]]).contiguous(), qdt if j == 0 else ft)
+            continue
         lowp(p + "ffn.intermediate.dense", "gate", li)
         lowp(p + "ffn.linear.dense", "up", li)
         lowp(p + "ffn.output.dense", "down", li)

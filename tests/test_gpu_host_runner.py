@@ -36,7 +36,8 @@ class Host:
         with torch.cuda.stream(self.stream):
             self.m = hostapi.Model(ops.cur_stream(), cfg.n_heads, cfg.n_kv, cfg.head_dim, span, KV[kv_mode], max_batch=batch, max_len=max_len)
             ref_graph.register_weights(self.m, model, ft)
-            self.graph = ref_graph.qwen2_graph(self.nl, model.quant.wbits, model.quant.group, cfg.eps, cfg.n_heads, cfg.n_kv, cfg.rope_theta)
+            self.graph = ref_graph.qwen2_graph(self.nl, model.quant.wbits, model.quant.group, cfg.eps, cfg.n_heads, cfg.n_kv, cfg.rope_theta,
+                                               moe=(cfg.moe.num_experts, cfg.moe.top_k) if cfg.moe is not None else None)
             ref_graph.add_graph(self.m, self.graph)
             self.report = self.m.graph_build(fuse=fuse)
         self.stream.synchronize()
@@ -100,6 +101,74 @@ def test_fused_operator_list_is_bit_identical_to_decode_session(pkg, shape, wbit
         assert ids == want[t][1], f"step {t}: ids differ"
         assert torch.equal(h.logits(), want[t][0]), f"step {t}: logits are not bit-identical to DecodeSession"
     h.close()
+
+
+MOE_SMALL = dict(hidden=512, layers=2, n_heads=4, n_kv=2, head_dim=128, inter=512, vocab=2048)
+
+
+@pytest.mark.parametrize("group,batch,experts,top_k", [
+    (-1, 1, 8, 2),      # one request: GEMV kernels, routing and expert launches apart
+    (128, 3, 8, 2),     # grouped routing + combine (the 8-launch block), row-major shared-expert activations
+    (-1, 8, 16, 4),     # + the shared expert's SwiGLU output in FRAG32 for its down projection
+])
+def test_mixture_of_experts_list_is_bit_identical_to_decode_session(pkg, group, batch, experts, top_k):
+    """BASELINE configs[4] architecture through the operator API: the reference's MoE layer list (qwen_v20_moe.py:318-391,
+    tests/ref_graph.py) -> fusion pass -> DihipMoeBlock, against decoder.DecodeSession (context phase and decode steps, bit for
+    bit) and the unfused list (MOEA16W8, CalcExpert, UnaryGLU, Gemm ... one launch per reference operator) within bf16 rounding;
+    the context phase against the oracle decoding the prompt token by token."""
+    from dash_infer_amd import decoder
+    from tests.test_gpu_decoder import oracle_of
+    cfg = decoder.ModelConfig("moe-runner-test", **MOE_SMALL, moe=decoder.MoEConfig(experts, top_k, 256))
+    model = decoder.build_random_model(cfg, decoder.QuantSpec(8, group), seed=1357, keep_fp=True)
+    span, max_len, steps = 16, 64, 5
+    rng = np.random.default_rng(batch + experts)
+    lens = [int(x) for x in rng.integers(3, 24, batch)]
+    prompts = [[int(t) for t in rng.integers(0, cfg.vocab, n)] for n in lens]
+    sess = decoder.DecodeSession(model, batch, max_len=max_len, span_len=span, kv_mode="none")
+    lo0 = sess.prefill(prompts).clone()
+    ids0 = sess.ids.cpu().tolist()
+    want = []
+    for _ in range(steps):
+        sess.step()
+        torch.cuda.synchronize()
+        want.append((sess.logits.clone(), sess.ids.cpu().tolist()))
+    # the context phase of request 0 against the oracle (numpy, independent of the GPU) fed the prompt one token at a time
+    ref = oracle_of(model, "none")
+    for tok in prompts[0]:
+        lo_ref = ref.step(np.asarray([tok]))
+    tol = 1e-2 * max(1.0, float(np.abs(lo_ref).max()))
+    err = float(np.abs(lo0[0].cpu().numpy() - lo_ref[0]).max())
+    assert err <= tol, f"MoE context phase differs from the oracle by {err:.3e}"
+    h = Host(model, batch, max_len, span, "none")
+    assert h.report["fused"] and h.report["device_resident"] and h.report["layers"] == len(model.layers), h.report["why"]
+    assert h.report["types"].count("DihipMoeBlock") == len(model.layers) and "MOEA16W8" not in h.report["types"]
+    for b, pr in enumerate(prompts):
+        k, v = h.spans()
+        first = h.start(pr, k, v)
+        assert first == ids0[b], f"request {b}: first id {first} != {ids0[b]}"
+        assert torch.equal(h.logits()[0], lo0[b]), f"request {b}: context-phase logits are not bit-identical"
+    for t in range(steps):
+        ids = h.steps(1, graph=True)
+        assert ids == want[t][1], f"step {t}: ids differ"
+        assert torch.equal(h.logits(), want[t][0]), f"step {t}: logits are not bit-identical to DecodeSession"
+    h.close()
+    # the unfused list: every reference operator its own launch, 16-bit activations between them
+    u = Host(model, batch, max_len, span, "none", fuse=False)
+    assert not u.report["fused"] and "MOEA16W8" in u.report["types"] and "CalcExpert" in u.report["types"]
+    for b, pr in enumerate(prompts):
+        k, v = u.spans()
+        u.start(pr, k, v)
+    worst = 0.0
+    for t in range(2):
+        u.steps(1, graph=False)
+        lo_u = u.logits().float()
+        scale = max(1.0, float(want[t][0].abs().max()))
+        worst = max(worst, float((lo_u - want[t][0]).abs().max()) / scale)
+        if u.m.sync_ids() != want[t][1]:
+            break   # a near-tie resolved differently: the histories diverge from here on
+    assert worst <= 3e-2, f"unfused MoE list differs from the fused one by {worst:.3e} (relative to max |logit|)"
+    print(f"MoE host runner: context vs oracle {err:.2e}; unfused vs fused {worst:.2e}")
+    u.close()
 
 
 def test_fused_operator_list_f16_is_bit_identical_to_decode_session(pkg):

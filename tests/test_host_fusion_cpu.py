@@ -98,3 +98,42 @@ def test_split_k_lm_head_on_one_rank_keeps_the_reference_tail(model):
     r = model.graph_fuse_dry()
     assert r["fused"] and not r["device_resident"]
     assert r["types"][-5:] == ["DihipFinalNorm", "GetLastLine", "Gemm", "AllReduce", "GenerateOp"]
+
+
+def test_mixture_of_experts_layer_becomes_one_block_operator(pkg):
+    """qwen_v20_moe.py:318-391: the twelve feed-forward operators of a MoE layer -> DihipMoeBlock; the reference's two
+    all-reduces (MOE rows, CalcExpert rows) become ONE all-reduce of the f32 hidden rows behind the block"""
+    from dash_infer_amd import hostapi
+    m = hostapi.Model(None, 4, 2, 128, 16)
+    g = ref_graph.qwen2_graph(2, 8, 128, 1e-6, 4, 2, 1e6, moe=(8, 2))
+    assert len(g) == 1 + 2 * (6 + 10) + 4
+    ref_graph.add_graph(m, g)
+    r = m.graph_fuse_dry()
+    assert r["fused"] and r["device_resident"] and r["layers"] == 2, r["why"]
+    per_layer = ["DihipNormGemm", "DihipRopeSpanAttn", "DihipGemmAddTo", "DihipMoeBlock"]
+    assert r["types"] == ["DihipEmbedding"] + per_layer * 2 + ["DihipLMHead", "DihipGreedy"]
+    w = r["wiring"].split("|")
+    p = "decoder.layer.0."
+    assert w[3].startswith(f"DihipGemmAddTo({p}attention.out,embedding.out)->({p}attention_add.out)[")    # no norm handed on
+    assert w[4].startswith(f"DihipMoeBlock({p}attention_add.out)->({p}final_add.out)[{p}ffn.layernorm.gamma,{p}mlp.gate.weight,{p}mlp.experts.gate_up_proj.weight,")
+    assert w[4].endswith(f"{p}shared_expert.down_proj.weight.zeros,{p}shared_expert_gate.weight]") and w[4].count(",") == 14
+    assert w[5].startswith(f"DihipNormGemm({p}final_add.out)->")                                           # the next layer norms itself
+    m.close()
+    # expert parallelism on two ranks: AllReduce after the attention projection and ONE after the block
+    m = hostapi.Model(None, 4, 2, 128, 16, rank=1, nranks=2)
+    ref_graph.add_graph(m, ref_graph.qwen2_graph(1, 8, -1, 1e-6, 4, 2, 1e6, tp_allreduce=True, tp_lm_head=True, moe=(8, 2, True)))
+    r = m.graph_fuse_dry()
+    assert r["fused"] and not r["device_resident"], r["why"]
+    assert r["types"][:7] == ["DihipEmbedding", "DihipNormGemm", "DihipRopeSpanAttn", "DihipGemmAddTo", "AllReduce", "DihipMoeBlock", "AllReduce"]
+    w = r["wiring"].split("|")
+    assert w[6] == "AllReduce(decoder.layer.0.final_add.out)->(decoder.layer.0.final_add.out)[]"
+    m.close()
+    # a block the pass does not know (CalcExpert on other tensors) leaves the whole list alone
+    m = hostapi.Model(None, 4, 2, 128, 16)
+    g = ref_graph.qwen2_graph(1, 8, 128, 1e-6, 4, 2, 1e6, moe=(8, 2))
+    k = next(i for i, op in enumerate(g) if op[0] == "CalcExpert")
+    g[k] = (g[k][0], g[k][1], [g[k][2][1], g[k][2][0]], g[k][3], g[k][4], g[k][5])
+    ref_graph.add_graph(m, g)
+    r = m.graph_fuse_dry()
+    assert not r["fused"] and "CalcExpert" in r["why"], r["why"]
+    m.close()

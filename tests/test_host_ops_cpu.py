@@ -21,7 +21,7 @@ def test_op_registry(pkg):
                        "TransMask", "PreProcessId", "UpdateId", "PostProcessId"]   # graph head / tail (host/id_ops_hip.cpp)
     # + the fused decode-step operators the fusion pass rewrites that graph into (host/fused_ops_hip.cpp)
     fused_types = ["DihipEmbedding", "DihipNormGemm", "DihipRopeSpanAttn", "DihipGemmAddTo", "DihipNormSwiGLU", "DihipLMHead", "DihipGreedy",
-                   "DihipFinalNorm"]
+                   "DihipFinalNorm", "DihipMoeBlock"]
     assert sorted(t for t in ops if not t.startswith("Dihip")) == sorted(reference_types)
     assert sorted(t for t in ops if t.startswith("Dihip")) == sorted(fused_types)
 
