@@ -19,12 +19,31 @@
 // wave-private LDS (W4; W8 slices have twice the chunks and recompute it).
 // Arithmetic per element as in the other decode kernels (exact integer MFMA, scale / zero-point per group on
 // the f32 accumulator); a group that straddles two K-slices is closed in both with the same (scale, zero).
+//
+// Round 4 (what-if timing above KSL_WAVES' definition):
+//   * the activation fragments are loaded WITHOUT the nontemporal hint: 256 workgroups read the same 115 - 229 KB, and `nt`
+//     lines are the first to leave L2 (-2.3 us on the 7B gate/up pair at M = 32).  The loads are inline asm because a plain
+//     builtin load of read-only memory is rematerialised by hipcc right before its use;
+//   * tried and removed: an eighth wave WITHOUT a K-slice (K = 3584 has 7) that does the cross-slice sums and the epilogues, so
+//     that no streaming wave reaches the next barrier late by a reduction: +3 % stand-alone at M = 16, -5 % at M = 32 (one wave
+//     then runs both fragments' SwiGLU epilogues), and in the decode step 11.9k against 12.2k tokens/s (profiles/r04q_*);
+//   * tried and removed: the weight ring in LDS filled by LDS-DMA (global_load_lds_dwordx4; 8 KiB per wave in flight at M = 32
+//     instead of the 4 KiB the 128 activation registers leave) -- bit-identical, 3 - 7 % SLOWER (profiles/r04n_*): the extra
+//     LDS round trip per chunk costs more than the deeper ring gives, because the ring is not what the kernel waits for.
 #pragma once
 #include "gemm_panel_kernel.hpp"
 
 namespace dihip {
 
 constexpr int KSL_WAVES = 8;
+// what-if builds for timing (tools/build_ksl_variant.sh; results are WRONG with any bit set; never in the product build):
+//   1 no exchange / barrier / reduction   2 no dequantisation + MFMA (the slot is consumed by an XOR)   4 no activation loads
+// Round 4 at M = 32 on the 7B gate/up pair (profiles/r04o_kslice_whatif.txt; launch pair incl. the 4.5 us RMSNorm kernel):
+// 29.8 us as built; without (1) 25.0, (2) 27.0, (4) 22.1, all three 16.4 = the weights alone at 6.3 TB/s -- the parts add up,
+// i.e. nothing overlaps, and the activation fragments every workgroup pulls are the largest of them.
+#ifndef DIHIP_KSL_X
+#define DIHIP_KSL_X 0
+#endif
 
 template <int WBITS, int FT, int MT, int EPI, int GPT>
 __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const PanelArgs a) {
@@ -122,12 +141,27 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
   }
   // ---- this wave's activations: XS k-steps x MT row tiles, 1 KiB contiguous per fragment ----
   u32x4_t xf[XS][MT];
-  {
+  if (active) {
     const u32x4_t* xp = reinterpret_cast<const u32x4_t*>(a.x) + (size_t)kt0 * KSTEPS * MT * 64 + lane;
 #pragma unroll
     for (int i = 0; i < XS; ++i)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) xf[i][mt] = __builtin_nontemporal_load(xp + (size_t)(i * MT + mt) * 64);
+      for (int mt = 0; mt < MT; ++mt) {
+        if constexpr (DIHIP_KSL_X & 4) {
+          xf[i][mt] = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+          asm volatile("" : "+v"(xf[i][mt]));
+        } else {
+          // temporal (every workgroup re-reads these lines from L2), not rematerialisable
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xf[i][mt]) : "v"(xp + (size_t)(i * MT + mt) * 64) : "memory");
+        }
+      }
+    // hipcc does not count asm loads: one explicit wait (the sums below need every fragment, and the ring, requested
+    // earlier, has landed by then as well)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < XS; ++i)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(xf[i][mt]));
   }
   DIHIP_KSL_STAMP(1);  // ring + activation loads issued
   if (active) {
@@ -164,13 +198,17 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
           f32x4_t g[MT], xs[MT];
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) g[mt] = xs[mt] = zero4;
+          if constexpr (DIHIP_KSL_X & 2) {
+            g[0][0] = __uint_as_float((slot.w[0] ^ slot.w[1] ^ slot.w[2] ^ slot.w[3]) & 0x3FFFFFFFu);
+          } else {
 #pragma unroll
-          for (int ks = 0; ks < KSTEPS; ++ks) {
-            const u32x4_t bf = EX::frag(slot.w, ks, ex_mask, ex_magic);
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+              const u32x4_t bf = EX::frag(slot.w, ks, ex_mask, ex_magic);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              g[mt] = mfma16<FT>(xf[c * KSTEPS + ks][mt], bf, g[mt]);
-              if constexpr (!XS_LDS) xs[mt] = mfma16<FT>(xf[c * KSTEPS + ks][mt], ones, xs[mt]);  // Sum_k x[m][k] of the chunk
+              for (int mt = 0; mt < MT; ++mt) {
+                g[mt] = mfma16<FT>(xf[c * KSTEPS + ks][mt], bf, g[mt]);
+                if constexpr (!XS_LDS) xs[mt] = mfma16<FT>(xf[c * KSTEPS + ks][mt], ones, xs[mt]);  // Sum_k x[m][k] of the chunk
+              }
             }
           }
           if constexpr (XS_LDS)
@@ -208,11 +246,16 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
           load_slot(slot, c);
           __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (DIHIP_KSL_X & 1) {
+          if (tot[0][0] == 1.2345e-30f) a.slab[lane] = tot[MT - 1][1];  // keeps the sums alive
+        } else {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xch[p & 1][wave][hh][mt][lane] = tot[mt];
+          for (int mt = 0; mt < MT; ++mt) xch[p & 1][wave][hh][mt][lane] = tot[mt];
+        }
       }
     }
     if (p == 0) DIHIP_KSL_STAMP(3);  // first pair streamed
+    if constexpr (DIHIP_KSL_X & 1) continue;
     __syncthreads();  // the pair's slices are in xch[p & 1]; its previous use (pair p - 2) was reduced before barrier p - 1
     if (p == 0) DIHIP_KSL_STAMP(4);  // first barrier passed
     // ---- reduce over the K-slices in fixed order + epilogue: fragment f = (half, row tile) per wave ----
