@@ -73,6 +73,7 @@ _SIGS = {
     "dihip_span_attn_fused_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "dihip_span_attn_decode_fused": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz]),
     "dihip_span_attn_decode_fused_sync": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp, sz]),
+    "dihip_span_attn_decode_step": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp, sz, i32]),
     "dihip_span_attn_merge_partials": (i32, [vp, vp, vp, i32, i32, i32, i32]),
     "dihip_prefill_attn": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32]),
     "dihip_rmsnorm": (i32, [vp, vp, vp, vp, f32, i32, i32, i32]),

@@ -24,6 +24,7 @@
 
 #include "span_attn_common.hpp"
 #include "span_attn_ft_mfma.hpp"
+#include "span_codec.hpp"
 
 namespace dihip {
 
@@ -251,11 +252,28 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const At
 //       zero-points leave through  sum_t P'_t (128 + z_t)  with the SAME rounded P'.
 // Everything else (split partials, last-arriver merge) is the epilogue shared with the VALU kernel.
 
+// FUSED (round 4): the decode-step form, as span_attn_ft_mfma_kernel<.., FUSED> for the 16-bit cache.  a.q is the fused
+// pre-Rotary qkv row, a.seq_lens the tokens already cached (a.len_bias = 1).  Query heads are rotated in the prologue (cos / sin
+// from a.rope_tab; the rotate-half partner d +- 64 of a lane's dims lives in lane ^ 32); in the workgroup whose range holds the
+// new token ONE wave rotates + quantises this step's K head and quantises its V head with the span codec (span_codec.hpp:
+// byte-identical to rope_kv_append_kernel), into LDS and -- one writer per (request, group) -- from there into the span; the new
+// token is then one more (single-token) block of that wave after its loop over the cached ones, built from the LDS copy.
+// One launch instead of two per layer: the append kernel (896 one-wave workgroups at batch 32) cost 5 us of launch latency.
+// what-if timing builds (tools/build_ksl_variant.sh NAME -DDIHIP_U4_X=.. span_attn): 1 no Rotary of q, 2 no new token; results
+// WRONG.  Batch 32 x 2048 tokens (profiles/r04v_u4_step_whatif.txt): 21.7 us per layer as first built, 20.0 without (1), 20.4
+// without (2), 18.4 without both; the committed form (permlane swaps for the Rotary partner, one quantisation by the last
+// wave and no barrier) takes 20.5 against 22.7 for the append launch + the op-boundary kernel.
+#ifndef DIHIP_U4_X
+#define DIHIP_U4_X 0
+#endif
+template <bool FUSED>
 __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const AttnArgs a) {
   constexpr int H = 128;
   constexpr int HC = MF_HC;
   constexpr int HB = H / 2;  // bytes per token-head row
+  constexpr int NEW_WAVE = ATTN_THREADS / 64 - 1;  // FUSED: the wave that handles this step's token
   __shared__ __attribute__((aligned(16))) float lds[4 * HC * ATTN_PSTRIDE + 4];
+  __shared__ __attribute__((aligned(16))) unsigned char newrow[2][FUSED ? 80 : 16];  // FUSED: {64 B nibbles, zero, scale} of the new K / V head
   unsigned* flag_lds = reinterpret_cast<unsigned*>(lds + 4 * HC * ATTN_PSTRIDE);
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -270,7 +288,12 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
   const int len = (int)a.seq_lens[b] + a.len_bias;
   const int tps = ((len + a.nsplits - 1) / a.nsplits + 31) & ~31;
   const int t0 = split * tps;
-  const int t1 = min(len, t0 + tps);
+  // FUSED: the split that holds this step's token (the last position) walks the CACHED tokens [t0, len - 1) in the loop and takes
+  // the new one from registers at the end -- nothing inside the loop knows about it (a conditional patch of the loaded tiles
+  // made hipcc drain the load queue at the join of every iteration: the whole kernel 4.6 us slower)
+  const int newpos = len - 1;
+  const bool has_new = FUSED && !(DIHIP_U4_X & 2) && newpos >= t0 && newpos < t0 + tps;  // workgroup-uniform (all head chunks of the group)
+  int t1 = has_new ? newpos : min(len, t0 + tps);
   const void* const* ksp = a.kspans + (size_t)b * a.span_stride;
   const void* const* vsp = a.vspans + (size_t)b * a.span_stride;
   const size_t par_off = (size_t)a.g * a.S * HB;  // (zero, scale) pairs follow the data of all groups
@@ -328,12 +351,33 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
   // produces them (pairs (e, e+4)); unscaled, so the bf16 values are exact
   u32x4_t qf[4];
   float qsum = 0.f;
+  const size_t qrow_stride = FUSED ? (size_t)(a.n + 2 * a.g) * H : (size_t)a.n * H;
+  const float* cs_row = FUSED ? a.rope_tab + (size_t)newpos * 128 : nullptr;  // {cos, sin} of dim pairs 0 .. 63 at that position
   {
     const bool hv = ni < nh;
-    const uint16_t* qrow = reinterpret_cast<const uint16_t*>(a.q) + ((size_t)b * a.n + h0 + (hv ? ni : 0)) * H + kb * 32;
+    const uint16_t* qrow = reinterpret_cast<const uint16_t*>(a.q) + (size_t)b * qrow_stride + (size_t)(h0 + (hv ? ni : 0)) * H + kb * 32;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       u32x4_t raw = *reinterpret_cast<const u32x4_t*>(qrow + ks * 8);
+      if constexpr (FUSED && !(DIHIP_U4_X & 1)) {
+        // Rotary (rotate-half, rope_kv_append_kernel's arithmetic): dims kb*32 + ks*8 + 2j + e; the partner d +- 64 is lane ^ 32
+        u32x4_t rot;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(raw[j], raw[j], false, false);  // {lower half, upper half} in every lane: one VALU
+          const uint32_t pw = kb < 2 ? sw[1] : sw[0];                                          // instruction, not a ds_bpermute round trip
+          const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(cs_row + (size_t)((kb & 1) * 32 + ks * 8 + 2 * j) * 2);  // {c0, s0, c1, s1}
+          float r[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float x = ft_bits_to_f32<DIHIP_BF16>(e ? raw[j] >> 16 : raw[j] & 0xFFFFu);
+            const float pt = ft_bits_to_f32<DIHIP_BF16>(e ? pw >> 16 : pw & 0xFFFFu);
+            r[e] = kb < 2 ? x * cs[2 * e] - pt * cs[2 * e + 1] : x * cs[2 * e] + pt * cs[2 * e + 1];
+          }
+          rot[j] = f32_to_ft_bits<DIHIP_BF16>(r[0]) | (f32_to_ft_bits<DIHIP_BF16>(r[1]) << 16);
+        }
+        raw = rot;
+      }
       if (!hv) raw = u32x4_t{0u, 0u, 0u, 0u};
 #pragma unroll
       for (int j = 0; j < 4; ++j) qsum += ft_bits_to_f32<DIHIP_BF16>(raw[j] & 0xFFFFu) + ft_bits_to_f32<DIHIP_BF16>(raw[j] >> 16);
@@ -341,6 +385,48 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
                        (raw[1] & 0xFFFFu) | (raw[3] << 16), (raw[1] >> 16) | (raw[3] & 0xFFFF0000u)};
     }
     qsum = rows_sum(qsum);
+  }
+
+  // FUSED: this step's K (rotated, rounded, quantised) and V head of the group, as the cache will hold them
+  u32x4_t knew = {};
+  uint32_t vnew = 0u;
+  float knz = 0.f, kns = 0.f, vnz = 0.f, vns = 0.f;
+  if constexpr (FUSED) {
+    if (has_new && wave == NEW_WAVE) {
+      // one wave alone, K then V: lane holds d = 2 * lane, 2 * lane + 1 (the codec's element order).  No workgroup barrier: the
+      // other waves start their token loops at once, and this wave reads back what it wrote itself (LDS operations of a wave
+      // execute in order); its first K / V tiles are in flight meanwhile.  The LAST wave: it has the fewest 32-token blocks.
+      const int sp = newpos / a.S, pos = newpos - sp * a.S;
+      const bool writer = hc == 0 && sp < a.span_stride;  // one per (request, group): DecoderCacheAppend; a token past the span table is dropped, as kv_append_kernel does
+#pragma unroll
+      for (int kv = 0; kv < 2; ++kv) {
+        const uint16_t* row = reinterpret_cast<const uint16_t*>(a.q) + (size_t)b * qrow_stride + (size_t)(a.n + (kv ? a.g : 0) + grp) * H;
+        const uint32_t w = reinterpret_cast<const uint32_t*>(row)[lane];
+        float x[2] = {ft_bits_to_f32<DIHIP_BF16>(w & 0xFFFFu), ft_bits_to_f32<DIHIP_BF16>(w >> 16)};
+        if (kv == 0) {
+          const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(cs_row + (size_t)((2 * lane) & 63) * 2);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float pt = __shfl_xor(x[e], 32, 64);
+            const float r = lane < 32 ? x[e] * cs[2 * e] - pt * cs[2 * e + 1] : x[e] * cs[2 * e] + pt * cs[2 * e + 1];
+            x[e] = ft_round<DIHIP_BF16>(r);
+          }
+        }
+        store_token_head<DIHIP_BF16, DIHIP_KV_U4, 2>(newrow[kv], x, 0, 0, 1, 1, H, lane);  // a one-token "span": data, then {zero, scale}
+        if (writer) {  // the same bytes into the span: 64 B of nibbles + the parameter pair
+          unsigned char* span = reinterpret_cast<unsigned char*>(const_cast<void*>((kv ? vsp : ksp)[sp]));
+          const size_t rowi = (size_t)grp * a.S + pos;
+          if (lane < 16) gstore<uint32_t>(span + rowi * HB + lane * 4, reinterpret_cast<const uint32_t*>(newrow[kv])[lane]);
+          if (lane == 16) gstore<uint64_t>(span + par_off + rowi * 8, *reinterpret_cast<const uint64_t*>(newrow[kv] + HB));
+        }
+      }
+      knew = *reinterpret_cast<const u32x4_t*>(newrow[0] + kb * 16);
+      knz = reinterpret_cast<const float*>(newrow[0] + HB)[0];
+      kns = reinterpret_cast<const float*>(newrow[0] + HB)[1];
+      vnew = reinterpret_cast<const uint32_t*>(newrow[1])[ni];
+      vnz = reinterpret_cast<const float*>(newrow[1] + HB)[0];
+      vns = reinterpret_cast<const float*>(newrow[1] + HB)[1];
+    }
   }
 
   const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -450,6 +536,25 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
       if (tb == tb0) DIHIP_U4_STAMP(2);  // first 32 tokens done
       issue(ba, tb + 2 * STEP);
       if (tb + STEP < t1) process(bb, tb + STEP);
+    }
+  }
+  if constexpr (FUSED) {
+    if (has_new && wave == NEW_WAVE) {
+      // this step's token as a block of its own: token 0 of tile 0 is (row ni = 0, parameters / V dwords of the lanes kb = 0, rr = 0),
+      // every other token of the block is masked (t1 = newpos + 1)
+      Buf bn;
+      bn.k[0] = bn.k[1] = knew;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          bn.kp[c][hh] = f32x4_t{knz, kns, knz, kns};
+          bn.vp[c][hh] = f32x4_t{vnz, vns, vnz, vns};
+        }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bn.v[j] = vnew;
+      t1 = newpos + 1;
+      process(bn, newpos);
     }
   }
   DIHIP_U4_STAMP(3);  // token loop done
@@ -602,7 +707,7 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
   a.trace = debug_trace_buffer((size_t)p.nsplits * g * p.nchunks * batch * 32 * sizeof(unsigned long long));
   bool ok = true;
   if (p.mfma && mode == DIHIP_KV_U4) {
-    hipLaunchKernelGGL(span_attn_u4_mfma_kernel, grid, dim3(ATTN_THREADS), 0, s, a);
+    hipLaunchKernelGGL(span_attn_u4_mfma_kernel<false>, grid, dim3(ATTN_THREADS), 0, s, a);
   } else if (p.mfma && dtype == DIHIP_BF16 && mode == DIHIP_KV_NONE) {
     hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_NONE, false>), grid, dim3(ATTN_THREADS), 0, s, a);
   } else if (p.mfma && dtype == DIHIP_F16 && mode == DIHIP_KV_NONE) {
@@ -655,9 +760,12 @@ size_t span_attn_fused_mfma_workspace_bytes(int batch, int n_heads, int n_groups
 int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* const* k_span_array, void* const* v_span_array,
                          const uint32_t* old_seq_lens_dev, const float* rope_table, int batch, int n_heads, int n_groups,
                          int span_len, int n_spans_per_request, int max_seq_len, int kv_mode, int dtype, float qk_scale, void* ws,
-                         size_t ws_bytes, bool* handled, void* sync, size_t sync_bytes) {
+                         size_t ws_bytes, bool* handled, void* sync, size_t sync_bytes, int out_layout) {
   *handled = false;
-  if (kv_mode != DIHIP_KV_NONE || !attn_use_mfma(kv_mode, dtype)) return DIHIP_SUCCESS;
+  // 16-bit cache (bf16 / f16) and uint4 cache with bf16 activations; the int8 cache keeps its append launch
+  const bool u4 = kv_mode == DIHIP_KV_U4 && dtype == DIHIP_BF16;
+  if ((kv_mode != DIHIP_KV_NONE && !u4) || !attn_use_mfma(kv_mode, dtype)) return DIHIP_SUCCESS;
+  if (out_layout == DIHIP_ACT_FRAG32 && (!u4 || batch > 32)) return DIHIP_SUCCESS;  // (the 16-bit form writes row-major rows)
   const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true);
   if (p.nsplits > 1 && (ws == nullptr || ws_bytes < p.partial_bytes)) return DIHIP_SUCCESS;  // caller's kernels size their own
   *handled = true;
@@ -686,7 +794,11 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
     const char* m = getenv("DIHIP_ATTN_MERGE");
     return (m && m[0] == 'l') ? 0 : (m && m[0] == 'n') ? 2 : 1;  // "none" (timing experiments only): partials written, never merged
   }();
-  if (static_tps) a.tps_static = ((max_seq_len + p.nsplits - 1) / p.nsplits + 31) & ~31;
+  if (static_tps && !u4) a.tps_static = ((max_seq_len + p.nsplits - 1) / p.nsplits + 31) & ~31;  // (the uint4 kernel splits by the request's length)
+  if (u4) {
+    a.len_bias = 1;
+    a.out_frag_mt = out_layout == DIHIP_ACT_FRAG32 ? (batch > 16 ? 2 : 1) : 0;
+  }
   // in-launch merge: needs the caller's zero-initialised ticket words (dihip_span_attn_decode_fused_sync)
   const bool merge_wt = merge_mode == 1 && p.nsplits > 1 && sync != nullptr &&
                         sync_bytes >= (size_t)batch * n_groups * p.nchunks * 128 && p.partial_bytes < (1ull << 31);
@@ -696,14 +808,16 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
   }
   const dim3 grid(p.nsplits, n_groups * p.nchunks, batch);
   a.trace = debug_trace_buffer((size_t)p.nsplits * n_groups * p.nchunks * batch * 32 * sizeof(unsigned long long));
-  if (dtype == DIHIP_BF16)
+  if (u4)
+    hipLaunchKernelGGL(span_attn_u4_mfma_kernel<true>, grid, dim3(ATTN_THREADS), 0, s, a);
+  else if (dtype == DIHIP_BF16)
     hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_NONE, true>), grid, dim3(ATTN_THREADS), 0, s, a);
   else
     hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_F16, DIHIP_KV_NONE, true>), grid, dim3(ATTN_THREADS), 0, s, a);
   if (p.nsplits > 1 && !merge_wt && merge_mode != 2) {
     const dim3 mg(batch * n_heads), mb(128);
     if (dtype == DIHIP_BF16)
-      hipLaunchKernelGGL(span_attn_split_merge_kernel<DIHIP_BF16>, mg, mb, 0, s, output, a.partials, n_heads, p.nsplits, 0);
+      hipLaunchKernelGGL(span_attn_split_merge_kernel<DIHIP_BF16>, mg, mb, 0, s, output, a.partials, n_heads, p.nsplits, a.out_frag_mt);
     else
       hipLaunchKernelGGL(span_attn_split_merge_kernel<DIHIP_F16>, mg, mb, 0, s, output, a.partials, n_heads, p.nsplits, 0);
   }

@@ -42,7 +42,7 @@ struct AttnArgs {
 int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* const* k_span_array, void* const* v_span_array,
                          const uint32_t* old_seq_lens_dev, const float* rope_table, int batch, int n_heads, int n_groups,
                          int span_len, int n_spans_per_request, int max_seq_len, int kv_mode, int dtype, float qk_scale, void* ws,
-                         size_t ws_bytes, bool* handled, void* sync = nullptr, size_t sync_bytes = 0);
+                         size_t ws_bytes, bool* handled, void* sync = nullptr, size_t sync_bytes = 0, int out_layout = 0);
 size_t span_attn_fused_mfma_workspace_bytes(int batch, int n_heads, int n_groups, int max_seq_len);
 // the op-boundary decode kernels (span_attn.hip: run_decode) on lengths seq_lens[b] + len_bias; returns a DIHIP status
 int span_attn_decode_biased(void* stream, void* output, const void* query, const void* const* k_span_array,

@@ -79,6 +79,16 @@ int dihip_span_attn_decode_fused_sync(void* stream, void* output, const void* qk
                                       int batch, int n_heads, int n_groups, int head_size, int span_len,
                                       int n_spans_per_request, int max_seq_len, int kv_mode, int dtype, float qk_scale, void* ws,
                                       size_t ws_bytes, void* sync, size_t sync_bytes) {
+  return dihip_span_attn_decode_step(stream, output, qkv, k_span_array, v_span_array, old_seq_lens_dev, rope_table, batch, n_heads,
+                                     n_groups, head_size, span_len, n_spans_per_request, max_seq_len, kv_mode, dtype, qk_scale, ws,
+                                     ws_bytes, sync, sync_bytes, DIHIP_ACT_ROWMAJOR);
+}
+
+int dihip_span_attn_decode_step(void* stream, void* output, const void* qkv, void* const* k_span_array,
+                                void* const* v_span_array, const uint32_t* old_seq_lens_dev, const float* rope_table, int batch,
+                                int n_heads, int n_groups, int head_size, int span_len, int n_spans_per_request, int max_seq_len,
+                                int kv_mode, int dtype, float qk_scale, void* ws, size_t ws_bytes, void* sync, size_t sync_bytes,
+                                int out_layout) {
   DIHIP_REQUIRE(batch >= 0 && n_heads > 0 && n_groups > 0 && n_spans_per_request > 0 && max_seq_len > 0, DIHIP_PARAM_ERROR,
                 "span_attn_decode_fused: invalid parameter");
   DIHIP_REQUIRE(output && qkv && k_span_array && v_span_array && old_seq_lens_dev && rope_table, DIHIP_PARAM_ERROR,
@@ -93,7 +103,21 @@ int dihip_span_attn_decode_fused_sync(void* stream, void* output, const void* qk
   DIHIP_REQUIRE(kv_mode == DIHIP_KV_NONE || kv_mode == DIHIP_KV_I8 || kv_mode == DIHIP_KV_U4, DIHIP_PARAM_ERROR,
                 "span_attn_decode_fused: unsupported kv mode %d", kv_mode);
   DIHIP_REQUIRE((reinterpret_cast<uintptr_t>(qkv) & 15) == 0, DIHIP_PARAM_ERROR, "span_attn_decode_fused: qkv must be 16-byte aligned");
+  DIHIP_REQUIRE(out_layout == DIHIP_ACT_ROWMAJOR || out_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "span_attn_decode_step: bad out_layout");
   if (batch == 0) return DIHIP_SUCCESS;
+  if (kv_mode == DIHIP_KV_U4) {
+    // uint4 cache, bf16 activations: one launch as well (span_attn_u4_mfma_kernel<FUSED>); otherwise the two launches below
+    static const bool two_launches = env_off("DIHIP_ATTN_U4_FUSED");  // =0: the append launch + the op-boundary kernel (A/B)
+    if (!two_launches) {
+      bool handled = false;
+      const int st = span_attn_fused_mfma(stream, output, qkv, k_span_array, v_span_array, old_seq_lens_dev, rope_table, batch,
+                                          n_heads, n_groups, span_len, n_spans_per_request, max_seq_len, kv_mode, dtype, qk_scale,
+                                          ws, ws_bytes, &handled, sync, sync_bytes, out_layout);
+      if (handled) return st;
+    }
+  }
+  DIHIP_REQUIRE(out_layout == DIHIP_ACT_ROWMAJOR, DIHIP_PARAM_ERROR,
+                "span_attn_decode_step: FRAG32 output is served by the one-launch uint4 form only (bf16 activations, batch <= 32)");
   if (kv_mode == DIHIP_KV_NONE) {
     // 16-bit cache: one launch, both contractions on the matrix cores (span_attn.hip); 10.7 vs 15.5 us per layer at batch 1
     bool handled = false;

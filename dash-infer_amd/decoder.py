@@ -567,6 +567,9 @@ class DecodeSession:
         # cores, at every batch size.  Quantised caches: the quantising append launch, then the matrix-core decode kernels
         # (dihip_span_attn_decode_fused would issue the same two launches; the explicit pair also has the FRAG32 output).
         self.fused_attention = kv_mode == "none"
+        # uint4 cache with bf16 rows (round 4): one launch as well, FRAG32 output included (dihip_span_attn_decode_step);
+        # DIHIP_ATTN_U4_FUSED=0 keeps the append launch (A/B)
+        self.step_attention = kv_mode == "u4" and dt == torch.bfloat16 and os.environ.get("DIHIP_ATTN_U4_FUSED", "1") != "0"
         # split sequences: the partial records are merged inside the attention launch (arrival tickets in attn_sync, zeroed
         # once) instead of by a second launch; DIHIP_DECODER_ATTN_MERGE=launch restores the two-launch form (A/B)
         self.attn_merge_in_launch = os.environ.get("DIHIP_DECODER_ATTN_MERGE", "ticket") != "launch"
@@ -722,6 +725,10 @@ class DecodeSession:
             ops.span_attn_decode_fused(self.qkv, self.kv[li], self.old_lens, self.rope_tab, self.n_loc, self.g_loc, self.H,
                                        self.max_len, self.scale, self.attn_ws, out=self.attn,
                                        sync=self.attn_sync if self.attn_merge_in_launch else None)
+        elif self.step_attention:
+            ops.span_attn_decode_step(self.qkv, self.kv[li], self.old_lens, self.rope_tab, self.n_loc, self.g_loc, self.H, self.max_len,
+                                      self.scale, self.attn_ws, self.attn_sync if self.attn_merge_in_launch else None, out=self.attn,
+                                      out_layout=ops.ACT_FRAG32 if self.attn_frag else ops.ACT_ROWMAJOR)
         else:
             ops.rope_kv_append(self.kv[li], self.q, self.qkv, self.old_lens, self.inv_freq, self.n_loc, self.g_loc, self.H)
             ops.span_attn_decode(self.q, self.kv[li], self.new_lens, self.n_loc, self.g_loc, self.H, self.max_len,

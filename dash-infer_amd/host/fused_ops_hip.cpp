@@ -505,6 +505,14 @@ class DihipRopeSpanAttnOp : public SpanAttnOpHIP {
                                                          aws->GetDataPtr(), aws->GetSizeInByte(), merge_in_launch ? sy->GetDataPtr() : nullptr,
                                                          merge_in_launch ? sy->GetSizeInByte() : 0));
     }
+    static const bool u4_step = env_on("DIHIP_ATTN_U4_FUSED", true);  // decoder.DecodeSession.step_attention
+    if (kv_mode_ == DIHIP_KV_U4 && dtype_ == BFLOAT16 && u4_step) {
+      // uint4 cache, bf16 rows: one launch as well (Rotary + quantising append + attention + merge), FRAG32 output included
+      return FromDihip(dihip_span_attn_decode_step(Stream(), out, qkv, kd, vd, old_lens, (const float*)tensor_map_->at("dihip.rope_table")->GetDataPtr(),
+                                                   batch_, n_, g_, h_, span_, max_spans_, max_len, kv_mode_, DihipDtype(dtype_), alpha_,
+                                                   aws->GetDataPtr(), aws->GetSizeInByte(), merge_in_launch ? sy->GetDataPtr() : nullptr,
+                                                   merge_in_launch ? sy->GetSizeInByte() : 0, out_layout_));
+    }
     AS_CHECK_STATUS(FromDihip(dihip_rope_kv_append(Stream(), kd, vd, q_dev_->GetDataPtr(), qkv, old_lens,
                                                    (const float*)tensor_map_->at("dihip.inv_freq")->GetDataPtr(), batch_, n_, g_, h_, span_,
                                                    max_spans_, kv_mode_, DihipDtype(dtype_))));

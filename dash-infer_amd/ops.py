@@ -441,6 +441,21 @@ def span_attn_decode_fused(qkv, kv, old_lens_dev, rope_tab, n, g, H, max_len, sc
     return out
 
 
+def span_attn_decode_step(qkv, kv, old_lens_dev, rope_tab, n, g, H, max_len, scale, ws, sync, out=None, out_layout=ACT_ROWMAJOR):
+    """span_attn_decode_fused with the output layout of span_attn_decode: the uint4 cache (bf16 rows) is one launch too --
+    Rotary, the quantising append and the attention -- and may write the o projection's FRAG32 layout."""
+    B = qkv.shape[0]
+    if out is None:
+        out = (torch.zeros(act_frag_numel(B, n * H), dtype=qkv.dtype, device=qkv.device) if out_layout == ACT_FRAG32
+               else torch.empty(B, n * H, dtype=qkv.dtype, device=qkv.device))
+    pool = kv.pool
+    check(lib().dihip_span_attn_decode_step(cur_stream(), ptr(out), ptr(qkv), ptr(kv.k_ptrs), ptr(kv.v_ptrs), ptr(old_lens_dev), ptr(rope_tab),
+                                            B, n, g, H, pool.S, kv.max_spans, max_len, capi.KV[pool.mode], dt_code(qkv), float(scale),
+                                            ptr(ws), ws.numel(), ptr(sync), sync.numel() if sync is not None else 0, int(out_layout)),
+          "dihip_span_attn_decode_step")
+    return out
+
+
 def span_attn_merge_partials(partials, batch, n, nsplits, dtype=torch.bfloat16):
     out = torch.empty(batch, n * 128, dtype=dtype, device=partials.device)
     check(lib().dihip_span_attn_merge_partials(cur_stream(), ptr(out), ptr(partials), batch, n, nsplits, dt_code(dtype)),

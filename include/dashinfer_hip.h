@@ -348,6 +348,15 @@ int dihip_span_attn_decode_fused_sync(void* stream, void* output, const void* qk
                                       int head_size, int span_len, int n_spans_per_request, int max_seq_len,
                                       int kv_mode, int dtype, float qk_scale, void* ws, size_t ws_bytes,
                                       void* sync, size_t sync_bytes);
+/* The same with the output layout of dihip_span_attn_decode_sync (DIHIP_ACT_ROWMAJOR / DIHIP_ACT_FRAG32).  Round 4: the uint4
+ * cache with bf16 activations is ONE launch as well -- Rotary, the quantising DecoderCacheAppend of the new token (byte-identical
+ * to dihip_rope_kv_append) and the attention with its split merge -- instead of the append launch + the op-boundary kernel;
+ * FRAG32 output is served by that form only (batch <= 32).  Workspace / sync as dihip_span_attn_decode_fused_sync. */
+int dihip_span_attn_decode_step(void* stream, void* output, const void* qkv, void* const* k_span_array,
+                                void* const* v_span_array, const uint32_t* old_seq_lens_dev, const float* rope_table,
+                                int batch, int n_heads, int n_groups, int head_size, int span_len,
+                                int n_spans_per_request, int max_seq_len, int kv_mode, int dtype, float qk_scale,
+                                void* ws, size_t ws_bytes, void* sync, size_t sync_bytes, int out_layout);
 
 /* merge of the per-split partial records  f32 [batch * n_heads][nsplits][132] = { o[128] (unnormalised), m, l, pad }  of a
  * decode attention launch into the FT [batch, n_heads * 128] output (the second launch of 3b) */

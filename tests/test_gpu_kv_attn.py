@@ -355,6 +355,72 @@ def test_fused_rope_append_attention_matches_separate_ops(ops, n, g, S, lens, mo
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,g,S,lens", [(28, 4, 128, [2048, 0, 1, 127, 128, 129, 1000, 2047] * 4),        # configs[2]: batch 32, GQA 7
+                                        (14, 2, 32, [0, 1, 30, 31, 32, 33, 63, 64, 500]), (8, 8, 16, [15, 16, 17, 300]),
+                                        (40, 2, 64, [1000, 64]),                                          # 20 heads per group: two head chunks share a KV head
+                                        (4, 1, 16, [0]), (3, 1, 128, [2048, 77, 5])])
+def test_u4_decode_step_matches_append_plus_attention(ops, n, g, S, lens):
+    """dihip_span_attn_decode_step on the uint4 cache (round 4: Rotary + quantising append + attention in ONE launch,
+    span_attn_u4_mfma_kernel<FUSED>) against dihip_rope_kv_append + dihip_span_attn_decode_sync: the spans BYTE-identical; the
+    output equal to the rounding of one bf16 ulp (the new token -- dequantised from exactly the bytes the cache receives -- joins
+    the online softmax as a block of its own after the cached ones: another order of the same sums); row-major and FRAG32 forms
+    of the step bit-identical to each other."""
+    from oracle import glue
+    seed = n * 31 + S + len(lens)
+    H, ft, mode = 128, "bf16", "u4"
+    B = len(lens)
+    pool, kv, _, _ = build_batch(ops, np.random.default_rng(seed), lens, n, g, H, S, mode, ft, extra_tokens=2)
+    pool2, kv2, _, _ = build_batch(ops, np.random.default_rng(seed), lens, n, g, H, S, mode, ft, extra_tokens=2)
+    pool3, kv3, _, _ = build_batch(ops, np.random.default_rng(seed), lens, n, g, H, S, mode, ft, extra_tokens=2)
+    rng = np.random.default_rng(seed + 1)
+    qkv = rng.normal(0, 1, (B, (n + 2 * g) * H)).astype(np.float32)
+    qkv[0, (n + g) * H: (n + g + 1) * H] = np.linspace(-2, -1, H)        # all-negative V head: the zero-point clamps at 15
+    qkv[-1, n * H: (n + 1) * H] = 0.5                                    # constant K head: scale at its floor
+    qkv = dev(bf16_round(qkv), ft)
+    inv_d = torch.from_numpy(glue.rope_inv_freq(H, 1000000.0)).cuda()
+    old = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    scale = 1.0 / np.sqrt(H)
+    max_len = max(lens) + 1
+    tab = ops.rope_table(inv_d, max_len + 3, H)
+    ws = torch.empty(max(ops.span_attn_workspace(B, n, H, max_len), ops.span_attn_fused_workspace(B, n, g, H, max_len), 256),
+                     dtype=torch.uint8, device="cuda")
+    sync = torch.zeros(int(ops.lib().dihip_span_attn_sync_bytes(B, n)), dtype=torch.uint8, device="cuda")
+    q_out = torch.empty(B, n * H, dtype=torch.bfloat16, device="cuda")
+    ops.rope_kv_append(kv, q_out, qkv, old, inv_d, n, g, H)
+    ref = ops.span_attn_decode(q_out, kv, old + 1, n, g, H, max_len, scale, ws, sync).clone()
+    ws.fill_(0x5A)
+    got = ops.span_attn_decode_step(qkv, kv2, old, tab, n, g, H, max_len, scale, ws, sync).clone()
+    torch.cuda.synchronize()
+    assert int(sync.view(torch.int32).abs().sum()) == 0, "ticket words must be zero after the launch"
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref.float().cpu().numpy(), rtol=8e-3, atol=2e-3,
+                               err_msg="one-launch uint4 step differs from append + attention")
+    for b in range(B):
+        for i in range(len(kv.k_idx[b])):
+            assert torch.equal(pool.span_view(kv.k_idx[b][i]), pool2.span_view(kv2.k_idx[b][i])), f"K span {b}/{i}"
+            assert torch.equal(pool.span_view(kv.v_idx[b][i]), pool2.span_view(kv2.v_idx[b][i])), f"V span {b}/{i}"
+    if B <= 32:
+        fr = ops.span_attn_decode_step(qkv, kv3, old, tab, n, g, H, max_len, scale, ws, sync, out_layout=ops.ACT_FRAG32)
+        torch.cuda.synchronize()
+        assert torch.equal(ops.act_from_frag(fr, B, n * H).view(torch.int16), got.view(torch.int16)), "FRAG32 output"
+    # the same step again on the grown cache (lengths + 1): the appended rows are read back from the spans this time
+    old2 = old + 1
+    qkv2 = dev(bf16_round(rng.normal(0, 1, (B, (n + 2 * g) * H)).astype(np.float32)), ft)
+    tab2 = ops.rope_table(inv_d, max_len + 4, H)
+    pool_ok = all(len(kv.k_idx[b]) * S > lens[b] + 1 for b in range(B))
+    if pool_ok:
+        ops.rope_kv_append(kv, q_out, qkv2, old2, inv_d, n, g, H)
+        ws_b = torch.empty(max(ops.span_attn_workspace(B, n, H, max_len + 1), ops.span_attn_fused_workspace(B, n, g, H, max_len + 1), 256),
+                           dtype=torch.uint8, device="cuda")
+        ref2 = ops.span_attn_decode(q_out, kv, old2 + 1, n, g, H, max_len + 1, scale, ws_b, sync).clone()
+        got2 = ops.span_attn_decode_step(qkv2, kv2, old2, tab2, n, g, H, max_len + 1, scale, ws_b, sync)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(got2.float().cpu().numpy(), ref2.float().cpu().numpy(), rtol=8e-3, atol=2e-3, err_msg="second step")
+        for b in range(B):
+            for i in range(len(kv.k_idx[b])):
+                assert torch.equal(pool.span_view(kv.k_idx[b][i]), pool2.span_view(kv2.k_idx[b][i])), f"K span {b}/{i} after step 2"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["none", "u4"])
 @pytest.mark.parametrize("B", [5, 24])
 def test_span_attention_frag32_output(ops, mode, B):
