@@ -115,7 +115,8 @@ __global__ __launch_bounds__(PANEL_THREADS) void gemm_panel_kernel(const PanelAr
     wp[v] = (v ? a.w1 : a.w0) + ((size_t)tile * a.KT + kt0) * 64 + lane;
     sp[v] = (v ? a.sz1 : a.sz0) + (size_t)tile * a.Gp * 16 + ni;
   }
-  const u32x4_t* xp = reinterpret_cast<const u32x4_t*>(a.x) + ((size_t)kt0 * NF + (wave % NF)) * 64 + lane;
+  const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)((size_t)a.KT * NF * 1024), 0x00020000);
+  const uint32_t xoff = (uint32_t)(((size_t)kt0 * NF + (wave % NF)) * 64 + lane) * 16u;
   auto load_slot = [&](Slot& r, int t) {
     const int tt = min(t, nk - 1);  // past the slice: a valid re-load (unconditional loads keep hipcc's vmcnt counting exact)
 #pragma unroll
@@ -126,7 +127,9 @@ __global__ __launch_bounds__(PANEL_THREADS) void gemm_panel_kernel(const PanelAr
       // right before its use instead of keeping it in the ring, and waits vmcnt(0) for it)
       r.s[v] = __builtin_nontemporal_load(sp[v] + (size_t)(GPT ? kt : (subc ? kt / a.ktpg : 0)) * 16);
     }
-    r.x = __builtin_nontemporal_load(xp + (size_t)tt * NF * 64);
+    // the activation k-tile is read by every panel (and K-slice) of the launch: a TEMPORAL load (round 4: `nt` lines are the first
+    // to leave L2), as a buffer load so that hipcc neither rematerialises it nor loses count of it
+    r.x = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xoff + (uint32_t)tt * (NF * 1024u), 0, 0));
   };
 
   const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
