@@ -497,6 +497,12 @@ def kernel_breakdown(sess, torch, ops, iters=5):
               lambda li, lw: ops.span_attn_decode_fused(sess.qkv, sess.kv[li], sess.old_lens, sess.rope_tab, sess.n_loc, sess.g_loc,
                                                         sess.H, sess.max_len, sess.scale, sess.attn_ws, out=sess.attn,
                                                         sync=sess.attn_sync if sess.attn_merge_in_launch else None))
+    elif getattr(sess, "step_attention", False):   # uint4 cache, bf16 rows: one launch (dihip_span_attn_decode_step)
+        timed("rope_append_span_attention", B * 2 * sess.g_loc * SEQ_LEN * kvb,
+              lambda li, lw: ops.span_attn_decode_step(sess.qkv, sess.kv[li], sess.old_lens, sess.rope_tab, sess.n_loc, sess.g_loc, sess.H,
+                                                       sess.max_len, sess.scale, sess.attn_ws,
+                                                       sess.attn_sync if sess.attn_merge_in_launch else None, out=sess.attn,
+                                                       out_layout=ops.ACT_FRAG32 if sess.attn_frag else ops.ACT_ROWMAJOR))
     else:
         def sep(li, lw):
             ops.rope_kv_append(sess.kv[li], sess.q, sess.qkv, sess.old_lens, sess.inv_freq, sess.n_loc, sess.g_loc, sess.H)
