@@ -259,10 +259,14 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_decode_kernel(const At
 // byte-identical to rope_kv_append_kernel), into LDS and -- one writer per (request, group) -- from there into the span; the new
 // token is then one more (single-token) block of that wave after its loop over the cached ones, built from the LDS copy.
 // One launch instead of two per layer: the append kernel (896 one-wave workgroups at batch 32) cost 5 us of launch latency.
-// what-if timing builds (tools/build_ksl_variant.sh NAME -DDIHIP_U4_X=.. span_attn): 1 no Rotary of q, 2 no new token; results
+// what-if timing builds (tools/build_ksl_variant.sh NAME -DDIHIP_U4_X=.. span_attn): 1 no Rotary of q, 2 no new token, 4 loads only
+// (no arithmetic in the token loop), 8 no V^T . P' half; results
 // WRONG.  Batch 32 x 2048 tokens (profiles/r04v_u4_step_whatif.txt): 21.7 us per layer as first built, 20.0 without (1), 20.4
 // without (2), 18.4 without both; the committed form (permlane swaps for the Rotary partner, one quantisation by the last
-// wave and no barrier) takes 20.5 against 22.7 for the append launch + the op-boundary kernel.
+// wave and no barrier) takes 20.5 against 22.7 for the append launch + the op-boundary kernel.  The op-boundary kernel itself
+// (profiles/r04ab_*): 19.3 us as built, 16.0 without the V^T . P' half, 14.9 with NO arithmetic in the token loop -- three
+// quarters of it is launch, the length -> span pointer -> data chain, 147 KB per CU at what a CU can keep in flight, and the
+// split hand-off; the nibble arithmetic that looks expensive (~300 VALU per 32 tokens) is the smaller part.
 #ifndef DIHIP_U4_X
 #define DIHIP_U4_X 0
 #endif
@@ -436,6 +440,15 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
   for (int dt = 0; dt < 8; ++dt) o[dt] = zero4;
 
   auto process = [&](const Buf& r, int tb) {
+    if constexpr ((DIHIP_U4_X & 4) != 0) {  // what-if: loads only
+      uint32_t x = r.k[0][0] ^ r.k[0][1] ^ r.k[0][2] ^ r.k[0][3] ^ r.k[1][0] ^ r.k[1][1] ^ r.k[1][2] ^ r.k[1][3];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x ^= r.v[j];
+      x ^= __float_as_uint(r.kp[0][0][0] + r.kp[0][1][0] + r.kp[1][0][0] + r.kp[1][1][0] + r.vp[0][0][0] + r.vp[0][1][0] + r.vp[1][0][0] + r.vp[1][1][0]);
+      l += __uint_as_float(x & 0x3FFFFFFFu);
+      m = 0.f;
+      return;
+    }
     // ---- scores of the 32 tokens (transposed): sc[c][r] = token tb + c*16 + kb*4 + r, head ni
     float sc[2][4];
 #pragma unroll
@@ -500,6 +513,10 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
       for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) o[dt][rr] *= corr;
+    }
+    if constexpr ((DIHIP_U4_X & 8) != 0) {  // what-if: no V^T . P' half
+      o[0][0] += __uint_as_float((pk[0] ^ pl[1] ^ r.v[0] ^ r.v[5]) & 0x3FFFFFFFu);
+      return;
     }
     // ---- O^T += V^T . P': k-slot j = token (j>>2)*16 + kb*4 + (j&3) on both operands
     uint32_t le[4], lo_[4], he[4], ho[4];
