@@ -191,7 +191,7 @@ def cpu_baseline_torch(wbits, group, seq_len=SEQ_LEN, budget_s=15.0, weights="bf
                 break
     except OSError:
         cpu_model = platform.processor()
-    return {"value": round(1.0 / med, 3), "unit": "tokens/s", "cores": best[1], "kind": "oneDNN-stand-in", "weights": weights,
+    return {"value": round(1.0 / med, 3), "unit": "tokens/s", "cores": best[1], "kind": "port", "port_of": "the reference's x86 decode graph on the libraries its CPU operators call (oneDNN / MKL via PyTorch-CPU): a stand-in, the reference's own x86 build needs LFS-stubbed libraries", "weights": weights,
             "library": f"PyTorch-CPU {torch.__version__} (oneDNN / MKL), torch.set_num_threads({best[1]}) of {cores} logical CPUs; {cpu_model}",
             "sample": f"whole Qwen2-7B decode step at batch 1, seq {seq_len}: 28 x [RMSNorm, qkv bf16 GEMV + bias, RoPE, GQA attention over "
                       f"{seq_len + 1} cached tokens (f32), o GEMV + residual, RMSNorm, gate/up GEMV + SwiGLU, down GEMV + residual] over "
