@@ -49,6 +49,14 @@
 
 namespace dihip {
 
+// what-if timing builds (tools/build_ksl_variant.sh NAME -DDIHIP_PF_X=.. gemm_prefill_inst; results WRONG with any bit set):
+//   1 no scale / zero-point fix-up   2 no A staging (LDS keeps what the prologue wrote)   4 no barrier   8 no nibble expansion
+// Round 4, the SwiGLU GEMM of a 2048-token prompt (profiles/r04af_*): 676 us as built (822 TFLOP/s); 645 without (1), 597 without (2),
+// 649 without (4), 654 without (8); 459 without all four (1 212 TFLOP/s = 48 % of the dense peak): the bare LDS-read + MFMA loop
+// of this tile shape is the ceiling, and the A staging (registers -> ds_write + the row-sum MFMAs) is the largest single extra.
+#ifndef DIHIP_PF_X
+#define DIHIP_PF_X 0
+#endif
 constexpr int PF_WAVES = 8;
 constexpr int PF_THREADS = PF_WAVES * 64;
 constexpr int PF_BM = 128;           // rows per workgroup (8 row tiles)
@@ -213,7 +221,10 @@ __global__ __launch_bounds__(PF_THREADS, 2) void gemm_prefill_kernel(const Prefi
     for (int ks = 0; ks < KSTEPS; ++ks) {
       u32x4_t bf[PF_CW];
 #pragma unroll
-      for (int c = 0; c < PF_CW; ++c) bf[c] = EX::frag(wcur[c], ks, ex_mask, ex_magic);
+      for (int c = 0; c < PF_CW; ++c) {
+        if constexpr ((DIHIP_PF_X & 8) != 0) bf[c] = wcur[c];
+        else bf[c] = EX::frag(wcur[c], ks, ex_mask, ex_magic);
+      }
 #pragma unroll
       for (int rt = 0; rt < PF_RT; ++rt) {
         const u32x4_t af = *reinterpret_cast<const u32x4_t*>(abase + ((size_t)(wm * PF_RT + rt) * KSTEPS + ks) * 1024);
@@ -230,7 +241,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void gemm_prefill_kernel(const Prefi
     __builtin_amdgcn_s_setprio(0);
     // ---- at the group's end: scale / zero-point on the f32 accumulators, with the group's row sums
     ++gl;
-    const bool gend = GPT || gl == a.ktpg || !more;
+    const bool gend = (GPT || gl == a.ktpg || !more) && (!(DIHIP_PF_X & 1) || !more);
     if (gend) {  // (uniform)
       const float* xs = xsum + (grp & 1) * PF_BM + wm * PF_RT * 16 + kb * 4;
       float s_[PF_CW], nz_[PF_CW];
@@ -259,9 +270,9 @@ __global__ __launch_bounds__(PF_THREADS, 2) void gemm_prefill_kernel(const Prefi
     // ---- the next A tile into the other buffer (its last readers passed the previous barrier); its row sums belong to
     // group `grp` (already advanced when this k-tile closed one): that group's table was last read two groups ago
     DIHIP_PF_STAMP(5);
-    if (more) stage_a(buf ^ 1, grp & 1, gl == 0);
+    if (more && !(DIHIP_PF_X & 2)) stage_a(buf ^ 1, grp & 1, gl == 0);
     DIHIP_PF_STAMP(6);
-    __syncthreads();
+    if constexpr (!(DIHIP_PF_X & 4)) __syncthreads();
     DIHIP_PF_STAMP(7);
   }
 #undef DIHIP_PF_STAMP
