@@ -60,10 +60,13 @@ struct Matcher {
     ++i;
     return true;
   }
-  bool typed(const OperatorProto*& out, const char* type, const std::string& in) {
+  // (further inputs are allowed: the exported graphs hand Rotary the position mask and GenerateOp the original ids;
+  // several_outputs: GenerateOp also declares next_beam_idx / hyps outputs, model_base.py GenerateOp)
+  bool typed(const OperatorProto*& out, const char* type, const std::string& in, bool several_outputs = false) {
     const OperatorProto* p = peek();
     if (!p || p->op_type != type) return fail(std::string("expected ") + type);
-    if (p->inputs.empty() || p->inputs[0] != in || p->outputs.size() != 1) return fail(std::string(type) + " with unexpected inputs");
+    if (p->inputs.empty() || p->inputs[0] != in || (several_outputs ? p->outputs.empty() : p->outputs.size() != 1))
+      return fail(std::string(type) + " with unexpected inputs");
     out = p;
     ++i;
     return true;
@@ -150,7 +153,8 @@ std::vector<OperatorProto> FuseDecoderGraph(const std::vector<OperatorProto>& gr
       if (attr_ptr(*rot, k)) return refuse(std::string("Rotary attribute ") + k + " (" + rot->op_name + ")");
     {
       const OperatorProto* p = m.peek();
-      if (!p || (p->op_type != "DecOptMQA" && p->op_type != "DecOptMHA") || p->inputs.size() != 1 || p->inputs[0] != rot->outputs[0] ||
+      // (the converter appends GenerateOp's beam index to the attention's inputs, qwen_v15.py:445-447: unused by SpanAttnOp)
+      if (!p || (p->op_type != "DecOptMQA" && p->op_type != "DecOptMHA") || p->inputs.empty() || p->inputs[0] != rot->outputs[0] ||
           p->outputs.size() != 1)
         return refuse(m.fail("expected DecOptMQA / DecOptMHA on the rotated rows") ? "" : "");
       att = p;
@@ -276,6 +280,7 @@ std::vector<OperatorProto> FuseDecoderGraph(const std::vector<OperatorProto>& gr
   const OperatorProto *lnf = m.peek(), *gll, *lm, *gen;
   ++m.i;
   const size_t tail_at = m.i;
+  bool dropped_update_id = false;
   auto simple_tail = [&]() -> bool {
     if (!m.typed(gll, "GetLastLine", lnf->outputs[0])) return false;
     if (!m.typed(lm, "Gemm", gll->outputs[0])) return false;
@@ -283,23 +288,31 @@ std::vector<OperatorProto> FuseDecoderGraph(const std::vector<OperatorProto>& gr
         attr_float(*lm, "alpha", 1.0f) != 1.0f || attr_int(*lm, "binary_type", 0) != 0 || lm->inputs.size() != 1)
       return m.fail("an lm_head Gemm the fused head does not implement");
     if (ctx.GetNranks() > 1) return m.fail("tensor-parallel lm_head: the fused head is single-rank");
-    if (!m.typed(gen, "GenerateOp", lm->outputs[0])) return false;
+    if (!m.typed(gen, "GenerateOp", lm->outputs[0], true)) return false;
+    // gen_graph = [GenerateOp, UpdateId] (qwen_v15.py:436-448): the stop checks of UpdateId need the token on the host; in the
+    // fused list they are the model runner's, at its sync points (HipModelRunner::Sync / dihost_request_poll)
+    if (const OperatorProto* u = m.peek(); u && u->op_type == "UpdateId" && m.i + 1 == graph.size()) {
+      dropped_update_id = true;
+      ++m.i;
+    }
     if (m.i != graph.size()) return m.fail("operators after GenerateOp");
     return true;
   };
   if (!simple_tail()) {
     // the tail as it is, behind a DihipFinalNorm: every remaining operator must be one the HIP backend registers and that reads FT rows
     const std::string why_simple = m.why;
-    for (size_t j = tail_at; j < graph.size(); ++j) {
+    size_t tail_end = graph.size();
+    if (tail_end > tail_at + 1 && graph[tail_end - 1].op_type == "UpdateId" && graph[tail_end - 2].op_type == "GenerateOp") --tail_end;  // as above
+    for (size_t j = tail_at; j < tail_end; ++j) {
       const std::string& t = graph[j].op_type;
       if (t != "GetLastLine" && t != "Gemm" && t != "AllReduce" && t != "AllGather" && t != "GenerateOp")
         return refuse(why_simple + ", and the tail holds " + t + " (" + graph[j].op_name + "), which cannot stay behind DihipFinalNorm");
     }
-    if (tail_at >= graph.size() || graph.back().op_type != "GenerateOp") return refuse(why_simple + ", and the list does not end in GenerateOp");
+    if (tail_at >= tail_end || graph[tail_end - 1].op_type != "GenerateOp") return refuse(why_simple + ", and the list does not end in GenerateOp");
     OperatorProto f_norm = make("DihipFinalNorm", lnf->op_name, {h}, lnf->outputs, lnf->weights);
     copy_attr(f_norm, *lnf, "eps");
     out.push_back(std::move(f_norm));
-    for (size_t j = tail_at; j < graph.size(); ++j) out.push_back(graph[j]);
+    for (size_t j = tail_at; j < tail_end; ++j) out.push_back(graph[j]);
     rep.fused = true;
     rep.device_resident = false;
     rep.why = "layers fused, the tail runs on the reference's own operators (" + why_simple + ")";
@@ -312,6 +325,7 @@ std::vector<OperatorProto> FuseDecoderGraph(const std::vector<OperatorProto>& gr
   OperatorProto f_gen = make("DihipGreedy", gen->op_name, {lm->outputs[0]}, gen->outputs, {});
   f_gen.attr = gen->attr;
   out.push_back(std::move(f_gen));
+  if (dropped_update_id) rep.why = "UpdateId behind GenerateOp is left to the model runner's sync points";
   rep.fused = true;
   rep.device_resident = true;
   rep.ops_after = (int)out.size();

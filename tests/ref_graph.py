@@ -71,6 +71,26 @@ def qwen2_graph(n_layers, wbits, group, eps, n_heads, n_kv, rope_theta, tp_allre
     return g
 
 
+def as_exported(graph):
+    """The same list with the arities the reference's converter actually writes (qwen_v15.py:408-452, model_base.py GenerateOp):
+    Rotary also takes the position mask of TransMask (which lives in pre_graph), the attention operator has GenerateOp's beam
+    index appended to its inputs, GenerateOp takes the original ids as a second input and declares three outputs, and gen_graph
+    ends in UpdateId -- decoder graph and gen_graph back to back, as AsModel runs them."""
+    out = []
+    for t, name, inputs, outputs, weights, attrs in graph:
+        inputs, outputs = list(inputs), list(outputs)
+        if t == "Rotary":
+            inputs.append("transmask.out1")
+        elif t in ("DecOptMQA", "DecOptMHA"):
+            inputs.append("generate.next_beam_idx")
+        elif t == "GenerateOp":
+            inputs.append("preprocess_id.out1")
+            outputs += ["generate.next_beam_idx", "generate.hyps"]
+        out.append((t, name, inputs, outputs, weights, attrs))
+    out.append(("UpdateId", "update_id", ["preprocess_id.out", "generate.next_beam_idx"], ["update_id.out"], [], ""))
+    return out
+
+
 def register_weights(m, model, ft="bf16"):
     """The product model's unpacked quantised weights (decoder.build_random_model(keep_fp=True)) under the reference's names."""
     fp = model.fp

@@ -25,7 +25,7 @@ KV = {"none": 0, "i8": 1, "u4": 2}
 class Host:
     """hostapi.Model + the reference graph + a span pool, on its own stream (a captured step needs a non-NULL stream)."""
 
-    def __init__(self, model, batch, max_len, span, kv_mode, fuse=True, ft="bf16"):
+    def __init__(self, model, batch, max_len, span, kv_mode, fuse=True, ft="bf16", exported=False):
         from dash_infer_amd import hostapi, ops
         cfg = model.cfg
         self.cfg, self.nl, self.spr = cfg, len(model.layers), (max_len + span - 1) // span
@@ -38,6 +38,8 @@ class Host:
             ref_graph.register_weights(self.m, model, ft)
             self.graph = ref_graph.qwen2_graph(self.nl, model.quant.wbits, model.quant.group, cfg.eps, cfg.n_heads, cfg.n_kv, cfg.rope_theta,
                                                moe=(cfg.moe.num_experts, cfg.moe.top_k) if cfg.moe is not None else None)
+            if exported:   # the arities the reference's converter writes + gen_graph's UpdateId (ref_graph.as_exported)
+                self.graph = ref_graph.as_exported(self.graph)
             ref_graph.add_graph(self.m, self.graph)
             self.report = self.m.graph_build(fuse=fuse)
         self.stream.synchronize()
@@ -169,6 +171,35 @@ def test_mixture_of_experts_list_is_bit_identical_to_decode_session(pkg, group, 
     assert worst <= 3e-2, f"unfused MoE list differs from the fused one by {worst:.3e} (relative to max |logit|)"
     print(f"MoE host runner: context vs oracle {err:.2e}; unfused vs fused {worst:.2e}")
     u.close()
+
+
+def test_exported_graph_arities_run_fused_and_bit_identical(pkg):
+    """the list with the converter's own arities (Rotary + position mask, attention + beam index, GenerateOp with two inputs and
+    three outputs, UpdateId behind it) goes through the same fused operators: ids and logits bit-identical to DecodeSession"""
+    from dash_infer_amd import decoder
+    cfg = decoder.ModelConfig("runner-test-exported", **SMALL)
+    model = decoder.build_random_model(cfg, decoder.QuantSpec(4, 128), seed=4242, keep_fp=True)
+    span, max_len, steps, batch = 16, 64, 4, 3
+    rng = np.random.default_rng(12)
+    prompts = [[int(t) for t in rng.integers(0, cfg.vocab, n)] for n in (5, 17, 30)]
+    sess = decoder.DecodeSession(model, batch, max_len=max_len, span_len=span, kv_mode="none")
+    lo0 = sess.prefill(prompts).clone()
+    ids0 = sess.ids.cpu().tolist()
+    want = []
+    for _ in range(steps):
+        sess.step()
+        torch.cuda.synchronize()
+        want.append((sess.logits.clone(), sess.ids.cpu().tolist()))
+    h = Host(model, batch, max_len, span, "none", exported=True)
+    assert h.report["fused"] and h.report["device_resident"] and "UpdateId" in h.report["why"], h.report["why"]
+    for b, pr in enumerate(prompts):
+        k, v = h.spans()
+        assert h.start(pr, k, v) == ids0[b]
+        assert torch.equal(h.logits()[0], lo0[b])
+    for t in range(steps):
+        assert h.steps(1, graph=True) == want[t][1]
+        assert torch.equal(h.logits(), want[t][0]), f"step {t}"
+    h.close()
 
 
 def test_fused_operator_list_f16_is_bit_identical_to_decode_session(pkg):

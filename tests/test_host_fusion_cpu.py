@@ -137,3 +137,31 @@ def test_mixture_of_experts_layer_becomes_one_block_operator(pkg):
     r = m.graph_fuse_dry()
     assert not r["fused"] and "CalcExpert" in r["why"], r["why"]
     m.close()
+
+
+def test_the_converters_own_arities_are_accepted(pkg):
+    """decoder graph + gen_graph as the reference's converter writes them (ref_graph.as_exported): Rotary with the position
+    mask, the attention with GenerateOp's beam index appended, GenerateOp with two inputs / three outputs, UpdateId behind it --
+    same fused list; UpdateId is the model runner's (stop checks need the token on the host)"""
+    from dash_infer_amd import hostapi
+    m = hostapi.Model(None, 4, 2, 128, 16)
+    plain = ref_graph.qwen2_graph(2, 4, 128, 1e-6, 4, 2, 1e6)
+    g = ref_graph.as_exported(plain)
+    assert len(g) == len(plain) + 1 and g[-1][0] == "UpdateId" and len(g[-2][3]) == 3 and len(g[4][2]) == 2
+    ref_graph.add_graph(m, g)
+    r = m.graph_fuse_dry()
+    assert r["fused"] and r["device_resident"] and r["layers"] == 2, r["why"]
+    per_layer = ["DihipNormGemm", "DihipRopeSpanAttn", "DihipGemmAddTo", "DihipNormSwiGLU", "DihipGemmAddTo"]
+    assert r["types"] == ["DihipEmbedding"] + per_layer * 2 + ["DihipLMHead", "DihipGreedy"]
+    assert "UpdateId" in r["why"]
+    w = r["wiring"].split("|")
+    assert w[2] == "DihipRopeSpanAttn(decoder.layer.0.attention.self.out)->(decoder.layer.0.attention.out)[]"
+    assert w[12] == "DihipGreedy(logits)->(generated_ids,generate.next_beam_idx,generate.hyps)[]"
+    m.close()
+    # the same with a tensor-parallel tail and with MoE layers
+    m = hostapi.Model(None, 4, 2, 128, 16, rank=0, nranks=2)
+    ref_graph.add_graph(m, ref_graph.as_exported(ref_graph.qwen2_graph(1, 8, -1, 1e-6, 4, 2, 1e6, tp_allreduce=True, tp_lm_head=True, moe=(8, 2, True))))
+    r = m.graph_fuse_dry()
+    assert r["fused"] and not r["device_resident"], r["why"]
+    assert r["types"][-5:] == ["DihipFinalNorm", "GetLastLine", "Gemm", "AllReduce", "GenerateOp"] and "DihipMoeBlock" in r["types"]
+    m.close()
