@@ -288,6 +288,10 @@ std::vector<OperatorProto> FuseDecoderGraph(const std::vector<OperatorProto>& gr
         attr_float(*lm, "alpha", 1.0f) != 1.0f || attr_int(*lm, "binary_type", 0) != 0 || lm->inputs.size() != 1)
       return m.fail("an lm_head Gemm the fused head does not implement");
     if (ctx.GetNranks() > 1) return m.fail("tensor-parallel lm_head: the fused head is single-rank");
+    if (m.i == graph.size()) {  // the decoder graph alone (AsModel keeps GenerateOp in gen_graph): fused up to the f32 logits
+      gen = nullptr;
+      return true;
+    }
     if (!m.typed(gen, "GenerateOp", lm->outputs[0], true)) return false;
     // gen_graph = [GenerateOp, UpdateId] (qwen_v15.py:436-448): the stop checks of UpdateId need the token on the host; in the
     // fused list they are the model runner's, at its sync points (HipModelRunner::Sync / dihost_request_poll)
@@ -322,6 +326,15 @@ std::vector<OperatorProto> FuseDecoderGraph(const std::vector<OperatorProto>& gr
   OperatorProto f_lm = make("DihipLMHead", lm->op_name, {h}, lm->outputs, {lnf->weights[0], lm->weights[0]});
   copy_attr(f_lm, *lnf, "eps");
   out.push_back(std::move(f_lm));
+  if (!gen) {
+    // GenerateOp (gen_graph) takes the f32 logits as they are (host/glue_ops_hip.cpp); without DihipGreedy nothing advances the
+    // device-resident length counters: the step state is staged per step, as with an unfused tail
+    rep.fused = true;
+    rep.device_resident = false;
+    rep.why = "no GenerateOp in this list (the decoder graph alone): fused up to the f32 logits, step state staged from the host";
+    rep.ops_after = (int)out.size();
+    return out;
+  }
   OperatorProto f_gen = make("DihipGreedy", gen->op_name, {lm->outputs[0]}, gen->outputs, {});
   f_gen.attr = gen->attr;
   out.push_back(std::move(f_gen));

@@ -165,3 +165,15 @@ def test_the_converters_own_arities_are_accepted(pkg):
     assert r["fused"] and not r["device_resident"], r["why"]
     assert r["types"][-5:] == ["DihipFinalNorm", "GetLastLine", "Gemm", "AllReduce", "GenerateOp"] and "DihipMoeBlock" in r["types"]
     m.close()
+
+
+def test_the_decoder_graph_alone_fuses_up_to_the_logits(pkg):
+    """AsModel keeps GenerateOp / UpdateId in gen_graph: a pass run per graph sees a list that ends in the lm_head Gemm"""
+    from dash_infer_amd import hostapi
+    m = hostapi.Model(None, 4, 2, 128, 16)
+    g = [op for op in ref_graph.qwen2_graph(1, 4, 128, 1e-6, 4, 2, 1e6) if op[0] != "GenerateOp"]
+    ref_graph.add_graph(m, g)
+    r = m.graph_fuse_dry()
+    assert r["fused"] and not r["device_resident"] and r["types"][-1] == "DihipLMHead" and "DihipGreedy" not in r["types"], r["why"]
+    assert "GenerateOp" in r["why"]
+    m.close()
