@@ -81,8 +81,9 @@ def as_exported(graph):
         inputs, outputs = list(inputs), list(outputs)
         if t == "Rotary":
             inputs.append("transmask.out1")
-        elif t in ("DecOptMQA", "DecOptMHA"):
-            inputs.append("generate.next_beam_idx")
+        elif t in ("DecOptMQA", "DecOptMHA"):   # [rotary out, attention mask, + the beam index appended at qwen_v15.py:445-447]
+            inputs += ["transmask.out", "generate.next_beam_idx"]
+            attrs = ";".join(a for a in (attrs, "size_per_head=i:128", "multigpu=i:1") if a)
         elif t == "GenerateOp":
             inputs.append("preprocess_id.out1")
             outputs += ["generate.next_beam_idx", "generate.hyps"]

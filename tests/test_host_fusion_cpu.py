@@ -147,7 +147,7 @@ def test_the_converters_own_arities_are_accepted(pkg):
     m = hostapi.Model(None, 4, 2, 128, 16)
     plain = ref_graph.qwen2_graph(2, 4, 128, 1e-6, 4, 2, 1e6)
     g = ref_graph.as_exported(plain)
-    assert len(g) == len(plain) + 1 and g[-1][0] == "UpdateId" and len(g[-2][3]) == 3 and len(g[4][2]) == 2
+    assert len(g) == len(plain) + 1 and g[-1][0] == "UpdateId" and len(g[-2][3]) == 3 and len(g[4][2]) == 3
     ref_graph.add_graph(m, g)
     r = m.graph_fuse_dry()
     assert r["fused"] and r["device_resident"] and r["layers"] == 2, r["why"]
