@@ -15,7 +15,8 @@ audit_asm_loads = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(audit_asm_loads)
 
 OBJ_DIR = os.path.join(ROOT, "dash-infer_amd", "lib", "obj")
-OBJECTS = sorted(glob.glob(os.path.join(OBJ_DIR, "gemv_stream_inst_*.o")))
+# + the K-slice GEMM (round 4: its activation fragments are asm loads behind one explicit wait)
+OBJECTS = sorted(glob.glob(os.path.join(OBJ_DIR, "gemv_stream_inst_*.o")) + glob.glob(os.path.join(OBJ_DIR, "gemm_kslice_inst_*.o")))
 
 
 def test_the_tool_sees_a_read_before_the_wait_and_not_after():
