@@ -21,9 +21,11 @@
 // the f32 accumulator); a group that straddles two K-slices is closed in both with the same (scale, zero).
 //
 // Round 4 (what-if timing above KSL_WAVES' definition):
-//   * the activation fragments are loaded WITHOUT the nontemporal hint: 256 workgroups read the same 115 - 229 KB, and `nt`
-//     lines are the first to leave L2 (-2.3 us on the 7B gate/up pair at M = 32).  The loads are inline asm because a plain
-//     builtin load of read-only memory is rematerialised by hipcc right before its use;
+//   * the activation fragments are loaded WITHOUT the nontemporal hint (-3 us on the 7B gate/up pair at M = 32, -2 at M = 16, with
+//     the same asm issue pattern either way: profiles/r04ai_*).  Not because `nt` lines miss: TCC_HIT / TCC_MISS / TCC_REQ of the
+//     launch are IDENTICAL with and without the bit (531k hits, 644k misses of 128 B: the 256 re-reads of the fragments hit L2 in
+//     both builds, profiles/r04ah_*) -- the hits of nontemporal requests are simply served slower on this part.  The loads are
+//     inline asm because a plain builtin load of read-only memory is rematerialised by hipcc right before its use;
 //   * tried and removed: an eighth wave WITHOUT a K-slice (K = 3584 has 7) that does the cross-slice sums and the epilogues, so
 //     that no streaming wave reaches the next barrier late by a reduction: +3 % stand-alone at M = 16, -5 % at M = 32 (one wave
 //     then runs both fragments' SwiGLU epilogues), and in the decode step 11.9k against 12.2k tokens/s (profiles/r04q_*);

@@ -127,8 +127,8 @@ __global__ __launch_bounds__(PANEL_THREADS) void gemm_panel_kernel(const PanelAr
       // right before its use instead of keeping it in the ring, and waits vmcnt(0) for it)
       r.s[v] = __builtin_nontemporal_load(sp[v] + (size_t)(GPT ? kt : (subc ? kt / a.ktpg : 0)) * 16);
     }
-    // the activation k-tile is read by every panel (and K-slice) of the launch: a TEMPORAL load (round 4: `nt` lines are the first
-    // to leave L2), as a buffer load so that hipcc neither rematerialises it nor loses count of it
+    // the activation k-tile is read by every panel (and K-slice) of the launch: a TEMPORAL load (round 4: L2 hits of nontemporal
+    // requests are served slower, gemm_kslice_kernel.hpp), as a buffer load so that hipcc neither rematerialises it nor loses count of it
     r.x = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xoff + (uint32_t)tt * (NF * 1024u), 0, 0));
   };
 
