@@ -246,12 +246,12 @@ def blocks_summary(times, steps):
 
 def host_runner_bench(args, torch, decoder, ops, model, sess, batch, max_len, kv_mode, fuse, graph, steps, blocks):
     """The SAME decode step through the C++ operator layer (dash-infer_amd/host): the reference's Qwen2 operator list
-    (tests/ref_graph.py: qwen_v15.py:187-388; the MoE layers of qwen_v20_moe.py:318-391 for cfg5_moe) -> fusion pass (host/fusion_pass.cpp; fuse=False: the list as it is, fourteen launches
+    (dash-infer_amd/ref_graph.py: qwen_v15.py:187-388; the MoE layers of qwen_v20_moe.py:318-391 for cfg5_moe) -> fusion pass (host/fusion_pass.cpp; fuse=False: the list as it is, fourteen launches
     per layer) -> OpFactory -> HipModelRunner (host/model_runner.cpp: Alloc -> Forward per operator per step, model.cpp:1248-1325),
     the fused step captured once as a hipGraph and replayed.  The requests adopt the Python session's cache spans (same random
     history); the weights are the same quantised tensors, re-laid-out by the operators' own InitV2."""
     from dash_infer_amd import hostapi
-    from tests import ref_graph
+    from dash_infer_amd import ref_graph
     cfg = model.cfg
     stream = torch.cuda.Stream()
     torch.cuda.synchronize()

@@ -5,8 +5,10 @@
 //     prefix whose cumulated probability EXCEEDS p; skipped for p <= 1e-7)  ->  softmax(logit / T) over that prefix  ->  the
 //     exponential race of kernel/cpu/sample.cpp:42-68: score_i = prob_i / q_i, q_i = -log1p(-u_i), u_i uniform in [0, 1), the first
 //     maximum wins.
-// top_k == 0 means "the whole vocabulary" in the reference; like its CONFIG_SAMPLE_CONSTRAIN_MAX_K build (generate_op.cpp:385-393)
-// this kernel serves k <= 1024 and maps 0 to 1024.  top_k == 1 is greedy: the arg-max, lowest index on ties.
+// top_k == 0 means "the whole vocabulary" in the reference; its CONFIG_SAMPLE_CONSTRAIN_MAX_K build (generate_op.cpp:383-391)
+// rejects every request whose k exceeds 1024 -- k = 0 included -- with PARAM_ERROR.  So does this backend, on the HOST
+// (host/sampling_host.h: SamplingParams::Gather): the per-row values are device arrays here, the kernel can only clamp what is out
+// of range to 1024 (documented in dashinfer_hip.h).  top_k == 1 is greedy: the arg-max, lowest index on ties.
 // The random stream is this backend's own (the reference draws from std::mt19937 on x86 and Philox on CUDA: neither is
 // reproducible on another device): u_i = 24 high bits of splitmix64(seed, position of the sampled token, candidate rank i) -- a
 // pure function of (request seed, sequence position, rank), so a captured decode step replays correctly with the positions read

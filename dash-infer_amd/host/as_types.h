@@ -213,7 +213,7 @@ class VirtualCache {
 // the sampling half of GenerateConfig (csrc/interface/allspark.h GenerateConfig: top_k / top_p / temperature / seed, the
 // fields GenerateOp reads per request, generate_op.cpp:60-140)
 struct GenerateConfig {
-  int top_k = 1;            // 0: the whole vocabulary (then top_p decides); 1: greedy
+  int top_k = 1;            // 1: greedy; 1 .. 1024 served; 0 (the whole vocabulary) and > 1024 are refused (sampling_host.h)
   float top_p = 1.0f;       // 0 or >= 1: off
   float temperature = 1.0f;
   unsigned long long seed = 0;

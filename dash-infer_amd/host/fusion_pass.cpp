@@ -227,6 +227,10 @@ std::vector<OperatorProto> FuseDecoderGraph(const std::vector<OperatorProto>& gr
       out.push_back(std::move(f_moe));
       // the reference all-reduces the MOE rows and the CalcExpert rows, the block adds them (and the residual on rank 0) first:
       // one all-reduce of the f32 hidden rows, the same sum
+      // -- which is only the same sum when BOTH partial results are rank-partial (or neither): one all-reduce present without
+      // the other means one addend is replicated and would be counted nranks times
+      if ((ar_moe != nullptr) != (ar_sh != nullptr))
+        return refuse("mixture-of-experts block: one of the two all-reduces (experts / shared expert) is missing (" + moe->op_name + ")");
       if (ar_moe || ar_sh) out.push_back(make("AllReduce", (ar_moe ? ar_moe : ar_sh)->op_name, {add2->outputs[0]}, {add2->outputs[0]}, {}));
       h = add2->outputs[0];
       ++rep.layers;

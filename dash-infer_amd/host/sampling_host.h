@@ -21,6 +21,8 @@ class SamplingParams {
     rows_ = rows;
     any_ = false;
     const size_t per = sizeof(int) + 2 * sizeof(float) + sizeof(unsigned long long) + sizeof(uint32_t);
+    // the previous forward's staging copy reads host_: it must have completed before the buffer is freed or rewritten
+    if (staged_ && hipEventSynchronize(staged_) != hipSuccess) return AsStatus::ALLSPARK_RUNTIME_ERROR;
     if ((size_t)rows > cap_) {
       if (host_) (void)hipHostFree(host_);
       cap_ = std::max<size_t>(rows, 32);
@@ -29,7 +31,6 @@ class SamplingParams {
       if (!dev_->GetDataPtr()) return AsStatus::ALLSPARK_MEMORY_ERROR;
     }
     if (!staged_ && hipEventCreateWithFlags(&staged_, hipEventDisableTiming) != hipSuccess) return AsStatus::ALLSPARK_RUNTIME_ERROR;
-    if (hipEventSynchronize(staged_) != hipSuccess) return AsStatus::ALLSPARK_RUNTIME_ERROR;
     // layout: seeds [cap] (8-byte aligned first), top_k [cap], top_p [cap], temperature [cap], position [cap]
     auto* seed = reinterpret_cast<unsigned long long*>(host_);
     auto* tk = reinterpret_cast<int*>(seed + cap_);
@@ -39,7 +40,10 @@ class SamplingParams {
       const GenerateContext* gc = rt->is_context ? rt->GetContextGenCtx() : rt->GetGenCtx(i);
       const GenerateConfig& g = gc->gen_cfg;
       if (!(g.temperature >= std::numeric_limits<float>::min())) return AsStatus::ALLSPARK_PARAM_ERROR;  // generate_op.cpp:357-362
-      if (g.top_k > 1024) return AsStatus::ALLSPARK_PARAM_ERROR;                                          // :389-392
+      // top_k == 0 is "the whole vocabulary" (real_k = vocab_size_, generate_op.cpp:338-339): like the reference's
+      // CONFIG_SAMPLE_CONSTRAIN_MAX_K build (:383-391, max_k_ > 1024 -> PARAM_ERROR) this backend serves 1 <= k <= 1024 and says
+      // so instead of sampling from a silently truncated distribution (dihip_sample clamps what it cannot check on the device)
+      if (g.top_k <= 0 || g.top_k > 1024) return AsStatus::ALLSPARK_PARAM_ERROR;
       seed[i] = g.seed;
       tk[i] = g.top_k;
       tp[i] = g.top_p;

@@ -424,7 +424,9 @@ int dihip_argmax(void* stream, int64_t* ids, const float* logits, int M, int N, 
 int dihip_argmax_advance(void* stream, int64_t* ids, const float* logits, int M, int N, void* ws,
                          size_t ws_bytes, uint32_t* counters_a, uint32_t* counters_b);
 /* The sampling half of GenerateOp (generate_op.cpp:472-600; arithmetic of its x86 path, generate_impl_cpu.hpp:120-170): per row
- *   top-k (k largest logits, descending; top_k <= 0 or > 1024 -> 1024, the reference's CONFIG_SAMPLE_CONSTRAIN_MAX_K limit) ->
+ *   top-k (k largest logits, descending; 1 <= top_k <= 1024, the reference's CONFIG_SAMPLE_CONSTRAIN_MAX_K limit.  The values live
+ *   on the device, so the HOST must reject what is out of range -- top_k == 0, "the whole vocabulary", included: the operators'
+ *   SamplingParams::Gather returns ALLSPARK_PARAM_ERROR as generate_op.cpp:383-391 does; the kernel itself clamps to 1024) ->
  *   softmax(logit / T) -> top-p (shortest prefix whose cumulated probability EXCEEDS p; p <= 1e-7: off, kernel/cpu/topp.cpp) ->
  *   softmax(logit / T) over the prefix -> exponential race prob_i / -log1p(-u_i), first maximum wins (kernel/cpu/sample.cpp:42-68).
  * top_k / top_p / temperature / seed: device arrays [M].  The random stream is the backend's own, a pure function of
