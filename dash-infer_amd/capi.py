@@ -75,6 +75,11 @@ _SIGS = {
     "dihip_span_attn_decode_fused_sync": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp, sz]),
     "dihip_span_attn_decode_step": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp, sz, i32]),
     "dihip_span_attn_merge_partials": (i32, [vp, vp, vp, i32, i32, i32, i32]),
+    "dihip_decode_attn_block_supported": (i32, [i32] * 10),
+    "dihip_decode_attn_block_sync_bytes": (sz, [i32, i32, i32]),
+    "dihip_decode_attn_block_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "dihip_decode_attn_block": (i32, [vp, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32,
+                                      i32, i32, f32, vp, sz, vp, sz]),
     "dihip_prefill_attn": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32]),
     "dihip_rmsnorm": (i32, [vp, vp, vp, vp, f32, i32, i32, i32]),
     "dihip_rope_qk": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32]),

@@ -1,0 +1,557 @@
+// decode_attn_block.hip -- the attention half of a batch-1 decode layer in ONE launch (include/dashinfer_hip.h section 3e):
+//     RMSNorm + qkv GEMV (+bias)  ->  Rotary + DecoderCacheAppend + paged attention + split merge  ->  o-projection + residual
+// i.e. LayerNormNoBeta -> Gemm[A16W4](qkv) -> Rotary -> DecOptMQA -> Gemm[A16W4](o) -> Binary ADD of the reference graph
+// (python/pyhie/allspark/model/qwen_v15.py:210-300; the operator loop it shortens: csrc/core/model/model.cpp:1248-1325).
+//
+// Why: in the launch chain these three operators are 20.2 of the layer's 44.5 us while moving 15 % of its bytes (profiles/r04zzzz_*):
+// every launch pays launch -> first byte (~1 us), its own dependent round trips and a tail, and none of the 19 MB they read
+// (8.3 MB qkv weights, 4.2 MB of K / V, 6.4 MB o weights) depends on what the previous operator computes.  Here ALL of it is
+// requested in the first microsecond of one launch -- it fits the register files: <= 8 KiB per wave -- and what remains
+// serial is the arithmetic and three hand-offs:
+//
+//   workgroups [0, NA)        attention: one (KV group, split) each, 4 waves (the body of span_attn_ft_mfma.hpp, bit for bit):
+//                             K / V tiles into registers at entry; q / k / v of this step arrive as GRANULES from the GEMV
+//                             workgroups; partial records -> arrival ticket -> the last split of a group merges (as the
+//                             stand-alone kernel) and publishes the merged heads as granules + one flag word per group.
+//   workgroups [NA, NA + NG)  GEMV: RMSNorm prologue + this workgroup's qkv column tiles from a register-resident weight share
+//                             (the K split of the stand-alone decode GEMV, so the sums are bit-identical to it), results
+//                             published as granules; its o-projection share has been in registers since entry: it waits for
+//                             the group flags, sweeps the attention output granules into LDS and finishes h += attn . Wo.
+//
+// Granule = 8 bytes {value, tag} written by ONE agent-scope store and read by agent-scope loads: the data is the flag (MI355X
+// guide, Guideline 16 form R2), so no fences and nothing outside the memory model.  tag = the launch's epoch: every workgroup
+// reads the epoch word at entry, the first GEMV workgroup writes epoch + 1 back when it is done -- by then every workgroup
+// has read it (its own last wait depends on all of them) -- so a replayed hipGraph needs no memset node and a stale granule
+// can only carry an older tag.  Every wait is bounded: on give-up an error word is set, results are garbage, nothing hangs.
+//
+// All NA + NG workgroups must be resident at once (<= one per CU: the host checks the CU count); the attention workgroups
+// have the low block indices, are dispatched first and wait on nobody but the GEMV workgroups' first phase, which waits on
+// nothing.
+//
+// Served: batch 1, bf16, int4 weights with one quantisation group per k-tile (g128), 16-bit cache, head size 128, <= 16
+// query heads per KV group.  Everything else: dihip_decode_attn_block_supported() == 0 and the caller keeps the launch chain.
+#include <algorithm>
+#include <cstdlib>
+
+#include "gemv_stream_kernel.hpp"
+#include "span_attn_ft_mfma.hpp"
+
+namespace dihip {
+
+bool gemv_block_plan(int wbits, int N, int K, int group_size, int nblocks, GemvArgs* g, int* max_units, size_t* lds_bytes);
+void span_attn_block_plan(int batch, int n_heads, int n_groups, int max_seq_len, int* nsplits, int* nchunks, int* tps_static,
+                          size_t* partial_bytes);
+
+constexpr int AB_THREADS = GEMV_THREADS;  // 8 waves
+constexpr int AB_RING = 8;                // 1 KiB weight chunks a wave holds per GEMV: the whole share is resident
+
+struct AttnBlockArgs {
+  GemvArgs q;  // RMSNorm + qkv projection: x = f32 hidden row, gamma, eps, bias; output -> qkv_gran
+  GemvArgs o;  // o projection: x <- out_gran; h_out = h_res + x . Wo
+  AttnArgs a;
+  unsigned* state;               // [0] epoch, [1] error
+  unsigned long long* qkv_gran;  // [(n + 2g) * H]
+  unsigned long long* out_gran;  // [n * H / 2]
+  size_t out_gran_bytes;
+  unsigned* grp_flag;            // [g]
+  int NA, NG;                    // attention / GEMV workgroups
+  unsigned spin_limit;
+  unsigned long long* trace;     // diagnostics (`make trace` build + dihip_debug_set_trace): [workgroup][32] wall-clock stamps, or null
+};
+
+// this wave's share of one GEMV (the bookkeeping of gemv_stream_body, M = 1)
+struct AbShare {
+  int wk, wn, k_lo, k_hi, nk, nu, total, u0, g_lo;
+  const char* wtile;
+  const char* stile;
+  size_t wstep, sstep;
+};
+
+__device__ __forceinline__ AbShare ab_share(const GemvArgs& g, int bid, int NB, int wave) {
+  AbShare s;
+  const int lgWK = __builtin_ctz(g.WK), lgWN = __builtin_ctz(g.WN);
+  s.wk = g.wmap ? wave >> lgWN : wave & (g.WK - 1);
+  s.wn = g.wmap ? wave & (g.WN - 1) : wave >> lgWK;
+  s.u0 = __builtin_amdgcn_readfirstlane(bid);
+  s.nu = g.nu_q + (s.u0 < g.nu_r ? 1 : 0);
+  const int gsz = g.ktpg < g.KT ? g.ktpg : 1;  // one group per k-tile (host contract): 1
+  s.g_lo = __builtin_amdgcn_readfirstlane(g.kcut[s.wk]);
+  s.k_lo = min(g.KT, s.g_lo * gsz);
+  s.k_hi = min(g.KT, __builtin_amdgcn_readfirstlane(g.kcut[s.wk + 1]) * gsz);
+  s.nk = s.k_hi - s.k_lo;
+  const int nvw = s.wn < s.nu ? (s.nu - s.wn + g.WN - 1) >> lgWN : 0;
+  s.total = __builtin_amdgcn_readfirstlane(nvw * s.nk);
+  const int t0 = s.u0 + s.wn * NB, tstep = g.WN * NB;
+  s.wtile = reinterpret_cast<const char*>(g.w0 + ((size_t)t0 * g.KT + s.k_lo) * 64);
+  s.stile = reinterpret_cast<const char*>(g.sz0 + ((size_t)t0 * g.Gp + s.g_lo) * 16);
+  s.wstep = (size_t)tstep * g.KT * 1024;
+  s.sstep = (size_t)tstep * g.Gp * 64;
+  return s;
+}
+
+// the whole share requested at once, in the order the stand-alone kernel streams it.  Slots beyond the share re-read the head
+// of the matrix: every asm load is unconditional, so no register of the ring is defined on one path only (a phi on an asm
+// output may be resolved by a copy BEFORE the data has landed: tools/audit_asm_loads.py)
+__device__ __forceinline__ void ab_issue(const GemvArgs& g, const AbShare& s, u32x4_t (&wb)[AB_RING], uint32_t (&sb)[AB_RING], int lane) {
+  const char* wtile = s.wtile;
+  const char* stile = s.stile;
+  const char* iwp = wtile;
+  const char* isp = stile;
+  const char* const dummy = reinterpret_cast<const char*>(g.w0);
+  int ikt = s.k_lo;
+  const uint32_t voff_w = (uint32_t)lane * 16u, voff_s = (uint32_t)(lane & 15) * 4u;
+#pragma unroll
+  for (int j = 0; j < AB_RING; ++j) {
+    const bool real = j < s.total;
+    stream_load_b128(wb[j], uniform_ptr(real ? iwp : dummy), voff_w);
+    stream_load_b32(sb[j], uniform_ptr(real ? isp : dummy), voff_s);
+    iwp += 1024;
+    isp += 64;
+    if (++ikt == s.k_hi) {
+      ikt = s.k_lo;
+      wtile += s.wstep;
+      stile += s.sstep;
+      iwp = wtile;
+      isp = stile;
+    }
+  }
+}
+
+// per-k-tile sums of an 8-element vector of the staged row (the arithmetic and order of gemv_stream_body::stage_vector, KTILE 128)
+__device__ __forceinline__ void ab_stage_vector(uint16_t* xs, float* xsum_tab, int i, const u32x4_t& v, bool store) {
+  if (store) *reinterpret_cast<u32x4_t*>(xs + (size_t)i * 8) = v;
+  float e[8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    e[2 * q] = bf16_bits_to_f32(v[q] & 0xFFFFu);
+    e[2 * q + 1] = bf16_bits_to_f32(v[q] >> 16);
+  }
+  float sum = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+  sum += dpp_f32<0xB1>(sum);
+  sum += dpp_f32<0x4E>(sum);
+  sum += dpp_f32<0x141>(sum);
+  sum += dpp_f32<0x140>(sum);
+  if ((i & 15) == 0) xsum_tab[(i >> 4) * 16] = sum;
+}
+
+// the resident share against the staged row: DIHIP_GEMV_CONSUME of gemv_stream_body for W4, bf16, M = 1, a group per k-tile
+__device__ __forceinline__ void ab_consume(const GemvArgs& g, const AbShare& s, const u32x4_t (&wb)[AB_RING], const uint32_t (&sb)[AB_RING],
+                                           unsigned char* smem, const float* xsum_tab, float* red, int lane) {
+  using EX = ExpandV<4, DIHIP_BF16>;
+  constexpr int KTILE = 128;
+  const int ni = lane & 15, kb = lane >> 4;
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  uint32_t ex_mask = 0x000F000Fu, ex_magic = 0x43004300u;
+  asm volatile("" : "+v"(ex_mask), "+v"(ex_magic));
+  if (s.nk == 0) {  // a k-slice without work: its partials must read as zero
+    for (int v = s.wn; v < s.nu; v += g.WN) {
+      float* dst = red + ((size_t)(v * g.WK + s.wk)) * 16;
+      if (lane < 16) dst[lane] = 0.f;
+    }
+  }
+  int cv = s.wn, ckt = s.k_lo;
+  const bool arow_valid = ni < 1;
+  const uint32_t xk_reset = arow_valid ? 256u + (uint32_t)(kb * 8 + s.k_lo * KTILE) * 2u : 0u;
+  const uint32_t xk_step = arow_valid ? (uint32_t)KTILE * 2u : 0u;
+  uint32_t xk = xk_reset;
+  const float* xt = xsum_tab + s.k_lo * 16;
+  float tot = 0.f;
+#pragma unroll
+  for (int j = 0; j < AB_RING; ++j) {
+    if (j >= s.total) break;
+    f32x4_t g0 = zero4, g1 = zero4;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const u32x4_t af = *reinterpret_cast<const u32x4_t*>(smem + xk + ks * 64);
+      const u32x4_t bf = EX::frag(wb[j], ks, ex_mask, ex_magic);
+      if (ks & 1) g1 = mfma16<DIHIP_BF16>(af, bf, ks == 1 ? zero4 : g1);
+      else g0 = mfma16<DIHIP_BF16>(af, bf, ks == 0 ? zero4 : g0);
+    }
+    xk += xk_step;
+    const bool tile_end = ++ckt == s.k_hi;
+    const float s_ = bf16_bits_to_f32(sb[j] & 0xFFFFu);
+    const float nzp_ = -(bf16_bits_to_f32(sb[j] >> 16) + EX::OFFSET);
+    tot = fmaf(s_, fmaf(nzp_, xt[0], g0[0] + g1[0]), tot);
+    xt += 16;
+    if (tile_end) {
+      float* dst = red + ((size_t)(cv * g.WK + s.wk)) * 16 + ni;
+      if (kb == 0) dst[0] = tot;
+      tot = 0.f;
+      ckt = s.k_lo;
+      cv += g.WN;
+      xk = xk_reset;
+      xt = xsum_tab + s.k_lo * 16;
+    }
+  }
+}
+
+__global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const AttnBlockArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int bid = (int)blockIdx.x;
+  unsigned tag = p.state[0] + 1u;
+  if (tag == 0u) tag = 1u;
+
+  if (bid < p.NA) {
+    // ------------------------------------------------------------------------------------------------ attention workgroup
+    // (It takes no column tiles: its length / span-pointer / K / V loads are dependent round trips whose waits -- loads return
+    // in order -- would also wait for a weight share requested before them, and a share requested after them would wait for
+    // the 64 KB of K / V: either way the workgroup would publish its tiles late, and every workgroup waits for all tiles.)
+    if (threadIdx.x >= ATTN_THREADS) return;  // a 4-wave body (barriers count live waves only)
+    AttnHandoff ho;
+    ho.qkv_gran = p.qkv_gran;
+    ho.out_gran = p.out_gran;
+    ho.out_gran_bytes = p.out_gran_bytes;
+    ho.grp_flag = p.grp_flag;
+    ho.err = p.state + 1;
+    ho.tag = tag;
+    ho.spin_limit = p.spin_limit;
+    const int ns = p.a.nsplits;
+    span_attn_ft_mfma_body<DIHIP_BF16, DIHIP_KV_NONE, true, true>(p.a, bid % ns, bid / ns, 0, ns, p.a.g, 1, smem, &ho);
+    return;
+  }
+
+  // ---------------------------------------------------------------------------------------------------- GEMV workgroup
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const GemvArgs& q = p.q;
+  const GemvArgs& o = p.o;
+  const int NB = p.NG;
+  const int lb = bid - p.NA;
+  const int ob = NB - 1 - lb;  // the o-projection's tiles are dealt in reverse block order: two qkv tiles -> one o tile
+  // wave 0's wall-clock stamps (tools/attn_block_trace.py on the `make trace` build); absent from the product build
+#if defined(DIHIP_GEMV_TRACE) && DIHIP_GEMV_TRACE
+#define DIHIP_AB_STAMP(I)                                                              \
+  do {                                                                                 \
+    if (p.trace && wave == 0) p.trace[(size_t)bid * 32 + (I)] = wall_clock64();        \
+  } while (0)
+#else
+#define DIHIP_AB_STAMP(I) do { } while (0)
+#endif
+  DIHIP_AB_STAMP(0);
+
+  // ---- loads that depend on nothing but the kernel arguments go out first: the epilogues' bias / residual elements (one per
+  // thread: a dependent global load in an epilogue is ~1 us on the launch's critical path), then the early activation batch:
+  // 8-element vectors i = j * THREADS + tid of the f32 hidden row + gamma (K <= 8192), then the qkv share ----
+  const int nq_e = (q.nu_q + (lb < q.nu_r ? 1 : 0)) * 16, no_e = (o.nu_q + (ob < o.nu_r ? 1 : 0)) * 16;  // epilogue elements (<= 512)
+  const int n_q = (lb + (tid >> 4) * NB) * 16 + (tid & 15), n_o = (ob + (tid >> 4) * NB) * 16 + (tid & 15);
+  uint32_t bias_bits = 0u, hres_bits = 0u;
+  {
+    const bool bq = q.bias != nullptr && tid < nq_e && n_q < q.N, bo = o.h_res != nullptr && tid < no_e && n_o < o.N;
+    // (unconditional asm loads, clamped: see ab_issue)
+    asm volatile("global_load_ushort %0, %1, %2" : "=&v"(bias_bits) : "v"((uint32_t)(bq ? n_q : 0) * 2u), "s"(q.bias ? q.bias : q.gamma));
+    asm volatile("global_load_dword %0, %1, %2" : "=&v"(hres_bits) : "v"((uint32_t)(bo ? n_o : 0) * 4u), "s"(o.h_res ? (const void*)o.h_res : q.x));
+  }
+  const int nvec_q = q.K >> 3;
+  u32x4_t ev[4], eg[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    // (both batches unconditionally, indices clamped: a batch defined on one path only is a phi, and the compiler resolves a phi on
+    // an asm load's registers with copies wherever it likes -- before the wait: tools/audit_asm_loads.py)
+    const uint32_t i = (uint32_t)min(j * AB_THREADS + tid, nvec_q - 1);
+    stream_load_plain_b128(ev[2 * j], q.x, i * 32u);
+    stream_load_plain_b128(ev[2 * j + 1], q.x, i * 32u + 16u);
+    stream_load_plain_b128(eg[j], q.gamma, i * 16u);
+  }
+  const AbShare sq = ab_share(q, lb, NB, wave);
+  u32x4_t wq[AB_RING], wo[AB_RING];
+  uint32_t sq_[AB_RING], so_[AB_RING];
+  ab_issue(q, sq, wq, sq_, lane);
+
+  uint16_t* xs = reinterpret_cast<uint16_t*>(smem + 256);
+  float* xsum_q = reinterpret_cast<float*>(smem + 256 + gemv_xs_bytes(1, q.RS));
+  float* red_q = xsum_q + (size_t)q.KT * 16;
+  if (tid < 16) reinterpret_cast<u32x4_t*>(smem)[tid] = u32x4_t{0u, 0u, 0u, 0u};  // zero block (A rows >= M)
+
+  // ---- RMSNorm prologue (gemv_stream_body PRO_RMSNORM, one row): rstd = 1/sqrt(mean(x^2)+eps); x_norm = FT((gamma*x)*rstd) ----
+  stream_wait<2 * AB_RING>();  // everything older than the ring: the early batch
+#pragma unroll
+  for (int j = 0; j < 4; ++j) early_landed(ev[j]);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) early_landed(eg[j]);
+  asm volatile("" : "+v"(bias_bits), "+v"(hres_bits));  // (older than the early batch)
+  {
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (j * AB_THREADS + tid < nvec_q) {
+        const f32x4_t h0 = __builtin_bit_cast(f32x4_t, ev[2 * j]), h1 = __builtin_bit_cast(f32x4_t, ev[2 * j + 1]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ss = fmaf(h0[c], h0[c], ss);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ss = fmaf(h1[c], h1[c], ss);
+      }
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) red_q[wave] = ss;
+    __syncthreads();
+    float tot_ss = 0.f;
+#pragma unroll
+    for (int w = 0; w < GEMV_WAVES; ++w) tot_ss += red_q[w];
+    const float rstd = 1.f / sqrtf(tot_ss / (float)q.K + q.eps);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = j * AB_THREADS + tid;
+      if (i < nvec_q) {
+        const f32x4_t h0 = __builtin_bit_cast(f32x4_t, ev[2 * j]), h1 = __builtin_bit_cast(f32x4_t, ev[2 * j + 1]);
+        u32x4_t v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float ga = bf16_bits_to_f32(eg[j][c] & 0xFFFFu), gb_ = bf16_bits_to_f32(eg[j][c] >> 16);
+          const float xa = c < 2 ? h0[2 * c] : h1[2 * c - 4], xb = c < 2 ? h0[2 * c + 1] : h1[2 * c - 3];
+          v[c] = pack_ft2<DIHIP_BF16>((ga * xa) * rstd, (gb_ * xb) * rstd);
+        }
+        ab_stage_vector(xs, xsum_q, i, v, true);
+      }
+    }
+  }
+  DIHIP_AB_STAMP(1);  // row normalised and staged
+  stream_wait<0>();   // the qkv share has landed
+#pragma unroll
+  for (int j = 0; j < AB_RING; ++j) stream_landed(wq[j], sq_[j]);
+  __syncthreads();  // the row is staged; the RMS partials in red_q have been read
+  DIHIP_AB_STAMP(2);  // qkv share landed
+
+  // ---- qkv tiles of this workgroup ----
+  ab_consume(q, sq, wq, sq_, smem, xsum_q, red_q, lane);
+  __syncthreads();
+  if (tid < nq_e && n_q < q.N) {  // element e = tid: column tile e / 16 of this workgroup, column e % 16
+    float v = 0.f;
+    const float* pr = red_q + ((size_t)(tid >> 4) * q.WK) * 16 + (tid & 15);
+    for (int s = 0; s < q.WK; ++s) v += pr[(size_t)s * 16];
+    v = __fmul_rn(q.alpha, v);
+    if (q.bias) v = __fadd_rn(v, bf16_bits_to_f32(bias_bits & 0xFFFFu));
+    const unsigned long long gran = ((unsigned long long)tag << 32) | (unsigned long long)f32_to_bf16_bits(v);
+    __hip_atomic_store(p.qkv_gran + n_q, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  DIHIP_AB_STAMP(3);  // qkv tiles published
+  // the o-projection's share: requested only now -- nothing on this workgroup's path needs it for several microseconds -- so
+  // that it does not queue in front of the qkv shares every workgroup of the launch waits for
+  const AbShare so = ab_share(o, ob, NB, wave);
+  ab_issue(o, so, wo, so_, lane);
+  stream_wait<0>();
+#pragma unroll
+  for (int j = 0; j < AB_RING; ++j) stream_landed(wo[j], so_[j]);
+
+  // ---- wait for the attention output: ONE lane per KV group polls the group's first output granule (the merging workgroup
+  // stores all of a group's granules in one go: when the first carries this launch's tag the others are at most a retry
+  // away), then one sweep of all granules.  (A separate flag word behind a store drain cost the producer ~0.7 us more.) ----
+  if (wave == 0) {
+    for (unsigned spins = 0;; ++spins) {
+      const unsigned f = lane < p.a.g ? (unsigned)(__hip_atomic_load(p.out_gran + (size_t)lane * p.a.hpg * 64, __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_AGENT) >> 32)
+                                      : tag;
+      if (__builtin_amdgcn_ballot_w64(f != tag) == 0ull) break;
+      if (spins > p.spin_limit) {
+        if (lane == 0) __hip_atomic_store(p.state + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  __syncthreads();  // (also: every reader of red_q / xs of the first phase is done)
+  DIHIP_AB_STAMP(4);  // every group's first output granule seen
+  float* xsum_o = reinterpret_cast<float*>(smem + 256 + gemv_xs_bytes(1, o.RS));
+  float* red_o = xsum_o + (size_t)o.KT * 16;
+  {
+    // thread -> 8-element vector i = its 4 consecutive granules: staged and summed per k-tile in one pass (ab_stage_vector)
+    const int nvec_o = o.K >> 3;
+    for (int i = tid; i < ((nvec_o + 15) & ~15); i += AB_THREADS) {  // (whole 16-lane rows: the sums cross lanes)
+      const int ic = min(i, nvec_o - 1);
+      unsigned long long gv[4];
+      for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          gv[j] = __hip_atomic_load(p.out_gran + (size_t)ic * 4 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && (unsigned)(gv[j] >> 32) == tag;
+        }
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+        if (spins > p.spin_limit) {
+          if (lane == 0) __hip_atomic_store(p.state + 1, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      const u32x4_t v = {(uint32_t)gv[0], (uint32_t)gv[1], (uint32_t)gv[2], (uint32_t)gv[3]};
+      if (i < nvec_o) ab_stage_vector(xs, xsum_o, i, v, true);
+    }
+  }
+  __syncthreads();
+  DIHIP_AB_STAMP(5);  // attention output swept into LDS
+
+  // ---- o-projection tiles: h_out = h_res + attn . Wo ----
+  ab_consume(o, so, wo, so_, smem, xsum_o, red_o, lane);
+  __syncthreads();
+  DIHIP_AB_STAMP(6);  // o tiles multiplied
+  if (tid < no_e && n_o < o.N) {
+    float v = 0.f;
+    const float* pr = red_o + ((size_t)(tid >> 4) * o.WK) * 16 + (tid & 15);
+    for (int s = 0; s < o.WK; ++s) v += pr[(size_t)s * 16];
+    const float base = o.h_res ? __uint_as_float(hres_bits) : 0.f;
+    o.h_out[n_o] = __fadd_rn(base, __fmul_rn(o.alpha, v));
+  }
+  DIHIP_AB_STAMP(7);
+#undef DIHIP_AB_STAMP
+  // the next launch's epoch (see the header: every workgroup has read the old one by now)
+  if (lb == 0 && tid == 0) p.state[0] = tag;
+}
+
+static bool attn_block_enabled() {
+  static const bool on = !env_off("DIHIP_ATTN_BLOCK");  // =0: "not supported" (callers keep the launch chain; A/B)
+  return on;
+}
+
+struct AbLayout {
+  size_t flags, tickets, qkv_gran, out_gran, total;
+};
+// attention / GEMV workgroup counts: every workgroup resident (<= one per CU), every GEMV workgroup owns >= 1 tile of both matrices
+static bool ab_grid(int n_heads, int n_groups, int head_size, int hidden, int nsplits, int* NA, int* NG) {
+  const int ncu = cached_num_cus();
+  if (ncu <= 0) return false;
+  *NA = nsplits * n_groups;
+  *NG = std::min(ncu - *NA, std::min((n_heads + 2 * n_groups) * head_size / 16, hidden / 16));
+  return *NG >= 32;
+}
+static AbLayout ab_layout(int n_heads, int n_groups, int head_size) {
+  AbLayout l;
+  l.flags = 64;
+  l.tickets = 128;
+  l.qkv_gran = (l.tickets + (size_t)n_groups * 128 + 255) & ~(size_t)255;
+  l.out_gran = l.qkv_gran + (size_t)(n_heads + 2 * n_groups) * head_size * 8;
+  l.total = l.out_gran + (size_t)n_heads * head_size / 2 * 8;
+  return l;
+}
+
+}  // namespace dihip
+
+using namespace dihip;
+
+extern "C" {
+
+int dihip_decode_attn_block_supported(int wbits, int group_size, int hidden, int n_heads, int n_groups, int head_size, int max_seq_len,
+                                      int kv_mode, int dtype, int batch) {
+  if (!attn_block_enabled() || batch != 1 || wbits != 4 || dtype != DIHIP_BF16 || kv_mode != DIHIP_KV_NONE || head_size != 128) return 0;
+  if (n_heads <= 0 || n_groups <= 0 || n_groups > 16 || n_heads % n_groups || n_heads / n_groups > MF_HC || hidden <= 0 || hidden > 8192 ||
+      hidden % 128 || max_seq_len <= 0)
+    return 0;
+  int ns, nc, tps;
+  size_t pb;
+  span_attn_block_plan(1, n_heads, n_groups, max_seq_len, &ns, &nc, &tps, &pb);
+  if (nc != 1 || ns < 2 || pb >= (1ull << 31)) return 0;  // (one split: no merge, no ticket -- the chain's single launch is as good)
+  int NA, NG;
+  if (!ab_grid(n_heads, n_groups, head_size, hidden, ns, &NA, &NG)) return 0;
+  GemvArgs gq{}, go{};
+  int mu;
+  size_t lds;
+  const int Nq = (n_heads + 2 * n_groups) * head_size, Ko = n_heads * head_size;
+  if (!gemv_block_plan(4, Nq, hidden, group_size, NG, &gq, &mu, &lds) || gq.ktpg != 1) return 0;
+  if (!gemv_block_plan(4, hidden, Ko, group_size, NG, &go, &mu, &lds) || go.ktpg != 1 || Ko > 8192) return 0;
+  // every wave's share must fit its ring: ceil(units / WN) * longest k-slice
+  auto fits = [](const GemvArgs& g) {
+    int longest = 0;
+    for (int i = 0; i < g.WK; ++i) longest = std::max(longest, g.kcut[i + 1] - g.kcut[i]);
+    return ((g.upb + g.WN - 1) / g.WN) * longest <= AB_RING;
+  };
+  return fits(gq) && fits(go) ? 1 : 0;
+}
+
+size_t dihip_decode_attn_block_sync_bytes(int n_heads, int n_groups, int head_size) {
+  if (n_heads <= 0 || n_groups <= 0 || head_size <= 0) return 0;
+  return ab_layout(n_heads, n_groups, head_size).total;
+}
+
+size_t dihip_decode_attn_block_workspace_bytes(int n_heads, int n_groups, int head_size, int max_seq_len) {
+  if (n_heads <= 0 || n_groups <= 0 || n_heads % n_groups || max_seq_len <= 0) return 0;
+  (void)head_size;
+  int ns, nc, tps;
+  size_t pb;
+  span_attn_block_plan(1, n_heads, n_groups, max_seq_len, &ns, &nc, &tps, &pb);
+  return pb + 256;
+}
+
+int dihip_decode_attn_block(void* stream, int wbits, const float* h_in, const float* h_res, float* h_out, const void* gamma, float eps,
+                            const void* qkv_w, const void* qkv_sz, const void* qkv_bias, const void* o_w, const void* o_sz,
+                            void* const* k_span_array, void* const* v_span_array, const uint32_t* old_seq_lens_dev,
+                            const float* rope_table, int hidden, int n_heads, int n_groups, int head_size, int group_size, int span_len,
+                            int n_spans_per_request, int max_seq_len, int kv_mode, int dtype, float qk_scale, void* ws, size_t ws_bytes,
+                            void* sync, size_t sync_bytes) {
+  DIHIP_REQUIRE(h_in && h_out && gamma && qkv_w && qkv_sz && o_w && o_sz && k_span_array && v_span_array && old_seq_lens_dev && rope_table &&
+                    ws && sync,
+                DIHIP_PARAM_ERROR, "decode_attn_block: null pointer");
+  DIHIP_REQUIRE(span_len == 16 || span_len == 32 || span_len == 64 || span_len == 128, DIHIP_PARAM_ERROR,
+                "span_attn: span length %d not in {16,32,64,128}", span_len);
+  DIHIP_REQUIRE(n_spans_per_request > 0, DIHIP_PARAM_ERROR, "decode_attn_block: invalid parameter");
+  DIHIP_REQUIRE(dihip_decode_attn_block_supported(wbits, group_size, hidden, n_heads, n_groups, head_size, max_seq_len, kv_mode, dtype, 1),
+                DIHIP_PARAM_ERROR,
+                "decode_attn_block: configuration not covered (batch 1, bf16, int4 g128, 16-bit cache, head size 128); see _supported");
+  DIHIP_REQUIRE(reinterpret_cast<uintptr_t>(h_in) % 16 == 0 && reinterpret_cast<uintptr_t>(gamma) % 16 == 0, DIHIP_PARAM_ERROR,
+                "decode_attn_block: the hidden row and gamma must be 16-byte aligned");
+  const AbLayout lay = ab_layout(n_heads, n_groups, head_size);
+  DIHIP_REQUIRE(sync_bytes >= lay.total && reinterpret_cast<uintptr_t>(sync) % 16 == 0, DIHIP_MEMORY_ERROR,
+                "decode_attn_block: sync buffer too small (%zu < %zu)", sync_bytes, lay.total);
+  int ns, nc, tps;
+  size_t pb;
+  span_attn_block_plan(1, n_heads, n_groups, max_seq_len, &ns, &nc, &tps, &pb);
+  DIHIP_REQUIRE(ws_bytes >= pb, DIHIP_MEMORY_ERROR, "decode_attn_block: workspace too small (%zu < %zu)", ws_bytes, pb);
+  AttnBlockArgs p{};
+  ab_grid(n_heads, n_groups, head_size, hidden, ns, &p.NA, &p.NG);
+  int mu;
+  size_t lds_q, lds_o;
+  const int Nq = (n_heads + 2 * n_groups) * head_size, Ko = n_heads * head_size;
+  gemv_block_plan(4, Nq, hidden, group_size, p.NG, &p.q, &mu, &lds_q);
+  gemv_block_plan(4, hidden, Ko, group_size, p.NG, &p.o, &mu, &lds_o);
+  p.q.w0 = reinterpret_cast<const u32x4_t*>(qkv_w);
+  p.q.sz0 = reinterpret_cast<const uint32_t*>(qkv_sz);
+  p.q.x = h_in;
+  p.q.gamma = gamma;
+  p.q.eps = eps;
+  p.q.bias = qkv_bias;
+  p.o.w0 = reinterpret_cast<const u32x4_t*>(o_w);
+  p.o.sz0 = reinterpret_cast<const uint32_t*>(o_sz);
+  p.o.h_res = h_res;
+  p.o.h_out = h_out;
+  char* sb = reinterpret_cast<char*>(sync);
+  p.state = reinterpret_cast<unsigned*>(sb);
+  p.grp_flag = reinterpret_cast<unsigned*>(sb + lay.flags);
+  p.qkv_gran = reinterpret_cast<unsigned long long*>(sb + lay.qkv_gran);
+  p.out_gran = reinterpret_cast<unsigned long long*>(sb + lay.out_gran);
+  p.out_gran_bytes = (size_t)n_heads * head_size / 2 * 8;
+  static const unsigned spin_limit = (unsigned)std::max(1024, env_int("DIHIP_ATTN_BLOCK_SPINS", 1 << 18));
+  p.spin_limit = spin_limit;
+  AttnArgs& a = p.a;
+  a.kspans = k_span_array;
+  a.vspans = v_span_array;
+  a.seq_lens = old_seq_lens_dev;
+  a.partials = reinterpret_cast<float*>(ws);
+  a.counters = reinterpret_cast<unsigned*>(sb + lay.tickets);
+  a.B = 1;
+  a.n = n_heads;
+  a.g = n_groups;
+  a.hpg = n_heads / n_groups;
+  a.S = span_len;
+  a.span_stride = n_spans_per_request;
+  a.nsplits = ns;
+  a.nchunks = 1;
+  a.scale = qk_scale;
+  a.rope_tab = rope_table;
+  a.tps_static = tps;
+  a.merge_wt = 1;
+  a.partial_bytes = pb;
+  p.trace = debug_trace_buffer((size_t)(p.NA + p.NG) * 32 * sizeof(unsigned long long));
+  a.trace = p.trace;  // (the attention body's own stamps: [workgroup][wave][8])
+  const size_t lds = std::max<size_t>(std::max(lds_q, lds_o), ((FT_MFMA_SMEM_BYTES + 15) & ~15) + FT_MFMA_GATHER_IMG_BYTES);
+  auto kern = decode_attn_block_kernel;
+  if (lds > 64 * 1024) {
+    static std::atomic<size_t> granted{0};
+    if (lds > granted.load(std::memory_order_relaxed)) {
+      DIHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                      DIHIP_RUNTIME_ERROR);
+      granted.store(lds, std::memory_order_relaxed);
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(p.NA + p.NG), dim3(AB_THREADS), lds, reinterpret_cast<hipStream_t>(stream), p);
+  return launch_status();
+}
+
+}  // extern "C"

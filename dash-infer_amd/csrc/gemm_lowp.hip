@@ -338,6 +338,38 @@ static GemvPlan make_gemv_plan(int wbits, int M, int N, int K, int group_size, b
   return p;
 }
 
+// The decode GEMV's plan for ONE row as the workgroups of ANOTHER launch run it (decode_attn_block.hip): the K split (WK, kcut)
+// and the wave grid are those of the stand-alone launch -- the sums are then bit-identical to it -- while the column tiles are dealt
+// over `nblocks` workgroups (block b owns tiles b, b + nblocks, ...).  Fills the shape / plan fields of *g (pointers are the
+// caller's); *max_units = most tiles one workgroup owns, *lds_bytes = its LDS need.  False: shape not served by the decode GEMV.
+bool gemv_block_plan(int wbits, int N, int K, int group_size, int nblocks, GemvArgs* g, int* max_units, size_t* lds_bytes) {
+  const GemvPlan gp = make_gemv_plan(wbits, 1, N, K, group_size, false);
+  const LowpDims d = lowp_dims(wbits, N, K, group_size);
+  if (!gp.ok || gp.MR != 1 || K != d.Kp || nblocks < 1 || nblocks > d.NTILES) return false;
+  g->M = 1;
+  g->N = N;
+  g->K = K;
+  g->ldx = K;
+  g->ldy = N;
+  g->KT = d.KT;
+  g->NTILES = d.NTILES;
+  g->Gp = lowp_dims(4, N, K, group_size).Gp;
+  g->ktpg = gp.ktpg;
+  g->kgroups = gp.kgroups;
+  g->WK = gp.WK;
+  g->WN = gp.WN;
+  g->RS = gp.RS;
+  g->nu_q = d.NTILES / nblocks;
+  g->nu_r = d.NTILES % nblocks;
+  g->upb = g->nu_q + (g->nu_r ? 1 : 0);
+  g->alpha = 1.f;
+  g->act = DIHIP_ACT_NONE;
+  fill_kcut(*g);
+  *max_units = g->upb;
+  *lds_bytes = gemv_lds_bytes(1, gp.RS, d.KT, g->upb, 0, gp.WK);
+  return true;
+}
+
 template <int WBITS, int FT>
 static hipError_t dispatch_gemv(const GemvPlan& p, int pro, int epi, const GemvArgs& a, hipStream_t s) {
   const bool gpt = WBITS != 16 && p.ktpg == 1;

@@ -769,6 +769,17 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
   return DIHIP_SA_SUCCESS;
 }
 
+// the decode-step plan of the 16-bit cache as decode_attn_block.hip runs it inside its own launch: the split count, split width
+// and record buffer of span_attn_fused_mfma below (same partial records, same merge order)
+void span_attn_block_plan(int batch, int n_heads, int n_groups, int max_seq_len, int* nsplits, int* nchunks, int* tps_static,
+                          size_t* partial_bytes) {
+  const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true);
+  *nsplits = p.nsplits;
+  *nchunks = p.nchunks;
+  *tps_static = ((max_seq_len + p.nsplits - 1) / p.nsplits + 31) & ~31;
+  *partial_bytes = p.partial_bytes;
+}
+
 // decode-step form (Rotary + cache append folded in) for the 16-bit cache: span_attn_ft_mfma_kernel<FT, NONE, true>
 size_t span_attn_fused_mfma_workspace_bytes(int batch, int n_heads, int n_groups, int max_seq_len) {
   return attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true).partial_bytes;

@@ -37,6 +37,20 @@ struct AttnArgs {
   unsigned long long* trace;  // diagnostics (`make trace` build + dihip_debug_set_trace): [workgroup][wave][8] wall-clock stamps, or null
 };
 
+// In-launch hand-off of the fused attention block (decode_attn_block.hip: RMSNorm + qkv GEMV, Rotary + append + attention and
+// the o-projection in ONE launch).  Transport: 8-byte granules {value (low dword), tag (high dword)} written by ONE aligned
+// agent-scope store and polled with agent-scope loads -- the data is the flag (MI355X guide, Guideline 16 form R2): a stale
+// line can only show an older tag.  `tag` is the launch's epoch (read from the state block at entry, never 0).
+struct AttnHandoff {
+  const unsigned long long* qkv_gran;  // [(n + 2g) * H]: one FT element of the fused pre-Rotary qkv row per granule
+  unsigned long long* out_gran;        // [n * H / 2]: two packed FT elements of the attention output per granule
+  size_t out_gran_bytes;
+  unsigned* grp_flag;                  // [g]: tag once the group's merged output granules have drained
+  unsigned* err;                       // set non-zero when a bounded wait gave up (results are then garbage, nothing hangs)
+  unsigned tag;
+  unsigned spin_limit;
+};
+
 // decode-step form on the matrix cores (span_attn.hip); returns a DIHIP status, DIHIP_PARAM_ERROR with
 // *handled = false when the configuration is not covered (caller falls back to its own kernels)
 int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* const* k_span_array, void* const* v_span_array,

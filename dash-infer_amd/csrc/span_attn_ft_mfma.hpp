@@ -8,9 +8,10 @@ namespace dihip {
 // Block epilogue shared by the decode kernels: the 4 waves have left one (o[128], m, l) record per head in
 // `lds` ([wave][HC] records of ATTN_PSTRIDE floats).  Combines them and writes the output, or, for split
 // sequences, the block's partial record for span_attn_split_merge_kernel.
-template <int FT, int HC>
+template <int FT, int HC, bool GRAN = false>
 __device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float* lds, unsigned* flag_lds, int b, int h0, int nh,
-                                                       int split, unsigned* counter, unsigned long long* tr);
+                                                       int split, unsigned* counter, unsigned long long* tr,
+                                                       const AttnHandoff* ho = nullptr, int grp = 0);
 
 template <int FT, int HC>
 __device__ __forceinline__ void attn_block_epilogue(const AttnArgs& a, float* lds, unsigned* flag_lds, int b, int h0, int nh,
@@ -79,8 +80,10 @@ __device__ __forceinline__ void attn_block_epilogue(const AttnArgs& a, float* ld
 
 // the last-arriving workgroup's part of attn_block_epilogue_wt: all nsplits records of its heads, read past the L1 (sc1),
 // merged in split order, output written.  MB = records per load batch.
-template <int FT, int MB, typename RSRC>
-__device__ __forceinline__ void merge_split_records(const AttnArgs& a, RSRC rsrc, int b, int h0, int nh, unsigned long long* tr) {
+// GRAN (fused attention block): the merged output leaves as granules for the o-projection's workgroups instead of FT rows
+template <int FT, int MB, bool GRAN = false, typename RSRC>
+__device__ __forceinline__ void merge_split_records(const AttnArgs& a, RSRC rsrc, int b, int h0, int nh, unsigned long long* tr,
+                                                    const AttnHandoff* ho = nullptr) {
   constexpr int H = 128;
   const int tid = threadIdx.x;
   for (int e = tid; e < nh * 32; e += ATTN_THREADS) {
@@ -122,6 +125,13 @@ __device__ __forceinline__ void merge_split_records(const AttnArgs& a, RSRC rsrc
     float r[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) r[q] = ll > 0.f ? oo[q] / ll : 0.f;
+    if constexpr (GRAN) {
+      // two granules (4 dims) in one 16-byte write-through store: each granule is whole inside its aligned 8-byte half
+      const auto grsrc = __builtin_amdgcn_make_buffer_rsrc(ho->out_gran, 0, (int)ho->out_gran_bytes, 0x00020000);
+      const u32x4_t gv = {pack_ft2<FT>(r[0], r[1]), ho->tag, pack_ft2<FT>(r[2], r[3]), ho->tag};
+      __builtin_amdgcn_raw_buffer_store_b128(gv, grsrc, (uint32_t)((((size_t)b * a.n + h0 + h) * (H / 2) + dq * 2) * 8), 0, 16 /* sc1 */);
+      continue;
+    }
     if constexpr (FT != DIHIP_F32) {
       if (!a.out_frag_mt) {  // row-major output: the lane's 4 dims are one 8-byte store (same round-to-nearest-even bits as store_ft)
         const u32x2_t pk = {pack_ft2<FT>(r[0], r[1]), pack_ft2<FT>(r[2], r[3])};
@@ -149,9 +159,10 @@ __device__ __forceinline__ void merge_split_records(const AttnArgs& a, RSRC rsrc
 // arrivals and merges head s, so that a group's heads merge on 7 CUs in parallel -- shorten the merge reads from 2.6 to 1.2 us
 // but see the last arrival 1.4 us late through their poll: 10.6 vs 10.2 us per layer, removed; the hand-off as a whole
 // costs ~3 us (store drain ~1, ticket ~0.5, reads of freshly handed-off records ~1.5-2.5) either way.)
-template <int FT, int HC>
+template <int FT, int HC, bool GRAN>
 __device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float* lds, unsigned* flag_lds, int b, int h0, int nh,
-                                                       int split, unsigned* counter, unsigned long long* tr) {
+                                                       int split, unsigned* counter, unsigned long long* tr,
+                                                       const AttnHandoff* ho, int grp) {
   constexpr int H = 128;
   const int tid = threadIdx.x;
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.partials, 0, (int)a.partial_bytes, 0x00020000);
@@ -197,10 +208,11 @@ __device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float*
   if (*flag_lds == 0u) return;
   // records per batch: all loads of a batch are in flight together.  The batch width follows the split count (8 / 16 / 24 /
   // 32), so that a 17-split plan issues 24 record loads per lane, not 32 (the excess re-reads the last record)
-  if (a.nsplits <= 8) merge_split_records<FT, 8>(a, rsrc, b, h0, nh, tr);
-  else if (a.nsplits <= 16) merge_split_records<FT, 16>(a, rsrc, b, h0, nh, tr);
-  else if (a.nsplits <= 24) merge_split_records<FT, 24>(a, rsrc, b, h0, nh, tr);
-  else merge_split_records<FT, 32>(a, rsrc, b, h0, nh, tr);
+  if (a.nsplits <= 8) merge_split_records<FT, 8, GRAN>(a, rsrc, b, h0, nh, tr, ho);
+  else if (a.nsplits <= 16) merge_split_records<FT, 16, GRAN>(a, rsrc, b, h0, nh, tr, ho);
+  else if (a.nsplits <= 24) merge_split_records<FT, 24, GRAN>(a, rsrc, b, h0, nh, tr, ho);
+  else merge_split_records<FT, 32, GRAN>(a, rsrc, b, h0, nh, tr, ho);
+  // (GRAN: no flag behind the granules -- the consumers poll the group's first granule, then sweep)
 }
 
 constexpr int MF_HC = 16;   // query heads per workgroup chunk (MFMA N)
@@ -241,15 +253,20 @@ __device__ __forceinline__ u32x4_t ld_qkv16(const uint16_t* p) { return *reinter
 #if defined(DIHIP_GEMV_TRACE) && DIHIP_GEMV_TRACE
 #define DIHIP_ATTN_STAMP(I)                                                                                          \
   do {                                                                                                               \
-    if (a.trace) a.trace[(((size_t)bz * gy + by) * gx + bx) * 32 + (threadIdx.x >> 6) * 8 + (I)] = wall_clock64();    \
+    if (a.trace && threadIdx.x < 256) a.trace[(((size_t)bz * gy + by) * gx + bx) * 32 + (threadIdx.x >> 6) * 8 + (I)] = wall_clock64(); \
   } while (0)
 #else
 #define DIHIP_ATTN_STAMP(I) do { } while (0)
 #endif
 
-template <int FT, int MODE, bool FUSED>
+// GATHER (fused attention block, FUSED form only): this step's q / k / v elements arrive as granules from the qkv GEMV's
+// workgroups of the SAME launch (AttnHandoff): swept into an LDS image behind the kernel's buffer while the K / V tiles are in
+// flight, and the merged output leaves as granules.  One head chunk per group (nchunks == 1).
+constexpr int FT_MFMA_GATHER_IMG_BYTES = (MF_HC + 2) * 128 * 2;
+template <int FT, int MODE, bool FUSED, bool GATHER = false>
 __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const int bx, const int by, const int bz, const int gx,
-                                                       const int gy, const int gz, unsigned char* smem) {
+                                                       const int gy, const int gz, unsigned char* smem,
+                                                       const AttnHandoff* ho = nullptr) {
   constexpr int H = 128;
   constexpr int HC = MF_HC;
   constexpr bool Q8 = MODE == DIHIP_KV_I8;
@@ -376,11 +393,15 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
 
   // rotate-half on a lane's fragments: dims ks*32 + kb*8 + e (ks = 0, 1) pair with ks + 2; table row = position.
   // Same arithmetic and rounding as dihip_rope_qk / the Rotary op: two products, one add, rounded to FT.
+  // GATHER: this lane's {cos, sin} rows are requested BEFORE the wait for the q granules (csr): the table row depends on the
+  // position alone, and a load issued after the hand-off is a whole round trip on the launch's critical path
+  f32x4_t csr[2][4];
   auto rotate = [&](u32x4_t (&f)[4], const float* cs_row) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const f32x4_t* t = reinterpret_cast<const f32x4_t*>(cs_row + (ks * 32 + kb * 8) * 2);
-      const f32x4_t c0 = t[0], c1 = t[1], c2 = t[2], c3 = t[3];  // {cos, sin} x 8 dims
+      const f32x4_t c0 = GATHER ? csr[ks][0] : t[0], c1 = GATHER ? csr[ks][1] : t[1], c2 = GATHER ? csr[ks][2] : t[2],
+                    c3 = GATHER ? csr[ks][3] : t[3];  // {cos, sin} x 8 dims
       const float cosv[8] = {c0[0], c0[2], c1[0], c1[2], c2[0], c2[2], c3[0], c3[2]};
       const float sinv[8] = {c0[1], c0[3], c1[1], c1[3], c2[1], c2[3], c3[1], c3[3]};
       u32x4_t lo_, hi_;
@@ -409,9 +430,49 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   float qsum = 0.f;
   const size_t qrow_stride = FUSED ? (size_t)(a.n + 2 * a.g) * H : (size_t)a.n * H;
   const float* cs_row = FUSED ? a.rope_tab + (size_t)newpos * 128 : nullptr;
+  uint16_t* const img = reinterpret_cast<uint16_t*>(smem + ((FT_MFMA_SMEM_BYTES + 15) & ~15));  // GATHER: [hpg q heads][k][v] x 128
+  if constexpr (GATHER) {
+    static_assert(FUSED && MODE == DIHIP_KV_NONE, "the gathering form is the decode step over the 16-bit cache");
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) csr[ks][j] = reinterpret_cast<const f32x4_t*>(cs_row + (ks * 32 + kb * 8) * 2)[j];
+    const int nq = a.hpg * H, tot = nq + 2 * H;
+    constexpr int GB = 5;  // granules per thread per sweep: (7 + 2) heads x 128 = 4.5 x 256 threads
+    for (int base = 0; base < tot; base += GB * ATTN_THREADS) {
+      int src[GB];
+#pragma unroll
+      for (int j = 0; j < GB; ++j) {
+        const int idx = min(base + j * ATTN_THREADS + tid, tot - 1);
+        src[j] = idx < nq ? h0 * H + idx : idx < nq + H ? (a.n + grp) * H + (idx - nq) : (a.n + a.g + grp) * H + (idx - nq - H);
+      }
+      unsigned long long gv[GB];
+      for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < GB; ++j) {
+          gv[j] = __hip_atomic_load(ho->qkv_gran + src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && (unsigned)(gv[j] >> 32) == ho->tag;
+        }
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+        if (spins > ho->spin_limit) {  // gives up (wave-uniform): garbage results, flagged, never a hang
+          if (lane == 0) __hip_atomic_store(ho->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int j = 0; j < GB; ++j) {
+        const int idx = base + j * ATTN_THREADS + tid;
+        if (idx < tot) img[idx] = (uint16_t)gv[j];
+      }
+    }
+    __syncthreads();
+  }
   {
     const bool hv = ni < nh;
-    const uint16_t* qrow = reinterpret_cast<const uint16_t*>(a.q) + (size_t)b * qrow_stride + (size_t)(h0 + (hv ? ni : 0)) * H;
+    const uint16_t* qrow = GATHER ? img + (size_t)(hv ? ni : 0) * H
+                                  : reinterpret_cast<const uint16_t*>(a.q) + (size_t)b * qrow_stride + (size_t)(h0 + (hv ? ni : 0)) * H;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       qf[ks] = ld_qkv16(qrow + (Q8 ? kb * 32 + ks * 8 : ks * 32 + kb * 8));
@@ -433,8 +494,9 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   u32x4_t knew[4] = {}, vnew = {};
   if constexpr (FUSED) {
     if (has_new) {
-      const uint16_t* krow = reinterpret_cast<const uint16_t*>(a.q) + (size_t)b * qrow_stride + (size_t)(a.n + grp) * H;
-      const uint16_t* vrow = krow + (size_t)a.g * H;
+      const uint16_t* krow = GATHER ? img + (size_t)a.hpg * H
+                                    : reinterpret_cast<const uint16_t*>(a.q) + (size_t)b * qrow_stride + (size_t)(a.n + grp) * H;
+      const uint16_t* vrow = GATHER ? krow + H : krow + (size_t)a.g * H;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) knew[ks] = ld_qkv16(krow + ks * 32 + kb * 8);
       rotate(knew, cs_row);
@@ -609,9 +671,10 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   }
   if constexpr (FUSED) {
     if (a.merge_wt) {
-      attn_block_epilogue_wt<FT, HC>(a, lds, flag_lds, b, h0, nh, split,
-                                     a.counters + (((size_t)b * a.g + grp) * a.nchunks + hc) * 32,  // one 128-byte line each
-                                     a.trace ? a.trace + (((size_t)bz * gy + by) * gx + bx) * 32 + (threadIdx.x >> 6) * 8 : nullptr);
+      attn_block_epilogue_wt<FT, HC, GATHER>(a, lds, flag_lds, b, h0, nh, split,
+                                             a.counters + (((size_t)b * a.g + grp) * a.nchunks + hc) * 32,  // one 128-byte line each
+                                             a.trace ? a.trace + (((size_t)bz * gy + by) * gx + bx) * 32 + (threadIdx.x >> 6) * 8 : nullptr,
+                                             ho, grp);
       DIHIP_ATTN_STAMP(7);
       return;
     }

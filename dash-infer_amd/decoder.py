@@ -573,6 +573,17 @@ class DecodeSession:
         # split sequences: the partial records are merged inside the attention launch (arrival tickets in attn_sync, zeroed
         # once) instead of by a second launch; DIHIP_DECODER_ATTN_MERGE=launch restores the two-launch form (A/B)
         self.attn_merge_in_launch = os.environ.get("DIHIP_DECODER_ATTN_MERGE", "ticket") != "launch"
+        # Batch 1 (round 5): RMSNorm + qkv GEMV, Rotary + append + attention + merge and the o-projection + residual as ONE launch
+        # (dihip_decode_attn_block: weights and K / V tiles requested at launch, the operators hand over in-launch); bit-identical
+        # to the three launches it replaces.  DIHIP_DECODER_ATTN_BLOCK=0 keeps the chain (A/B).
+        self.attn_block = (batch == 1 and self.fused_attention and self.attn_merge_in_launch
+                           and os.environ.get("DIHIP_DECODER_ATTN_BLOCK", "1") != "0"
+                           and ops.decode_attn_block_supported(model.layers[0].qkv, cfg.hidden, self.n_loc, self.g_loc, H, max_len, kv_mode, dt, batch))
+        if self.attn_block:
+            need_ws = int(lib().dihip_decode_attn_block_workspace_bytes(self.n_loc, self.g_loc, H, max_len))
+            if self.attn_ws.numel() < need_ws:
+                self.attn_ws = torch.empty(need_ws, dtype=torch.uint8, device=device)
+            self.block_sync = torch.zeros(int(lib().dihip_decode_attn_block_sync_bytes(self.n_loc, self.g_loc, H)), dtype=torch.uint8, device=device)
         if not self.fused_attention and batch <= 32 and ops.prefers_frag(model.layers[0].o, batch):
             self.attn_frag = True
             self.attn = torch.zeros(ops.act_frag_numel(batch, self.n_loc * H), dtype=dt, device=device)
@@ -717,6 +728,20 @@ class DecodeSession:
         lw = m.layers[li]
         tp_on = self.comm is not None and m.nranks > 1
         nf = self.norm_fuse and not tp_on
+        if self.attn_block:
+            h_res = self.h if (not tp_on or m.rank == 0) else None
+            ops.decode_attn_block(self.h, h_res, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, lw.o, self.kv[li], self.old_lens, self.rope_tab,
+                                  self.n_loc, self.g_loc, self.H, self.max_len, self.scale, self.attn_ws, self.block_sync, out=self.h)
+            if tp_on:
+                self._allreduce(self.h, () if cfg.moe is not None else (lw.gate.w, lw.up.w))
+            if cfg.moe is not None:
+                self._moe_block(lw, tp_on)
+                return
+            ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act,
+                                  y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
+            nxt = m.layers[li + 1].qkv if li + 1 < len(m.layers) else m.lm_head
+            self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag, next_weights=(nxt.w,))
+            return
         if nf and not first:
             ops.prenorm_gemm(self.xn1, lw.qkv, lw.qkv_bias, sc, self.B, x_layout=self.xn1_layout, out=self.qkv)
         else:

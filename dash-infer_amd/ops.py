@@ -456,6 +456,27 @@ def span_attn_decode_step(qkv, kv, old_lens_dev, rope_tab, n, g, H, max_len, sca
     return out
 
 
+def decode_attn_block_supported(qkv_w, hidden, n, g, H, max_len, kv_mode, dtype, batch):
+    """True when dihip_decode_attn_block serves this configuration (batch 1, bf16, int4 g128, 16-bit cache, ...)."""
+    return bool(lib().dihip_decode_attn_block_supported(qkv_w.wbits, qkv_w.group, hidden, n, g, H, max_len, capi.KV[kv_mode],
+                                                         capi.BF16 if dtype == torch.bfloat16 else capi.F16, batch))
+
+
+def decode_attn_block(h, h_res, gamma, eps, qkv_w, qkv_bias, o_w, kv, old_lens_dev, rope_tab, n, g, H, max_len, scale, ws, sync, out=None):
+    """RMSNorm + qkv GEMV, Rotary + cache append + paged attention (+ split merge) and the o-projection + residual of ONE
+    request in ONE launch (dihip_decode_attn_block): out = h_res + attention(norm(h)) . Wo, bit-identical to the three calls.
+    h: f32 [1, hidden]; sync: zeroed once (dihip_decode_attn_block_sync_bytes); ws: dihip_decode_attn_block_workspace_bytes."""
+    out = out if out is not None else torch.empty_like(h)
+    pool = kv.pool
+    check(lib().dihip_decode_attn_block(cur_stream(), qkv_w.wbits, ptr(h), ptr(h_res) if h_res is not None else None, ptr(out), ptr(gamma),
+                                        float(eps), ptr(qkv_w.w), ptr(qkv_w.sz), ptr(qkv_bias) if qkv_bias is not None else None,
+                                        ptr(o_w.w), ptr(o_w.sz), ptr(kv.k_ptrs), ptr(kv.v_ptrs), ptr(old_lens_dev), ptr(rope_tab),
+                                        h.shape[-1], n, g, H, qkv_w.group, pool.S, kv.max_spans, max_len, capi.KV[pool.mode],
+                                        dt_code(gamma), float(scale), ptr(ws), ws.numel(), ptr(sync), sync.numel()),
+          "dihip_decode_attn_block")
+    return out
+
+
 def span_attn_merge_partials(partials, batch, n, nsplits, dtype=torch.bfloat16):
     out = torch.empty(batch, n * 128, dtype=dtype, device=partials.device)
     check(lib().dihip_span_attn_merge_partials(cur_stream(), ptr(out), ptr(partials), batch, n, nsplits, dt_code(dtype)),

@@ -362,6 +362,30 @@ int dihip_span_attn_decode_step(void* stream, void* output, const void* qkv, voi
  * decode attention launch into the FT [batch, n_heads * 128] output (the second launch of 3b) */
 int dihip_span_attn_merge_partials(void* stream, void* output, const float* partials, int batch, int n_heads,
                                    int nsplits, int dtype);
+/* 3e. The attention half of a batch-1 decode layer as ONE launch (round 5): LayerNormNoBeta -> Gemm[A16W4](qkv, +bias) -> Rotary ->
+ * DecOptMQA (DecoderCacheAppend + SpanAttention + reduce) -> Gemm[A16W4](o) -> Binary ADD of the reference graph
+ * (qwen_v15.py:210-300; the operator loop it shortens: csrc/core/model/model.cpp:1248-1325).  Equivalent, BIT FOR BIT, to
+ *     dihip_fused_norm_gemm(h_in ...) ; dihip_span_attn_decode_fused_sync(...) ; dihip_fused_gemm_addto(attn, o ..., h_res, h_out)
+ * at M = 1: the qkv and o weights and the K / V tiles are requested in the first microsecond of the launch, the three operators
+ * hand their rows over INSIDE it (8-byte {value, tag} granules, agent-scope stores / loads, bounded waits; csrc/decode_attn_block.hip).
+ *   h_in   : f32 [hidden] input of the norm (16-byte aligned);  h_res : f32 [hidden] residual or NULL (row-parallel TP ranks > 0);
+ *   h_out  : f32 [hidden] (may alias h_in / h_res);  gamma: bf16 [hidden];  qkv_* / o_*: packed int4 weights (section 1), bf16 bias or NULL
+ *   ws     : >= dihip_decode_attn_block_workspace_bytes(...) (no initialisation)
+ *   sync   : >= dihip_decode_attn_block_sync_bytes(...), 16-byte aligned, zeroed ONCE by the caller; calls sharing it must be ordered
+ *            on one stream (hipGraph replay included: the launch keeps its own epoch in it).  Word 1 of `sync` is an error flag: non-zero
+ *            after a launch whose bounded wait gave up (never observed; results are then undefined, nothing hangs).
+ * _supported() == 0 (other batch sizes, dtypes, caches, weight formats, too few CUs, DIHIP_ATTN_BLOCK=0): keep the three calls. */
+int dihip_decode_attn_block_supported(int wbits, int group_size, int hidden, int n_heads, int n_groups, int head_size,
+                                      int max_seq_len, int kv_mode, int dtype, int batch);
+size_t dihip_decode_attn_block_sync_bytes(int n_heads, int n_groups, int head_size);
+size_t dihip_decode_attn_block_workspace_bytes(int n_heads, int n_groups, int head_size, int max_seq_len);
+int dihip_decode_attn_block(void* stream, int wbits, const float* h_in, const float* h_res, float* h_out, const void* gamma,
+                            float eps, const void* qkv_w, const void* qkv_sz, const void* qkv_bias, const void* o_w,
+                            const void* o_sz, void* const* k_span_array, void* const* v_span_array,
+                            const uint32_t* old_seq_lens_dev, const float* rope_table, int hidden, int n_heads, int n_groups,
+                            int head_size, int group_size, int span_len, int n_spans_per_request, int max_seq_len, int kv_mode,
+                            int dtype, float qk_scale, void* ws, size_t ws_bytes, void* sync, size_t sync_bytes);
+
 /* =============================================================================================
  * 4. Prefill attention (replaces xformer_prefill_attention,
  *    csrc/core/kernel/cuda/xformer_mha/xformer_mha.h:26-41): causal softmax(alpha Q K^T) V, GQA.

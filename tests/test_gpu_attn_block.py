@@ -1,0 +1,100 @@
+"""dihip_decode_attn_block -- RMSNorm + qkv GEMV, Rotary + cache append + paged attention (+ split merge) and the o-projection
++ residual of a batch-1 decode layer in ONE launch -- against the three launches it replaces
+(dihip_fused_norm_gemm, dihip_span_attn_decode_fused_sync, dihip_fused_gemm_addto): the hidden row and the cache spans must be
+BIT-IDENTICAL (same K split, same partial records, same merge order; csrc/decode_attn_block.hip), eager, back to back (the
+launch keeps its own epoch in the sync buffer) and under hipGraph replay.  The chain itself is checked against the oracle in
+test_gpu_gemm.py / test_gpu_kv_attn.py / test_gpu_decoder.py.  Reference operators: qwen_v15.py:210-300."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# Qwen2-7B attention widths (the launch needs >= one column tile per GEMV workgroup: small models keep the chain)
+W7B = dict(hidden=3584, layers=2, n_heads=28, n_kv=4, head_dim=128, inter=1024, vocab=2048)
+
+
+def _model(decoder, seed=11, **over):
+    cfg = decoder.ModelConfig("attn-block", **{**W7B, **over})
+    return decoder.build_random_model(cfg, decoder.QuantSpec(4, 128, gptq_like_zeros=True), seed=seed)
+
+
+def _session(decoder, model, max_len, block):
+    old = os.environ.get("DIHIP_DECODER_ATTN_BLOCK")
+    os.environ["DIHIP_DECODER_ATTN_BLOCK"] = "1" if block else "0"
+    try:
+        return decoder.DecodeSession(model, 1, max_len=max_len, span_len=128)
+    finally:
+        if old is None:
+            del os.environ["DIHIP_DECODER_ATTN_BLOCK"]
+        else:
+            os.environ["DIHIP_DECODER_ATTN_BLOCK"] = old
+
+
+def _err_word(sess):
+    return int(sess.block_sync.view(torch.int32)[1].item())
+
+
+@pytest.mark.parametrize("history", [0, 1, 127, 128, 700, 2047])
+def test_one_launch_equals_the_three_it_replaces(pkg, history):
+    from dash_infer_amd import decoder, ops
+    model = _model(decoder)
+    max_len = 2048 + 64
+    a, b = _session(decoder, model, max_len, False), _session(decoder, model, max_len, True)
+    assert not a.attn_block and b.attn_block, "the fused launch must serve the Qwen2-7B attention widths on this GPU"
+    for s in (a, b):
+        s.fill_cache_random(max(history, 1), seed=5)
+    b.pool.pool.copy_(a.pool.pool)
+    gen = torch.Generator(device="cuda").manual_seed(history + 3)
+    h0 = torch.randn(1, model.cfg.hidden, generator=gen, device="cuda", dtype=torch.float32)
+    for s in (a, b):
+        s.set_state([7], [history])
+    for step in range(3):  # three steps back to back: the block's epoch advances, the new rows of step t are history of t + 1
+        for s in (a, b):
+            s.h.copy_(h0 * (1.0 + 0.25 * step))
+            s.run_single_layer(0)
+            s.old_lens += 1
+            s.new_lens += 1
+        torch.cuda.synchronize()
+        assert _err_word(b) == 0, "a bounded wait of the fused launch gave up"
+        assert torch.equal(a.h, b.h), f"history {history} step {step}: max diff {(a.h - b.h).abs().max().item():.3e}"
+        assert torch.isfinite(b.h).all()
+    assert torch.equal(a.pool.pool, b.pool.pool), "cache spans differ (DecoderCacheAppend inside the launch)"
+
+
+def test_decode_steps_through_a_replayed_graph_are_bit_identical(pkg):
+    """whole decode steps (2 layers, final norm, lm_head, greedy) through a captured hipGraph, replayed: logits of every step equal"""
+    from dash_infer_amd import decoder
+    model = _model(decoder, seed=23)
+    max_len = 512
+    outs = []
+    for block in (False, True):
+        s = _session(decoder, model, max_len, block)
+        assert s.attn_block == block
+        s.fill_cache_random(200, seed=9)
+        s.set_state([3], [200])
+        s.capture()
+        logits = []
+        for _ in range(6):
+            s.replay()
+            torch.cuda.synchronize()
+            logits.append(s.logits.clone())
+        if block:
+            assert _err_word(s) == 0
+        outs.append((logits, s.ids.clone(), s.pool.pool.clone()))
+    for t, (la, lb) in enumerate(zip(outs[0][0], outs[1][0])):
+        assert torch.equal(la, lb), f"step {t}: max logit diff {(la - lb).abs().max().item():.3e}"
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+def test_unsupported_configurations_keep_the_chain(pkg):
+    from dash_infer_amd import decoder
+    small = decoder.ModelConfig("small", hidden=512, layers=1, n_heads=4, n_kv=2, head_dim=128, inter=1024, vocab=1024)
+    m = decoder.build_random_model(small, decoder.QuantSpec(4, 128), seed=3)
+    assert not _session(decoder, m, 64, True).attn_block           # fewer column tiles than GEMV workgroups
+    m8 = decoder.build_random_model(decoder.ModelConfig("w8", **W7B), decoder.QuantSpec(8, -1), seed=3)
+    assert not _session(decoder, m8, 256, True).attn_block          # int8 weights: twice the chunks per wave
+    m4 = _model(decoder)
+    assert not decoder.DecodeSession(m4, 2, max_len=256, span_len=128).attn_block                     # batch 2
+    assert not decoder.DecodeSession(m4, 1, max_len=256, span_len=128, kv_mode="u4").attn_block       # quantised cache
