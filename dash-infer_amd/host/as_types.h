@@ -188,6 +188,14 @@ class HIPContext : public DeviceContext {
   // runner (a plain Alloc -> Forward loop over the operators) every attention operator uploads the lengths itself per step.
   bool LensOnDevice() const { return lens_on_device_; }
   void SetLensOnDevice(bool v) const { lens_on_device_ = v; }
+  // Which operator produces a tensor of the fused list (registered at Init, in list order): the o-projection finds the attention
+  // and qkv operators in front of it and, for one request on the 16-bit cache, runs all three as ONE launch
+  // (dihip_decode_attn_block; host/fused_ops_hip.cpp DihipGemmAddTo).  Opaque here: the operators cast to their own interfaces.
+  void RegisterProducer(const std::string& tensor, void* op) const { producer_[tensor] = op; }
+  void* Producer(const std::string& tensor) const {
+    auto it = producer_.find(tensor);
+    return it == producer_.end() ? nullptr : it->second;
+  }
 
  private:
   hipStream_t stream_ = nullptr;
@@ -195,6 +203,7 @@ class HIPContext : public DeviceContext {
   mutable std::map<std::string, ActLayoutPref> layout_pref_;
   mutable std::map<std::string, int> act_layout_;
   mutable bool lens_on_device_ = false;
+  mutable std::map<std::string, void*> producer_;
 };
 
 // VirtualCache (csrc/runtime/cache/virtual_cache.h:93-139): the per-request paged cache of all layers, as the span

@@ -120,6 +120,43 @@ int read_group(const OperatorProto& p) {
   return a ? *(const int*)a : -1;
 }
 
+// ---- the attention half of a batch-1 decode layer as ONE launch (dihip_decode_attn_block, round 5) ---------------------------------
+// DihipNormGemm(qkv) -> DihipRopeSpanAttn -> DihipGemmAddTo(o) stay three operators of the list (context phase, batches, quantised
+// caches run them as before); for ONE request on the 16-bit cache with int4 g128 weights the o-projection operator, which finds
+// the two in front of it through HIPContext::Producer at Init, tells them at Reshape to skip their launches and issues the
+// single launch in its own Forward with what they hand over here.
+struct AttnBlockQkv {
+  const AsTensor* h = nullptr;  // f32 hidden rows (input of the norm)
+  const void* gamma = nullptr;
+  float eps = 0.f;
+  const PackedLowp* w = nullptr;
+  const void* bias = nullptr;
+  int act = 0, m = 0;
+};
+class AttnBlockQkvPart {
+ public:
+  virtual ~AttnBlockQkvPart() = default;
+  virtual AttnBlockQkv BlockQkv() const = 0;
+  virtual void BlockSkip(bool skip) = 0;
+};
+struct AttnBlockAttn {
+  void* const* kd = nullptr;
+  void* const* vd = nullptr;
+  const uint32_t* old_lens = nullptr;
+  const float* rope_tab = nullptr;
+  AsTensor* ws = nullptr;
+  int n = 0, g = 0, h = 0, span = 0, max_spans = 0, kv_mode = 0, batch = 0, seq = 0;
+  DataType dt = BFLOAT16;
+  float alpha = 0.f;
+  std::string qkv_name;  // its input: the qkv operator's output
+};
+class AttnBlockAttnPart {
+ public:
+  virtual ~AttnBlockAttnPart() = default;
+  virtual AttnBlockAttn BlockAttn() const = 0;  // valid after this step's Forward (the lengths are staged there)
+  virtual void BlockSkip(bool skip) = 0;
+};
+
 }  // namespace
 
 // ===================================================================================================== DihipEmbedding
@@ -161,7 +198,7 @@ REGISTER_OP(DihipEmbedding, HIP, DihipEmbeddingOp)
 // y = act(RMSNorm(h; gamma, eps) . W + bias): weights [gamma, W, scales, zeros, (bias)]; inputs [h, (xnorm)]; attrs eps, wbits,
 // GroupSize, activation.  With a second input and 4 < M <= 32 in the decoder phase the normalised rows come from the producer
 // of h (DihipGemmAddTo) and the GEMM reads them directly (dihip_prenorm_gemm).
-class DihipNormGemmOp : public AsOperator {
+class DihipNormGemmOp : public AsOperator, public AttnBlockQkvPart {
  public:
   explicit DihipNormGemmOp(const std::string& t = "") : AsOperator(t) {}
   AsStatus Init(const OperatorProto& op_proto, const DeviceContext& ctx, const TensorMap& weights_map, TensorMap* tensor_map) override {
@@ -178,9 +215,23 @@ class DihipNormGemmOp : public AsOperator {
     if (!sync_) return AsStatus::ALLSPARK_MEMORY_ERROR;
     if (in_names_.size() > 1) hip_ctx(&ctx).AdvertiseLayoutPref(in_names_[1], w_.pref(0));
     tensor_map_->at(out_names_[0])->SetDataType(w_.ft);
+    hip_ctx(&ctx).RegisterProducer(out_names_[0] + "\x01qkv", static_cast<AttnBlockQkvPart*>(this));
     return AsStatus::ALLSPARK_SUCCESS;
   }
+  AttnBlockQkv BlockQkv() const override {
+    AttnBlockQkv q;
+    q.h = tensor_map_->at(in_names_[0]).get();
+    q.gamma = weights_[0]->GetDataPtr();
+    q.eps = eps_;
+    q.w = &w_;
+    q.bias = weights_.size() == 5 ? weights_[4]->GetDataPtr() : nullptr;
+    q.act = act_;
+    q.m = m_;
+    return q;
+  }
+  void BlockSkip(bool skip) override { skip_ = skip; }
   AsStatus Reshape(RuntimeContext*) override {
+    skip_ = false;  // (the o-projection's Reshape, later in the list, decides anew)
     AsTensor* h = tensor_map_->at(in_names_[0]).get();
     Shape s = h->GetShape();
     if (s.empty() || (int)s.back() != w_.k || h->GetDataType() != FLOAT32) return AsStatus::ALLSPARK_PARAM_ERROR;
@@ -192,6 +243,7 @@ class DihipNormGemmOp : public AsOperator {
     return grow_workspace(tensor_map_, dihip_gemm_lowp_workspace_bytes(w_.wbits, std::max(m_, 1), w_.n, w_.k, w_.group));
   }
   AsStatus Forward(RuntimeContext* rt) override {
+    if (skip_) return AsStatus::ALLSPARK_SUCCESS;  // part of the o-projection's single launch (AttnBlockQkvPart)
     AsTensor* h = tensor_map_->at(in_names_[0]).get();
     AsTensor* y = tensor_map_->at(out_names_[0]).get();
     AsTensor* wsp = tensor_map_->at("workspace").get();
@@ -212,6 +264,7 @@ class DihipNormGemmOp : public AsOperator {
   PackedLowp w_;
   float eps_ = 1e-6f;
   int act_ = 0, m_ = 0;
+  bool skip_ = false;
   std::unique_ptr<AsTensor> sync_;
 };
 REGISTER_OP(DihipNormGemm, HIP, DihipNormGemmOp)
@@ -307,7 +360,26 @@ class DihipGemmAddToOp : public AsOperator {
     if (!sync_) return AsStatus::ALLSPARK_MEMORY_ERROR;
     hip_ctx(&ctx).AdvertiseLayoutPref(in_names_[0], w_.pref(0));
     tensor_map_->at(out_names_[0])->SetDataType(FLOAT32);
+    // the attention operator and the qkv projection in front of it (registered by their Init: the list is built in order)
+    blk_attn_ = static_cast<AttnBlockAttnPart*>(hip_ctx(&ctx).Producer(in_names_[0] + "\x01attn"));  // (keys carry the interface)
+    if (blk_attn_) {
+      blk_qkv_ = static_cast<AttnBlockQkvPart*>(hip_ctx(&ctx).Producer(blk_attn_->BlockAttn().qkv_name + "\x01qkv"));
+      if (!blk_qkv_) blk_attn_ = nullptr;
+    }
     return AsStatus::ALLSPARK_SUCCESS;
+  }
+  // ONE launch for qkv projection + attention + this projection (see AttnBlockQkvPart): decoder phase, one request, 16-bit cache,
+  // int4 weights with a group per k-tile -- what dihip_decode_attn_block_supported says for this GPU
+  bool BlockEligible(RuntimeContext* rt) const {
+    static const bool enabled = env_on("DIHIP_DECODER_ATTN_BLOCK", true);
+    if (!enabled || !blk_attn_ || !blk_qkv_ || !rt || rt->is_context || m_ != 1 || norm_now_) return false;
+    const AttnBlockQkv q = blk_qkv_->BlockQkv();
+    const AttnBlockAttn a = blk_attn_->BlockAttn();
+    if (q.m != 1 || q.act != 0 || a.batch != 1 || a.seq != 1 || !q.w || q.w->wbits != w_.wbits || q.w->group != w_.group || q.w->ft != w_.ft ||
+        a.dt != w_.ft || q.w->n != (a.n + 2 * a.g) * a.h || w_.k != a.n * a.h || w_.n != q.w->k)
+      return false;
+    if (hip_ctx(ctx_).ActLayout(in_names_[0]) != DIHIP_ACT_ROWMAJOR) return false;
+    return dihip_decode_attn_block_supported(w_.wbits, w_.group, w_.n, a.n, a.g, a.h, ctx_->GetModelMaxLength(), a.kv_mode, DihipDtype(w_.ft), 1) != 0;
   }
   AsStatus Reshape(RuntimeContext* rt) override {
     AsTensor* x = tensor_map_->at(in_names_[0]).get();
@@ -329,6 +401,25 @@ class DihipGemmAddToOp : public AsOperator {
       const size_t bytes = frag ? dihip_act_frag_bytes(m_, w_.n) : (size_t)m_ * w_.n * SizeofType(w_.ft);
       AS_CHECK_STATUS(ensure_capacity_zeroed(xn, bytes, std::move(s), stream_of(ctx_)));
     }
+    block_now_ = BlockEligible(rt);
+    if (blk_attn_ && blk_qkv_) {
+      blk_qkv_->BlockSkip(block_now_);
+      blk_attn_->BlockSkip(block_now_);
+    }
+    if (block_now_) {
+      const AttnBlockAttn a = blk_attn_->BlockAttn();
+      hipStream_t s = stream_of(ctx_);
+      // shared by the layers (their launches are ordered on one stream): hand-off state, zeroed once
+      const size_t sb = dihip_decode_attn_block_sync_bytes(a.n, a.g, a.h);
+      auto it = tensor_map_->find("dihip.attn_block_sync");
+      if (it == tensor_map_->end() || it->second->GetSizeInByte() < sb) {
+        auto t = std::make_shared<AsTensor>("dihip.attn_block_sync", DeviceType::HIP, INT8, Shape{(int64_t)sb});
+        if (!t->GetDataPtr() || hipMemsetAsync(t->GetDataPtr(), 0, sb, s) != hipSuccess) return AsStatus::ALLSPARK_MEMORY_ERROR;
+        (*tensor_map_)["dihip.attn_block_sync"] = t;
+      }
+      const size_t wb = dihip_decode_attn_block_workspace_bytes(a.n, a.g, a.h, ctx_->GetModelMaxLength());
+      if (a.ws->GetSizeInByte() < wb) AS_CHECK_STATUS(a.ws->SetShape(Shape{(int64_t)wb}));
+    }
     return grow_workspace(tensor_map_, dihip_gemm_lowp_workspace_bytes(w_.wbits, std::max(m_, 1), w_.n, w_.k, w_.group));
   }
   AsStatus Forward(RuntimeContext*) override {
@@ -339,6 +430,17 @@ class DihipGemmAddToOp : public AsOperator {
     const float* h_res = add_residual ? (const float*)tensor_map_->at(in_names_[1])->GetDataPtr() : nullptr;
     const int x_layout = hip_ctx(ctx_).ActLayout(in_names_[0]);
     hipStream_t s = stream_of(ctx_);
+    if (block_now_) {
+      const AttnBlockQkv q = blk_qkv_->BlockQkv();
+      const AttnBlockAttn a = blk_attn_->BlockAttn();
+      if (!a.old_lens) return AsStatus::ALLSPARK_INVALID_CALL_ERROR;  // the attention operator's Forward of this step stages them
+      AsTensor* sy = tensor_map_->at("dihip.attn_block_sync").get();
+      return FromDihip(dihip_decode_attn_block(s, w_.wbits, (const float*)q.h->GetDataPtr(), h_res, (float*)y->GetDataPtr(), q.gamma, q.eps,
+                                               q.w->w->GetDataPtr(), q.w->sz->GetDataPtr(), q.bias, w_.w->GetDataPtr(), w_.sz->GetDataPtr(), a.kd, a.vd,
+                                               a.old_lens, a.rope_tab, w_.n, a.n, a.g, a.h, w_.group, a.span, a.max_spans, ctx_->GetModelMaxLength(),
+                                               a.kv_mode, DihipDtype(w_.ft), a.alpha, a.ws->GetDataPtr(), a.ws->GetSizeInByte(), sy->GetDataPtr(),
+                                               sy->GetSizeInByte()));
+    }
     if (norm_now_) {
       AsTensor* xn = tensor_map_->at(out_names_[1]).get();
       return FromDihip(dihip_fused_gemm_addto_norm(s, w_.wbits, x->GetDataPtr(), w_.w->GetDataPtr(), w_.sz->GetDataPtr(), h_res,
@@ -354,8 +456,10 @@ class DihipGemmAddToOp : public AsOperator {
  private:
   PackedLowp w_;
   float eps_ = 1e-6f;
-  bool has_norm_ = false, norm_now_ = false;
+  bool has_norm_ = false, norm_now_ = false, block_now_ = false;
   int m_ = 0, xn_layout_ = DIHIP_ACT_ROWMAJOR;
+  AttnBlockAttnPart* blk_attn_ = nullptr;
+  AttnBlockQkvPart* blk_qkv_ = nullptr;
   std::unique_ptr<AsTensor> sync_;
 };
 REGISTER_OP(DihipGemmAddTo, HIP, DihipGemmAddToOp)
@@ -369,7 +473,7 @@ REGISTER_OP(DihipGemmAddTo, HIP, DihipGemmAddToOp)
 // Device-resident step state (graph replay): the span tables live on the device and are re-uploaded by Alloc only when a request
 // claimed a new span or the batch changed; the lengths are read from "dihip.old_seq_lens" / "dihip.new_seq_lens" when a model
 // runner keeps them on the device (HIPContext::LensOnDevice), else uploaded per step like SpanAttnOpHIP does.
-class DihipRopeSpanAttnOp : public SpanAttnOpHIP {
+class DihipRopeSpanAttnOp : public SpanAttnOpHIP, public AttnBlockAttnPart {
  public:
   explicit DihipRopeSpanAttnOp(const std::string& t = "") : SpanAttnOpHIP(t) {}
   ~DihipRopeSpanAttnOp() override {
@@ -398,10 +502,36 @@ class DihipRopeSpanAttnOp : public SpanAttnOpHIP {
     if (hipMemcpy(shared->GetDataPtr(), inv.data(), inv.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
       return AsStatus::ALLSPARK_RUNTIME_ERROR;
     if (hipEventCreateWithFlags(&staged_, hipEventDisableTiming) != hipSuccess) return AsStatus::ALLSPARK_RUNTIME_ERROR;
+    hip_ctx(&ctx).RegisterProducer(out_names_[0] + "\x01attn", static_cast<AttnBlockAttnPart*>(this));
     return AsStatus::ALLSPARK_SUCCESS;
   }
+  AttnBlockAttn BlockAttn() const override {
+    AttnBlockAttn a;
+    a.kd = k_arr_dev_ ? reinterpret_cast<void* const*>(k_arr_dev_->GetDataPtr()) : nullptr;
+    a.vd = v_arr_dev_ ? reinterpret_cast<void* const*>(v_arr_dev_->GetDataPtr()) : nullptr;
+    a.old_lens = blk_old_lens_;
+    auto tab = tensor_map_->find("dihip.rope_table");
+    a.rope_tab = tab == tensor_map_->end() ? nullptr : (const float*)tab->second->GetDataPtr();
+    auto ws = tensor_map_->find("dihip.attn_ws");
+    a.ws = ws == tensor_map_->end() ? nullptr : ws->second.get();
+    a.n = n_;
+    a.g = g_;
+    a.h = h_;
+    a.span = span_;
+    a.max_spans = max_spans_;
+    a.kv_mode = kv_mode_;
+    a.batch = batch_;
+    a.seq = seq_;
+    a.dt = dtype_;
+    a.alpha = alpha_;
+    a.qkv_name = in_names_[0];
+    return a;
+  }
+  void BlockSkip(bool skip) override { skip_ = skip; }
 
   AsStatus Reshape(RuntimeContext* rt) override {
+    skip_ = false;  // (the o-projection's Reshape, later in the list, decides anew)
+    blk_old_lens_ = nullptr;
     AS_CHECK_STATUS(SpanAttnOpHIP::Reshape(rt));
     const int nb = std::max(batch_, 1), max_len = ctx_->GetModelMaxLength();
     // shared between the layers: rope table (cos, sin per position), attention workspace, arrival tickets
@@ -488,6 +618,8 @@ class DihipRopeSpanAttnOp : public SpanAttnOpHIP {
       old_lens = (const uint32_t*)lens_dev_->GetDataPtr();
       new_lens = old_lens + batch_;
     }
+    blk_old_lens_ = old_lens;
+    if (skip_) return AsStatus::ALLSPARK_SUCCESS;  // part of the o-projection's single launch (AttnBlockAttnPart): lengths staged, nothing launched
     void* const* kd = reinterpret_cast<void* const*>(k_arr_dev_->GetDataPtr());
     void* const* vd = reinterpret_cast<void* const*>(v_arr_dev_->GetDataPtr());
     const void* qkv = tensor_map_->at(in_names_[0])->GetDataPtr();
@@ -542,6 +674,8 @@ class DihipRopeSpanAttnOp : public SpanAttnOpHIP {
 
   float base_ = 10000.f;
   int out_layout_ = DIHIP_ACT_ROWMAJOR;
+  bool skip_ = false;
+  const uint32_t* blk_old_lens_ = nullptr;
   bool tables_valid_ = false;
   std::vector<int> staged_spans_;
   hipEvent_t staged_ = nullptr;

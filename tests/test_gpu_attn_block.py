@@ -15,9 +15,9 @@ pytestmark = pytest.mark.gpu
 W7B = dict(hidden=3584, layers=2, n_heads=28, n_kv=4, head_dim=128, inter=1024, vocab=2048)
 
 
-def _model(decoder, seed=11, **over):
+def _model(decoder, seed=11, keep_fp=False, **over):
     cfg = decoder.ModelConfig("attn-block", **{**W7B, **over})
-    return decoder.build_random_model(cfg, decoder.QuantSpec(4, 128, gptq_like_zeros=True), seed=seed)
+    return decoder.build_random_model(cfg, decoder.QuantSpec(4, 128, gptq_like_zeros=True), seed=seed, keep_fp=keep_fp)
 
 
 def _session(decoder, model, max_len, block):
@@ -98,3 +98,43 @@ def test_unsupported_configurations_keep_the_chain(pkg):
     m4 = _model(decoder)
     assert not decoder.DecodeSession(m4, 2, max_len=256, span_len=128).attn_block                     # batch 2
     assert not decoder.DecodeSession(m4, 1, max_len=256, span_len=128, kv_mode="u4").attn_block       # quantised cache
+
+
+def test_cpp_operator_list_runs_the_block_and_matches_decode_session(pkg):
+    """The C++ operator layer (host/fused_ops_hip.cpp): DihipNormGemm, DihipRopeSpanAttn and DihipGemmAddTo stay three operators; for
+    one request the o-projection issues the single launch and the other two skip theirs.  Logits bit-identical to DecodeSession with
+    the block on AND to the three-launch chain (DIHIP_DECODER_ATTN_BLOCK=0 is read once per process on the C++ side: the chain is
+    covered through the Python session here), context phase + graph-replayed steps; then a second request joins (batch 2: chain)."""
+    from dash_infer_amd import decoder
+    from tests.test_gpu_host_runner import Host
+    model = _model(decoder, seed=31, keep_fp=True)   # (the operator layer re-lays-out the unpacked weights itself)
+    cfg = model.cfg
+    span, max_len, steps = 128, 384, 5
+    prompt = [int(t) for t in torch.randint(0, cfg.vocab, (150,), generator=torch.Generator().manual_seed(1)).tolist()]
+    want = {}
+    for block in (False, True):
+        s = _session(decoder, model, max_len, block)
+        assert s.attn_block == block
+        lo0 = s.prefill([prompt]).clone()
+        out = []
+        for _ in range(steps):
+            s.step()
+            torch.cuda.synchronize()
+            out.append((s.logits.clone(), s.ids.cpu().tolist()))
+        want[block] = (lo0, out)
+    for t in range(steps):
+        assert torch.equal(want[False][1][t][0], want[True][1][t][0]), f"python runner, step {t}: block != chain"
+    h = Host(model, 2, max_len, span, "none")
+    assert h.report["fused"], h.report["why"]
+    k, v = h.spans()
+    h.start(prompt, k, v)
+    assert torch.equal(h.logits()[0], want[True][0][0])
+    for t in range(steps):
+        ids = h.steps(1, graph=True)
+        assert ids == want[True][1][t][1], f"step {t}: ids differ"
+        assert torch.equal(h.logits(), want[True][1][t][0]), f"step {t}: logits are not bit-identical to DecodeSession"
+    # a second request joins: batch 2 runs the three launches again (Reshape re-decides), then leaves
+    k2, v2 = h.spans()
+    h.start(prompt[:40], k2, v2)
+    h.steps(2, graph=True)
+    h.close()
