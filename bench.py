@@ -31,6 +31,11 @@ WORKLOADS = {
     # head, qkv 8192 -> 1280, o 1024 -> 8192, gate/up 8192 -> 3712, down 3712 -> 8192, vocabulary slice 19008; 80 layers),
     # batch 16, 4096 cached tokens.  The all-reduces are NOT in it (one GPU): it is the rank-local part of the TP = 8 step.
     "cfg3_rank":     (4, 128, "none", 16, True),
+    # The headline model's TP = 8 target on ONE GPU: rank 0's share of Qwen2-7B int4 g128 at TP = 8 (tp.py: 4 of the 28 query heads +
+    # their replicated KV head, qkv 3584 -> 768, o 512 -> 3584, gate/up 3584 -> 2432 (19 of the 148 groups), down 2432 -> 3584,
+    # vocabulary slice 19008; 28 layers, ~15.4 MB of weights per layer), batch 1, 2048 cached tokens.  All-reduces NOT in it: the
+    # rank-local part of the TP = 8 step, i.e. the ceiling of the >= 3.5x target (per-layer fixed cost does not shard).
+    "tp8_rank_7b":   (4, 128, "none", 1, True),
     # BASELINE configs[4] (decode part): the MoE feed-forward block of Qwen2-57B-A14B -- router, top-8 of 64 int8 experts
     # (3584 -> 2560 -> 3584), combine -- 16 tokens, 28 layers' expert stacks; attention / shared expert are the dense path
     "moe_layer":     (8, -1, "none", 16, False),
@@ -510,6 +515,11 @@ def kernel_breakdown(sess, torch, ops, iters=5):
                                  sess.attn_ws, sess.attn_sync, out=sess.attn,
                                  out_layout=ops.ACT_FRAG32 if sess.attn_frag else ops.ACT_ROWMAJOR)
         timed("rope_append_span_attention", B * 2 * sess.g_loc * SEQ_LEN * kvb, sep)
+    if getattr(sess, "attn_block", False):
+        # what the step actually runs at batch 1 (round 5): the three operators above + the o-projection below as ONE launch
+        timed("attn_block_qkv_attention_o", l0.qkv.nbytes + act_b(l0.qkv) + B * 2 * sess.g_loc * SEQ_LEN * kvb + l0.o.nbytes + act_b(l0.o),
+              lambda li, lw: ops.decode_attn_block(sess.h, sess.h, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, lw.o, sess.kv[li], sess.old_lens, sess.rope_tab,
+                                                   sess.n_loc, sess.g_loc, sess.H, sess.max_len, sess.scale, sess.attn_ws, sess.block_sync, out=sess.partial))
     timed("o_gemv_addto", l0.o.nbytes + act_b(l0.o),
           lambda li, lw: ops.fused_gemm_addto(sess.attn, lw.o, sess.h, sc, out=sess.partial, M=B,
                                               x_layout=ops.ACT_FRAG32 if sess.attn_frag else ops.ACT_ROWMAJOR))
@@ -623,7 +633,7 @@ def tp_ab_runs(args, torch, decoder, model, comm, batch, max_len, kv_mode, ids, 
     return res
 
 
-def secondary_workloads(names=("int4_b32_u4kv", "int8_b1", "prefill_2048"), steps=10, warmup=3, timeout=420):
+def secondary_workloads(names=("int4_b32_u4kv", "int8_b1", "prefill_2048", "cfg3_rank", "tp8_rank_7b", "cfg5_moe"), steps=10, warmup=3, timeout=420):
     import subprocess
     res = []
     for w in names:
@@ -645,6 +655,40 @@ def secondary_workloads(names=("int4_b32_u4kv", "int8_b1", "prefill_2048"), step
         except Exception as e:  # noqa: BLE001
             res.append({"workload": w, "error": repr(e)})
     return res
+
+
+def rocprof_kernel_stats(workload, steps=16, warmup=4, timeout=300):
+    """`rocprofv3 --kernel-trace --stats` of a short run of THIS bench (same workload, Python runner, nothing extra), collected INSIDE
+    the run when rocprofv3 is on PATH, so that roofline.frac comes from the same clock as the summaries under profiles/ (kernel begin
+    .. end, no graph-node boundary).  Returns ({kernel name: {"calls", "avg_us"}}, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if os.environ.get("DIHIP_BENCH_ROCPROF", "1") == "0":
+        return None, "DIHIP_BENCH_ROCPROF=0"
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    d = tempfile.mkdtemp(prefix="dihip_prof_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "b", "--", sys.executable, os.path.abspath(__file__),
+           "--workload", workload, "--steps", str(steps), "--warmup", str(warmup), "--blocks", "2", "--no-cpu-baseline", "--no-extra",
+           "--runner", "python"]
+    try:
+        env = dict(os.environ, TMPDIR="/tmp", DIHIP_BENCH_ROCPROF="0")
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd="/tmp", env=env)
+        files = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+        if p.returncode != 0 or not files:
+            return None, f"rocprofv3 rc {p.returncode}: {(p.stderr or p.stdout)[-300:]}"
+        stats = {}
+        for r in csv.DictReader(open(files[0])):
+            stats[r["Name"]] = {"calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 3), "pct": float(r["Percentage"])}
+        return stats, "rocprofv3 --kernel-trace --stats of `bench.py --workload %s --steps %d --runner python`, collected inside this run" % (workload, steps)
+    except Exception as e:  # noqa: BLE001 -- a profiler hiccup never costs the bench line
+        return None, repr(e)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def csrc_tree_hash():
@@ -740,6 +784,10 @@ def main():
         assert world == 1, "cfg3_rank times ONE rank's share of the TP = 8 step on one GPU (use --gpus 1)"
         cfg = decoder.ModelConfig("Qwen2-72B/TP8-rank", hidden=8192, layers=80, n_heads=8, n_kv=1, head_dim=128, inter=3712, vocab=19008)
         model_name = "Qwen2-72B (rank-local share of TP=8: all-reduce excluded)"
+    if args.workload == "tp8_rank_7b":
+        assert world == 1, "tp8_rank_7b times ONE rank's share of the TP = 8 step on one GPU (use --gpus 1)"
+        cfg = decoder.ModelConfig("Qwen2-7B/TP8-rank", hidden=3584, layers=28, n_heads=4, n_kv=1, head_dim=128, inter=2432, vocab=19008)
+        model_name = "Qwen2-7B (rank-0 share of TP=8: all-reduce excluded)"
     if args.workload == "cfg5_moe":
         cfg, model_name = decoder.QWEN2_57B_A14B, "Qwen2-57B-A14B"
     spec = decoder.QuantSpec(wbits, group, gptq_like_zeros=gptq)
@@ -907,9 +955,31 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": "dihip::" + kname + kdesc,
                                "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4),
+                               "clock": "HIP events on the launch stream around hipGraph-chained launches of this kernel over all layers "
+                                        "(includes the ~1.6 us dependent-launch boundary)",
                                "traffic": traffic, "traffic_source": traffic_source,
                                "avg_launch_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["bytes"]}
             out["kernels"] = kb
+            # the same kernel on the profiler's clock (kernel begin .. end), collected inside this run: `achieved` / `frac` then
+            # follow from THAT average -- the figure the summaries under profiles/ give -- and the event-timed one stays beside it
+            if world == 1 and args.workload == "int4_b1" and not args.no_extra and args.layers is None:
+                stats, note = rocprof_kernel_stats(args.workload)
+                rl = out["roofline"]
+                rl["rocprof_note"] = note
+                if stats:
+                    key = kname.rstrip(">")
+                    hit = [(n, v) for n, v in stats.items() if key in n]
+                    if hit:
+                        calls = sum(v["calls"] for _, v in hit)
+                        avg = sum(v["avg_us"] * v["calls"] for _, v in hit) / calls
+                        rl.update({"achieved_graph_events": rl["achieved"], "frac_graph_events": rl["frac"],
+                                   "avg_kernel_us_rocprof": round(avg, 3), "rocprof_calls": calls,
+                                   "achieved": round(dom["bytes"] / (avg * 1e-6) / 1e9, 1),
+                                   "frac": round(dom["bytes"] / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "clock": "rocprofv3 --kernel-trace --stats average of this kernel, collected inside this run (kernel "
+                                            "begin .. end); achieved_graph_events / frac_graph_events: HIP events around graph-chained "
+                                            "launches (includes the ~1.6 us boundary)"})
+                    out["rocprof_top_kernels"] = [{"kernel": n[:120], **v} for n, v in sorted(stats.items(), key=lambda kv: -kv[1]["pct"])[:12]]
         except StopIteration:
             pass
         except Exception as e:  # never lose the headline number to the breakdown
