@@ -267,7 +267,9 @@ def host_runner_bench(args, torch, decoder, ops, model, sess, batch, max_len, kv
             ref_graph.register_weights(m, model)
             g = ref_graph.qwen2_graph(len(model.layers), model.quant.wbits, model.quant.group, cfg.eps, cfg.n_heads, cfg.n_kv, cfg.rope_theta,
                                       moe=(cfg.moe.num_experts, cfg.moe.top_k) if cfg.moe is not None else None)
-            ref_graph.add_graph(m, g)
+            # the list travels as a SERIALIZED allspark TransformerProto (csrc/proto/allspark.proto) and enters the C++ layer through its
+            # wire-format reader (host/graph_wire.h) -- the ingest AsModel does from a converter export (model.cpp:265-287)
+            m.graph_add_serialized(ref_graph.to_transformer_proto(g))
             rep = m.graph_build(fuse=fuse)
             gen = torch.Generator().manual_seed(7)
             ids = torch.randint(0, cfg.vocab, (batch,), generator=gen).tolist()

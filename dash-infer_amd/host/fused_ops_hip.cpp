@@ -488,7 +488,7 @@ class DihipRopeSpanAttnOp : public SpanAttnOpHIP, public AttnBlockAttnPart {
     for (const char* k : {"rotary_type", "rotary_pct", "invfreq_type", "ntk_model_embed", "logn_model_embedding", "mrope_section_size",
                           "seqlen_extrapolation", "rope_ratio", "original_max_position_embeddings", "use_weight"})
       if ((p = attr_ptr(op_proto, k))) {  // only the base rotary of the Qwen2 graph; the fusion pass leaves other variants unfused
-        const bool neutral = (std::string(k) == "rotary_pct" && *(const float*)p == 1.0f) ||
+        const bool neutral = ((std::string(k) == "rotary_pct" || std::string(k) == "seqlen_extrapolation") && *(const float*)p == 1.0f) ||
                              ((std::string(k) == "rotary_type" || std::string(k) == "invfreq_type") && *(const int*)p == 0);
         if (!neutral) return AsStatus::ALLSPARK_PARAM_ERROR;
       }

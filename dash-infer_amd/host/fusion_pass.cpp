@@ -134,6 +134,15 @@ std::vector<OperatorProto> FuseDecoderGraph(const std::vector<OperatorProto>& gr
   ++m.i;
   out.push_back(make("DihipEmbedding", emb->op_name, emb->inputs, emb->outputs, emb->weights));
   std::string h = emb->outputs[0], xnorm_in;
+  // the converter puts RichEmbedding(input_ids, embedding.out) -> embedding.out behind the embedding (qwen_v15.py:197-206: rows of
+  // multimedia placeholders are overwritten IN PLACE with the request's own embeddings).  Without such inputs -- the model runner
+  // has no path that carries them -- it is the identity: the fused list, whose embedding rows are the f32 hidden stream, drops it.
+  if (const OperatorProto* re = m.peek(); re && re->op_type == "RichEmbedding") {
+    if (re->inputs.size() != 2 || re->inputs[1] != h || re->outputs.size() != 1 || re->outputs[0] != h)
+      return refuse(m.fail("RichEmbedding that is not the in-place form behind the embedding") ? "" : "");
+    ++m.i;
+    rep.why = "RichEmbedding dropped (identity without multimedia inputs; the fused list does not serve them)";
+  }
   for (;;) {
     // a decoder layer starts with LayerNormNoBeta(h) followed by a weight-only Gemm; the tail with LayerNormNoBeta , GetLastLine
     const OperatorProto* ln1 = m.peek();
@@ -149,8 +158,11 @@ std::vector<OperatorProto> FuseDecoderGraph(const std::vector<OperatorProto>& gr
     if (attr_int(*rot, "rotary_type", 0) != 0 || attr_float(*rot, "rotary_pct", 1.0f) != 1.0f || attr_int(*rot, "invfreq_type", 0) != 0)
       return refuse("a Rotary variant the fused attention does not implement (" + rot->op_name + ")");
     for (const char* k : {"ntk_model_embed", "logn_model_embedding", "mrope_section_size", "seqlen_extrapolation", "rope_ratio",
-                          "original_max_position_embeddings", "use_weight"})
+                          "original_max_position_embeddings", "use_weight"}) {
+      // (the converter always writes seqlen_extrapolation, 1.0 unless the user extrapolates: qwen_v15.py:228-230)
+      if (std::string(k) == "seqlen_extrapolation" && attr_float(*rot, k, 1.0f) == 1.0f) continue;
       if (attr_ptr(*rot, k)) return refuse(std::string("Rotary attribute ") + k + " (" + rot->op_name + ")");
+    }
     {
       const OperatorProto* p = m.peek();
       // (the converter appends GenerateOp's beam index to the attention's inputs, qwen_v15.py:445-447: unused by SpanAttnOp)

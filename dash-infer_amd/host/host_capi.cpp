@@ -6,6 +6,7 @@
 #include <sstream>
 #include <thread>
 
+#include "graph_wire.h"
 #include "model_runner.h"
 #include "operator.h"
 
@@ -272,6 +273,26 @@ int dihost_graph_add_op(dihost_model_t m, const char* op_type, const char* op_na
   const int rc = parse_proto(proto, op_type, op_name, inputs, outputs, weights, attrs);
   if (rc) return rc;
   m->graph.push_back(std::move(proto));
+  return 0;
+}
+// The operator lists of a SERIALIZED TransformerProto (the reference converter's output, graph_wire.h), appended in the order
+// given -- `graphs`: comma-separated graph names, NULL / "" = "decoder,gen_graph", the two AsModel runs per step
+// (model.cpp:566-650 / :1248-1325; pre_graph / post_graph are id bookkeeping on the host: the model runner's own).
+int dihost_graph_add_serialized(dihost_model_t m, const void* data, size_t bytes, const char* graphs) {
+  std::map<std::string, std::vector<OperatorProto>> all;
+  std::vector<std::string> names;
+  if (!data || !wire::parse_transformer(std::string_view(reinterpret_cast<const char*>(data), bytes), all, names)) {
+    g_err = "not a serialized TransformerProto (allspark.proto)";
+    return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  }
+  for (const std::string& g : split(graphs && graphs[0] ? graphs : "decoder,gen_graph", ',')) {
+    auto it = all.find(g);
+    if (it == all.end()) {
+      g_err = "no graph named " + g + " in the serialized model";
+      return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+    }
+    for (const OperatorProto& op : it->second) m->graph.push_back(op);
+  }
   return 0;
 }
 int dihost_graph_build(dihost_model_t m, int fuse) {

@@ -25,6 +25,7 @@ _SIGS = {
     "dihost_ops_alloc_concurrent": (i32, [vp, C.POINTER(i32), i32]),
     "dihost_cache_seq_len": (C.c_long, [vp, i32, i32]),
     "dihost_graph_add_op": (i32, [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+    "dihost_graph_add_serialized": (i32, [vp, C.c_char_p, C.c_size_t, C.c_char_p]),
     "dihost_graph_build": (i32, [vp, i32]),
     "dihost_graph_report": (C.c_char_p, [vp]),
     "dihost_graph_fuse_dry": (C.c_char_p, [vp]),
@@ -142,6 +143,12 @@ class Model:
     def graph_add_op(self, op_type, op_name, inputs, outputs, weights=(), attrs=""):
         _ck(lib().dihost_graph_add_op(self.h, op_type.encode(), op_name.encode(), ",".join(inputs).encode(), ",".join(outputs).encode(),
                                       ",".join(weights).encode(), attrs.encode()), "graph_add_op " + op_type)
+
+    def graph_add_serialized(self, model_bytes, graphs=None):
+        """The operator lists of a serialized allspark TransformerProto (what the reference's converter writes; graph_proto.py) --
+        graphs: names in order, default decoder + gen_graph, the two graphs AsModel runs per step."""
+        _ck(lib().dihost_graph_add_serialized(self.h, model_bytes, len(model_bytes), ",".join(graphs).encode() if graphs else None),
+            "graph_add_serialized")
 
     @staticmethod
     def _report(text):

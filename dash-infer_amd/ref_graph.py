@@ -11,7 +11,7 @@ def qwen2_graph(n_layers, wbits, group, eps, n_heads, n_kv, rope_theta, tp_allre
     gattr = f"GroupSize=i:{group}" if group and group > 0 else ""
 
     def lowp(name, inp, out, act=0, bias=False):
-        w = [name + ".weight", name + ".weight.scales", name + ".weight.zeros"] + ([name + ".bias"] if bias else [])
+        w = [name + ".weight", name + ".weight.scale", name + ".weight.zero_point"] + ([name + ".bias"] if bias else [])
         attrs = ";".join(a for a in (gattr, f"activation=i:{act}" if act else "", "alpha=f:1.0") if a)
         return (gemm, name, [inp], [out], w, attrs)
 
@@ -100,8 +100,8 @@ def register_weights(m, model, ft="bf16"):
     def lowp(name, key, li):
         q, s, z = fp[li][key]
         m.set_weight(name + ".weight", q, qdt)
-        m.set_weight(name + ".weight.scales", s, ft)
-        m.set_weight(name + ".weight.zeros", z, ft)
+        m.set_weight(name + ".weight.scale", s, ft)
+        m.set_weight(name + ".weight.zero_point", z, ft)
 
     m.set_weight("embedding.word_embeddings", fp["embed"], ft)
     for li in range(len(model.layers)):
@@ -118,7 +118,7 @@ def register_weights(m, model, ft="bf16"):
             m.set_weight(p + "shared_expert_gate.weight", mo["shared_gate_w"], ft)
             cat = lambda a, b: [torch.cat([x, y], dim=1).contiguous() for x, y in zip(a, b)]      # columns [gate | up] (unary.cu:122-132)
             gq, gs, gz = cat(fp[li]["gate"], fp[li]["up"])
-            for name, t, dt in ((".weight", gq, qdt), (".weight.scales", gs, ft), (".weight.zeros", gz, ft)):
+            for name, t, dt in ((".weight", gq, qdt), (".weight.scale", gs, ft), (".weight.zero_point", gz, ft)):
                 m.set_weight(p + "shared_expert.gate_up_proj" + name, t, dt)
             lowp(p + "shared_expert.down_proj", "down", li)
             gu = [cat(g_, u_) for g_, u_ in zip(mo["experts_gate"], mo["experts_up"])]
@@ -131,6 +131,28 @@ def register_weights(m, model, ft="bf16"):
         lowp(p + "ffn.output.dense", "down", li)
     m.set_weight("final.layernorm.gamma", fp["final_norm"], ft)
     m.set_weight("lm_head.weight", fp["lm_head"], ft)
+
+
+def to_transformer_proto(graph, gen_ops=("GenerateOp", "UpdateId")):
+    """The list as a SERIALIZED allspark TransformerProto (graph_proto.py: csrc/proto/allspark.proto), graphs "decoder" + "gen_graph"
+    like the converter's export (qwen_v15.py:408-452) -- the bytes hostapi.Model.graph_add_serialized / the reference's AsModel read.
+    Attributes: "k=i:v" -> int32, "f" -> float32, "b" -> one byte (the raw bytes InitV2 reads through a pointer cast)."""
+    import struct
+    from . import graph_proto as gp
+    m = gp.TransformerProto()
+    m.model_type = "Qwen_v15"
+    m.graph_names.extend(["decoder", "gen_graph"])
+    for t, name, inputs, outputs, weights, attrs in graph:
+        op = m.graphs["gen_graph" if t in gen_ops else "decoder"].ops.add()
+        op.op_type, op.op_name = t, name
+        for lst, names in ((op.inputs, inputs), (op.outputs, outputs), (op.weights, weights)):
+            for n in names:
+                lst.add().name = n
+        for kv in filter(None, attrs.split(";")):
+            k, _, tv = kv.partition("=")
+            ty, _, v = tv.partition(":")
+            op.attr[k] = struct.pack("<i", int(v)) if ty == "i" else struct.pack("<f", float(v)) if ty == "f" else bytes([int(v) != 0])
+    return m.SerializeToString()
 
 
 def add_graph(m, graph):

@@ -53,6 +53,10 @@ long dihost_cache_seq_len(dihost_model_t m, int request, int layer);
  *   "fused=<0|1>;layers=<n>;ops=<before>-><after>;why=<text>;types=<operator types, comma-separated>[;wiring=<op(in)->(out)[weights]|...>]" */
 int dihost_graph_add_op(dihost_model_t m, const char* op_type, const char* op_name, const char* inputs, const char* outputs,
                         const char* weights, const char* attrs);
+/* The same from a SERIALIZED allspark TransformerProto (csrc/proto/allspark.proto: what the reference's converter writes and AsModel
+ * parses, model.cpp:265-287): the operators of the named graphs are appended in order (graphs: comma-separated, NULL = "decoder,gen_graph",
+ * the two graphs of a step).  Tensor names and raw attribute bytes are taken as they are (host/graph_wire.h); weights bind by name. */
+int dihost_graph_add_serialized(dihost_model_t m, const void* data, size_t bytes, const char* graphs);
 int dihost_graph_build(dihost_model_t m, int fuse);
 const char* dihost_graph_report(dihost_model_t m);
 const char* dihost_graph_fuse_dry(dihost_model_t m);

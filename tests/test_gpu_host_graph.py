@@ -46,9 +46,9 @@ def build_graph(m, model, wbits, group):
     def lowp(name, key, li, inputs, out, act=0, bias=None):
         q, s, z = fp[li][key]
         m.set_weight(name + ".weight", q, qdt)
-        m.set_weight(name + ".weight.scales", s, "bf16")
-        m.set_weight(name + ".weight.zeros", z, "bf16")
-        w = [name + ".weight", name + ".weight.scales", name + ".weight.zeros"]
+        m.set_weight(name + ".weight.scale", s, "bf16")
+        m.set_weight(name + ".weight.zero_point", z, "bf16")
+        w = [name + ".weight", name + ".weight.scale", name + ".weight.zero_point"]
         if bias is not None:
             m.set_weight(name + ".bias", bias, "bf16")
             w.append(name + ".bias")

@@ -25,7 +25,7 @@ KV = {"none": 0, "i8": 1, "u4": 2}
 class Host:
     """hostapi.Model + the reference graph + a span pool, on its own stream (a captured step needs a non-NULL stream)."""
 
-    def __init__(self, model, batch, max_len, span, kv_mode, fuse=True, ft="bf16", exported=False):
+    def __init__(self, model, batch, max_len, span, kv_mode, fuse=True, ft="bf16", exported=False, serialized=None):
         from dash_infer_amd import hostapi, ops
         cfg = model.cfg
         self.cfg, self.nl, self.spr = cfg, len(model.layers), (max_len + span - 1) // span
@@ -40,7 +40,10 @@ class Host:
                                                moe=(cfg.moe.num_experts, cfg.moe.top_k) if cfg.moe is not None else None)
             if exported:   # the arities the reference's converter writes + gen_graph's UpdateId (ref_graph.as_exported)
                 self.graph = ref_graph.as_exported(self.graph)
-            ref_graph.add_graph(self.m, self.graph)
+            if serialized is not None:   # bytes of an allspark TransformerProto: through the C++ wire reader (host/graph_wire.h)
+                self.m.graph_add_serialized(serialized)
+            else:
+                ref_graph.add_graph(self.m, self.graph)
             self.report = self.m.graph_build(fuse=fuse)
         self.stream.synchronize()
 
@@ -408,4 +411,33 @@ def test_layers_fused_behind_the_reference_tail(pkg):
         assert float((lo - want[t][0]).abs().max()) <= 2 ** -7 * scale, f"step {t}"
         if ids != want[t][1]:
             break                   # a near-tie decided differently by the FT logits: later steps see other inputs
+    h.close()
+
+
+def test_a_graph_serialized_by_the_reference_converter_runs_bit_identically(pkg):
+    """tests/golden/qwen2_a16w4_g128.asgraph.pb -- a TransformerProto whose graphs the reference's own Qwen_v15._build_graph + quantize_op
+    wrote (tests/golden/make_graph_golden.py) -- through host/graph_wire.h, the fusion pass and the model runner: context phase and
+    graph-replayed decode steps bit-identical to DecodeSession over the same weights (bound by the converter's names)."""
+    import os
+    from dash_infer_amd import decoder
+    data = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "qwen2_a16w4_g128.asgraph.pb"), "rb").read()
+    cfg = decoder.ModelConfig("export", hidden=3584, layers=2, n_heads=28, n_kv=4, head_dim=128, inter=1024, vocab=2048)
+    model = decoder.build_random_model(cfg, decoder.QuantSpec(4, 128), seed=77, keep_fp=True)
+    span, max_len, steps = 128, 256, 4
+    prompt = [int(t) for t in np.random.default_rng(3).integers(0, cfg.vocab, 70)]
+    sess = decoder.DecodeSession(model, 1, max_len=max_len, span_len=span)
+    lo0 = sess.prefill([prompt]).clone()
+    want = []
+    for _ in range(steps):
+        sess.step()
+        torch.cuda.synchronize()
+        want.append((sess.logits.clone(), sess.ids.cpu().tolist()))
+    h = Host(model, 1, max_len, span, "none", serialized=data)
+    assert h.report["fused"] and h.report["layers"] == 2, h.report["why"]
+    k, v = h.spans()
+    first = h.start(prompt, k, v)
+    assert first == int(lo0.argmax()) and torch.equal(h.logits()[0], lo0[0])
+    for t in range(steps):
+        ids = h.steps(1, graph=True)
+        assert ids == want[t][1] and torch.equal(h.logits(), want[t][0]), f"step {t}"
     h.close()

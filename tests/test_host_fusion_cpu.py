@@ -35,7 +35,7 @@ def test_two_layer_graph_is_fused_five_operators_per_layer(model):
     assert w[5].endswith("decoder.layer.1.attention.layernorm.gamma]")
     assert w[6].startswith("DihipNormGemm(decoder.layer.0.final_add.out,decoder.layer.0.ffn.output.dense.dihip_xnorm)->")
     assert w[10].startswith("DihipGemmAddTo(decoder.layer.1.ffn.mul.out,decoder.layer.1.attention_add.out)->(decoder.layer.1.final_add.out)[")
-    assert w[10].endswith("decoder.layer.1.ffn.output.dense.weight.zeros]")
+    assert w[10].endswith("decoder.layer.1.ffn.output.dense.weight.zero_point]")
     assert w[11] == "DihipLMHead(decoder.layer.1.final_add.out)->(logits)[final.layernorm.gamma,lm_head.weight]"
     assert w[12] == "DihipGreedy(logits)->(generated_ids)[]"
 
@@ -116,7 +116,7 @@ def test_mixture_of_experts_layer_becomes_one_block_operator(pkg):
     p = "decoder.layer.0."
     assert w[3].startswith(f"DihipGemmAddTo({p}attention.out,embedding.out)->({p}attention_add.out)[")    # no norm handed on
     assert w[4].startswith(f"DihipMoeBlock({p}attention_add.out)->({p}final_add.out)[{p}ffn.layernorm.gamma,{p}mlp.gate.weight,{p}mlp.experts.gate_up_proj.weight,")
-    assert w[4].endswith(f"{p}shared_expert.down_proj.weight.zeros,{p}shared_expert_gate.weight]") and w[4].count(",") == 14
+    assert w[4].endswith(f"{p}shared_expert.down_proj.weight.zero_point,{p}shared_expert_gate.weight]") and w[4].count(",") == 14
     assert w[5].startswith(f"DihipNormGemm({p}final_add.out)->")                                           # the next layer norms itself
     m.close()
     # expert parallelism on two ranks: AllReduce after the attention projection and ONE after the block
