@@ -101,6 +101,7 @@ class AsTensor {
     }
     return AsStatus::ALLSPARK_SUCCESS;
   }
+  bool OwnsStorage() const { return owner_; }
   void Free() {
     if (owner_ && data_) {
       if (dev_ == CPU) free(data_);

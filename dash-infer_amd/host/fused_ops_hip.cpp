@@ -79,7 +79,7 @@ struct PackedLowp {
   DataType ft = BFLOAT16;
   std::unique_ptr<AsTensor> w, sz;
   AsStatus Pack(const std::string& name, int bits, int group_size, const AsTensor* wq, const AsTensor* scales, const AsTensor* zeros,
-                hipStream_t s) {
+                hipStream_t s, bool release_source = true) {
     wbits = bits;
     group = group_size;
     if (wbits != 4 && wbits != 8) return AsStatus::ALLSPARK_PARAM_ERROR;
@@ -94,8 +94,16 @@ struct PackedLowp {
     w = std::make_unique<AsTensor>(name + ".packed_w", DeviceType::HIP, INT8, Shape{(int64_t)dihip_gemm_lowp_packed_weight_bytes(wbits, n, k)});
     sz = std::make_unique<AsTensor>(name + ".packed_sz", DeviceType::HIP, INT8, Shape{(int64_t)dihip_gemm_lowp_packed_sz_bytes(n, k, group)});
     if (!w->GetDataPtr() || !sz->GetDataPtr()) return AsStatus::ALLSPARK_MEMORY_ERROR;
-    return FromDihip(dihip_gemm_lowp_pack(s, wbits, wq->GetDataPtr(), scales->GetDataPtr(), zeros->GetDataPtr(), n, k, group,
-                                          DihipDtype(ft), w->GetDataPtr(), sz->GetDataPtr()));
+    AS_CHECK_STATUS(FromDihip(dihip_gemm_lowp_pack(s, wbits, wq->GetDataPtr(), scales->GetDataPtr(), zeros->GetDataPtr(), n, k, group,
+                                                   DihipDtype(ft), w->GetDataPtr(), sz->GetDataPtr())));
+    // The reference re-lays-out IN PLACE (gemm_a16w8_gpu.cpp:456-469: weights_buffer synced, no second copy).  The tile-major form
+    // has another size, so the source is released instead once the pack launch has read it -- when the weight map owns it (a view
+    // of caller memory, as the test harness registers, is the caller's to free): no weight is held twice.
+    if (release_source && wq->OwnsStorage()) {  // (release_source = false: a scratch tensor the caller re-uses)
+      if (hipStreamSynchronize(s) != hipSuccess) return AsStatus::ALLSPARK_RUNTIME_ERROR;
+      const_cast<AsTensor*>(wq)->Free();
+    }
+    return AsStatus::ALLSPARK_SUCCESS;
   }
   ActLayoutPref pref(int dual) const { return ActLayoutPref{wbits, n, k, group, dual, ft == BFLOAT16 ? 1 : 0}; }
   // (the small-batch kernels, and with them the FRAG32 layout, are bf16: f16 activations stay row-major)
@@ -745,7 +753,7 @@ class DihipMoeBlockOp : public MoeA16W8HIP {
           hipMemcpy2DAsync(tz.GetDataPtr(), (size_t)inter * 2, (const char*)guz->GetDataPtr() + (size_t)half * inter * 2, (size_t)inter * 4, (size_t)inter * 2, G,
                            hipMemcpyDeviceToDevice, s) != hipSuccess)
         return AsStatus::ALLSPARK_RUNTIME_ERROR;
-      AS_CHECK_STATUS((half ? su_ : sg_).Pack(op_name_ + (half ? ".shared_up" : ".shared_gate"), wb, grp, &tw, &ts, &tz, s));
+      AS_CHECK_STATUS((half ? su_ : sg_).Pack(op_name_ + (half ? ".shared_up" : ".shared_gate"), wb, grp, &tw, &ts, &tz, s, false));
     }
     AS_CHECK_STATUS(sd_.Pack(op_name_ + ".shared_down", wb, grp, weights_[11], weights_[12], weights_[13], s));
     if (sg_.n != inter || sg_.k != hidden_ || sd_.k != inter || sd_.n != hidden_ || sd_.ft != ftype_) return AsStatus::ALLSPARK_PARAM_ERROR;

@@ -60,9 +60,16 @@ class GemmLowpHIP : public AsOperator {
     sync_ = std::make_unique<AsTensor>(op_name_ + ".sync", DeviceType::HIP, INT8, Shape{(int64_t)dihip_gemm_lowp_sync_bytes()});
     if (hipMemsetAsync(sync_->GetDataPtr(), 0, sync_->GetSizeInByte(), hctx.GetStream()) != hipSuccess)
       return AsStatus::ALLSPARK_RUNTIME_ERROR;
-    return FromDihip(dihip_gemm_lowp_pack(hctx.GetStream(), WBITS, weights_[0]->GetDataPtr(), weights_[1]->GetDataPtr(),
-                                          weights_[2]->GetDataPtr(), n_, k_, group_size_, DihipDtype(ftype_),
-                                          packed_w_->GetDataPtr(), packed_sz_->GetDataPtr()));
+    AS_CHECK_STATUS(FromDihip(dihip_gemm_lowp_pack(hctx.GetStream(), WBITS, weights_[0]->GetDataPtr(), weights_[1]->GetDataPtr(),
+                                                   weights_[2]->GetDataPtr(), n_, k_, group_size_, DihipDtype(ftype_),
+                                                   packed_w_->GetDataPtr(), packed_sz_->GetDataPtr())));
+    // (the reference re-lays-out in place, gemm_a16w8_gpu.cpp:456-469; here the unpacked source is released once packed, when the
+    // weight map owns it -- no weight is held twice)
+    if (weights_[0]->OwnsStorage()) {
+      if (hipStreamSynchronize(hctx.GetStream()) != hipSuccess) return AsStatus::ALLSPARK_RUNTIME_ERROR;
+      const_cast<AsTensor*>(static_cast<const AsTensor*>(weights_[0]))->Free();
+    }
+    return AsStatus::ALLSPARK_SUCCESS;
   }
 
   AsStatus Reshape(RuntimeContext*) override {
