@@ -78,6 +78,9 @@ _SIGS = {
     "dihip_decode_attn_block_supported": (i32, [i32] * 10),
     "dihip_decode_attn_block_sync_bytes": (sz, [i32, i32, i32]),
     "dihip_decode_attn_block_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "dihip_decode_mlp_block_supported": (i32, [i32] * 6),
+    "dihip_decode_mlp_block_sync_bytes": (sz, [i32]),
+    "dihip_decode_mlp_block": (i32, [vp, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz]),
     "dihip_decode_attn_block": (i32, [vp, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                                       i32, i32, f32, vp, sz, vp, sz]),
     "dihip_prefill_attn": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32]),

@@ -370,6 +370,36 @@ bool gemv_block_plan(int wbits, int N, int K, int group_size, int nblocks, GemvA
   return true;
 }
 
+// The stand-alone decode GEMV's plan and shape fields for one row, as run_gemm fills them (decode_mlp_block.hip runs the bodies of
+// two such launches inside one: same blocks, same K split, same sums).  Pointers are the caller's.
+bool gemv_plan_args(int wbits, int N, int K, int group_size, bool dual, GemvArgs* g, int* blocks, size_t* lds_bytes) {
+  const GemvPlan gp = make_gemv_plan(wbits, 1, N, K, group_size, dual);
+  const LowpDims d = lowp_dims(wbits, N, K, group_size);
+  if (!gp.ok || gp.MR != 1 || K != d.Kp) return false;
+  g->M = 1;
+  g->N = N;
+  g->K = K;
+  g->ldx = K;
+  g->ldy = N;
+  g->KT = d.KT;
+  g->NTILES = d.NTILES;
+  g->Gp = lowp_dims(4, N, K, group_size).Gp;
+  g->ktpg = gp.ktpg;
+  g->kgroups = gp.kgroups;
+  g->upb = gp.upb;
+  g->nu_q = d.NTILES / gp.blocks;
+  g->nu_r = d.NTILES % gp.blocks;
+  g->WK = gp.WK;
+  g->WN = gp.WN;
+  g->RS = gp.RS;
+  g->alpha = 1.f;
+  g->act = DIHIP_ACT_NONE;
+  fill_kcut(*g);
+  *blocks = gp.blocks;
+  *lds_bytes = gp.lds_bytes;
+  return true;
+}
+
 template <int WBITS, int FT>
 static hipError_t dispatch_gemv(const GemvPlan& p, int pro, int epi, const GemvArgs& a, hipStream_t s) {
   const bool gpt = WBITS != 16 && p.ktpg == 1;

@@ -584,6 +584,15 @@ class DecodeSession:
             if self.attn_ws.numel() < need_ws:
                 self.attn_ws = torch.empty(need_ws, dtype=torch.uint8, device=device)
             self.block_sync = torch.zeros(int(lib().dihip_decode_attn_block_sync_bytes(self.n_loc, self.g_loc, H)), dtype=torch.uint8, device=device)
+        # The feed-forward half -- RMSNorm + gate / up + SwiGLU and the down projection + residual -- as ONE launch as well
+        # (dihip_decode_mlp_block: two launches per layer) is bit-identical but NOT faster: 26.6 vs 25.8 us per layer, because the
+        # decode GEMV consumes a resident chunk no faster than HBM delivers one, so the 64 KB per workgroup prefetched across the
+        # hand-off buy nothing and the hand-off (3.7 us) costs more than the boundary it replaces (profiles/r05_mlp_block_timeline.txt).
+        # OFF by default; DIHIP_DECODER_MLP_BLOCK=1 runs it (A/B, tests).
+        self.mlp_block = (batch == 1 and cfg.moe is None and os.environ.get("DIHIP_DECODER_MLP_BLOCK", "0") == "1"
+                          and ops.decode_mlp_block_supported(model.layers[0].gate, cfg.hidden, dt, batch))
+        if self.mlp_block:
+            self.mlp_sync = torch.zeros(int(lib().dihip_decode_mlp_block_sync_bytes(model.layers[0].gate.N)), dtype=torch.uint8, device=device)
         if not self.fused_attention and batch <= 32 and ops.prefers_frag(model.layers[0].o, batch):
             self.attn_frag = True
             self.attn = torch.zeros(ops.act_frag_numel(batch, self.n_loc * H), dtype=dt, device=device)
@@ -737,10 +746,7 @@ class DecodeSession:
             if cfg.moe is not None:
                 self._moe_block(lw, tp_on)
                 return
-            ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act,
-                                  y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
-            nxt = m.layers[li + 1].qkv if li + 1 < len(m.layers) else m.lm_head
-            self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag, next_weights=(nxt.w,))
+            self._mlp(li, tp_on)
             return
         if nf and not first:
             ops.prenorm_gemm(self.xn1, lw.qkv, lw.qkv_bias, sc, self.B, x_layout=self.xn1_layout, out=self.qkv)
@@ -777,9 +783,21 @@ class DecodeSession:
                 self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag)  # lm_head applies the final norm itself
             return
         self._proj_residual(self.attn, lw.o, tp_on, frag=self.attn_frag, next_weights=(lw.gate.w, lw.up.w))
+        self._mlp(li, tp_on)
+
+    def _mlp(self, li, tp_on):
+        """the dense feed-forward half of layer li on self.h (in place), + its all-reduce under TP"""
+        m, cfg, sc = self.model, self.model.cfg, self.scratch
+        lw = m.layers[li]
+        nxt = m.layers[li + 1].qkv if li + 1 < len(m.layers) else m.lm_head
+        if self.mlp_block:
+            h_res = self.h if (not tp_on or m.rank == 0) else None
+            ops.decode_mlp_block(self.h, h_res, lw.ln2, cfg.eps, lw.gate, lw.up, lw.down, self.mlp_sync, out=self.h)
+            if tp_on:
+                self._allreduce(self.h, (nxt.w,))
+            return
         ops.fused_norm_swiglu(self.h, lw.ln2, cfg.eps, lw.gate, lw.up, sc, out=self.act,
                               y_layout=ops.ACT_FRAG32 if self.act_frag else ops.ACT_ROWMAJOR)
-        nxt = m.layers[li + 1].qkv if li + 1 < len(m.layers) else m.lm_head
         self._proj_residual(self.act, lw.down, tp_on, frag=self.act_frag, next_weights=(nxt.w,))
 
     def _head(self):

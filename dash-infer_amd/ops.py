@@ -477,6 +477,22 @@ def decode_attn_block(h, h_res, gamma, eps, qkv_w, qkv_bias, o_w, kv, old_lens_d
     return out
 
 
+def decode_mlp_block_supported(gate_w, hidden, dtype, batch):
+    """True when dihip_decode_mlp_block serves this configuration (batch 1, bf16, int4 g128, decode-GEMV shapes)."""
+    return bool(lib().dihip_decode_mlp_block_supported(gate_w.wbits, gate_w.group, hidden, gate_w.N, capi.BF16 if dtype == torch.bfloat16 else capi.F16,
+                                                        batch))
+
+
+def decode_mlp_block(h, h_res, gamma, eps, gate_w, up_w, down_w, sync, out=None):
+    """RMSNorm + gate / up GEMV + SwiGLU and the down projection + residual of ONE request in ONE launch (dihip_decode_mlp_block):
+    out = h_res + SwiGLU(norm(h)) . Wdown, bit-identical to fused_norm_swiglu + fused_gemm_addto.  sync: zeroed once."""
+    out = out if out is not None else torch.empty_like(h)
+    check(lib().dihip_decode_mlp_block(cur_stream(), gate_w.wbits, ptr(h), ptr(h_res) if h_res is not None else None, ptr(out), ptr(gamma), float(eps),
+                                       ptr(gate_w.w), ptr(gate_w.sz), ptr(up_w.w), ptr(up_w.sz), ptr(down_w.w), ptr(down_w.sz), h.shape[-1],
+                                       gate_w.N, gate_w.group, dt_code(gamma), ptr(sync), sync.numel()), "dihip_decode_mlp_block")
+    return out
+
+
 def span_attn_merge_partials(partials, batch, n, nsplits, dtype=torch.bfloat16):
     out = torch.empty(batch, n * 128, dtype=dtype, device=partials.device)
     check(lib().dihip_span_attn_merge_partials(cur_stream(), ptr(out), ptr(partials), batch, n, nsplits, dt_code(dtype)),

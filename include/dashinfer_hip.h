@@ -386,6 +386,19 @@ int dihip_decode_attn_block(void* stream, int wbits, const float* h_in, const fl
                             int head_size, int group_size, int span_len, int n_spans_per_request, int max_seq_len, int kv_mode,
                             int dtype, float qk_scale, void* ws, size_t ws_bytes, void* sync, size_t sync_bytes);
 
+/* 3f. The feed-forward half of a batch-1 decode layer as ONE launch (round 5): LayerNormNoBeta -> Gemm[A16W4](gate, SILU) ||
+ * Gemm[A16W4](up) -> Binary MUL -> Gemm[A16W4](down) -> Binary ADD (qwen_v15.py:300-388).  Equivalent, BIT FOR BIT, to
+ *     dihip_fused_norm_swiglu(h_in ...) ; dihip_fused_gemm_addto(act, down ..., h_res, h_out)
+ * at M = 1: the SwiGLU row is handed over inside the launch (granules + one flag word per producing workgroup) while the down
+ * projection's first 64 KB per workgroup are already streaming (csrc/decode_mlp_block.hip).  With 3e a decode layer is two launches.
+ *   h_in / h_res / h_out as in 3e;  sync: >= dihip_decode_mlp_block_sync_bytes(inter), 16-byte aligned, zeroed ONCE (word 1 = error flag);
+ *   calls sharing `sync` must be ordered on one stream (hipGraph replay included).  _supported() == 0: keep the two calls. */
+int dihip_decode_mlp_block_supported(int wbits, int group_size, int hidden, int inter, int dtype, int batch);
+size_t dihip_decode_mlp_block_sync_bytes(int inter);
+int dihip_decode_mlp_block(void* stream, int wbits, const float* h_in, const float* h_res, float* h_out, const void* gamma, float eps,
+                           const void* gate_w, const void* gate_sz, const void* up_w, const void* up_sz, const void* down_w,
+                           const void* down_sz, int hidden, int inter, int group_size, int dtype, void* sync, size_t sync_bytes);
+
 /* =============================================================================================
  * 4. Prefill attention (replaces xformer_prefill_attention,
  *    csrc/core/kernel/cuda/xformer_mha/xformer_mha.h:26-41): causal softmax(alpha Q K^T) V, GQA.
