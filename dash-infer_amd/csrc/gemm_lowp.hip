@@ -637,7 +637,8 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
     }
   }
   // batched decode with FRAG32 activations: panels of 8 column tiles sharing x through LDS (gemm_panel_kernel.hpp)
-  if (c.dtype == DIHIP_BF16 && gemv_stream_enabled() && c.x_layout == DIHIP_ACT_FRAG32 && c.pro == PRO_PLAIN && c.M > 4 &&
+  const bool f16_act = c.dtype == DIHIP_F16;  // (round 5: the small-batch and context-phase kernels are instantiated for f16 as well)
+  if ((c.dtype == DIHIP_BF16 || f16_act) && gemv_stream_enabled() && c.x_layout == DIHIP_ACT_FRAG32 && c.pro == PRO_PLAIN && c.M > 4 &&
       c.M <= 32 && c.wbits != 16 && c.K == d.Kp && (d.group == 0 || d.group % d.KTILE == 0)) {
     const KslicePlan kp = make_kslice_plan(c.wbits, c.M, c.N, c.K, c.group_size, dual);
     if (kp.ok) {
@@ -680,7 +681,9 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
       const int mt = c.M > 16 ? 2 : 1;
       hipError_t e = hipErrorInvalidValue;
 #define KSLICE_GO(W_, MT_, EPI_, G_) \
-      if (c.wbits == W_ && mt == MT_ && c.epi == EPI_ && (int)gpt == G_) e = launch_gemm_kslice<W_, DIHIP_BF16, MT_, EPI_, G_>(g, kp.groups, kp.waves, stream);
+      if (c.wbits == W_ && mt == MT_ && c.epi == EPI_ && (int)gpt == G_)                                                       \
+        e = f16_act ? launch_gemm_kslice<W_, DIHIP_F16, MT_, EPI_, G_>(g, kp.groups, kp.waves, stream)                         \
+                    : launch_gemm_kslice<W_, DIHIP_BF16, MT_, EPI_, G_>(g, kp.groups, kp.waves, stream);
 #define KSLICE_ALL(W_, G_) KSLICE_GO(W_, 1, EPI_STD, G_) KSLICE_GO(W_, 2, EPI_STD, G_) KSLICE_GO(W_, 1, EPI_SWIGLU, G_) \
       KSLICE_GO(W_, 2, EPI_SWIGLU, G_) KSLICE_GO(W_, 1, EPI_ADDTO, G_) KSLICE_GO(W_, 2, EPI_ADDTO, G_)
       KSLICE_ALL(4, 0) KSLICE_ALL(4, 1) KSLICE_ALL(8, 0)  // W8 with a group per k-tile (g64) is excluded by the plan: not instantiated
@@ -730,7 +733,9 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
       const int mt = c.M > 16 ? 2 : 1;
       hipError_t e = hipErrorInvalidValue;
 #define PANEL_GO(W_, MT_, EPI_, G_) \
-      if (c.wbits == W_ && mt == MT_ && c.epi == EPI_ && (int)gpt == G_) e = launch_gemm_panel<W_, DIHIP_BF16, MT_, EPI_, G_>(g, pp.panels, stream);
+      if (c.wbits == W_ && mt == MT_ && c.epi == EPI_ && (int)gpt == G_)                                          \
+        e = f16_act ? launch_gemm_panel<W_, DIHIP_F16, MT_, EPI_, G_>(g, pp.panels, stream)                       \
+                    : launch_gemm_panel<W_, DIHIP_BF16, MT_, EPI_, G_>(g, pp.panels, stream);
 #define PANEL_ALL(W_, G_) PANEL_GO(W_, 1, EPI_STD, G_) PANEL_GO(W_, 2, EPI_STD, G_) PANEL_GO(W_, 1, EPI_SWIGLU, G_) \
       PANEL_GO(W_, 2, EPI_SWIGLU, G_) PANEL_GO(W_, 1, EPI_ADDTO, G_) PANEL_GO(W_, 2, EPI_ADDTO, G_)
       PANEL_ALL(4, 0) PANEL_ALL(4, 1) PANEL_ALL(8, 0) PANEL_ALL(8, 1)
@@ -742,7 +747,7 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
     }
   }
   // small decode batches whose activations do not fit in LDS: register-resident A (gemv_batch_kernel.hpp)
-  if (c.dtype == DIHIP_BF16 && gemv_stream_enabled() && gemv_aligned && c.pro == PRO_PLAIN && c.M > 1 && c.M <= 32 &&
+  if ((c.dtype == DIHIP_BF16 || f16_act) && gemv_stream_enabled() && gemv_aligned && c.pro == PRO_PLAIN && c.M > 1 && c.M <= 32 &&
       c.wbits != 16 && (d.group == 0 || d.group % d.KTILE == 0)) {
     GembArgs g{};
     g.w0 = reinterpret_cast<const u32x4_t*>(c.w0);
@@ -782,7 +787,8 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
     hipError_t e = hipErrorInvalidValue;
 #define GEMB_GO(W_, MT_, NT_, EPI_, G_) \
     if (c.wbits == W_ && mt == MT_ && nt == NT_ && c.epi == EPI_ && (int)gpt == G_) \
-      e = launch_gemv_batch<W_, DIHIP_BF16, MT_, NT_, EPI_, G_>(g, blocks, stream);
+      e = f16_act ? launch_gemv_batch<W_, DIHIP_F16, MT_, NT_, EPI_, G_>(g, blocks, stream)  \
+                  : launch_gemv_batch<W_, DIHIP_BF16, MT_, NT_, EPI_, G_>(g, blocks, stream);
 #define GEMB_EPIS(W_, MT_, NT_, G_) GEMB_GO(W_, MT_, NT_, EPI_STD, G_) GEMB_GO(W_, MT_, NT_, EPI_SWIGLU, G_) GEMB_GO(W_, MT_, NT_, EPI_ADDTO, G_)
 #define GEMB_ALL(W_, G_) GEMB_EPIS(W_, 1, 1, G_) GEMB_EPIS(W_, 2, 1, G_) GEMB_EPIS(W_, 1, 2, G_) GEMB_EPIS(W_, 2, 2, G_)
     GEMB_ALL(4, 0) GEMB_ALL(4, 1) GEMB_ALL(8, 0) GEMB_ALL(8, 1)
@@ -798,7 +804,7 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
   // context phase (M >= 64 rows): 128 x 256 workgroup tiles, A through LDS, every weight byte read once per 128 rows
   // (gemm_prefill_kernel.hpp).  DIHIP_GEMM_PREFILL=0 keeps the general kernel (A/B, diagnostics).
   static const bool prefill_on = !env_off("DIHIP_GEMM_PREFILL");
-  if (prefill_on && c.dtype == DIHIP_BF16 && c.pro == PRO_PLAIN && c.M >= 64 && (c.wbits == 4 || c.wbits == 8) && gemv_aligned &&
+  if (prefill_on && (c.dtype == DIHIP_BF16 || f16_act) && c.pro == PRO_PLAIN && c.M >= 64 && (c.wbits == 4 || c.wbits == 8) && gemv_aligned &&
       (d.group == 0 || d.group % d.KTILE == 0) && (c.epi != EPI_SWIGLU || (c.w1 && c.sz1))) {
     PrefillArgs g{};
     g.w0 = reinterpret_cast<const u32x4_t*>(c.w0);
@@ -828,7 +834,8 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
     const bool gpt = g.ktpg == 1;
     hipError_t e = hipErrorInvalidValue;
 #define PREFILL_GO(W_, EPI_, G_) \
-    if (c.wbits == W_ && c.epi == EPI_ && (int)gpt == G_) e = launch_gemm_prefill<W_, DIHIP_BF16, EPI_, G_>(g, blocks, stream);
+    if (c.wbits == W_ && c.epi == EPI_ && (int)gpt == G_)                                          \
+      e = f16_act ? launch_gemm_prefill<W_, DIHIP_F16, EPI_, G_>(g, blocks, stream) : launch_gemm_prefill<W_, DIHIP_BF16, EPI_, G_>(g, blocks, stream);
 #define PREFILL_ALL(W_) PREFILL_GO(W_, EPI_STD, 0) PREFILL_GO(W_, EPI_STD, 1) PREFILL_GO(W_, EPI_SWIGLU, 0) PREFILL_GO(W_, EPI_SWIGLU, 1) \
     PREFILL_GO(W_, EPI_ADDTO, 0) PREFILL_GO(W_, EPI_ADDTO, 1)
     PREFILL_ALL(4) PREFILL_ALL(8)
@@ -1130,7 +1137,7 @@ static int norm_to_ws(hipStream_t s, const float* h, const void* gamma, float ep
     slab = std::max(slab, make_kslice_plan(wbits, M, N, K, group_size, dual, true).slab_bytes);
   }
   const size_t off = (slab + 255) & ~(size_t)255;
-  const bool frag = dtype == DIHIP_BF16 && (force_frag || batch_kernel_shape(wbits, M, N, K, group_size, dual));  // the small-batch kernels are bf16
+  const bool frag = force_frag || batch_kernel_shape(wbits, M, N, K, group_size, dual);  // (bf16 and f16: both instantiated since round 5)
   const int mt = M > 16 ? 2 : 1;
   const size_t xbytes = frag ? (size_t)mt * 16 * K * 2 : (size_t)M * K * 2;
   DIHIP_REQUIRE(ws && ws_bytes >= off + xbytes, DIHIP_MEMORY_ERROR, "fused gemm: workspace too small");
@@ -1197,8 +1204,8 @@ int dihip_fused_norm_swiglu_ex(void* stream, int wbits, const float* h, const vo
                                size_t ws_bytes, void* sync, int dtype, int y_layout) {
   DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16, DIHIP_PARAM_ERROR, "fused path: bf16 or f16 activations");
   DIHIP_REQUIRE(y_layout == DIHIP_ACT_ROWMAJOR || y_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "fused swiglu: bad y_layout");
-  DIHIP_REQUIRE(y_layout == DIHIP_ACT_ROWMAJOR || (dtype == DIHIP_BF16 && M > 4 && batch_kernel_eligible(wbits, M, N, K, group_size)), DIHIP_PARAM_ERROR,
-                "fused swiglu: FRAG32 output needs the small-batch kernel (bf16, 4 < M <= 32, K a multiple of the k-tile)");
+  DIHIP_REQUIRE(y_layout == DIHIP_ACT_ROWMAJOR || (M > 4 && batch_kernel_eligible(wbits, M, N, K, group_size)), DIHIP_PARAM_ERROR,
+                "fused swiglu: FRAG32 output needs the small-batch kernel (4 < M <= 32, K a multiple of the k-tile)");
   DIHIP_REQUIRE(sync != nullptr, DIHIP_PARAM_ERROR, "fused path needs a sync buffer");
   if (M == 0) return DIHIP_SUCCESS;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

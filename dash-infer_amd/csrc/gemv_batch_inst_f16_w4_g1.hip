@@ -1,0 +1,5 @@
+// explicit instantiations: small-batch decode GEMM (gemv_batch_kernel.hpp), W4, f16, GPT=1
+#include "gemv_batch_kernel.hpp"
+namespace dihip {
+DIHIP_DEFINE_GEMB_LAUNCH_SET(4, DIHIP_F16, 1)
+}  // namespace dihip

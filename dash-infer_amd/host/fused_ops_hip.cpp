@@ -106,11 +106,11 @@ struct PackedLowp {
     return AsStatus::ALLSPARK_SUCCESS;
   }
   ActLayoutPref pref(int dual) const { return ActLayoutPref{wbits, n, k, group, dual, ft == BFLOAT16 ? 1 : 0}; }
-  // (the small-batch kernels, and with them the FRAG32 layout, are bf16: f16 activations stay row-major)
-  bool prefers_frag(int m, int dual) const { return ft == BFLOAT16 && dihip_gemm_lowp_prefers_frag(wbits, m, n, k, group, dual) != 0; }
+  // (the small-batch kernels, and with them the FRAG32 layout, serve bf16 and -- since round 5 -- f16)
+  bool prefers_frag(int m, int dual) const { return dihip_gemm_lowp_prefers_frag(wbits, m, n, k, group, dual) != 0; }
 };
 bool pref_frag(const ActLayoutPref* p, int m) {
-  return p && p->bf16 && dihip_gemm_lowp_prefers_frag(p->wbits, m, p->n, p->k, p->group, p->dual) != 0;
+  return p && dihip_gemm_lowp_prefers_frag(p->wbits, m, p->n, p->k, p->group, p->dual) != 0;
 }
 
 std::unique_ptr<AsTensor> zeroed(const std::string& name, size_t bytes, hipStream_t s) {

@@ -388,7 +388,9 @@ def test_real_width_batched_decode_vs_oracle(pkg, name, shape, kv_mode, batch, g
     (SMALL, 8, -1, "none", 3, False),      # int8 per-channel
     (SMALL, 4, 128, "i8", 2, False),       # quantising append + the int8-cache attention kernels
     (WIDE, 8, 128, "none", 4, False),      # int8 sub-channel at M = 4
-    (WIDE, 4, 128, "u4", 17, False),       # M > 4: general kernel with the fused norm, f16 + uint4 cache (VALU attention kernel)
+    (WIDE, 4, 128, "u4", 17, False),       # M > 4: small-batch kernels (f16 since round 5) with the fused norm, f16 + uint4 cache (VALU attention kernel)
+    (WIDE, 4, 128, "i8", 32, True),        # batch 32, int8 cache, captured graph: FRAG32 chain in f16
+    (WIDE, 8, -1, "none", 9, False),       # int8 per-channel, 16-bit cache
 ])
 def test_f16_greedy_decode_matches_oracle(pkg, shape, wbits, group, kv_mode, batch, graph):
     from dash_infer_amd import decoder
