@@ -80,7 +80,9 @@ if "trace" in os.environ.get("DIHIP_LIB_DIR", ""):
     ns, g = 17, 4
     na = int(os.environ.get("NA", ns * g))
     names_a = ["entry", "K/V requested", "q gathered (+rotate)", "tiles done", "records drained", "ticket taken", "merge loads landed", "end"]
-    names_g = ["entry", "row staged, shares requested", "shares landed", "qkv published", "group flags seen", "output swept", "o multiplied", "end"]
+    names_a[4] = "records stored (dist. merge) / drained"
+    names_g = ["entry", "row staged, shares requested", "shares landed", "qkv published", "group sentinels seen", "output swept", "o multiplied", "end",
+               "record slices seen (dist. merge)", "merged elements published"]
     def show(rows, names, title):
         print(title, f"({rows.shape[0]} workgroups; us after the launch's first stamp: median / max)")
         for i, nm in enumerate(names):
@@ -90,4 +92,4 @@ if "trace" in os.environ.get("DIHIP_LIB_DIR", ""):
                 rel = (col - base) / 100.0
                 print(f"  {i} {nm:32s} {rel.median().item():7.2f} {rel.max().item():7.2f}   (n={col.numel()})")
     show(t[:na][used[:na]][:, :8], names_a, "attention workgroups, wave 0")
-    show(t[na:][used[na:]][:, :8], names_g, "GEMV workgroups, wave 0")
+    show(t[na:][used[na:]][:, :10], names_g, "GEMV workgroups, wave 0 (stamps 8, 9 come between 3 and 4)")
