@@ -37,6 +37,11 @@ _SIGS = {
     "dihip_fused_gemm_addto_norm": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, i32, i32, vp, f32, vp, i32]),
     "dihip_prenorm_gemm": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp, i32]),
     "dihip_prenorm_swiglu": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, i32, i32]),
+    "dihip_fused_gemm_addto_prenorm": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, i32, i32, vp, f32, vp, i32, vp, sz, vp]),
+    "dihip_prenorm_gemm_rowsq": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp, i32, vp, i32, f32]),
+    "dihip_prenorm_swiglu_rowsq": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, i32, i32, vp, i32, f32]),
+    "dihip_prenorm_rowsq_supported": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
+    "dihip_rowsq_bytes": (sz, []),
     "dihip_gemm_lowp_prefers_frag": (i32, [i32, i32, i32, i32, i32, i32]),
     "dihip_moe_route": (i32, [vp, vp, i32, i32, i32, vp, vp, i32]),
     "dihip_rmsnorm_rows": (i32, [vp, vp, vp, vp, f32, i32, i32, i32]),

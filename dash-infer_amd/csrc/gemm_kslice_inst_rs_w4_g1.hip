@@ -1,0 +1,7 @@
+// explicit instantiations: K-slice GEMM for batched decode, deferred-RMSNorm consumer (gemm_kslice_kernel.hpp, RS = 1), W4, bf16, GPT=1
+#include <algorithm>
+
+#include "gemm_kslice_kernel.hpp"
+namespace dihip {
+DIHIP_DEFINE_KSLICE_RS_LAUNCH_SET(4, 1)
+}  // namespace dihip

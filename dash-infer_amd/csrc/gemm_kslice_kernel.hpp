@@ -47,7 +47,10 @@ constexpr int KSL_WAVES = 8;
 #define DIHIP_KSL_X 0
 #endif
 
-template <int WBITS, int FT, int MT, int EPI, int GPT>
+
+// RS = 1: the deferred-RMSNorm consumer (PanelArgs::rowsq; unsplit K, EPI_STD / EPI_SWIGLU).  Its own instantiations: with the code
+// merely compiled in, the plain launches ran 1.5 - 2 us slower (main-loop scheduling; profiles/r05_deferred_norm.txt).
+template <int WBITS, int FT, int MT, int EPI, int GPT, int RS = 0>
 __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const PanelArgs a) {
   using WT = WTraits<WBITS>;
   using EX = ExpandV<WBITS, FT>;
@@ -68,6 +71,13 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
   // W8 slices have 8 chunks (2 x the LDS); their sums are recomputed per chunk.
   constexpr bool XS_LDS = WBITS == 4;
   __shared__ __attribute__((aligned(16))) f32x4_t xsl[XS_LDS ? KSL_WAVES : 1][XS_LDS ? CH : 1][MT][64];
+  // deferred RMSNorm, consumer side (PanelArgs::rowsq; unsplit K only -- with a slab the reduction kernel applies it): the
+  // producer's partial sums per row are added by thread (row, part) in a fixed order -- 16 loads requested right behind the
+  // activation loads and added behind their wait -- and meet in rsp; the epilogue lanes finish 1 / rms for their own rows.
+  // (Measured: a slice-less helper wave +1.7 us, adding the parts before the activation loads +1.3, requesting them at entry
+  // +0.7 at M = 32 / +2.1 at M = 16 -- loads return in order; profiles/r05_deferred_norm.txt.)
+  __shared__ float rsp[RS ? 16 : 1][32];
+  __shared__ float rstd_l[RS ? 32 : 1];
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -90,7 +100,35 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
 #define DIHIP_KSL_STAMP(I) do { } while (0)
 #endif
   DIHIP_KSL_STAMP(0);  // entry
-
+  // (nothing of this is kept live across the main loop: the MT = 2 variants have no register to spare -- the epilogue
+  // re-derives what it needs from the kernel arguments)
+  static_assert(!RS || EPI != EPI_ADDTO, "deferred row norms: consumer epilogues only");
+  auto rs_parts = [&]() { return min((int)blockDim.x >> 5, 16); };
+  float rs_r[16];  // the first 16 parts of thread (row, part): requested BEHIND the ring and the activation loads (loads return in order, and the
+                   // parts were written by the previous launch on other XCDs: requested first they held everything else back, +0.7 .. 2 us)
+  // thread (row, part) adds parts part, part + nparts, ... in that order
+  auto rs_sum = [&]() {
+    const int rs_nparts = rs_parts();
+    if (tid >= rs_nparts * 32) return;
+    const int m = tid & 31, part = tid >> 5;
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += rs_r[j];
+    for (int p0 = part + 16 * rs_nparts; p0 < a.rowsq_parts; p0 += rs_nparts * 16) {
+      float r[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) r[j] = p0 + j * rs_nparts < a.rowsq_parts ? a.rowsq[(size_t)(p0 + j * rs_nparts) * 32 + m] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) t += r[j];
+    }
+    rsp[part][m] = t;
+  };
+  auto rs_request = [&]() {
+    const int rs_nparts = rs_parts();
+    const int m = tid & 31, part = min(tid >> 5, rs_nparts - 1);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) rs_r[j] = part + j * rs_nparts < a.rowsq_parts ? a.rowsq[(size_t)(part + j * rs_nparts) * 32 + m] : 0.f;
+  };
   // units of this workgroup: blockIdx.x, + gridDim.x, ...; a unit is a column tile (SwiGLU: the gate / up tile pair)
   const int NB = gridDim.x;
   const int nu = (a.nunits - (int)blockIdx.x + NB - 1) / NB;
@@ -157,6 +195,9 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
           asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xf[i][mt]) : "v"(xp + (size_t)(i * MT + mt) * 64) : "memory");
         }
       }
+    if constexpr (RS) {
+      rs_request();
+    }
     // hipcc does not count asm loads: one explicit wait (the sums below need every fragment, and the ring, requested
     // earlier, has landed by then as well)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -165,7 +206,13 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(xf[i][mt]));
   }
+  if constexpr (RS) {
+    if (!active) rs_request();  // (a slice-less wave)
+  }
   DIHIP_KSL_STAMP(1);  // ring + activation loads issued
+  if constexpr (RS) {  // (the 16 registers are live in the prologue only, where even the MT = 2 variants have room)
+    rs_sum();
+  }
   if (active) {
     if constexpr (XS_LDS) {
 #pragma unroll
@@ -180,6 +227,21 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
     }
   }
 
+  if constexpr (RS) {
+    // one barrier of the prologue: the parts' sums are in rsp; 32 lanes of the LAST wave (never an epilogue wave with >= 3 waves)
+    // finish 1 / rms per row -- 16 LDS reads in flight -- and the epilogues read rstd_l behind the first pair's barrier
+    __syncthreads();
+    if (wave == (int)(blockDim.x >> 6) - 1 && lane < 32) {
+      const int np_ = rs_parts();
+      float pv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) pv[q] = rsp[min(q, np_ - 1)][lane];
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t += q < np_ ? pv[q] : 0.f;
+      rstd_l[lane] = 1.f / sqrtf(t / (float)a.K + a.rowsq_eps);
+    }
+  }
   DIHIP_KSL_STAMP(2);  // activation sums done: ring and activations have landed
   // NP is rounded up to whole bodies: a dummy pair re-loads the last tiles and stores nothing (a guarded pair would put
   // its loads behind a branch, and hipcc drains the queue at such a join)
@@ -288,7 +350,14 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
           a.slab[(((size_t)blockIdx.y * DUAL) * a.M + m) * a.N + n] = v[rr];
           if constexpr (DUAL == 2) a.slab[(((size_t)blockIdx.y * DUAL + 1) * a.M + m) * a.N + n] = v2[rr];
         } else {
-          panel_epilogue<FT, EPI>(a, m, n, v[rr], v2[rr], MT);
+          if constexpr (RS) {
+            int mo = m;
+            asm volatile("" : "+v"(mo));  // (opaque: the LDS address is formed here, not hoisted into a register that lives across the main loop)
+            const float r_ = rstd_l[mo];
+            panel_epilogue<FT, EPI>(a, m, n, v[rr] * r_, v2[rr] * r_, MT);
+          } else {
+            panel_epilogue<FT, EPI>(a, m, n, v[rr], v2[rr], MT);
+          }
         }
       }
     }
@@ -299,6 +368,20 @@ __global__ __launch_bounds__(KSL_WAVES * 64) void gemm_kslice_kernel(const Panel
 
 template <int WBITS, int FT, int MT, int EPI, int GPT>
 hipError_t launch_gemm_kslice(const PanelArgs& a, int groups, int waves, hipStream_t stream);
+// the deferred-RMSNorm consumer (bf16, unsplit K, a.rowsq set)
+template <int WBITS, int MT, int EPI, int GPT>
+hipError_t launch_gemm_kslice_rs(const PanelArgs& a, int groups, int waves, hipStream_t stream);
+#define DIHIP_DEFINE_KSLICE_RS_LAUNCH(WBITS, MT, EPI, GPT)                                                     \
+  template <>                                                                                                 \
+  hipError_t launch_gemm_kslice_rs<WBITS, MT, EPI, GPT>(const PanelArgs& a, int groups, int waves, hipStream_t s) { \
+    hipLaunchKernelGGL((gemm_kslice_kernel<WBITS, DIHIP_BF16, MT, EPI, GPT, 1>), dim3(groups, 1), dim3(waves * 64), 0, s, a); \
+    return hipGetLastError();                                                                                 \
+  }
+#define DIHIP_DEFINE_KSLICE_RS_LAUNCH_SET(WBITS, GPT)      \
+  DIHIP_DEFINE_KSLICE_RS_LAUNCH(WBITS, 1, EPI_STD, GPT)    \
+  DIHIP_DEFINE_KSLICE_RS_LAUNCH(WBITS, 2, EPI_STD, GPT)    \
+  DIHIP_DEFINE_KSLICE_RS_LAUNCH(WBITS, 1, EPI_SWIGLU, GPT) \
+  DIHIP_DEFINE_KSLICE_RS_LAUNCH(WBITS, 2, EPI_SWIGLU, GPT)
 
 #define DIHIP_DEFINE_KSLICE_LAUNCH(WBITS, FT, MT, EPI, GPT)                                                   \
   template <>                                                                                                 \

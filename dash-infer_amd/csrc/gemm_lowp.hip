@@ -241,6 +241,15 @@ struct GemmCall {
   void* n_out;
   int n_frag_mt;
   bool* n_done;
+  // deferred RMSNorm (gemv_batch_kernel.hpp, GembArgs).  Producer: n_rowsq != null asks for n_out = FT(gamma * h_out) and the
+  // row partials instead of the finished norm; *n_parts = parts written, 0 when the serving kernel does not offer it (the
+  // norm is then produced as above).  Consumer: rowsq != null -- rows are scaled by 1 / rms on the accumulator.
+  float* n_rowsq;
+  size_t n_rowsq_bytes;
+  int* n_parts;
+  const float* rowsq;
+  int rowsq_parts;
+  float rowsq_eps;
 };
 
 
@@ -588,6 +597,9 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
                             (c.pro == PRO_PLAIN || reinterpret_cast<uintptr_t>(c.gamma) % 16 == 0);
   const bool f16_std = c.dtype == DIHIP_F16;  // every form of the decode GEMV exists for f16 as well
   const bool want_frag = c.x_layout == DIHIP_ACT_FRAG32 || c.y_layout == DIHIP_ACT_FRAG32;  // small-batch kernel only
+  DIHIP_REQUIRE(!c.rowsq || (c.M > 4 && c.M <= 32 && c.dtype == DIHIP_BF16 && c.rowsq_parts > 0 && c.epi != EPI_ADDTO), DIHIP_PARAM_ERROR,
+                "gemm_lowp: deferred row norms are taken by the small-batch kernels only (4 < M <= 32, bf16); see dihip_prenorm_rowsq_supported");
+  if (c.n_parts) *c.n_parts = 0;
   if ((c.dtype == DIHIP_BF16 || f16_std) && gemv_stream_enabled() && gemv_aligned && !want_frag) {
     const GemvPlan gp = make_gemv_plan(c.wbits, c.M, c.N, c.K, c.group_size, dual);
     if (gp.ok) {
@@ -679,14 +691,29 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
       }
       const bool gpt = g.ktpg == 1;
       const int mt = c.M > 16 ? 2 : 1;
+      const int waves = kp.waves;
+      if (c.rowsq) {  // deferred row norms: in the epilogue (unsplit K) or in the slab reduction
+        g.rowsq = c.rowsq;
+        g.rowsq_parts = c.rowsq_parts;
+        g.rowsq_eps = c.rowsq_eps;
+      }
       hipError_t e = hipErrorInvalidValue;
 #define KSLICE_GO(W_, MT_, EPI_, G_) \
       if (c.wbits == W_ && mt == MT_ && c.epi == EPI_ && (int)gpt == G_)                                                       \
-        e = f16_act ? launch_gemm_kslice<W_, DIHIP_F16, MT_, EPI_, G_>(g, kp.groups, kp.waves, stream)                         \
-                    : launch_gemm_kslice<W_, DIHIP_BF16, MT_, EPI_, G_>(g, kp.groups, kp.waves, stream);
+        e = f16_act ? launch_gemm_kslice<W_, DIHIP_F16, MT_, EPI_, G_>(g, kp.groups, waves, stream)                            \
+                    : launch_gemm_kslice<W_, DIHIP_BF16, MT_, EPI_, G_>(g, kp.groups, waves, stream);
 #define KSLICE_ALL(W_, G_) KSLICE_GO(W_, 1, EPI_STD, G_) KSLICE_GO(W_, 2, EPI_STD, G_) KSLICE_GO(W_, 1, EPI_SWIGLU, G_) \
       KSLICE_GO(W_, 2, EPI_SWIGLU, G_) KSLICE_GO(W_, 1, EPI_ADDTO, G_) KSLICE_GO(W_, 2, EPI_ADDTO, G_)
+      if (c.rowsq && kp.nslices == 1) {  // the deferred-RMSNorm consumer has its own instantiations (bf16)
+#define KSLICE_RS_GO(W_, MT_, EPI_, G_) \
+        if (c.wbits == W_ && mt == MT_ && c.epi == EPI_ && (int)gpt == G_) e = launch_gemm_kslice_rs<W_, MT_, EPI_, G_>(g, kp.groups, waves, stream);
+#define KSLICE_RS_ALL(W_, G_) KSLICE_RS_GO(W_, 1, EPI_STD, G_) KSLICE_RS_GO(W_, 2, EPI_STD, G_) KSLICE_RS_GO(W_, 1, EPI_SWIGLU, G_) KSLICE_RS_GO(W_, 2, EPI_SWIGLU, G_)
+        KSLICE_RS_ALL(4, 0) KSLICE_RS_ALL(4, 1) KSLICE_RS_ALL(8, 0)
+#undef KSLICE_RS_ALL
+#undef KSLICE_RS_GO
+      } else {
       KSLICE_ALL(4, 0) KSLICE_ALL(4, 1) KSLICE_ALL(8, 0)  // W8 with a group per k-tile (g64) is excluded by the plan: not instantiated
+      }
 #undef KSLICE_ALL
 #undef KSLICE_GO
       DIHIP_REQUIRE(e == hipSuccess, DIHIP_RUNTIME_ERROR, "gemm_kslice: launch failed (wbits=%d M=%d epi=%d): %s", c.wbits, c.M,
@@ -731,6 +758,12 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
       }
       const bool gpt = g.ktpg == 1;
       const int mt = c.M > 16 ? 2 : 1;
+      if (c.rowsq) {
+        DIHIP_REQUIRE(pp.nslices > 1, DIHIP_PARAM_ERROR, "gemm_panel: deferred row norms need the split-K reduction; see dihip_prenorm_rowsq_supported");
+        g.rowsq = c.rowsq;
+        g.rowsq_parts = c.rowsq_parts;
+        g.rowsq_eps = c.rowsq_eps;
+      }
       hipError_t e = hipErrorInvalidValue;
 #define PANEL_GO(W_, MT_, EPI_, G_) \
       if (c.wbits == W_ && mt == MT_ && c.epi == EPI_ && (int)gpt == G_)                                          \
@@ -784,6 +817,22 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
     g.upb = env_upb > 0 ? env_upb : (d.NTILES <= ncu ? 1 : (d.NTILES + ncu - 1) / ncu);
     const int nt = env_nt > 0 ? std::min(env_nt, 2) : (g.upb >= 2 ? 2 : 1);
     const int blocks = (d.NTILES + g.upb - 1) / g.upb;
+    if (c.epi == EPI_ADDTO && c.n_rowsq && c.n_gamma && c.n_out && c.n_parts && c.dtype == DIHIP_BF16 && g.upb <= GEMB_MAXU &&
+        (size_t)blocks * 32 * sizeof(float) <= c.n_rowsq_bytes) {  // deferred RMSNorm, producer side
+      g.n_gamma = c.n_gamma;
+      g.n_out = c.n_out;
+      g.n_frag_mt = c.n_frag_mt;
+      g.n_rowsq = c.n_rowsq;
+      *c.n_parts = blocks;
+      if (c.n_done) *c.n_done = true;
+    }
+    if (c.rowsq) {
+      DIHIP_REQUIRE(c.epi == EPI_STD, DIHIP_PARAM_ERROR, "gemv_batch: deferred row norms on the plain epilogue only; see dihip_prenorm_rowsq_supported");
+      DIHIP_REQUIRE(c.rowsq_parts <= 16 * (GEMB_THREADS / 32), DIHIP_PARAM_ERROR, "gemv_batch: more than %d row-norm parts", 16 * (GEMB_THREADS / 32));
+      g.rowsq = c.rowsq;
+      g.rowsq_parts = c.rowsq_parts;
+      g.rowsq_eps = c.rowsq_eps;
+    }
     hipError_t e = hipErrorInvalidValue;
 #define GEMB_GO(W_, MT_, NT_, EPI_, G_) \
     if (c.wbits == W_ && mt == MT_ && nt == NT_ && c.epi == EPI_ && (int)gpt == G_) \
@@ -801,6 +850,7 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
   }
   DIHIP_REQUIRE(!want_frag, DIHIP_PARAM_ERROR,
                 "gemm_lowp: the FRAG32 activation layout needs the small-batch kernel (see dihip_gemm_lowp_prefers_frag)");
+  DIHIP_REQUIRE(!c.rowsq, DIHIP_PARAM_ERROR, "gemm_lowp: this shape is not served by a kernel that takes deferred row norms");
   // context phase (M >= 64 rows): 128 x 256 workgroup tiles, A through LDS, every weight byte read once per 128 rows
   // (gemm_prefill_kernel.hpp).  DIHIP_GEMM_PREFILL=0 keeps the general kernel (A/B, diagnostics).
   static const bool prefill_on = !env_off("DIHIP_GEMM_PREFILL");
@@ -1309,10 +1359,11 @@ int dihip_fused_gemm_addto_ex(void* stream, int wbits, const void* x, const void
   return run_gemm(reinterpret_cast<hipStream_t>(stream), c);
 }
 
-int dihip_fused_gemm_addto_norm(void* stream, int wbits, const void* x, const void* w_packed, const void* sz_packed,
+static int gemm_addto_norm_impl(void* stream, int wbits, const void* x, const void* w_packed, const void* sz_packed,
                                 const float* h_res, float* h_out, int M, int N, int K, int group_size, void* ws,
                                 size_t ws_bytes, void* sync, int dtype, int x_layout, const void* gamma, float eps,
-                                void* xnorm, int xnorm_layout) {
+                                void* xnorm, int xnorm_layout, float* rowsq, size_t rowsq_bytes, int* rowsq_parts) {
+  if (rowsq_parts) *rowsq_parts = 0;
   DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16, DIHIP_PARAM_ERROR, "fused path: bf16 or f16 activations");
   DIHIP_REQUIRE(x_layout == DIHIP_ACT_ROWMAJOR || x_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "fused addto: bad x_layout");
   DIHIP_REQUIRE(xnorm_layout == DIHIP_ACT_ROWMAJOR || (xnorm_layout == DIHIP_ACT_FRAG32 && M <= 32 && N % 32 == 0),
@@ -1345,10 +1396,50 @@ int dihip_fused_gemm_addto_norm(void* stream, int wbits, const void* x, const vo
   c.n_out = xnorm;
   c.n_frag_mt = xnorm_layout == DIHIP_ACT_FRAG32 ? (M > 16 ? 2 : 1) : 0;
   c.n_done = &done;
+  c.n_rowsq = rowsq;
+  c.n_rowsq_bytes = rowsq_bytes;
+  c.n_parts = rowsq ? rowsq_parts : nullptr;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int st = run_gemm(s, c);
   if (st || done) return st;
   return launch_rmsnorm_rows(s, h_out, gamma, eps, M, N, xnorm, c.n_frag_mt, dtype);  // this plan has no slab reduction to ride on
+}
+
+int dihip_fused_gemm_addto_norm(void* stream, int wbits, const void* x, const void* w_packed, const void* sz_packed,
+                                const float* h_res, float* h_out, int M, int N, int K, int group_size, void* ws,
+                                size_t ws_bytes, void* sync, int dtype, int x_layout, const void* gamma, float eps,
+                                void* xnorm, int xnorm_layout) {
+  return gemm_addto_norm_impl(stream, wbits, x, w_packed, sz_packed, h_res, h_out, M, N, K, group_size, ws, ws_bytes, sync, dtype, x_layout,
+                              gamma, eps, xnorm, xnorm_layout, nullptr, 0, nullptr);
+}
+
+// ... with the RMSNorm DEFERRED where the serving kernel offers it (gemv_batch_kernel.hpp): *rowsq_parts > 0 -- xnorm holds
+// FT(gamma * h_out) and rowsq[part][32] the partial sums of h_out^2, to be handed to dihip_prenorm_{gemm,swiglu}_rowsq;
+// *rowsq_parts == 0 -- xnorm is the finished norm (as dihip_fused_gemm_addto_norm)
+int dihip_fused_gemm_addto_prenorm(void* stream, int wbits, const void* x, const void* w_packed, const void* sz_packed,
+                                   const float* h_res, float* h_out, int M, int N, int K, int group_size, void* ws,
+                                   size_t ws_bytes, void* sync, int dtype, int x_layout, const void* gamma, float eps,
+                                   void* xnorm, int xnorm_layout, float* rowsq, size_t rowsq_bytes, int* rowsq_parts) {
+  DIHIP_REQUIRE(rowsq && rowsq_parts && reinterpret_cast<uintptr_t>(rowsq) % 16 == 0, DIHIP_PARAM_ERROR, "fused addto + prenorm: null / misaligned rowsq");
+  return gemm_addto_norm_impl(stream, wbits, x, w_packed, sz_packed, h_res, h_out, M, N, K, group_size, ws, ws_bytes, sync, dtype, x_layout,
+                              gamma, eps, xnorm, xnorm_layout, rowsq, rowsq_bytes, rowsq_parts);
+}
+
+size_t dihip_rowsq_bytes() { return (size_t)256 * 32 * sizeof(float); }  // one part per workgroup of a producer (<= one per CU)
+
+// can a prenorm GEMM (dual = 0) / SwiGLU pair (dual = 1) of this shape take deferred row norms?  (mirrors run_gemm's dispatch)
+int dihip_prenorm_rowsq_supported(int wbits, int M, int N, int K, int group_size, int dual, int dtype, int x_layout) {
+  static const bool on = !env_off("DIHIP_DEFER_RMSNORM");  // =0: never (A/B; callers then keep the norm launch)
+  if (!on || M <= 4 || M > 32 || dtype != DIHIP_BF16 || (wbits != 4 && wbits != 8) || !gemv_stream_enabled()) return 0;
+  const LowpDims d = lowp_dims(wbits, N, K, group_size);
+  if (K != d.Kp || !(d.group == 0 || d.group % d.KTILE == 0)) return 0;
+  if (x_layout == DIHIP_ACT_FRAG32) {
+    const KslicePlan kp = make_kslice_plan(wbits, M, N, K, group_size, dual != 0);
+    if (kp.ok) return 1;
+    const PanelPlan pp = make_panel_plan(wbits, M, N, K, group_size, dual != 0);
+    if (pp.ok) return pp.nslices > 1 ? 1 : 0;
+  }
+  return dual ? 0 : 1;  // gemv_batch_kernel: plain epilogue only
 }
 
 // LayerNormNoBeta of the f32 hidden rows into FT rows, on its own (the MoE layer feeds four consumers from it)
@@ -1362,6 +1453,13 @@ int dihip_rmsnorm_rows(void* stream, void* xnorm, const float* h, const void* ga
 int dihip_prenorm_gemm(void* stream, int wbits, const void* xnorm, int x_layout, const void* w_packed, const void* sz_packed,
                        const void* bias, void* y, int M, int N, int K, int group_size, int act, void* ws, size_t ws_bytes,
                        void* sync, int dtype) {
+  return dihip_prenorm_gemm_rowsq(stream, wbits, xnorm, x_layout, w_packed, sz_packed, bias, y, M, N, K, group_size, act, ws, ws_bytes, sync,
+                                  dtype, nullptr, 0, 0.f);
+}
+
+int dihip_prenorm_gemm_rowsq(void* stream, int wbits, const void* xnorm, int x_layout, const void* w_packed, const void* sz_packed,
+                             const void* bias, void* y, int M, int N, int K, int group_size, int act, void* ws, size_t ws_bytes,
+                             void* sync, int dtype, const float* rowsq, int rowsq_parts, float eps) {
   DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16, DIHIP_PARAM_ERROR, "fused path: bf16 or f16 activations");
   DIHIP_REQUIRE(x_layout == DIHIP_ACT_ROWMAJOR || x_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "prenorm gemm: bad x_layout");
   DIHIP_REQUIRE(sync != nullptr && xnorm && y, DIHIP_PARAM_ERROR, "prenorm gemm: null pointer");
@@ -1386,12 +1484,23 @@ int dihip_prenorm_gemm(void* stream, int wbits, const void* xnorm, int x_layout,
   c.ws = ws;
   c.ws_bytes = ws_bytes;
   c.sync = sync;
+  c.rowsq = rowsq_parts > 0 ? rowsq : nullptr;
+  c.rowsq_parts = rowsq_parts;
+  c.rowsq_eps = eps;
   return run_gemm(reinterpret_cast<hipStream_t>(stream), c);
 }
 
 int dihip_prenorm_swiglu(void* stream, int wbits, const void* xnorm, int x_layout, const void* wg_packed,
                          const void* szg_packed, const void* wu_packed, const void* szu_packed, void* y, int M, int N, int K,
                          int group_size, void* ws, size_t ws_bytes, void* sync, int dtype, int y_layout) {
+  return dihip_prenorm_swiglu_rowsq(stream, wbits, xnorm, x_layout, wg_packed, szg_packed, wu_packed, szu_packed, y, M, N, K, group_size, ws,
+                                    ws_bytes, sync, dtype, y_layout, nullptr, 0, 0.f);
+}
+
+int dihip_prenorm_swiglu_rowsq(void* stream, int wbits, const void* xnorm, int x_layout, const void* wg_packed,
+                               const void* szg_packed, const void* wu_packed, const void* szu_packed, void* y, int M, int N, int K,
+                               int group_size, void* ws, size_t ws_bytes, void* sync, int dtype, int y_layout, const float* rowsq,
+                               int rowsq_parts, float eps) {
   DIHIP_REQUIRE(dtype == DIHIP_BF16 || dtype == DIHIP_F16, DIHIP_PARAM_ERROR, "fused path: bf16 or f16 activations");
   DIHIP_REQUIRE(x_layout == DIHIP_ACT_ROWMAJOR || x_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "prenorm swiglu: bad x_layout");
   DIHIP_REQUIRE(y_layout == DIHIP_ACT_ROWMAJOR || y_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "prenorm swiglu: bad y_layout");
@@ -1420,6 +1529,9 @@ int dihip_prenorm_swiglu(void* stream, int wbits, const void* xnorm, int x_layou
   c.ws = ws;
   c.ws_bytes = ws_bytes;
   c.sync = sync;
+  c.rowsq = rowsq_parts > 0 ? rowsq : nullptr;
+  c.rowsq_parts = rowsq_parts;
+  c.rowsq_eps = eps;
   return run_gemm(reinterpret_cast<hipStream_t>(stream), c);
 }
 

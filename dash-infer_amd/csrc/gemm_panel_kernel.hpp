@@ -59,6 +59,14 @@ struct PanelArgs {
   float n_eps;
   void* n_out;          // FT, row-major [M, N] or FRAG32 (n_frag_mt = 1 / 2)
   int n_frag_mt;
+  // deferred RMSNorm (gemv_batch_kernel.hpp, GembArgs): producer side -- n_prenorm: n_out = FT(gamma * h_out) WITHOUT 1/rms and
+  // n_rowsq[part][32] partial sums of h_out^2 (split-K reduction: part = row block); consumer side (EPI_STD / EPI_SWIGLU) --
+  // rowsq != null: the accumulators of row m are multiplied by 1 / sqrt(Sum_p rowsq[p][m] / K + rowsq_eps)
+  int n_prenorm;
+  float* n_rowsq;
+  const float* rowsq;
+  int rowsq_parts;
+  float rowsq_eps;
   unsigned long long* trace;  // diagnostics (dihip_debug_set_trace; K-slice kernel): [workgroup][8 waves][8] wall-clock stamps, or null
 };
 
@@ -274,12 +282,63 @@ template <int FT, int EPI>
 __global__ __launch_bounds__(256) void gemm_panel_reduce_kernel(const PanelArgs a, int mt_tiles) {
   constexpr int DUAL = EPI == EPI_SWIGLU ? 2 : 1;
   const size_t total = (size_t)a.M * a.N;
+  // deferred RMSNorm, consumer side: 1 / rms per row from the producer's partial sums.  A workgroup that makes one pass over 256
+  // consecutive elements touches at most two rows (N >= 256): 128 threads per row add the parts (thread i: parts i, i + 128,
+  // ...), wave sums in DPP order, the two waves of a row in order -- one short round of loads.  Otherwise: all 32 rows, thread
+  // (row, part) with 8 parts in LDS.  Every workgroup adds a row's parts in the same order.
+  __shared__ float rsp[EPI != EPI_ADDTO ? 8 : 1][32];
+  __shared__ float rstd_l[EPI != EPI_ADDTO ? 32 : 1];
+  bool rs_on = false;
+  if constexpr (EPI != EPI_ADDTO) {
+    rs_on = a.rowsq != nullptr;
+    if (rs_on) {
+      const bool one_pass = (size_t)gridDim.x * 256 >= total && a.N >= 256 && a.rowsq_parts <= 256;
+      if (one_pass) {
+        const size_t e0 = (size_t)blockIdx.x * 256;
+        const int m_lo = (int)(e0 / a.N);
+        const int row = min(m_lo + (int)(threadIdx.x >> 7), 31), i = threadIdx.x & 127;
+        const float p0 = i < a.rowsq_parts ? a.rowsq[(size_t)i * 32 + row] : 0.f;
+        const float p1 = i + 128 < a.rowsq_parts ? a.rowsq[(size_t)(i + 128) * 32 + row] : 0.f;
+        const float t = wave_sum(p0 + p1);
+        if ((threadIdx.x & 63) == 0) rsp[0][threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x < 2) rstd_l[min(m_lo + (int)threadIdx.x, 31)] = 1.f / sqrtf((rsp[0][2 * threadIdx.x] + rsp[0][2 * threadIdx.x + 1]) / (float)a.K + a.rowsq_eps);
+        __syncthreads();
+      } else {
+        const int m = threadIdx.x & 31, part = threadIdx.x >> 5;
+        float t = 0.f;
+        for (int p0 = part; p0 < a.rowsq_parts; p0 += 8 * 32) {
+          float r[32];
+#pragma unroll
+          for (int j = 0; j < 32; ++j) r[j] = p0 + j * 8 < a.rowsq_parts ? a.rowsq[(size_t)(p0 + j * 8) * 32 + m] : 0.f;
+#pragma unroll
+          for (int j = 0; j < 32; ++j) t += r[j];
+        }
+        rsp[part][m] = t;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+          float tt = 0.f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) tt += rsp[q][threadIdx.x];
+          rstd_l[threadIdx.x] = 1.f / sqrtf(tt / (float)a.K + a.rowsq_eps);
+        }
+        __syncthreads();
+      }
+    }
+  }
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const int m = (int)(e / a.N), n = (int)(e - (size_t)m * a.N);
     float v = 0.f, v2 = 0.f;
     for (int s = 0; s < a.nslices; ++s) {
       v += a.slab[((size_t)s * DUAL) * total + e];
       if constexpr (DUAL == 2) v2 += a.slab[((size_t)s * DUAL + 1) * total + e];
+    }
+    if constexpr (EPI != EPI_ADDTO) {
+      if (rs_on) {
+        const float r_ = rstd_l[m];
+        v *= r_;
+        v2 *= r_;
+      }
     }
     panel_epilogue<FT, EPI>(a, m, n, v, v2, mt_tiles);
   }

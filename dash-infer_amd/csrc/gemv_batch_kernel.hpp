@@ -50,7 +50,23 @@ struct GembArgs {
   int upb;      // units (column tiles; SwiGLU: gate/up tile pairs) per workgroup
   int xfrag;    // x is in the FRAG32 activation layout (act_frag_index) instead of row-major [M, ldx]
   int yfrag;    // y (EPI_STD / EPI_SWIGLU) is written in the FRAG32 layout
+  // Deferred RMSNorm (round 5; dihip_fused_gemm_addto_prenorm / dihip_prenorm_gemm_rowsq): the 1/rms of a row is a scalar that
+  // commutes with the GEMM, so the LayerNormNoBeta between a residual GEMM and the next GEMM needs no launch of its own --
+  //   producer (EPI_ADDTO, n_out != null): next to h_out the epilogue writes n_out = FT(gamma * h_out) -- no 1/rms -- in the
+  //     consumer's layout, and n_rowsq[blockIdx.x][32] = this workgroup's share of Sum_n h_out[m][n]^2 (fixed order);
+  //   consumer (EPI_STD, rowsq != null): every accumulator of row m is multiplied by 1 / sqrt(Sum_p rowsq[p][m] / K + eps)
+  //     before alpha / bias -- parts summed in a fixed order, every workgroup the same way.
+  // The rounding point moves (the reference rounds (gamma * x) * rstd to FT, here gamma * x is rounded and rstd applied to the
+  // f32 accumulator): same relative precision, not the same bits -- parity is asserted against the oracle's tolerance.
+  const void* n_gamma;
+  void* n_out;
+  int n_frag_mt;
+  float* n_rowsq;
+  const float* rowsq;
+  int rowsq_parts;
+  float rowsq_eps;
 };
+constexpr int GEMB_MAXU = 8;  // units per workgroup the producer form keeps row partials for
 
 
 
@@ -69,6 +85,9 @@ __global__ __launch_bounds__(GEMB_THREADS) void gemv_batch_kernel(const GembArgs
   constexpr int NCHUNK = DUAL == 2 ? NT : 1;
 
   __shared__ __attribute__((aligned(16))) float red[CU * GEMB_WAVES * 16 * MT * 16];
+  __shared__ float rsq[EPI == EPI_ADDTO ? GEMB_MAXU : 1][32];  // producer: Sum h^2 per (unit of this workgroup, row)
+  __shared__ float rsp[EPI == EPI_STD ? GEMB_THREADS / 32 : 1][32];  // consumer: partial sums of the producer's parts
+  __shared__ float rstd_l[EPI == EPI_STD ? 32 : 1];                  // consumer: 1 / rms per row
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,6 +96,25 @@ __global__ __launch_bounds__(GEMB_THREADS) void gemv_batch_kernel(const GembArgs
   const int u_lo = blockIdx.x * a.upb;
   const int u_hi = min(a.NTILES, u_lo + a.upb);
   const int ngroups = (u_hi - u_lo + NT - 1) / NT;
+
+  // deferred RMSNorm, consumer side: 1 / rms of every row from the producer's per-workgroup partial sums -- thread (row, part)
+  // adds its parts in a fixed order, 16 parts meet in LDS.  The loads go out BEHIND the first k-tile's loads (loads return in
+  // order, and the parts come from other XCDs: requested first they would hold the weights back)
+  float rs_t[16];
+  bool rs_on = false;
+  if constexpr (EPI == EPI_STD) rs_on = a.rowsq != nullptr;
+  auto rs_request = [&]() {
+    if constexpr (EPI == EPI_STD) {
+      if (rs_on) {
+        const int m = tid & 31, part = tid >> 5;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int pj = part + j * (GEMB_THREADS / 32);
+          rs_t[j] = pj < a.rowsq_parts ? a.rowsq[(size_t)pj * 32 + m] : 0.f;
+        }
+      }
+    }
+  };
 
   // K split in whole quantisation groups
   const bool subc = QUANT && a.ktpg < a.KT;
@@ -155,8 +193,21 @@ __global__ __launch_bounds__(GEMB_THREADS) void gemv_batch_kernel(const GembArgs
   const u32x4_t ones = FT == DIHIP_BF16 ? u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}
                                         : u32x4_t{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
 
+  // consumer: this thread's parts, added in order, to LDS (once per thread, at its first flush)
+  auto rs_stage = [&]() {
+    if constexpr (EPI == EPI_STD) {
+      if (rs_on) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += rs_t[j];
+        rsp[tid >> 5][tid & 31] = t;
+      }
+    }
+  };
+  bool rs_first = true;
   // ---- combine the 8 k-slices of a finished unit group through LDS (fixed order) + epilogue ----------
   auto flush = [&](int grp) {
+    if (rs_first) rs_stage();  // (the parts have landed long ago; their sums meet behind the first barrier below)
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) {
 #pragma unroll
@@ -168,6 +219,18 @@ __global__ __launch_bounds__(GEMB_THREADS) void gemv_batch_kernel(const GembArgs
           for (int r = 0; r < 4; ++r) red[((u * GEMB_WAVES + wave) * (16 * MT) + mt * 16 + kb * 4 + r) * 16 + ni] = tot[j][v][mt][r];
       }
       __syncthreads();
+      if constexpr (EPI == EPI_STD) {
+        if (rs_on && rs_first) {  // (every wave of the workgroup flushes the same number of times: uniform)
+          if (tid < 32) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < GEMB_THREADS / 32; ++q) t += rsp[q][tid];
+            rstd_l[tid] = 1.f / sqrtf(t / (float)a.K + a.rowsq_eps);
+          }
+          __syncthreads();
+        }
+        rs_first = false;
+      }
       const int per = a.M * 16;
       const int count = DUAL == 2 ? per : per * NT;
       for (int e = tid; e < count; e += GEMB_THREADS) {
@@ -176,12 +239,16 @@ __global__ __launch_bounds__(GEMB_THREADS) void gemv_batch_kernel(const GembArgs
         const int col = rem & 15, m = rem >> 4;
         const int tile = u_lo + grp * NT + (DUAL == 2 ? c : u);
         const int n = tile * 16 + col;
-        if (tile >= u_hi || n >= a.N) continue;
+        const bool valid = tile < u_hi && n < a.N;
+        bool prep = false;
+        if constexpr (EPI == EPI_ADDTO) prep = a.n_out != nullptr;
+        if (!valid && !prep) continue;
         float v = 0.f, v2 = 0.f;
         for (int s = 0; s < GEMB_WAVES; ++s) v += red[((u * GEMB_WAVES + s) * (16 * MT) + m) * 16 + col];
         if constexpr (DUAL == 2)
           for (int s = 0; s < GEMB_WAVES; ++s) v2 += red[((GEMB_WAVES + s) * (16 * MT) + m) * 16 + col];
         if constexpr (EPI == EPI_STD) {
+          if (rs_on) v *= rstd_l[m];
           v = __fmul_rn(a.alpha, v);
           if (a.bias) v = __fadd_rn(v, load_ft<FT>(a.bias, n));
           v = apply_act(v, a.act);
@@ -190,13 +257,38 @@ __global__ __launch_bounds__(GEMB_THREADS) void gemv_batch_kernel(const GembArgs
         } else if constexpr (EPI == EPI_SWIGLU) {
           store_ft<FT>(a.y, a.yfrag ? act_frag_index(m, n, MT) : (size_t)m * a.ldy + n, (v / (1.f + expf(-v))) * v2);
         } else {
-          const float base = a.h_res ? a.h_res[(size_t)m * a.N + n] : 0.f;
-          a.h_out[(size_t)m * a.N + n] = __fadd_rn(base, __fmul_rn(a.alpha, v));
+          float hv = 0.f;
+          if (valid) {
+            const float base = a.h_res ? a.h_res[(size_t)m * a.N + n] : 0.f;
+            hv = __fadd_rn(base, __fmul_rn(a.alpha, v));
+            a.h_out[(size_t)m * a.N + n] = hv;
+          }
+          if (prep) {  // (whole 16-lane rows of one (unit, row) reach this point together: count is a multiple of 16)
+            if (valid)
+              store_ft<FT>(a.n_out, a.n_frag_mt ? act_frag_index(m, n, a.n_frag_mt) : (size_t)m * a.N + n, load_ft<FT>(a.n_gamma, n) * hv);
+            float sq = hv * hv;
+            sq += dpp_f32<0xB1>(sq);
+            sq += dpp_f32<0x4E>(sq);
+            sq += dpp_f32<0x141>(sq);
+            sq += dpp_f32<0x140>(sq);
+            const int lu = grp * NT + u;
+            if (col == 0 && lu < GEMB_MAXU) rsq[lu][m] = sq;
+          }
         }
       }
       __syncthreads();
     }
     reset_acc();
+  };
+  // producer: this workgroup's row partials, units added in order
+  auto finish = [&]() {
+    if constexpr (EPI == EPI_ADDTO) {
+      if (a.n_rowsq && tid < 32) {
+        float t = 0.f;
+        for (int lu = 0; lu < u_hi - u_lo; ++lu) t += rsq[lu][tid];
+        a.n_rowsq[(size_t)blockIdx.x * 32 + tid] = tid < a.M ? t : 0.f;
+      }
+    }
   };
 
   auto run_kt = [&](const KtRegs& r, int grp, int kt) {
@@ -271,7 +363,9 @@ __global__ __launch_bounds__(GEMB_THREADS) void gemv_batch_kernel(const GembArgs
   };
 
   if (nk == 0) {  // more waves than K groups: this wave only takes part in the combines
+    rs_request();
     for (int grp = 0; grp < ngroups; ++grp) flush(grp);
+    finish();
     return;
   }
   const int total = ngroups * nk;
@@ -286,6 +380,7 @@ __global__ __launch_bounds__(GEMB_THREADS) void gemv_batch_kernel(const GembArgs
   KtRegs ra, rb;
   load_kt(ra, lg, lk);
   DIHIP_GEMB_ADV(lg, lk);
+  rs_request();
   int it = 0;
   for (; it + 1 < total; it += 2) {
     load_kt(rb, min(lg, ngroups - 1), lk);
@@ -299,6 +394,7 @@ __global__ __launch_bounds__(GEMB_THREADS) void gemv_batch_kernel(const GembArgs
   }
   if (it < total) run_kt(ra, rg, rk);
 #undef DIHIP_GEMB_ADV
+  finish();
 }
 
 template <int WBITS, int FT, int MT, int NT, int EPI, int GPT>

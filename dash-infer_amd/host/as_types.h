@@ -164,6 +164,15 @@ class DeviceContext {
 struct ActLayoutPref {
   int wbits = 0, n = 0, k = 0, group = -1, dual = 0, bf16 = 1;
 };
+// Deferred RMSNorm (include/dashinfer_hip.h, "with the RMSNorm DEFERRED"): what the producer of a pre-normalised tensor left for
+// its consumer in this step -- parts > 0: the tensor holds FT(gamma * h), `rowsq` the partial sums of h^2, and the consumer scales
+// its accumulators by 1 / rms; parts == 0: the tensor is the finished norm.  Written at the producer's Forward, read at the
+// consumer's Forward of the same step (list order).
+struct RowNormState {
+  const float* rowsq = nullptr;
+  int parts = 0;
+  float eps = 0.f;
+};
 
 class HIPContext : public DeviceContext {
  public:
@@ -192,6 +201,11 @@ class HIPContext : public DeviceContext {
   // Which operator produces a tensor of the fused list (registered at Init, in list order): the o-projection finds the attention
   // and qkv operators in front of it and, for one request on the 16-bit cache, runs all three as ONE launch
   // (dihip_decode_attn_block; host/fused_ops_hip.cpp DihipGemmAddTo).  Opaque here: the operators cast to their own interfaces.
+  void SetRowNorm(const std::string& tensor, const RowNormState& r) const { row_norm_[tensor] = r; }
+  RowNormState RowNorm(const std::string& tensor) const {
+    auto it = row_norm_.find(tensor);
+    return it == row_norm_.end() ? RowNormState{} : it->second;
+  }
   void RegisterProducer(const std::string& tensor, void* op) const { producer_[tensor] = op; }
   void* Producer(const std::string& tensor) const {
     auto it = producer_.find(tensor);
@@ -205,6 +219,7 @@ class HIPContext : public DeviceContext {
   mutable std::map<std::string, int> act_layout_;
   mutable bool lens_on_device_ = false;
   mutable std::map<std::string, void*> producer_;
+  mutable std::map<std::string, RowNormState> row_norm_;
 };
 
 // VirtualCache (csrc/runtime/cache/virtual_cache.h:93-139): the per-request paged cache of all layers, as the span

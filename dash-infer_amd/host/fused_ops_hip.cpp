@@ -259,9 +259,10 @@ class DihipNormGemmOp : public AsOperator, public AttnBlockQkvPart {
     hipStream_t s = stream_of(ctx_);
     if (in_names_.size() > 1 && norm_fuse_active(ctx_, rt, m_)) {
       AsTensor* xn = tensor_map_->at(in_names_[1]).get();
-      return FromDihip(dihip_prenorm_gemm(s, w_.wbits, xn->GetDataPtr(), hip_ctx(ctx_).ActLayout(in_names_[1]), w_.w->GetDataPtr(),
-                                          w_.sz->GetDataPtr(), bias, y->GetDataPtr(), m_, w_.n, w_.k, w_.group, act_, wsp->GetDataPtr(),
-                                          wsp->GetSizeInByte(), sync_->GetDataPtr(), DihipDtype(w_.ft)));
+      const RowNormState rn = hip_ctx(ctx_).RowNorm(in_names_[1]);  // (parts == 0: the finished norm)
+      return FromDihip(dihip_prenorm_gemm_rowsq(s, w_.wbits, xn->GetDataPtr(), hip_ctx(ctx_).ActLayout(in_names_[1]), w_.w->GetDataPtr(),
+                                                w_.sz->GetDataPtr(), bias, y->GetDataPtr(), m_, w_.n, w_.k, w_.group, act_, wsp->GetDataPtr(),
+                                                wsp->GetSizeInByte(), sync_->GetDataPtr(), DihipDtype(w_.ft), rn.rowsq, rn.parts, rn.eps));
     }
     return FromDihip(dihip_fused_norm_gemm(s, w_.wbits, (const float*)h->GetDataPtr(), weights_[0]->GetDataPtr(), eps_, w_.w->GetDataPtr(),
                                            w_.sz->GetDataPtr(), bias, y->GetDataPtr(), m_, w_.n, w_.k, w_.group, act_, wsp->GetDataPtr(),
@@ -323,9 +324,11 @@ class DihipNormSwiGLUOp : public AsOperator {
     hipStream_t s = stream_of(ctx_);
     if (in_names_.size() > 1 && norm_fuse_active(ctx_, rt, m_)) {
       AsTensor* xn = tensor_map_->at(in_names_[1]).get();
-      return FromDihip(dihip_prenorm_swiglu(s, g_.wbits, xn->GetDataPtr(), hip_ctx(ctx_).ActLayout(in_names_[1]), g_.w->GetDataPtr(),
-                                            g_.sz->GetDataPtr(), u_.w->GetDataPtr(), u_.sz->GetDataPtr(), y->GetDataPtr(), m_, g_.n, g_.k,
-                                            g_.group, wsp->GetDataPtr(), wsp->GetSizeInByte(), sync_->GetDataPtr(), DihipDtype(g_.ft), y_layout_));
+      const RowNormState rn = hip_ctx(ctx_).RowNorm(in_names_[1]);
+      return FromDihip(dihip_prenorm_swiglu_rowsq(s, g_.wbits, xn->GetDataPtr(), hip_ctx(ctx_).ActLayout(in_names_[1]), g_.w->GetDataPtr(),
+                                                  g_.sz->GetDataPtr(), u_.w->GetDataPtr(), u_.sz->GetDataPtr(), y->GetDataPtr(), m_, g_.n, g_.k,
+                                                  g_.group, wsp->GetDataPtr(), wsp->GetSizeInByte(), sync_->GetDataPtr(), DihipDtype(g_.ft), y_layout_,
+                                                  rn.rowsq, rn.parts, rn.eps));
     }
     return FromDihip(dihip_fused_norm_swiglu_ex(s, g_.wbits, (const float*)h->GetDataPtr(), weights_[0]->GetDataPtr(), eps_, g_.w->GetDataPtr(),
                                                 g_.sz->GetDataPtr(), u_.w->GetDataPtr(), u_.sz->GetDataPtr(), y->GetDataPtr(), m_, g_.n, g_.k,
@@ -363,6 +366,8 @@ class DihipGemmAddToOp : public AsOperator {
       eps_ = *(const float*)e;
       if ((int)weights_[3]->GetShape()[0] != w_.n || weights_[3]->GetDataType() != w_.ft) return AsStatus::ALLSPARK_PARAM_ERROR;
       tensor_map_->at(out_names_[1])->SetDataType(w_.ft);
+      rowsq_ = zeroed(op_name_ + ".rowsq", dihip_rowsq_bytes(), stream_of(&ctx));
+      if (!rowsq_) return AsStatus::ALLSPARK_MEMORY_ERROR;
     }
     sync_ = zeroed(op_name_ + ".sync", dihip_gemm_lowp_sync_bytes(), stream_of(&ctx));
     if (!sync_) return AsStatus::ALLSPARK_MEMORY_ERROR;
@@ -408,6 +413,10 @@ class DihipGemmAddToOp : public AsOperator {
       hip_ctx(ctx_).SetActLayout(out_names_[1], xn_layout_);
       const size_t bytes = frag ? dihip_act_frag_bytes(m_, w_.n) : (size_t)m_ * w_.n * SizeofType(w_.ft);
       AS_CHECK_STATUS(ensure_capacity_zeroed(xn, bytes, std::move(s), stream_of(ctx_)));
+      // deferred RMSNorm: when the kernel that will serve the consumer takes row partials, 16-bit cache (DecodeSession.defer_ln1 / defer_ln2)
+      const ActLayoutPref* cp = hip_ctx(ctx_).LayoutPref(out_names_[1]);
+      defer_now_ = norm_now_ && cp && cp->bf16 && w_.ft == BFLOAT16 && ctx_->GetCacheMode() == AsCacheMode::AsCacheDefault &&
+                   dihip_prenorm_rowsq_supported(cp->wbits, m_, cp->n, cp->k, cp->group, cp->dual, DIHIP_BF16, xn_layout_) != 0;
     }
     block_now_ = BlockEligible(rt);
     if (blk_attn_ && blk_qkv_) {
@@ -449,8 +458,19 @@ class DihipGemmAddToOp : public AsOperator {
                                                a.kv_mode, DihipDtype(w_.ft), a.alpha, a.ws->GetDataPtr(), a.ws->GetSizeInByte(), sy->GetDataPtr(),
                                                sy->GetSizeInByte()));
     }
+    if (norm_now_ && defer_now_) {
+      AsTensor* xn = tensor_map_->at(out_names_[1]).get();
+      int parts = 0;
+      const int st = dihip_fused_gemm_addto_prenorm(s, w_.wbits, x->GetDataPtr(), w_.w->GetDataPtr(), w_.sz->GetDataPtr(), h_res, (float*)y->GetDataPtr(),
+                                                    m_, w_.n, w_.k, w_.group, wsp->GetDataPtr(), wsp->GetSizeInByte(), sync_->GetDataPtr(),
+                                                    DihipDtype(w_.ft), x_layout, weights_[3]->GetDataPtr(), eps_, xn->GetDataPtr(), xn_layout_,
+                                                    (float*)rowsq_->GetDataPtr(), rowsq_->GetSizeInByte(), &parts);
+      hip_ctx(ctx_).SetRowNorm(out_names_[1], RowNormState{(const float*)rowsq_->GetDataPtr(), parts, eps_});
+      return FromDihip(st);
+    }
     if (norm_now_) {
       AsTensor* xn = tensor_map_->at(out_names_[1]).get();
+      hip_ctx(ctx_).SetRowNorm(out_names_[1], RowNormState{});
       return FromDihip(dihip_fused_gemm_addto_norm(s, w_.wbits, x->GetDataPtr(), w_.w->GetDataPtr(), w_.sz->GetDataPtr(), h_res,
                                                    (float*)y->GetDataPtr(), m_, w_.n, w_.k, w_.group, wsp->GetDataPtr(), wsp->GetSizeInByte(),
                                                    sync_->GetDataPtr(), DihipDtype(w_.ft), x_layout, weights_[3]->GetDataPtr(), eps_,
@@ -464,8 +484,9 @@ class DihipGemmAddToOp : public AsOperator {
  private:
   PackedLowp w_;
   float eps_ = 1e-6f;
-  bool has_norm_ = false, norm_now_ = false, block_now_ = false;
+  bool has_norm_ = false, norm_now_ = false, block_now_ = false, defer_now_ = false;
   int m_ = 0, xn_layout_ = DIHIP_ACT_ROWMAJOR;
+  std::unique_ptr<AsTensor> rowsq_;
   AttnBlockAttnPart* blk_attn_ = nullptr;
   AttnBlockQkvPart* blk_qkv_ = nullptr;
   std::unique_ptr<AsTensor> sync_;

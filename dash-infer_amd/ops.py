@@ -292,6 +292,48 @@ def prenorm_swiglu(xnorm, pg, pu, scratch, M, x_layout=ACT_ROWMAJOR, out=None, y
     return out
 
 
+# -- the same three with the RMSNorm DEFERRED (include/dashinfer_hip.h, "with the RMSNorm DEFERRED"): the producer leaves
+# FT(gamma * h) and per-workgroup partial sums of h^2, the consumer scales its accumulators by 1 / rms
+def rowsq_buffer(device):
+    return torch.zeros(int(lib().dihip_rowsq_bytes()) // 4, dtype=torch.float32, device=device)
+
+
+def prenorm_rowsq_supported(pw, M, dual=False, x_layout=ACT_ROWMAJOR):
+    return bool(lib().dihip_prenorm_rowsq_supported(pw.wbits, int(M), pw.N, pw.K, pw.group, 1 if dual else 0, dt_code(pw.dtype), int(x_layout)))
+
+
+def fused_gemm_addto_prenorm(x, pw, h_res, scratch, gamma, eps, xnorm, rowsq, out=None, x_layout=ACT_ROWMAJOR, xnorm_layout=ACT_ROWMAJOR, M=None):
+    """-> (h_out, parts): parts > 0 -- xnorm = FT(gamma * h_out), rowsq[part][32] partial sums of h_out^2; parts == 0 -- xnorm is
+    the finished norm (the kernel that served the call does not offer the deferred form)"""
+    import ctypes as _C
+    M = x.shape[0] if M is None else M
+    h_out = out if out is not None else torch.empty(M, pw.N, dtype=torch.float32, device=x.device)
+    parts = _C.c_int(0)
+    check(lib().dihip_fused_gemm_addto_prenorm(cur_stream(), pw.wbits, ptr(x), ptr(pw.w), ptr(pw.sz), ptr(h_res), ptr(h_out),
+                                               M, pw.N, pw.K, pw.group, ptr(scratch.ws), scratch.ws_bytes, ptr(scratch.sync),
+                                               dt_code(x), int(x_layout), ptr(gamma), float(eps), ptr(xnorm), int(xnorm_layout),
+                                               ptr(rowsq), rowsq.numel() * 4, _C.addressof(parts)), "dihip_fused_gemm_addto_prenorm")
+    return h_out, int(parts.value)
+
+
+def prenorm_gemm_rowsq(xnorm, pw, bias, scratch, M, rowsq, parts, eps, x_layout=ACT_ROWMAJOR, act=None, out=None):
+    y = out if out is not None else torch.empty(M, pw.N, dtype=pw.dtype, device=xnorm.device)
+    check(lib().dihip_prenorm_gemm_rowsq(cur_stream(), pw.wbits, ptr(xnorm), int(x_layout), ptr(pw.w), ptr(pw.sz), ptr(bias), ptr(y),
+                                         M, pw.N, pw.K, pw.group, capi.ACT[act], ptr(scratch.ws), scratch.ws_bytes, ptr(scratch.sync),
+                                         dt_code(pw.dtype), ptr(rowsq), int(parts), float(eps)), "dihip_prenorm_gemm_rowsq")
+    return y
+
+
+def prenorm_swiglu_rowsq(xnorm, pg, pu, scratch, M, rowsq, parts, eps, x_layout=ACT_ROWMAJOR, out=None, y_layout=ACT_ROWMAJOR):
+    if out is None:
+        out = (torch.zeros(act_frag_numel(M, pg.N), dtype=pg.dtype, device=xnorm.device) if y_layout == ACT_FRAG32
+               else torch.empty(M, pg.N, dtype=pg.dtype, device=xnorm.device))
+    check(lib().dihip_prenorm_swiglu_rowsq(cur_stream(), pg.wbits, ptr(xnorm), int(x_layout), ptr(pg.w), ptr(pg.sz), ptr(pu.w), ptr(pu.sz),
+                                           ptr(out), M, pg.N, pg.K, pg.group, ptr(scratch.ws), scratch.ws_bytes, ptr(scratch.sync),
+                                           dt_code(pg.dtype), int(y_layout), ptr(rowsq), int(parts), float(eps)), "dihip_prenorm_swiglu_rowsq")
+    return out
+
+
 def lm_head(h, gamma, eps, pw, scratch, out=None):
     M = h.shape[0]
     logits = out if out is not None else torch.empty(M, pw.N, dtype=torch.float32, device=h.device)

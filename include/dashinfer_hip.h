@@ -165,6 +165,33 @@ int dihip_prenorm_swiglu(void* stream, int wbits, const void* xnorm, int x_layou
                          const void* szg_packed, const void* wu_packed, const void* szu_packed, void* y,
                          int M, int N, int K, int group_size, void* ws, size_t ws_bytes, void* sync,
                          int dtype, int y_layout);
+/* ... with the RMSNorm DEFERRED (round 5): 1 / rms of a row is a scalar and commutes with the GEMM, so the LayerNormNoBeta between a
+ * residual GEMM and the next GEMM (qwen_v15.py:296-361) needs neither a launch nor a pass of its own --
+ *   producer  dihip_fused_gemm_addto_prenorm:  h_out = h_res + x.W;  xnorm = FT(gamma * h_out) (NO 1 / rms);
+ *             rowsq[part][32] = partial sums of h_out[m][.]^2, one part per workgroup, *rowsq_parts of them (fixed order);
+ *             *rowsq_parts == 0: the serving kernel does not offer it and xnorm is the FINISHED norm (dihip_fused_gemm_addto_norm);
+ *   consumer  dihip_prenorm_gemm_rowsq / dihip_prenorm_swiglu_rowsq:  every accumulator of row m is multiplied by
+ *             1 / sqrt(Sum_p rowsq[p][m] / K + eps) before alpha / bias / SwiGLU (rowsq_parts == 0: plain dihip_prenorm_*).
+ * The reference rounds (gamma * x) * rstd to FT; here gamma * x is rounded and rstd is applied to the f32 accumulator: the
+ * same relative precision, NOT the same bits (tests: against the oracle's tolerance, and the full-depth parity cases).
+ * bf16, 4 < M <= 32.  dihip_prenorm_rowsq_supported(...): does the kernel that will serve the consumer take deferred rows
+ * (dual = 1: the SwiGLU pair)?  Ask BEFORE calling the producer; rowsq: dihip_rowsq_bytes() bytes, 16-byte aligned.
+ * DIHIP_DEFER_RMSNORM=0: never supported (A/B). */
+int dihip_fused_gemm_addto_prenorm(void* stream, int wbits, const void* x, const void* w_packed,
+                                   const void* sz_packed, const float* h_res, float* h_out, int M, int N,
+                                   int K, int group_size, void* ws, size_t ws_bytes, void* sync, int dtype,
+                                   int x_layout, const void* gamma, float eps, void* xnorm, int xnorm_layout,
+                                   float* rowsq, size_t rowsq_bytes, int* rowsq_parts);
+int dihip_prenorm_gemm_rowsq(void* stream, int wbits, const void* xnorm, int x_layout, const void* w_packed,
+                             const void* sz_packed, const void* bias, void* y, int M, int N, int K,
+                             int group_size, int act, void* ws, size_t ws_bytes, void* sync, int dtype,
+                             const float* rowsq, int rowsq_parts, float eps);
+int dihip_prenorm_swiglu_rowsq(void* stream, int wbits, const void* xnorm, int x_layout, const void* wg_packed,
+                               const void* szg_packed, const void* wu_packed, const void* szu_packed, void* y,
+                               int M, int N, int K, int group_size, void* ws, size_t ws_bytes, void* sync,
+                               int dtype, int y_layout, const float* rowsq, int rowsq_parts, float eps);
+int dihip_prenorm_rowsq_supported(int wbits, int M, int N, int K, int group_size, int dual, int dtype, int x_layout);
+size_t dihip_rowsq_bytes(void);
 
 /* ---------------------------------------------------------------------------------------------
  * 1b. Mixture-of-experts decode path with weight-only experts (BASELINE configs[4]).
