@@ -42,6 +42,7 @@ _SIGS = {
     "dihip_prenorm_swiglu_rowsq": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp, i32, i32, vp, i32, f32]),
     "dihip_prenorm_rowsq_supported": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
     "dihip_rowsq_bytes": (sz, []),
+    "dihip_gemm_prefill_tail_parts": (i32, [i32, i32, i32, i32, i32, i32]),
     "dihip_gemm_lowp_prefers_frag": (i32, [i32, i32, i32, i32, i32, i32]),
     "dihip_moe_route": (i32, [vp, vp, i32, i32, i32, vp, vp, i32]),
     "dihip_rmsnorm_rows": (i32, [vp, vp, vp, vp, f32, i32, i32, i32]),

@@ -486,6 +486,41 @@ static PanelPlan make_panel_plan(int wbits, int M, int N, int K, int group_size,
 }
 
 // ---- batched decode, FRAG32 activations, register-resident K-slices (gemm_kslice_kernel.hpp) ---------------------
+// Context-phase GEMM, tail split (gemm_prefill_kernel.hpp, PrefillArgs::tail_cb): when the grid of 128 x 256 tiles ends in a
+// round that fills at most half the chip, the column blocks of that round are split in K instead -- `ksplit` workgroups per
+// tile, whole quantisation groups each, all of them within one round -- and a reduction launch adds the parts.  Qwen2-7B at
+// 2048 rows: qkv 288 tiles -> 256 + 32 x 7 parts (176 -> ~115 us), gate / up 2368 -> 2304 + 64 x 4.  DIHIP_PREFILL_TAIL_SPLIT=0: off.
+struct PrefillTail {
+  int col_blocks, mblocks, tail_cb, ksplit;
+  size_t slab_bytes;
+};
+static PrefillTail prefill_tail_plan(int wbits, int M, int N, int K, int group_size, bool dual) {
+  PrefillTail t{};
+  const LowpDims d = lowp_dims(wbits, N, K, group_size);
+  const int tpb = dual ? PF_WN * PF_CW / 2 : PF_WN * PF_CW;
+  t.col_blocks = (d.NTILES + tpb - 1) / tpb;
+  t.mblocks = (M + PF_BM - 1) / PF_BM;
+  t.tail_cb = t.col_blocks;
+  t.ksplit = 1;
+  static const bool on = !env_off("DIHIP_PREFILL_TAIL_SPLIT");
+  int ncu = cached_num_cus();
+  if (ncu <= 0) ncu = 256;
+  const int blocks = t.col_blocks * t.mblocks, rem = blocks % ncu;
+  if (!on || M < 64 || (wbits != 4 && wbits != 8) || blocks <= ncu || rem == 0 || rem > ncu / 2) return t;
+  const int tcb = (rem + t.mblocks - 1) / t.mblocks, tiles = tcb * t.mblocks;
+  if (tiles > ncu / 2 || tcb >= t.col_blocks) return t;
+  const int ktpg = d.group ? d.group / d.KTILE : d.KT;
+  const int units = d.group ? d.KT / std::max(ktpg, 1) : d.KT;  // K parts hold whole groups (per-channel: whole k-tiles)
+  int best = 1;
+  for (int ks = 2; ks <= 8; ++ks)
+    if (units % ks == 0 && tiles * ks <= ncu) best = ks;
+  if (best == 1) return t;
+  t.tail_cb = t.col_blocks - tcb;
+  t.ksplit = best;
+  t.slab_bytes = (size_t)tiles * best * PF_BM * 256 * sizeof(float);
+  return t;
+}
+
 struct KslicePlan {
   bool ok;
   int groups, nslices, waves, nunits;
@@ -879,7 +914,16 @@ static int run_gemm(hipStream_t stream, const GemmCall& c) {
     g.ktpg = d.group ? d.group / d.KTILE : (1 << 28);
     const int tiles_per_block = dual ? PF_WN * PF_CW / 2 : PF_WN * PF_CW;
     g.col_blocks = (d.NTILES + tiles_per_block - 1) / tiles_per_block;
-    const int blocks = g.col_blocks * ((c.M + PF_BM - 1) / PF_BM);
+    g.tail_cb = g.col_blocks;
+    g.ksplit = 1;
+    int blocks = g.col_blocks * ((c.M + PF_BM - 1) / PF_BM);
+    const PrefillTail pt = prefill_tail_plan(c.wbits, c.M, c.N, c.K, c.group_size, dual);
+    if (pt.ksplit > 1 && c.ws && c.ws_bytes >= pt.slab_bytes && reinterpret_cast<uintptr_t>(c.ws) % 16 == 0) {
+      g.tail_cb = pt.tail_cb;
+      g.ksplit = pt.ksplit;
+      g.slab = reinterpret_cast<float*>(c.ws);
+      blocks = pt.tail_cb * pt.mblocks + (pt.col_blocks - pt.tail_cb) * pt.mblocks * pt.ksplit;
+    }
     g.trace = debug_trace_buffer((size_t)blocks * PF_WAVES * 4 * 8 * sizeof(unsigned long long));
     const bool gpt = g.ktpg == 1;
     hipError_t e = hipErrorInvalidValue;
@@ -1098,12 +1142,20 @@ int dihip_gemm_lowp_pack(void* stream, int wbits, const void* wq, const void* sc
 
 size_t dihip_gemm_lowp_sync_bytes(void) { return GEMM_SYNC_BYTES; }
 
+// K parts per tail tile the context-phase GEMM of this shape is launched with on this GPU (1: no tail split; diagnostics / tests)
+int dihip_gemm_prefill_tail_parts(int wbits, int M, int N, int K, int group_size, int dual) {
+  if (M < 64 || N <= 0 || K <= 0) return 1;
+  return prefill_tail_plan(wbits, M, N, K, group_size, dual != 0).ksplit;
+}
+
 size_t dihip_gemm_lowp_workspace_bytes(int wbits, int M, int N, int K, int group_size) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   // sized for the dual (SwiGLU) form, the self-contained counter area and the M > 4 norm buffer
   const GemmPlan p1 = make_plan(wbits, M, N, K, group_size, false);
   const GemmPlan p2 = make_plan(wbits, M, N, K, group_size, true);
   size_t slab = std::max(p1.slab_bytes, p2.slab_bytes);
+  if (wbits != 16 && M >= 64)
+    slab = std::max(slab, std::max(prefill_tail_plan(wbits, M, N, K, group_size, false).slab_bytes, prefill_tail_plan(wbits, M, N, K, group_size, true).slab_bytes));
   if (wbits != 16 && M > 4 && M <= 32) {
     slab = std::max(slab, make_panel_plan(wbits, M, N, K, group_size, false).slab_bytes);
     slab = std::max(slab, make_panel_plan(wbits, M, N, K, group_size, true).slab_bytes);
@@ -1182,6 +1234,7 @@ static int norm_to_ws(hipStream_t s, const float* h, const void* gamma, float ep
                       int* x_layout, bool force_frag = false) {
   const GemmPlan p = make_plan(wbits, M, N, K, group_size, dual);
   size_t slab = p.slab_bytes;
+  if (wbits != 16 && M >= 64) slab = std::max(slab, prefill_tail_plan(wbits, M, N, K, group_size, dual).slab_bytes);
   if (wbits != 16 && M > 4 && M <= 32) {
     slab = std::max(slab, make_panel_plan(wbits, M, N, K, group_size, dual).slab_bytes);
     slab = std::max(slab, make_kslice_plan(wbits, M, N, K, group_size, dual, true).slab_bytes);

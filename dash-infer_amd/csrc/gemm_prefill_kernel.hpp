@@ -88,6 +88,13 @@ struct PrefillArgs {
   int Gp;      // (scale, zero) groups stored per tile
   int ktpg;    // k-tiles per quantisation group (per-channel: >= KT)
   int col_blocks;
+  // Tail split (round 5): column blocks [tail_cb, col_blocks) -- the workgroups that would otherwise run as a last, mostly empty
+  // round on the chip (qkv of Qwen2-7B at 2048 rows: 288 tiles on 256 CUs) -- are walked by `ksplit` workgroups each, one
+  // K range apiece (whole quantisation groups), which leave their f32 tile in `slab`; gemm_prefill_tail_reduce_kernel adds the
+  // parts in order and applies the epilogue.  tail_cb == col_blocks: no split.
+  int tail_cb;
+  int ksplit;
+  float* slab;  // [tail tile][ksplit][PF_BM][256] f32
   unsigned long long* trace;  // per-wave cycle stamps (library built with -DDIHIP_PF_TRACE, tools/prefill_trace.py)
 };
 
@@ -115,7 +122,20 @@ __global__ __launch_bounds__(PF_THREADS, 2) void gemm_prefill_kernel(const Prefi
   const int wm = wave / PF_WN, wn = wave - wm * PF_WN;  // this wave's place in the PF_WM x PF_WN grid
   // consecutive workgroups share a column block (its weights stay hot in the L2s) and walk the rows
   const int mblocks = (a.M + PF_BM - 1) / PF_BM;
-  const int cb = blockIdx.x / mblocks, mb = blockIdx.x - cb * mblocks;
+  int cb = blockIdx.x / mblocks, mb = blockIdx.x - cb * mblocks;
+  int kt0 = 0, kt1 = a.KT, split_part = -1, split_tile = 0;  // this workgroup's k-tiles; tail split: its part and tile
+  if (cb >= a.tail_cb) {  // (uniform) mb fastest, then the K part, then the column block: the 16 row blocks of a part share its weights
+    const int idx = (int)blockIdx.x - a.tail_cb * mblocks;
+    mb = idx % mblocks;
+    const int t = idx / mblocks;
+    split_part = t % a.ksplit;
+    const int cbt = t / a.ksplit;
+    cb = a.tail_cb + cbt;
+    const int per = a.KT / a.ksplit;
+    kt0 = split_part * per;
+    kt1 = kt0 + per;
+    split_tile = cbt * mblocks + mb;
+  }
   const int m0 = mb * PF_BM;
 
   // ---- this wave's column tiles -------------------------------------------------------------------
@@ -183,12 +203,14 @@ __global__ __launch_bounds__(PF_THREADS, 2) void gemm_prefill_kernel(const Prefi
   uint32_t ex_mask = 0x000F000Fu, ex_magic = FT == DIHIP_BF16 ? 0x43004300u : 0x64006400u;
   asm volatile("" : "+v"(ex_mask), "+v"(ex_magic));
 
-  // ---- prologue: k-tile 0 into buffer 0 ----------------------------------------------------------------
-  load_a(0);
-  load_b(0);
+  // ---- prologue: the first k-tile into buffer 0 ----------------------------------------------------------------
+  int gl = 0;                                                   // k-tiles of the running group done
+  int grp = GPT ? kt0 : (a.ktpg < a.KT ? kt0 / a.ktpg : 0);     // running group (a K part starts on a group boundary)
+  load_a(kt0);
+  load_b(kt0);
 #pragma unroll
-  for (int c = 0; c < PF_CW; ++c) szreg[c] = szp[c][0];
-  stage_a(0, 0, true);
+  for (int c = 0; c < PF_CW; ++c) szreg[c] = szp[c][(size_t)min(grp, a.Gp - 1) * 16];
+  stage_a(0, grp & 1, true);
   __syncthreads();
 
 #ifdef DIHIP_PF_TRACE
@@ -201,15 +223,13 @@ __global__ __launch_bounds__(PF_THREADS, 2) void gemm_prefill_kernel(const Prefi
 #else
 #define DIHIP_PF_STAMP(I) do { } while (0)
 #endif
-  int gl = 0;   // k-tiles of the running group done
-  int grp = 0;  // running group
-  for (int kt = 0; kt < a.KT; ++kt) {
-    const int buf = kt & 1;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
     DIHIP_PF_STAMP(0);
     u32x4_t wcur[PF_CW];
 #pragma unroll
     for (int c = 0; c < PF_CW; ++c) wcur[c] = wreg[c];
-    const bool more = kt + 1 < a.KT;
+    const bool more = kt + 1 < kt1;
     if (more) {  // (uniform) the loads of the next k-tile fly while this one is multiplied
       load_a(kt + 1);
       load_b(kt + 1);
@@ -277,6 +297,22 @@ __global__ __launch_bounds__(PF_THREADS, 2) void gemm_prefill_kernel(const Prefi
   }
 #undef DIHIP_PF_STAMP
 
+  // ---- tail split: this part's f32 tile to the slab (rows / columns of the workgroup tile; SwiGLU: gate columns, then up) ----
+  if (split_part >= 0) {  // (uniform)
+    float* st = a.slab + ((size_t)split_tile * a.ksplit + split_part) * (PF_BM * 256);
+#pragma unroll
+    for (int rt = 0; rt < PF_RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = (wm * PF_RT + rt) * 16 + kb * 4 + r;
+#pragma unroll
+        for (int c = 0; c < PF_CW; ++c) {
+          const int col = DUAL ? (c < HCW ? 0 : 128) + (wn * HCW + (c % HCW)) * 16 + ni : (wn * PF_CW + c) * 16 + ni;
+          st[(size_t)row * 256 + col] = tot[rt][c][r];
+        }
+      }
+    return;
+  }
   // ---- epilogue: lane (kb, ni) holds rows rt * 16 + kb * 4 + r of column tile c, column ni --------------------
 #pragma unroll
   for (int rt = 0; rt < PF_RT; ++rt) {
@@ -315,6 +351,41 @@ __global__ __launch_bounds__(PF_THREADS, 2) void gemm_prefill_kernel(const Prefi
   }
 }
 
+// tail split: the K parts of every split tile added in order + the epilogue of gemm_prefill_kernel
+template <int FT, int EPI>
+__global__ __launch_bounds__(256) void gemm_prefill_tail_reduce_kernel(const PrefillArgs a) {
+  constexpr bool DUAL = EPI == EPI_SWIGLU;
+  constexpr int NC = DUAL ? 128 : 256;  // output columns of a workgroup tile
+  const int mblocks = (a.M + PF_BM - 1) / PF_BM;
+  const size_t total = (size_t)(a.col_blocks - a.tail_cb) * mblocks * PF_BM * NC;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int col = (int)(e % NC);
+    const size_t q = e / NC;
+    const int row = (int)(q % PF_BM), tile = (int)(q / PF_BM);
+    const int cbt = tile / mblocks, mb = tile - cbt * mblocks;
+    const int m = mb * PF_BM + row, n = (a.tail_cb + cbt) * NC + col;
+    if (m >= a.M || n >= a.N) continue;
+    const float* st = a.slab + (size_t)tile * a.ksplit * (PF_BM * 256) + (size_t)row * 256 + col;
+    float v = 0.f, v2 = 0.f;
+    for (int s = 0; s < a.ksplit; ++s) {
+      v += st[(size_t)s * (PF_BM * 256)];
+      if constexpr (DUAL) v2 += st[(size_t)s * (PF_BM * 256) + 128];
+    }
+    if constexpr (DUAL) {
+      store_ft<FT>(a.y, (size_t)m * a.ldy + n, (v / (1.f + expf(-v))) * v2);
+    } else if constexpr (EPI == EPI_STD) {
+      v = a.alpha * v;
+      if (a.bias) v += load_ft<FT>(a.bias, n);
+      v = apply_act(v, a.act);
+      if (a.residual) v = ft_round<FT>(v) + load_ft<FT>(a.residual, (size_t)m * a.ldy + n);
+      store_ft<FT>(a.y, (size_t)m * a.ldy + n, v);
+    } else {
+      const float base = a.h_res ? a.h_res[(size_t)m * a.N + n] : 0.f;
+      a.h_out[(size_t)m * a.N + n] = base + a.alpha * v;
+    }
+  }
+}
+
 template <int WBITS, int FT, int EPI, int GPT>
 hipError_t launch_gemm_prefill(const PrefillArgs& a, int blocks, hipStream_t stream);
 
@@ -337,6 +408,10 @@ hipError_t launch_gemm_prefill(const PrefillArgs& a, int blocks, hipStream_t str
       }                                                                                                            \
     }                                                                                                              \
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(PF_THREADS), lds, s, a);                                           \
+    if (a.tail_cb < a.col_blocks) {                                                                                \
+      const size_t outs = (size_t)(a.col_blocks - a.tail_cb) * ((a.M + PF_BM - 1) / PF_BM) * PF_BM * 256;          \
+      hipLaunchKernelGGL((gemm_prefill_tail_reduce_kernel<FT, EPI>), dim3((unsigned)std::min<size_t>((outs + 1023) / 1024, 2048)), dim3(256), 0, s, a); \
+    }                                                                                                              \
     return hipGetLastError();                                                                                      \
   }
 

@@ -85,6 +85,10 @@ int dihip_gemm_lowp_pack(void* stream, int wbits, const void* wq, const void* sc
                          const void* zeros, int N, int K, int group_size, int dtype,
                          void* w_packed, void* sz_packed);
 
+/* Context phase (M >= 64): when the grid of 128 x 256 tiles would end in a round that fills at most half the chip, the column blocks of
+ * that round are split in K (whole quantisation groups per part, parts added in order by a reduction launch): the number of parts per
+ * tail tile for this shape on this GPU, 1 = no split.  Diagnostics / tests; DIHIP_PREFILL_TAIL_SPLIT=0 turns the split off. */
+int dihip_gemm_prefill_tail_parts(int wbits, int M, int N, int K, int group_size, int dual);
 /* scratch (split-K slabs; contents need no initialisation) and sync (arrival counters; must be
  * zero-filled ONCE by the owner, the kernels leave it zero) sizes */
 size_t dihip_gemm_lowp_workspace_bytes(int wbits, int M, int N, int K, int group_size);

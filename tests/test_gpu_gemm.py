@@ -627,3 +627,48 @@ def test_prefill_gemm_all_epilogues(ops, M, N, K, wbits, G):
     g = gemm_ref.gemm_a16wx(x, q, s, z, G, wbits, round_out=False).astype(np.float64)
     u = gemm_ref.gemm_a16wx(x, qu, su, zu, G, wbits, round_out=False).astype(np.float64)
     assert_close(act.float().cpu().numpy(), bf16_round(((g / (1 + np.exp(-g))) * u).astype(np.float32)), "bf16", what="prefill SwiGLU")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Context-phase GEMM, tail split (gemm_prefill_kernel.hpp, PrefillArgs::tail_cb): shapes whose grid of 128 x 256 tiles ends in a
+# round that fills at most half of the chip -- the column blocks of that round are split in K and added by a reduction launch.
+# Every epilogue, groups of one k-tile / two k-tiles / per-channel, ragged M and N, against the oracle; the split must be ON for
+# these shapes on this GPU (dihip_gemm_prefill_tail_parts), or the test says nothing.
+@pytest.mark.gpu
+@pytest.mark.parametrize("wbits,G,M,N,K", [(4, 128, 2048, 4608, 1024),     # the qkv projection's grid: 288 tiles -> 256 + 32 x 8 parts
+                                           (4, 256, 2000, 4600, 1024),     # ragged rows / columns, a group = two k-tiles
+                                           (8, -1, 2048, 4608, 512),       # per-channel: a part closes its sum with the one scale
+                                           (4, 128, 1100, 7400, 768)])     # 9 row blocks x 29 column blocks = 261 tiles: a 5-tile tail
+def test_prefill_gemm_tail_split(ops, wbits, G, M, N, K):
+    from dash_infer_amd.capi import lib
+    rng = np.random.default_rng(M + N + K + wbits)
+    x, q, s, z = make_case(rng, M, N, K, G, wbits, "bf16", style="iq")
+    pw = ops.pack_lowp(to_dev(q), to_dev(s, "bf16"), to_dev(z, "bf16"), G, wbits)
+    xd = to_dev(x, "bf16")
+    sc = ops.Scratch(ops.lowp_workspace_bytes(wbits, M, N, K, G))
+    parts = int(lib().dihip_gemm_prefill_tail_parts(wbits, M, N, K, G, 0))
+    assert parts > 1, "this shape must run with a split tail on a 256-CU part"
+    # STD: alpha, bias, activation, FT residual
+    bias = bf16_round(rng.normal(0, 0.3, N).astype(np.float32))
+    res = bf16_round(rng.normal(0, 1, (M, N)).astype(np.float32))
+    y = ops.gemm_lowp(xd, pw, bias=to_dev(bias, "bf16"), residual=to_dev(res, "bf16"), act="silu", alpha=0.5, scratch=sc)
+    pre = gemm_ref.gemm_a16wx(x, q, s, z, G, wbits, alpha=0.5, bias=bias, act="silu", ft="bf16")
+    assert_close(y.float().cpu().numpy(), bf16_round(pre + res), "bf16", what=f"tail split STD ({parts} parts)", pre=pre)
+    # f32 hidden-stream update
+    h = rng.normal(0, 1.5, (M, N)).astype(np.float32)
+    h2 = ops.fused_gemm_addto(xd, pw, to_dev(h), sc, M=M)
+    ref = h + gemm_ref.gemm_a16wx(x, q, s, z, G, wbits, round_out=False)
+    np.testing.assert_allclose(h2.cpu().numpy(), ref, rtol=2e-5, atol=3e-5 * np.abs(ref).max())
+    # SwiGLU pair (128 output columns per workgroup: its own grid, its own tail)
+    Ns = {4608: 4224, 4600: 4220, 7400: 4224}[N]   # 33 column blocks of 128 x 16 (or 9) row blocks
+    parts2 = int(lib().dihip_gemm_prefill_tail_parts(wbits, M, Ns, K, G, 1))
+    _, qg, sg, zg = make_case(rng, 1, Ns, K, G, wbits, "bf16", style="iq")
+    _, qu, su, zu = make_case(rng, 1, Ns, K, G, wbits, "bf16", style="iq")
+    pg = ops.pack_lowp(to_dev(qg), to_dev(sg, "bf16"), to_dev(zg, "bf16"), G, wbits)
+    pu = ops.pack_lowp(to_dev(qu), to_dev(su, "bf16"), to_dev(zu, "bf16"), G, wbits)
+    sc2 = ops.Scratch(ops.lowp_workspace_bytes(wbits, M, Ns, K, G))
+    act = ops.prenorm_swiglu(xd, pg, pu, sc2, M)
+    g = gemm_ref.gemm_a16wx(x, qg, sg, zg, G, wbits, round_out=False).astype(np.float64)
+    u = gemm_ref.gemm_a16wx(x, qu, su, zu, G, wbits, round_out=False).astype(np.float64)
+    assert_close(act.float().cpu().numpy(), bf16_round(((g / (1 + np.exp(-g))) * u).astype(np.float32)), "bf16", what=f"tail split SwiGLU ({parts2} parts)")
+    print(f"\n[prefill tail split] W{wbits} g{G} M{M} N{N} K{K}: {parts} parts per tail tile; SwiGLU pair N{Ns}: {parts2}")
