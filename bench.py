@@ -299,7 +299,8 @@ def prefill_bench(args, torch, decoder, ops):
     cfg = decoder.QWEN2_7B
     L = 2048
     t0 = time.time()
-    model = decoder.build_random_model(cfg, decoder.QuantSpec(wbits, group, gptq_like_zeros=gptq), seed=1234, layers=args.layers)
+    host_leg = args.runner in ("auto", "host")
+    model = decoder.build_random_model(cfg, decoder.QuantSpec(wbits, group, gptq_like_zeros=gptq), seed=1234, layers=args.layers, keep_fp=host_leg)
     sess = decoder.DecodeSession(model, 1, max_len=L + 16, span_len=128, kv_mode=kv_mode)
     gen = torch.Generator().manual_seed(11)
     prompt = [int(t) for t in torch.randint(0, cfg.vocab, (L,), generator=gen)]
@@ -319,6 +320,15 @@ def prefill_bench(args, torch, decoder, ops):
     torch.cuda.synchronize()
     t_wall = (time.perf_counter() - t_wall) / steps
     ms = e0.elapsed_time(e1) / steps
+    # the same context phase through the C++ operator layer: serialized reference graph -> fusion pass -> OpFactory(HIP) -> model runner
+    # (request_start = AsModel's context phase of one request: PreProcessId, embedding, the fused layers at M = 2048, GetLastLine, lm_head,
+    # GenerateOp), over the Python session's span pool
+    host = None
+    if host_leg:
+        try:
+            host = prefill_host_bench(args, torch, ops, model, sess, prompt, steps)
+        except Exception as e:  # the line must still be printed: the Python session's figure stands
+            host = {"error": f"{type(e).__name__}: {e}"[:300]}
     # the attention kernel alone: all layers' calls on resident fused qkv rows
     n, g, H = cfg.n_heads, cfg.n_kv, cfg.head_dim
     qkv = (torch.randn(L, (n + 2 * g) * H, device="cuda") * 0.5).to(torch.bfloat16)
@@ -369,7 +379,8 @@ def prefill_bench(args, torch, decoder, ops):
     out_d = {
         "metric": "prefill (context phase) tokens/sec, Qwen2-7B weight-only quantized, one 2048-token prompt",
         "value": round(L / (ms * 1e-3), 1), "unit": "tokens/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
-        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "runner": "python: decoder.DecodeSession.prefill (ctypes over the C-ABI)",
+        "python_runner": {"tokens_per_s": round(L / (ms * 1e-3), 1), "ms_per_prompt": round(ms, 3)}, "host_runner": host, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic (random-init InstantQuant weights of the Qwen2-7B shapes, random prompt)",
         "config": {"workload": f"Qwen2-7B prefill_2048: int{wbits} weight-only group {group}, 16-bit KV spans, batch 1, prompt {L} tokens, "
                                f"{nl} layers, eager launches (DecodeSession.prefill)", "global_batch": 1, "seq_len": L, "parallelism": "tp1",
@@ -386,9 +397,52 @@ def prefill_bench(args, torch, decoder, ops):
             gemm_flops / max(1e-9, (ms * 1e-3 - attn_us * nl * 1e-6)) / 1e12, 1), "host_wall_ms": round(t_wall * 1e3, 3)},
         "build_s": round(t_build, 1),
     }
+    if host and "ms_per_prompt" in host and host.get("fused"):  # as for the decode workloads: `value` is the C++ operator layer's figure
+        out_d["value"], out_d["ms_per_step"] = host["tokens_per_s"], host["ms_per_prompt"]
+        out_d["runner"] = "host: C++ operator layer -- serialized reference graph -> fusion pass -> OpFactory(HIP) -> model runner (context phase, eager)"
     if args.layers is not None:
         out_d["invalid"] = "debug run with a truncated layer stack"
     return out_d
+
+
+def prefill_host_bench(args, torch, ops, model, sess, prompt, steps):
+    from dash_infer_amd import hostapi
+    from dash_infer_amd import ref_graph
+    cfg = model.cfg
+    L = len(prompt)
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        m = hostapi.Model(ops.cur_stream(), cfg.n_heads, cfg.n_kv, cfg.head_dim, sess.pool.S, 0, max_batch=1, max_len=sess.max_len)
+        try:
+            ref_graph.register_weights(m, model)
+            g = ref_graph.qwen2_graph(len(model.layers), model.quant.wbits, model.quant.group, cfg.eps, cfg.n_heads, cfg.n_kv, cfg.rope_theta)
+            m.graph_add_serialized(ref_graph.to_transformer_proto(g))
+            rep = m.graph_build(fuse=True)
+            ks = [[int(p) for p in sess.kv[li].k_host[0].tolist()] for li in range(len(model.layers))]
+            vs = [[int(p) for p in sess.kv[li].v_host[0].tolist()] for li in range(len(model.layers))]
+
+            def once():
+                first = m.request_start(prompt, ks, vs)
+                m.request_stop(0)
+                return first
+
+            for _ in range(max(1, args.warmup)):
+                once()
+            stream.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t_wall = time.perf_counter()
+            e0.record(stream)
+            for _ in range(steps):
+                first = once()
+            e1.record(stream)
+            stream.synchronize()
+            t_wall = (time.perf_counter() - t_wall) / steps
+            ms = e0.elapsed_time(e1) / steps
+        finally:
+            m.close()
+    return {"tokens_per_s": round(L / (ms * 1e-3), 1), "ms_per_prompt": round(ms, 3), "host_wall_ms": round(t_wall * 1e3, 3), "fused": rep["fused"],
+            "operators": rep["ops"], "first_token": int(first) if first is not None else None}
 
 
 def moe_layer_bench(args, torch, ops):
