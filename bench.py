@@ -704,7 +704,7 @@ def secondary_workloads(names=("int4_b32_u4kv", "int8_b1", "prefill_2048", "cfg3
                 continue
             d = json.loads(line[-1])
             keep = {k: d.get(k) for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "step_hbm", "roofline",
-                                          "blocks", "attention", "gemms", "kernels") if k in d}
+                                          "blocks", "attention", "gemms", "kernels", "runner", "python_runner", "host_runner") if k in d}
             keep["workload"] = w
             keep["wall_s"] = round(time.time() - t0, 1)
             res.append(keep)
