@@ -993,6 +993,12 @@ class DihipGreedyOp : public AsOperator {
     if (s.size() < 2 || x->GetDataType() != FLOAT32) return AsStatus::ALLSPARK_PARAM_ERROR;
     vocab_ = (int)s.back();
     rows_ = (int)(x->Count() / vocab_);
+    // rows of this forward per request (the context phase's prompt length): this operator sees the LAST row's logits only, so the
+    // length comes from the graph's input ids (GenerateOpHIP reads it off its [batch, seq, vocab] input) -- used for the sampled
+    // token's position when no virtual cache carries the sequence length (sampling_host.h: StagePositions)
+    seq_ = 1;
+    auto ids = tensor_map_->find("input_ids");
+    if (rt && rt->is_context && ids != tensor_map_->end() && ids->second->GetShape().size() >= 2) seq_ = std::max(1, (int)ids->second->GetShape()[1]);
     if (rt && rt->GetGenCtxListSize() > 0) AS_CHECK_STATUS(params_.Gather(rt, rows_, stream_of(ctx_)));
     AsTensor* y = tensor_map_->at(out_names_[0]).get();
     y->SetDataType(INT64);
