@@ -417,6 +417,9 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
           }
         }
         store_token_head<DIHIP_BF16, DIHIP_KV_U4, 2>(newrow[kv], x, 0, 0, 1, 1, H, lane);  // a one-token "span": data, then {zero, scale}
+        // (the row is read back below through pointers of other types: the byte stores must not be moved past those reads -- ADVICE r4)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         if (writer) {  // the same bytes into the span: 64 B of nibbles + the parameter pair
           unsigned char* span = reinterpret_cast<unsigned char*>(const_cast<void*>((kv ? vsp : ksp)[sp]));
           const size_t rowi = (size_t)grp * a.S + pos;
@@ -790,10 +793,13 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
                          int span_len, int n_spans_per_request, int max_seq_len, int kv_mode, int dtype, float qk_scale, void* ws,
                          size_t ws_bytes, bool* handled, void* sync, size_t sync_bytes, int out_layout) {
   *handled = false;
-  // 16-bit cache (bf16 / f16) and uint4 cache with bf16 activations; the int8 cache keeps its append launch
+  // 16-bit and int8 cache (bf16 / f16) and uint4 cache with bf16 activations (uint4 with f16 rows keeps its append launch).
+  // DIHIP_ATTN_I8_FUSED=0: the int8 cache keeps the append launch too (A/B)
   const bool u4 = kv_mode == DIHIP_KV_U4 && dtype == DIHIP_BF16;
-  if ((kv_mode != DIHIP_KV_NONE && !u4) || !attn_use_mfma(kv_mode, dtype)) return DIHIP_SUCCESS;
-  if (out_layout == DIHIP_ACT_FRAG32 && (!u4 || batch > 32)) return DIHIP_SUCCESS;  // (the 16-bit form writes row-major rows)
+  static const bool i8_fused = !env_off("DIHIP_ATTN_I8_FUSED");
+  const bool i8 = kv_mode == DIHIP_KV_I8 && i8_fused;
+  if ((kv_mode != DIHIP_KV_NONE && !u4 && !i8) || !attn_use_mfma(kv_mode, dtype)) return DIHIP_SUCCESS;
+  if (out_layout == DIHIP_ACT_FRAG32 && ((!u4 && !i8) || batch > 32)) return DIHIP_SUCCESS;  // (the 16-bit form writes row-major rows)
   const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true);
   if (p.nsplits > 1 && (ws == nullptr || ws_bytes < p.partial_bytes)) return DIHIP_SUCCESS;  // caller's kernels size their own
   *handled = true;
@@ -823,10 +829,8 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
     return (m && m[0] == 'l') ? 0 : (m && m[0] == 'n') ? 2 : 1;  // "none" (timing experiments only): partials written, never merged
   }();
   if (static_tps && !u4) a.tps_static = ((max_seq_len + p.nsplits - 1) / p.nsplits + 31) & ~31;  // (the uint4 kernel splits by the request's length)
-  if (u4) {
-    a.len_bias = 1;
-    a.out_frag_mt = out_layout == DIHIP_ACT_FRAG32 ? (batch > 16 ? 2 : 1) : 0;
-  }
+  if (u4) a.len_bias = 1;
+  if (u4 || i8) a.out_frag_mt = out_layout == DIHIP_ACT_FRAG32 ? (batch > 16 ? 2 : 1) : 0;
   // in-launch merge: needs the caller's zero-initialised ticket words (dihip_span_attn_decode_fused_sync)
   const bool merge_wt = merge_mode == 1 && p.nsplits > 1 && sync != nullptr &&
                         sync_bytes >= (size_t)batch * n_groups * p.nchunks * 128 && p.partial_bytes < (1ull << 31);
@@ -838,6 +842,10 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
   a.trace = debug_trace_buffer((size_t)p.nsplits * n_groups * p.nchunks * batch * 32 * sizeof(unsigned long long));
   if (u4)
     hipLaunchKernelGGL(span_attn_u4_mfma_kernel<true>, grid, dim3(ATTN_THREADS), 0, s, a);
+  else if (i8 && dtype == DIHIP_BF16)
+    hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_I8, true>), grid, dim3(ATTN_THREADS), 0, s, a);
+  else if (i8)
+    hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_F16, DIHIP_KV_I8, true>), grid, dim3(ATTN_THREADS), 0, s, a);
   else if (dtype == DIHIP_BF16)
     hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_NONE, true>), grid, dim3(ATTN_THREADS), 0, s, a);
   else

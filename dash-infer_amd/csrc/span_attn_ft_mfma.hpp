@@ -2,6 +2,7 @@
 // other decode kernels of span_attn.hip).
 #pragma once
 #include "span_attn_common.hpp"
+#include "span_codec.hpp"
 
 namespace dihip {
 
@@ -270,7 +271,8 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   constexpr int H = 128;
   constexpr int HC = MF_HC;
   constexpr bool Q8 = MODE == DIHIP_KV_I8;
-  static_assert(!FUSED || MODE == DIHIP_KV_NONE, "the decode-step form covers the 16-bit cache");
+  static_assert(!FUSED || MODE == DIHIP_KV_NONE || MODE == DIHIP_KV_I8, "the decode-step form covers the 16-bit and the int8 cache");
+  static_assert(!GATHER || MODE == DIHIP_KV_NONE, "the gathering form is the decode step over the 16-bit cache");
   constexpr int ROWB = Q8 ? H : H * 2;  // bytes per token-head row in the span
   // the per-wave V tiles and the epilogue records share one buffer (a barrier separates the two uses): FT_MFMA_SMEM_BYTES
   float* lds = reinterpret_cast<float*>(smem);
@@ -481,7 +483,32 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
         for (int j = 0; j < 4; ++j) qsum += hv ? ft_bits_to_f32<FT>(qf[ks][j] & 0xFFFFu) + ft_bits_to_f32<FT>(qf[ks][j] >> 16) : 0.f;
       }
     }
-    if constexpr (FUSED) rotate(qf, cs_row);
+    if constexpr (FUSED && Q8) {
+      // int8 rows order the dims kb*32 + ks*8 + e: the rotate-half partner d +- 64 sits in lane +- 32 (same ks, same dword) --
+      // one cross-half exchange per dword; products, sum and FT rounding as dihip_rope_qk / the Rotary op
+      qsum = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        u32x4_t rot;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t pw = (uint32_t)__shfl_xor((int)qf[ks][j], 32, 64);
+          const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(cs_row + (size_t)((kb & 1) * 32 + ks * 8 + 2 * j) * 2);  // {c0, s0, c1, s1}
+          float r[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float x = ft_bits_to_f32<FT>(e ? qf[ks][j] >> 16 : qf[ks][j] & 0xFFFFu);
+            const float pt = ft_bits_to_f32<FT>(e ? pw >> 16 : pw & 0xFFFFu);
+            r[e] = kb < 2 ? x * cs[2 * e] - pt * cs[2 * e + 1] : x * cs[2 * e] + pt * cs[2 * e + 1];
+          }
+          rot[j] = f32_to_ft_bits<FT>(r[0]) | (f32_to_ft_bits<FT>(r[1]) << 16);
+          qsum += hv ? ft_bits_to_f32<FT>(rot[j] & 0xFFFFu) + ft_bits_to_f32<FT>(rot[j] >> 16) : 0.f;  // (of the ROTATED row, as the two-launch form sums it)
+        }
+        qf[ks] = rot;
+      }
+    } else if constexpr (FUSED) {
+      rotate(qf, cs_row);
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
       if (!hv) qf[ks] = u32x4_t{0u, 0u, 0u, 0u};
@@ -492,7 +519,42 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   // FUSED: this step's K (rotated, rounded) and V head of the group, as the cache will hold them
   const bool has_new = FUSED && newpos >= t0 && newpos < t0 + tps;  // workgroup-uniform (all head chunks of the group)
   u32x4_t knew[4] = {}, vnew = {};
-  if constexpr (FUSED) {
+  // int8: the new K / V head rotated, rounded and QUANTISED as the append kernel does (store_token_head) -- every wave for itself into
+  // its own 2 x 144 bytes of LDS ({128 codes, zero, scale}; no workgroup barrier: a wave reads back what it wrote itself, LDS
+  // operations of a wave execute in order); the tile loop substitutes codes and parameters where a lane's token is the new one
+  unsigned char* const nrow = smem + ((FT_MFMA_SMEM_BYTES + 15) & ~15) + wave * 288;
+  if constexpr (FUSED && Q8) {
+    if (has_new) {
+      const int sp = newpos >> lgS, pos = newpos - (sp << lgS);
+      const bool writer = hc == 0 && wave == 0 && sp < a.span_stride;  // one per (request, group): DecoderCacheAppend; past the span table: dropped
+#pragma unroll
+      for (int kv = 0; kv < 2; ++kv) {
+        const uint16_t* row = reinterpret_cast<const uint16_t*>(a.q) + (size_t)b * qrow_stride + (size_t)(a.n + (kv ? a.g : 0) + grp) * H;
+        const uint32_t w = reinterpret_cast<const uint32_t*>(row)[lane];  // lane holds d = 2 * lane, 2 * lane + 1 (the codec's element order)
+        float x[2] = {ft_bits_to_f32<FT>(w & 0xFFFFu), ft_bits_to_f32<FT>(w >> 16)};
+        if (kv == 0) {
+          const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(cs_row + (size_t)((2 * lane) & 63) * 2);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float pt = __shfl_xor(x[e], 32, 64);
+            const float r = lane < 32 ? x[e] * cs[2 * e] - pt * cs[2 * e + 1] : x[e] * cs[2 * e] + pt * cs[2 * e + 1];
+            x[e] = ft_round<FT>(r);
+          }
+        }
+        unsigned char* nr = nrow + kv * 144;
+        store_token_head<FT, DIHIP_KV_I8, 2>(nr, x, 0, 0, 1, 1, H, lane);  // a one-token "span": 128 codes, then {zero, scale}
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (writer) {  // the same bytes into the span
+          unsigned char* span = reinterpret_cast<unsigned char*>(const_cast<void*>((kv ? vsp : ksp)[sp]));
+          const size_t rowi = (size_t)grp * a.S + pos;
+          if (lane < 32) gstore<uint32_t>(span + rowi * ROWB + lane * 4, reinterpret_cast<const uint32_t*>(nr)[lane]);
+          if (lane == 32) gstore<uint64_t>(span + par_off + rowi * 8, *reinterpret_cast<const uint64_t*>(nr + H));
+        }
+      }
+    }
+  }
+  if constexpr (FUSED && !Q8) {
     if (has_new) {
       const uint16_t* krow = GATHER ? img + (size_t)a.hpg * H
                                     : reinterpret_cast<const uint16_t*>(a.q) + (size_t)b * qrow_stride + (size_t)(a.n + grp) * H;
@@ -528,7 +590,34 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
     constexpr int STEP = 4 * MF_TOK;
     for (int tb = tb0; tb < t1; tb += STEP) {
       // FUSED: lanes whose (clamped) token is this step's token take the register copy (see above)
-      if constexpr (FUSED) {
+      if constexpr (FUSED && Q8) {
+        if (has_new) {
+          const float knz = reinterpret_cast<const float*>(nrow + H)[0], kns = reinterpret_cast<const float*>(nrow + H)[1];
+          const float vnz = reinterpret_cast<const float*>(nrow + 144 + H)[0], vns = reinterpret_cast<const float*>(nrow + 144 + H)[1];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            int base = tb + c * 16;
+            base = base < t1 ? base : ((t1 - 1) & ~15);
+            const int last = min(15, t1 - 1 - base);
+            if (base + min(ni, last) == newpos) {  // K codes: this lane's 32 dims of the row
+              kreg[c][0] = *reinterpret_cast<const u32x4_t*>(nrow + kb * 32);
+              kreg[c][1] = *reinterpret_cast<const u32x4_t*>(nrow + kb * 32 + 16);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+              if (base + kb * 4 + rr == newpos) {  // parameters of token c*16 + kb*4 + rr (loaded unclamped)
+                kpar[c][rr >> 1][(rr & 1) * 2] = knz;
+                kpar[c][rr >> 1][(rr & 1) * 2 + 1] = kns;
+                vpar[c][rr >> 1][(rr & 1) * 2] = vnz;
+                vpar[c][rr >> 1][(rr & 1) * 2 + 1] = vns;
+              }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              if (base + min(i * 8 + (lane >> 3), last) == newpos) vreg[c * 2 + i] = *reinterpret_cast<const u32x4_t*>(nrow + 144 + (lane & 7) * 16);
+          }
+        }
+      }
+      if constexpr (FUSED && !Q8) {
         if (has_new) {
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
@@ -686,7 +775,8 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
 
 template <int FT, int MODE, bool FUSED>
 __global__ __launch_bounds__(ATTN_THREADS, 2) void span_attn_ft_mfma_kernel(const AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[FT_MFMA_SMEM_BYTES];
+  // (+ the int8 decode step's per-wave new-row buffers: 4 x 2 x 144 bytes behind the tiles)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[FT_MFMA_SMEM_BYTES + (FUSED && MODE == DIHIP_KV_I8 ? 16 + 4 * 288 : 0)];
   span_attn_ft_mfma_body<FT, MODE, FUSED>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z, smem);
 }
 

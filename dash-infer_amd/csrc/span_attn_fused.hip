@@ -9,8 +9,12 @@
 //
 //   16-bit cache      span_attn_ft_mfma_kernel<.., FUSED> (span_attn_ft_mfma.hpp): Rotary, append and both contractions on
 //                     the matrix cores in one launch, + the split merge.
-//   int8 / uint4 cache  rope_kv_append_kernel (span_cache.hip: Rotary, quantising append, rotated q into the workspace), then
-//                     the matrix-core decode kernels of the op boundary (span_attn.hip) on lengths + 1, + the split merge.
+//   int8 cache        the same kernel, MODE = I8 (round 5): every wave of the workgroup that holds the new token quantises this step's
+//                     K / V head into its own LDS row as the append kernel does and substitutes codes + parameters in its tiles;
+//                     bit-identical to the two launches below (output and span bytes).
+//   uint4 cache       bf16 rows: span_attn_u4_mfma_kernel<FUSED> (round 4), one launch; f16 rows: rope_kv_append_kernel
+//                     (span_cache.hip: Rotary, quantising append, rotated q into the workspace), then the matrix-core decode
+//                     kernels of the op boundary (span_attn.hip) on lengths + 1, + the split merge.
 //
 // (Until round 2 the quantised caches, and the 16-bit cache before its matrix-core form existed, went through a VALU
 // kernel with one query head per wave that did all of it in one launch: 22 - 325 spilled VGPRs depending on the heads per
@@ -105,10 +109,11 @@ int dihip_span_attn_decode_step(void* stream, void* output, const void* qkv, voi
   DIHIP_REQUIRE((reinterpret_cast<uintptr_t>(qkv) & 15) == 0, DIHIP_PARAM_ERROR, "span_attn_decode_fused: qkv must be 16-byte aligned");
   DIHIP_REQUIRE(out_layout == DIHIP_ACT_ROWMAJOR || out_layout == DIHIP_ACT_FRAG32, DIHIP_PARAM_ERROR, "span_attn_decode_step: bad out_layout");
   if (batch == 0) return DIHIP_SUCCESS;
-  if (kv_mode == DIHIP_KV_U4) {
-    // uint4 cache, bf16 activations: one launch as well (span_attn_u4_mfma_kernel<FUSED>); otherwise the two launches below
+  if (kv_mode == DIHIP_KV_U4 || kv_mode == DIHIP_KV_I8) {
+    // uint4 cache with bf16 activations (span_attn_u4_mfma_kernel<FUSED>) and int8 cache (span_attn_ft_mfma_kernel<FT, I8, FUSED>,
+    // round 5): one launch as well; otherwise (uint4 with f16 rows, DIHIP_ATTN_I8_FUSED=0) the two launches below
     static const bool two_launches = env_off("DIHIP_ATTN_U4_FUSED");  // =0: the append launch + the op-boundary kernel (A/B)
-    if (!two_launches) {
+    if (kv_mode == DIHIP_KV_I8 || !two_launches) {
       bool handled = false;
       const int st = span_attn_fused_mfma(stream, output, qkv, k_span_array, v_span_array, old_seq_lens_dev, rope_table, batch,
                                           n_heads, n_groups, span_len, n_spans_per_request, max_seq_len, kv_mode, dtype, qk_scale,
@@ -117,7 +122,7 @@ int dihip_span_attn_decode_step(void* stream, void* output, const void* qkv, voi
     }
   }
   DIHIP_REQUIRE(out_layout == DIHIP_ACT_ROWMAJOR, DIHIP_PARAM_ERROR,
-                "span_attn_decode_step: FRAG32 output is served by the one-launch uint4 form only (bf16 activations, batch <= 32)");
+                "span_attn_decode_step: FRAG32 output is served by the one-launch uint4 / int8 forms only (batch <= 32)");
   if (kv_mode == DIHIP_KV_NONE) {
     // 16-bit cache: one launch, both contractions on the matrix cores (span_attn.hip); 10.7 vs 15.5 us per layer at batch 1
     bool handled = false;

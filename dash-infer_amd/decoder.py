@@ -569,7 +569,10 @@ class DecodeSession:
         self.fused_attention = kv_mode == "none"
         # uint4 cache with bf16 rows (round 4): one launch as well, FRAG32 output included (dihip_span_attn_decode_step);
         # DIHIP_ATTN_U4_FUSED=0 keeps the append launch (A/B)
-        self.step_attention = kv_mode == "u4" and dt == torch.bfloat16 and os.environ.get("DIHIP_ATTN_U4_FUSED", "1") != "0"
+        self.step_attention = ((kv_mode == "u4" and dt == torch.bfloat16 and os.environ.get("DIHIP_ATTN_U4_FUSED", "1") != "0")
+                               # int8 cache: one launch too, where it pays (batch 1: -1.8 us per layer; batch 32: +1.3 -- every workgroup
+                               # rotates its query heads itself; profiles/r05_i8_decode_step.txt)
+                               or (kv_mode == "i8" and batch <= 4 and os.environ.get("DIHIP_ATTN_I8_FUSED", "1") != "0"))
         # split sequences: the partial records are merged inside the attention launch (arrival tickets in attn_sync, zeroed
         # once) instead of by a second launch; DIHIP_DECODER_ATTN_MERGE=launch restores the two-launch form (A/B)
         self.attn_merge_in_launch = os.environ.get("DIHIP_DECODER_ATTN_MERGE", "ticket") != "launch"

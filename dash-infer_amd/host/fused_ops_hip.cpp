@@ -667,8 +667,9 @@ class DihipRopeSpanAttnOp : public SpanAttnOpHIP, public AttnBlockAttnPart {
                                                          merge_in_launch ? sy->GetSizeInByte() : 0));
     }
     static const bool u4_step = env_on("DIHIP_ATTN_U4_FUSED", true);  // decoder.DecodeSession.step_attention
-    if (kv_mode_ == DIHIP_KV_U4 && dtype_ == BFLOAT16 && u4_step) {
-      // uint4 cache, bf16 rows: one launch as well (Rotary + quantising append + attention + merge), FRAG32 output included
+    static const bool i8_step = env_on("DIHIP_ATTN_I8_FUSED", true);
+    if ((kv_mode_ == DIHIP_KV_U4 && dtype_ == BFLOAT16 && u4_step) || (kv_mode_ == DIHIP_KV_I8 && i8_step && batch_ <= 4)) {  // (int8: where it pays, as DecodeSession)
+      // uint4 cache with bf16 rows, int8 cache: one launch as well (Rotary + quantising append + attention + merge), FRAG32 output included
       return FromDihip(dihip_span_attn_decode_step(Stream(), out, qkv, kd, vd, old_lens, (const float*)tensor_map_->at("dihip.rope_table")->GetDataPtr(),
                                                    batch_, n_, g_, h_, span_, max_spans_, max_len, kv_mode_, DihipDtype(dtype_), alpha_,
                                                    aws->GetDataPtr(), aws->GetSizeInByte(), merge_in_launch ? sy->GetDataPtr() : nullptr,

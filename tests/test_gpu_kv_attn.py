@@ -355,19 +355,22 @@ def test_fused_rope_append_attention_matches_separate_ops(ops, n, g, S, lens, mo
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["u4", "i8"])
 @pytest.mark.parametrize("n,g,S,lens", [(28, 4, 128, [2048, 0, 1, 127, 128, 129, 1000, 2047] * 4),        # configs[2]: batch 32, GQA 7
                                         (14, 2, 32, [0, 1, 30, 31, 32, 33, 63, 64, 500]), (8, 8, 16, [15, 16, 17, 300]),
                                         (40, 2, 64, [1000, 64]),                                          # 20 heads per group: two head chunks share a KV head
                                         (4, 1, 16, [0]), (3, 1, 128, [2048, 77, 5])])
-def test_u4_decode_step_matches_append_plus_attention(ops, n, g, S, lens):
+def test_quantised_decode_step_matches_append_plus_attention(ops, n, g, S, lens, mode):
     """dihip_span_attn_decode_step on the uint4 cache (round 4: Rotary + quantising append + attention in ONE launch,
-    span_attn_u4_mfma_kernel<FUSED>) against dihip_rope_kv_append + dihip_span_attn_decode_sync: the spans BYTE-identical; the
-    output equal to the rounding of one bf16 ulp (the new token -- dequantised from exactly the bytes the cache receives -- joins
-    the online softmax as a block of its own after the cached ones: another order of the same sums); row-major and FRAG32 forms
-    of the step bit-identical to each other."""
+    span_attn_u4_mfma_kernel<FUSED>) and on the int8 cache (round 5: span_attn_ft_mfma_kernel<FT, I8, FUSED>) against
+    dihip_rope_kv_append + dihip_span_attn_decode_sync: the spans BYTE-identical; the output equal to the rounding of one bf16 ulp
+    (uint4: the new token -- dequantised from exactly the bytes the cache receives -- joins the online softmax as a block of its
+    own after the cached ones; int8: the new token's codes and parameters are substituted in its own tile, but the split width comes
+    from max_seq_len instead of the request's length: another order of the same sums either way); row-major and FRAG32 forms of
+    the step bit-identical to each other."""
     from oracle import glue
     seed = n * 31 + S + len(lens)
-    H, ft, mode = 128, "bf16", "u4"
+    H, ft = 128, "bf16"
     B = len(lens)
     pool, kv, _, _ = build_batch(ops, np.random.default_rng(seed), lens, n, g, H, S, mode, ft, extra_tokens=2)
     pool2, kv2, _, _ = build_batch(ops, np.random.default_rng(seed), lens, n, g, H, S, mode, ft, extra_tokens=2)
@@ -393,7 +396,7 @@ def test_u4_decode_step_matches_append_plus_attention(ops, n, g, S, lens):
     torch.cuda.synchronize()
     assert int(sync.view(torch.int32).abs().sum()) == 0, "ticket words must be zero after the launch"
     np.testing.assert_allclose(got.float().cpu().numpy(), ref.float().cpu().numpy(), rtol=8e-3, atol=2e-3,
-                               err_msg="one-launch uint4 step differs from append + attention")
+                               err_msg=f"one-launch {mode} step differs from append + attention")
     for b in range(B):
         for i in range(len(kv.k_idx[b])):
             assert torch.equal(pool.span_view(kv.k_idx[b][i]), pool2.span_view(kv2.k_idx[b][i])), f"K span {b}/{i}"
