@@ -382,7 +382,12 @@ int dihip_span_attn_decode_fused_sync(void* stream, void* output, const void* qk
 /* The same with the output layout of dihip_span_attn_decode_sync (DIHIP_ACT_ROWMAJOR / DIHIP_ACT_FRAG32).  Round 4: the uint4
  * cache with bf16 activations is ONE launch as well -- Rotary, the quantising DecoderCacheAppend of the new token (byte-identical
  * to dihip_rope_kv_append) and the attention with its split merge -- instead of the append launch + the op-boundary kernel;
- * FRAG32 output is served by that form only (batch <= 32).  Workspace / sync as dihip_span_attn_decode_fused_sync. */
+ * FRAG32 output is served by the one-launch forms only (batch <= 32).  Round 5: the int8 cache (bf16 / f16 rows) is ONE launch as
+ * well (span_attn_ft_mfma_kernel<FT, I8, FUSED>: every wave of the workgroup that holds the new token quantises this step's K / V
+ * head into its own LDS row with the arithmetic of the append kernel and substitutes codes + parameters in its tiles; span bytes
+ * identical to dihip_rope_kv_append; DIHIP_ATTN_I8_FUSED=0 keeps the append launch).  The runners use it for batch <= 4, where it
+ * saves 1.8 us per layer (at batch 32 it measured +1.3: profiles/r05_i8_decode_step.txt).  f16 rows with the uint4 cache keep the
+ * append launch.  Workspace / sync as dihip_span_attn_decode_fused_sync. */
 int dihip_span_attn_decode_step(void* stream, void* output, const void* qkv, void* const* k_span_array,
                                 void* const* v_span_array, const uint32_t* old_seq_lens_dev, const float* rope_table,
                                 int batch, int n_heads, int n_groups, int head_size, int span_len,
