@@ -100,8 +100,13 @@ class ModelWeights:
 
 def _pack(q, s, z, spec, rows=None, cols=None, n_full=None):
     """Slice a quantised [K,N] weight (rows / cols = index lists or None) and pack it for the GPU."""
+    return ops.pack_lowp(*_slice(q, s, z, spec, rows, cols, n_full), spec.group, spec.wbits)
+
+
+def _slice(q, s, z, spec, rows=None, cols=None, n_full=None):
+    """A rank's slice of a quantised [K,N] weight, unpacked as the converter would hand it to the operator: (q, scales, zeros)."""
     if rows is None and cols is None:
-        return ops.pack_lowp(q.contiguous(), s.contiguous(), z.contiguous(), spec.group, spec.wbits)
+        return q.contiguous(), s.contiguous(), z.contiguous()
     if spec.wbits == 4:
         # work on unpacked nibbles for column slicing
         K = q.shape[0]
@@ -132,7 +137,7 @@ def _pack(q, s, z, spec, rows=None, cols=None, n_full=None):
         assert len(rows) % g == 0 and rows[0] % g == 0, "row split must be group aligned"
         grp = torch.tensor([r // g for r in rows[::g]], device=s.device)
         ss, zz = ss[grp, :], zz[grp, :]
-    return ops.pack_lowp(qq, ss.contiguous(), zz.contiguous(), spec.group, spec.wbits)
+    return qq, ss.contiguous(), zz.contiguous()
 
 
 def decisive_permutation(vocab, seed):
@@ -189,6 +194,13 @@ def build_random_model(cfg: ModelConfig, spec: QuantSpec, seed=1234, device="cud
                       "qkv_bias": b_qkv, "ln1": ln1, "ln2": ln2}
         cols = tp.qkv_columns(me, n, g, H) if nranks > 1 else None
         rows_o = tp.o_rows(me, H) if nranks > 1 else None
+        if fp is not None and nranks > 1:
+            # under tensor parallelism fp holds THIS RANK'S slices, as the reference's converter splits them for the operators
+            # (GROUP_VSPLIT qkv, HSPLIT o / down, VSPLIT gate / up; qwen_v15.py:540-569): what ref_graph.register_weights binds
+            fp[li].update(qkv=_slice(*qs["qkv"], spec, cols=cols, n_full=(n + 2 * g) * H), qkv_bias=b_qkv[cols].contiguous(),
+                          o=_slice(*qs["o"], spec, rows=rows_o, n_full=cfg.hidden),
+                          gate=_slice(*qs["gate"], spec, cols=ffn_cols, n_full=cfg.inter), up=_slice(*qs["up"], spec, cols=ffn_cols, n_full=cfg.inter),
+                          down=_slice(*qs["down"], spec, rows=ffn_cols, n_full=cfg.hidden))
         lw = LayerWeights(
             ln1=ln1,
             qkv=_pack(*qs["qkv"], spec, cols=cols, n_full=(n + 2 * g) * H),
@@ -259,6 +271,8 @@ def build_random_model(cfg: ModelConfig, spec: QuantSpec, seed=1234, device="cud
         assert cfg.hidden % (32 * nranks) == 0, "K-split lm_head: hidden must split into whole 32-row k-tiles per rank"
         kloc = cfg.hidden // nranks
         lm = ops.pack_dense(w_lm[rank * kloc:(rank + 1) * kloc, :].contiguous())
+        if fp is not None and nranks > 1:
+            fp["lm_head"] = w_lm[rank * kloc:(rank + 1) * kloc, :].contiguous()   # HSPLIT (model_base.py:690-703)
     else:
         lm = ops.pack_dense(w_lm[:, rank * vloc:(rank + 1) * vloc].contiguous())
     wbytes += lm.nbytes

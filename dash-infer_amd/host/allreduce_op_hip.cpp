@@ -31,6 +31,10 @@ class AllReduceOpHIP : public AsOperator {
         return AsStatus::ALLSPARK_RUNTIME_ERROR;
       return AsStatus::ALLSPARK_SUCCESS;
     }
+    const size_t bytes = (size_t)count_ * SizeofType(x->GetDataType());
+    if (h->GetP2PComm() && bytes <= dihip_p2p_ar_max_bytes() && bytes % 16 == 0)  // decode rows: latency bound on a ring, one shot over xGMI instead
+      return FromDihip(dihip_p2p_allreduce_sum(h->GetP2PComm(), h->GetStream(), x->GetDataPtr(), y->GetDataPtr(), (size_t)count_,
+                                               DihipDtype(x->GetDataType())));
     if (!h->GetRCCLComm()) return AsStatus::ALLSPARK_PARAM_ERROR;
     return FromDihip(dihip_allreduce_sum(h->GetRCCLComm(), h->GetStream(), x->GetDataPtr(), y->GetDataPtr(), (size_t)count_,
                                          DihipDtype(x->GetDataType())));

@@ -181,6 +181,11 @@ class HIPContext : public DeviceContext {
   void SetStream(hipStream_t s) { stream_ = s; }
   void* GetRCCLComm() const { return comm_; }
   void SetRCCLComm(void* c) { comm_ = c; }
+  // the one-shot peer-to-peer communicator for decode-sized messages (dihip_p2p_ar_create, include/dashinfer_hip.h section 6b), or
+  // null: the AllReduce operator uses it for messages up to dihip_p2p_ar_max_bytes() and RCCL beyond (bench.py --gpus N does the
+  // same choice in the Python runner); it is also what lets rank THREADS of one process on one GPU stand in for a node in tests
+  void* GetP2PComm() const { return p2p_comm_; }
+  void SetP2PComm(void* c) { p2p_comm_ = c; }
 
   // ---- annotations of the fused decode graph (host/fused_ops_hip.cpp; written at Init / Reshape, read at Forward) ----
   void AdvertiseLayoutPref(const std::string& tensor, const ActLayoutPref& p) const { layout_pref_[tensor] = p; }
@@ -215,6 +220,7 @@ class HIPContext : public DeviceContext {
  private:
   hipStream_t stream_ = nullptr;
   void* comm_ = nullptr;
+  void* p2p_comm_ = nullptr;
   mutable std::map<std::string, ActLayoutPref> layout_pref_;
   mutable std::map<std::string, int> act_layout_;
   mutable bool lens_on_device_ = false;

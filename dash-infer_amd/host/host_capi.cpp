@@ -122,6 +122,11 @@ int dihost_model_create(dihost_model_t* m, void* stream, int num_heads, int num_
   *m = p;
   return 0;
 }
+int dihost_model_set_p2p_comm(dihost_model_t m, void* p2p_comm) {
+  if (!m) return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  m->ctx.SetP2PComm(p2p_comm);
+  return 0;
+}
 int dihost_model_destroy(dihost_model_t m) {
   delete m;
   return 0;

@@ -13,6 +13,7 @@ vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
 _SIGS = {
     "dihost_model_create": (i32, [C.POINTER(vp), vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dihost_model_destroy": (i32, [vp]),
+    "dihost_model_set_p2p_comm": (i32, [vp, vp]),
     "dihost_set_tensor": (i32, [vp, C.c_char_p, i32, i32, C.POINTER(C.c_int64), vp]),
     "dihost_set_weight": (i32, [vp, C.c_char_p, i32, i32, C.POINTER(C.c_int64), vp]),
     "dihost_get_tensor": (i32, [vp, C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_int64), C.POINTER(vp)]),
@@ -88,6 +89,10 @@ class Model:
         _ck(lib().dihost_model_create(C.byref(self.h), stream, n_heads, n_groups, head_size, span, cache_mode, max_batch, max_len,
                                       rank, nranks, comm), "dihost_model_create")
         self._keep = []
+
+    def set_p2p_comm(self, handle):
+        """the rank's one-shot peer-to-peer communicator (capi dihip_p2p_ar_create) for the AllReduce operator"""
+        _ck(lib().dihost_model_set_p2p_comm(self.h, handle), "set_p2p_comm")
 
     def close(self):
         if self.h:

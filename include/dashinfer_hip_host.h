@@ -17,6 +17,10 @@ typedef struct dihost_model* dihost_model_t; /* HIPContext + tensor map + weight
 /* dtype codes are allspark DataType values (FLOAT32 1, FLOAT16 2, INT8 3, INT32 5, BFLOAT16 9, UINT8 10) */
 int dihost_model_create(dihost_model_t* m, void* stream, int num_heads, int num_groups, int size_per_head, int span_size,
                         int cache_mode, int max_batch, int max_length, int rank, int nranks, void* rccl_comm);
+/* tensor parallelism: the one-shot peer-to-peer communicator of this rank (dihip_p2p_ar_create), used by the AllReduce operator for
+ * decode-sized messages; RCCL (rccl_comm above) beyond dihip_p2p_ar_max_bytes().  One model per rank: a process per GPU on a node,
+ * or -- tests -- a thread per rank on one GPU (as_engine.cpp:243-286 runs a thread per rank too) */
+int dihost_model_set_p2p_comm(dihost_model_t m, void* p2p_comm);
 int dihost_model_destroy(dihost_model_t m);
 /* tensors are views of caller-owned device memory (torch tensors in the tests) */
 int dihost_set_tensor(dihost_model_t m, const char* name, int dtype, int ndim, const int64_t* shape, void* data);

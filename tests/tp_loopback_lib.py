@@ -242,3 +242,105 @@ def run_tp_decode(nranks, kv_mode, batch, wbits, group, comm_kind, overlap, moe=
         assert np.array_equal(ids_tp[sure], ref_ids[sure])
         if not np.array_equal(ids_tp, ref_ids):
             break  # a near-tie resolved differently: the sequences part here, nothing further to compare
+
+
+def run_tp_decode_host(nranks, kv_mode, batch, wbits, group):
+    """Tensor-parallel decode through the C++ OPERATOR LAYER: one hostapi.Model (HIPContext with rank / nranks, the rank's one-shot
+    P2P communicator) per rank THREAD, the reference's operator list with its AllReduce operators and the K-split lm_head
+    (ref_graph.qwen2_graph(tp_allreduce=True, tp_lm_head=True): qwen_v15.py:187-388, model_base.py:690-703) -> fusion pass ->
+    OpFactory(HIP) -> model runner, each rank over its own slices of the quantised weights (decoder.build_random_model(rank, nranks,
+    keep_fp=True): GROUP_VSPLIT / HSPLIT / VSPLIT as the reference's splitters cut them) and its own share of the KV heads.  Every rank
+    must hold the SAME all-reduced logits row and the same next token; both must match the single-rank DecodeSession (the row-parallel
+    layers only change the f32 summation order; the TP tail's logits are FT: tolerance 2^-7 of the logit scale).  The reference runs a
+    thread per rank in one process as well (as_engine.cpp:243-286)."""
+    from dash_infer_amd import decoder, hostapi, ops, ref_graph, tp
+    cfg = decoder.ModelConfig("tp-host-test", hidden=1024, layers=2, n_heads=8, n_kv=2, head_dim=128, inter=1024, vocab=4096)
+    if nranks == 8:
+        cfg = decoder.ModelConfig("tp8-host-test", hidden=1024, layers=2, n_heads=28, n_kv=4, head_dim=128, inter=1024, vocab=4096)
+    spec = decoder.QuantSpec(wbits, group)
+    steps, span, max_len = 5, 16, 32
+    rng = np.random.default_rng(nranks * 37 + batch)
+    ids0 = [int(t) for t in rng.integers(0, cfg.vocab, batch)]
+    model1 = decoder.build_random_model(cfg, spec, seed=99)
+    sess = decoder.DecodeSession(model1, batch, max_len=max_len, span_len=span, kv_mode=kv_mode)
+    sess.set_state(ids0, [0] * batch)
+    ref = []
+    for _ in range(steps):
+        sess.step()
+        torch.cuda.synchronize()
+        ref.append((sess.logits.cpu().numpy().copy(), sess.ids.cpu().numpy().copy()))
+    del sess, model1
+    shared = LoopbackP2PComm.Shared(nranks)
+    results, errors, reports = [None] * nranks, [], [None] * nranks
+    KV = {"none": 0, "i8": 1, "u4": 2}
+    nl, spr = cfg.layers, (max_len + span - 1) // span
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(0)
+            model = decoder.build_random_model(cfg, spec, seed=99, rank=rank, nranks=nranks, keep_fp=True, lm_head_split="k")
+            comm = LoopbackP2PComm(shared, rank, nranks)
+            g_loc = len(tp.shard_heads(cfg.n_heads, cfg.n_kv, nranks)[rank].kv_heads)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                with SETUP_LOCK:
+                    pool = ops.SpanPool(2 * batch * nl * spr + 4, g_loc, span, cfg.head_dim, kv_mode, torch.bfloat16)
+                    m = hostapi.Model(ops.cur_stream(), cfg.n_heads, cfg.n_kv, cfg.head_dim, span, KV[kv_mode], max_batch=batch, max_len=max_len,
+                                      rank=rank, nranks=nranks)
+                    m.set_p2p_comm(comm.handle)
+                    ref_graph.register_weights(m, model)
+                    ref_graph.add_graph(m, ref_graph.qwen2_graph(nl, wbits, group, cfg.eps, cfg.n_heads, cfg.n_kv, cfg.rope_theta,
+                                                                 tp_allreduce=True, tp_lm_head=True))
+                    reports[rank] = m.graph_build(fuse=True)
+                    for b in range(batch):
+                        ks = [[pool.alloc()[0] for _ in range(spr)] for _ in range(nl)]
+                        vs = [[pool.alloc()[0] for _ in range(spr)] for _ in range(nl)]
+                        m.request_adopt(0, ids0[b], ks, vs)
+                    torch.cuda.synchronize()
+                shared.bar.wait()
+                out = []
+                for _ in range(steps):
+                    m.decode_steps(1, graph=False)
+                    ids = m.sync_ids()
+                    _, shp, ptr = m.get_tensor("logits")
+                    st.synchronize()
+                    out.append((_view_bf16(ptr, shp).float().cpu().numpy().reshape(-1, shp[-1]).copy(), np.array(ids)))
+                    shared.bar.wait()
+                m.close()
+            results[rank] = out
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()[-1500:]))
+            shared.bar.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    shared.close()
+    assert not errors, errors
+    assert all(r is not None for r in results)
+    assert all(rep["fused"] for rep in reports), [rep["why"] for rep in reports]
+    for t in range(steps):
+        logits, ids_tp = results[0][t]
+        assert logits.shape[1] == cfg.vocab
+        for r in range(1, nranks):
+            assert np.array_equal(results[r][t][0], logits), f"step {t}: rank {r} holds another logits row than rank 0"
+            assert np.array_equal(results[r][t][1], ids_tp), f"step {t}: rank {r} chose another token"
+        ref_logits, ref_ids = ref[t]
+        scale = max(1.0, float(np.abs(ref_logits).max()))
+        tol = (6e-2 if kv_mode == "u4" else 1e-2) + 2.0 ** -7 * scale
+        np.testing.assert_allclose(logits, ref_logits, rtol=0, atol=tol, err_msg=f"step {t}")
+        top2 = np.sort(ref_logits, axis=-1)[:, -2:]
+        sure = (top2[:, 1] - top2[:, 0]) > 2 * tol
+        assert np.array_equal(ids_tp[sure], ref_ids[sure]), f"step {t}: greedy ids"
+        if not np.array_equal(ids_tp, ref_ids):
+            break
+    print(f"[host TP loop-back] nranks {nranks}, batch {batch}, kv {kv_mode}: {reports[0]['ops']} operators, logits within tolerance, ids equal", flush=True)
+
+
+def _view_bf16(ptr, shape):
+    """a torch view of device memory the C++ layer owns (tests/test_gpu_host_runner.py: view_of)"""
+    from tests.test_gpu_host_graph import view_of
+    return view_of(ptr, shape, torch.bfloat16)
