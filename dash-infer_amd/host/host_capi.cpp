@@ -6,7 +6,10 @@
 #include <sstream>
 #include <thread>
 
+#include <algorithm>
+
 #include "graph_wire.h"
+#include "weight_file.h"
 #include "model_runner.h"
 #include "operator.h"
 
@@ -142,6 +145,76 @@ int dihost_set_tensor(dihost_model_t m, const char* name, int dtype, int ndim, c
 }
 int dihost_set_weight(dihost_model_t m, const char* name, int dtype, int ndim, const int64_t* shape, void* data) {
   return put(m->weights, name, dtype, ndim, shape, data);
+}
+int dihost_get_weight(dihost_model_t m, const char* name, int* dtype, int* ndim, int64_t* shape8, void** data) {
+  auto it = m->weights.find(name);
+  if (it == m->weights.end()) return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  const AsTensor& t = *it->second;
+  if (dtype) *dtype = t.GetDataType();
+  if (ndim) *ndim = (int)t.GetShape().size();
+  if (shape8)
+    for (size_t i = 0; i < t.GetShape().size() && i < 8; ++i) shape8[i] = t.GetShape()[i];
+  if (data) *data = t.GetDataPtr();
+  return 0;
+}
+// the records of a serialized weight file (.asparam, host/weight_file.h) as text, one per line: name|dtype|d0,d1,...|split_mode|offset|nbytes
+// (no device work: usable without a GPU).  *need = bytes of the whole text incl. the terminator; out may be null / short
+int dihost_weight_file_index(const char* path, char* out, size_t cap, size_t* need) {
+  std::vector<WeightRecord> recs;
+  std::string err;
+  if (!path || !IndexWeightFile(path, &recs, &err)) {
+    g_err = err.empty() ? "weight file: null path" : err;
+    return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  }
+  std::string text;
+  for (const WeightRecord& r : recs) {
+    text += r.name + "|" + std::to_string((int)r.dtype) + "|";
+    for (size_t i = 0; i < r.shape.size(); ++i) text += (i ? "," : "") + std::to_string(r.shape[i]);
+    text += "|" + std::to_string(r.split_mode) + "|" + std::to_string(r.offset) + "|" + std::to_string(r.nbytes) + "\n";
+  }
+  if (need) *need = text.size() + 1;
+  if (out && cap > 0) {
+    const size_t n = std::min(cap - 1, text.size());
+    std::memcpy(out, text.data(), n);
+    out[n] = 0;
+  }
+  return 0;
+}
+// every record of the file becomes a weight of the model under its own name, in device memory the model OWNS (the weight-only
+// operators free it once they have re-laid it out, as the reference re-lays-out in place): what WeightManager::LoadWeightForModel
+// hands the operators (csrc/runtime/weight/weight_manager.cpp), for one rank (the TP split is the converter's / the caller's)
+int dihost_weights_load_file(dihost_model_t m, const char* path, int* count) {
+  if (!m) return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  std::vector<WeightRecord> recs;
+  std::string err;
+  if (!path || !IndexWeightFile(path, &recs, &err)) {
+    g_err = err.empty() ? "weight file: null path" : err;
+    return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  }
+  FILE* fp = std::fopen(path, "rb");
+  if (!fp) return (int)AsStatus::ALLSPARK_IO_ERROR;
+  std::vector<char> stage;
+  int n = 0;
+  for (const WeightRecord& r : recs) {
+    auto t = std::make_shared<AsTensor>(r.name, DeviceType::HIP, r.dtype, Shape(r.shape.begin(), r.shape.end()));
+    if ((long long)t->GetSizeInByte() < r.nbytes || (r.nbytes > 0 && !t->GetDataPtr())) {
+      std::fclose(fp);
+      g_err = "weight file: cannot allocate " + r.name;
+      return (int)AsStatus::ALLSPARK_MEMORY_ERROR;
+    }
+    stage.resize((size_t)r.nbytes);
+    if (std::fseek(fp, (long)r.offset, SEEK_SET) != 0 || std::fread(stage.data(), 1, stage.size(), fp) != stage.size() ||
+        (r.nbytes > 0 && hipMemcpy(t->GetDataPtr(), stage.data(), stage.size(), hipMemcpyHostToDevice) != hipSuccess)) {
+      std::fclose(fp);
+      g_err = "weight file: cannot read / upload " + r.name;
+      return (int)AsStatus::ALLSPARK_IO_ERROR;
+    }
+    m->weights[r.name] = t;
+    ++n;
+  }
+  std::fclose(fp);
+  if (count) *count = n;
+  return 0;
 }
 int dihost_get_tensor(dihost_model_t m, const char* name, int* dtype, int* ndim, int64_t* shape8, void** data) {
   auto it = m->tensors.find(name);

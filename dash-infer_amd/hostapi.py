@@ -14,6 +14,9 @@ _SIGS = {
     "dihost_model_create": (i32, [C.POINTER(vp), vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "dihost_model_destroy": (i32, [vp]),
     "dihost_model_set_p2p_comm": (i32, [vp, vp]),
+    "dihost_weight_file_index": (i32, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "dihost_weights_load_file": (i32, [vp, C.c_char_p, C.POINTER(i32)]),
+    "dihost_get_weight": (i32, [vp, C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_int64), C.POINTER(vp)]),
     "dihost_set_tensor": (i32, [vp, C.c_char_p, i32, i32, C.POINTER(C.c_int64), vp]),
     "dihost_set_weight": (i32, [vp, C.c_char_p, i32, i32, C.POINTER(C.c_int64), vp]),
     "dihost_get_tensor": (i32, [vp, C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_int64), C.POINTER(vp)]),
@@ -89,6 +92,19 @@ class Model:
         _ck(lib().dihost_model_create(C.byref(self.h), stream, n_heads, n_groups, head_size, span, cache_mode, max_batch, max_len,
                                       rank, nranks, comm), "dihost_model_create")
         self._keep = []
+
+    def load_weight_file(self, path):
+        """every record of a serialized weight file (.asparam) as a weight of the model, in memory the model owns -> records loaded"""
+        n = i32(0)
+        _ck(lib().dihost_weights_load_file(self.h, str(path).encode(), C.byref(n)), "weights_load_file")
+        return int(n.value)
+
+    def get_weight(self, name):
+        """-> (dtype code, shape, device pointer)"""
+        dt, nd, ptr = i32(), i32(), vp()
+        shp = (C.c_int64 * 8)()
+        _ck(lib().dihost_get_weight(self.h, name.encode(), C.byref(dt), C.byref(nd), shp, C.byref(ptr)), "get_weight")
+        return dt.value, [int(shp[i]) for i in range(nd.value)], ptr.value
 
     def set_p2p_comm(self, handle):
         """the rank's one-shot peer-to-peer communicator (capi dihip_p2p_ar_create) for the AllReduce operator"""
@@ -236,3 +252,16 @@ class Model:
 
     def set_phase(self, is_context):
         _ck(lib().dihost_set_phase(self.h, int(is_context)), "set_phase")
+
+
+def weight_file_index(path):
+    """The records of a serialized weight file (.asparam) -> [(name, dtype code, shape, split_mode, offset, nbytes)]; needs no GPU."""
+    need = C.c_size_t(0)
+    _ck(lib().dihost_weight_file_index(str(path).encode(), None, 0, C.byref(need)), "weight_file_index")
+    buf = C.create_string_buffer(need.value)
+    _ck(lib().dihost_weight_file_index(str(path).encode(), buf, need.value, None), "weight_file_index")
+    out = []
+    for line in buf.value.decode().splitlines():
+        name, dt, shape, split, off, nb = line.rsplit("|", 5)
+        out.append((name, int(dt), [int(d) for d in shape.split(",") if d], int(split), int(off), int(nb)))
+    return out

@@ -25,6 +25,16 @@ int dihost_model_destroy(dihost_model_t m);
 /* tensors are views of caller-owned device memory (torch tensors in the tests) */
 int dihost_set_tensor(dihost_model_t m, const char* name, int dtype, int ndim, const int64_t* shape, void* data);
 int dihost_set_weight(dihost_model_t m, const char* name, int dtype, int ndim, const int64_t* shape, void* data);
+/* A serialized weight file of the reference's converter (".asparam": python/pyhie/allspark/model/model_base.py -> csrc/utility/
+ * allsparkz_util.cpp:264-339; reader on the reference side: WeightFileParser, csrc/runtime/weight/weight_loader.cpp) --
+ *   _index: its records as text, one per line "name|dtype|d0,d1,...|split_mode|offset|nbytes" (DataType codes of allspark.proto; no
+ *           device work, *need = bytes incl. the terminator, `out` may be null);
+ *   _load_file: every record becomes a weight of the model under its own name in device memory the MODEL owns (freed by the
+ *           weight-only operators once re-laid-out); dense records only, little endian; *count = records loaded;
+ *   dihost_get_weight: a weight's type / shape / device pointer (tests). */
+int dihost_weight_file_index(const char* path, char* out, size_t cap, size_t* need);
+int dihost_weights_load_file(dihost_model_t m, const char* path, int* count);
+int dihost_get_weight(dihost_model_t m, const char* name, int* dtype, int* ndim, int64_t* shape8, void** data);
 /* output tensors are owned by the model: shape / pointer after Reshape */
 int dihost_get_tensor(dihost_model_t m, const char* name, int* dtype, int* ndim, int64_t* shape8, void** data);
 

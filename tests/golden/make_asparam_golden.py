@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""tests/golden/tiny_qwen2_a16w4.asparam: a serialized weight file written by the REFERENCE'S OWN writer -- allspark::util::
+save_allsparky_tofile + set_global_header of csrc/utility/allsparkz_util.cpp, compiled from where it lies into
+oracle/_ref/libdashinfer_ref_asparam.so (oracle/Makefile target refasparam) -- one record per weight of a 1-layer Qwen2-shaped model with
+A16W4 sub-channel weights, under the names and split modes the reference's converter gives them (qwen_v15.py:130-165, 540-569;
+quantization_utils.py:56-110).  The arrays are a pure function of the seed (tiny_model(): tests rebuild them to compare).
+Runs only where /root/reference exists (the writer is the reference's); the committed bytes travel.
+
+    python tests/golden/make_asparam_golden.py"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+OUT = os.path.dirname(os.path.abspath(__file__))
+# allspark.proto SplitMode
+NOSPLIT, VSPLIT, HSPLIT, GROUP_VSPLIT = 0, 1, 2, 6
+
+
+def ref_writer():
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libdashinfer_ref_asparam.so"))
+    lib.ref_asparam_append.restype = C.c_int
+    lib.ref_asparam_append.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_char, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
+    lib.ref_asparam_finish.restype = C.c_int
+    lib.ref_asparam_finish.argtypes = [C.c_char_p]
+    return lib
+
+
+def descr(a, bf16=False):
+    """(type letter, word size) as the converter writes them; bf16 arrays travel as uint16 here"""
+    if bf16:
+        return b"b", 2
+    return {"float32": (b"f", 4), "float16": (b"f", 2), "int8": (b"i", 1), "uint8": (b"u", 1), "int64": (b"i", 8), "int32": (b"i", 4)}[str(a.dtype)]
+
+
+def write(path, records):
+    """records: [(name, array, split_mode, bf16?)]"""
+    lib = ref_writer()
+    if os.path.exists(path):
+        os.remove(path)
+    for name, a, split, bf16 in records:
+        a = np.ascontiguousarray(a)
+        letter, word = descr(a, bf16)
+        shape = (C.c_int * a.ndim)(*a.shape)
+        assert lib.ref_asparam_append(path.encode(), name.encode(), a.ctypes.data, a.nbytes, letter, word, shape, a.ndim, split) == 0
+    assert lib.ref_asparam_finish(path.encode()) == 0
+
+
+def tiny_model(seed=5):
+    """1 layer, hidden 256, 2 query / 1 KV head of 128, intermediate 512, vocabulary 320, int4 g128: [(name, array, split, bf16)]"""
+    rng = np.random.default_rng(seed)
+    hidden, n, g, H, inter, vocab, G = 256, 2, 1, 128, 512, 320, 128
+    bf = lambda shape, s=0.05: (rng.normal(0, s, shape).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)   # bf16 bit patterns (truncated)
+    recs = [("embedding.word_embeddings", bf((vocab, hidden)), NOSPLIT, True)]
+
+    def lowp(name, K, N, split):
+        recs.append((name + ".weight", rng.integers(0, 256, (K, N // 2), dtype=np.uint8), split, False))                # two nibbles per byte
+        recs.append((name + ".weight.scale", bf((K // G, N), 0.01), split, True))
+        recs.append((name + ".weight.zero_point", bf((K // G, N), 3.0), split, True))
+
+    p = "decoder.layer.0."
+    recs.append((p + "attention.layernorm.gamma", bf((hidden,), 1.0), NOSPLIT, True))
+    lowp(p + "attention.self", hidden, (n + 2 * g) * H, GROUP_VSPLIT)
+    recs.append((p + "attention.self.bias", bf(((n + 2 * g) * H,), 0.1), GROUP_VSPLIT, True))
+    lowp(p + "attention.output.dense", n * H, hidden, HSPLIT)
+    recs.append((p + "ffn.layernorm.gamma", bf((hidden,), 1.0), NOSPLIT, True))
+    lowp(p + "ffn.intermediate.dense", hidden, inter, VSPLIT)
+    lowp(p + "ffn.linear.dense", hidden, inter, VSPLIT)
+    lowp(p + "ffn.output.dense", inter, hidden, HSPLIT)
+    recs.append(("final.layernorm.gamma", bf((hidden,), 1.0), NOSPLIT, True))
+    recs.append(("lm_head.weight", bf((hidden, vocab)), VSPLIT, True))
+    recs.append(("a.scalar.f32", np.array([1.5], np.float32), NOSPLIT, False))          # rank-1 shapes print as "(1,)"
+    recs.append(("an.int64.table", np.arange(12, dtype=np.int64).reshape(3, 4), NOSPLIT, False))
+    return recs
+
+
+def main():
+    recs = tiny_model()
+    path = os.path.join(OUT, "tiny_qwen2_a16w4.asparam")
+    write(path, recs)
+    print(path, os.path.getsize(path), "bytes,", len(recs), "records")
+
+
+if __name__ == "__main__":
+    main()

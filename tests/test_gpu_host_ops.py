@@ -508,3 +508,72 @@ def test_preprocess_id_and_update_id_follow_a_request_through_its_stop_condition
             assert got == [tok], (name, t)
             assert finish == (t >= sc["done_after"]), (name, t, finish)
     m.close()
+
+
+def test_weights_from_a_serialized_file(env):
+    """A model whose weights come from a serialized weight file (tests/golden/tiny_qwen2_a16w4.asparam: written by the REFERENCE'S OWN
+    writer, tests/golden/make_asparam_golden.py) through `dihost_weights_load_file` (host/weight_file.h): every record sits in device memory
+    under its name with the bytes of the file, and the fused operator list built over it -- context phase and decode steps -- gives logits
+    BIT-IDENTICAL to the same list over the same arrays bound from torch tensors (the path every other test takes).  Together with
+    tests/test_host_graph_serialized.py this is the reference's export -- graph + weights, as AsModel reads them (model.cpp:265-287,
+    weight_manager.cpp) -- entering the C++ layer with nothing hand-built in between."""
+    import importlib.util
+    import os
+    hostapi, ops = env
+    from dash_infer_amd import ref_graph
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "tests", "golden", "tiny_qwen2_a16w4.asparam")
+    spec = importlib.util.spec_from_file_location("make_asparam_golden", os.path.join(root, "tests", "golden", "make_asparam_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    recs = mod.tiny_model()
+    hidden, n, g, H, vocab, span, max_len = 256, 2, 1, 128, 320, 16, 64
+    TORCH = {"float32": torch.float32, "uint8": torch.uint8, "int64": torch.int64}
+    NAME = {"float32": "f32", "uint8": "u8", "int64": "i64"}
+
+    def run(from_file):
+        stream = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        pool = ops.SpanPool(2 * 1 * (max_len // span) + 4, g, span, H, "none", torch.bfloat16)
+        keep = []
+        with torch.cuda.stream(stream):
+            m = hostapi.Model(ops.cur_stream(), n, g, H, span, 0, max_batch=1, max_len=max_len)
+            if from_file:
+                assert m.load_weight_file(path) == len(recs)
+                for name, arr, _, bf16 in recs:      # the bytes in device memory are the file's
+                    dt, shape, ptr = m.get_weight(name)
+                    assert shape == list(arr.shape), name
+                    got = view_of(ptr, [int(arr.nbytes)], torch.uint8).cpu().numpy()
+                    assert got.tobytes() == np.ascontiguousarray(arr).tobytes(), name
+            else:
+                for name, arr, _, bf16 in recs:
+                    if bf16:
+                        t = torch.from_numpy(arr.view(np.int16).copy()).cuda().view(torch.bfloat16)
+                        m.set_weight(name, t, "bf16")
+                    else:
+                        t = torch.from_numpy(arr.copy()).cuda()
+                        m.set_weight(name, t, NAME[str(arr.dtype)])
+                    keep.append(t)
+            ref_graph.add_graph(m, ref_graph.qwen2_graph(1, 4, 128, 1e-6, n, g, 1e6))
+            rep = m.graph_build(fuse=True)
+            assert rep["fused"], rep["why"]
+            ks = [[pool.alloc()[0] for _ in range(max_len // span)]]
+            vs = [[pool.alloc()[0] for _ in range(max_len // span)]]
+            prompt = [int(t) for t in np.random.default_rng(2).integers(0, vocab, 21)]
+            out = [m.request_start(prompt, ks, vs)]
+            logits = []
+            for _ in range(3):
+                m.decode_steps(1, graph=True)
+                out += m.sync_ids()
+                _, shp, ptr = m.get_tensor("logits")
+                stream.synchronize()
+                logits.append(view_of(ptr, shp, torch.float32).clone())
+            m.close()
+        return out, logits
+
+    ids_a, lo_a = run(True)
+    ids_b, lo_b = run(False)
+    assert ids_a == ids_b
+    for t, (x, y) in enumerate(zip(lo_a, lo_b)):
+        assert torch.equal(x, y), f"step {t}: logits differ between file-loaded and tensor-bound weights"
+        assert torch.isfinite(x).all()
