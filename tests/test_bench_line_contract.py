@@ -1,0 +1,59 @@
+"""The committed driver-style bench line (profiles/r05z_bench_default.json: `python bench.py`, no flags, on an MI355X) against the contract the
+driver reads: one JSON object with metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline /
+dtype / data / config.workload, a `roofline` object for the dominant kernel and a `cpu_baseline` object -- and internally consistent numbers
+(value = batch / ms_per_step, roofline.frac = achieved / peak, the step's HBM fraction from its algorithmic bytes).  Guards the SHAPE of the line
+on CPU; the numbers themselves are the GPU box's."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line():
+    return json.load(open(os.path.join(ROOT, "profiles", "r05z_bench_default.json")))
+
+
+def test_required_fields_and_types():
+    d = _line()
+    for k, t in (("metric", str), ("value", (int, float)), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", (int, float)),
+                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert k in d and isinstance(d[k], t), k
+    assert "vs_baseline" in d and d["vs_baseline"] is None          # BASELINE.md holds no published number for this metric
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] in ("weak", "strong") and d["unit"] == "tokens/s"
+    assert "synthetic" in d["data"] and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["unit"] == d["unit"]
+
+
+def test_numbers_are_consistent():
+    d = _line()
+    batch = d["config"]["global_batch"]
+    assert abs(d["value"] - batch * 1e3 / d["ms_per_step"]) <= 2e-3 * d["value"]
+    r = d["roofline"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 2e-4
+    # achieved = algorithmic bytes per launch / the kernel's average duration on the profiler's clock
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_kernel_us_rocprof"] * 1e-6) / 1e9) <= 2e-3 * r["achieved"]
+    h = d["step_hbm"]
+    assert abs(h["frac_of_peak"] - h["achieved_GBps_per_gpu"] / 8000.0) <= 2e-4
+    assert abs(h["achieved_GBps_per_gpu"] - h["algorithmic_bytes_per_rank"] / (d["ms_per_step"] * 1e-3) / 1e9) <= 2e-3 * h["achieved_GBps_per_gpu"]
+    b = d["blocks"]
+    assert b["count"] == 5 and b["steps_each"] == d["steps"] and b["ms_per_step_min"] <= d["ms_per_step"] <= b["ms_per_step_max"]
+    # `value` is the C++ operator layer's figure; the Python runner and the unfused operator list are beside it
+    assert d["runner"].startswith("host") and d["host_runner"]["fused_graph"]["tokens_per_s"] == round(d["value"], 2) or \
+        abs(d["host_runner"]["fused_graph"]["tokens_per_s"] - d["value"]) < 0.02
+    assert d["host_runner"]["unfused_eager"]["tokens_per_s"] < d["value"] and d["python_runner"]["tokens_per_s"] > 0
+
+
+def test_extra_workloads_are_the_named_ones():
+    d = _line()
+    names = [w.get("workload") for w in d["extra"]["workloads"]]
+    assert names == ["int4_b32_u4kv", "int8_b1", "prefill_2048", "cfg3_rank", "tp8_rank_7b", "cfg5_moe"]
+    for w in d["extra"]["workloads"]:
+        assert "error" not in w, w
+        assert w["value"] > 0 and w["ms_per_step"] > 0 and "roofline" in w
