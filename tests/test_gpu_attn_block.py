@@ -138,3 +138,28 @@ def test_cpp_operator_list_runs_the_block_and_matches_decode_session(pkg):
     h.start(prompt[:40], k2, v2)
     h.steps(2, graph=True)
     h.close()
+
+
+def test_a_rank_that_does_not_carry_the_residual(pkg):
+    """Under tensor parallelism only rank 0 adds the residual (gemm_op.cpp:133-137): the other ranks call the launch with h_res = NULL and must
+    get exactly h_res = 0 (the all-reduce behind it sums the ranks' rows).  Same launch, same cache append."""
+    from dash_infer_amd import decoder, ops
+    model = _model(decoder, seed=41)
+    cfg = model.cfg
+    outs = []
+    for null_res in (True, False):
+        s = _session(decoder, model, 512, True)
+        assert s.attn_block
+        s.fill_cache_random(300, seed=2)
+        s.set_state([5], [300])
+        gen = torch.Generator(device="cuda").manual_seed(8)
+        h_in = torch.randn(1, cfg.hidden, generator=gen, device="cuda", dtype=torch.float32)
+        lw = model.layers[0]
+        out = torch.full_like(h_in, float("nan"))
+        res = None if null_res else torch.zeros_like(h_in)
+        ops.decode_attn_block(h_in, res, lw.ln1, cfg.eps, lw.qkv, lw.qkv_bias, lw.o, s.kv[0], s.old_lens, s.rope_tab, s.n_loc, s.g_loc, s.H, s.max_len,
+                              s.scale, s.attn_ws, s.block_sync, out=out)
+        torch.cuda.synchronize()
+        assert _err_word(s) == 0 and torch.isfinite(out).all()
+        outs.append((out.clone(), s.pool.pool.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
