@@ -2,6 +2,8 @@
 // csrc/core/operator/nccl/allreduce/allreduce_op.cpp:23-95): in -> out sum all-reduce over the RCCL
 // communicator of the context.  Unlike the reference (which calls ctx->Synchronize() after the
 // collective, allreduce_op.cpp:90) the op only enqueues: ordering is the stream's.
+#include <cstdlib>
+
 #include "dashinfer_hip.h"
 #include "operator.h"
 
@@ -25,7 +27,11 @@ class AllReduceOpHIP : public AsOperator {
     const HIPContext* h = static_cast<const HIPContext*>(ctx_);
     AsTensor* x = tensor_map_->at(in_names_[0]).get();
     AsTensor* y = tensor_map_->at(out_names_[0]).get();
-    if (h->GetNranks() == 1) {  // single rank: copy (allreduce_op.cpp:70-80 behaviour)
+    // single rank: copy (allreduce_op.cpp:70-80 behaviour) -- unless DIHIP_ALLREDUCE_FORCE_RCCL=1 sends a one-rank communicator through the
+    // collective itself (the only way a one-GPU box executes the RCCL path: tests/test_gpu_rccl_one_rank.py)
+    const char* fe = h->GetNranks() == 1 ? getenv("DIHIP_ALLREDUCE_FORCE_RCCL") : nullptr;
+    const bool force_rccl = fe && fe[0] == '1';
+    if (h->GetNranks() == 1 && !(force_rccl && h->GetRCCLComm())) {
       if (x->GetDataPtr() != y->GetDataPtr() &&
           hipMemcpyAsync(y->GetDataPtr(), x->GetDataPtr(), x->GetSizeInByte(), hipMemcpyDeviceToDevice, h->GetStream()) != hipSuccess)
         return AsStatus::ALLSPARK_RUNTIME_ERROR;

@@ -57,3 +57,52 @@ def test_extra_workloads_are_the_named_ones():
     for w in d["extra"]["workloads"]:
         assert "error" not in w, w
         assert w["value"] > 0 and w["ms_per_step"] > 0 and "roofline" in w
+
+
+# ---- round 6: the line the driver parses is SMALL and LAST (BENCH_r05.json came back `parsed: null` on a 21 KB line) ---------------------
+def _bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_headline_line_of_a_full_record_is_under_4_kb_and_keeps_the_contract():
+    b = _bench()
+    full = _line()                                     # round 5's 21 KB record: everything a run can attach
+    line = b.headline_line(full, "gpurun_out/bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) < 4096, len(text)
+    assert json.loads(text) == line
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "step_hbm", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"] and "workload" in line["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in line["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    # the secondary workloads ride as numbers only
+    assert [w["workload"] for w in line["extra"]] == ["int4_b32_u4kv", "int8_b1", "prefill_2048", "cfg3_rank", "tp8_rank_7b", "cfg5_moe"]
+    assert all(len(json.dumps(w)) < 260 for w in line["extra"])
+
+
+def test_headline_line_sheds_optional_parts_before_it_exceeds_the_limit():
+    b = _bench()
+    full = _line()
+    full["extra"]["workloads"] = full["extra"]["workloads"] * 8     # 48 secondary workloads: cannot fit
+    full["tp_ab"] = [{"allreduce": "rccl", "overlap": False, "tokens_per_s": 1.0, "error": "x" * 500}] * 8
+    line = b.headline_line(full, None)
+    assert len(json.dumps(line)) < 4096
+    for k in ("metric", "value", "ms_per_step", "config", "step_hbm", "roofline", "cpu_baseline"):
+        assert k in line, k
+
+
+def test_bench_prints_the_headline_last_and_alone():
+    """Structure of main(): exactly one print of the headline on the rank-0 path, after the detail file is written."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.count("print(json.dumps(headline_line(out, detail)), flush=True)") == 1
+    tail = main[main.index("print(json.dumps(headline_line(out, detail)), flush=True)"):]
+    assert "print(" not in tail[len("print(json.dumps(headline_line(out, detail)), flush=True)"):]
