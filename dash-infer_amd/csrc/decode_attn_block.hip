@@ -32,6 +32,8 @@
 // query heads per KV group.  Everything else: dihip_decode_attn_block_supported() == 0 and the caller keeps the launch chain.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 
 #include "gemv_stream_kernel.hpp"
 #include "span_attn_ft_mfma.hpp"
@@ -49,11 +51,13 @@ struct AttnBlockArgs {
   GemvArgs q;  // RMSNorm + qkv projection: x = f32 hidden row, gamma, eps, bias; output -> qkv_gran
   GemvArgs o;  // o projection: x <- out_gran; h_out = h_res + x . Wo
   AttnArgs a;
-  unsigned* state;               // [0] epoch, [1] error
+  unsigned* state;               // [0] epoch, [1] error, [2] record-buffer parity
   unsigned long long* qkv_gran;  // [(n + 2g) * H]
   unsigned long long* out_gran;  // [n * H / 2]
   size_t out_gran_bytes;
   unsigned* grp_flag;            // [g]
+  unsigned* rec;                 // polled split records [n][nsplits][ATTN_PSTRIDE] (zero between launches), or null: ticket protocol
+  unsigned rec_bytes;
   int NA, NG;                    // attention / GEMV workgroups
   unsigned spin_limit;
   unsigned long long* trace;     // diagnostics (`make trace` build + dihip_debug_set_trace): [workgroup][32] wall-clock stamps, or null
@@ -205,6 +209,9 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
     ho.err = p.state + 1;
     ho.tag = tag;
     ho.spin_limit = p.spin_limit;
+    ho.rec = p.rec;
+    ho.rec_bytes = p.rec_bytes;
+    ho.parity = p.state[2] & 1u;
     const int ns = p.a.nsplits;
     span_attn_ft_mfma_body<DIHIP_BF16, DIHIP_KV_NONE, true, true>(p.a, bid % ns, bid / ns, 0, ns, p.a.g, 1, smem, &ho);
     return;
@@ -394,7 +401,10 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
   DIHIP_AB_STAMP(7);
 #undef DIHIP_AB_STAMP
   // the next launch's epoch (see the header: every workgroup has read the old one by now)
-  if (lb == 0 && tid == 0) p.state[0] = tag;
+  if (lb == 0 && tid == 0) {
+    p.state[0] = tag;
+    p.state[2] = (p.state[2] & 1u) ^ 1u;  // record-buffer parity of the next launch (its own word: the tag skips 0 when it wraps)
+  }
 }
 
 static bool attn_block_enabled() {
@@ -403,8 +413,9 @@ static bool attn_block_enabled() {
 }
 
 struct AbLayout {
-  size_t flags, tickets, qkv_gran, out_gran, total;
+  size_t flags, tickets, qkv_gran, out_gran, rec, rec_bytes, total;
 };
+constexpr int AB_POLLED_MAX_SPLITS = 32;  // polled split records: one load batch of the merger covers every split
 // attention / GEMV workgroup counts: every workgroup resident (<= one per CU), every GEMV workgroup owns >= 1 tile of both matrices
 static bool ab_grid(int n_heads, int n_groups, int head_size, int hidden, int nsplits, int* NA, int* NG) {
   const int ncu = cached_num_cus();
@@ -419,7 +430,9 @@ static AbLayout ab_layout(int n_heads, int n_groups, int head_size) {
   l.tickets = 128;
   l.qkv_gran = (l.tickets + (size_t)n_groups * 128 + 255) & ~(size_t)255;
   l.out_gran = l.qkv_gran + (size_t)(n_heads + 2 * n_groups) * head_size * 8;
-  l.total = l.out_gran + (size_t)n_heads * head_size / 2 * 8;
+  l.rec = (l.out_gran + (size_t)n_heads * head_size / 2 * 8 + 255) & ~(size_t)255;
+  l.rec_bytes = (size_t)n_heads * AB_POLLED_MAX_SPLITS * ATTN_PSTRIDE * sizeof(float);  // one buffer; two alternate by launch parity
+  l.total = l.rec + 2 * l.rec_bytes;
   return l;
 }
 
@@ -517,6 +530,26 @@ int dihip_decode_attn_block(void* stream, int wbits, const float* h_in, const fl
   p.qkv_gran = reinterpret_cast<unsigned long long*>(sb + lay.qkv_gran);
   p.out_gran = reinterpret_cast<unsigned long long*>(sb + lay.out_gran);
   p.out_gran_bytes = (size_t)n_heads * head_size / 2 * 8;
+  // split records polled by the group's merger instead of write-through + drain + ticket + reload (DIHIP_ATTN_BLOCK_POLLED=0: A/B)
+  static const bool polled = !env_off("DIHIP_ATTN_BLOCK_POLLED");
+  if (polled && ns <= AB_POLLED_MAX_SPLITS) {
+    p.rec = reinterpret_cast<unsigned*>(sb + lay.rec);
+    p.rec_bytes = (unsigned)((size_t)n_heads * ns * ATTN_PSTRIDE * sizeof(float));
+    // the record buffers are zero between launches only where the LAST launch's owners zeroed them: a launch with another record
+    // layout on the same sync buffer (another split count) starts from a cleared region (a memset node when captured; rare)
+    static std::mutex mu;
+    static std::unordered_map<const void*, unsigned> last_layout;
+    const unsigned key = ((unsigned)n_heads << 16) | (unsigned)ns;
+    bool clear = false;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = last_layout.find(sync);
+      clear = it != last_layout.end() && it->second != key;
+      last_layout[sync] = key;
+    }
+    if (clear)
+      DIHIP_CHECK_HIP(hipMemsetAsync(sb + lay.rec, 0, 2 * lay.rec_bytes, reinterpret_cast<hipStream_t>(stream)), DIHIP_RUNTIME_ERROR);
+  }
   static const unsigned spin_limit = (unsigned)std::max(1024, env_int("DIHIP_ATTN_BLOCK_SPINS", 1 << 18));
   p.spin_limit = spin_limit;
   AttnArgs& a = p.a;

@@ -49,6 +49,12 @@ struct AttnHandoff {
   unsigned* err;                       // set non-zero when a bounded wait gave up (results are then garbage, nothing hangs)
   unsigned tag;
   unsigned spin_limit;
+  // polled split records (round 6; null: write-through records + arrival ticket in AttnArgs::partials): TWO buffers of
+  // [n][nsplits][ATTN_PSTRIDE] words (rec_bytes each) inside the block's own sync buffer, used alternately by launch parity, zero
+  // before use.  See merge_polled_items (span_attn_ft_mfma.hpp).
+  unsigned* rec;
+  unsigned rec_bytes;
+  unsigned parity;
 };
 
 // decode-step form on the matrix cores (span_attn.hip); returns a DIHIP status, DIHIP_PARAM_ERROR with

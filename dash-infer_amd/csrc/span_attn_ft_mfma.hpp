@@ -216,6 +216,133 @@ __device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float*
   // (GRAN: no flag behind the granules -- the consumers poll the group's first granule, then sweep)
 }
 
+// Polled split records (AttnHandoff::rec; fused attention block, round 6).  Replaces write-through + drain + ticket + reload of
+// attn_block_epilogue_wt on the block's critical path (profiles/r06_attn_block_timeline.txt: tiles done -> merged granules 4.8 us,
+// 2.9 of them one workgroup pulling 17 x 7 records = 123 KB per pass through its CU's memory queue):
+//   * every split workgroup stores its record COMPLEMENTED (~bits) into the launch's record buffer (zero beforehand) with 16-byte
+//     write-through stores -- no drain, no ticket;
+//   * the merge is DISTRIBUTED: the group's (head, 4-dim) items are dealt over its split workgroups (14 each at 17 splits x 7
+//     heads); the owner of an item polls the item's chunk of every split record until none is zero (the data is the flag: a 16-byte
+//     store lands whole; ~6 KB per pass and workgroup), merges in split order with merge_split_records' single-batch arithmetic
+//     (bit-identical output) and publishes the item's output granules;
+//   * two record buffers alternate by launch parity: the owner zeroes its chunks of the OTHER buffer (the previous launch's records,
+//     whose readers are long gone) for the next launch -- a reader never races a reset.
+template <int FT, int MB>
+__device__ __forceinline__ void merge_polled_items(const AttnArgs& a, const AttnHandoff* ho, int b, int h0, int i0, int cnt,
+                                                   unsigned long long* tr) {
+  constexpr int H = 128;
+  constexpr uint32_t RB = ATTN_PSTRIDE * (uint32_t)sizeof(float);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint32_t half = ho->rec_bytes;  // bytes of one buffer
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ho->rec, 0, (int)(2 * half), 0x00020000);
+  const auto grsrc = __builtin_amdgcn_make_buffer_rsrc(ho->out_gran, 0, (int)ho->out_gran_bytes, 0x00020000);
+  const uint32_t cur = ho->parity ? half : 0u, oth = ho->parity ? 0u : half;
+  for (int e0 = (tid & ~63); e0 < cnt; e0 += ATTN_THREADS) {  // whole waves (the retry is wave-uniform); a wave beyond the slice leaves
+    const int item = i0 + min(e0 + lane, cnt - 1);
+    const int h = item >> 5, dq = item & 31;
+    const uint32_t hoff = (uint32_t)(((size_t)b * a.n + h0 + h) * a.nsplits) * RB;
+    u32x4_t ov[MB];
+    u32x2_t mv[MB];
+    for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+      for (int j = 0; j < MB; ++j) {
+        const uint32_t ro = cur + hoff + (uint32_t)min(j, a.nsplits - 1) * RB;
+        ov[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ro + dq * 16, 0, 16 /* sc1 */);
+        mv[j] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, ro + H * 4, 0, 16);
+      }
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < MB; ++j) ok = ok && ((ov[j][0] | ov[j][1] | ov[j][2] | ov[j][3]) != 0u) && ((mv[j][0] | mv[j][1]) != 0u);
+      if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+      if (spins > ho->spin_limit) {  // gives up (wave-uniform): garbage results, flagged, never a hang
+        if (lane == 0) __hip_atomic_store(ho->err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+#if defined(DIHIP_GEMV_TRACE) && DIHIP_GEMV_TRACE
+    if (tr) tr[6] = wall_clock64();
+#endif
+    float bm = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < MB; ++j)
+      if (j < a.nsplits) bm = fmaxf(bm, __uint_as_float(~mv[j][0]));
+    // (merge_split_records with one batch: mm = -inf, so the carry is 0 and ll / oo start from 0 * 0)
+    float ll = 0.f;
+    f32x4_t oo = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      if (j < a.nsplits) {
+        const float c = safe_exp_diff(__uint_as_float(~mv[j][0]), bm);
+        ll = fmaf(__uint_as_float(~mv[j][1]), c, ll);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) oo[q] = fmaf(__uint_as_float(~ov[j][q]), c, oo[q]);
+      }
+    }
+    float r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = ll > 0.f ? oo[q] / ll : 0.f;
+    if (e0 + lane < cnt) {
+      const u32x4_t gv = {pack_ft2<FT>(r[0], r[1]), ho->tag, pack_ft2<FT>(r[2], r[3]), ho->tag};
+      __builtin_amdgcn_raw_buffer_store_b128(gv, grsrc, (uint32_t)((((size_t)b * a.n + h0 + h) * (H / 2) + dq * 2) * 8), 0, 16 /* sc1 */);
+      // this item's chunks of the OTHER buffer back to zero for the next launch (write-through: no line stays in this XCD's L2)
+      const u32x4_t z4 = {0u, 0u, 0u, 0u};
+      for (int j = 0; j < a.nsplits; ++j) {
+        const uint32_t ro = oth + hoff + (uint32_t)j * RB;
+        __builtin_amdgcn_raw_buffer_store_b128(z4, rsrc, ro + dq * 16, 0, 16);
+        if (dq == 0) __builtin_amdgcn_raw_buffer_store_b128(z4, rsrc, ro + H * 4, 0, 16);
+      }
+    }
+  }
+}
+
+template <int FT, int HC>
+__device__ __forceinline__ void attn_block_epilogue_polled(const AttnArgs& a, float* lds, int b, int h0, int nh, int split,
+                                                           unsigned long long* tr, const AttnHandoff* ho) {
+  constexpr int H = 128;
+  const int tid = threadIdx.x;
+  const uint32_t half = ho->rec_bytes;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ho->rec, 0, (int)(2 * half), 0x00020000);
+  const uint32_t cur = ho->parity ? half : 0u;
+  __syncthreads();
+  for (int e = tid; e < nh * 32; e += ATTN_THREADS) {  // the block record: the arithmetic of attn_block_epilogue_wt
+    const int h = e >> 5, dq = e & 31;
+    float mm = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) mm = fmaxf(mm, lds[(w * HC + h) * ATTN_PSTRIDE + H]);
+    float ll = 0.f;
+    f32x4_t oo = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* rec = lds + (w * HC + h) * ATTN_PSTRIDE;
+      const float c = safe_exp_diff(rec[H], mm);
+      ll += rec[H + 1] * c;
+      const f32x4_t ov = *reinterpret_cast<const f32x4_t*>(rec + dq * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) oo[j] += ov[j] * c;
+    }
+    const uint32_t roff = cur + (uint32_t)((((size_t)b * a.n + h0 + h) * a.nsplits + split) * ATTN_PSTRIDE * sizeof(float));
+    const u32x4_t ob = __builtin_bit_cast(u32x4_t, oo);
+    const u32x4_t oc = {~ob[0], ~ob[1], ~ob[2], ~ob[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(oc, rsrc, roff + dq * 16, 0, 16 /* sc1 */);
+    if (dq == 0) {
+      const u32x4_t ml = {~__float_as_uint(mm), ~__float_as_uint(ll), ~0u, ~0u};
+      __builtin_amdgcn_raw_buffer_store_b128(ml, rsrc, roff + H * 4, 0, 16);
+    }
+  }
+#if defined(DIHIP_GEMV_TRACE) && DIHIP_GEMV_TRACE
+  if (tr) tr[4] = wall_clock64();
+#endif
+  // this workgroup's slice of the group's items (no drain: the stores are on their way; the owners' polls see them land)
+  const int items = nh * 32, per = (items + a.nsplits - 1) / a.nsplits;
+  const int i0 = split * per, cnt = min(per, items - i0);
+  if (cnt <= 0) return;
+  if (a.nsplits <= 8) merge_polled_items<FT, 8>(a, ho, b, h0, i0, cnt, tr);
+  else if (a.nsplits <= 16) merge_polled_items<FT, 16>(a, ho, b, h0, i0, cnt, tr);
+  else if (a.nsplits <= 24) merge_polled_items<FT, 24>(a, ho, b, h0, i0, cnt, tr);
+  else merge_polled_items<FT, 32>(a, ho, b, h0, i0, cnt, tr);
+}
+
 constexpr int MF_HC = 16;   // query heads per workgroup chunk (MFMA N)
 constexpr int MF_TOK = 32;  // tokens per wave iteration
 
@@ -254,10 +381,16 @@ __device__ __forceinline__ u32x4_t ld_qkv16(const uint16_t* p) { return *reinter
 #if defined(DIHIP_GEMV_TRACE) && DIHIP_GEMV_TRACE
 #define DIHIP_ATTN_STAMP(I)                                                                                          \
   do {                                                                                                               \
-    if (a.trace && threadIdx.x < 256) a.trace[(((size_t)bz * gy + by) * gx + bx) * 32 + (threadIdx.x >> 6) * 8 + (I)] = wall_clock64(); \
+    if (a.trace && threadIdx.x < 192) a.trace[(((size_t)bz * gy + by) * gx + bx) * 32 + (threadIdx.x >> 6) * 8 + (I)] = wall_clock64(); \
+  } while (0)
+// wave 0's finer stamps inside the tile loop (slots 24 .. 31: wave 3 does not stamp)
+#define DIHIP_ATTN_STAMPX(I)                                                                                         \
+  do {                                                                                                               \
+    if (a.trace && threadIdx.x < 64) a.trace[(((size_t)bz * gy + by) * gx + bx) * 32 + 24 + (I)] = wall_clock64();   \
   } while (0)
 #else
 #define DIHIP_ATTN_STAMP(I) do { } while (0)
+#define DIHIP_ATTN_STAMPX(I) do { } while (0)
 #endif
 
 // GATHER (fused attention block, FUSED form only): this step's q / k / v elements arrive as granules from the qkv GEMV's
@@ -470,6 +603,7 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
       }
     }
     __syncthreads();
+    DIHIP_ATTN_STAMPX(4);  // granules swept into the LDS image
   }
   {
     const bool hv = ni < nh;
@@ -655,6 +789,7 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
         for (int i = 0; i < 8; ++i)
           *reinterpret_cast<u32x4_t*>(vt + (i * 4 + (lane >> 4)) * MF_VPITCH + (lane & 15) * 16) = vreg[i];
       }
+      DIHIP_ATTN_STAMPX(0);  // V tile written to LDS
       load_v(tb + STEP);
       // ---- scores of the 32 tokens (transposed): sc[c][r] = token tb + c*16 + kb*4 + r, head ni
       float sc[2][4];
@@ -679,6 +814,7 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
           sc[c][rr] = tb + c * 16 + kb * 4 + rr < t1 ? v : -INFINITY;
         }
       }
+      DIHIP_ATTN_STAMPX(1);  // scores done
       load_k(tb + STEP);
       // ---- online softmax (lane-local + two cross-row shuffles)
       float mn = m;
@@ -726,6 +862,7 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) o[dt][rr] *= corr;
       }
+      DIHIP_ATTN_STAMPX(2);  // softmax done
       // ---- O^T += V^T . P: A = V^T from the LDS tile by transpose reads; k-slot j = token (j>>2)*16 + kb*4 + (j&3)
       const u32x4_t pkv = {pk[0], pk[1], pk[2], pk[3]};
       const u32x4_t plv = {pl[0], pl[1], pl[2], pl[3]};
@@ -739,6 +876,7 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
       }
     }
   }
+  DIHIP_ATTN_STAMPX(3);  // loop left
   l = rows_sum(l);
   if constexpr (Q8) {
     czero = rows_sum(czero);
@@ -756,6 +894,14 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
     if (kb == 0) {
       rec[H] = m;
       rec[H + 1] = l;
+    }
+  }
+  if constexpr (GATHER) {
+    if (ho->rec) {  // polled records (nsplits <= 32): no drain, no ticket
+      attn_block_epilogue_polled<FT, HC>(a, lds, b, h0, nh, split,
+                                         a.trace ? a.trace + (((size_t)bz * gy + by) * gx + bx) * 32 + (threadIdx.x >> 6) * 8 : nullptr, ho);
+      DIHIP_ATTN_STAMP(7);
+      return;
     }
   }
   if constexpr (FUSED) {

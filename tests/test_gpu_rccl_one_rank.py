@@ -10,7 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-DT = {torch.float32: 1, torch.float16: 2, torch.bfloat16: 9}
+DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}   # DIHIP_F32 / DIHIP_F16 / DIHIP_BF16 (span::DataType numbering)
 
 
 @pytest.fixture(scope="module")
@@ -48,9 +48,9 @@ def test_allreduce_sum_over_one_rank_is_the_input(comm, dtype, count):
 def test_allreduce_refuses_what_the_reference_refuses(comm):
     lib, h = comm
     x = torch.zeros(16, dtype=torch.int32, device="cuda")
-    assert lib.dihip_allreduce_sum(h, None, x.data_ptr(), x.data_ptr(), 16, 5) != 0      # int32: GetNcclType has no entry (nccl_utils.hpp:9-27)
-    assert lib.dihip_allreduce_sum(None, None, x.data_ptr(), x.data_ptr(), 16, 1) != 0   # no communicator
-    assert lib.dihip_allreduce_sum(h, None, x.data_ptr(), x.data_ptr(), 0, 1) == 0       # empty message: nothing to do
+    assert lib.dihip_allreduce_sum(h, None, x.data_ptr(), x.data_ptr(), 16, 5) != 0      # not an FT code: GetNcclType has no entry (nccl_utils.hpp:9-27)
+    assert lib.dihip_allreduce_sum(None, None, x.data_ptr(), x.data_ptr(), 16, 0) != 0   # no communicator
+    assert lib.dihip_allreduce_sum(h, None, x.data_ptr(), x.data_ptr(), 0, 0) == 0       # empty message: nothing to do
 
 
 def test_allreduce_inside_a_captured_graph(comm):
@@ -61,14 +61,14 @@ def test_allreduce_inside_a_captured_graph(comm):
     y = torch.zeros_like(x)
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
-        assert lib.dihip_allreduce_sum(h, ops.cur_stream(), x.data_ptr(), y.data_ptr(), x.numel(), 9) == 0   # warm: RCCL's lazy set-up outside capture
+        assert lib.dihip_allreduce_sum(h, ops.cur_stream(), x.data_ptr(), y.data_ptr(), x.numel(), 2) == 0   # warm: RCCL's lazy set-up outside capture
     s.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.stream(s):
         with torch.cuda.graph(g, stream=s):
-            assert lib.dihip_allreduce_sum(h, ops.cur_stream(), x.data_ptr(), y.data_ptr(), x.numel(), 9) == 0, lib.dihip_last_error()
+            assert lib.dihip_allreduce_sum(h, ops.cur_stream(), x.data_ptr(), y.data_ptr(), x.numel(), 2) == 0, lib.dihip_last_error()
             y.mul_(2)
-            assert lib.dihip_allreduce_sum(h, ops.cur_stream(), y.data_ptr(), y.data_ptr(), x.numel(), 9) == 0
+            assert lib.dihip_allreduce_sum(h, ops.cur_stream(), y.data_ptr(), y.data_ptr(), x.numel(), 2) == 0
     for i in range(3):
         x.fill_(float(i + 1))
         g.replay()

@@ -92,4 +92,5 @@ if "trace" in os.environ.get("DIHIP_LIB_DIR", ""):
                 rel = (col - base) / 100.0
                 print(f"  {i} {nm:32s} {rel.median().item():7.2f} {rel.max().item():7.2f}   (n={col.numel()})")
     show(t[:na][used[:na]][:, :8], names_a, "attention workgroups, wave 0")
+    show(t[:na][used[:na]][:, 24:32], ["V tile in LDS", "scores done", "softmax done", "loop left", "granules swept"], "attention workgroups, wave 0, inside the tile")
     show(t[na:][used[na:]][:, :10], names_g, "GEMV workgroups, wave 0 (stamps 8, 9 come between 3 and 4)")
