@@ -46,6 +46,13 @@ void span_attn_block_plan(int batch, int n_heads, int n_groups, int max_seq_len,
 
 constexpr int AB_THREADS = GEMV_THREADS;  // 8 waves
 constexpr int AB_RING = 8;                // 1 KiB weight chunks a wave holds per GEMV: the whole share is resident
+#ifndef DIHIP_AB_EARLY
+#define DIHIP_AB_EARLY 4
+#endif
+constexpr int AB_EARLY = DIHIP_AB_EARLY;  // slots of the qkv share requested before the RMSNorm prologue (the rest at its barrier)
+#ifndef DIHIP_AB_WAVE_SWEEP
+#define DIHIP_AB_WAVE_SWEEP 1             // every wave sweeps ITS k-slice of the attention output (0: workgroup sweep between two barriers, round 5)
+#endif
 
 struct AttnBlockArgs {
   GemvArgs q;  // RMSNorm + qkv projection: x = f32 hidden row, gamma, eps, bias; output -> qkv_gran
@@ -93,30 +100,35 @@ __device__ __forceinline__ AbShare ab_share(const GemvArgs& g, int bid, int NB, 
   return s;
 }
 
-// the whole share requested at once, in the order the stand-alone kernel streams it.  Slots beyond the share re-read the head
-// of the matrix: every asm load is unconditional, so no register of the ring is defined on one path only (a phi on an asm
-// output may be resolved by a copy BEFORE the data has landed: tools/audit_asm_loads.py)
-__device__ __forceinline__ void ab_issue(const GemvArgs& g, const AbShare& s, u32x4_t (&wb)[AB_RING], uint32_t (&sb)[AB_RING], int lane) {
-  const char* wtile = s.wtile;
-  const char* stile = s.stile;
-  const char* iwp = wtile;
-  const char* isp = stile;
+// the share is requested in the order the stand-alone kernel streams it, slots [J0, J1) per call (the cursor carries on).  Slots
+// beyond the share re-read the head of the matrix: every asm load is unconditional, so no register of the ring is defined on one
+// path only (a phi on an asm output may be resolved by a copy BEFORE the data has landed: tools/audit_asm_loads.py)
+struct AbCursor {
+  const char* wtile;
+  const char* stile;
+  const char* iwp;
+  const char* isp;
+  int ikt;
+};
+__device__ __forceinline__ AbCursor ab_cursor(const AbShare& s) { return AbCursor{s.wtile, s.stile, s.wtile, s.stile, s.k_lo}; }
+template <int J0, int J1>
+__device__ __forceinline__ void ab_issue(const GemvArgs& g, const AbShare& s, AbCursor& c, u32x4_t (&wb)[AB_RING], uint32_t (&sb)[AB_RING],
+                                         int lane) {
   const char* const dummy = reinterpret_cast<const char*>(g.w0);
-  int ikt = s.k_lo;
   const uint32_t voff_w = (uint32_t)lane * 16u, voff_s = (uint32_t)(lane & 15) * 4u;
 #pragma unroll
-  for (int j = 0; j < AB_RING; ++j) {
+  for (int j = J0; j < J1; ++j) {
     const bool real = j < s.total;
-    stream_load_b128(wb[j], uniform_ptr(real ? iwp : dummy), voff_w);
-    stream_load_b32(sb[j], uniform_ptr(real ? isp : dummy), voff_s);
-    iwp += 1024;
-    isp += 64;
-    if (++ikt == s.k_hi) {
-      ikt = s.k_lo;
-      wtile += s.wstep;
-      stile += s.sstep;
-      iwp = wtile;
-      isp = stile;
+    stream_load_b128(wb[j], uniform_ptr(real ? c.iwp : dummy), voff_w);
+    stream_load_b32(sb[j], uniform_ptr(real ? c.isp : dummy), voff_s);
+    c.iwp += 1024;
+    c.isp += 64;
+    if (++c.ikt == s.k_hi) {
+      c.ikt = s.k_lo;
+      c.wtile += s.wstep;
+      c.stile += s.sstep;
+      c.iwp = c.wtile;
+      c.isp = c.stile;
     }
   }
 }
@@ -263,7 +275,11 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
   const AbShare sq = ab_share(q, lb, NB, wave);
   u32x4_t wq[AB_RING], wo[AB_RING];
   uint32_t sq_[AB_RING], so_[AB_RING];
-  ab_issue(q, sq, wq, sq_, lane);
+  // the qkv share in two halves, AB_EARLY slots here and the rest at the RMSNorm's barrier: a CU holds ~32 KiB of outstanding misses,
+  // and eight waves asking for 8 KiB each queue the second half of the workgroup behind the first (the stand-alone kernel's 4 + 4
+  // ring fill, profiles/r03_gemv_wave_timeline.txt); -DDIHIP_AB_EARLY=8: everything at once (round 5)
+  AbCursor cq = ab_cursor(sq);
+  ab_issue<0, AB_EARLY>(q, sq, cq, wq, sq_, lane);
 
   uint16_t* xs = reinterpret_cast<uint16_t*>(smem + 256);
   float* xsum_q = reinterpret_cast<float*>(smem + 256 + gemv_xs_bytes(1, q.RS));
@@ -271,7 +287,7 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
   if (tid < 16) reinterpret_cast<u32x4_t*>(smem)[tid] = u32x4_t{0u, 0u, 0u, 0u};  // zero block (A rows >= M)
 
   // ---- RMSNorm prologue (gemv_stream_body PRO_RMSNORM, one row): rstd = 1/sqrt(mean(x^2)+eps); x_norm = FT((gamma*x)*rstd) ----
-  stream_wait<2 * AB_RING>();  // everything older than the ring: the early batch
+  stream_wait<2 * AB_EARLY>();  // everything older than the ring's first part: the early batch
 #pragma unroll
   for (int j = 0; j < 4; ++j) early_landed(ev[j]);
 #pragma unroll
@@ -292,6 +308,7 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
     ss = wave_sum(ss);
     if (lane == 0) red_q[wave] = ss;
     __syncthreads();
+    ab_issue<AB_EARLY, AB_RING>(q, sq, cq, wq, sq_, lane);  // (the rest of the qkv share flies while the row is normalised and staged)
     float tot_ss = 0.f;
 #pragma unroll
     for (int w = 0; w < GEMV_WAVES; ++w) tot_ss += red_q[w];
@@ -335,11 +352,61 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
   // the o-projection's share: requested only now -- nothing on this workgroup's path needs it for several microseconds -- so
   // that it does not queue in front of the qkv shares every workgroup of the launch waits for
   const AbShare so = ab_share(o, ob, NB, wave);
-  ab_issue(o, so, wo, so_, lane);
+  AbCursor co = ab_cursor(so);
+  ab_issue<0, AB_RING>(o, so, co, wo, so_, lane);
   stream_wait<0>();
 #pragma unroll
   for (int j = 0; j < AB_RING; ++j) stream_landed(wo[j], so_[j]);
 
+  float* xsum_o = reinterpret_cast<float*>(smem + 256 + gemv_xs_bytes(1, o.RS));
+  float* red_o = xsum_o + (size_t)o.KT * 16;
+#if DIHIP_AB_WAVE_SWEEP
+  // ---- wait for the attention output, PER WAVE: a wave multiplies only its k-slice of the row (k-tiles [k_lo, k_hi) = vectors
+  // [16 k_lo, 16 k_hi) of 8 elements), so it polls, sweeps and stages that slice itself and starts its tiles without a workgroup
+  // barrier on either side (round 5: one polling wave, barrier, workgroup sweep, barrier: 2.5 us from the merged output to the end).
+  // One lane per KV group polls the group's first output granule, then the slice's granules are swept until all carry this launch's
+  // tag.  Waves sharing a k-slice (WN > 1) stage the same bytes twice. ----
+  __syncthreads();  // every reader of red_q / xs of the first phase is done (far off the critical path: the output is microseconds away)
+  for (unsigned spins = 0;; ++spins) {
+    const unsigned f = lane < p.a.g ? (unsigned)(__hip_atomic_load(p.out_gran + (size_t)lane * p.a.hpg * 64, __ATOMIC_RELAXED,
+                                                                   __HIP_MEMORY_SCOPE_AGENT) >> 32)
+                                    : tag;
+    if (__builtin_amdgcn_ballot_w64(f != tag) == 0ull) break;
+    if (spins > p.spin_limit) {
+      if (lane == 0) __hip_atomic_store(p.state + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(4);
+    if (wave & 1) __builtin_amdgcn_s_sleep(2);  // (the waves of a workgroup drift out of step)
+  }
+  DIHIP_AB_STAMP(4);  // every group's first output granule seen
+  {
+    const int v_lo = so.k_lo * 16, v_hi = so.k_hi * 16;  // whole 16-lane rows: the per-k-tile sums cross lanes
+    for (int i0 = v_lo; i0 < v_hi; i0 += 64) {
+      const int i = i0 + lane, ic = min(i, v_hi - 1);
+      unsigned long long gv[4];
+      for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          gv[j] = __hip_atomic_load(p.out_gran + (size_t)ic * 4 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && (unsigned)(gv[j] >> 32) == tag;
+        }
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+        if (spins > p.spin_limit) {
+          if (lane == 0) __hip_atomic_store(p.state + 1, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      const u32x4_t v = {(uint32_t)gv[0], (uint32_t)gv[1], (uint32_t)gv[2], (uint32_t)gv[3]};
+      ab_stage_vector(xs, xsum_o, ic, v, i < v_hi);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave reads back what it staged itself: LDS operations of a wave execute in order
+  __builtin_amdgcn_wave_barrier();
+  DIHIP_AB_STAMP(5);  // this wave's slice of the attention output swept into LDS
+#else
   // ---- wait for the attention output: ONE lane per KV group polls the group's first output granule (the merging workgroup
   // stores all of a group's granules in one go: when the first carries this launch's tag the others are at most a retry
   // away), then one sweep of all granules.  (A separate flag word behind a store drain cost the producer ~0.7 us more.) ----
@@ -358,8 +425,6 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
   }
   __syncthreads();  // (also: every reader of red_q / xs of the first phase is done)
   DIHIP_AB_STAMP(4);  // every group's first output granule seen
-  float* xsum_o = reinterpret_cast<float*>(smem + 256 + gemv_xs_bytes(1, o.RS));
-  float* red_o = xsum_o + (size_t)o.KT * 16;
   {
     // thread -> 8-element vector i = its 4 consecutive granules: staged and summed per k-tile in one pass (ab_stage_vector)
     const int nvec_o = o.K >> 3;
@@ -386,6 +451,7 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
   }
   __syncthreads();
   DIHIP_AB_STAMP(5);  // attention output swept into LDS
+#endif
 
   // ---- o-projection tiles: h_out = h_res + attn . Wo ----
   ab_consume(o, so, wo, so_, smem, xsum_o, red_o, lane);

@@ -225,6 +225,8 @@ __device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float*
 //     heads); the owner of an item polls the item's chunk of every split record until none is zero (the data is the flag: a 16-byte
 //     store lands whole; ~6 KB per pass and workgroup), merges in split order with merge_split_records' single-batch arithmetic
 //     (bit-identical output) and publishes the item's output granules;
+//   * measured and dropped (profiles/r06_attn_block_polls.txt): all four waves polling a slice out of step (+1.4 us: a poll pass is 34
+//     memory-side loads per lane, and four times the passes delay the stores they wait for), sleeping before the first poll (no effect);
 //   * two record buffers alternate by launch parity: the owner zeroes its chunks of the OTHER buffer (the previous launch's records,
 //     whose readers are long gone) for the next launch -- a reader never races a reset.
 template <int FT, int MB>
@@ -258,7 +260,7 @@ __device__ __forceinline__ void merge_polled_items(const AttnArgs& a, const Attn
         if (lane == 0) __hip_atomic_store(ho->err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
-      __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_s_sleep(2);
     }
 #if defined(DIHIP_GEMV_TRACE) && DIHIP_GEMV_TRACE
     if (tr) tr[6] = wall_clock64();
