@@ -31,6 +31,7 @@
 // Served: batch 1, bf16, int4 weights with one quantisation group per k-tile (g128), 16-bit cache, head size 128, <= 16
 // query heads per KV group.  Everything else: dihip_decode_attn_block_supported() == 0 and the caller keeps the launch chain.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <unordered_map>
@@ -67,6 +68,7 @@ struct AttnBlockArgs {
   unsigned rec_bytes;
   int NA, NG;                    // attention / GEMV workgroups
   unsigned spin_limit;
+  unsigned fault;                // tests (DIHIP_ATTN_BLOCK_FAULT=1): GEMV workgroup 0 withholds its qkv rows -> the waits give up
   unsigned long long* trace;     // diagnostics (`make trace` build + dihip_debug_set_trace): [workgroup][32] wall-clock stamps, or null
 };
 
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
   // ---- qkv tiles of this workgroup ----
   ab_consume(q, sq, wq, sq_, smem, xsum_q, red_q, lane);
   __syncthreads();
-  if (tid < nq_e && n_q < q.N) {  // element e = tid: column tile e / 16 of this workgroup, column e % 16
+  if (tid < nq_e && n_q < q.N && !(p.fault && lb == 0)) {  // element e = tid: column tile e / 16 of this workgroup, column e % 16
     float v = 0.f;
     const float* pr = red_q + ((size_t)(tid >> 4) * q.WK) * 16 + (tid & 15);
     for (int s = 0; s < q.WK; ++s) v += pr[(size_t)s * 16];
@@ -532,7 +534,25 @@ int dihip_decode_attn_block_supported(int wbits, int group_size, int hidden, int
     for (int i = 0; i < g.WK; ++i) longest = std::max(longest, g.kcut[i + 1] - g.kcut[i]);
     return ((g.upb + g.WN - 1) / g.WN) * longest <= AB_RING;
   };
-  return fits(gq) && fits(go) ? 1 : 0;
+  if (!fits(gq) || !fits(go)) return 0;
+  // every workgroup of the launch must be RESIDENT at once (they wait for one another): the grid is <= one workgroup per CU by
+  // construction; the kernel itself must fit a CU with its LDS at this block size (ask the occupancy calculator, once)
+  const size_t lds_need = std::max<size_t>(std::max(lds, (size_t)0), ((FT_MFMA_SMEM_BYTES + 15) & ~15) + FT_MFMA_GATHER_IMG_BYTES);
+  static std::atomic<int> occ{-1};
+  int o = occ.load(std::memory_order_relaxed);
+  if (o < 0) {
+    int nb = 0;
+    const size_t lds_q = std::max<size_t>(lds_need, 64 * 1024);  // (asked with a generous LDS figure: the answer is cached for all shapes)
+    if (lds_q > 64 * 1024 - 1 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(decode_attn_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q) != hipSuccess)
+      nb = 0;
+    else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decode_attn_block_kernel, AB_THREADS, lds_q) != hipSuccess)
+      nb = 0;
+    (void)hipGetLastError();
+    o = nb;
+    occ.store(o, std::memory_order_relaxed);
+  }
+  return o >= 1 ? 1 : 0;
 }
 
 size_t dihip_decode_attn_block_sync_bytes(int n_heads, int n_groups, int head_size) {
@@ -547,6 +567,20 @@ size_t dihip_decode_attn_block_workspace_bytes(int n_heads, int n_groups, int he
   size_t pb;
   span_attn_block_plan(1, n_heads, n_groups, max_seq_len, &ns, &nc, &tps, &pb);
   return pb + 256;
+}
+
+int dihip_decode_attn_block_status_async(void* stream, const void* sync, unsigned* host_word) {
+  DIHIP_REQUIRE(sync && host_word, DIHIP_PARAM_ERROR, "decode_attn_block_status: null pointer");
+  DIHIP_CHECK_HIP(hipMemcpyAsync(host_word, reinterpret_cast<const unsigned*>(sync) + 1, sizeof(unsigned), hipMemcpyDeviceToHost,
+                                 reinterpret_cast<hipStream_t>(stream)),
+                  DIHIP_RUNTIME_ERROR);
+  return DIHIP_SUCCESS;
+}
+
+int dihip_decode_attn_block_reset(void* stream, void* sync, size_t sync_bytes) {
+  DIHIP_REQUIRE(sync && sync_bytes >= 64, DIHIP_PARAM_ERROR, "decode_attn_block_reset: bad argument");
+  DIHIP_CHECK_HIP(hipMemsetAsync(sync, 0, sync_bytes, reinterpret_cast<hipStream_t>(stream)), DIHIP_RUNTIME_ERROR);
+  return DIHIP_SUCCESS;
 }
 
 int dihip_decode_attn_block(void* stream, int wbits, const float* h_in, const float* h_res, float* h_out, const void* gamma, float eps,
@@ -618,6 +652,11 @@ int dihip_decode_attn_block(void* stream, int wbits, const float* h_in, const fl
   }
   static const unsigned spin_limit = (unsigned)std::max(1024, env_int("DIHIP_ATTN_BLOCK_SPINS", 1 << 18));
   p.spin_limit = spin_limit;
+  {
+    const char* f = getenv("DIHIP_ATTN_BLOCK_FAULT");  // (read per call: a test switches it inside one process)
+    p.fault = f && f[0] == '1';
+    if (p.fault) p.spin_limit = 1024;
+  }
   AttnArgs& a = p.a;
   a.kspans = k_span_array;
   a.vspans = v_span_array;

@@ -971,6 +971,23 @@ class DecodeSession:
         # the capture pass itself does not execute; state is still (ids0, lens0)
         return self.graph
 
+    def check_handoffs(self):
+        """At a synchronisation point of the caller: the fused attention block's error word (word 1 of its sync buffer, set when a bounded
+        hand-off wait of a launch gave up).  Non-zero -> the steps since the last check are invalid: the buffer's invariants are restored,
+        the session keeps the three-launch chain from here (captured graphs are dropped: capture again) and RuntimeError is raised --
+        never silently wrong tokens (ADVICE r5).  The C++ runner does the same in HipModelRunner::Sync."""
+        if not getattr(self, "attn_block", False):
+            return
+        torch.cuda.synchronize()
+        code = int(self.block_sync.view(torch.int32)[1].item())
+        if code:
+            ops.check(lib().dihip_decode_attn_block_reset(ops.cur_stream(), ops.ptr(self.block_sync), self.block_sync.numel()), "attn_block_reset")
+            torch.cuda.synchronize()
+            self.attn_block = False
+            self.graph = self.graph_multi = None
+            raise RuntimeError(f"attention block: a bounded hand-off wait gave up (code {code}); the decode steps since the last check are "
+                               "invalid, the launch chain serves from here")
+
     def replay(self):
         self.graph.replay()
 

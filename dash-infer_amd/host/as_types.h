@@ -211,6 +211,9 @@ class HIPContext : public DeviceContext {
     auto it = row_norm_.find(tensor);
     return it == row_norm_.end() ? RowNormState{} : it->second;
   }
+  // the fused attention block's hand-offs timed out once (model_runner.cpp Sync read the error word): the launch chain serves from then on
+  bool AttnBlockDisabled() const { return attn_block_off_; }
+  void DisableAttnBlock() const { attn_block_off_ = true; }
   void RegisterProducer(const std::string& tensor, void* op) const { producer_[tensor] = op; }
   void* Producer(const std::string& tensor) const {
     auto it = producer_.find(tensor);
@@ -224,6 +227,7 @@ class HIPContext : public DeviceContext {
   mutable std::map<std::string, ActLayoutPref> layout_pref_;
   mutable std::map<std::string, int> act_layout_;
   mutable bool lens_on_device_ = false;
+  mutable bool attn_block_off_ = false;
   mutable std::map<std::string, void*> producer_;
   mutable std::map<std::string, RowNormState> row_norm_;
 };

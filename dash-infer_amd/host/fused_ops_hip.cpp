@@ -385,7 +385,7 @@ class DihipGemmAddToOp : public AsOperator {
   // int4 weights with a group per k-tile -- what dihip_decode_attn_block_supported says for this GPU
   bool BlockEligible(RuntimeContext* rt) const {
     static const bool enabled = env_on("DIHIP_DECODER_ATTN_BLOCK", true);
-    if (!enabled || !blk_attn_ || !blk_qkv_ || !rt || rt->is_context || m_ != 1 || norm_now_) return false;
+    if (!enabled || hip_ctx(ctx_).AttnBlockDisabled() || !blk_attn_ || !blk_qkv_ || !rt || rt->is_context || m_ != 1 || norm_now_) return false;
     const AttnBlockQkv q = blk_qkv_->BlockQkv();
     const AttnBlockAttn a = blk_attn_->BlockAttn();
     if (q.m != 1 || q.act != 0 || a.batch != 1 || a.seq != 1 || !q.w || q.w->wbits != w_.wbits || q.w->group != w_.group || q.w->ft != w_.ft ||

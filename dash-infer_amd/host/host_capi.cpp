@@ -464,6 +464,16 @@ int dihost_sync_ids(dihost_model_t m, int64_t* ids_host, int capacity) {
   const AsStatus st = m->runner->Sync(&ids);
   if (st != AsStatus::ALLSPARK_SUCCESS) {
     g_err = m->runner->last_error();
+    if (m->runner->handoff_failed()) {  // the harness owns the caches: back to the rolled-back lengths (an engine would fail the requests)
+      for (auto& gc : m->runner->running()) {
+        auto* k = dynamic_cast<ListVirtualCache*>(gc->virtual_k_cache.get());
+        auto* v = dynamic_cast<ListVirtualCache*>(gc->virtual_v_cache.get());
+        if (k && v) {
+          k->Rewind((size_t)gc->step);
+          v->Rewind((size_t)gc->step);
+        }
+      }
+    }
     return -(int)st;
   }
   for (int i = 0; i < (int)ids.size() && i < capacity; ++i) ids_host[i] = ids[i];

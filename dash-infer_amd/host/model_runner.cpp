@@ -1,6 +1,10 @@
 // model_runner.cpp -- see model_runner.h.
 #include "model_runner.h"
 
+#include <string>
+
+#include "dashinfer_hip.h"
+
 #include <algorithm>
 
 namespace allspark {
@@ -18,6 +22,7 @@ HipModelRunner::~HipModelRunner() {
   ops_.clear();
   if (ids_pinned_) (void)hipHostFree(ids_pinned_);
   if (lens_pinned_) (void)hipHostFree(lens_pinned_);
+  if (block_err_pinned_) (void)hipHostFree(block_err_pinned_);
   if (prompt_pinned_) (void)hipHostFree(prompt_pinned_);
   if (staged_) (void)hipEventDestroy(staged_);
 }
@@ -62,6 +67,7 @@ AsStatus HipModelRunner::Build(const std::vector<OperatorProto>& graph, bool fus
     return Fail(AsStatus::ALLSPARK_MEMORY_ERROR, "runner state tensors");
   if (hipHostMalloc((void**)&ids_pinned_, 2 * mb * sizeof(int64_t), hipHostMallocDefault) != hipSuccess ||
       hipHostMalloc((void**)&lens_pinned_, 2 * mb * sizeof(int32_t), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&block_err_pinned_, 64, hipHostMallocDefault) != hipSuccess ||
       hipEventCreateWithFlags(&staged_, hipEventDisableTiming) != hipSuccess)
     return Fail(AsStatus::ALLSPARK_MEMORY_ERROR, "pinned staging");
   BindIds(prompt_dev_->GetDataPtr(), 1, 1);
@@ -214,6 +220,7 @@ AsStatus HipModelRunner::DecodeSteps(int n, bool use_graph) {
       AS_CHECK_STATUS(ForEach(&decode_rt_, 2));
     }
     for (auto& gc : running_) gc->step += 1;  // model.cpp:1320
+    ++steps_since_sync_;
   }
   return AsStatus::ALLSPARK_SUCCESS;
 }
@@ -243,7 +250,35 @@ AsStatus HipModelRunner::Sync(std::vector<int64_t>* ids) {
     if (hipMemcpyAsync(ids_pinned_ + mb, (*tensors_)[ids_out_name_]->GetDataPtr(), (size_t)B * sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess)
       return Fail(AsStatus::ALLSPARK_RUNTIME_ERROR, "id readback");
   }
+  // the fused attention block's error word rides on the same synchronisation (a hand-off that timed out must not turn into
+  // silently wrong tokens): the copy is enqueued beside the id readback, read after the one stream synchronise
+  unsigned* blk_err = block_err_pinned_;
+  auto blk = tensors_->find("dihip.attn_block_sync");
+  const bool blk_live = blk != tensors_->end() && blk->second->GetDataPtr() && !ctx_->AttnBlockDisabled() && blk_err;
+  if (blk_live) {
+    *blk_err = 0u;
+    if (dihip_decode_attn_block_status_async(s, blk->second->GetDataPtr(), blk_err) != 0) return Fail(AsStatus::ALLSPARK_RUNTIME_ERROR, "block status readback");
+  }
   if (hipStreamSynchronize(s) != hipSuccess) return Fail(AsStatus::ALLSPARK_RUNTIME_ERROR, "stream synchronise");
+  if (blk_live && *blk_err != 0u) {
+    const unsigned code = *blk_err;
+    // the step(s) since the last synchronise are invalid; the ids on the device are garbage: keep the host's last good ones, switch the
+    // layers back to their three launches (Reshape re-decides, the captured step is dropped) and restore the buffer's invariants
+    for (auto& gc : running_) gc->step -= std::min(gc->step, steps_since_sync_);  // back to the state of the last good synchronise
+    steps_since_sync_ = 0;
+    handoff_failed_ = true;
+    ctx_->DisableAttnBlock();
+    (void)dihip_decode_attn_block_reset(s, blk->second->GetDataPtr(), blk->second->GetSizeInByte());
+    (void)hipStreamSynchronize(s);
+    dirty_ = true;
+    DropGraph();
+    return Fail(AsStatus::ALLSPARK_RUNTIME_ERROR,
+                "attention block: a bounded hand-off wait gave up (code " + std::to_string(code) +
+                    "): the decode steps since the last synchronise are invalid; the launch chain serves from here "
+                    "(were all workgroups resident? CU mask / another stream's kernel on this GPU)");
+  }
+  steps_since_sync_ = 0;
+  handoff_failed_ = false;
   if (B > 0 && !dirty_)
     for (int b = 0; b < B; ++b) next_ids_[b] = ids_pinned_[mb + b];
   if (ids) *ids = next_ids_;

@@ -409,12 +409,23 @@ int dihip_span_attn_merge_partials(void* stream, void* output, const float* part
  *   ws     : >= dihip_decode_attn_block_workspace_bytes(...) (no initialisation)
  *   sync   : >= dihip_decode_attn_block_sync_bytes(...), 16-byte aligned, zeroed ONCE by the caller; calls sharing it must be ordered
  *            on one stream (hipGraph replay included: the launch keeps its own epoch in it).  Word 1 of `sync` is an error flag: non-zero
- *            after a launch whose bounded wait gave up (never observed; results are then undefined, nothing hangs).
+ *            after a launch whose bounded wait gave up (results are then undefined, nothing hangs).  The caller READS it at its next
+ *            synchronisation point: dihip_decode_attn_block_status_async() enqueues the copy of the word to host memory on the stream
+ *            (beside the token readback: no extra synchronisation); non-zero -> the step's results are invalid, dihip_decode_attn_block_reset()
+ *            restores the buffer's invariants (epoch, record buffers) and the caller keeps the three-call chain from there
+ *            (host/model_runner.cpp Sync; decoder.DecodeSession.check_handoffs).  The wait can only give up when the launch's workgroups
+ *            are not all resident (every one of them is needed for the others to finish): _supported() checks the grid against the CU count
+ *            AND the kernel's occupancy, but a CU mask or another stream's kernel on the same GPU can still take CUs away.
+ *            Since round 6 the split records of the attention live in `sync` too (two buffers alternating by launch: polled by their
+ *            consumers, zeroed by them for the launch after next); DIHIP_ATTN_BLOCK_FAULT=1 (tests) makes one workgroup withhold its
+ *            rows so that the waits time out.
  * _supported() == 0 (other batch sizes, dtypes, caches, weight formats, too few CUs, DIHIP_ATTN_BLOCK=0): keep the three calls. */
 int dihip_decode_attn_block_supported(int wbits, int group_size, int hidden, int n_heads, int n_groups, int head_size,
                                       int max_seq_len, int kv_mode, int dtype, int batch);
 size_t dihip_decode_attn_block_sync_bytes(int n_heads, int n_groups, int head_size);
 size_t dihip_decode_attn_block_workspace_bytes(int n_heads, int n_groups, int head_size, int max_seq_len);
+int dihip_decode_attn_block_status_async(void* stream, const void* sync, unsigned* host_word);
+int dihip_decode_attn_block_reset(void* stream, void* sync, size_t sync_bytes);
 int dihip_decode_attn_block(void* stream, int wbits, const float* h_in, const float* h_res, float* h_out, const void* gamma,
                             float eps, const void* qkv_w, const void* qkv_sz, const void* qkv_bias, const void* o_w,
                             const void* o_sz, void* const* k_span_array, void* const* v_span_array,

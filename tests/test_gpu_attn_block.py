@@ -163,3 +163,75 @@ def test_a_rank_that_does_not_carry_the_residual(pkg):
         assert _err_word(s) == 0 and torch.isfinite(out).all()
         outs.append((out.clone(), s.pool.pool.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_a_timed_out_handoff_is_reported_and_the_chain_takes_over(pkg, monkeypatch):
+    """a bounded wait that gives up must never become silently wrong tokens.  DIHIP_ATTN_BLOCK_FAULT=1 makes one
+    GEMV workgroup withhold its qkv rows (and shortens the spin limit): every consumer times out, the launch sets the error word and
+    returns garbage.  DecodeSession.check_handoffs() -- the caller's synchronisation point -- raises, restores the buffer and leaves the
+    session on the three-launch chain: the SAME steps decoded again equal the chain's, bit for bit."""
+    from dash_infer_amd import decoder
+    model = _model(decoder, seed=41)
+    max_len = 512
+    ref = _session(decoder, model, max_len, False)
+    ref.fill_cache_random(180, seed=2)
+    ref.set_state([5], [180])
+    want = []
+    for _ in range(3):
+        ref.step()
+        torch.cuda.synchronize()
+        want.append((ref.logits.clone(), ref.ids.clone()))
+    s = _session(decoder, model, max_len, True)
+    assert s.attn_block
+    s.fill_cache_random(180, seed=2)
+    s.set_state([5], [180])
+    s.step()                       # a good step first: the epoch and the record buffers are in their steady state
+    torch.cuda.synchronize()
+    s.check_handoffs()
+    assert torch.equal(s.logits, want[0][0])
+    monkeypatch.setenv("DIHIP_ATTN_BLOCK_FAULT", "1")
+    s.step()
+    monkeypatch.delenv("DIHIP_ATTN_BLOCK_FAULT")
+    with pytest.raises(RuntimeError, match="hand-off wait gave up"):
+        s.check_handoffs()
+    assert not s.attn_block and _err_word(s) == 0
+    # the caller re-runs from its last good state (ids / lengths of step 1) on the chain
+    s.set_state(want[0][1].tolist(), [181])
+    for t in (1, 2):
+        s.step()
+        torch.cuda.synchronize()
+        s.check_handoffs()
+        assert torch.equal(s.logits, want[t][0]) and torch.equal(s.ids, want[t][1]), f"step {t} after the recovery"
+
+
+def test_cpp_runner_reads_the_error_word_at_sync_and_recovers(pkg, monkeypatch):
+    """The same through the C++ operator layer: HipModelRunner::Sync reads the error word beside the id readback; a timed-out launch
+    fails THAT synchronise (AsStatus RUNTIME_ERROR, message names the hand-off), the requests are rolled back to the last good
+    synchronise, the attention block is switched off for the context and the next decode_steps decodes the same tokens on the chain."""
+    from dash_infer_amd import decoder, hostapi
+    from tests.test_gpu_host_runner import Host
+    model = _model(decoder, seed=43, keep_fp=True)
+    cfg = model.cfg
+    span, max_len = 128, 384
+    prompt = [int(t) for t in torch.randint(0, cfg.vocab, (90,), generator=torch.Generator().manual_seed(2)).tolist()]
+    ref = _session(decoder, model, max_len, False)
+    ref.prefill([prompt])
+    want = []
+    for _ in range(4):
+        ref.step()
+        torch.cuda.synchronize()
+        want.append(ref.ids.cpu().tolist())
+    h = Host(model, 1, max_len, span, "none")
+    assert h.report["fused"], h.report["why"]
+    k, v = h.spans()
+    h.start(prompt, k, v)
+    assert h.steps(1, graph=False) == want[0]
+    monkeypatch.setenv("DIHIP_ATTN_BLOCK_FAULT", "1")
+    with pytest.raises(hostapi.HostError, match="hand-off wait gave up"):
+        h.steps(2, graph=False)
+    monkeypatch.delenv("DIHIP_ATTN_BLOCK_FAULT")
+    # rolled back to the state after step 0; the chain decodes steps 1 .. 3 (eager, then replayed from a fresh capture)
+    assert h.steps(1, graph=False) == want[1]
+    assert h.steps(1, graph=True) == want[2]
+    assert h.steps(1, graph=True) == want[3]
+    h.close()
