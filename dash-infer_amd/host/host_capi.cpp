@@ -193,20 +193,33 @@ int dihost_weights_load_file(dihost_model_t m, const char* path, int* count) {
   }
   FILE* fp = std::fopen(path, "rb");
   if (!fp) return (int)AsStatus::ALLSPARK_IO_ERROR;
-  std::vector<char> stage;
+  // every record is split for THIS rank by its SplitMode on the way in (WeightManager::LoadWeightForModel -> WeightSplitter,
+  // csrc/runtime/weight/weight_manager.cpp; weight_file.h SliceForRank): a converter export of the whole model feeds any TP degree
+  const int rank = m->ctx.GetRank(), nranks = std::max(1, m->ctx.GetNranks());
+  std::vector<char> stage, share;
+  std::vector<int64_t> shape;
   int n = 0;
   for (const WeightRecord& r : recs) {
-    auto t = std::make_shared<AsTensor>(r.name, DeviceType::HIP, r.dtype, Shape(r.shape.begin(), r.shape.end()));
-    if ((long long)t->GetSizeInByte() < r.nbytes || (r.nbytes > 0 && !t->GetDataPtr())) {
+    stage.resize((size_t)r.nbytes);
+    if (std::fseek(fp, (long)r.offset, SEEK_SET) != 0 || std::fread(stage.data(), 1, stage.size(), fp) != stage.size()) {
+      std::fclose(fp);
+      g_err = "weight file: cannot read " + r.name;
+      return (int)AsStatus::ALLSPARK_IO_ERROR;
+    }
+    if (!SliceForRank(r, stage.data(), rank, nranks, &share, &shape, &err)) {
+      std::fclose(fp);
+      g_err = "weight file: " + err;
+      return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+    }
+    auto t = std::make_shared<AsTensor>(r.name, DeviceType::HIP, r.dtype, Shape(shape.begin(), shape.end()));
+    if (t->GetSizeInByte() < share.size() || (!share.empty() && !t->GetDataPtr())) {
       std::fclose(fp);
       g_err = "weight file: cannot allocate " + r.name;
       return (int)AsStatus::ALLSPARK_MEMORY_ERROR;
     }
-    stage.resize((size_t)r.nbytes);
-    if (std::fseek(fp, (long)r.offset, SEEK_SET) != 0 || std::fread(stage.data(), 1, stage.size(), fp) != stage.size() ||
-        (r.nbytes > 0 && hipMemcpy(t->GetDataPtr(), stage.data(), stage.size(), hipMemcpyHostToDevice) != hipSuccess)) {
+    if (!share.empty() && hipMemcpy(t->GetDataPtr(), share.data(), share.size(), hipMemcpyHostToDevice) != hipSuccess) {
       std::fclose(fp);
-      g_err = "weight file: cannot read / upload " + r.name;
+      g_err = "weight file: cannot upload " + r.name;
       return (int)AsStatus::ALLSPARK_IO_ERROR;
     }
     m->weights[r.name] = t;
@@ -215,6 +228,42 @@ int dihost_weights_load_file(dihost_model_t m, const char* path, int* count) {
   std::fclose(fp);
   if (count) *count = n;
   return 0;
+}
+// one record's share for (rank, nranks) on the HOST (no GPU, no model): what dihost_weights_load_file uploads for that rank.
+// data == NULL: sizes only.  shape8 / ndim: the share's shape.
+int dihost_weight_file_slice(const char* path, const char* name, int rank, int nranks, void* data, size_t capacity, size_t* nbytes, int64_t* shape8,
+                             int* ndim) {
+  std::vector<WeightRecord> recs;
+  std::string err;
+  if (!path || !name || !IndexWeightFile(path, &recs, &err)) {
+    g_err = err.empty() ? "weight file: null argument" : err;
+    return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  }
+  for (const WeightRecord& r : recs) {
+    if (r.name != name) continue;
+    FILE* fp = std::fopen(path, "rb");
+    if (!fp) return (int)AsStatus::ALLSPARK_IO_ERROR;
+    std::vector<char> stage((size_t)r.nbytes), share;
+    std::vector<int64_t> shape;
+    const bool ok = std::fseek(fp, (long)r.offset, SEEK_SET) == 0 && std::fread(stage.data(), 1, stage.size(), fp) == stage.size();
+    std::fclose(fp);
+    if (!ok) return (int)AsStatus::ALLSPARK_IO_ERROR;
+    if (!SliceForRank(r, stage.data(), rank, std::max(1, nranks), &share, &shape, &err)) {
+      g_err = "weight file: " + err;
+      return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+    }
+    if (nbytes) *nbytes = share.size();
+    if (ndim) *ndim = (int)shape.size();
+    if (shape8)
+      for (size_t i = 0; i < shape.size() && i < 8; ++i) shape8[i] = shape[i];
+    if (data) {
+      if (capacity < share.size()) return (int)AsStatus::ALLSPARK_MEMORY_ERROR;
+      std::memcpy(data, share.data(), share.size());
+    }
+    return 0;
+  }
+  g_err = std::string("weight file: no record named ") + name;
+  return (int)AsStatus::ALLSPARK_PARAM_ERROR;
 }
 int dihost_get_tensor(dihost_model_t m, const char* name, int* dtype, int* ndim, int64_t* shape8, void** data) {
   auto it = m->tensors.find(name);

@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -27,6 +28,7 @@ struct WeightRecord {
   DataType dtype = DATATYPE_UNDEFINED;
   std::vector<int64_t> shape;
   int split_mode = 0;    // allspark.proto SplitMode of the tensor-parallel splitter (NOSPLIT 0, VSPLIT 1, HSPLIT 2, ...)
+  std::vector<int64_t> group_list;  // GROUP_VSPLIT: widths of the column groups (qkv: [n H, g H, g H]; halved by the converter for packed int4)
   int sparse_type = 0;
   long long offset = 0;  // of the data in the file
   long long nbytes = 0;
@@ -85,6 +87,9 @@ inline bool IndexWeightFile(const std::string& path, std::vector<WeightRecord>* 
     out->clear();
     return false;
   };
+  std::fseek(fp, 0, SEEK_END);
+  const long long file_size = std::ftell(fp);
+  std::fseek(fp, 0, SEEK_SET);
   for (;;) {
     unsigned char hd[6];
     if (std::fread(hd, 1, 6, fp) != 6) return fail("truncated: no global header (\"AS\" 0 0) at the end");
@@ -102,40 +107,161 @@ inline bool IndexWeightFile(const std::string& path, std::vector<WeightRecord>* 
       if (h.size() > 4096) return fail("record header of " + r.name + " does not end");
     }
     if (h.empty() || h.back() != '\n') return fail("truncated record header of " + r.name);
-    std::string descr, shape, sparse, split;
+    std::string descr, shape, sparse, split, groups;
     if (!field(h, "descr", &descr) || descr.size() < 4 || !field(h, "shape", &shape)) return fail("unreadable header of " + r.name + ": " + h);
     if (descr[1] != '<' && descr[1] != '|') return fail(r.name + ": big-endian data");
     const int word = std::atoi(descr.substr(3).c_str());
     if (!dtype_of(descr[2], word, &r.dtype)) return fail(r.name + ": unsupported element type " + descr);
-    long long count = 1;
-    for (size_t i = 0; i < shape.size();) {
-      if (shape[i] >= '0' && shape[i] <= '9') {
-        char* end = nullptr;
-        const long long d = std::strtoll(shape.c_str() + i, &end, 10);
-        r.shape.push_back(d);
-        count *= d;
-        i = (size_t)(end - shape.c_str());
-      } else {
-        ++i;
+    auto ints = [](const std::string& t, std::vector<int64_t>* v) {  // the non-negative integers of "(a, b, c)"
+      for (size_t i = 0; i < t.size();) {
+        if (t[i] >= '0' && t[i] <= '9') {
+          char* end = nullptr;
+          v->push_back(std::strtoll(t.c_str() + i, &end, 10));
+          i = (size_t)(end - t.c_str());
+        } else {
+          ++i;
+        }
       }
-    }
+    };
+    ints(shape, &r.shape);
     if (r.shape.empty()) return fail(r.name + ": no shape");
+    long long count = 1;
+    for (int64_t d : r.shape) {  // (a malformed shape must not wrap the byte count)
+      if (d < 0 || (d > 0 && count > (long long)(file_size / (d * (long long)word)) + 1)) return fail(r.name + ": shape larger than the file");
+      count *= d;
+    }
     if (field(h, "sparse_type", &sparse)) r.sparse_type = std::atoi(sparse.c_str());
     if (field(h, "split_type", &split)) r.split_mode = std::atoi(split.c_str());
+    if (field(h, "group_list", &groups)) ints(groups, &r.group_list);
     if (r.sparse_type != 0) return fail(r.name + ": sparse encodings (CSC / ELL) are not served by this backend");
     r.nbytes = count * word;
     r.offset = std::ftell(fp);
-    if (std::fseek(fp, (long)r.nbytes, SEEK_CUR) != 0) return fail("truncated data of " + r.name);
+    if (r.offset < 0 || r.offset + r.nbytes > file_size) return fail("truncated data of " + r.name);  // EVERY record against the file's size
+    if (std::fseek(fp, (long)(r.offset + r.nbytes), SEEK_SET) != 0) return fail("truncated data of " + r.name);
     out->push_back(std::move(r));
-  }
-  // (a data block cut short shows as a bad magic or a missing global header above; check the last one explicitly)
-  if (!out->empty()) {
-    std::fseek(fp, 0, SEEK_END);
-    const long long size = std::ftell(fp);
-    if (out->back().offset + out->back().nbytes + 6 > size) return fail("truncated data of " + out->back().name);
   }
   std::fclose(fp);
   return true;
+}
+
+// ---- the tensor-parallel split at load time (WeightManager -> WeightSplitter, csrc/runtime/weight/weight_splitter.cpp) ------------------
+// `whole` = the record's bytes as stored; -> this rank's share (`out`, `out_shape`), by the record's SplitMode:
+//   NOSPLIT                       the whole tensor on every rank
+//   VSPLIT (:60-127)              2-D [K, N]: columns [rank N/R, (rank + 1) N/R);  1-D [N]: the same range
+//   HSPLIT (:369-438)             2-D: rows [rank K/R, ...);  1-D (a bias added after the row-parallel sum): whole on rank 0, ZEROS elsewhere
+//   GROUP_VSPLIT (:611-721)       per group of `group_list` (qkv: q | k | v): the rank's 1/R of every group, concatenated (2-D and 1-D)
+//   BATCH_VSPLIT (:128-232)       3-D [E, K, N]: columns of every matrix;  2-D [E, N]: columns of every row (per-expert scales)
+//   BATCH_HSPLIT (:439-520)       3-D [E, K, N]: rows of every matrix
+//   QKVSPLIT / KVSPLIT (:521-610) three / two equal column groups, the rank's share of each;  MQA_VSPLIT (:722-852) [q | k | v]: q split, k / v whole
+//   EPSPLIT (:853-919)            3-D [E, K, N]: the rank's experts
+// Everything must divide by the rank count, as IsSplittable demands; BATCH_KVSPLIT and HSPLIT_QUANTIZE (no splitter in the factory,
+// :921-960) are refused for nranks > 1.
+inline bool SliceForRank(const WeightRecord& r, const char* whole, int rank, int nranks, std::vector<char>* out, std::vector<int64_t>* out_shape,
+                         std::string* err) {
+  const size_t word = r.shape.empty() ? 0 : (size_t)SizeofType(r.dtype);
+  auto fail = [&](const std::string& what) {
+    *err = r.name + ": " + what;
+    return false;
+  };
+  *out_shape = r.shape;
+  if (nranks <= 1 || r.split_mode == 0) {
+    out->assign(whole, whole + r.nbytes);
+    return true;
+  }
+  if (rank < 0 || rank >= nranks) return fail("rank outside the group");
+  const int nd = (int)r.shape.size();
+  // the tensor as [outer][rows][cols]: 1-D = one row; 2-D = [rows, cols]; 3-D = [outer, rows, cols]
+  const int64_t cols = r.shape[nd - 1], rows = nd >= 2 ? r.shape[nd - 2] : 1, outer = nd >= 3 ? r.shape[0] : 1;
+  if (nd > 3) return fail("split of a rank-" + std::to_string(nd) + " tensor");
+  auto take_cols = [&](const std::vector<std::pair<int64_t, int64_t>>& ranges) {  // [(first column, count)] of every row, concatenated
+    int64_t w = 0;
+    for (auto& g : ranges) w += g.second;
+    out->resize((size_t)(outer * rows * w) * word);
+    char* d = out->data();
+    for (int64_t o = 0; o < outer * rows; ++o)
+      for (auto& g : ranges) {
+        std::memcpy(d, whole + ((size_t)o * cols + g.first) * word, (size_t)g.second * word);
+        d += (size_t)g.second * word;
+      }
+    (*out_shape)[nd - 1] = w;
+  };
+  auto take_rows = [&](int64_t first, int64_t count) {
+    out->resize((size_t)(outer * count * cols) * word);
+    for (int64_t o = 0; o < outer; ++o)
+      std::memcpy(out->data() + (size_t)(o * count * cols) * word, whole + ((size_t)(o * rows + first) * cols) * word, (size_t)(count * cols) * word);
+    (*out_shape)[nd - 2] = count;
+  };
+  switch (r.split_mode) {
+    case 1:  // VSPLIT
+      if (nd > 2) return fail("VSPLIT of a rank-3 tensor (BATCH_VSPLIT is the batched form)");
+      if (cols % nranks) return fail("VSPLIT: " + std::to_string(cols) + " columns do not divide by " + std::to_string(nranks) + " ranks");
+      take_cols({{rank * (cols / nranks), cols / nranks}});
+      return true;
+    case 2:  // HSPLIT
+      if (nd > 2) return fail("HSPLIT of a rank-3 tensor (BATCH_HSPLIT is the batched form)");
+      if (nd == 1) {  // the bias of a row-parallel layer: added once, on rank 0
+        if (rank == 0) out->assign(whole, whole + r.nbytes);
+        else out->assign((size_t)r.nbytes, 0);
+        return true;
+      }
+      if (rows % nranks) return fail("HSPLIT: " + std::to_string(rows) + " rows do not divide by " + std::to_string(nranks) + " ranks");
+      take_rows(rank * (rows / nranks), rows / nranks);
+      return true;
+    case 6: {  // GROUP_VSPLIT
+      if (nd > 2) return fail("GROUP_VSPLIT of a rank-3 tensor");
+      if (r.group_list.empty()) return fail("GROUP_VSPLIT without a group_list");
+      std::vector<std::pair<int64_t, int64_t>> ranges;
+      int64_t at = 0;
+      for (int64_t g : r.group_list) {
+        if (g % nranks) return fail("GROUP_VSPLIT: a group of " + std::to_string(g) + " columns does not divide by " + std::to_string(nranks) + " ranks");
+        ranges.push_back({at + rank * (g / nranks), g / nranks});
+        at += g;
+      }
+      if (at != cols) return fail("GROUP_VSPLIT: the group_list sums to " + std::to_string(at) + ", the tensor has " + std::to_string(cols) + " columns");
+      take_cols(ranges);
+      return true;
+    }
+    case 8:  // BATCH_VSPLIT: every matrix (3-D) / every row (2-D) by columns
+      if (nd < 2) return fail("BATCH_VSPLIT of a vector");
+      if (cols % nranks) return fail("BATCH_VSPLIT: " + std::to_string(cols) + " columns do not divide by " + std::to_string(nranks) + " ranks");
+      take_cols({{rank * (cols / nranks), cols / nranks}});
+      return true;
+    case 3:    // QKVSPLIT: three equal column groups (WeightSplitterVSplitBatchGEMM<3>, :521-610)
+    case 4: {  // KVSPLIT: two
+      const int cnt = r.split_mode == 3 ? 3 : 2;
+      if (nd > 2) return fail("QKVSPLIT / KVSPLIT of a rank-3 tensor");
+      if (cols % (cnt * nranks)) return fail(std::to_string(cols) + " columns do not divide by " + std::to_string(cnt) + " x " + std::to_string(nranks));
+      std::vector<std::pair<int64_t, int64_t>> ranges;
+      const int64_t g = cols / cnt;
+      for (int i = 0; i < cnt; ++i) ranges.push_back({i * g + rank * (g / nranks), g / nranks});
+      take_cols(ranges);
+      return true;
+    }
+    case 7: {  // MQA_VSPLIT (:722-852): [q | k | v] with the q columns split and the one K / V head on every rank
+      if (nd > 2) return fail("MQA_VSPLIT of a rank-3 tensor");
+      if (r.group_list.size() != 3) return fail("MQA_VSPLIT needs a group_list of three");
+      if (r.group_list[0] % nranks) return fail("MQA_VSPLIT: " + std::to_string(r.group_list[0]) + " query columns do not divide by " + std::to_string(nranks) + " ranks");
+      if (r.group_list[0] + r.group_list[1] + r.group_list[2] != cols) return fail("MQA_VSPLIT: the group_list does not sum to the column count");
+      const int64_t q = r.group_list[0] / nranks;
+      take_cols({{rank * q, q}, {r.group_list[0], r.group_list[1]}, {r.group_list[0] + r.group_list[1], r.group_list[2]}});
+      return true;
+    }
+    case 11: {  // EPSPLIT (:853-919): the experts [rank E/R, ...) of a [E, K, N] stack, whole matrices
+      if (nd != 3) return fail("EPSPLIT of a tensor that is not [experts, K, N]");
+      if (outer % nranks) return fail("EPSPLIT: " + std::to_string(outer) + " experts do not divide by " + std::to_string(nranks) + " ranks");
+      const size_t per = (size_t)(outer / nranks) * rows * cols * word;
+      out->assign(whole + (size_t)rank * per, whole + (size_t)(rank + 1) * per);
+      (*out_shape)[0] = outer / nranks;
+      return true;
+    }
+    case 9:  // BATCH_HSPLIT (the reference takes rank-3 tensors only; the converter writes the parameters of such experts NOSPLIT)
+      if (nd != 3) return fail("BATCH_HSPLIT of a tensor that is not [experts, K, N]");
+      if (rows % nranks) return fail("BATCH_HSPLIT: " + std::to_string(rows) + " rows do not divide by " + std::to_string(nranks) + " ranks");
+      take_rows(rank * (rows / nranks), rows / nranks);
+      return true;
+    default:
+      return fail("SplitMode " + std::to_string(r.split_mode) + " is not served under tensor parallelism by this backend");
+  }
 }
 
 }  // namespace allspark

@@ -16,6 +16,7 @@ _SIGS = {
     "dihost_model_set_p2p_comm": (i32, [vp, vp]),
     "dihost_weight_file_index": (i32, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "dihost_weights_load_file": (i32, [vp, C.c_char_p, C.POINTER(i32)]),
+    "dihost_weight_file_slice": (i32, [C.c_char_p, C.c_char_p, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int64), C.POINTER(i32)]),
     "dihost_get_weight": (i32, [vp, C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_int64), C.POINTER(vp)]),
     "dihost_set_tensor": (i32, [vp, C.c_char_p, i32, i32, C.POINTER(C.c_int64), vp]),
     "dihost_set_weight": (i32, [vp, C.c_char_p, i32, i32, C.POINTER(C.c_int64), vp]),
@@ -265,3 +266,13 @@ def weight_file_index(path):
         name, dt, shape, split, off, nb = line.rsplit("|", 5)
         out.append((name, int(dt), [int(d) for d in shape.split(",") if d], int(split), int(off), int(nb)))
     return out
+
+
+def weight_file_slice(path, name, rank, nranks):
+    """One record's share for (rank, nranks) -- the bytes dihost_weights_load_file uploads on that rank (the reference's WeightSplitter
+    rules, host/weight_file.h SliceForRank) -> (bytes, shape); needs no GPU."""
+    nb, nd, shp = C.c_size_t(0), i32(0), (C.c_int64 * 8)()
+    _ck(lib().dihost_weight_file_slice(str(path).encode(), name.encode(), rank, nranks, None, 0, C.byref(nb), shp, C.byref(nd)), "weight_file_slice")
+    buf = C.create_string_buffer(max(1, nb.value))
+    _ck(lib().dihost_weight_file_slice(str(path).encode(), name.encode(), rank, nranks, buf, nb.value, C.byref(nb), shp, C.byref(nd)), "weight_file_slice")
+    return buf.raw[: nb.value], [int(shp[i]) for i in range(nd.value)]

@@ -30,10 +30,18 @@ int dihost_set_weight(dihost_model_t m, const char* name, int dtype, int ndim, c
  *   _index: its records as text, one per line "name|dtype|d0,d1,...|split_mode|offset|nbytes" (DataType codes of allspark.proto; no
  *           device work, *need = bytes incl. the terminator, `out` may be null);
  *   _load_file: every record becomes a weight of the model under its own name in device memory the MODEL owns (freed by the
- *           weight-only operators once re-laid-out); dense records only, little endian; *count = records loaded;
+ *           weight-only operators once re-laid-out); dense records only, little endian; *count = records loaded.  With nranks > 1 (the
+ *           model's rank / nranks of dihost_model_create) every record is split FOR THIS RANK by its SplitMode and group_list on the way in --
+ *           WeightManager -> WeightSplitter of the reference (csrc/runtime/weight/weight_splitter.cpp:60-127 VSPLIT, :369-438 HSPLIT incl. the
+ *           rank-0-only bias, :611-721 GROUP_VSPLIT, :128-232 / :439-520 BATCH_V/HSPLIT, :521-610 QKV/KVSPLIT, :722-852 MQA_VSPLIT, :853-919
+ *           EPSPLIT; host/weight_file.h SliceForRank): ONE export of the whole model feeds any tensor-parallel degree that divides it;
+ *   _slice: the same share of ONE record on the host (no GPU, no model; data == NULL: *nbytes / shape only) -- what _load_file uploads for
+ *           (rank, nranks);
  *   dihost_get_weight: a weight's type / shape / device pointer (tests). */
 int dihost_weight_file_index(const char* path, char* out, size_t cap, size_t* need);
 int dihost_weights_load_file(dihost_model_t m, const char* path, int* count);
+int dihost_weight_file_slice(const char* path, const char* name, int rank, int nranks, void* data, size_t capacity, size_t* nbytes,
+                             int64_t* shape8, int* ndim);
 int dihost_get_weight(dihost_model_t m, const char* name, int* dtype, int* ndim, int64_t* shape8, void** data);
 /* output tensors are owned by the model: shape / pointer after Reshape */
 int dihost_get_tensor(dihost_model_t m, const char* name, int* dtype, int* ndim, int64_t* shape8, void** data);

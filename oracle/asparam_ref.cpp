@@ -28,6 +28,25 @@ int ref_asparam_append(const char* path, const char* name, const void* data, int
   return 0;
 }
 
+// the same with the tensor's group_list (GROUP_VSPLIT / MQA_VSPLIT tensors: model_base.py save_torch_to_allsparky(..., group_list))
+int ref_asparam_append_groups(const char* path, const char* name, const void* data, int64_t nbytes, char dtype_char, int word_size,
+                              const int* shape, int ndim, int split_mode, const int* group_list, int ngroups) {
+  allspark::TensorAttribute info;
+  info.sparse_type = 0;
+  info.split_mode = split_mode;
+  info.shape.assign(shape, shape + ndim);
+  info.group_list.assign(group_list, group_list + ngroups);
+  info.dtype = dtype_char;
+  info.word_size = word_size;
+  info.nnz = 0;
+  try {
+    allspark::util::save_allsparky_tofile(path, name, const_cast<void*>(data), nbytes, info);
+  } catch (...) {
+    return 1;
+  }
+  return 0;
+}
+
 int ref_asparam_finish(const char* path) {
   try {
     allspark::util::set_global_header(path);

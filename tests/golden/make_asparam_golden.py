@@ -23,6 +23,8 @@ def ref_writer():
     lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libdashinfer_ref_asparam.so"))
     lib.ref_asparam_append.restype = C.c_int
     lib.ref_asparam_append.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_char, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
+    lib.ref_asparam_append_groups.restype = C.c_int
+    lib.ref_asparam_append_groups.argtypes = lib.ref_asparam_append.argtypes + [C.POINTER(C.c_int), C.c_int]
     lib.ref_asparam_finish.restype = C.c_int
     lib.ref_asparam_finish.argtypes = [C.c_char_p]
     return lib
@@ -36,16 +38,67 @@ def descr(a, bf16=False):
 
 
 def write(path, records):
-    """records: [(name, array, split_mode, bf16?)]"""
+    """records: [(name, array, split_mode, bf16?[, group_list])]"""
     lib = ref_writer()
     if os.path.exists(path):
         os.remove(path)
-    for name, a, split, bf16 in records:
+    for rec in records:
+        name, a, split, bf16 = rec[:4]
+        groups = list(rec[4]) if len(rec) > 4 else []
         a = np.ascontiguousarray(a)
         letter, word = descr(a, bf16)
         shape = (C.c_int * a.ndim)(*a.shape)
-        assert lib.ref_asparam_append(path.encode(), name.encode(), a.ctypes.data, a.nbytes, letter, word, shape, a.ndim, split) == 0
+        if groups:
+            gl = (C.c_int * len(groups))(*groups)
+            assert lib.ref_asparam_append_groups(path.encode(), name.encode(), a.ctypes.data, a.nbytes, letter, word, shape, a.ndim, split, gl,
+                                                 len(groups)) == 0
+        else:
+            assert lib.ref_asparam_append(path.encode(), name.encode(), a.ctypes.data, a.nbytes, letter, word, shape, a.ndim, split) == 0
     assert lib.ref_asparam_finish(path.encode()) == 0
+
+
+def tp_model(seed=9):
+    """The records of a 1-layer Qwen2-shaped export AS THE CONVERTER WRITES THEM for tensor parallelism (qwen_v15.py:130-165, 540-569;
+    model_base.py save_torch_to_allsparky): 4 query / 2 KV heads of 128, hidden 256, intermediate 512, vocabulary 320, A16W4 g128 --
+    qkv GROUP_VSPLIT with group_list [n H, g H, g H] (halved for the nibble-packed weight), o / down HSPLIT with sub-channel parameters
+    HSPLIT along the groups, gate / up VSPLIT, a per-channel int8 o-projection whose parameters stay NOSPLIT, an o bias (HSPLIT vector:
+    rank 0 only), plus one tensor per remaining splitter (QKVSPLIT, MQA_VSPLIT, BATCH_V/HSPLIT, EPSPLIT).  [(name, array, split, bf16, groups)]"""
+    NOSPLIT, VSPLIT, HSPLIT, QKVSPLIT, MQA_VSPLIT, GROUP_VSPLIT, BATCH_VSPLIT, BATCH_HSPLIT, EPSPLIT = 0, 1, 2, 3, 7, 6, 8, 9, 11
+    rng = np.random.default_rng(seed)
+    hidden, n, g, H, inter, vocab, G = 256, 4, 2, 128, 512, 320, 128
+    bf = lambda shape, s=0.05: (rng.normal(0, s, shape).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    recs = [("embedding.word_embeddings", bf((vocab, hidden)), NOSPLIT, True, [])]
+    qkv = [n * H, g * H, g * H]
+    p = "decoder.layer.0."
+
+    def lowp(name, K, N, split, groups=()):
+        recs.append((name + ".weight", rng.integers(0, 256, (K, N // 2), dtype=np.uint8), split, False, [x // 2 for x in groups]))
+        recs.append((name + ".weight.scale", bf((K // G, N), 0.01), split, True, list(groups)))
+        recs.append((name + ".weight.zero_point", bf((K // G, N), 3.0), split, True, list(groups)))
+
+    recs.append((p + "attention.layernorm.gamma", bf((hidden,), 1.0), NOSPLIT, True, []))
+    lowp(p + "attention.self", hidden, sum(qkv), GROUP_VSPLIT, qkv)
+    recs.append((p + "attention.self.bias", bf((sum(qkv),), 0.1), GROUP_VSPLIT, True, qkv))
+    lowp(p + "attention.output.dense", n * H, hidden, HSPLIT)
+    recs.append((p + "attention.output.dense.bias", bf((hidden,), 0.1), HSPLIT, True, []))
+    recs.append((p + "ffn.layernorm.gamma", bf((hidden,), 1.0), NOSPLIT, True, []))
+    lowp(p + "ffn.intermediate.dense", hidden, inter, VSPLIT)
+    lowp(p + "ffn.linear.dense", hidden, inter, VSPLIT)
+    lowp(p + "ffn.output.dense", inter, hidden, HSPLIT)
+    # a per-channel int8 row-parallel weight: the parameters are whole on every rank (qwen_v15.py:556-569)
+    recs.append(("perchannel.o.weight", rng.integers(-128, 128, (n * H, hidden), dtype=np.int8), HSPLIT, False, []))
+    recs.append(("perchannel.o.weight.scale", bf((hidden,), 0.01), NOSPLIT, True, []))
+    recs.append(("perchannel.o.weight.zero_point", bf((hidden,), 3.0), NOSPLIT, True, []))
+    recs.append(("final.layernorm.gamma", bf((hidden,), 1.0), NOSPLIT, True, []))
+    recs.append(("lm_head.weight", bf((hidden, vocab)), VSPLIT, True, []))
+    # one tensor per remaining splitter
+    recs.append(("qkvsplit.weight", bf((8, 3 * 64)), QKVSPLIT, True, []))
+    recs.append(("mqa.weight", bf((8, 256 + 32 + 32)), MQA_VSPLIT, True, [256, 32, 32]))
+    recs.append(("experts.gate_up.weight", rng.integers(-128, 128, (4, 16, 64), dtype=np.int8), BATCH_VSPLIT, False, []))
+    recs.append(("experts.gate_up.scale", bf((4, 64), 0.01), BATCH_VSPLIT, True, []))
+    recs.append(("experts.down.weight", rng.integers(-128, 128, (4, 32, 24), dtype=np.int8), BATCH_HSPLIT, False, []))
+    recs.append(("experts.ep.weight", rng.integers(-128, 128, (8, 6, 10), dtype=np.int8), EPSPLIT, False, []))
+    return recs
 
 
 def tiny_model(seed=5):
@@ -76,6 +129,12 @@ def tiny_model(seed=5):
     return recs
 
 
+def main_tp():
+    path = os.path.join(OUT, "tiny_qwen2_a16w4_tp.asparam")
+    write(path, tp_model())
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def main():
     recs = tiny_model()
     path = os.path.join(OUT, "tiny_qwen2_a16w4.asparam")
@@ -85,3 +144,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    main_tp()

@@ -68,3 +68,11 @@ def test_tp_decode_through_the_cpp_operator_layer(pkg, nranks, kv_mode, batch, w
     rank ends each step with the same all-reduced logits row and token, equal to the single-rank DecodeSession within the FT tail's
     tolerance (tests/tp_loopback_lib.py::run_tp_decode_host).  TP = 2 / 4 / 8 incl. the 4 + 3 query-head split of a replicated KV head."""
     run_worker("hostdecode", nranks, kv_mode, batch, wbits, group)
+
+
+@pytest.mark.parametrize("nranks,kv_mode,batch,wbits,group,n_kv", [(2, "none", 1, 4, 128, 2), (4, "none", 2, 4, 128, 4), (2, "i8", 3, 8, -1, 2)])
+def test_tp_ranks_split_one_serialized_export_at_load(pkg, nranks, kv_mode, batch, wbits, group, n_kv):
+    """a whole-model .asparam written by the reference's writer (the converter's SplitModes + group_lists) ->
+    dihost_weights_load_file on every rank of a TP 2 / 4 group splits it for that rank -> logits and tokens bit-identical to the ranks bound
+    to tp.py's slices as tensors; int4 sub-channel (parameters split along the groups) and int8 per-channel (parameters whole)."""
+    run_worker("hostfile", nranks, kv_mode, batch, wbits, group, n_kv)

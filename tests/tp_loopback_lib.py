@@ -244,7 +244,58 @@ def run_tp_decode(nranks, kv_mode, batch, wbits, group, comm_kind, overlap, moe=
             break  # a near-tie resolved differently: the sequences part here, nothing further to compare
 
 
-def run_tp_decode_host(nranks, kv_mode, batch, wbits, group):
+def write_model_asparam(path, model, n_heads, n_kv, head_dim, group, tp_lm_head=True):
+    """The WHOLE model (decoder.build_random_model(keep_fp=True), one rank) as a serialized weight file the way the reference's converter
+    exports it for tensor parallelism -- names of ref_graph.register_weights, SplitModes and group_lists of qwen_v15.py:130-165, 540-569 /
+    model_base.py:690-703 -- written by the REFERENCE'S OWN writer (oracle/_ref/libdashinfer_ref_asparam.so, tests/golden/make_asparam_golden.py)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_asparam_golden", os.path.join(root, "tests", "golden", "make_asparam_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    NOSPLIT, VSPLIT, HSPLIT, GROUP_VSPLIT = 0, 1, 2, 6
+    fp = model.fp
+    w4 = model.quant.wbits == 4
+    recs = []
+
+    def host(t):
+        t = t.detach().cpu().contiguous()
+        if t.dtype == torch.bfloat16:
+            return t.view(torch.int16).numpy().view(np.uint16), True
+        return t.numpy(), False
+
+    def put(name, t, mode, groups=()):
+        a, bf = host(t)
+        recs.append((name, a, mode, bf, list(groups)))
+
+    def lowp(name, qsz, mode, groups=()):
+        q, s, z = qsz
+        put(name + ".weight", q, mode, [x // 2 for x in groups] if w4 else groups)
+        # parameters of a row-split weight: sub-channel -> split along the groups, per-channel -> whole on every rank (qwen_v15.py:556-569)
+        pmode = mode if (mode != HSPLIT or group > 0) else NOSPLIT
+        put(name + ".weight.scale", s, pmode, groups)
+        put(name + ".weight.zero_point", z, pmode, groups)
+
+    qkv = [n_heads * head_dim, n_kv * head_dim, n_kv * head_dim]
+    put("embedding.word_embeddings", fp["embed"], NOSPLIT)
+    for li in range(len(model.layers)):
+        p = f"decoder.layer.{li}."
+        put(p + "attention.layernorm.gamma", fp[li]["ln1"], NOSPLIT)
+        put(p + "ffn.layernorm.gamma", fp[li]["ln2"], NOSPLIT)
+        lowp(p + "attention.self", fp[li]["qkv"], GROUP_VSPLIT, qkv)
+        put(p + "attention.self.bias", fp[li]["qkv_bias"], GROUP_VSPLIT, qkv)
+        lowp(p + "attention.output.dense", fp[li]["o"], HSPLIT)
+        lowp(p + "ffn.intermediate.dense", fp[li]["gate"], VSPLIT)
+        lowp(p + "ffn.linear.dense", fp[li]["up"], VSPLIT)
+        lowp(p + "ffn.output.dense", fp[li]["down"], HSPLIT)
+    put("final.layernorm.gamma", fp["final_norm"], NOSPLIT)
+    put("lm_head.weight", fp["lm_head"], HSPLIT if tp_lm_head else VSPLIT)
+    mk.write(path, recs)
+    return len(recs)
+
+
+def run_tp_decode_host(nranks, kv_mode, batch, wbits, group, weight_file=None, n_kv=2, return_results=False):
     """Tensor-parallel decode through the C++ OPERATOR LAYER: one hostapi.Model (HIPContext with rank / nranks, the rank's one-shot
     P2P communicator) per rank THREAD, the reference's operator list with its AllReduce operators and the K-split lm_head
     (ref_graph.qwen2_graph(tp_allreduce=True, tp_lm_head=True): qwen_v15.py:187-388, model_base.py:690-703) -> fusion pass ->
@@ -254,7 +305,7 @@ def run_tp_decode_host(nranks, kv_mode, batch, wbits, group):
     layers only change the f32 summation order; the TP tail's logits are FT: tolerance 2^-7 of the logit scale).  The reference runs a
     thread per rank in one process as well (as_engine.cpp:243-286)."""
     from dash_infer_amd import decoder, hostapi, ops, ref_graph, tp
-    cfg = decoder.ModelConfig("tp-host-test", hidden=1024, layers=2, n_heads=8, n_kv=2, head_dim=128, inter=1024, vocab=4096)
+    cfg = decoder.ModelConfig("tp-host-test", hidden=1024, layers=2, n_heads=8, n_kv=n_kv, head_dim=128, inter=1024, vocab=4096)
     if nranks == 8:
         cfg = decoder.ModelConfig("tp8-host-test", hidden=1024, layers=2, n_heads=28, n_kv=4, head_dim=128, inter=1024, vocab=4096)
     spec = decoder.QuantSpec(wbits, group)
@@ -278,7 +329,9 @@ def run_tp_decode_host(nranks, kv_mode, batch, wbits, group):
     def worker(rank):
         try:
             torch.cuda.set_device(0)
-            model = decoder.build_random_model(cfg, spec, seed=99, rank=rank, nranks=nranks, keep_fp=True, lm_head_split="k")
+            # weight_file: the rank's tensors come from ONE export of the whole model, split at load by the C++ layer (dihost_weights_load_file:
+            # the reference's WeightSplitter rules); else from decoder.build_random_model's own tp.py slices, bound as tensors
+            model = None if weight_file else decoder.build_random_model(cfg, spec, seed=99, rank=rank, nranks=nranks, keep_fp=True, lm_head_split="k")
             comm = LoopbackP2PComm(shared, rank, nranks)
             g_loc = len(tp.shard_heads(cfg.n_heads, cfg.n_kv, nranks)[rank].kv_heads)
             st = torch.cuda.Stream()
@@ -288,7 +341,10 @@ def run_tp_decode_host(nranks, kv_mode, batch, wbits, group):
                     m = hostapi.Model(ops.cur_stream(), cfg.n_heads, cfg.n_kv, cfg.head_dim, span, KV[kv_mode], max_batch=batch, max_len=max_len,
                                       rank=rank, nranks=nranks)
                     m.set_p2p_comm(comm.handle)
-                    ref_graph.register_weights(m, model)
+                    if weight_file:
+                        assert m.load_weight_file(weight_file) > 0
+                    else:
+                        ref_graph.register_weights(m, model)
                     ref_graph.add_graph(m, ref_graph.qwen2_graph(nl, wbits, group, cfg.eps, cfg.n_heads, cfg.n_kv, cfg.rope_theta,
                                                                  tp_allreduce=True, tp_lm_head=True))
                     reports[rank] = m.graph_build(fuse=True)
@@ -337,7 +393,36 @@ def run_tp_decode_host(nranks, kv_mode, batch, wbits, group):
         assert np.array_equal(ids_tp[sure], ref_ids[sure]), f"step {t}: greedy ids"
         if not np.array_equal(ids_tp, ref_ids):
             break
-    print(f"[host TP loop-back] nranks {nranks}, batch {batch}, kv {kv_mode}: {reports[0]['ops']} operators, logits within tolerance, ids equal", flush=True)
+    print(f"[host TP loop-back] nranks {nranks}, batch {batch}, kv {kv_mode}{', weights split at load from ' + weight_file if weight_file else ''}: "
+          f"{reports[0]['ops']} operators, logits within tolerance, ids equal", flush=True)
+    if return_results:
+        return results
+
+
+def run_tp_decode_host_from_file(nranks, kv_mode, batch, wbits, group, n_kv):
+    """VERDICT r5 missing #1 / next #7: ONE serialized export of the whole model (written by the reference's own writer with the
+    converter's SplitModes and group_lists) feeds every rank of a TP group -- each rank's C++ model splits the records for itself at load
+    (dihost_weights_load_file: host/weight_file.h SliceForRank = the reference's WeightSplitter rules).  The decode must be BIT-IDENTICAL
+    to the same ranks bound to dash-infer_amd/tp.py's slices as tensors (the run above), logits row and tokens, every step, every rank."""
+    import os
+    import tempfile
+    from dash_infer_amd import decoder
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", "libdashinfer_ref_asparam.so")):
+        print("[host TP from file] oracle/_ref/libdashinfer_ref_asparam.so not built: skipped", flush=True)
+        return
+    cfg = decoder.ModelConfig("tp-host-test", hidden=1024, layers=2, n_heads=8, n_kv=n_kv, head_dim=128, inter=1024, vocab=4096)
+    whole = decoder.build_random_model(cfg, decoder.QuantSpec(wbits, group), seed=99, keep_fp=True)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "whole_model.asparam")
+        n = write_model_asparam(path, whole, cfg.n_heads, cfg.n_kv, cfg.head_dim, group)
+        del whole
+        bound = run_tp_decode_host(nranks, kv_mode, batch, wbits, group, n_kv=n_kv, return_results=True)
+        loaded = run_tp_decode_host(nranks, kv_mode, batch, wbits, group, weight_file=path, n_kv=n_kv, return_results=True)
+    for r in range(nranks):
+        for t, ((la, ia), (lb, ib)) in enumerate(zip(bound[r], loaded[r])):
+            assert np.array_equal(la, lb) and np.array_equal(ia, ib), f"rank {r} step {t}: split-at-load differs from the tensor-bound slices"
+    print(f"[host TP from file] nranks {nranks}: {n} records, every rank's logits and tokens bit-identical to the tensor-bound run", flush=True)
 
 
 def _view_bf16(ptr, shape):
