@@ -12,8 +12,9 @@ from tests import tp_loopback_lib  # noqa: E402
 
 if sys.argv[1] == "allreduce":
     tp_loopback_lib.run_p2p_allreduce(int(sys.argv[2]))
-elif sys.argv[1] == "hostfile":  # hostfile <nranks> <kv> <batch> <wbits> <group> <n_kv>: the same with the weights split at load from ONE export
-    tp_loopback_lib.run_tp_decode_host_from_file(int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]))
+elif sys.argv[1] == "hostfile":  # hostfile <nranks> <kv> <batch> <wbits> <group> <n_kv> <file|bound> <out.npz>: weights split at load from ONE export / bound as tensors
+    tp_loopback_lib.run_tp_decode_host_from_file(int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]),
+                                                 sys.argv[8], sys.argv[9])
 elif sys.argv[1] == "hostdecode":  # hostdecode <nranks> <kv> <batch> <wbits> <group>: the C++ operator layer, a rank per thread
     tp_loopback_lib.run_tp_decode_host(int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]))
 else:

@@ -71,8 +71,19 @@ def test_tp_decode_through_the_cpp_operator_layer(pkg, nranks, kv_mode, batch, w
 
 
 @pytest.mark.parametrize("nranks,kv_mode,batch,wbits,group,n_kv", [(2, "none", 1, 4, 128, 2), (4, "none", 2, 4, 128, 4), (2, "i8", 3, 8, -1, 2)])
-def test_tp_ranks_split_one_serialized_export_at_load(pkg, nranks, kv_mode, batch, wbits, group, n_kv):
+def test_tp_ranks_split_one_serialized_export_at_load(pkg, tmp_path, nranks, kv_mode, batch, wbits, group, n_kv):
     """a whole-model .asparam written by the reference's writer (the converter's SplitModes + group_lists) ->
-    dihost_weights_load_file on every rank of a TP 2 / 4 group splits it for that rank -> logits and tokens bit-identical to the ranks bound
-    to tp.py's slices as tensors; int4 sub-channel (parameters split along the groups) and int8 per-channel (parameters whole)."""
-    run_worker("hostfile", nranks, kv_mode, batch, wbits, group, n_kv)
+    dihost_weights_load_file on every rank of a TP 2 / 4 group splits it for that rank -> logits and tokens BIT-IDENTICAL to the ranks bound
+    to tp.py's slices as tensors; int4 sub-channel (parameters split along the groups) and int8 per-channel (parameters whole).  One
+    variant per worker process (tests/tp_loopback_lib.py run_tp_decode_host_from_file)."""
+    import numpy as np
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdashinfer_ref_asparam.so")):
+        pytest.skip("oracle/_ref/libdashinfer_ref_asparam.so not built (needs /root/reference: oracle/Makefile refasparam)")
+    out = {}
+    for which in ("bound", "file"):
+        path = str(tmp_path / f"{which}.npz")
+        run_worker("hostfile", nranks, kv_mode, batch, wbits, group, n_kv, which, path)
+        out[which] = np.load(path)
+    assert sorted(out["bound"].files) == sorted(out["file"].files) and len(out["file"].files) == nranks * 5 * 2
+    for k in out["bound"].files:
+        assert np.array_equal(out["bound"][k], out["file"][k]), f"{k}: split-at-load differs from the tensor-bound slices"

@@ -399,30 +399,31 @@ def run_tp_decode_host(nranks, kv_mode, batch, wbits, group, weight_file=None, n
         return results
 
 
-def run_tp_decode_host_from_file(nranks, kv_mode, batch, wbits, group, n_kv):
+def run_tp_decode_host_from_file(nranks, kv_mode, batch, wbits, group, n_kv, which, out_path):
     """VERDICT r5 missing #1 / next #7: ONE serialized export of the whole model (written by the reference's own writer with the
     converter's SplitModes and group_lists) feeds every rank of a TP group -- each rank's C++ model splits the records for itself at load
     (dihost_weights_load_file: host/weight_file.h SliceForRank = the reference's WeightSplitter rules).  The decode must be BIT-IDENTICAL
-    to the same ranks bound to dash-infer_amd/tp.py's slices as tensors (the run above), logits row and tokens, every step, every rank."""
+    to the same ranks bound to dash-infer_amd/tp.py's slices as tensors, logits row and tokens, every step, every rank.
+    which = "file" | "bound": ONE variant per process (rank threads of two runs in one process can end up sharing a hardware queue,
+    and a rank that waits for a peer queued behind it never returns); every rank's (logits, ids) of every step -> out_path (.npz)."""
     import os
     import tempfile
     from dash_infer_amd import decoder
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if not os.path.exists(os.path.join(root, "oracle", "_ref", "libdashinfer_ref_asparam.so")):
+    if which == "file" and not os.path.exists(os.path.join(root, "oracle", "_ref", "libdashinfer_ref_asparam.so")):
         print("[host TP from file] oracle/_ref/libdashinfer_ref_asparam.so not built: skipped", flush=True)
         return
-    cfg = decoder.ModelConfig("tp-host-test", hidden=1024, layers=2, n_heads=8, n_kv=n_kv, head_dim=128, inter=1024, vocab=4096)
-    whole = decoder.build_random_model(cfg, decoder.QuantSpec(wbits, group), seed=99, keep_fp=True)
     with tempfile.TemporaryDirectory() as d:
-        path = os.path.join(d, "whole_model.asparam")
-        n = write_model_asparam(path, whole, cfg.n_heads, cfg.n_kv, cfg.head_dim, group)
-        del whole
-        bound = run_tp_decode_host(nranks, kv_mode, batch, wbits, group, n_kv=n_kv, return_results=True)
-        loaded = run_tp_decode_host(nranks, kv_mode, batch, wbits, group, weight_file=path, n_kv=n_kv, return_results=True)
-    for r in range(nranks):
-        for t, ((la, ia), (lb, ib)) in enumerate(zip(bound[r], loaded[r])):
-            assert np.array_equal(la, lb) and np.array_equal(ia, ib), f"rank {r} step {t}: split-at-load differs from the tensor-bound slices"
-    print(f"[host TP from file] nranks {nranks}: {n} records, every rank's logits and tokens bit-identical to the tensor-bound run", flush=True)
+        path = None
+        if which == "file":
+            cfg = decoder.ModelConfig("tp-host-test", hidden=1024, layers=2, n_heads=8, n_kv=n_kv, head_dim=128, inter=1024, vocab=4096)
+            whole = decoder.build_random_model(cfg, decoder.QuantSpec(wbits, group), seed=99, keep_fp=True)
+            path = os.path.join(d, "whole_model.asparam")
+            n = write_model_asparam(path, whole, cfg.n_heads, cfg.n_kv, cfg.head_dim, group)
+            del whole
+            print(f"[host TP from file] {n} records written by the reference's writer", flush=True)
+        res = run_tp_decode_host(nranks, kv_mode, batch, wbits, group, weight_file=path, n_kv=n_kv, return_results=True)
+    np.savez(out_path, **{f"r{r}_t{t}_{k}": v for r in range(nranks) for t, (lo, ids) in enumerate(res[r]) for k, v in (("logits", lo), ("ids", ids))})
 
 
 def _view_bf16(ptr, shape):
