@@ -2,6 +2,7 @@
 // csrc/core/operator/nccl/allreduce/allreduce_op.cpp:23-95): in -> out sum all-reduce over the RCCL
 // communicator of the context.  Unlike the reference (which calls ctx->Synchronize() after the
 // collective, allreduce_op.cpp:90) the op only enqueues: ordering is the stream's.
+#include <algorithm>
 #include <cstdlib>
 
 #include "dashinfer_hip.h"
@@ -41,6 +42,17 @@ class AllReduceOpHIP : public AsOperator {
     if (h->GetP2PComm() && bytes <= dihip_p2p_ar_max_bytes() && bytes % 16 == 0)  // decode rows: latency bound on a ring, one shot over xGMI instead
       return FromDihip(dihip_p2p_allreduce_sum(h->GetP2PComm(), h->GetStream(), x->GetDataPtr(), y->GetDataPtr(), (size_t)count_,
                                                DihipDtype(x->GetDataType())));
+    if (h->GetP2PComm() && !h->GetRCCLComm() && bytes % 16 == 0) {
+      // no RCCL communicator (rank threads on one GPU; a node set up with the peer-to-peer path only): a longer message -- the K-split
+      // lm_head's logits rows -- goes out as slot-sized pieces, each a one-shot exchange of its own
+      const size_t es = SizeofType(x->GetDataType()), piece = dihip_p2p_ar_max_bytes() / es;
+      for (size_t at = 0; at < (size_t)count_; at += piece) {
+        const size_t n = std::min(piece, (size_t)count_ - at);
+        AS_CHECK_STATUS(FromDihip(dihip_p2p_allreduce_sum(h->GetP2PComm(), h->GetStream(), (const char*)x->GetDataPtr() + at * es,
+                                                          (char*)y->GetDataPtr() + at * es, n, DihipDtype(x->GetDataType()))));
+      }
+      return AsStatus::ALLSPARK_SUCCESS;
+    }
     if (!h->GetRCCLComm()) return AsStatus::ALLSPARK_PARAM_ERROR;
     return FromDihip(dihip_allreduce_sum(h->GetRCCLComm(), h->GetStream(), x->GetDataPtr(), y->GetDataPtr(), (size_t)count_,
                                          DihipDtype(x->GetDataType())));

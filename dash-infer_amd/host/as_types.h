@@ -212,6 +212,10 @@ class HIPContext : public DeviceContext {
     return it == row_norm_.end() ? RowNormState{} : it->second;
   }
   // the fused attention block's hand-offs timed out once (model_runner.cpp Sync read the error word): the launch chain serves from then on
+  // the tensor the graph's first operator reads the token ids from (the model runner sets it; the sampling operator reads the prompt
+  // length off its shape in the context phase)
+  const std::string& InputIdsName() const { return ids_name_; }
+  void SetInputIdsName(const std::string& n) const { ids_name_ = n; }
   bool AttnBlockDisabled() const { return attn_block_off_; }
   void DisableAttnBlock() const { attn_block_off_ = true; }
   void RegisterProducer(const std::string& tensor, void* op) const { producer_[tensor] = op; }
@@ -228,6 +232,7 @@ class HIPContext : public DeviceContext {
   mutable std::map<std::string, int> act_layout_;
   mutable bool lens_on_device_ = false;
   mutable bool attn_block_off_ = false;
+  mutable std::string ids_name_ = "input_ids";
   mutable std::map<std::string, void*> producer_;
   mutable std::map<std::string, RowNormState> row_norm_;
 };

@@ -991,14 +991,19 @@ class DihipGreedyOp : public AsOperator {
   AsStatus Reshape(RuntimeContext* rt) override {
     AsTensor* x = tensor_map_->at(in_names_[0]).get();
     const Shape& s = x->GetShape();
-    if (s.size() < 2 || x->GetDataType() != FLOAT32) return AsStatus::ALLSPARK_PARAM_ERROR;
+    // f32 logits from DihipLMHead; FT logits from the tensor-parallel tail (Gemm(splitk) + AllReduce, model_base.py:690-703): cast to f32 first
+    if (s.size() < 2 || (x->GetDataType() != FLOAT32 && x->GetDataType() != BFLOAT16 && x->GetDataType() != FLOAT16)) return AsStatus::ALLSPARK_PARAM_ERROR;
     vocab_ = (int)s.back();
     rows_ = (int)(x->Count() / vocab_);
+    if (x->GetDataType() != FLOAT32) {
+      if (!f32_) f32_ = std::make_unique<AsTensor>(op_name_ + ".logits_f32", DeviceType::HIP, FLOAT32, Shape{(int64_t)rows_ * vocab_});
+      AS_CHECK_STATUS(f32_->SetShape(Shape{(int64_t)rows_ * vocab_}));
+    }
     // rows of this forward per request (the context phase's prompt length): this operator sees the LAST row's logits only, so the
     // length comes from the graph's input ids (GenerateOpHIP reads it off its [batch, seq, vocab] input) -- used for the sampled
     // token's position when no virtual cache carries the sequence length (sampling_host.h: StagePositions)
     seq_ = 1;
-    auto ids = tensor_map_->find("input_ids");
+    auto ids = tensor_map_->find(hip_ctx(ctx_).InputIdsName());  // (the runner names the graph's id tensor: a converter export need not call it "input_ids")
     if (rt && rt->is_context && ids != tensor_map_->end() && ids->second->GetShape().size() >= 2) seq_ = std::max(1, (int)ids->second->GetShape()[1]);
     if (rt && rt->GetGenCtxListSize() > 0) AS_CHECK_STATUS(params_.Gather(rt, rows_, stream_of(ctx_)));
     AsTensor* y = tensor_map_->at(out_names_[0]).get();
@@ -1019,6 +1024,15 @@ class DihipGreedyOp : public AsOperator {
       ca = (uint32_t*)o->second->GetDataPtr();
       cb = (uint32_t*)n->second->GetDataPtr();
     }
+    const float* logits = (const float*)x->GetDataPtr();
+    if (x->GetDataType() != FLOAT32) {
+      // GenerateOp's rows: the last row of every request ([batch, seq, vocab] -> seq - 1 in the context phase, batch 1; get_last_line semantics)
+      const size_t es = SizeofType(x->GetDataType());
+      const char* last = (const char*)x->GetDataPtr() + (x->GetShape().size() == 3 ? (size_t)(x->GetShape()[1] - 1) * vocab_ * es : 0);
+      const int rows = x->GetShape().size() == 3 ? (int)x->GetShape()[0] : rows_;
+      AS_CHECK_STATUS(FromDihip(dihip_cast_to_f32(s, (float*)f32_->GetDataPtr(), last, (size_t)rows * vocab_, DihipDtype(x->GetDataType()))));
+      logits = (const float*)f32_->GetDataPtr();
+    }
     if (params_.any_sampling()) {
       // position of the sampled token = tokens in the sequence after this step: new_seq_lens on the device, else staged
       const uint32_t* pos = cb;
@@ -1026,20 +1040,20 @@ class DihipGreedyOp : public AsOperator {
         AS_CHECK_STATUS(params_.StagePositions(rt, rt->is_context ? seq_ : 1, s));
         pos = params_.dev_pos();
       }
-      return FromDihip(dihip_sample(s, (int64_t*)y->GetDataPtr(), (const float*)x->GetDataPtr(), rows_, vocab_, params_.top_k(), params_.top_p(),
+      return FromDihip(dihip_sample(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, params_.top_k(), params_.top_p(),
                                     params_.temperature(), params_.seed(), pos, ca, cb, nullptr, nullptr));
     }
     if (on_dev) {
       auto o = tensor_map_->find("dihip.old_seq_lens"), n = tensor_map_->find("dihip.new_seq_lens");
-      return FromDihip(dihip_argmax_advance(s, (int64_t*)y->GetDataPtr(), (const float*)x->GetDataPtr(), rows_, vocab_, ws_->GetDataPtr(),
+      return FromDihip(dihip_argmax_advance(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, ws_->GetDataPtr(),
                                             ws_->GetSizeInByte(), (uint32_t*)o->second->GetDataPtr(), (uint32_t*)n->second->GetDataPtr()));
     }
-    return FromDihip(dihip_argmax(s, (int64_t*)y->GetDataPtr(), (const float*)x->GetDataPtr(), rows_, vocab_, ws_->GetDataPtr(), ws_->GetSizeInByte()));
+    return FromDihip(dihip_argmax(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, ws_->GetDataPtr(), ws_->GetSizeInByte()));
   }
 
  private:
   int rows_ = 0, vocab_ = 0, seq_ = 1;
-  std::unique_ptr<AsTensor> ws_;
+  std::unique_ptr<AsTensor> ws_, f32_;
   SamplingParams params_;
 };
 REGISTER_OP(DihipGreedy, HIP, DihipGreedyOp)

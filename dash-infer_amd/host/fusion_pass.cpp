@@ -333,9 +333,15 @@ std::vector<OperatorProto> FuseDecoderGraph(const std::vector<OperatorProto>& gr
     copy_attr(f_norm, *lnf, "eps");
     out.push_back(std::move(f_norm));
     for (size_t j = tail_at; j < tail_end; ++j) out.push_back(graph[j]);
+    // the sampling operator of such a tail: DihipGreedy reads FT logits too (cast to f32 first) and advances the device-resident
+    // length counters in its launch, so the step state stays on the device under tensor parallelism as well -- GetLastLine, Gemm(splitk)
+    // and AllReduce only enqueue -- and the step replays as a hipGraph.  Sampling parameters as in the one-rank list.
+    OperatorProto& gen_tp = out.back();
+    gen_tp.op_type = "DihipGreedy";
+    gen_tp.inputs.resize(1);
     rep.fused = true;
-    rep.device_resident = false;
-    rep.why = "layers fused, the tail runs on the reference's own operators (" + why_simple + ")";
+    rep.device_resident = true;
+    rep.why = "layers fused, the tail keeps the reference's operators (" + why_simple + ") in front of DihipGreedy";
     rep.ops_after = (int)out.size();
     return out;
   }

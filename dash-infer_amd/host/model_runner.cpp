@@ -49,6 +49,7 @@ AsStatus HipModelRunner::Build(const std::vector<OperatorProto>& graph, bool fus
   }
   fused_ = fusion_.fused && fusion_.device_resident;  // device-resident step state (and graph replay) needs the fused tail
   ids_in_name_ = protos_.front().inputs[0];
+  ctx_->SetInputIdsName(ids_in_name_);
   // The converter's gen_graph writes the sampled ids back into the tensor the embedding reads ("dec_ids", qwen_v15.py:440-447:
   // gen_op.outputs[0].CopyFrom(preprocess_ids.outputs[0])).  Here the input name is re-bound per phase (prompt rows / the running
   // batch's ids) while the sampling operator's output is one fixed device buffer: the output gets a name of its own.

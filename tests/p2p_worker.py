@@ -16,7 +16,8 @@ elif sys.argv[1] == "hostfile":  # hostfile <nranks> <kv> <batch> <wbits> <group
     tp_loopback_lib.run_tp_decode_host_from_file(int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]),
                                                  sys.argv[8], sys.argv[9])
 elif sys.argv[1] == "hostdecode":  # hostdecode <nranks> <kv> <batch> <wbits> <group>: the C++ operator layer, a rank per thread
-    tp_loopback_lib.run_tp_decode_host(int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]))
+    tp_loopback_lib.run_tp_decode_host(int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]),
+                                       graph=len(sys.argv) > 7 and sys.argv[7] == "graph")
 else:
     nranks, kv, batch, wbits, group, overlap = int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), bool(int(sys.argv[7]))
     tp_loopback_lib.run_tp_decode(nranks, kv, batch, wbits, group, sys.argv[8] if len(sys.argv) > 8 else "p2p", overlap)

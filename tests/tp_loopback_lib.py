@@ -295,7 +295,7 @@ def write_model_asparam(path, model, n_heads, n_kv, head_dim, group, tp_lm_head=
     return len(recs)
 
 
-def run_tp_decode_host(nranks, kv_mode, batch, wbits, group, weight_file=None, n_kv=2, return_results=False):
+def run_tp_decode_host(nranks, kv_mode, batch, wbits, group, weight_file=None, n_kv=2, return_results=False, graph=False):
     """Tensor-parallel decode through the C++ OPERATOR LAYER: one hostapi.Model (HIPContext with rank / nranks, the rank's one-shot
     P2P communicator) per rank THREAD, the reference's operator list with its AllReduce operators and the K-split lm_head
     (ref_graph.qwen2_graph(tp_allreduce=True, tp_lm_head=True): qwen_v15.py:187-388, model_base.py:690-703) -> fusion pass ->
@@ -356,7 +356,7 @@ def run_tp_decode_host(nranks, kv_mode, batch, wbits, group, weight_file=None, n
                 shared.bar.wait()
                 out = []
                 for _ in range(steps):
-                    m.decode_steps(1, graph=False)
+                    m.decode_steps(1, graph=graph)   # graph: every rank thread captures its step once (its all-reduce launches inside) and replays it
                     ids = m.sync_ids()
                     _, shp, ptr = m.get_tensor("logits")
                     st.synchronize()
@@ -377,7 +377,7 @@ def run_tp_decode_host(nranks, kv_mode, batch, wbits, group, weight_file=None, n
     shared.close()
     assert not errors, errors
     assert all(r is not None for r in results)
-    assert all(rep["fused"] for rep in reports), [rep["why"] for rep in reports]
+    assert all(rep["fused"] and rep["device_resident"] for rep in reports), [rep["why"] for rep in reports]
     for t in range(steps):
         logits, ids_tp = results[0][t]
         assert logits.shape[1] == cfg.vocab
@@ -393,7 +393,7 @@ def run_tp_decode_host(nranks, kv_mode, batch, wbits, group, weight_file=None, n
         assert np.array_equal(ids_tp[sure], ref_ids[sure]), f"step {t}: greedy ids"
         if not np.array_equal(ids_tp, ref_ids):
             break
-    print(f"[host TP loop-back] nranks {nranks}, batch {batch}, kv {kv_mode}{', weights split at load from ' + weight_file if weight_file else ''}: "
+    print(f"[host TP loop-back] nranks {nranks}, batch {batch}, kv {kv_mode}{', hipGraph replay' if graph else ''}{', weights split at load from ' + weight_file if weight_file else ''}: "
           f"{reports[0]['ops']} operators, logits within tolerance, ids equal", flush=True)
     if return_results:
         return results
