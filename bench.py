@@ -292,6 +292,69 @@ def host_runner_bench(args, torch, decoder, ops, model, sess, batch, max_len, kv
             "why_unfused": rep["why"] if not rep["fused"] else None, "last_ids": last[:4]}
 
 
+def host_runner_bench_tp(args, torch, decoder, ops, cfg, spec, sess, comm, batch, max_len, kv_mode, rank, world, local_rank, steps, blocks):
+    """N > 1: the decode step through the C++ operator layer on every rank -- one HipModelRunner per rank PROCESS over
+    its tp.py weight slices (the reference-shaped K-split lm_head: Gemm(splitk) + AllReduce, model_base.py:690-703), the reference's
+    operator list with its AllReduce operators -> fusion pass -> OpFactory(HIP), HIPContext carrying the rank's RCCL communicator (and
+    the one-shot P2P communicator when it passed its probe: AllReduceOpHIP takes it for decode rows), the step captured and replayed as
+    a hipGraph.  Set-up is VOTED: a rank that cannot build its model makes every rank skip the leg (nobody is left alone in a
+    collective).  -> the host_runner record, or {"skipped": why}."""
+    import torch.distributed as dist
+    from dash_infer_amd import hostapi, ref_graph
+    dev = torch.device("cuda", local_rank)
+    m, err, stream = None, None, torch.cuda.Stream()
+    rccl = comm.rccl if isinstance(comm, decoder.P2PComm) else comm
+    try:
+        if not isinstance(rccl, decoder.RcclComm):
+            raise RuntimeError(f"the C++ layer needs the C-ABI RCCL communicator (got {type(rccl).__name__})")
+        model_k = decoder.build_random_model(cfg, spec, seed=1234, rank=rank, nranks=world, layers=args.layers, keep_fp=True, lm_head_split="k")
+        kvc = {"none": 0, "i8": 1, "u4": 2}[kv_mode]
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            m = hostapi.Model(ops.cur_stream(), cfg.n_heads, cfg.n_kv, cfg.head_dim, sess.pool.S, kvc, max_batch=batch, max_len=max_len,
+                              rank=rank, nranks=world, comm=rccl.handle)
+            if isinstance(comm, decoder.P2PComm):
+                m.set_p2p_comm(comm.handle)
+            ref_graph.register_weights(m, model_k)
+            g = ref_graph.qwen2_graph(len(model_k.layers), model_k.quant.wbits, model_k.quant.group, cfg.eps, cfg.n_heads, cfg.n_kv, cfg.rope_theta,
+                                      tp_allreduce=True, tp_lm_head=True)
+            m.graph_add_serialized(ref_graph.to_transformer_proto(g))
+            rep = m.graph_build(fuse=True)
+            if not (rep["fused"] and rep["device_resident"]):
+                raise RuntimeError("the tensor-parallel list did not fuse: " + rep["why"])
+            gen = torch.Generator().manual_seed(7)
+            ids = torch.randint(0, cfg.vocab, (batch,), generator=gen).tolist()
+            for b in range(batch):
+                ks = [[int(p) for p in sess.kv[li].k_host[b].tolist()] for li in range(len(model_k.layers))]
+                vs = [[int(p) for p in sess.kv[li].v_host[b].tolist()] for li in range(len(model_k.layers))]
+                m.request_adopt(SEQ_LEN, ids[b], ks, vs)
+        stream.synchronize()
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"[:300]
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        if m is not None:
+            m.close()
+        return {"skipped": err or "another rank could not set the C++ runner up"}
+    try:
+        with torch.cuda.stream(stream):
+            m.decode_steps(max(2, args.warmup), graph=True)
+            m.sync_ids()
+
+            def run_n(n):
+                m.decode_steps(n, graph=True)
+
+            med, times = timed_blocks(run_n, steps, blocks, world, dev, sync=stream.synchronize, before_block=lambda: m.requests_rewind(SEQ_LEN))
+            last = m.sync_ids()
+    finally:
+        m.close()
+    return {"fused_graph": {"tokens_per_s": round(batch * steps / med, 2), "ms_per_step": round(med / steps * 1e3, 4), "blocks": blocks_summary(times, steps),
+                            "fused": True, "operators": f"{rep['ops']} ({len(rep['types'])} operators run per step)", "hipGraph": True,
+                            "allreduce": "AllReduceOpHIP: " + ("one-shot P2P for decode rows, RCCL beyond" if isinstance(comm, decoder.P2PComm) else "RCCL"),
+                            "lm_head": "K-split Gemm + AllReduce (the reference's TP tail)", "last_ids": last[:4]}}
+
+
 def prefill_bench(args, torch, decoder, ops):
     """--workload prefill_2048 (see WORKLOADS).  Timed with HIP events on the launch stream around whole prefill calls (eager
     launches: the context phase is not graph-captured); the attention kernel alone is timed the same way over all layers' calls."""
@@ -902,6 +965,8 @@ def headline_line(out, detail=None, limit=4096):
         if out.get(k) not in (None, False):
             line[k] = _short(out[k], 160) if isinstance(out[k], str) else out[k]
     line["runner"] = _short(out.get("runner", ""), 90)
+    if isinstance(out.get("host_runner"), dict) and out["host_runner"].get("skipped"):
+        line["host_runner_skipped"] = _short(out["host_runner"]["skipped"], 160)
     if out.get("python_runner"):
         line["python_runner_tokens_per_s"] = out["python_runner"].get("tokens_per_s")
     if out.get("blocks"):
@@ -1120,7 +1185,24 @@ def main():
             if args.runner == "host":
                 raise
             host_runner = {"error": repr(e)}
-    value_from_host = host_leg and isinstance(host_runner, dict) and "fused_graph" in host_runner and host_runner["fused_graph"].get("fused")
+    if world == 1 and os.environ.get("DIHIP_BENCH_HOST_TP") == "force" and cfg.moe is None:
+        # plumbing check on a one-GPU box: the N > 1 leg with a ONE-rank process group and RCCL communicator (the list keeps its AllReduce
+        # operators and the K-split tail; nothing is exchanged).  Not a measurement: reported under host_runner_tp_selftest only.
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        c1 = decoder.RcclComm(0, 1, torch.device("cuda", local_rank))
+        selftest = host_runner_bench_tp(args, torch, decoder, ops, cfg, spec, sess, c1, batch, max_len, kv_mode, 0, 1, local_rank, max(4, args.steps // 4), 1)
+        dist.destroy_process_group()
+        if isinstance(host_runner, dict):
+            host_runner["tp_leg_selftest_one_rank"] = selftest
+    if world > 1 and args.runner != "python" and os.environ.get("DIHIP_BENCH_HOST_TP", "1") != "0" and cfg.moe is None:
+        host_runner = host_runner_bench_tp(args, torch, decoder, ops, cfg, spec, sess, comm, batch, max_len, kv_mode, rank, world, local_rank,
+                                           args.steps, blocks)
+        if "fused_graph" in host_runner:
+            host_runner["fused_graph_vs_python_runner"] = round(host_runner["fused_graph"]["tokens_per_s"] / python_runner["tokens_per_s"], 4)
+    value_from_host = isinstance(host_runner, dict) and "fused_graph" in host_runner and host_runner["fused_graph"].get("fused")
     if value_from_host:
         elapsed = host_runner["fused_graph"]["ms_per_step"] * 1e-3 * args.steps
         block_times = None
@@ -1160,7 +1242,8 @@ def main():
                    "layers": len(model.layers)},
         "step_hbm": {"algorithmic_bytes_per_rank": int(step_bytes), "achieved_GBps_per_gpu": round(step_gbs, 1),
                      "frac_of_peak": round(step_gbs / HBM_PEAK_GBS, 4)},
-        "runner": ("host: C++ operator layer -- reference operator list -> fusion pass -> OpFactory(HIP) -> model runner, hipGraph replay"
+        "runner": (("host: C++ operator layer -- reference operator list -> fusion pass -> OpFactory(HIP) -> model runner, hipGraph replay"
+                    + (f", one runner per rank process (TP={world})" if world > 1 else ""))
                    if value_from_host else "python: decoder.DecodeSession over the C-ABI (hipGraph replay)"),
         "blocks": blocks_summary(block_times, args.steps) if block_times else (host_runner or {}).get("fused_graph", {}).get("blocks"),
         "python_runner": python_runner,
