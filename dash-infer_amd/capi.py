@@ -109,6 +109,7 @@ _SIGS = {
     "dihip_argmax": (i32, [vp, vp, vp, i32, i32, vp, sz]),
     "dihip_argmax_advance": (i32, [vp, vp, vp, i32, i32, vp, sz, vp, vp]),
     "dihip_sample": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dihip_sample_rows": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32]),
     "dihip_argmax_partial": (i32, [vp, vp, vp, i32, i32, i32, vp, sz]),
     "dihip_argmax_merge": (i32, [vp, vp, vp, i32, i32]),
     "dihip_embedding": (i32, [vp, vp, vp, vp, i32, i32, i32]),

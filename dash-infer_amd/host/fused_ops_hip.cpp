@@ -1040,8 +1040,8 @@ class DihipGreedyOp : public AsOperator {
         AS_CHECK_STATUS(params_.StagePositions(rt, rt->is_context ? seq_ : 1, s));
         pos = params_.dev_pos();
       }
-      return FromDihip(dihip_sample(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, params_.top_k(), params_.top_p(),
-                                    params_.temperature(), params_.seed(), pos, ca, cb, nullptr, nullptr));
+      return FromDihip(dihip_sample_rows(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, params_.top_k(), params_.top_p(),
+                                         params_.temperature(), params_.seed(), pos, ca, cb, params_.wide_rows()));
     }
     if (on_dev) {
       auto o = tensor_map_->find("dihip.old_seq_lens"), n = tensor_map_->find("dihip.new_seq_lens");

@@ -364,8 +364,8 @@ class GenerateOpHIP : public AsOperator {
     }
     if (rt && rt->GetGenCtxListSize() > 0 && params_.any_sampling()) {
       AS_CHECK_STATUS(params_.StagePositions(rt, rt->is_context ? seq_ : 1, s));
-      return FromDihip(dihip_sample(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, params_.top_k(), params_.top_p(), params_.temperature(),
-                                    params_.seed(), params_.dev_pos(), nullptr, nullptr, nullptr, nullptr));
+      return FromDihip(dihip_sample_rows(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, params_.top_k(), params_.top_p(), params_.temperature(),
+                                         params_.seed(), params_.dev_pos(), nullptr, nullptr, params_.wide_rows()));
     }
     return FromDihip(dihip_argmax(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, ws + off, wsp->GetSizeInByte() - off));
   }

@@ -16,10 +16,12 @@ class SamplingParams {
     if (staged_) (void)hipEventDestroy(staged_);
   }
   bool any_sampling() const { return any_; }
+  int wide_rows() const { return wide_; }  // rows with top_k == 0 or > 1024 (dihip_sample_rows launches the wide kernel only when there are any)
   // Reshape time: the requests of this forward (context: the one being prefilled)
   AsStatus Gather(const RuntimeContext* rt, int rows, hipStream_t s) {
     rows_ = rows;
     any_ = false;
+    wide_ = 0;
     const size_t per = sizeof(int) + 2 * sizeof(float) + sizeof(unsigned long long) + sizeof(uint32_t);
     // the previous forward's staging copy reads host_: it must have completed before the buffer is freed or rewritten
     if (staged_ && hipEventSynchronize(staged_) != hipSuccess) return AsStatus::ALLSPARK_RUNTIME_ERROR;
@@ -40,10 +42,10 @@ class SamplingParams {
       const GenerateContext* gc = rt->is_context ? rt->GetContextGenCtx() : rt->GetGenCtx(i);
       const GenerateConfig& g = gc->gen_cfg;
       if (!(g.temperature >= std::numeric_limits<float>::min())) return AsStatus::ALLSPARK_PARAM_ERROR;  // generate_op.cpp:357-362
-      // top_k == 0 is "the whole vocabulary" (real_k = vocab_size_, generate_op.cpp:338-339): like the reference's
-      // CONFIG_SAMPLE_CONSTRAIN_MAX_K build (:383-391, max_k_ > 1024 -> PARAM_ERROR) this backend serves 1 <= k <= 1024 and says
-      // so instead of sampling from a silently truncated distribution (dihip_sample clamps what it cannot check on the device)
-      if (g.top_k <= 0 || g.top_k > 1024) return AsStatus::ALLSPARK_PARAM_ERROR;
+      // top_k == 0 is "the whole vocabulary" (real_k = vocab_size_, generate_op.cpp:338-339: pure top-p sampling) and any k is served, as
+      // the reference's default build does: rows with k == 0 or k > 1024 take the sort-free wide kernel (csrc/sample.hip, round 6)
+      if (g.top_k < 0) return AsStatus::ALLSPARK_PARAM_ERROR;
+      wide_ += g.top_k == 0 || g.top_k > 1024;
       seed[i] = g.seed;
       tk[i] = g.top_k;
       tp[i] = g.top_p;
@@ -86,6 +88,7 @@ class SamplingParams {
   size_t cap_ = 0;
   int rows_ = 0;
   bool any_ = false;
+  int wide_ = 0;
   hipEvent_t staged_ = nullptr;
 };
 

@@ -508,19 +508,24 @@ int dihip_argmax(void* stream, int64_t* ids, const float* logits, int M, int N, 
 int dihip_argmax_advance(void* stream, int64_t* ids, const float* logits, int M, int N, void* ws,
                          size_t ws_bytes, uint32_t* counters_a, uint32_t* counters_b);
 /* The sampling half of GenerateOp (generate_op.cpp:472-600; arithmetic of its x86 path, generate_impl_cpu.hpp:120-170): per row
- *   top-k (k largest logits, descending; 1 <= top_k <= 1024, the reference's CONFIG_SAMPLE_CONSTRAIN_MAX_K limit.  The values live
- *   on the device, so the HOST must reject what is out of range -- top_k == 0, "the whole vocabulary", included: the operators'
- *   SamplingParams::Gather returns ALLSPARK_PARAM_ERROR as generate_op.cpp:383-391 does; the kernel itself clamps to 1024) ->
+ *   top-k (k largest logits, descending; top_k == 0 = the whole vocabulary, generate_op.cpp:338-339; rows with 1 <= top_k <= 1024 sort
+ *   their candidates in LDS, rows with top_k == 0 or > 1024 run the sort-free wide kernel: see dihip_sample_rows) ->
  *   softmax(logit / T) -> top-p (shortest prefix whose cumulated probability EXCEEDS p; p <= 1e-7: off, kernel/cpu/topp.cpp) ->
  *   softmax(logit / T) over the prefix -> exponential race prob_i / -log1p(-u_i), first maximum wins (kernel/cpu/sample.cpp:42-68).
  * top_k / top_p / temperature / seed: device arrays [M].  The random stream is the backend's own, a pure function of
- * (seed[m], position[m], candidate rank): position = device-resident index of the token being sampled (NULL: 0), so that a
+ * (seed[m], position[m], candidate rank -- wide rows: 0x40000000 + token index): position = device-resident index of the token being sampled (NULL: 0), so that a
  * captured step replays; counters_a / _b (may be NULL) advance by one per row like dihip_argmax_advance.  probs_out / cand_out
  * (tests, may be NULL): [M, 1024] final probabilities / candidate indices in sorted order (0 / -1 beyond the kept prefix / k). */
 int dihip_sample(void* stream, int64_t* ids, const float* logits, int M, int N, const int* top_k,
                  const float* top_p, const float* temperature, const unsigned long long* seed,
                  const uint32_t* position, uint32_t* counters_a, uint32_t* counters_b, float* probs_out,
                  int* cand_out);
+/* the same without the diagnostics outputs; wide_rows = how many rows have top_k == 0 (the whole vocabulary: pure top-p sampling, generate_op.cpp:
+ * 338-339) or top_k > 1024 -- those rows run the sort-free wide kernel (csrc/sample.hip: the same pipeline with fixed-point masses, a radix
+ * select by mass for the top-p prefix and a random stream keyed by the token index), launched only when wide_rows != 0 (-1: unknown). */
+int dihip_sample_rows(void* stream, int64_t* ids, const float* logits, int M, int N, const int* top_k, const float* top_p,
+                      const float* temperature, const unsigned long long* seed, const uint32_t* position, uint32_t* counters_a,
+                      uint32_t* counters_b, int wide_rows);
 /* vocabulary-parallel greedy sampling for TP: one {f32 value, i32 global index} pair per row
  * from this rank's logits slice [M, N] (global index = local + index_offset); after an
  * all-gather of the pairs ([nparts][M]) every rank merges them to the same ids.                */

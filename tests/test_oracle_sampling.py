@@ -43,3 +43,19 @@ def test_the_exponential_race_draws_with_the_final_probabilities():
         tok, _ = sampling.sample(logits, top_k=4, top_p=1.0, temperature=1.0, seed=1234, position=pos)
         counts[tok] += 1
     np.testing.assert_allclose(counts / n, probs, atol=0.02)
+
+
+def test_wide_rows_whole_vocabulary_top_p_and_fixed_point_prefix():
+    """top_k == 0 = the whole vocabulary (generate_op.cpp:338-339); the wide restatement picks the same final set as the sorted pipeline
+    (fixed-point masses only move a cut that sits within 2^-32 of the target) and draws with the final probabilities."""
+    rng = np.random.default_rng(3)
+    x = rng.normal(0, 2, 3000).astype(np.float32)
+    for k, p, T in ((0, 0.9, 1.0), (0, 1.0, 1.0), (2000, 0.5, 0.7), (0, 0.0, 1.3)):
+        idx_w, e = sampling.wide_final_set(x, k, p, T)
+        idx_n, p2 = sampling.final_probs(x, k if k else len(x), p, T)
+        assert list(idx_w) == list(idx_n)
+        np.testing.assert_allclose(e / e.sum(), p2, rtol=1e-5)
+    assert len(sampling.candidates(x, 0)[0]) == len(x)               # k = 0: every token is a candidate
+    small = np.log(np.array([0.5, 0.3, 0.2], np.float32))
+    draws = [sampling.sample_wide(small, 0, 1.0, 1.0, 11, pos)[0] for pos in range(3000)]
+    np.testing.assert_allclose(np.bincount(draws, minlength=3) / 3000, [0.5, 0.3, 0.2], atol=0.04)
