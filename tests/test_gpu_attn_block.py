@@ -235,3 +235,43 @@ def test_cpp_runner_reads_the_error_word_at_sync_and_recovers(pkg, monkeypatch):
     assert h.steps(1, graph=True) == want[2]
     assert h.steps(1, graph=True) == want[3]
     h.close()
+
+
+def test_block_under_load_is_bit_identical_and_never_times_out(pkg):
+    """The launch's hand-offs (tagged granules, polled split records with their two parity buffers) under UNEVEN load with warm caches
+    (MI355X guide: the conditions that expose a stale or torn hand-off): 200 launches back to back over four alternating hidden rows -- so
+    that a granule or record left over from the previous launch would carry other data -- while a second stream saturates HBM and a
+    third issues a stream of tiny kernels.  Every launch equals the three-launch chain's bits for its row; the error word stays zero."""
+    from dash_infer_amd import decoder
+    from tests.test_gpu_gemv_stress import Load, REPS
+    model = _model(decoder, seed=51)
+    max_len = 2048 + 64
+    a, b = _session(decoder, model, max_len, False), _session(decoder, model, max_len, True)
+    assert b.attn_block
+    for s in (a, b):
+        s.fill_cache_random(1777, seed=6)
+    b.pool.pool.copy_(a.pool.pool)
+    for s in (a, b):
+        s.set_state([9], [1777])
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    rows = [torch.randn(1, model.cfg.hidden, generator=gen, device="cuda", dtype=torch.float32) * (0.5 + 0.5 * i) for i in range(4)]
+    want = []
+    for h0 in rows:                      # the chain on the idle GPU (the appended K / V row of position 1777 is rewritten each time)
+        a.h.copy_(h0)
+        a.run_single_layer(0)
+        torch.cuda.synchronize()
+        want.append(a.h.clone())
+    keep = torch.empty((REPS,) + tuple(want[0].shape), dtype=torch.float32, device="cuda")
+    load = Load()
+    load.enqueue()
+    for r in range(REPS):
+        b.h.copy_(rows[(r // 2) % 4], non_blocking=True)
+        b.run_single_layer(r % 2)        # both layers' weights, one sync buffer: the epoch and the record parity advance per launch
+        if r % 2 == 0:
+            keep[r].copy_(b.h, non_blocking=True)
+    torch.cuda.synchronize()
+    load.wait()
+    assert _err_word(b) == 0, "a bounded wait gave up under load"
+    bad = [r for r in range(0, REPS, 2) if not torch.equal(keep[r], want[(r // 2) % 4])]
+    assert not bad, f"{len(bad)} launches differ from the chain (first: repetition {bad[0]})"
+    b.check_handoffs()
