@@ -1269,7 +1269,7 @@ def main():
                            "note": "algorithmic bytes count every DISTINCT routed expert of a layer once per step; the slot kernels stream an "
                                    "expert once per GROUP of up to 4 slots that picked it (once per slot with DIHIP_MOE_GROUP=0)"}
     if rank == 0:
-        budget = float(os.environ.get("DIHIP_BENCH_BUDGET_S", "330"))   # wall budget of the whole run; the headline prints regardless
+        budget = float(os.environ.get("DIHIP_BENCH_BUDGET_S", "420"))   # wall budget of the whole run; the headline prints regardless
         deadline = t_main + budget
         full = args.workload == "int4_b1" and world == 1 and not args.no_extra and args.layers is None
         try:

@@ -12,18 +12,22 @@ if [ -z "$SKIP_TESTS" ]; then
   DIHIP_FULL_DEPTH_ABLATION=${ABLATION:-0} timeout 2400 python -m pytest tests -m gpu -q -s --timeout 900 2>&1 | grep -E "FULL DEPTH|configs\[|7B-width|operator graph|\[int4_b1\]|\[int4_b32_u4kv\]|\[cfg3_rank\]|\[kv codec|\[deferred norm|\[prefill tail|passed|failed|error" | cut -c1-900 > $OUT/pytest_gpu.log
   tail -3 $OUT/pytest_gpu.log
 fi
-( time timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err ) 2> $OUT/bench_default_time.txt
+( time timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err ) 2> $OUT/bench_default_time.txt
+cp gpurun_out/bench_detail.json $OUT/bench_detail.json 2>/dev/null
 python - <<PY
 import json
-d = json.load(open("$OUT/bench_default.json"))
-print("int4_b1", d["value"], d["ms_per_step"], d["step_hbm"]["frac_of_peak"], d["roofline"]["frac"], {k: v["avg_us"] for k, v in d["kernels"].items()})
-print("python runner", d.get("python_runner"), "cpu_baseline", (d.get("cpu_baseline") or {}).get("value"))
-for w in d.get("extra", {}).get("workloads", []):
-    print(" ", w.get("workload"), w.get("value"), w.get("ms_per_step"), (w.get("step_hbm") or {}).get("frac_of_peak"), (w.get("roofline") or {}).get("frac"))
+lines = [l for l in open("$OUT/bench_default.json").read().splitlines() if l.strip()]
+print("stdout lines:", len(lines), "bytes of the last:", len(lines[-1]))
+d = json.loads(lines[-1])
+print("int4_b1", d["value"], d["ms_per_step"], d["step_hbm"]["frac_of_peak"], "roofline", d["roofline"]["kernel"][:40], d["roofline"]["frac"], d["roofline"].get("traffic"),
+      "gemv", (d.get("roofline_gemv") or {}).get("frac"), (d.get("roofline_gemv") or {}).get("traffic"), d.get("kernels_us"))
+print("python runner", d.get("python_runner_tokens_per_s"), "cpu_baseline", (d.get("cpu_baseline") or {}).get("value"), "wall_s", d.get("wall_s"))
+for w in d.get("extra", []):
+    print(" ", w)
 PY
 tail -3 $OUT/bench_default_time.txt
 for w in moe_layer; do
-  timeout 300 python bench.py --workload $w --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err
+  timeout 300 python bench.py --workload $w --no-cpu-baseline 2> $OUT/bench_$w.err | tail -1 > $OUT/bench_$w.json
   python - <<PY
 import json
 try:
