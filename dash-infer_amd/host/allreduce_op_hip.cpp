@@ -24,8 +24,42 @@ class AllReduceOpHIP : public AsOperator {
     count_ = x->Count();
     return tensor_map_->at(out_names_[0])->SetShape(Shape(x->GetShape()));
   }
-  AsStatus Forward(RuntimeContext*) override {
+  ~AllReduceOpHIP() override {
+    if (fork_) (void)hipEventDestroy(fork_);
+    if (join_) (void)hipEventDestroy(join_);
+  }
+  AsStatus Forward(RuntimeContext* rt) override {
     const HIPContext* h = static_cast<const HIPContext*>(ctx_);
+    // DIHIP_TP_OVERLAP=1 (north star): the collective on the context's side stream between two events, the weights of the operator
+    // that reads the reduced rows pulled on-die by the main stream meanwhile (HIPContext::ConsumerWeights), then the join.  Under
+    // stream capture the events become a fork / join of the graph.  Decoder phase only (the context phase's messages are bandwidth).
+    static const bool overlap = [] { const char* e = getenv("DIHIP_TP_OVERLAP"); return e && e[0] == '1'; }();
+    if (overlap && h->GetNranks() > 1 && rt && !rt->is_context && !in_side_) {
+      hipStream_t main = h->GetStream(), side = h->SideStream();
+      if (side && (fork_ || hipEventCreateWithFlags(&fork_, hipEventDisableTiming) == hipSuccess) &&
+          (join_ || hipEventCreateWithFlags(&join_, hipEventDisableTiming) == hipSuccess)) {
+        if (hipEventRecord(fork_, main) != hipSuccess || hipStreamWaitEvent(side, fork_, 0) != hipSuccess) return AsStatus::ALLSPARK_RUNTIME_ERROR;
+        const_cast<HIPContext*>(h)->SetStream(side);
+        in_side_ = true;
+        const AsStatus st = Forward(rt);  // the collective itself, on the side stream
+        in_side_ = false;
+        const_cast<HIPContext*>(h)->SetStream(main);
+        AS_CHECK_STATUS(st);
+        if (hipEventRecord(join_, side) != hipSuccess) return AsStatus::ALLSPARK_RUNTIME_ERROR;
+        if (const auto* ws = h->ConsumerWeights(out_names_[0])) {
+          const void* bufs[8];
+          size_t bytes[8];
+          int n = 0;
+          for (const auto& w : *ws)
+            if (n < 8) {
+              bufs[n] = w.ptr;
+              bytes[n++] = w.bytes;
+            }
+          if (n) AS_CHECK_STATUS(FromDihip(dihip_prefetch(main, bufs, bytes, n, 64)));
+        }
+        return hipStreamWaitEvent(main, join_, 0) == hipSuccess ? AsStatus::ALLSPARK_SUCCESS : AsStatus::ALLSPARK_RUNTIME_ERROR;
+      }
+    }
     AsTensor* x = tensor_map_->at(in_names_[0]).get();
     AsTensor* y = tensor_map_->at(out_names_[0]).get();
     // single rank: copy (allreduce_op.cpp:70-80 behaviour) -- unless DIHIP_ALLREDUCE_FORCE_RCCL=1 sends a one-rank communicator through the
@@ -60,6 +94,8 @@ class AllReduceOpHIP : public AsOperator {
 
  private:
   int64_t count_ = 0;
+  hipEvent_t fork_ = nullptr, join_ = nullptr;
+  bool in_side_ = false;
 };
 REGISTER_OP(AllReduce, HIP, AllReduceOpHIP)
 

@@ -212,6 +212,26 @@ class HIPContext : public DeviceContext {
     return it == row_norm_.end() ? RowNormState{} : it->second;
   }
   // the fused attention block's hand-offs timed out once (model_runner.cpp Sync read the error word): the launch chain serves from then on
+  // Tensor-parallel all-reduce beside the next GEMV's weights (north star: "overlapped with the next GEMM on a side HIP stream"): the
+  // weight-streaming operators register their packed weights under the name of the hidden-row tensor they READ; the AllReduce operator
+  // that WRITES that tensor runs its collective on the side stream between two events while the main stream pulls those weights on-die
+  // (dihip_prefetch), and joins.  DIHIP_TP_OVERLAP=1 (off by default: a fork / join inside a captured step measured ~20 us on this
+  // runtime; the reference synchronises the host instead, allreduce_op.cpp:84-92).
+  struct WeightSpan {
+    const void* ptr;
+    size_t bytes;
+  };
+  void RegisterConsumerWeights(const std::string& tensor, const void* ptr, size_t bytes) const {
+    if (ptr && bytes) consumer_w_[tensor].push_back(WeightSpan{ptr, bytes});
+  }
+  const std::vector<WeightSpan>* ConsumerWeights(const std::string& tensor) const {
+    auto it = consumer_w_.find(tensor);
+    return it == consumer_w_.end() ? nullptr : &it->second;
+  }
+  hipStream_t SideStream() const {  // created on first use, lives as long as the context
+    if (!side_ && hipStreamCreateWithFlags(&side_, hipStreamNonBlocking) != hipSuccess) side_ = nullptr;
+    return side_;
+  }
   // the tensor the graph's first operator reads the token ids from (the model runner sets it; the sampling operator reads the prompt
   // length off its shape in the context phase)
   const std::string& InputIdsName() const { return ids_name_; }
@@ -233,6 +253,8 @@ class HIPContext : public DeviceContext {
   mutable bool lens_on_device_ = false;
   mutable bool attn_block_off_ = false;
   mutable std::string ids_name_ = "input_ids";
+  mutable std::map<std::string, std::vector<WeightSpan>> consumer_w_;
+  mutable hipStream_t side_ = nullptr;
   mutable std::map<std::string, void*> producer_;
   mutable std::map<std::string, RowNormState> row_norm_;
 };

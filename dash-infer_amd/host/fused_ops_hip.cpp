@@ -222,6 +222,7 @@ class DihipNormGemmOp : public AsOperator, public AttnBlockQkvPart {
     sync_ = zeroed(op_name_ + ".sync", dihip_gemm_lowp_sync_bytes(), stream_of(&ctx));
     if (!sync_) return AsStatus::ALLSPARK_MEMORY_ERROR;
     if (in_names_.size() > 1) hip_ctx(&ctx).AdvertiseLayoutPref(in_names_[1], w_.pref(0));
+    hip_ctx(&ctx).RegisterConsumerWeights(in_names_[0], w_.w->GetDataPtr(), w_.w->GetSizeInByte());
     tensor_map_->at(out_names_[0])->SetDataType(w_.ft);
     hip_ctx(&ctx).RegisterProducer(out_names_[0] + "\x01qkv", static_cast<AttnBlockQkvPart*>(this));
     return AsStatus::ALLSPARK_SUCCESS;
@@ -298,6 +299,7 @@ class DihipNormSwiGLUOp : public AsOperator {
     sync_ = zeroed(op_name_ + ".sync", dihip_gemm_lowp_sync_bytes(), stream_of(&ctx));
     if (!sync_) return AsStatus::ALLSPARK_MEMORY_ERROR;
     if (in_names_.size() > 1) hip_ctx(&ctx).AdvertiseLayoutPref(in_names_[1], g_.pref(1));
+    for (const PackedLowp* pw : {&g_, &u_}) hip_ctx(&ctx).RegisterConsumerWeights(in_names_[0], pw->w->GetDataPtr(), pw->w->GetSizeInByte());
     tensor_map_->at(out_names_[0])->SetDataType(g_.ft);
     return AsStatus::ALLSPARK_SUCCESS;
   }
