@@ -74,8 +74,11 @@ int dihip_decode_mlp_block_supported(int wbits, int group_size, int hidden, int 
   if (!gemv_plan_args(4, inter, hidden, group_size, true, &g, &bg, &lg) || g.ktpg != 1) return 0;
   if (!gemv_plan_args(4, hidden, inter, group_size, false, &d, &bd, &ld) || d.ktpg != 1) return 0;
   const int ncu = cached_num_cus();
-  // every workgroup resident at once, one per CU; the consumers are a subset of the producers' launch
-  return ncu > 0 && bg <= ncu && bd <= ncu && bg <= 1024 && std::max(lg, ld) <= 150 * 1024 ? 1 : 0;
+  // every workgroup resident at once, one per CU; the consumers are a subset of the producers' launch.  bd <= bg: the
+  // epoch word is advanced by workgroup 0 when ITS consumer part is done, which waits for every PRODUCER -- a consumer-only workgroup
+  // (block index >= bg: TP-rank shapes, hidden / 16 > the gate/up blocks) could still be about to read the old epoch; and the flag poll
+  // covers 4 * 64 producers
+  return ncu > 0 && bg <= ncu && bd <= bg && bg <= 256 && std::max(lg, ld) <= 150 * 1024 ? 1 : 0;
 }
 
 size_t dihip_decode_mlp_block_sync_bytes(int inter) { return inter > 0 ? mb_layout(inter).total : 0; }

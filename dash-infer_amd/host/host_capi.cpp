@@ -423,6 +423,12 @@ int dihost_graph_add_serialized(dihost_model_t m, const void* data, size_t bytes
   return 0;
 }
 int dihost_graph_build(dihost_model_t m, int fuse) {
+  // ONE build per model: the weight-only operators release the model-owned source tensors once re-laid-out (PackedLowp::Pack,
+  // GemmLowpHIP::InitV2), so a second build -- fuse = 0 after fuse = 1, a retry after a failed CallInit -- would pack from freed memory
+  if (m->runner) {
+    g_err = "graph_build: this model has been built already (its source weights were released after the re-layout): create a new model";
+    return (int)AsStatus::ALLSPARK_INVALID_CALL_ERROR;
+  }
   m->runner = std::make_unique<HipModelRunner>(&m->ctx, &m->tensors, &m->weights, &m->weights_buffer);
   const AsStatus st = m->runner->Build(m->graph, fuse != 0);
   if (st != AsStatus::ALLSPARK_SUCCESS) g_err = m->runner->last_error();

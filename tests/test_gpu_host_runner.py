@@ -441,3 +441,19 @@ def test_a_graph_serialized_by_the_reference_converter_runs_bit_identically(pkg)
         ids = h.steps(1, graph=True)
         assert ids == want[t][1] and torch.equal(h.logits(), want[t][0]), f"step {t}"
     h.close()
+
+
+def test_a_second_build_of_one_model_is_refused(pkg):
+    """the weight-only operators release the model-owned source weights once re-laid-out, so a model is built ONCE -- a second
+    dihost_graph_build (fuse = 0 after fuse = 1, a retry) is an INVALID_CALL with a message, not a pack from freed memory."""
+    from dash_infer_amd import decoder, hostapi
+    cfg = decoder.ModelConfig("runner-test", **SMALL)
+    model = decoder.build_random_model(cfg, decoder.QuantSpec(4, 128), seed=3, keep_fp=True)
+    h = Host(model, 1, 64, 16, "none")
+    assert h.report["fused"]
+    with pytest.raises(hostapi.HostError, match="built already"):
+        h.m.graph_build(fuse=False)
+    k, v = h.spans()
+    h.start([1, 2, 3], k, v)          # the first build still serves
+    assert len(h.steps(2, graph=True)) == 1
+    h.close()
