@@ -64,7 +64,7 @@ struct AttnBlockArgs {
   unsigned long long* out_gran;  // [n * H / 2]
   size_t out_gran_bytes;
   unsigned* grp_flag;            // [g]
-  unsigned* rec;                 // polled split records [n][nsplits][ATTN_PSTRIDE] (zero between launches), or null: ticket protocol
+  unsigned* rec;                 // polled split records: two buffers of [n][nsplits][ATTN_PSTRIDE] words, zero before use
   unsigned rec_bytes;
   int NA, NG;                    // attention / GEMV workgroups
   unsigned spin_limit;
@@ -519,7 +519,7 @@ int dihip_decode_attn_block_supported(int wbits, int group_size, int hidden, int
   int ns, nc, tps;
   size_t pb;
   span_attn_block_plan(1, n_heads, n_groups, max_seq_len, &ns, &nc, &tps, &pb);
-  if (nc != 1 || ns < 2 || pb >= (1ull << 31)) return 0;  // (one split: no merge, no ticket -- the chain's single launch is as good)
+  if (nc != 1 || ns < 2 || ns > AB_POLLED_MAX_SPLITS || pb >= (1ull << 31)) return 0;  // (one split: no merge -- the chain's single launch is as good; > 32: the record buffers' layout)
   int NA, NG;
   if (!ab_grid(n_heads, n_groups, head_size, hidden, ns, &NA, &NG)) return 0;
   GemvArgs gq{}, go{};
@@ -630,9 +630,8 @@ int dihip_decode_attn_block(void* stream, int wbits, const float* h_in, const fl
   p.qkv_gran = reinterpret_cast<unsigned long long*>(sb + lay.qkv_gran);
   p.out_gran = reinterpret_cast<unsigned long long*>(sb + lay.out_gran);
   p.out_gran_bytes = (size_t)n_heads * head_size / 2 * 8;
-  // split records polled by the group's merger instead of write-through + drain + ticket + reload (DIHIP_ATTN_BLOCK_POLLED=0: A/B)
-  static const bool polled = !env_off("DIHIP_ATTN_BLOCK_POLLED");
-  if (polled && ns <= AB_POLLED_MAX_SPLITS) {
+  // split records polled by their items' owners (the only protocol of the block since round 6; _supported() admits ns <= 32)
+  {
     p.rec = reinterpret_cast<unsigned*>(sb + lay.rec);
     p.rec_bytes = (unsigned)((size_t)n_heads * ns * ATTN_PSTRIDE * sizeof(float));
     // the record buffers are zero between launches only where the LAST launch's owners zeroed them: a launch with another record

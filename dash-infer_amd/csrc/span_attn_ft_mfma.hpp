@@ -210,7 +210,10 @@ __device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float*
   // records per batch: all loads of a batch are in flight together.  The batch width follows the split count (8 / 16 / 24 /
   // 32), so that a 17-split plan issues 24 record loads per lane, not 32 (the excess re-reads the last record)
   if (a.nsplits <= 8) merge_split_records<FT, 8, GRAN>(a, rsrc, b, h0, nh, tr, ho);
+  else if (a.nsplits <= 12) merge_split_records<FT, 12, GRAN>(a, rsrc, b, h0, nh, tr, ho);
   else if (a.nsplits <= 16) merge_split_records<FT, 16, GRAN>(a, rsrc, b, h0, nh, tr, ho);
+  else if (a.nsplits <= 18) merge_split_records<FT, 18, GRAN>(a, rsrc, b, h0, nh, tr, ho);  // (17 splits of a 2048-token history: every record
+  else if (a.nsplits <= 20) merge_split_records<FT, 20, GRAN>(a, rsrc, b, h0, nh, tr, ho);  //  beyond the count is two more loads per lane: round 6)
   else if (a.nsplits <= 24) merge_split_records<FT, 24, GRAN>(a, rsrc, b, h0, nh, tr, ho);
   else merge_split_records<FT, 32, GRAN>(a, rsrc, b, h0, nh, tr, ho);
   // (GRAN: no flag behind the granules -- the consumers poll the group's first granule, then sweep)
@@ -260,7 +263,10 @@ __device__ __forceinline__ void merge_polled_items(const AttnArgs& a, const Attn
         if (lane == 0) __hip_atomic_store(ho->err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
-      __builtin_amdgcn_s_sleep(2);
+#ifndef DIHIP_AB_SLEEP_M
+#define DIHIP_AB_SLEEP_M 2
+#endif
+      __builtin_amdgcn_s_sleep(DIHIP_AB_SLEEP_M);
     }
 #if defined(DIHIP_GEMV_TRACE) && DIHIP_GEMV_TRACE
     if (tr) tr[6] = wall_clock64();
@@ -288,6 +294,95 @@ __device__ __forceinline__ void merge_polled_items(const AttnArgs& a, const Attn
       const u32x4_t gv = {pack_ft2<FT>(r[0], r[1]), ho->tag, pack_ft2<FT>(r[2], r[3]), ho->tag};
       __builtin_amdgcn_raw_buffer_store_b128(gv, grsrc, (uint32_t)((((size_t)b * a.n + h0 + h) * (H / 2) + dq * 2) * 8), 0, 16 /* sc1 */);
       // this item's chunks of the OTHER buffer back to zero for the next launch (write-through: no line stays in this XCD's L2)
+      const u32x4_t z4 = {0u, 0u, 0u, 0u};
+      for (int j = 0; j < a.nsplits; ++j) {
+        const uint32_t ro = oth + hoff + (uint32_t)j * RB;
+        __builtin_amdgcn_raw_buffer_store_b128(z4, rsrc, ro + dq * 16, 0, 16);
+        if (dq == 0) __builtin_amdgcn_raw_buffer_store_b128(z4, rsrc, ro + H * 4, 0, 16);
+      }
+    }
+  }
+}
+
+// More than 20 splits (long histories): the same merge in two phases, so that the records of all splits never sit in registers together --
+// (1) poll the {m, l} chunk of every split (2 registers each), take the maximum, the coefficients exp(m_j - max) and the normaliser in split
+// order; (2) poll the item's o-chunks eight splits at a time and accumulate in split order.  Sum for sum the arithmetic of the single batch.
+template <int FT>
+__device__ __forceinline__ void merge_polled_items_wide(const AttnArgs& a, const AttnHandoff* ho, int b, int h0, int i0, int cnt,
+                                                        unsigned long long* tr) {
+  constexpr int H = 128, MAXS = 32, SB = 8;
+  constexpr uint32_t RB = ATTN_PSTRIDE * (uint32_t)sizeof(float);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint32_t half = ho->rec_bytes;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ho->rec, 0, (int)(2 * half), 0x00020000);
+  const auto grsrc = __builtin_amdgcn_make_buffer_rsrc(ho->out_gran, 0, (int)ho->out_gran_bytes, 0x00020000);
+  const uint32_t cur = ho->parity ? half : 0u, oth = ho->parity ? 0u : half;
+  for (int e0 = (tid & ~63); e0 < cnt; e0 += ATTN_THREADS) {
+    const int item = i0 + min(e0 + lane, cnt - 1);
+    const int h = item >> 5, dq = item & 31;
+    const uint32_t hoff = (uint32_t)(((size_t)b * a.n + h0 + h) * a.nsplits) * RB;
+    u32x2_t mv[MAXS];
+    for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+      for (int j = 0; j < MAXS; ++j) mv[j] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, cur + hoff + (uint32_t)min(j, a.nsplits - 1) * RB + H * 4, 0, 16 /* sc1 */);
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < MAXS; ++j) ok = ok && ((mv[j][0] | mv[j][1]) != 0u);
+      if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+      if (spins > ho->spin_limit) {
+        if (lane == 0) __hip_atomic_store(ho->err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    float bm = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < MAXS; ++j)
+      if (j < a.nsplits) bm = fmaxf(bm, __uint_as_float(~mv[j][0]));
+    float cj[MAXS];
+    float ll = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXS; ++j) {
+      cj[j] = 0.f;
+      if (j < a.nsplits) {
+        cj[j] = safe_exp_diff(__uint_as_float(~mv[j][0]), bm);
+        ll = fmaf(__uint_as_float(~mv[j][1]), cj[j], ll);
+      }
+    }
+    f32x4_t oo = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s0 = 0; s0 < MAXS; s0 += SB) {
+      if (s0 >= a.nsplits) break;
+      u32x4_t ov[SB];
+      for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+        for (int j = 0; j < SB; ++j) ov[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, cur + hoff + (uint32_t)min(s0 + j, a.nsplits - 1) * RB + dq * 16, 0, 16);
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < SB; ++j) ok = ok && ((ov[j][0] | ov[j][1] | ov[j][2] | ov[j][3]) != 0u);
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+        if (spins > ho->spin_limit) {
+          if (lane == 0) __hip_atomic_store(ho->err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+#pragma unroll
+      for (int j = 0; j < SB; ++j)
+        if (s0 + j < a.nsplits) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) oo[q] = fmaf(__uint_as_float(~ov[j][q]), cj[s0 + j], oo[q]);
+        }
+    }
+#if defined(DIHIP_GEMV_TRACE) && DIHIP_GEMV_TRACE
+    if (tr) tr[6] = wall_clock64();
+#endif
+    float r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = ll > 0.f ? oo[q] / ll : 0.f;
+    if (e0 + lane < cnt) {
+      const u32x4_t gv = {pack_ft2<FT>(r[0], r[1]), ho->tag, pack_ft2<FT>(r[2], r[3]), ho->tag};
+      __builtin_amdgcn_raw_buffer_store_b128(gv, grsrc, (uint32_t)((((size_t)b * a.n + h0 + h) * (H / 2) + dq * 2) * 8), 0, 16 /* sc1 */);
       const u32x4_t z4 = {0u, 0u, 0u, 0u};
       for (int j = 0; j < a.nsplits; ++j) {
         const uint32_t ro = oth + hoff + (uint32_t)j * RB;
@@ -339,10 +434,18 @@ __device__ __forceinline__ void attn_block_epilogue_polled(const AttnArgs& a, fl
   const int items = nh * 32, per = (items + a.nsplits - 1) / a.nsplits;
   const int i0 = split * per, cnt = min(per, items - i0);
   if (cnt <= 0) return;
-  if (a.nsplits <= 8) merge_polled_items<FT, 8>(a, ho, b, h0, i0, cnt, tr);
-  else if (a.nsplits <= 16) merge_polled_items<FT, 16>(a, ho, b, h0, i0, cnt, tr);
-  else if (a.nsplits <= 24) merge_polled_items<FT, 24>(a, ho, b, h0, i0, cnt, tr);
-  else merge_polled_items<FT, 32>(a, ho, b, h0, i0, cnt, tr);
+  // batch width = loads per pass and lane = EXACTLY the split count: every record beyond it that a wider batch re-reads is two more
+  // memory-side loads per lane and pass on the launch's critical path (measured at 17 splits: 24 wide 18.35 us per layer, 20 wide 17.70,
+  // profiles/r06_attn_block_polls.txt)
+  switch (a.nsplits) {
+#define DIHIP_MPI(N) case N: merge_polled_items<FT, N>(a, ho, b, h0, i0, cnt, tr); break;
+    DIHIP_MPI(2) DIHIP_MPI(3) DIHIP_MPI(4) DIHIP_MPI(5) DIHIP_MPI(6) DIHIP_MPI(7) DIHIP_MPI(8) DIHIP_MPI(9) DIHIP_MPI(10) DIHIP_MPI(11)
+    DIHIP_MPI(12) DIHIP_MPI(13) DIHIP_MPI(14) DIHIP_MPI(15) DIHIP_MPI(16) DIHIP_MPI(17) DIHIP_MPI(18) DIHIP_MPI(19) DIHIP_MPI(20)
+#undef DIHIP_MPI
+    // (beyond 20 splits: the two-phase form below -- a 32-wide single batch needs 192 registers for the records alone and put the whole block
+    // kernel at its 256-VGPR ceiling: spills)
+    default: merge_polled_items_wide<FT>(a, ho, b, h0, i0, cnt, tr); break;
+  }
 }
 
 constexpr int MF_HC = 16;   // query heads per workgroup chunk (MFMA N)
@@ -596,7 +699,10 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
           if (lane == 0) __hip_atomic_store(ho->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
-        __builtin_amdgcn_s_sleep(1);
+#ifndef DIHIP_AB_SLEEP_Q
+#define DIHIP_AB_SLEEP_Q 1
+#endif
+        __builtin_amdgcn_s_sleep(DIHIP_AB_SLEEP_Q);
       }
 #pragma unroll
       for (int j = 0; j < GB; ++j) {
@@ -899,14 +1005,13 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
     }
   }
   if constexpr (GATHER) {
-    if (ho->rec) {  // polled records (nsplits <= 32): no drain, no ticket
-      attn_block_epilogue_polled<FT, HC>(a, lds, b, h0, nh, split,
-                                         a.trace ? a.trace + (((size_t)bz * gy + by) * gx + bx) * 32 + (threadIdx.x >> 6) * 8 : nullptr, ho);
-      DIHIP_ATTN_STAMP(7);
-      return;
-    }
-  }
-  if constexpr (FUSED) {
+    // the fused block: polled split records (nsplits <= 32, the host's contract), no drain, no ticket.  (The ticket protocol below is not
+    // compiled into the block any more: its 32-wide reload kept the whole kernel at the register ceiling.)
+    attn_block_epilogue_polled<FT, HC>(a, lds, b, h0, nh, split,
+                                       a.trace ? a.trace + (((size_t)bz * gy + by) * gx + bx) * 32 + (threadIdx.x >> 6) * 8 : nullptr, ho);
+    DIHIP_ATTN_STAMP(7);
+    return;
+  } else if constexpr (FUSED) {
     if (a.merge_wt) {
       attn_block_epilogue_wt<FT, HC, GATHER>(a, lds, flag_lds, b, h0, nh, split,
                                              a.counters + (((size_t)b * a.g + grp) * a.nchunks + hc) * 32,  // one 128-byte line each

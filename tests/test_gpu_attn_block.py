@@ -63,6 +63,34 @@ def test_one_launch_equals_the_three_it_replaces(pkg, history):
     assert torch.equal(a.pool.pool, b.pool.pool), "cache spans differ (DecoderCacheAppend inside the launch)"
 
 
+@pytest.mark.parametrize("max_len,history", [(3008, 2990), (2560, 1000), (1100, 1090), (300, 256)])
+def test_other_split_counts_are_bit_identical_too(pkg, max_len, history):
+    """The split count follows max_len (one split per 128 tokens up to what the CUs hold): 24 splits run the two-phase merge (more than 20
+    splits: the {m, l} chunks first, then the o-chunks eight splits at a time), 20 / 9 / 3 splits their exact-width single batch -- all
+    bit-identical to the chain, whose merge is the same sums in the same order."""
+    from dash_infer_amd import decoder
+    model = _model(decoder, seed=13)
+    a, b = _session(decoder, model, max_len, False), _session(decoder, model, max_len, True)
+    assert b.attn_block, f"max_len {max_len}: the block must serve this split count"
+    for s in (a, b):
+        s.fill_cache_random(max(history, 1), seed=4)
+    b.pool.pool.copy_(a.pool.pool)
+    gen = torch.Generator(device="cuda").manual_seed(max_len)
+    h0 = torch.randn(1, model.cfg.hidden, generator=gen, device="cuda", dtype=torch.float32)
+    for s in (a, b):
+        s.set_state([11], [history])
+    for step in range(3):
+        for s in (a, b):
+            s.h.copy_(h0 * (1.0 + 0.5 * step))
+            s.run_single_layer(step % 2)
+            s.old_lens += 1
+            s.new_lens += 1
+        torch.cuda.synchronize()
+        assert _err_word(b) == 0
+        assert torch.equal(a.h, b.h), f"max_len {max_len} step {step}: max diff {(a.h - b.h).abs().max().item():.3e}"
+    assert torch.equal(a.pool.pool, b.pool.pool)
+
+
 def test_decode_steps_through_a_replayed_graph_are_bit_identical(pkg):
     """whole decode steps (2 layers, final norm, lm_head, greedy) through a captured hipGraph, replayed: logits of every step equal"""
     from dash_infer_amd import decoder
