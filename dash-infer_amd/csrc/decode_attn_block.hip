@@ -51,9 +51,7 @@ constexpr int AB_RING = 8;                // 1 KiB weight chunks a wave holds pe
 #define DIHIP_AB_EARLY 4
 #endif
 constexpr int AB_EARLY = DIHIP_AB_EARLY;  // slots of the qkv share requested before the RMSNorm prologue (the rest at its barrier)
-#ifndef DIHIP_AB_WAVE_SWEEP
-#define DIHIP_AB_WAVE_SWEEP 1             // every wave sweeps ITS k-slice of the attention output (0: workgroup sweep between two barriers, round 5)
-#endif
+
 
 struct AttnBlockArgs {
   GemvArgs q;  // RMSNorm + qkv projection: x = f32 hidden row, gamma, eps, bias; output -> qkv_gran
@@ -362,7 +360,6 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
 
   float* xsum_o = reinterpret_cast<float*>(smem + 256 + gemv_xs_bytes(1, o.RS));
   float* red_o = xsum_o + (size_t)o.KT * 16;
-#if DIHIP_AB_WAVE_SWEEP
   // ---- wait for the attention output, PER WAVE: a wave multiplies only its k-slice of the row (k-tiles [k_lo, k_hi) = vectors
   // [16 k_lo, 16 k_hi) of 8 elements), so it polls, sweeps and stages that slice itself and starts its tiles without a workgroup
   // barrier on either side (round 5: one polling wave, barrier, workgroup sweep, barrier: 2.5 us from the merged output to the end).
@@ -384,16 +381,16 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
   DIHIP_AB_STAMP(4);  // every group's first output granule seen
   {
     const int v_lo = so.k_lo * 16, v_hi = so.k_hi * 16;  // whole 16-lane rows: the per-k-tile sums cross lanes
+    const auto og_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out_gran, 0, (int)p.out_gran_bytes, 0x00020000);
     for (int i0 = v_lo; i0 < v_hi; i0 += 64) {
       const int i = i0 + lane, ic = min(i, v_hi - 1);
-      unsigned long long gv[4];
+      // the vector's four granules = the two 16-byte stores {v01, tag, v23, tag} of the merging lanes: TWO 16-byte loads, not four of 8
+      // (every load of a poll pass is on the launch's critical path: profiles/r06_attn_block_polls.txt)
+      u32x4_t g0, g1;
       for (unsigned spins = 0;; ++spins) {
-        bool ok = true;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          gv[j] = __hip_atomic_load(p.out_gran + (size_t)ic * 4 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = ok && (unsigned)(gv[j] >> 32) == tag;
-        }
+        g0 = __builtin_amdgcn_raw_buffer_load_b128(og_rsrc, (uint32_t)ic * 32u, 0, 16 /* sc1 */);
+        g1 = __builtin_amdgcn_raw_buffer_load_b128(og_rsrc, (uint32_t)ic * 32u + 16u, 0, 16);
+        const bool ok = g0[1] == tag && g0[3] == tag && g1[1] == tag && g1[3] == tag;
         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
         if (spins > p.spin_limit) {
           if (lane == 0) __hip_atomic_store(p.state + 1, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -401,59 +398,13 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
         }
         __builtin_amdgcn_s_sleep(2);
       }
-      const u32x4_t v = {(uint32_t)gv[0], (uint32_t)gv[1], (uint32_t)gv[2], (uint32_t)gv[3]};
+      const u32x4_t v = {g0[0], g0[2], g1[0], g1[2]};
       ab_stage_vector(xs, xsum_o, ic, v, i < v_hi);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave reads back what it staged itself: LDS operations of a wave execute in order
   __builtin_amdgcn_wave_barrier();
   DIHIP_AB_STAMP(5);  // this wave's slice of the attention output swept into LDS
-#else
-  // ---- wait for the attention output: ONE lane per KV group polls the group's first output granule (the merging workgroup
-  // stores all of a group's granules in one go: when the first carries this launch's tag the others are at most a retry
-  // away), then one sweep of all granules.  (A separate flag word behind a store drain cost the producer ~0.7 us more.) ----
-  if (wave == 0) {
-    for (unsigned spins = 0;; ++spins) {
-      const unsigned f = lane < p.a.g ? (unsigned)(__hip_atomic_load(p.out_gran + (size_t)lane * p.a.hpg * 64, __ATOMIC_RELAXED,
-                                                                     __HIP_MEMORY_SCOPE_AGENT) >> 32)
-                                      : tag;
-      if (__builtin_amdgcn_ballot_w64(f != tag) == 0ull) break;
-      if (spins > p.spin_limit) {
-        if (lane == 0) __hip_atomic_store(p.state + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(4);
-    }
-  }
-  __syncthreads();  // (also: every reader of red_q / xs of the first phase is done)
-  DIHIP_AB_STAMP(4);  // every group's first output granule seen
-  {
-    // thread -> 8-element vector i = its 4 consecutive granules: staged and summed per k-tile in one pass (ab_stage_vector)
-    const int nvec_o = o.K >> 3;
-    for (int i = tid; i < ((nvec_o + 15) & ~15); i += AB_THREADS) {  // (whole 16-lane rows: the sums cross lanes)
-      const int ic = min(i, nvec_o - 1);
-      unsigned long long gv[4];
-      for (unsigned spins = 0;; ++spins) {
-        bool ok = true;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          gv[j] = __hip_atomic_load(p.out_gran + (size_t)ic * 4 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = ok && (unsigned)(gv[j] >> 32) == tag;
-        }
-        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-        if (spins > p.spin_limit) {
-          if (lane == 0) __hip_atomic_store(p.state + 1, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(2);
-      }
-      const u32x4_t v = {(uint32_t)gv[0], (uint32_t)gv[1], (uint32_t)gv[2], (uint32_t)gv[3]};
-      if (i < nvec_o) ab_stage_vector(xs, xsum_o, i, v, true);
-    }
-  }
-  __syncthreads();
-  DIHIP_AB_STAMP(5);  // attention output swept into LDS
-#endif
 
   // ---- o-projection tiles: h_out = h_res + attn . Wo ----
   ab_consume(o, so, wo, so_, smem, xsum_o, red_o, lane);
