@@ -26,7 +26,7 @@ bool gemv_plan_args(int wbits, int N, int K, int group_size, bool dual, GemvArgs
 struct MlpBlockArgs {
   GemvArgs gu;    // RMSNorm + gate / up + SwiGLU
   GemvArgs down;  // down projection + residual
-  unsigned* state;  // [0] epoch, [1] error
+  unsigned* state;  // [0] epoch, [1] error, [3] arrival counter of the epoch hand-over (zero between launches)
   int nb_gu, nb_down;
 };
 
@@ -37,11 +37,22 @@ __global__ __launch_bounds__(GEMV_THREADS) void decode_mlp_block_kernel(const Ml
   if (tag == 0u) tag = 1u;
   // (the argument blocks are read where they lie, in the kernel-argument segment: the ring loads take wave-uniform bases in SGPRs)
   if (bid < p.nb_gu) gemv_stream_body<4, DIHIP_BF16, 1, PRO_RMSNORM, EPI_SWIGLU, 1, false, 1>(p.gu, bid, p.nb_gu, smem, tag);
-  if (bid >= p.nb_down) return;
-  __syncthreads();  // (the staging area is re-used)
-  gemv_stream_body<4, DIHIP_BF16, 1, PRO_PLAIN, EPI_ADDTO, 1, false, 2>(p.down, bid, p.nb_down, smem, tag);
-  // the next launch's epoch: workgroup 0 is done only after every producer's flag, i.e. after every workgroup has read the old one
-  if (bid == 0 && threadIdx.x == 0) p.state[0] = tag;
+  if (bid < p.nb_down) {
+    __syncthreads();  // (the staging area is re-used)
+    gemv_stream_body<4, DIHIP_BF16, 1, PRO_PLAIN, EPI_ADDTO, 1, false, 2>(p.down, bid, p.nb_down, smem, tag);
+  }
+  // The next launch's epoch is written by the LAST workgroup to finish (an arrival counter in state[3], left at zero): every workgroup
+  // has read the old epoch by then -- its own arrival comes after.  (Round 5 let workgroup 0 write it once ITS waits were over, which
+  // covers every PRODUCER only: with more down-projection blocks than gate / up blocks -- Qwen2-7B: 251 against 237 -- a consumer-only
+  // workgroup could still be about to read the word.  ADVICE r5.)
+  if (threadIdx.x == 0) {
+    const unsigned total = (unsigned)max(p.nb_gu, p.nb_down);
+    const unsigned t = __hip_atomic_fetch_add(p.state + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == total - 1u) {
+      __hip_atomic_store(p.state + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.state + 0, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 static bool mlp_block_enabled() {
@@ -74,11 +85,8 @@ int dihip_decode_mlp_block_supported(int wbits, int group_size, int hidden, int 
   if (!gemv_plan_args(4, inter, hidden, group_size, true, &g, &bg, &lg) || g.ktpg != 1) return 0;
   if (!gemv_plan_args(4, hidden, inter, group_size, false, &d, &bd, &ld) || d.ktpg != 1) return 0;
   const int ncu = cached_num_cus();
-  // every workgroup resident at once, one per CU; the consumers are a subset of the producers' launch.  bd <= bg: the
-  // epoch word is advanced by workgroup 0 when ITS consumer part is done, which waits for every PRODUCER -- a consumer-only workgroup
-  // (block index >= bg: TP-rank shapes, hidden / 16 > the gate/up blocks) could still be about to read the old epoch; and the flag poll
-  // covers 4 * 64 producers
-  return ncu > 0 && bg <= ncu && bd <= bg && bg <= 256 && std::max(lg, ld) <= 150 * 1024 ? 1 : 0;
+  // every workgroup resident at once, one per CU (the launch has max(bg, bd) workgroups); the flag poll covers 4 * 64 producers
+  return ncu > 0 && bg <= ncu && bd <= ncu && bg <= 256 && std::max(lg, ld) <= 150 * 1024 ? 1 : 0;
 }
 
 size_t dihip_decode_mlp_block_sync_bytes(int inter) { return inter > 0 ? mb_layout(inter).total : 0; }
