@@ -43,7 +43,7 @@ namespace dihip {
 
 bool gemv_block_plan(int wbits, int N, int K, int group_size, int nblocks, GemvArgs* g, int* max_units, size_t* lds_bytes);
 void span_attn_block_plan(int batch, int n_heads, int n_groups, int max_seq_len, int* nsplits, int* nchunks, int* tps_static,
-                          size_t* partial_bytes);
+                          size_t* partial_bytes, int* waves);
 
 constexpr int AB_THREADS = GEMV_THREADS;  // 8 waves
 constexpr int AB_RING = 8;                // 1 KiB weight chunks a wave holds per GEMV: the whole share is resident
@@ -201,6 +201,8 @@ __device__ __forceinline__ void ab_consume(const GemvArgs& g, const AbShare& s, 
   }
 }
 
+// AW = live waves of an attention workgroup (the plan's: 4; 8 with DIHIP_ATTN_WIDE=1 -- the stand-alone kernel's forms, same records)
+template <int AW>
 __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const AttnBlockArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int bid = (int)blockIdx.x;
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
     // (It takes no column tiles: its length / span-pointer / K / V loads are dependent round trips whose waits -- loads return
     // in order -- would also wait for a weight share requested before them, and a share requested after them would wait for
     // the 64 KB of K / V: either way the workgroup would publish its tiles late, and every workgroup waits for all tiles.)
-    if (threadIdx.x >= ATTN_THREADS) return;  // a 4-wave body (barriers count live waves only)
+    if (threadIdx.x >= AW * 64) return;  // an AW-wave body (barriers count live waves only)
     AttnHandoff ho;
     ho.qkv_gran = p.qkv_gran;
     ho.out_gran = p.out_gran;
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
     ho.rec_bytes = p.rec_bytes;
     ho.parity = p.state[2] & 1u;
     const int ns = p.a.nsplits;
-    span_attn_ft_mfma_body<DIHIP_BF16, DIHIP_KV_NONE, true, true>(p.a, bid % ns, bid / ns, 0, ns, p.a.g, 1, smem, &ho);
+    span_attn_ft_mfma_body<DIHIP_BF16, DIHIP_KV_NONE, true, true, AW>(p.a, bid % ns, bid / ns, 0, ns, p.a.g, 1, smem, &ho);
     return;
   }
 
@@ -443,6 +445,7 @@ static bool ab_grid(int n_heads, int n_groups, int head_size, int hidden, int ns
   *NG = std::min(ncu - *NA, std::min((n_heads + 2 * n_groups) * head_size / 16, hidden / 16));
   return *NG >= 32;
 }
+static size_t ab_attn_lds(int aw) { return (size_t)((ft_mfma_smem_bytes(aw) + 15) & ~15) + FT_MFMA_GATHER_IMG_BYTES; }
 static AbLayout ab_layout(int n_heads, int n_groups, int head_size) {
   AbLayout l;
   l.flags = 64;
@@ -467,9 +470,9 @@ int dihip_decode_attn_block_supported(int wbits, int group_size, int hidden, int
   if (n_heads <= 0 || n_groups <= 0 || n_groups > 16 || n_heads % n_groups || n_heads / n_groups > MF_HC || hidden <= 0 || hidden > 8192 ||
       hidden % 128 || max_seq_len <= 0)
     return 0;
-  int ns, nc, tps;
+  int ns, nc, tps, aw;
   size_t pb;
-  span_attn_block_plan(1, n_heads, n_groups, max_seq_len, &ns, &nc, &tps, &pb);
+  span_attn_block_plan(1, n_heads, n_groups, max_seq_len, &ns, &nc, &tps, &pb, &aw);
   if (nc != 1 || ns < 2 || ns > AB_POLLED_MAX_SPLITS || pb >= (1ull << 31)) return 0;  // (one split: no merge -- the chain's single launch is as good; > 32: the record buffers' layout)
   int NA, NG;
   if (!ab_grid(n_heads, n_groups, head_size, hidden, ns, &NA, &NG)) return 0;
@@ -488,22 +491,24 @@ int dihip_decode_attn_block_supported(int wbits, int group_size, int hidden, int
   if (!fits(gq) || !fits(go)) return 0;
   // every workgroup of the launch must be RESIDENT at once (they wait for one another): the grid is <= one workgroup per CU by
   // construction; the kernel itself must fit a CU with its LDS at this block size (ask the occupancy calculator, once)
-  const size_t lds_need = std::max<size_t>(std::max(lds, (size_t)0), ((FT_MFMA_SMEM_BYTES + 15) & ~15) + FT_MFMA_GATHER_IMG_BYTES);
-  static std::atomic<int> occ{-1};
-  int o = occ.load(std::memory_order_relaxed);
+  const size_t lds_need = std::max<size_t>(lds, ab_attn_lds(aw));
+  static std::atomic<int> occ[2] = {{-1}, {-1}};
+  std::atomic<int>& oc = occ[aw == 8];
+  int o = oc.load(std::memory_order_relaxed);
   if (o < 0) {
     int nb = 0;
-    const size_t lds_q = std::max<size_t>(lds_need, 64 * 1024);  // (asked with a generous LDS figure: the answer is cached for all shapes)
-    if (lds_q > 64 * 1024 - 1 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(decode_attn_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q) != hipSuccess)
+    const size_t lds_q = std::max<size_t>(lds_need, 96 * 1024);  // (asked with a generous LDS figure: the answer is cached for all shapes)
+    const void* kern = aw == 8 ? reinterpret_cast<const void*>(decode_attn_block_kernel<8>) : reinterpret_cast<const void*>(decode_attn_block_kernel<4>);
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q) != hipSuccess)
       nb = 0;
-    else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decode_attn_block_kernel, AB_THREADS, lds_q) != hipSuccess)
+    else if ((aw == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decode_attn_block_kernel<8>, AB_THREADS, lds_q)
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decode_attn_block_kernel<4>, AB_THREADS, lds_q)) != hipSuccess)
       nb = 0;
     (void)hipGetLastError();
     o = nb;
-    occ.store(o, std::memory_order_relaxed);
+    oc.store(o, std::memory_order_relaxed);
   }
-  return o >= 1 ? 1 : 0;
+  return o >= 1 && lds_need <= 150 * 1024 ? 1 : 0;
 }
 
 size_t dihip_decode_attn_block_sync_bytes(int n_heads, int n_groups, int head_size) {
@@ -514,9 +519,9 @@ size_t dihip_decode_attn_block_sync_bytes(int n_heads, int n_groups, int head_si
 size_t dihip_decode_attn_block_workspace_bytes(int n_heads, int n_groups, int head_size, int max_seq_len) {
   if (n_heads <= 0 || n_groups <= 0 || n_heads % n_groups || max_seq_len <= 0) return 0;
   (void)head_size;
-  int ns, nc, tps;
+  int ns, nc, tps, aw;
   size_t pb;
-  span_attn_block_plan(1, n_heads, n_groups, max_seq_len, &ns, &nc, &tps, &pb);
+  span_attn_block_plan(1, n_heads, n_groups, max_seq_len, &ns, &nc, &tps, &pb, &aw);
   return pb + 256;
 }
 
@@ -554,9 +559,9 @@ int dihip_decode_attn_block(void* stream, int wbits, const float* h_in, const fl
   const AbLayout lay = ab_layout(n_heads, n_groups, head_size);
   DIHIP_REQUIRE(sync_bytes >= lay.total && reinterpret_cast<uintptr_t>(sync) % 16 == 0, DIHIP_MEMORY_ERROR,
                 "decode_attn_block: sync buffer too small (%zu < %zu)", sync_bytes, lay.total);
-  int ns, nc, tps;
+  int ns, nc, tps, aw;
   size_t pb;
-  span_attn_block_plan(1, n_heads, n_groups, max_seq_len, &ns, &nc, &tps, &pb);
+  span_attn_block_plan(1, n_heads, n_groups, max_seq_len, &ns, &nc, &tps, &pb, &aw);
   DIHIP_REQUIRE(ws_bytes >= pb, DIHIP_MEMORY_ERROR, "decode_attn_block: workspace too small (%zu < %zu)", ws_bytes, pb);
   AttnBlockArgs p{};
   ab_grid(n_heads, n_groups, head_size, hidden, ns, &p.NA, &p.NG);
@@ -628,14 +633,15 @@ int dihip_decode_attn_block(void* stream, int wbits, const float* h_in, const fl
   a.partial_bytes = pb;
   p.trace = debug_trace_buffer((size_t)(p.NA + p.NG) * 32 * sizeof(unsigned long long));
   a.trace = p.trace;  // (the attention body's own stamps: [workgroup][wave][8])
-  const size_t lds = std::max<size_t>(std::max(lds_q, lds_o), ((FT_MFMA_SMEM_BYTES + 15) & ~15) + FT_MFMA_GATHER_IMG_BYTES);
-  auto kern = decode_attn_block_kernel;
+  const size_t lds = std::max<size_t>(std::max(lds_q, lds_o), ab_attn_lds(aw));
+  auto kern = aw == 8 ? decode_attn_block_kernel<8> : decode_attn_block_kernel<4>;
   if (lds > 64 * 1024) {
-    static std::atomic<size_t> granted{0};
-    if (lds > granted.load(std::memory_order_relaxed)) {
+    static std::atomic<size_t> granted[2] = {{0}, {0}};
+    std::atomic<size_t>& gr = granted[aw == 8];
+    if (lds > gr.load(std::memory_order_relaxed)) {
       DIHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                       DIHIP_RUNTIME_ERROR);
-      granted.store(lds, std::memory_order_relaxed);
+      gr.store(lds, std::memory_order_relaxed);
     }
   }
   hipLaunchKernelGGL(kern, dim3(p.NA + p.NG), dim3(AB_THREADS), lds, reinterpret_cast<hipStream_t>(stream), p);

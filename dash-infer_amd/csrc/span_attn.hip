@@ -17,6 +17,7 @@
 //   span_attn_ft_mfma_kernel       16-bit and int8 caches on MFMA (V^T through an LDS tile + transpose reads);
 //                                  FUSED = the decode-step form with Rotary and the cache append folded in.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <new>
 #include <type_traits>
@@ -36,38 +37,44 @@ __global__ __launch_bounds__(128) void span_attn_split_merge_kernel(void* out, c
   constexpr int H = 128;
   const int bh = blockIdx.x, d = threadIdx.x;
   const float* base = partials + (size_t)bh * nsplits * ATTN_PSTRIDE;
-  float mm = -INFINITY, ll = 0.f, oo = 0.f;
   constexpr int MB = 32;  // splits per batch: all loads of a batch are in flight together (one round trip up to 32 splits:
                           // the 17-split plan of batch 1 at 2048 tokens took two with MB = 16, ~1.3 us of a 4.5 us launch)
+  // merge_order4 (span_attn_common.hpp): the maximum of all splits first (beyond one batch: a pass over the m words) ...
+  float M = -INFINITY;
+  if (nsplits > MB) {
+    for (int sb = 0; sb < nsplits; sb += MB) {
+      float mv[MB];
+#pragma unroll
+      for (int j = 0; j < MB; ++j) mv[j] = base[(size_t)min(sb + j, nsplits - 1) * ATTN_PSTRIDE + H];
+#pragma unroll
+      for (int j = 0; j < MB; ++j) M = fmaxf(M, mv[j]);
+    }
+  }
+  // ... then four fma chains over j = r (mod 4), combined as (s0 + s1) + (s2 + s3)
+  float l4[4] = {0.f, 0.f, 0.f, 0.f}, o4[4] = {0.f, 0.f, 0.f, 0.f};
   for (int sb = 0; sb < nsplits; sb += MB) {
     float mv[MB], lv[MB], ov[MB];
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
-      const bool in = sb + j < nsplits;
-      const float* rec = base + (size_t)(in ? sb + j : 0) * ATTN_PSTRIDE;
+      const float* rec = base + (size_t)min(sb + j, nsplits - 1) * ATTN_PSTRIDE;
       mv[j] = rec[H];
       lv[j] = rec[H + 1];
       ov[j] = rec[d];
-      if (!in) {
-        mv[j] = -INFINITY;
-        lv[j] = 0.f;
-        ov[j] = 0.f;
-      }
     }
-    float bm = mm;
+    if (nsplits <= MB) {
 #pragma unroll
-    for (int j = 0; j < MB; ++j) bm = fmaxf(bm, mv[j]);
-    const float carry = safe_exp_diff(mm, bm);
-    ll *= carry;
-    oo *= carry;
+      for (int j = 0; j < MB; ++j) M = fmaxf(M, mv[j]);
+    }
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
-      const float c = safe_exp_diff(mv[j], bm);
-      ll = fmaf(lv[j], c, ll);
-      oo = fmaf(ov[j], c, oo);
+      if (sb + j < nsplits) {
+        const float c = safe_exp_diff(mv[j], M);
+        l4[j & 3] = fmaf(lv[j], c, l4[j & 3]);
+        o4[j & 3] = fmaf(ov[j], c, o4[j & 3]);
+      }
     }
-    mm = bm;
   }
+  const float ll = (l4[0] + l4[1]) + (l4[2] + l4[3]), oo = (o4[0] + o4[1]) + (o4[2] + o4[3]);
   const int b = bh / n, h = bh - b * n;
   const size_t idx = out_frag_mt ? act_frag_index(b, h * H + d, out_frag_mt) : (size_t)bh * H + d;
   store_ft<FT>(out, idx, ll > 0.f ? oo / ll : 0.f);
@@ -610,6 +617,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void span_attn_u4_mfma_kernel(const A
 // ------------------------------------------------------------------------------------------
 struct AttnPlan {
   int HC, nchunks, nsplits;
+  int waves;  // live waves per workgroup: 4, or 8 for the wide form of the 16-bit MFMA kernel (batch 1)
   bool mfma;
   size_t partial_bytes;
 };
@@ -620,11 +628,21 @@ static bool attn_use_mfma(int mode, int dtype) {
   return mode == DIHIP_KV_U4 ? dtype == DIHIP_BF16 : (mode == DIHIP_KV_NONE || mode == DIHIP_KV_I8);
 }
 
+// the 16-bit cache's MFMA kernel has an 8-wave form (span_attn_ft_mfma_w8_kernel; the fused attention block runs the same body)
+static bool attn_wide_ok(int mode, int dtype) {
+  // opt-in (DIHIP_ATTN_WIDE=1): measured at 2048 tokens, 28 / 4 heads -- 9 split records instead of 17, but the 8-wave workgroup's own merge
+  // and its two waves per SIMD in the tile phase give the gain back: block 16.4 against 15.8 us per layer (profiles/r06_attn_block_polls.txt)
+  static const bool enabled = [] { const char* e = getenv("DIHIP_ATTN_WIDE"); return e && e[0] == '1'; }();
+  return enabled && mode == DIHIP_KV_NONE && (dtype == DIHIP_BF16 || dtype == DIHIP_F16);
+}
+
 static AttnPlan attn_plan(int batch, int n_heads, int n_groups, int max_seq_len, int num_cus, bool mfma = false,
-                          int split_cap = 256) {
+                          int split_cap = 256, bool wide_ok = false) {
   AttnPlan p;
   const int hpg = n_heads / n_groups;
   p.mfma = mfma;
+  // batch 1, opt-in: one 8-wave workgroup per CU covers 256 tokens per pass -- half the split records of the 4-wave form
+  p.waves = mfma && wide_ok && batch == 1 ? 8 : 4;
   p.HC = mfma ? MF_HC : hpg <= 1 ? 1 : hpg <= 2 ? 2 : hpg <= 4 ? 4 : 8;
   p.nchunks = (hpg + p.HC - 1) / p.HC;
   if (num_cus <= 0) num_cus = cached_num_cus();
@@ -632,10 +650,11 @@ static AttnPlan attn_plan(int batch, int n_heads, int n_groups, int max_seq_len,
   const long base = (long)batch * n_groups * p.nchunks;
   static const int wgs_per_cu = std::max(0, env_int("DIHIP_ATTN_WGS_PER_CU", 0));  // workgroups (4 waves) the split count aims at per CU
   // the MFMA kernel hides latency with two co-resident workgroups per CU; the VALU kernel measured best with one
-  const int per_cu = wgs_per_cu > 0 ? wgs_per_cu : (mfma ? 2 : 1);
+  const int per_cu = wgs_per_cu > 0 ? wgs_per_cu : (mfma && p.waves == 4 ? 2 : 1);
   long want = ((long)num_cus * per_cu + base - 1) / base;
   static const int min_tps = std::max(32, env_int("DIHIP_ATTN_SPLIT_TOKENS", 128));  // fewest tokens per split (diagnostics)
-  const long max_splits = std::max(1, (max_seq_len + min_tps - 1) / min_tps);  // >= 128 tokens per split
+  const int split_tokens = std::max(min_tps, 32 * p.waves);                               // one pass of the workgroup
+  const long max_splits = std::max(1, (max_seq_len + split_tokens - 1) / split_tokens);  // >= 128 (256) tokens per split
   p.nsplits = (int)std::max<long>(1, std::min<long>(std::min<long>(want, max_splits), split_cap));
   // two workgroups per CU only while a split keeps >= 256 tokens: below that the second workgroup buys no bandwidth and every
   // extra split is another record to merge (one TP = 8 rank of Qwen2-72B, batch 16 x 1 KV head x 4096 tokens: 16 splits 15.4 us,
@@ -660,6 +679,27 @@ static void launch_attn(const AttnPlan& p, const AttnArgs& a, dim3 grid, hipStre
   }
 }
 
+// the 8-wave form of the 16-bit MFMA kernel: 72 KB of dynamic LDS (granted once per instantiation)
+template <int FT, bool FUSED>
+static bool launch_w8_t(dim3 grid, hipStream_t s, const AttnArgs& a) {
+  constexpr int lds = ft_mfma_smem_bytes(8);
+  auto kern = span_attn_ft_mfma_w8_kernel<FT, FUSED>;
+  static std::atomic<bool> granted{false};
+  if (!granted.load(std::memory_order_relaxed)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      set_last_error("span_attn: %d bytes of LDS refused", lds);
+      return false;
+    }
+    granted.store(true, std::memory_order_relaxed);
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
+  return true;
+}
+static bool launch_w8(int dtype, bool fused, dim3 grid, hipStream_t s, const AttnArgs& a) {
+  if (dtype == DIHIP_BF16) return fused ? launch_w8_t<DIHIP_BF16, true>(grid, s, a) : launch_w8_t<DIHIP_BF16, false>(grid, s, a);
+  return fused ? launch_w8_t<DIHIP_F16, true>(grid, s, a) : launch_w8_t<DIHIP_F16, false>(grid, s, a);
+}
+
 static bool span_len_valid(int S) { return S == 16 || S == 32 || S == 64 || S == 128; }
 
 // returns 0 or an SaStatus-like code: 3 param, 1 hip
@@ -679,7 +719,7 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
     set_last_error("span_attn: span length %d not in {16,32,64,128}", S);
     return DIHIP_SA_PARAM_ERROR;
   }
-  const AttnPlan p = attn_plan(batch, n, g, max_seq_len, num_cus, attn_use_mfma(mode, dtype));
+  const AttnPlan p = attn_plan(batch, n, g, max_seq_len, num_cus, attn_use_mfma(mode, dtype), 256, attn_wide_ok(mode, dtype));
   if (p.nsplits > 1 && (ws == nullptr || ws_bytes < p.partial_bytes)) {
     set_last_error("span_attn: workspace too small (%zu < %zu)", ws_bytes, p.partial_bytes);
     return DIHIP_SA_PARAM_ERROR;
@@ -728,6 +768,8 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
   bool ok = true;
   if (p.mfma && mode == DIHIP_KV_U4) {
     hipLaunchKernelGGL(span_attn_u4_mfma_kernel<false>, grid, dim3(ATTN_THREADS), 0, s, a);
+  } else if (p.mfma && p.waves == 8) {
+    if (!launch_w8(dtype, false, grid, s, a)) return DIHIP_SA_HIP_ERROR;
   } else if (p.mfma && dtype == DIHIP_BF16 && mode == DIHIP_KV_NONE) {
     hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_NONE, false>), grid, dim3(ATTN_THREADS), 0, s, a);
   } else if (p.mfma && dtype == DIHIP_F16 && mode == DIHIP_KV_NONE) {
@@ -775,9 +817,10 @@ static int run_decode(hipStream_t s, void* out, const void* q, const void* const
 // the decode-step plan of the 16-bit cache as decode_attn_block.hip runs it inside its own launch: the split count, split width
 // and record buffer of span_attn_fused_mfma below (same partial records, same merge order)
 void span_attn_block_plan(int batch, int n_heads, int n_groups, int max_seq_len, int* nsplits, int* nchunks, int* tps_static,
-                          size_t* partial_bytes) {
-  const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true);
+                          size_t* partial_bytes, int* waves) {
+  const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true, 256, attn_wide_ok(DIHIP_KV_NONE, DIHIP_BF16));
   *nsplits = p.nsplits;
+  *waves = p.waves;
   *nchunks = p.nchunks;
   *tps_static = ((max_seq_len + p.nsplits - 1) / p.nsplits + 31) & ~31;
   *partial_bytes = p.partial_bytes;
@@ -785,7 +828,7 @@ void span_attn_block_plan(int batch, int n_heads, int n_groups, int max_seq_len,
 
 // decode-step form (Rotary + cache append folded in) for the 16-bit cache: span_attn_ft_mfma_kernel<FT, NONE, true>
 size_t span_attn_fused_mfma_workspace_bytes(int batch, int n_heads, int n_groups, int max_seq_len) {
-  return attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true).partial_bytes;
+  return attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true).partial_bytes;  // (the 4-wave plan: at least the 8-wave form's split count)
 }
 
 int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* const* k_span_array, void* const* v_span_array,
@@ -800,7 +843,7 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
   const bool i8 = kv_mode == DIHIP_KV_I8 && i8_fused;
   if ((kv_mode != DIHIP_KV_NONE && !u4 && !i8) || !attn_use_mfma(kv_mode, dtype)) return DIHIP_SUCCESS;
   if (out_layout == DIHIP_ACT_FRAG32 && ((!u4 && !i8) || batch > 32)) return DIHIP_SUCCESS;  // (the 16-bit form writes row-major rows)
-  const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true);
+  const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, 0, true, 256, attn_wide_ok(kv_mode, dtype));
   if (p.nsplits > 1 && (ws == nullptr || ws_bytes < p.partial_bytes)) return DIHIP_SUCCESS;  // caller's kernels size their own
   *handled = true;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -846,7 +889,9 @@ int span_attn_fused_mfma(void* stream, void* output, const void* qkv, void* cons
     hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_I8, true>), grid, dim3(ATTN_THREADS), 0, s, a);
   else if (i8)
     hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_F16, DIHIP_KV_I8, true>), grid, dim3(ATTN_THREADS), 0, s, a);
-  else if (dtype == DIHIP_BF16)
+  else if (p.waves == 8) {
+    if (!launch_w8(dtype, true, grid, s, a)) return DIHIP_RUNTIME_ERROR;
+  } else if (dtype == DIHIP_BF16)
     hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_BF16, DIHIP_KV_NONE, true>), grid, dim3(ATTN_THREADS), 0, s, a);
   else
     hipLaunchKernelGGL((span_attn_ft_mfma_kernel<DIHIP_F16, DIHIP_KV_NONE, true>), grid, dim3(ATTN_THREADS), 0, s, a);
@@ -927,7 +972,7 @@ int span_attn_decode_biased(void* stream, void* output, const void* query, const
   return st == DIHIP_SA_PARAM_ERROR ? DIHIP_PARAM_ERROR : DIHIP_RUNTIME_ERROR;
 }
 size_t span_attn_decode_workspace_bytes(int batch, int n_heads, int n_groups, int max_seq_len, int kv_mode, int dtype) {
-  return attn_plan(batch, n_heads, n_groups, max_seq_len, 0, attn_use_mfma(kv_mode, dtype)).partial_bytes;
+  return attn_plan(batch, n_heads, n_groups, max_seq_len, 0, attn_use_mfma(kv_mode, dtype)).partial_bytes;  // (4-wave plan: an upper bound)
 }
 }  // namespace dihip
 
@@ -1088,7 +1133,7 @@ int dihip_debug_attn_plan(int batch, int n_heads, int n_groups, int max_seq_len,
                           int* mfma) {
   if (batch <= 0 || n_heads <= 0 || n_groups <= 0 || n_heads % n_groups || max_seq_len <= 0) return DIHIP_SA_PARAM_ERROR;
   const bool m = attn_use_mfma(kv_mode, dtype);
-  const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, num_cus, m);
+  const AttnPlan p = attn_plan(batch, n_heads, n_groups, max_seq_len, num_cus, m, 256, attn_wide_ok(kv_mode, dtype));
   if (nsplits) *nsplits = p.nsplits;
   if (mfma) *mfma = m ? 1 : 0;
   return DIHIP_SUCCESS;

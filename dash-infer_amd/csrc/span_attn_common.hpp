@@ -161,5 +161,14 @@ __device__ __forceinline__ float safe_exp_diff(float a, float b) {  // exp(a - b
   return a == -INFINITY ? 0.f : __expf(a - b);
 }
 
+// merge_order4 -- THE order in which the partial records (o[128], m, l) of a split sequence are merged, in every implementation
+// (span_attn_split_merge_kernel, merge_split_records, merge_polled_items4: bit-identical outputs):
+//   M   = max_j m_j                                      over all splits
+//   c_j = safe_exp_diff(m_j, M)
+//   s_r = fma chain over j = r, r + 4, r + 8, ...  (ascending), from 0:  s_r = fmaf(x_j, c_j, s_r)        r = 0 .. 3,  x = l or an element of o
+//   sum = (s_0 + s_1) + (s_2 + s_3);   out = l_sum > 0 ? o_sum / l_sum : 0
+// Four chains so that a quad of lanes can share the splits of one item -- each lane polls and multiplies a quarter of the records of the
+// fused attention block's hand-off, two DPP steps combine -- and so that a sequential merge has four independent chains.
+
 
 }  // namespace dihip

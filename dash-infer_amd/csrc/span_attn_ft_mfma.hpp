@@ -9,27 +9,29 @@ namespace dihip {
 // Block epilogue shared by the decode kernels: the 4 waves have left one (o[128], m, l) record per head in
 // `lds` ([wave][HC] records of ATTN_PSTRIDE floats).  Combines them and writes the output, or, for split
 // sequences, the block's partial record for span_attn_split_merge_kernel.
-template <int FT, int HC, bool GRAN = false>
+// NW = live waves of the workgroup (4; 8 for the wide form of the 16-bit MFMA kernel: span_attn_ft_mfma_body).
+template <int FT, int HC, bool GRAN = false, int NW = 4>
 __device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float* lds, unsigned* flag_lds, int b, int h0, int nh,
                                                        int split, unsigned* counter, unsigned long long* tr,
                                                        const AttnHandoff* ho = nullptr, int grp = 0);
 
-template <int FT, int HC>
+template <int FT, int HC, int NW = 4>
 __device__ __forceinline__ void attn_block_epilogue(const AttnArgs& a, float* lds, unsigned* flag_lds, int b, int h0, int nh,
                                                     int split, unsigned long long* tr = nullptr) {
   constexpr int H = 128;
   const int tid = threadIdx.x;
   if (a.merge_wt) {  // in-launch merge of the split partials (ticket words from the caller): see attn_block_epilogue_wt
-    attn_block_epilogue_wt<FT, HC>(a, lds, flag_lds, b, h0, nh, split, a.counters + ((size_t)b * gridDim.y + blockIdx.y) * 32, tr);
+    attn_block_epilogue_wt<FT, HC, false, NW>(a, lds, flag_lds, b, h0, nh, split, a.counters + ((size_t)b * gridDim.y + blockIdx.y) * 32, tr);
     return;
   }
   __syncthreads();
   // thread -> (head, dim) pairs of the block result; kept in registers for the epilogue
-  constexpr int PER_THREAD = (HC * H + ATTN_THREADS - 1) / ATTN_THREADS;
+  constexpr int NT = NW * 64;
+  constexpr int PER_THREAD = (HC * H + NT - 1) / NT;
   float bo[PER_THREAD], bm[PER_THREAD], bl[PER_THREAD];
 #pragma unroll
   for (int e = 0; e < PER_THREAD; ++e) {
-    const int idx = tid + e * ATTN_THREADS;
+    const int idx = tid + e * NT;
     const int h = idx / H, d = idx - h * H;
     bo[e] = 0.f;
     bm[e] = -INFINITY;
@@ -37,10 +39,10 @@ __device__ __forceinline__ void attn_block_epilogue(const AttnArgs& a, float* ld
     if (h < nh) {
       float mm = -INFINITY;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) mm = fmaxf(mm, lds[(w * HC + h) * ATTN_PSTRIDE + H]);
+      for (int w = 0; w < NW; ++w) mm = fmaxf(mm, lds[(w * HC + h) * ATTN_PSTRIDE + H]);
       float ll = 0.f, oo = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
+      for (int w = 0; w < NW; ++w) {
         const float* rec = lds + (w * HC + h) * ATTN_PSTRIDE;
         const float c = safe_exp_diff(rec[H], mm);
         ll += rec[H + 1] * c;
@@ -55,7 +57,7 @@ __device__ __forceinline__ void attn_block_epilogue(const AttnArgs& a, float* ld
   if (a.nsplits > 1 || a.force_partials) {
 #pragma unroll
     for (int e = 0; e < PER_THREAD; ++e) {
-      const int idx = tid + e * ATTN_THREADS;
+      const int idx = tid + e * NT;
       const int h = idx / H, d = idx - h * H;
       if (h < nh) {
         float* rec = a.partials + (((size_t)b * a.n + h0 + h) * a.nsplits + split) * ATTN_PSTRIDE;
@@ -70,7 +72,7 @@ __device__ __forceinline__ void attn_block_epilogue(const AttnArgs& a, float* ld
   }
 #pragma unroll
   for (int e = 0; e < PER_THREAD; ++e) {
-    const int idx = tid + e * ATTN_THREADS;
+    const int idx = tid + e * NT;
     const int h = idx / H, d = idx - h * H;
     if (h < nh) {
       const size_t idx = a.out_frag_mt ? act_frag_index(b, (h0 + h) * H + d, a.out_frag_mt) : ((size_t)b * a.n + h0 + h) * H + d;
@@ -82,16 +84,30 @@ __device__ __forceinline__ void attn_block_epilogue(const AttnArgs& a, float* ld
 // the last-arriving workgroup's part of attn_block_epilogue_wt: all nsplits records of its heads, read past the L1 (sc1),
 // merged in split order, output written.  MB = records per load batch.
 // GRAN (fused attention block): the merged output leaves as granules for the o-projection's workgroups instead of FT rows
-template <int FT, int MB, bool GRAN = false, typename RSRC>
+template <int FT, int MB, bool GRAN = false, int NW = 4, typename RSRC>
 __device__ __forceinline__ void merge_split_records(const AttnArgs& a, RSRC rsrc, int b, int h0, int nh, unsigned long long* tr,
                                                     const AttnHandoff* ho = nullptr) {
   constexpr int H = 128;
   const int tid = threadIdx.x;
-  for (int e = tid; e < nh * 32; e += ATTN_THREADS) {
+  for (int e = tid; e < nh * 32; e += NW * 64) {
     const int h = e >> 5, dq = e & 31;
     const uint32_t hoff = (uint32_t)(((size_t)b * a.n + h0 + h) * a.nsplits * ATTN_PSTRIDE * sizeof(float));
-    float mm = -INFINITY, ll = 0.f;
-    f32x4_t oo = {0.f, 0.f, 0.f, 0.f};
+    // merge_order4 (span_attn_common.hpp): the maximum of ALL splits first (plans beyond one load batch: a pass over the {m, l} words) ...
+    float M = -INFINITY;
+    if (a.nsplits > MB) {
+      for (int sb = 0; sb < a.nsplits; sb += MB) {
+        u32x2_t mv[MB];
+#pragma unroll
+        for (int j = 0; j < MB; ++j)
+          mv[j] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, hoff + (uint32_t)(min(sb + j, a.nsplits - 1) * (ATTN_PSTRIDE * (int)sizeof(float))) + H * 4, 0, 16);
+#pragma unroll
+        for (int j = 0; j < MB; ++j) M = fmaxf(M, __uint_as_float(mv[j][0]));  // (a repeated last record changes no maximum)
+      }
+    }
+    // ... then four fma chains over the splits j = r (mod 4) in ascending order, combined as (s0 + s1) + (s2 + s3)
+    float l4[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t o4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    static_assert(MB % 4 == 0, "a load batch keeps the chains' phase");
     for (int sb = 0; sb < a.nsplits; sb += MB) {
       u32x4_t ov[MB];
       u32x2_t mv[MB];
@@ -101,25 +117,24 @@ __device__ __forceinline__ void merge_split_records(const AttnArgs& a, RSRC rsrc
         ov[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ro + dq * 16, 0, 16 /* sc1 */);
         mv[j] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, ro + H * 4, 0, 16);
       }
-      float bm = mm;
+      if (a.nsplits <= MB) {
 #pragma unroll
-      for (int j = 0; j < MB; ++j)
-        if (sb + j < a.nsplits) bm = fmaxf(bm, __uint_as_float(mv[j][0]));
-      const float carry = safe_exp_diff(mm, bm);
-      ll *= carry;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) oo[q] *= carry;
+        for (int j = 0; j < MB; ++j) M = fmaxf(M, __uint_as_float(mv[j][0]));
+      }
 #pragma unroll
       for (int j = 0; j < MB; ++j) {
         if (sb + j < a.nsplits) {
-          const float c = safe_exp_diff(__uint_as_float(mv[j][0]), bm);
-          ll = fmaf(__uint_as_float(mv[j][1]), c, ll);
+          const float c = safe_exp_diff(__uint_as_float(mv[j][0]), M);
+          l4[j & 3] = fmaf(__uint_as_float(mv[j][1]), c, l4[j & 3]);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) oo[q] = fmaf(__uint_as_float(ov[j][q]), c, oo[q]);
+          for (int q = 0; q < 4; ++q) o4[j & 3][q] = fmaf(__uint_as_float(ov[j][q]), c, o4[j & 3][q]);
         }
       }
-      mm = bm;
     }
+    const float ll = (l4[0] + l4[1]) + (l4[2] + l4[3]);
+    f32x4_t oo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) oo[q] = (o4[0][q] + o4[1][q]) + (o4[2][q] + o4[3][q]);
 #if defined(DIHIP_GEMV_TRACE) && DIHIP_GEMV_TRACE
     if (tr) tr[6] = wall_clock64();
 #endif
@@ -160,7 +175,7 @@ __device__ __forceinline__ void merge_split_records(const AttnArgs& a, RSRC rsrc
 // arrivals and merges head s, so that a group's heads merge on 7 CUs in parallel -- shorten the merge reads from 2.6 to 1.2 us
 // but see the last arrival 1.4 us late through their poll: 10.6 vs 10.2 us per layer, removed; the hand-off as a whole
 // costs ~3 us (store drain ~1, ticket ~0.5, reads of freshly handed-off records ~1.5-2.5) either way.)
-template <int FT, int HC, bool GRAN>
+template <int FT, int HC, bool GRAN, int NW>
 __device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float* lds, unsigned* flag_lds, int b, int h0, int nh,
                                                        int split, unsigned* counter, unsigned long long* tr,
                                                        const AttnHandoff* ho, int grp) {
@@ -168,15 +183,15 @@ __device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float*
   const int tid = threadIdx.x;
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.partials, 0, (int)a.partial_bytes, 0x00020000);
   __syncthreads();
-  for (int e = tid; e < nh * 32; e += ATTN_THREADS) {
+  for (int e = tid; e < nh * 32; e += NW * 64) {
     const int h = e >> 5, dq = e & 31;
     float mm = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) mm = fmaxf(mm, lds[(w * HC + h) * ATTN_PSTRIDE + H]);
+    for (int w = 0; w < NW; ++w) mm = fmaxf(mm, lds[(w * HC + h) * ATTN_PSTRIDE + H]);
     float ll = 0.f;
     f32x4_t oo = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
       const float* rec = lds + (w * HC + h) * ATTN_PSTRIDE;
       const float c = safe_exp_diff(rec[H], mm);
       ll += rec[H + 1] * c;
@@ -207,15 +222,16 @@ __device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float*
   if (tr) tr[5] = wall_clock64();
 #endif
   if (*flag_lds == 0u) return;
-  // records per batch: all loads of a batch are in flight together.  The batch width follows the split count (8 / 16 / 24 /
-  // 32), so that a 17-split plan issues 24 record loads per lane, not 32 (the excess re-reads the last record)
-  if (a.nsplits <= 8) merge_split_records<FT, 8, GRAN>(a, rsrc, b, h0, nh, tr, ho);
-  else if (a.nsplits <= 12) merge_split_records<FT, 12, GRAN>(a, rsrc, b, h0, nh, tr, ho);
-  else if (a.nsplits <= 16) merge_split_records<FT, 16, GRAN>(a, rsrc, b, h0, nh, tr, ho);
-  else if (a.nsplits <= 18) merge_split_records<FT, 18, GRAN>(a, rsrc, b, h0, nh, tr, ho);  // (17 splits of a 2048-token history: every record
-  else if (a.nsplits <= 20) merge_split_records<FT, 20, GRAN>(a, rsrc, b, h0, nh, tr, ho);  //  beyond the count is two more loads per lane: round 6)
-  else if (a.nsplits <= 24) merge_split_records<FT, 24, GRAN>(a, rsrc, b, h0, nh, tr, ho);
-  else merge_split_records<FT, 32, GRAN>(a, rsrc, b, h0, nh, tr, ho);
+  // records per batch: all loads of a batch are in flight together.  The batch width follows the split count (8 / 12 / 16 / 20 / 24),
+  // so that a 17-split plan issues 20 record loads per lane, not 32 (the excess re-reads the last record)
+  if (a.nsplits <= 8) merge_split_records<FT, 8, GRAN, NW>(a, rsrc, b, h0, nh, tr, ho);
+  else if (a.nsplits <= 12) merge_split_records<FT, 12, GRAN, NW>(a, rsrc, b, h0, nh, tr, ho);
+  else if (a.nsplits <= 16) merge_split_records<FT, 16, GRAN, NW>(a, rsrc, b, h0, nh, tr, ho);
+  else if (a.nsplits <= 20) merge_split_records<FT, 20, GRAN, NW>(a, rsrc, b, h0, nh, tr, ho);  // (17 splits of a 2048-token history: every record
+                                                                                                //  beyond the count is two more loads per lane: round 6)
+  else if (a.nsplits <= 24) merge_split_records<FT, 24, GRAN, NW>(a, rsrc, b, h0, nh, tr, ho);
+  else merge_split_records<FT, 16, GRAN, NW>(a, rsrc, b, h0, nh, tr, ho);  // (beyond 24: the maximum pass, then batches of 16 -- four chains of
+                                                                           //  accumulators beside a 32-wide batch do not fit the registers)
   // (GRAN: no flag behind the granules -- the consumers poll the group's first granule, then sweep)
 }
 
@@ -226,38 +242,42 @@ __device__ __forceinline__ void attn_block_epilogue_wt(const AttnArgs& a, float*
 //     write-through stores -- no drain, no ticket;
 //   * the merge is DISTRIBUTED: the group's (head, 4-dim) items are dealt over its split workgroups (14 each at 17 splits x 7
 //     heads); the owner of an item polls the item's chunk of every split record until none is zero (the data is the flag: a 16-byte
-//     store lands whole; ~6 KB per pass and workgroup), merges in split order with merge_split_records' single-batch arithmetic
-//     (bit-identical output) and publishes the item's output granules;
+//     store lands whole; ~6 KB per pass and workgroup), merges with the arithmetic of every split merge of this library (merge_order4,
+//     span_attn_common.hpp: bit-identical output) and publishes the item's output granules;
 //   * measured and dropped (profiles/r06_attn_block_polls.txt): all four waves polling a slice out of step (+1.4 us: a poll pass is 34
 //     memory-side loads per lane, and four times the passes delay the stores they wait for), sleeping before the first poll (no effect);
 //   * two record buffers alternate by launch parity: the owner zeroes its chunks of the OTHER buffer (the previous launch's records,
 //     whose readers are long gone) for the next launch -- a reader never races a reset.
-template <int FT, int MB>
-__device__ __forceinline__ void merge_polled_items(const AttnArgs& a, const AttnHandoff* ho, int b, int h0, int i0, int cnt,
-                                                   unsigned long long* tr) {
+// FOUR lanes per item (round 6, second half): lane r of an item's quad polls the records of the splits j = r, r + 4, r + 8, ... only --
+// ceil(nsplits / 4) records per lane and pass instead of all of them (17 splits: 10 loads instead of 34; a poll pass is what the detection of
+// the last record is quantised in) -- and merges them; the quads combine with two DPP steps.  The arithmetic is merge_order4
+// (span_attn_common.hpp): lane r's chain IS chain r, the DPP steps are (s0 + s1) + (s2 + s3) in every lane (float addition commutes bit for bit).
+template <int FT, int MB4, int NW>
+__device__ __forceinline__ void merge_polled_items4(const AttnArgs& a, const AttnHandoff* ho, int b, int h0, int i0, int cnt,
+                                                    unsigned long long* tr) {
   constexpr int H = 128;
   constexpr uint32_t RB = ATTN_PSTRIDE * (uint32_t)sizeof(float);
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 3;
   const uint32_t half = ho->rec_bytes;  // bytes of one buffer
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ho->rec, 0, (int)(2 * half), 0x00020000);
   const auto grsrc = __builtin_amdgcn_make_buffer_rsrc(ho->out_gran, 0, (int)ho->out_gran_bytes, 0x00020000);
   const uint32_t cur = ho->parity ? half : 0u, oth = ho->parity ? 0u : half;
-  for (int e0 = (tid & ~63); e0 < cnt; e0 += ATTN_THREADS) {  // whole waves (the retry is wave-uniform); a wave beyond the slice leaves
-    const int item = i0 + min(e0 + lane, cnt - 1);
+  for (int e0 = (tid >> 6) * 16; e0 < cnt; e0 += NW * 16) {  // whole waves, 16 items each (the retry is wave-uniform)
+    const int item = i0 + min(e0 + (lane >> 2), cnt - 1);
     const int h = item >> 5, dq = item & 31;
     const uint32_t hoff = (uint32_t)(((size_t)b * a.n + h0 + h) * a.nsplits) * RB;
-    u32x4_t ov[MB];
-    u32x2_t mv[MB];
+    u32x4_t ov[MB4];
+    u32x2_t mv[MB4];
     for (unsigned spins = 0;; ++spins) {
 #pragma unroll
-      for (int j = 0; j < MB; ++j) {
-        const uint32_t ro = cur + hoff + (uint32_t)min(j, a.nsplits - 1) * RB;
+      for (int j = 0; j < MB4; ++j) {
+        const uint32_t ro = cur + hoff + (uint32_t)min(r + 4 * j, a.nsplits - 1) * RB;
         ov[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ro + dq * 16, 0, 16 /* sc1 */);
         mv[j] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, ro + H * 4, 0, 16);
       }
       bool ok = true;
 #pragma unroll
-      for (int j = 0; j < MB; ++j) ok = ok && ((ov[j][0] | ov[j][1] | ov[j][2] | ov[j][3]) != 0u) && ((mv[j][0] | mv[j][1]) != 0u);
+      for (int j = 0; j < MB4; ++j) ok = ok && ((ov[j][0] | ov[j][1] | ov[j][2] | ov[j][3]) != 0u) && ((mv[j][0] | mv[j][1]) != 0u);
       if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
       if (spins > ho->spin_limit) {  // gives up (wave-uniform): garbage results, flagged, never a hang
         if (lane == 0) __hip_atomic_store(ho->err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -273,127 +293,51 @@ __device__ __forceinline__ void merge_polled_items(const AttnArgs& a, const Attn
 #endif
     float bm = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < MB; ++j)
-      if (j < a.nsplits) bm = fmaxf(bm, __uint_as_float(~mv[j][0]));
-    // (merge_split_records with one batch: mm = -inf, so the carry is 0 and ll / oo start from 0 * 0)
+    for (int j = 0; j < MB4; ++j)
+      if (r + 4 * j < a.nsplits) bm = fmaxf(bm, __uint_as_float(~mv[j][0]));
+    bm = fmaxf(bm, dpp_mov_f32<0xB1>(bm));  // quad_perm [1,0,3,2]
+    bm = fmaxf(bm, dpp_mov_f32<0x4E>(bm));  // quad_perm [2,3,0,1]
     float ll = 0.f;
     f32x4_t oo = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < MB; ++j) {
-      if (j < a.nsplits) {
+    for (int j = 0; j < MB4; ++j) {
+      if (r + 4 * j < a.nsplits) {
         const float c = safe_exp_diff(__uint_as_float(~mv[j][0]), bm);
         ll = fmaf(__uint_as_float(~mv[j][1]), c, ll);
 #pragma unroll
         for (int q = 0; q < 4; ++q) oo[q] = fmaf(__uint_as_float(~ov[j][q]), c, oo[q]);
       }
     }
-    float r[4];
+    ll += dpp_mov_f32<0xB1>(ll);
+    ll += dpp_mov_f32<0x4E>(ll);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = ll > 0.f ? oo[q] / ll : 0.f;
-    if (e0 + lane < cnt) {
-      const u32x4_t gv = {pack_ft2<FT>(r[0], r[1]), ho->tag, pack_ft2<FT>(r[2], r[3]), ho->tag};
-      __builtin_amdgcn_raw_buffer_store_b128(gv, grsrc, (uint32_t)((((size_t)b * a.n + h0 + h) * (H / 2) + dq * 2) * 8), 0, 16 /* sc1 */);
-      // this item's chunks of the OTHER buffer back to zero for the next launch (write-through: no line stays in this XCD's L2)
+    for (int q = 0; q < 4; ++q) {
+      oo[q] += dpp_mov_f32<0xB1>(oo[q]);
+      oo[q] += dpp_mov_f32<0x4E>(oo[q]);
+    }
+    float rr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rr[q] = ll > 0.f ? oo[q] / ll : 0.f;
+    if (e0 + (lane >> 2) < cnt) {
+      if (r == 0) {
+        const u32x4_t gv = {pack_ft2<FT>(rr[0], rr[1]), ho->tag, pack_ft2<FT>(rr[2], rr[3]), ho->tag};
+        __builtin_amdgcn_raw_buffer_store_b128(gv, grsrc, (uint32_t)((((size_t)b * a.n + h0 + h) * (H / 2) + dq * 2) * 8), 0, 16 /* sc1 */);
+      }
+      // this item's chunks of the OTHER buffer back to zero for the next launch (write-through: no line stays in this XCD's L2): lane r its splits
       const u32x4_t z4 = {0u, 0u, 0u, 0u};
-      for (int j = 0; j < a.nsplits; ++j) {
-        const uint32_t ro = oth + hoff + (uint32_t)j * RB;
-        __builtin_amdgcn_raw_buffer_store_b128(z4, rsrc, ro + dq * 16, 0, 16);
-        if (dq == 0) __builtin_amdgcn_raw_buffer_store_b128(z4, rsrc, ro + H * 4, 0, 16);
+#pragma unroll
+      for (int j = 0; j < MB4; ++j) {
+        if (r + 4 * j < a.nsplits) {
+          const uint32_t ro = oth + hoff + (uint32_t)(r + 4 * j) * RB;
+          __builtin_amdgcn_raw_buffer_store_b128(z4, rsrc, ro + dq * 16, 0, 16);
+          if (dq == 0) __builtin_amdgcn_raw_buffer_store_b128(z4, rsrc, ro + H * 4, 0, 16);
+        }
       }
     }
   }
 }
 
-// More than 20 splits (long histories): the same merge in two phases, so that the records of all splits never sit in registers together --
-// (1) poll the {m, l} chunk of every split (2 registers each), take the maximum, the coefficients exp(m_j - max) and the normaliser in split
-// order; (2) poll the item's o-chunks eight splits at a time and accumulate in split order.  Sum for sum the arithmetic of the single batch.
-template <int FT>
-__device__ __forceinline__ void merge_polled_items_wide(const AttnArgs& a, const AttnHandoff* ho, int b, int h0, int i0, int cnt,
-                                                        unsigned long long* tr) {
-  constexpr int H = 128, MAXS = 32, SB = 8;
-  constexpr uint32_t RB = ATTN_PSTRIDE * (uint32_t)sizeof(float);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const uint32_t half = ho->rec_bytes;
-  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ho->rec, 0, (int)(2 * half), 0x00020000);
-  const auto grsrc = __builtin_amdgcn_make_buffer_rsrc(ho->out_gran, 0, (int)ho->out_gran_bytes, 0x00020000);
-  const uint32_t cur = ho->parity ? half : 0u, oth = ho->parity ? 0u : half;
-  for (int e0 = (tid & ~63); e0 < cnt; e0 += ATTN_THREADS) {
-    const int item = i0 + min(e0 + lane, cnt - 1);
-    const int h = item >> 5, dq = item & 31;
-    const uint32_t hoff = (uint32_t)(((size_t)b * a.n + h0 + h) * a.nsplits) * RB;
-    u32x2_t mv[MAXS];
-    for (unsigned spins = 0;; ++spins) {
-#pragma unroll
-      for (int j = 0; j < MAXS; ++j) mv[j] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, cur + hoff + (uint32_t)min(j, a.nsplits - 1) * RB + H * 4, 0, 16 /* sc1 */);
-      bool ok = true;
-#pragma unroll
-      for (int j = 0; j < MAXS; ++j) ok = ok && ((mv[j][0] | mv[j][1]) != 0u);
-      if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-      if (spins > ho->spin_limit) {
-        if (lane == 0) __hip_atomic_store(ho->err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-    float bm = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < MAXS; ++j)
-      if (j < a.nsplits) bm = fmaxf(bm, __uint_as_float(~mv[j][0]));
-    float cj[MAXS];
-    float ll = 0.f;
-#pragma unroll
-    for (int j = 0; j < MAXS; ++j) {
-      cj[j] = 0.f;
-      if (j < a.nsplits) {
-        cj[j] = safe_exp_diff(__uint_as_float(~mv[j][0]), bm);
-        ll = fmaf(__uint_as_float(~mv[j][1]), cj[j], ll);
-      }
-    }
-    f32x4_t oo = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s0 = 0; s0 < MAXS; s0 += SB) {
-      if (s0 >= a.nsplits) break;
-      u32x4_t ov[SB];
-      for (unsigned spins = 0;; ++spins) {
-#pragma unroll
-        for (int j = 0; j < SB; ++j) ov[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, cur + hoff + (uint32_t)min(s0 + j, a.nsplits - 1) * RB + dq * 16, 0, 16);
-        bool ok = true;
-#pragma unroll
-        for (int j = 0; j < SB; ++j) ok = ok && ((ov[j][0] | ov[j][1] | ov[j][2] | ov[j][3]) != 0u);
-        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-        if (spins > ho->spin_limit) {
-          if (lane == 0) __hip_atomic_store(ho->err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(2);
-      }
-#pragma unroll
-      for (int j = 0; j < SB; ++j)
-        if (s0 + j < a.nsplits) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) oo[q] = fmaf(__uint_as_float(~ov[j][q]), cj[s0 + j], oo[q]);
-        }
-    }
-#if defined(DIHIP_GEMV_TRACE) && DIHIP_GEMV_TRACE
-    if (tr) tr[6] = wall_clock64();
-#endif
-    float r[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = ll > 0.f ? oo[q] / ll : 0.f;
-    if (e0 + lane < cnt) {
-      const u32x4_t gv = {pack_ft2<FT>(r[0], r[1]), ho->tag, pack_ft2<FT>(r[2], r[3]), ho->tag};
-      __builtin_amdgcn_raw_buffer_store_b128(gv, grsrc, (uint32_t)((((size_t)b * a.n + h0 + h) * (H / 2) + dq * 2) * 8), 0, 16 /* sc1 */);
-      const u32x4_t z4 = {0u, 0u, 0u, 0u};
-      for (int j = 0; j < a.nsplits; ++j) {
-        const uint32_t ro = oth + hoff + (uint32_t)j * RB;
-        __builtin_amdgcn_raw_buffer_store_b128(z4, rsrc, ro + dq * 16, 0, 16);
-        if (dq == 0) __builtin_amdgcn_raw_buffer_store_b128(z4, rsrc, ro + H * 4, 0, 16);
-      }
-    }
-  }
-}
-
-template <int FT, int HC>
+template <int FT, int HC, int NW>
 __device__ __forceinline__ void attn_block_epilogue_polled(const AttnArgs& a, float* lds, int b, int h0, int nh, int split,
                                                            unsigned long long* tr, const AttnHandoff* ho) {
   constexpr int H = 128;
@@ -402,15 +346,15 @@ __device__ __forceinline__ void attn_block_epilogue_polled(const AttnArgs& a, fl
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ho->rec, 0, (int)(2 * half), 0x00020000);
   const uint32_t cur = ho->parity ? half : 0u;
   __syncthreads();
-  for (int e = tid; e < nh * 32; e += ATTN_THREADS) {  // the block record: the arithmetic of attn_block_epilogue_wt
+  for (int e = tid; e < nh * 32; e += NW * 64) {  // the block record: the arithmetic of attn_block_epilogue_wt
     const int h = e >> 5, dq = e & 31;
     float mm = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) mm = fmaxf(mm, lds[(w * HC + h) * ATTN_PSTRIDE + H]);
+    for (int w = 0; w < NW; ++w) mm = fmaxf(mm, lds[(w * HC + h) * ATTN_PSTRIDE + H]);
     float ll = 0.f;
     f32x4_t oo = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
       const float* rec = lds + (w * HC + h) * ATTN_PSTRIDE;
       const float c = safe_exp_diff(rec[H], mm);
       ll += rec[H + 1] * c;
@@ -434,17 +378,16 @@ __device__ __forceinline__ void attn_block_epilogue_polled(const AttnArgs& a, fl
   const int items = nh * 32, per = (items + a.nsplits - 1) / a.nsplits;
   const int i0 = split * per, cnt = min(per, items - i0);
   if (cnt <= 0) return;
-  // batch width = loads per pass and lane = EXACTLY the split count: every record beyond it that a wider batch re-reads is two more
-  // memory-side loads per lane and pass on the launch's critical path (measured at 17 splits: 24 wide 18.35 us per layer, 20 wide 17.70,
-  // profiles/r06_attn_block_polls.txt)
-  switch (a.nsplits) {
-#define DIHIP_MPI(N) case N: merge_polled_items<FT, N>(a, ho, b, h0, i0, cnt, tr); break;
-    DIHIP_MPI(2) DIHIP_MPI(3) DIHIP_MPI(4) DIHIP_MPI(5) DIHIP_MPI(6) DIHIP_MPI(7) DIHIP_MPI(8) DIHIP_MPI(9) DIHIP_MPI(10) DIHIP_MPI(11)
-    DIHIP_MPI(12) DIHIP_MPI(13) DIHIP_MPI(14) DIHIP_MPI(15) DIHIP_MPI(16) DIHIP_MPI(17) DIHIP_MPI(18) DIHIP_MPI(19) DIHIP_MPI(20)
-#undef DIHIP_MPI
-    // (beyond 20 splits: the two-phase form below -- a 32-wide single batch needs 192 registers for the records alone and put the whole block
-    // kernel at its 256-VGPR ceiling: spills)
-    default: merge_polled_items_wide<FT>(a, ho, b, h0, i0, cnt, tr); break;
+  // a quad of lanes per item, ceil(nsplits / 4) records per lane and pass (merge_polled_items4)
+  switch ((a.nsplits + 3) >> 2) {  // records per lane: the quad's lanes share the splits (nsplits <= 32: the host's contract)
+    case 1: merge_polled_items4<FT, 1, NW>(a, ho, b, h0, i0, cnt, tr); break;
+    case 2: merge_polled_items4<FT, 2, NW>(a, ho, b, h0, i0, cnt, tr); break;
+    case 3: merge_polled_items4<FT, 3, NW>(a, ho, b, h0, i0, cnt, tr); break;
+    case 4: merge_polled_items4<FT, 4, NW>(a, ho, b, h0, i0, cnt, tr); break;
+    case 5: merge_polled_items4<FT, 5, NW>(a, ho, b, h0, i0, cnt, tr); break;
+    case 6: merge_polled_items4<FT, 6, NW>(a, ho, b, h0, i0, cnt, tr); break;
+    case 7: merge_polled_items4<FT, 7, NW>(a, ho, b, h0, i0, cnt, tr); break;
+    default: merge_polled_items4<FT, 8, NW>(a, ho, b, h0, i0, cnt, tr); break;
   }
 }
 
@@ -476,9 +419,14 @@ __device__ __forceinline__ f32x4_t mfma_ft(const u32x4_t& a_, const u32x4_t& b_,
 // the SAME lane); the workgroup whose range holds the new token rotates / rounds this step's K head and takes its V
 // head, one wave writes both into the span (byte-identical to DecoderCacheAppend), and every lane whose (clamped)
 // token is the new one uses the register copy -- the span row itself may not be written yet.
-constexpr int FT_MFMA_EPI_BYTES = (4 * MF_HC * ATTN_PSTRIDE + 4) * 4;
-constexpr int FT_MFMA_VT_BYTES = 4 * MF_TOK * MF_VPITCH;
-constexpr int FT_MFMA_SMEM_BYTES = FT_MFMA_EPI_BYTES > FT_MFMA_VT_BYTES ? FT_MFMA_EPI_BYTES : FT_MFMA_VT_BYTES;
+// NW (16-bit cache only): live waves per workgroup.  4: two workgroups share a CU.  8 (batch 1, DIHIP_ATTN_WIDE=1: attn_plan): one workgroup
+// per CU that covers 256 tokens per pass -- half the split records for the merge to wait for, the whole K / V share of a 2048-token history
+// still requested up front.  Measured equal to slightly slower than the 4-wave form (profiles/r06_attn_block_polls.txt): kept as an A/B form.
+constexpr int ft_mfma_smem_bytes(int nw) {
+  const int epi = (nw * MF_HC * ATTN_PSTRIDE + 4) * 4, vt = nw * MF_TOK * MF_VPITCH;
+  return epi > vt ? epi : vt;
+}
+constexpr int FT_MFMA_SMEM_BYTES = ft_mfma_smem_bytes(4);
 
 __device__ __forceinline__ u32x4_t ld_qkv16(const uint16_t* p) { return *reinterpret_cast<const u32x4_t*>(p); }  // 16 bytes of the fused qkv row
 
@@ -502,7 +450,7 @@ __device__ __forceinline__ u32x4_t ld_qkv16(const uint16_t* p) { return *reinter
 // workgroups of the SAME launch (AttnHandoff): swept into an LDS image behind the kernel's buffer while the K / V tiles are in
 // flight, and the merged output leaves as granules.  One head chunk per group (nchunks == 1).
 constexpr int FT_MFMA_GATHER_IMG_BYTES = (MF_HC + 2) * 128 * 2;
-template <int FT, int MODE, bool FUSED, bool GATHER = false>
+template <int FT, int MODE, bool FUSED, bool GATHER = false, int NW = 4>
 __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const int bx, const int by, const int bz, const int gx,
                                                        const int gy, const int gz, unsigned char* smem,
                                                        const AttnHandoff* ho = nullptr) {
@@ -511,10 +459,13 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   constexpr bool Q8 = MODE == DIHIP_KV_I8;
   static_assert(!FUSED || MODE == DIHIP_KV_NONE || MODE == DIHIP_KV_I8, "the decode-step form covers the 16-bit and the int8 cache");
   static_assert(!GATHER || MODE == DIHIP_KV_NONE, "the gathering form is the decode step over the 16-bit cache");
+  static_assert(NW == 4 || (NW == 8 && MODE == DIHIP_KV_NONE), "the 8-wave form covers the 16-bit cache");
+  constexpr int NT = NW * 64;
+  constexpr int SMEM = (ft_mfma_smem_bytes(NW) + 15) & ~15;
   constexpr int ROWB = Q8 ? H : H * 2;  // bytes per token-head row in the span
   // the per-wave V tiles and the epilogue records share one buffer (a barrier separates the two uses): FT_MFMA_SMEM_BYTES
   float* lds = reinterpret_cast<float*>(smem);
-  unsigned* flag_lds = reinterpret_cast<unsigned*>(lds + 4 * HC * ATTN_PSTRIDE);
+  unsigned* flag_lds = reinterpret_cast<unsigned*>(lds + NW * HC * ATTN_PSTRIDE);
 
   const int tid = threadIdx.x, lane = tid & 63;
   DIHIP_ATTN_STAMP(0);
@@ -633,15 +584,12 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
 
   // rotate-half on a lane's fragments: dims ks*32 + kb*8 + e (ks = 0, 1) pair with ks + 2; table row = position.
   // Same arithmetic and rounding as dihip_rope_qk / the Rotary op: two products, one add, rounded to FT.
-  // GATHER: this lane's {cos, sin} rows are requested BEFORE the wait for the q granules (csr): the table row depends on the
-  // position alone, and a load issued after the hand-off is a whole round trip on the launch's critical path
-  f32x4_t csr[2][4];
+  // (GATHER: the sweep of the granules rotates -- see there)
   auto rotate = [&](u32x4_t (&f)[4], const float* cs_row) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const f32x4_t* t = reinterpret_cast<const f32x4_t*>(cs_row + (ks * 32 + kb * 8) * 2);
-      const f32x4_t c0 = GATHER ? csr[ks][0] : t[0], c1 = GATHER ? csr[ks][1] : t[1], c2 = GATHER ? csr[ks][2] : t[2],
-                    c3 = GATHER ? csr[ks][3] : t[3];  // {cos, sin} x 8 dims
+      const f32x4_t c0 = t[0], c1 = t[1], c2 = t[2], c3 = t[3];  // {cos, sin} x 8 dims
       const float cosv[8] = {c0[0], c0[2], c1[0], c1[2], c2[0], c2[2], c3[0], c3[2]};
       const float sinv[8] = {c0[1], c0[3], c1[1], c1[3], c2[1], c2[3], c3[1], c3[3]};
       u32x4_t lo_, hi_;
@@ -670,30 +618,38 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   float qsum = 0.f;
   const size_t qrow_stride = FUSED ? (size_t)(a.n + 2 * a.g) * H : (size_t)a.n * H;
   const float* cs_row = FUSED ? a.rope_tab + (size_t)newpos * 128 : nullptr;
-  uint16_t* const img = reinterpret_cast<uint16_t*>(smem + ((FT_MFMA_SMEM_BYTES + 15) & ~15));  // GATHER: [hpg q heads][k][v] x 128
+  uint16_t* const img = reinterpret_cast<uint16_t*>(smem + SMEM);  // GATHER: [hpg q heads][k][v] x 128
   if constexpr (GATHER) {
     static_assert(FUSED && MODE == DIHIP_KV_NONE, "the gathering form is the decode step over the 16-bit cache");
+    // The sweep ROTATES: a thread takes the two granules of a rotate-half pair (dims d, d + 64 of a query head or of this step's K head),
+    // applies the Rotary arithmetic of rotate() below -- two products, one add, rounded to FT -- once, and the LDS image holds rotated
+    // rows.  (Round 5 / 6 rotated the fragments: ~256 instructions in EVERY wave after the hand-off, and as many again for the K head in
+    // the workgroup of the last split -- the one every merge waits for.)  The {cos, sin} pair depends on d = tid % 64 alone: requested
+    // before the wait.  V granules (no rotation): one more load for 128 threads.
+    const int npair = (a.hpg + 1) * 64;
+    constexpr int GP = NW == 8 ? 1 : 2;  // pairs per thread and round: (7 + 1) heads x 64 = 1 x 512 threads = 2 x 256
+    const float cs[2] = {cs_row[(tid & 63) * 2], cs_row[(tid & 63) * 2 + 1]};
+    for (int base = 0; base < npair; base += GP * NT) {
+      int s0[GP], s1[GP];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) csr[ks][j] = reinterpret_cast<const f32x4_t*>(cs_row + (ks * 32 + kb * 8) * 2)[j];
-    const int nq = a.hpg * H, tot = nq + 2 * H;
-    constexpr int GB = 5;  // granules per thread per sweep: (7 + 2) heads x 128 = 4.5 x 256 threads
-    for (int base = 0; base < tot; base += GB * ATTN_THREADS) {
-      int src[GB];
-#pragma unroll
-      for (int j = 0; j < GB; ++j) {
-        const int idx = min(base + j * ATTN_THREADS + tid, tot - 1);
-        src[j] = idx < nq ? h0 * H + idx : idx < nq + H ? (a.n + grp) * H + (idx - nq) : (a.n + a.g + grp) * H + (idx - nq - H);
+      for (int j = 0; j < GP; ++j) {
+        const int pi = min(base + j * NT + tid, npair - 1), hh = pi >> 6, d = pi & 63;
+        s0[j] = (hh < a.hpg ? (h0 + hh) * H : (a.n + grp) * H) + d;
+        s1[j] = s0[j] + 64;
       }
-      unsigned long long gv[GB];
+      const bool has_v = base == 0 && tid < H;
+      const int sv = (a.n + a.g + grp) * H + (has_v ? tid : 0);
+      unsigned long long g0[GP], g1[GP], gvv;
       for (unsigned spins = 0;; ++spins) {
         bool ok = true;
 #pragma unroll
-        for (int j = 0; j < GB; ++j) {
-          gv[j] = __hip_atomic_load(ho->qkv_gran + src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = ok && (unsigned)(gv[j] >> 32) == ho->tag;
+        for (int j = 0; j < GP; ++j) {
+          g0[j] = __hip_atomic_load(ho->qkv_gran + s0[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          g1[j] = __hip_atomic_load(ho->qkv_gran + s1[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && (unsigned)(g0[j] >> 32) == ho->tag && (unsigned)(g1[j] >> 32) == ho->tag;
         }
+        gvv = __hip_atomic_load(ho->qkv_gran + sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = ok && (unsigned)(gvv >> 32) == ho->tag;
         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
         if (spins > ho->spin_limit) {  // gives up (wave-uniform): garbage results, flagged, never a hang
           if (lane == 0) __hip_atomic_store(ho->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -705,10 +661,18 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
         __builtin_amdgcn_s_sleep(DIHIP_AB_SLEEP_Q);
       }
 #pragma unroll
-      for (int j = 0; j < GB; ++j) {
-        const int idx = base + j * ATTN_THREADS + tid;
-        if (idx < tot) img[idx] = (uint16_t)gv[j];
+      for (int j = 0; j < GP; ++j) {
+        const int pi = base + j * NT + tid;
+        if (pi < npair) {
+          const float x0 = ft_bits_to_f32<FT>((uint32_t)g0[j] & 0xFFFFu), x1 = ft_bits_to_f32<FT>((uint32_t)g1[j] & 0xFFFFu);
+          const float r0 = x0 * cs[0] - x1 * cs[1];
+          const float r1 = x1 * cs[0] + x0 * cs[1];
+          const int at = (pi >> 6) * H + (pi & 63);
+          img[at] = (uint16_t)f32_to_ft_bits<FT>(r0);
+          img[at + 64] = (uint16_t)f32_to_ft_bits<FT>(r1);
+        }
       }
+      if (has_v) img[(a.hpg + 1) * H + tid] = (uint16_t)gvv;
     }
     __syncthreads();
     DIHIP_ATTN_STAMPX(4);  // granules swept into the LDS image
@@ -748,8 +712,8 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
         }
         qf[ks] = rot;
       }
-    } else if constexpr (FUSED) {
-      rotate(qf, cs_row);
+    } else if constexpr (FUSED && !GATHER) {
+      rotate(qf, cs_row);  // (GATHER: the image holds rotated rows)
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
@@ -764,7 +728,7 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   // int8: the new K / V head rotated, rounded and QUANTISED as the append kernel does (store_token_head) -- every wave for itself into
   // its own 2 x 144 bytes of LDS ({128 codes, zero, scale}; no workgroup barrier: a wave reads back what it wrote itself, LDS
   // operations of a wave execute in order); the tile loop substitutes codes and parameters where a lane's token is the new one
-  unsigned char* const nrow = smem + ((FT_MFMA_SMEM_BYTES + 15) & ~15) + wave * 288;
+  unsigned char* const nrow = smem + SMEM + wave * 288;
   if constexpr (FUSED && Q8) {
     if (has_new) {
       const int sp = newpos >> lgS, pos = newpos - (sp << lgS);
@@ -803,7 +767,7 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
       const uint16_t* vrow = GATHER ? krow + H : krow + (size_t)a.g * H;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) knew[ks] = ld_qkv16(krow + ks * 32 + kb * 8);
-      rotate(knew, cs_row);
+      if constexpr (!GATHER) rotate(knew, cs_row);
       vnew = ld_qkv16(vrow + (lane & 15) * 8);
       if (hc == 0 && wave == 0 && (newpos >> lgS) < a.span_stride) {  // one writer per (request, group): DecoderCacheAppend; a token
         // past the span table is dropped, as kv_append_kernel does (span_cache.hip) -- never written over a cached one
@@ -829,7 +793,7 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   const unsigned char* tr0 = vt + (kb * 4 + (ni >> 2)) * MF_VPITCH + (ni & 3) * 8;
 
   if (active) {
-    constexpr int STEP = 4 * MF_TOK;
+    constexpr int STEP = NW * MF_TOK;
     for (int tb = tb0; tb < t1; tb += STEP) {
       // FUSED: lanes whose (clamped) token is this step's token take the register copy (see above)
       if constexpr (FUSED && Q8) {
@@ -1007,21 +971,21 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   if constexpr (GATHER) {
     // the fused block: polled split records (nsplits <= 32, the host's contract), no drain, no ticket.  (The ticket protocol below is not
     // compiled into the block any more: its 32-wide reload kept the whole kernel at the register ceiling.)
-    attn_block_epilogue_polled<FT, HC>(a, lds, b, h0, nh, split,
-                                       a.trace ? a.trace + (((size_t)bz * gy + by) * gx + bx) * 32 + (threadIdx.x >> 6) * 8 : nullptr, ho);
+    attn_block_epilogue_polled<FT, HC, NW>(a, lds, b, h0, nh, split,
+                                           a.trace && threadIdx.x < 192 ? a.trace + (((size_t)bz * gy + by) * gx + bx) * 32 + (threadIdx.x >> 6) * 8 : nullptr, ho);
     DIHIP_ATTN_STAMP(7);
     return;
   } else if constexpr (FUSED) {
     if (a.merge_wt) {
-      attn_block_epilogue_wt<FT, HC, GATHER>(a, lds, flag_lds, b, h0, nh, split,
-                                             a.counters + (((size_t)b * a.g + grp) * a.nchunks + hc) * 32,  // one 128-byte line each
-                                             a.trace ? a.trace + (((size_t)bz * gy + by) * gx + bx) * 32 + (threadIdx.x >> 6) * 8 : nullptr,
-                                             ho, grp);
+      attn_block_epilogue_wt<FT, HC, GATHER, NW>(a, lds, flag_lds, b, h0, nh, split,
+                                                 a.counters + (((size_t)b * a.g + grp) * a.nchunks + hc) * 32,  // one 128-byte line each
+                                                 a.trace && threadIdx.x < 192 ? a.trace + (((size_t)bz * gy + by) * gx + bx) * 32 + (threadIdx.x >> 6) * 8 : nullptr,
+                                                 ho, grp);
       DIHIP_ATTN_STAMP(7);
       return;
     }
   }
-  attn_block_epilogue<FT, HC>(a, lds, flag_lds, b, h0, nh, split);
+  attn_block_epilogue<FT, HC, NW>(a, lds, flag_lds, b, h0, nh, split);
   DIHIP_ATTN_STAMP(7);
 }
 
@@ -1031,6 +995,13 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void span_attn_ft_mfma_kernel(cons
   // (+ the int8 decode step's per-wave new-row buffers: 4 x 2 x 144 bytes behind the tiles)
   __shared__ __attribute__((aligned(16))) unsigned char smem[FT_MFMA_SMEM_BYTES + (FUSED && MODE == DIHIP_KV_I8 ? 16 + 4 * 288 : 0)];
   span_attn_ft_mfma_body<FT, MODE, FUSED>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z, smem);
+}
+
+// the 8-wave form (16-bit cache, batch 1: AttnPlan::waves): 72 KB of V tiles -- dynamic LDS, ft_mfma_smem_bytes(8)
+template <int FT, bool FUSED>
+__global__ __launch_bounds__(512) void span_attn_ft_mfma_w8_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  span_attn_ft_mfma_body<FT, DIHIP_KV_NONE, FUSED, false, 8>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z, dyn_smem);
 }
 
 }  // namespace dihip

@@ -303,3 +303,22 @@ def test_block_under_load_is_bit_identical_and_never_times_out(pkg):
     bad = [r for r in range(0, REPS, 2) if not torch.equal(keep[r], want[(r // 2) % 4])]
     assert not bad, f"{len(bad)} launches differ from the chain (first: repetition {bad[0]})"
     b.check_handoffs()
+
+
+def test_the_eight_wave_attention_form_in_a_process_of_its_own():
+    """DIHIP_ATTN_WIDE=1 (read once per process): 8-wave attention workgroups at batch 1 -- half the split count -- in the stand-alone kernel
+    (span_attn_ft_mfma_w8_kernel) AND in the block (decode_attn_block_kernel<8>): the bit-identity tests of this file and the oracle
+    comparisons of the 16-bit cache's decode attention, re-run in a child process with the switch on."""
+    import subprocess
+    import sys
+    if os.environ.get("DIHIP_ATTN_WIDE") == "1":
+        pytest.skip("already the child")
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, DIHIP_ATTN_WIDE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(here, "test_gpu_attn_block.py"), os.path.join(here, "test_gpu_kv_attn.py"),
+                        "-k", "one_launch_equals or other_split_counts or replayed_graph or span_attention_unquantised or fused_rope_append or long_context"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here))
+    tail = (r.stdout or "")[-1500:] + (r.stderr or "")[-500:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "failed" not in r.stdout, tail

@@ -77,8 +77,12 @@ if "trace" in os.environ.get("DIHIP_LIB_DIR", ""):
     used = t[:, 0] > 0
     t0 = t[used][:, :].clone()
     base = t0[t0 > 0].min()
-    ns, g = 17, 4
+    import ctypes
+    ns_c, mf_c = ctypes.c_int(0), ctypes.c_int(0)
+    ops.lib().dihip_debug_attn_plan(1, cfg.n_heads, cfg.n_kv, b.max_len, 0, 2, 0, ctypes.byref(ns_c), ctypes.byref(mf_c))  # 16-bit cache, bf16
+    ns, g = ns_c.value, cfg.n_kv
     na = int(os.environ.get("NA", ns * g))
+    print(f"plan: {ns} splits x {g} groups = {na} attention workgroups")
     names_a = ["entry", "K/V requested", "q gathered (+rotate)", "tiles done", "records drained", "ticket taken", "merge loads landed", "end"]
     names_a[4] = "records stored (dist. merge) / drained"
     names_g = ["entry", "row staged, shares requested", "shares landed", "qkv published", "group sentinels seen", "output swept", "o multiplied", "end",

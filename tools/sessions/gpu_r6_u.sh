@@ -1,0 +1,19 @@
+#!/bin/bash
+# r6 u: 8-wave attention workgroups at batch 1 (9 splits of a 2048-token history instead of 17) + Rotary in the granule sweep: tests, A/B (DIHIP_ATTN_WIDE=0), timelines
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r6u
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests/test_gpu_attn_block.py tests/test_gpu_kv_attn.py tests/test_gpu_attn_merge_stress.py tests/test_gpu_host_runner.py tests/test_gpu_decoder.py -q -x --timeout 900 2>&1 | tail -12 | tee $OUT/pytest.log
+for rep in 1 2 3; do
+  for W in 1 0; do
+    r=$(DIHIP_ATTN_WIDE=$W timeout 300 python tools/attn_block_trace.py 2>&1 | grep "one launch" | sed 's/.*: *//; s/ us per.*//')
+    echo "rep $rep WIDE=$W -> $r" | tee -a $OUT/sweep.txt
+  done
+done
+make -C dash-infer_amd/csrc trace -j16 2>&1 | grep -E "error" | head
+DIHIP_LIB_DIR=$PWD/dash-infer_amd/lib/trace timeout 300 python tools/attn_block_trace.py 2>&1 | tee $OUT/trace_7b.txt | tail -34
+DIHIP_ATTN_WIDE=0 DIHIP_LIB_DIR=$PWD/dash-infer_amd/lib/trace timeout 300 python tools/attn_block_trace.py 2>&1 | tee $OUT/trace_7b_w4.txt | tail -34
+for W in 1 0; do
+DIHIP_ATTN_WIDE=$W timeout 300 python bench.py --no-extra --no-cpu-baseline --steps 32 --warmup 8 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench WIDE=$W', d['value'], d['ms_per_step'])" | tee -a $OUT/sweep.txt
+done
+DIHIP_ATTN_WIDE=1 timeout 300 python bench.py --workload tp8_rank_7b --no-extra --no-cpu-baseline --steps 32 --warmup 8 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('tp8', d['value'], d['ms_per_step'])" | tee -a $OUT/sweep.txt
