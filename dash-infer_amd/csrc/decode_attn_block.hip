@@ -209,7 +209,14 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
   unsigned tag = p.state[0] + 1u;
   if (tag == 0u) tag = 1u;
 
-  if (bid < p.NA) {
+  // Workgroups are dispatched in the order of their ids, 256 of them over ~1.4 us: the GEMV workgroups take the FIRST ids -- the qkv rows
+  // every attention workgroup waits for are published by the last of them -- the attention workgroups, whose K / V requests have ~3 us of
+  // slack before q arrives, the last.  (-DDIHIP_AB_GEMV_FIRST=0: attention first, as rounds 5 / 6a had it.)
+#ifndef DIHIP_AB_GEMV_FIRST
+#define DIHIP_AB_GEMV_FIRST 1
+#endif
+  const int ab = DIHIP_AB_GEMV_FIRST ? bid - p.NG : bid;  // attention workgroup index, if >= 0 and < NA
+  if (ab >= 0 && ab < p.NA) {
     // ------------------------------------------------------------------------------------------------ attention workgroup
     // (It takes no column tiles: its length / span-pointer / K / V loads are dependent round trips whose waits -- loads return
     // in order -- would also wait for a weight share requested before them, and a share requested after them would wait for
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
     ho.rec_bytes = p.rec_bytes;
     ho.parity = p.state[2] & 1u;
     const int ns = p.a.nsplits;
-    span_attn_ft_mfma_body<DIHIP_BF16, DIHIP_KV_NONE, true, true, AW>(p.a, bid % ns, bid / ns, 0, ns, p.a.g, 1, smem, &ho);
+    span_attn_ft_mfma_body<DIHIP_BF16, DIHIP_KV_NONE, true, true, AW>(p.a, ab % ns, ab / ns, 0, ns, p.a.g, 1, smem, &ho);
     return;
   }
 
@@ -238,13 +245,13 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
   const GemvArgs& q = p.q;
   const GemvArgs& o = p.o;
   const int NB = p.NG;
-  const int lb = bid - p.NA;
+  const int lb = DIHIP_AB_GEMV_FIRST ? bid : bid - p.NA;
   const int ob = NB - 1 - lb;  // the o-projection's tiles are dealt in reverse block order: two qkv tiles -> one o tile
   // wave 0's wall-clock stamps (tools/attn_block_trace.py on the `make trace` build); absent from the product build
 #if defined(DIHIP_GEMV_TRACE) && DIHIP_GEMV_TRACE
 #define DIHIP_AB_STAMP(I)                                                              \
   do {                                                                                 \
-    if (p.trace && wave == 0) p.trace[(size_t)bid * 32 + (I)] = wall_clock64();        \
+    if (p.trace && wave == 0) p.trace[(size_t)(p.NA + lb) * 32 + (I)] = wall_clock64(); \
   } while (0)
 #else
 #define DIHIP_AB_STAMP(I) do { } while (0)

@@ -499,6 +499,16 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   // (a request longer than its span table cannot be served: the length is clamped, the new token's store below is skipped)
   const int len = min((int)a.seq_lens[b] + (FUSED ? 1 : a.len_bias), a.span_stride * a.S);
   const int newpos = (int)a.seq_lens[b] + (FUSED ? 1 : a.len_bias) - 1;  // FUSED: position of this step's token
+  // FUSED: the span pointers of this step's token, requested HERE: the workgroup that appends the token needs them microseconds later, and a
+  // pointer load issued there is a dependent round trip (~0.45 us, timeline by split: profiles/r06_attn_block_polls.txt) in front of its tile
+  // loop -- on the path of the one split every merge of the group waits for
+  const void* knp = nullptr;
+  const void* vnp = nullptr;
+  if constexpr (FUSED && !Q8) {
+    const int nsp = min(newpos >> lgS, a.span_stride - 1);
+    knp = ksp[nsp];
+    vnp = vsp[nsp];
+  }
   const int tps = spec ? a.tps_static : (((len + a.nsplits - 1) / a.nsplits + 31) & ~31);
   const int t0 = split * tps;
   const int t1 = min(len, t0 + tps);
@@ -626,6 +636,17 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
     // rows.  (Round 5 / 6 rotated the fragments: ~256 instructions in EVERY wave after the hand-off, and as many again for the K head in
     // the workgroup of the last split -- the one every merge waits for.)  The {cos, sin} pair depends on d = tid % 64 alone: requested
     // before the wait.  V granules (no rotation): one more load for 128 threads.
+    // The V tile of the first pass goes to LDS BEFORE the wait (it does not depend on q; the new token's rows are patched in the loop)
+#ifndef DIHIP_AB_VEARLY
+#define DIHIP_AB_VEARLY 1
+#endif
+    if constexpr (DIHIP_AB_VEARLY) {
+      if (active) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          *reinterpret_cast<u32x4_t*>(smem + wave * (MF_TOK * MF_VPITCH) + (i * 4 + (lane >> 4)) * MF_VPITCH + (lane & 15) * 16) = vreg[i];
+      }
+    }
     const int npair = (a.hpg + 1) * 64;
     constexpr int GP = NW == 8 ? 1 : 2;  // pairs per thread and round: (7 + 1) heads x 64 = 1 x 512 threads = 2 x 256
     const float cs[2] = {cs_row[(tid & 63) * 2], cs_row[(tid & 63) * 2 + 1]};
@@ -772,8 +793,8 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
       if (hc == 0 && wave == 0 && (newpos >> lgS) < a.span_stride) {  // one writer per (request, group): DecoderCacheAppend; a token
         // past the span table is dropped, as kv_append_kernel does (span_cache.hip) -- never written over a cached one
         const int sp = newpos >> lgS, pos = newpos - (sp << lgS);
-        unsigned char* kd = reinterpret_cast<unsigned char*>(const_cast<void*>(ksp[sp])) + ((size_t)grp * a.S + pos) * ROWB;
-        unsigned char* vd = reinterpret_cast<unsigned char*>(const_cast<void*>(vsp[sp])) + ((size_t)grp * a.S + pos) * ROWB;
+        unsigned char* kd = reinterpret_cast<unsigned char*>(const_cast<void*>(knp)) + ((size_t)grp * a.S + pos) * ROWB;
+        unsigned char* vd = reinterpret_cast<unsigned char*>(const_cast<void*>(vnp)) + ((size_t)grp * a.S + pos) * ROWB;
         if (ni == 0) {
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) gstore<u32x4_t>(kd + ks * 64 + kb * 16, knew[ks]);
@@ -792,6 +813,11 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
   // transpose-read addresses: lane p of a 16-lane group supplies row p/4 (token), columns (p%4)*4.. of a 4 x 16 block
   const unsigned char* tr0 = vt + (kb * 4 + (ni >> 2)) * MF_VPITCH + (ni & 3) * 8;
 
+#ifdef DIHIP_AB_VEARLY
+  constexpr bool v_staged = GATHER && DIHIP_AB_VEARLY;  // the first pass's V tile was stored before the wait for q
+#else
+  constexpr bool v_staged = false;
+#endif
   if (active) {
     constexpr int STEP = NW * MF_TOK;
     for (int tb = tb0; tb < t1; tb += STEP) {
@@ -836,7 +862,12 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-              if (base + min(i * 4 + (lane >> 4), last) == newpos) vreg[c * 4 + i] = vnew;
+              if (base + min(i * 4 + (lane >> 4), last) == newpos) {
+                if (v_staged && tb == tb0)  // (the tile sits in LDS already: patch the row)
+                  *reinterpret_cast<u32x4_t*>(vt + ((c * 4 + i) * 4 + (lane >> 4)) * MF_VPITCH + (lane & 15) * 16) = vnew;
+                else
+                  vreg[c * 4 + i] = vnew;
+              }
           }
         }
       }
@@ -857,9 +888,11 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
             vsc[c][rr] = vpar[c][rr >> 1][(rr & 1) * 2 + 1];
           }
       } else {
+        if (!(v_staged && tb == tb0)) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-          *reinterpret_cast<u32x4_t*>(vt + (i * 4 + (lane >> 4)) * MF_VPITCH + (lane & 15) * 16) = vreg[i];
+          for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<u32x4_t*>(vt + (i * 4 + (lane >> 4)) * MF_VPITCH + (lane & 15) * 16) = vreg[i];
+        }
       }
       DIHIP_ATTN_STAMPX(0);  // V tile written to LDS
       load_v(tb + STEP);
@@ -896,6 +929,7 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
         for (int rr = 0; rr < 4; ++rr) mn = fmaxf(mn, sc[c][rr]);
       mn = rows_max(mn);
       const float corr = safe_exp_diff(m, mn);
+      const float m_old = m;
       m = mn;
       float ps = 0.f, cz = 0.f;
       uint32_t pk[4], pl[4];
@@ -928,7 +962,8 @@ __device__ __forceinline__ void span_attn_ft_mfma_body(const AttnArgs& a, const 
         }
       l = l * corr + ps;
       czero = czero * corr + cz;
-      if (__builtin_amdgcn_ballot_w64(corr != 1.f) != 0ull) {
+      // (a first tile -- m_old = -inf in every lane, o still all zero -- skips the 32 multiplications by corr = 0: same bits, o stays +0)
+      if (__builtin_amdgcn_ballot_w64(corr != 1.f && m_old != -INFINITY) != 0ull) {
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt)
 #pragma unroll

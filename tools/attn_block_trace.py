@@ -96,5 +96,11 @@ if "trace" in os.environ.get("DIHIP_LIB_DIR", ""):
                 rel = (col - base) / 100.0
                 print(f"  {i} {nm:32s} {rel.median().item():7.2f} {rel.max().item():7.2f}   (n={col.numel()})")
     show(t[:na][used[:na]][:, :8], names_a, "attention workgroups, wave 0")
+    if os.environ.get("BY_SPLIT"):
+        # per split index (max over the groups): which workgroup is the late one?
+        ta = t[:na].view(g, ns, 32)
+        for col, nm in ((2, "q gathered"), (3, "tiles done"), (4, "records stored"), (6, "merge loads landed"), (7, "end")):
+            v = (ta[:, :, col].max(dim=0).values - base) / 100.0
+            print(f"  by split, {nm:20s}: " + " ".join(f"{x:5.2f}" for x in v.tolist()))
     show(t[:na][used[:na]][:, 24:32], ["V tile in LDS", "scores done", "softmax done", "loop left", "granules swept"], "attention workgroups, wave 0, inside the tile")
     show(t[na:][used[na:]][:, :10], names_g, "GEMV workgroups, wave 0 (stamps 8, 9 come between 3 and 4)")
