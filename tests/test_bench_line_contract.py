@@ -1,4 +1,4 @@
-"""The committed driver-style bench line (profiles/r06z_bench_default.json: the stdout of `python bench.py --gpus 1 --steps 20 --warmup 5`, the
+"""The committed driver-style bench line (profiles/r06zb_bench_default.json: the stdout of `python bench.py --gpus 1 --steps 20 --warmup 5`, the
 driver's own command, on an MI355X) against the contract the driver reads: ONE JSON line under 4 KB with metric / value / unit / n_gpus / steps /
 warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, a `roofline` object for the TIME-dominant
 kernel (+ `roofline_gemv`), a `cpu_baseline` object -- and internally consistent numbers (value = batch / ms_per_step, roofline.frac = achieved /
@@ -17,12 +17,17 @@ def _line():
 
 
 def _stdout():
-    return open(os.path.join(ROOT, "profiles", "r06z_bench_default.json")).read()
+    return open(os.path.join(ROOT, "profiles", "r06zb_bench_default.json")).read()
 
 
 def _headline():
     lines = [l for l in _stdout().splitlines() if l.strip()]
     return json.loads(lines[-1])
+
+
+def _second(d):
+    """the runner-up roofline object, named by what it is (`roofline_attn_block` / `roofline_gemv`)"""
+    return d.get("roofline_attn_block") or d["roofline_gemv"]
 
 
 def test_stdout_is_one_small_line():
@@ -39,13 +44,16 @@ def test_required_fields_and_types():
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] in ("weak", "strong") and d["unit"] == "tokens/s"
     assert d["steps"] == 20 and d["warmup"] == 5                     # the driver's flags
     assert "synthetic" in d["data"] and "workload" in d["config"] and "model" not in d["config"]
-    for r in (d["roofline"], d["roofline_gemv"]):
+    for r in (d["roofline"], _second(d)):
         for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
             assert k in r, k
         assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
         assert r["traffic"] is not None and r["traffic"] >= r["algorithmic_bytes_per_launch"]      # PMC bytes per launch, never below the algorithmic ones
-    # `roofline` is the kernel the step spends most of its time in
-    assert d["roofline"]["share_of_step"] >= d["roofline_gemv"]["share_of_step"] and "decode_attn_block_kernel" in d["roofline"]["kernel"]
+    # `roofline` is the kernel the step spends most of its time in; the runner-up rides along: the two are the fused attention block and the
+    # RMSNorm + gate/up + SwiGLU GEMV (since the second half of round 6 the GEMV leads: the block went from 16.7 to 14.3 us)
+    assert d["roofline"]["share_of_step"] >= _second(d)["share_of_step"]
+    names = d["roofline"]["kernel"] + " | " + _second(d)["kernel"]
+    assert "decode_attn_block_kernel" in names and "gate/up" in names
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -56,7 +64,7 @@ def test_numbers_are_consistent():
     d = _headline()
     batch = d["config"]["global_batch"]
     assert abs(d["value"] - batch * 1e3 / d["ms_per_step"]) <= 2e-3 * d["value"]
-    for r in (d["roofline"], d["roofline_gemv"]):
+    for r in (d["roofline"], _second(d)):
         assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 2e-4
         # achieved = algorithmic bytes per launch / the kernel's average duration on the profiler's clock
         assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_kernel_us_rocprof"] * 1e-6) / 1e9) <= 2e-3 * r["achieved"]
@@ -68,11 +76,12 @@ def test_numbers_are_consistent():
     assert b["count"] == 5 and b["ms_per_step_min"] <= d["ms_per_step"] <= b["ms_per_step_max"]
     # `value` is the C++ operator layer's figure; the Python runner's is beside it
     assert d["runner"].startswith("host") and d["python_runner_tokens_per_s"] > 0
-    # the committed rocprofv3 summary of the same command agrees with the line's kernel durations (profiles/r06z_bench_int4_b1_kernel_stats.csv)
+    # the committed rocprofv3 summary of the same command agrees with the line's kernel durations (profiles/r06zb_bench_int4_b1_kernel_stats.csv)
     import csv
-    rows = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r06z_bench_int4_b1_kernel_stats.csv")))}
+    rows = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r06zb_bench_int4_b1_kernel_stats.csv")))}
     blk = [v for k, v in rows.items() if "decode_attn_block_kernel" in k][0]
-    assert abs(blk - d["roofline"]["avg_kernel_us_rocprof"]) <= 0.05 * blk
+    in_line = [r for r in (d["roofline"], _second(d)) if "decode_attn_block_kernel" in r["kernel"]][0]
+    assert abs(blk - in_line["avg_kernel_us_rocprof"]) <= 0.05 * blk
 
 
 def test_extra_workloads_are_the_named_ones():

@@ -20,7 +20,8 @@ lines = [l for l in open("$OUT/bench_default.json").read().splitlines() if l.str
 print("stdout lines:", len(lines), "bytes of the last:", len(lines[-1]))
 d = json.loads(lines[-1])
 print("int4_b1", d["value"], d["ms_per_step"], d["step_hbm"]["frac_of_peak"], "roofline", d["roofline"]["kernel"][:40], d["roofline"]["frac"], d["roofline"].get("traffic"),
-      "gemv", (d.get("roofline_gemv") or {}).get("frac"), (d.get("roofline_gemv") or {}).get("traffic"), d.get("kernels_us"))
+      "runner-up", (d.get("roofline_attn_block") or d.get("roofline_gemv") or {}).get("kernel", "")[:40], (d.get("roofline_attn_block") or d.get("roofline_gemv") or {}).get("frac"),
+      (d.get("roofline_attn_block") or d.get("roofline_gemv") or {}).get("traffic"), d.get("kernels_us"))
 print("python runner", d.get("python_runner_tokens_per_s"), "cpu_baseline", (d.get("cpu_baseline") or {}).get("value"), "wall_s", d.get("wall_s"))
 for w in d.get("extra", []):
     print(" ", w)
