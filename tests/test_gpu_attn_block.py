@@ -63,11 +63,11 @@ def test_one_launch_equals_the_three_it_replaces(pkg, history):
     assert torch.equal(a.pool.pool, b.pool.pool), "cache spans differ (DecoderCacheAppend inside the launch)"
 
 
-@pytest.mark.parametrize("max_len,history", [(3008, 2990), (2560, 1000), (1100, 1090), (300, 256)])
+@pytest.mark.parametrize("max_len,history", [(3584, 3570), (3008, 2990), (2560, 1000), (1100, 1090), (300, 256)])
 def test_other_split_counts_are_bit_identical_too(pkg, max_len, history):
-    """The split count follows max_len (one split per 128 tokens up to what the CUs hold): 24 splits run the two-phase merge (more than 20
-    splits: the {m, l} chunks first, then the o-chunks eight splits at a time), 20 / 9 / 3 splits their exact-width single batch -- all
-    bit-identical to the chain, whose merge is the same sums in the same order."""
+    """The split count follows max_len (one split per 128 tokens up to what the CUs hold): 28 / 24 / 20 / 9 / 3 splits -- the block's quad-lane
+    merge polls 7 / 6 / 5 / 3 / 1 records per lane; the chain's in-launch merge loads one batch of <= 24 records per lane, and at 28 splits takes
+    the maximum pass first and then batches of 16 -- all bit-identical: every split merge sums in merge_order4 (csrc/span_attn_common.hpp)."""
     from dash_infer_amd import decoder
     model = _model(decoder, seed=13)
     a, b = _session(decoder, model, max_len, False), _session(decoder, model, max_len, True)
