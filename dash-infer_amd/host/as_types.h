@@ -186,6 +186,13 @@ class HIPContext : public DeviceContext {
   // same choice in the Python runner); it is also what lets rank THREADS of one process on one GPU stand in for a node in tests
   void* GetP2PComm() const { return p2p_comm_; }
   void SetP2PComm(void* c) { p2p_comm_ = c; }
+  // The sequence length the decode-step LAUNCH PLANS are made for (split count and split width of the paged attention, the fused attention
+  // block's grid): the running requests' length rounded up to a bucket, never the engine's maximum length -- with an 8192-token engine a
+  // 2048-token request would otherwise be split 64 ways (47 empty splits to merge) and the attention block, which serves up to 28 splits,
+  // would never run.  The model runner moves it (host/model_runner.cpp DecodeSteps: Reshape + a new captured step when the bucket changes);
+  // buffers keep being sized by GetModelMaxLength().  0 / unset: the maximum length.
+  int PlanLength() const { return plan_len_ > 0 ? std::min(plan_len_, max_length_) : max_length_; }
+  void SetPlanLength(int n) { plan_len_ = n; }
 
   // ---- annotations of the fused decode graph (host/fused_ops_hip.cpp; written at Init / Reshape, read at Forward) ----
   void AdvertiseLayoutPref(const std::string& tensor, const ActLayoutPref& p) const { layout_pref_[tensor] = p; }
@@ -248,6 +255,7 @@ class HIPContext : public DeviceContext {
   hipStream_t stream_ = nullptr;
   void* comm_ = nullptr;
   void* p2p_comm_ = nullptr;
+  int plan_len_ = 0;
   mutable std::map<std::string, ActLayoutPref> layout_pref_;
   mutable std::map<std::string, int> act_layout_;
   mutable bool lens_on_device_ = false;

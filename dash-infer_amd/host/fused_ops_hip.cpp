@@ -394,7 +394,7 @@ class DihipGemmAddToOp : public AsOperator {
         a.dt != w_.ft || q.w->n != (a.n + 2 * a.g) * a.h || w_.k != a.n * a.h || w_.n != q.w->k)
       return false;
     if (hip_ctx(ctx_).ActLayout(in_names_[0]) != DIHIP_ACT_ROWMAJOR) return false;
-    return dihip_decode_attn_block_supported(w_.wbits, w_.group, w_.n, a.n, a.g, a.h, ctx_->GetModelMaxLength(), a.kv_mode, DihipDtype(w_.ft), 1) != 0;
+    return dihip_decode_attn_block_supported(w_.wbits, w_.group, w_.n, a.n, a.g, a.h, hip_ctx(ctx_).PlanLength(), a.kv_mode, DihipDtype(w_.ft), 1) != 0;
   }
   AsStatus Reshape(RuntimeContext* rt) override {
     AsTensor* x = tensor_map_->at(in_names_[0]).get();
@@ -456,7 +456,7 @@ class DihipGemmAddToOp : public AsOperator {
       AsTensor* sy = tensor_map_->at("dihip.attn_block_sync").get();
       return FromDihip(dihip_decode_attn_block(s, w_.wbits, (const float*)q.h->GetDataPtr(), h_res, (float*)y->GetDataPtr(), q.gamma, q.eps,
                                                q.w->w->GetDataPtr(), q.w->sz->GetDataPtr(), q.bias, w_.w->GetDataPtr(), w_.sz->GetDataPtr(), a.kd, a.vd,
-                                               a.old_lens, a.rope_tab, w_.n, a.n, a.g, a.h, w_.group, a.span, a.max_spans, ctx_->GetModelMaxLength(),
+                                               a.old_lens, a.rope_tab, w_.n, a.n, a.g, a.h, w_.group, a.span, a.max_spans, hip_ctx(ctx_).PlanLength(),
                                                a.kv_mode, DihipDtype(w_.ft), a.alpha, a.ws->GetDataPtr(), a.ws->GetSizeInByte(), sy->GetDataPtr(),
                                                sy->GetSizeInByte()));
     }
@@ -661,7 +661,7 @@ class DihipRopeSpanAttnOp : public SpanAttnOpHIP, public AttnBlockAttnPart {
       const char* e = getenv("DIHIP_DECODER_ATTN_MERGE");
       return !(e && std::string(e) == "launch");
     }();
-    const int max_len = ctx_->GetModelMaxLength();
+    const int max_len = hip_ctx(ctx_).PlanLength();  // (the launch plan's length: the runner's bucket, <= the engine's maximum)
     if (kv_mode_ == 0) {
       return FromDihip(dihip_span_attn_decode_fused_sync(Stream(), out, qkv, kd, vd, old_lens, (const float*)tensor_map_->at("dihip.rope_table")->GetDataPtr(),
                                                          batch_, n_, g_, h_, span_, max_spans_, max_len, kv_mode_, DihipDtype(dtype_), alpha_,

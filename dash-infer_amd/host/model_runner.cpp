@@ -197,7 +197,23 @@ AsStatus HipModelRunner::PrepareBatch() {
 AsStatus HipModelRunner::DecodeSteps(int n, bool use_graph) {
   if (use_graph && !fused_) return Fail(AsStatus::ALLSPARK_INVALID_CALL_ERROR, "graph replay needs the fused operator list (" + fusion_.why + ")");
   hipStream_t s = ctx_->GetStream();
+  // launch plans follow the running requests' length in buckets (HIPContext::PlanLength), not the engine's maximum length; a new bucket is a
+  // batch change as far as the operators are concerned: ids back to the host, Reshape, a new captured step (once per `bucket` tokens)
+  static const int bucket = [] {
+    const char* e = getenv("DIHIP_PLAN_BUCKET");  // tokens; 0: plans for the maximum length (A/B)
+    return e ? std::max(0, atoi(e)) : 512;
+  }();
   for (int it = 0; it < n; ++it) {
+    if (bucket > 0 && !running_.empty()) {
+      int need = 1;
+      for (const auto& gc : running_) need = std::max(need, gc->step + 1);
+      const int want = std::min(ctx_->GetModelMaxLength(), (need + bucket - 1) / bucket * bucket);
+      if (want != ctx_->PlanLength()) {
+        if (!dirty_) AS_CHECK_STATUS(Sync(nullptr));  // (the next ids are on the device)
+        ctx_->SetPlanLength(want);
+        dirty_ = true;
+      }
+    }
     if (dirty_) AS_CHECK_STATUS(PrepareBatch());
     for (const auto& gc : running_)
       if (gc->step + 1 > ctx_->GetModelMaxLength()) return Fail(AsStatus::ALLSPARK_EXCEED_LIMIT_ERROR, "sequence length limit");

@@ -180,7 +180,7 @@ class SpanAttnOpHIP : public AsOperator {
                                               max_spans_, kv_mode_, DihipDtype(dtype_))));
     return FromDihip(dihip_span_attn_decode_sync(Stream(), tensor_map_->at(out_names_[0])->GetDataPtr(), q_dev_->GetDataPtr(),
                                                  (const void* const*)kd, (const void* const*)vd, lens_d + batch_, batch_, n_, g_, h_,
-                                                 span_, max_spans_, ctx_->GetModelMaxLength(), kv_mode_, DihipDtype(dtype_), alpha_,
+                                                 span_, max_spans_, static_cast<const HIPContext*>(ctx_)->PlanLength(), kv_mode_, DihipDtype(dtype_), alpha_,
                                                  attn_ws_->GetDataPtr(), attn_ws_->GetSizeInByte(), sync_->GetDataPtr(),
                                                  sync_->GetSizeInByte(), DIHIP_ACT_ROWMAJOR));
   }

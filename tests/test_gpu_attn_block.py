@@ -322,3 +322,38 @@ def test_the_eight_wave_attention_form_in_a_process_of_its_own():
     tail = (r.stdout or "")[-1500:] + (r.stderr or "")[-500:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout and "failed" not in r.stdout, tail
+
+
+def test_launch_plans_follow_the_requests_length_not_the_engines_maximum(pkg):
+    """host/model_runner.cpp DecodeSteps + HIPContext::PlanLength: the decode step's launch plans (attention split count / width, the fused block's
+    grid) are made for the running requests' length rounded up to a 512-token bucket, not for the engine's maximum length.  One request of
+    ~1000 tokens decodes across the 1024 bucket boundary in an engine of 4096 tokens and in one of 1536: the plans are the same (1024, then 1536),
+    so logits and ids are BIT-IDENTICAL at every step -- with plans made for the maximum length they could not be (32 against 12 splits) and the
+    4096-token engine could not run the attention block at all (its 32 x 4 attention workgroups leave too few for the GEMVs); eager steps and
+    the re-captured graph agree as well."""
+    from dash_infer_amd import decoder
+    from tests.test_gpu_host_runner import Host
+    model = _model(decoder, seed=37, keep_fp=True)
+    cfg = model.cfg
+    span, steps = 128, 8
+    prompt = [int(t) for t in torch.randint(0, cfg.vocab, (1019,), generator=torch.Generator().manual_seed(2)).tolist()]
+    from dash_infer_amd import ops
+    sup = lambda n: ops.decode_attn_block_supported(model.layers[0].qkv, cfg.hidden, cfg.n_heads, cfg.n_kv, cfg.head_dim, n, "none", torch.bfloat16, 1)
+    assert not sup(4096) and sup(1024) and sup(1536)
+    runs = {}
+    for tag, max_len, graph in (("4096 graph", 4096, True), ("1536 graph", 1536, True), ("4096 eager", 4096, False)):
+        h = Host(model, 1, max_len, span, "none")
+        assert h.report["fused"], h.report["why"]
+        k, v = h.spans()
+        first = h.start(prompt, k, v)
+        out = []
+        for _ in range(steps):    # lengths 1020 .. 1027: the bucket moves from 1024 to 1536 after the fifth step
+            ids = h.steps(1, graph=graph)
+            out.append((h.logits().float().clone(), ids))
+        runs[tag] = (first, out)
+        h.close()
+    for other in ("1536 graph", "4096 eager"):
+        assert runs["4096 graph"][0] == runs[other][0]
+        for t, ((la, ia), (lb, ib)) in enumerate(zip(runs["4096 graph"][1], runs[other][1])):
+            assert ia == ib, f"{other}, step {t}: ids differ"
+            assert torch.equal(la, lb), f"{other}, step {t}: max diff {(la - lb).abs().max().item():.3e}"
