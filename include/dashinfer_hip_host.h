@@ -93,7 +93,10 @@ int dihost_request_adopt(dihost_model_t m, int cached_len, int64_t next_id, int 
                          void* const* v_spans);
 int dihost_request_stop(dihost_model_t m, int index);
 /* n decoder steps of the running batch (Alloc -> Forward per operator per step, csrc/core/model/model.cpp:1248-1325);
- * use_graph != 0: the step is captured once as a hipGraph and replayed (fused list only; the context stream must not be NULL) */
+ * use_graph != 0: the step is captured once as a hipGraph and replayed (fused list only; the context stream must not be NULL).
+ * The step's launch plans (attention split count / width, the fused attention block's grid) are made for the running requests' length
+ * rounded up to DIHIP_PLAN_BUCKET tokens (default 512; 0: for max_len), never for more than max_len: when the bucket moves the runner
+ * synchronises, reshapes the operators and captures the step again (host/model_runner.cpp; HIPContext::PlanLength). */
 int dihost_decode_steps(dihost_model_t m, int n, int use_graph);
 /* synchronises the stream; ids generated by the last step, one per running request -> count (negative AsStatus on error) */
 int dihost_sync_ids(dihost_model_t m, int64_t* ids_host, int capacity);
