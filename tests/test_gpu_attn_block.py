@@ -357,3 +357,21 @@ def test_launch_plans_follow_the_requests_length_not_the_engines_maximum(pkg):
         for t, ((la, ia), (lb, ib)) in enumerate(zip(runs["4096 graph"][1], runs[other][1])):
             assert ia == ib, f"{other}, step {t}: ids differ"
             assert torch.equal(la, lb), f"{other}, step {t}: max diff {(la - lb).abs().max().item():.3e}"
+    # ... and across 3584 tokens, where the bucket's plan (4096: 32 splits) no longer fits the block: the step goes on through the three launches
+    # (Reshape decides anew), captured again -- graph and eager agree bit for bit on both sides of the boundary
+    assert sup(3584) and not sup(4096)
+    prompt = [int(t) for t in torch.randint(0, cfg.vocab, (3580,), generator=torch.Generator().manual_seed(3)).tolist()]
+    runs = {}
+    for graph in (True, False):
+        h = Host(model, 1, 4096, span, "none")
+        k, v = h.spans()
+        first = h.start(prompt, k, v)
+        out = []
+        for _ in range(7):        # lengths 3581 .. 3587
+            ids = h.steps(1, graph=graph)
+            out.append((h.logits().float().clone(), ids))
+        runs[graph] = (first, out)
+        h.close()
+    assert runs[True][0] == runs[False][0]
+    for t, ((la, ia), (lb, ib)) in enumerate(zip(runs[True][1], runs[False][1])):
+        assert ia == ib and torch.equal(la, lb), f"across 3584, step {t}"
