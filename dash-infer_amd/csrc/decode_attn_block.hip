@@ -46,7 +46,23 @@ void span_attn_block_plan(int batch, int n_heads, int n_groups, int max_seq_len,
                           size_t* partial_bytes, int* waves);
 
 constexpr int AB_THREADS = GEMV_THREADS;  // 8 waves
-constexpr int AB_RING = 8;                // 1 KiB weight chunks a wave holds per GEMV: the whole share is resident
+// The weight format of the launch's two GEMVs (both the same): what the stand-alone decode GEMV instantiates for it
+//   WB = 4: int4 with a quantisation group per k-tile of 128 (GPT form: scale and zero applied per chunk)        -- ring of 8 chunks per wave
+//   WB = 8: int8 per channel (InstantQuant, BASELINE configs[1]): k-tiles of 64, ONE (scale, zero) per column, applied at the end of the
+//           wave's k-slice (the MFMA accumulators run through it)                                                  -- ring of 16 chunks per wave
+template <int WB>
+struct AbFmt;
+template <>
+struct AbFmt<4> {
+  static constexpr int KTILE = 128, KSTEPS = 4, RING = 8, EARLY_DEFAULT = 4;
+  static constexpr bool GPT = true;
+};
+template <>
+struct AbFmt<8> {
+  static constexpr int KTILE = 64, KSTEPS = 2, RING = 16, EARLY_DEFAULT = 8;
+  static constexpr bool GPT = false;
+};
+constexpr int AB_RING = AbFmt<4>::RING;   // 1 KiB weight chunks a wave holds per GEMV (int4): the whole share is resident
 #ifndef DIHIP_AB_EARLY
 #define DIHIP_AB_EARLY 4
 #endif
@@ -94,7 +110,7 @@ __device__ __forceinline__ AbShare ab_share(const GemvArgs& g, int bid, int NB, 
   s.total = __builtin_amdgcn_readfirstlane(nvw * s.nk);
   const int t0 = s.u0 + s.wn * NB, tstep = g.WN * NB;
   s.wtile = reinterpret_cast<const char*>(g.w0 + ((size_t)t0 * g.KT + s.k_lo) * 64);
-  s.stile = reinterpret_cast<const char*>(g.sz0 + ((size_t)t0 * g.Gp + s.g_lo) * 16);
+  s.stile = reinterpret_cast<const char*>(g.sz0 + ((size_t)t0 * g.Gp + (g.ktpg < g.KT ? s.g_lo : 0)) * 16);  // (per-channel: the tile's one group)
   s.wstep = (size_t)tstep * g.KT * 1024;
   s.sstep = (size_t)tstep * g.Gp * 64;
   return s;
@@ -111,8 +127,8 @@ struct AbCursor {
   int ikt;
 };
 __device__ __forceinline__ AbCursor ab_cursor(const AbShare& s) { return AbCursor{s.wtile, s.stile, s.wtile, s.stile, s.k_lo}; }
-template <int J0, int J1>
-__device__ __forceinline__ void ab_issue(const GemvArgs& g, const AbShare& s, AbCursor& c, u32x4_t (&wb)[AB_RING], uint32_t (&sb)[AB_RING],
+template <int J0, int J1, int RING, bool GPT>
+__device__ __forceinline__ void ab_issue(const GemvArgs& g, const AbShare& s, AbCursor& c, u32x4_t (&wb)[RING], uint32_t (&sb)[RING],
                                          int lane) {
   const char* const dummy = reinterpret_cast<const char*>(g.w0);
   const uint32_t voff_w = (uint32_t)lane * 16u, voff_s = (uint32_t)(lane & 15) * 4u;
@@ -122,7 +138,7 @@ __device__ __forceinline__ void ab_issue(const GemvArgs& g, const AbShare& s, Ab
     stream_load_b128(wb[j], uniform_ptr(real ? c.iwp : dummy), voff_w);
     stream_load_b32(sb[j], uniform_ptr(real ? c.isp : dummy), voff_s);
     c.iwp += 1024;
-    c.isp += 64;
+    if constexpr (GPT) c.isp += 64;  // (per-channel: every chunk of the tile reads the tile's one scale word)
     if (++c.ikt == s.k_hi) {
       c.ikt = s.k_lo;
       c.wtile += s.wstep;
@@ -133,7 +149,8 @@ __device__ __forceinline__ void ab_issue(const GemvArgs& g, const AbShare& s, Ab
   }
 }
 
-// per-k-tile sums of an 8-element vector of the staged row (the arithmetic and order of gemv_stream_body::stage_vector, KTILE 128)
+// per-k-tile sums of an 8-element vector of the staged row (the arithmetic and order of gemv_stream_body::stage_vector; KTILE 128 or 64)
+template <int KTILE>
 __device__ __forceinline__ void ab_stage_vector(uint16_t* xs, float* xsum_tab, int i, const u32x4_t& v, bool store) {
   if (store) *reinterpret_cast<u32x4_t*>(xs + (size_t)i * 8) = v;
   float e[8];
@@ -146,15 +163,20 @@ __device__ __forceinline__ void ab_stage_vector(uint16_t* xs, float* xsum_tab, i
   sum += dpp_f32<0xB1>(sum);
   sum += dpp_f32<0x4E>(sum);
   sum += dpp_f32<0x141>(sum);
-  sum += dpp_f32<0x140>(sum);
-  if ((i & 15) == 0) xsum_tab[(i >> 4) * 16] = sum;
+  if constexpr (KTILE >= 128) sum += dpp_f32<0x140>(sum);
+  constexpr int VPT = KTILE / 8;  // vectors per k-tile
+  if ((i & (VPT - 1)) == 0) xsum_tab[(i / VPT) * 16] = sum;
 }
 
-// the resident share against the staged row: DIHIP_GEMV_CONSUME of gemv_stream_body for W4, bf16, M = 1, a group per k-tile
-__device__ __forceinline__ void ab_consume(const GemvArgs& g, const AbShare& s, const u32x4_t (&wb)[AB_RING], const uint32_t (&sb)[AB_RING],
-                                           unsigned char* smem, const float* xsum_tab, float* red, int lane) {
-  using EX = ExpandV<4, DIHIP_BF16>;
-  constexpr int KTILE = 128;
+// the resident share against the staged row: DIHIP_GEMV_CONSUME of gemv_stream_body for bf16, M = 1 -- int4 with a group per k-tile (GPT:
+// scale and zero per chunk) or int8 per channel (one scale / zero per column: the MFMA accumulators and the sum of x run through the
+// wave's whole k-slice of a tile, one fma pair at its end)
+template <int WB>
+__device__ __forceinline__ void ab_consume(const GemvArgs& g, const AbShare& s, const u32x4_t (&wb)[AbFmt<WB>::RING],
+                                           const uint32_t (&sb)[AbFmt<WB>::RING], unsigned char* smem, const float* xsum_tab, float* red, int lane) {
+  using EX = ExpandV<WB, DIHIP_BF16>;
+  constexpr int KTILE = AbFmt<WB>::KTILE, KSTEPS = AbFmt<WB>::KSTEPS, RING = AbFmt<WB>::RING;
+  constexpr bool GPT = AbFmt<WB>::GPT;
   const int ni = lane & 15, kb = lane >> 4;
   const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
   uint32_t ex_mask = 0x000F000Fu, ex_magic = 0x43004300u;
@@ -172,38 +194,79 @@ __device__ __forceinline__ void ab_consume(const GemvArgs& g, const AbShare& s, 
   uint32_t xk = xk_reset;
   const float* xt = xsum_tab + s.k_lo * 16;
   float tot = 0.f;
+  if constexpr (GPT) {
 #pragma unroll
-  for (int j = 0; j < AB_RING; ++j) {
-    if (j >= s.total) break;
+    for (int j = 0; j < RING; ++j) {
+      if (j >= s.total) break;
+      f32x4_t g0 = zero4, g1 = zero4;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const u32x4_t af = *reinterpret_cast<const u32x4_t*>(smem + xk + ks * 64);
+        const u32x4_t bf = EX::frag(wb[j], ks, ex_mask, ex_magic);
+        if (ks & 1) g1 = mfma16<DIHIP_BF16>(af, bf, ks == 1 ? zero4 : g1);
+        else g0 = mfma16<DIHIP_BF16>(af, bf, ks == 0 ? zero4 : g0);
+      }
+      xk += xk_step;
+      const bool tile_end = ++ckt == s.k_hi;
+      const float s_ = bf16_bits_to_f32(sb[j] & 0xFFFFu);
+      const float nzp_ = -(bf16_bits_to_f32(sb[j] >> 16) + EX::OFFSET);
+      tot = fmaf(s_, fmaf(nzp_, xt[0], g0[0] + g1[0]), tot);
+      xt += 16;
+      if (tile_end) {
+        float* dst = red + ((size_t)(cv * g.WK + s.wk)) * 16 + ni;
+        if (kb == 0) dst[0] = tot;
+        tot = 0.f;
+        ckt = s.k_lo;
+        cv += g.WN;
+        xk = xk_reset;
+        xt = xsum_tab + s.k_lo * 16;
+      }
+    }
+  } else {
+    // per channel: the accumulators and the sum of x run through the wave's k-slice of a tile (no early exit from the loop: sixteen
+    // slots with a break do not unroll, and a ring indexed at run time lives in scratch)
+    float xacc = 0.f;
     f32x4_t g0 = zero4, g1 = zero4;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const u32x4_t af = *reinterpret_cast<const u32x4_t*>(smem + xk + ks * 64);
-      const u32x4_t bf = EX::frag(wb[j], ks, ex_mask, ex_magic);
-      if (ks & 1) g1 = mfma16<DIHIP_BF16>(af, bf, ks == 1 ? zero4 : g1);
-      else g0 = mfma16<DIHIP_BF16>(af, bf, ks == 0 ? zero4 : g0);
-    }
-    xk += xk_step;
-    const bool tile_end = ++ckt == s.k_hi;
-    const float s_ = bf16_bits_to_f32(sb[j] & 0xFFFFu);
-    const float nzp_ = -(bf16_bits_to_f32(sb[j] >> 16) + EX::OFFSET);
-    tot = fmaf(s_, fmaf(nzp_, xt[0], g0[0] + g1[0]), tot);
-    xt += 16;
-    if (tile_end) {
-      float* dst = red + ((size_t)(cv * g.WK + s.wk)) * 16 + ni;
-      if (kb == 0) dst[0] = tot;
-      tot = 0.f;
-      ckt = s.k_lo;
-      cv += g.WN;
-      xk = xk_reset;
-      xt = xsum_tab + s.k_lo * 16;
+    for (int j = 0; j < RING; ++j) {
+      if (j < s.total) {
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          const u32x4_t af = *reinterpret_cast<const u32x4_t*>(smem + xk + ks * 64);
+          const u32x4_t bf = EX::frag(wb[j], ks, ex_mask, ex_magic);
+          if (ks & 1) g1 = mfma16<DIHIP_BF16>(af, bf, g1);
+          else g0 = mfma16<DIHIP_BF16>(af, bf, g0);
+        }
+        xk += xk_step;
+        xacc += xt[0];
+        xt += 16;
+        if (++ckt == s.k_hi) {  // the group ends with the k-slice
+          const float s_ = bf16_bits_to_f32(sb[j] & 0xFFFFu);
+          const float nzp_ = -(bf16_bits_to_f32(sb[j] >> 16) + EX::OFFSET);
+          tot = fmaf(s_, fmaf(nzp_, xacc, g0[0] + g1[0]), tot);
+          xacc = 0.f;
+          g0 = zero4;
+          g1 = zero4;
+          float* dst = red + ((size_t)(cv * g.WK + s.wk)) * 16 + ni;
+          if (kb == 0) dst[0] = tot;
+          tot = 0.f;
+          ckt = s.k_lo;
+          cv += g.WN;
+          xk = xk_reset;
+          xt = xsum_tab + s.k_lo * 16;
+        }
+      }
     }
   }
 }
 
 // AW = live waves of an attention workgroup (the plan's: 4; 8 with DIHIP_ATTN_WIDE=1 -- the stand-alone kernel's forms, same records)
-template <int AW>
+// WB = weight bits of the two GEMVs (AbFmt)
+template <int AW, int WB = 4>
 __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const AttnBlockArgs p) {
+  constexpr int RING = AbFmt<WB>::RING, KTILE = AbFmt<WB>::KTILE;
+  constexpr bool GPT = AbFmt<WB>::GPT;
+  constexpr int EARLY = WB == 4 ? AB_EARLY : AbFmt<WB>::EARLY_DEFAULT;  // slots of the qkv share requested before the RMSNorm prologue
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int bid = (int)blockIdx.x;
   unsigned tag = p.state[0] + 1u;
@@ -282,13 +345,13 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
     stream_load_plain_b128(eg[j], q.gamma, i * 16u);
   }
   const AbShare sq = ab_share(q, lb, NB, wave);
-  u32x4_t wq[AB_RING], wo[AB_RING];
-  uint32_t sq_[AB_RING], so_[AB_RING];
+  u32x4_t wq[RING], wo[RING];
+  uint32_t sq_[RING], so_[RING];
   // the qkv share in two halves, AB_EARLY slots here and the rest at the RMSNorm's barrier: a CU holds ~32 KiB of outstanding misses,
   // and eight waves asking for 8 KiB each queue the second half of the workgroup behind the first (the stand-alone kernel's 4 + 4
   // ring fill, profiles/r03_gemv_wave_timeline.txt); -DDIHIP_AB_EARLY=8: everything at once (round 5)
   AbCursor cq = ab_cursor(sq);
-  ab_issue<0, AB_EARLY>(q, sq, cq, wq, sq_, lane);
+  ab_issue<0, EARLY, RING, GPT>(q, sq, cq, wq, sq_, lane);
 
   uint16_t* xs = reinterpret_cast<uint16_t*>(smem + 256);
   float* xsum_q = reinterpret_cast<float*>(smem + 256 + gemv_xs_bytes(1, q.RS));
@@ -296,7 +359,7 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
   if (tid < 16) reinterpret_cast<u32x4_t*>(smem)[tid] = u32x4_t{0u, 0u, 0u, 0u};  // zero block (A rows >= M)
 
   // ---- RMSNorm prologue (gemv_stream_body PRO_RMSNORM, one row): rstd = 1/sqrt(mean(x^2)+eps); x_norm = FT((gamma*x)*rstd) ----
-  stream_wait<2 * AB_EARLY>();  // everything older than the ring's first part: the early batch
+  stream_wait<2 * EARLY>();  // everything older than the ring's first part: the early batch
 #pragma unroll
   for (int j = 0; j < 4; ++j) early_landed(ev[j]);
 #pragma unroll
@@ -317,7 +380,7 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
     ss = wave_sum(ss);
     if (lane == 0) red_q[wave] = ss;
     __syncthreads();
-    ab_issue<AB_EARLY, AB_RING>(q, sq, cq, wq, sq_, lane);  // (the rest of the qkv share flies while the row is normalised and staged)
+    ab_issue<EARLY, RING, RING, GPT>(q, sq, cq, wq, sq_, lane);  // (the rest of the qkv share flies while the row is normalised and staged)
     float tot_ss = 0.f;
 #pragma unroll
     for (int w = 0; w < GEMV_WAVES; ++w) tot_ss += red_q[w];
@@ -334,19 +397,19 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
           const float xa = c < 2 ? h0[2 * c] : h1[2 * c - 4], xb = c < 2 ? h0[2 * c + 1] : h1[2 * c - 3];
           v[c] = pack_ft2<DIHIP_BF16>((ga * xa) * rstd, (gb_ * xb) * rstd);
         }
-        ab_stage_vector(xs, xsum_q, i, v, true);
+        ab_stage_vector<KTILE>(xs, xsum_q, i, v, true);
       }
     }
   }
   DIHIP_AB_STAMP(1);  // row normalised and staged
   stream_wait<0>();   // the qkv share has landed
 #pragma unroll
-  for (int j = 0; j < AB_RING; ++j) stream_landed(wq[j], sq_[j]);
+  for (int j = 0; j < RING; ++j) stream_landed(wq[j], sq_[j]);
   __syncthreads();  // the row is staged; the RMS partials in red_q have been read
   DIHIP_AB_STAMP(2);  // qkv share landed
 
   // ---- qkv tiles of this workgroup ----
-  ab_consume(q, sq, wq, sq_, smem, xsum_q, red_q, lane);
+  ab_consume<WB>(q, sq, wq, sq_, smem, xsum_q, red_q, lane);
   __syncthreads();
   if (tid < nq_e && n_q < q.N && !(p.fault && lb == 0)) {  // element e = tid: column tile e / 16 of this workgroup, column e % 16
     float v = 0.f;
@@ -362,10 +425,10 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
   // that it does not queue in front of the qkv shares every workgroup of the launch waits for
   const AbShare so = ab_share(o, ob, NB, wave);
   AbCursor co = ab_cursor(so);
-  ab_issue<0, AB_RING>(o, so, co, wo, so_, lane);
+  ab_issue<0, RING, RING, GPT>(o, so, co, wo, so_, lane);
   stream_wait<0>();
 #pragma unroll
-  for (int j = 0; j < AB_RING; ++j) stream_landed(wo[j], so_[j]);
+  for (int j = 0; j < RING; ++j) stream_landed(wo[j], so_[j]);
 
   float* xsum_o = reinterpret_cast<float*>(smem + 256 + gemv_xs_bytes(1, o.RS));
   float* red_o = xsum_o + (size_t)o.KT * 16;
@@ -389,7 +452,7 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
   }
   DIHIP_AB_STAMP(4);  // every group's first output granule seen
   {
-    const int v_lo = so.k_lo * 16, v_hi = so.k_hi * 16;  // whole 16-lane rows: the per-k-tile sums cross lanes
+    const int v_lo = so.k_lo * (KTILE / 8), v_hi = so.k_hi * (KTILE / 8);  // whole k-tiles (16 or 8 lanes): the per-k-tile sums cross lanes
     const auto og_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out_gran, 0, (int)p.out_gran_bytes, 0x00020000);
     for (int i0 = v_lo; i0 < v_hi; i0 += 64) {
       const int i = i0 + lane, ic = min(i, v_hi - 1);
@@ -408,7 +471,7 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
         __builtin_amdgcn_s_sleep(2);
       }
       const u32x4_t v = {g0[0], g0[2], g1[0], g1[2]};
-      ab_stage_vector(xs, xsum_o, ic, v, i < v_hi);
+      ab_stage_vector<KTILE>(xs, xsum_o, ic, v, i < v_hi);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave reads back what it staged itself: LDS operations of a wave execute in order
@@ -416,7 +479,7 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
   DIHIP_AB_STAMP(5);  // this wave's slice of the attention output swept into LDS
 
   // ---- o-projection tiles: h_out = h_res + attn . Wo ----
-  ab_consume(o, so, wo, so_, smem, xsum_o, red_o, lane);
+  ab_consume<WB>(o, so, wo, so_, smem, xsum_o, red_o, lane);
   __syncthreads();
   DIHIP_AB_STAMP(6);  // o tiles multiplied
   if (tid < no_e && n_o < o.N) {
@@ -452,6 +515,11 @@ static bool ab_grid(int n_heads, int n_groups, int head_size, int hidden, int ns
   *NG = std::min(ncu - *NA, std::min((n_heads + 2 * n_groups) * head_size / 16, hidden / 16));
   return *NG >= 32;
 }
+using AbKernel = void (*)(const AttnBlockArgs);
+static AbKernel ab_kernel(int aw, int wbits) {
+  if (wbits == 8) return aw == 8 ? decode_attn_block_kernel<8, 8> : decode_attn_block_kernel<4, 8>;
+  return aw == 8 ? decode_attn_block_kernel<8, 4> : decode_attn_block_kernel<4, 4>;
+}
 static size_t ab_attn_lds(int aw) { return (size_t)((ft_mfma_smem_bytes(aw) + 15) & ~15) + FT_MFMA_GATHER_IMG_BYTES; }
 static AbLayout ab_layout(int n_heads, int n_groups, int head_size) {
   AbLayout l;
@@ -473,7 +541,9 @@ extern "C" {
 
 int dihip_decode_attn_block_supported(int wbits, int group_size, int hidden, int n_heads, int n_groups, int head_size, int max_seq_len,
                                       int kv_mode, int dtype, int batch) {
-  if (!attn_block_enabled() || batch != 1 || wbits != 4 || dtype != DIHIP_BF16 || kv_mode != DIHIP_KV_NONE || head_size != 128) return 0;
+  if (!attn_block_enabled() || batch != 1 || (wbits != 4 && wbits != 8) || dtype != DIHIP_BF16 || kv_mode != DIHIP_KV_NONE || head_size != 128) return 0;
+  static const bool w8_on = !env_off("DIHIP_ATTN_BLOCK_W8");  // =0: int8 weights keep the three launches (A/B)
+  if (wbits == 8 && !w8_on) return 0;
   if (n_heads <= 0 || n_groups <= 0 || n_groups > 16 || n_heads % n_groups || n_heads / n_groups > MF_HC || hidden <= 0 || hidden > 8192 ||
       hidden % 128 || max_seq_len <= 0)
     return 0;
@@ -487,29 +557,34 @@ int dihip_decode_attn_block_supported(int wbits, int group_size, int hidden, int
   int mu;
   size_t lds;
   const int Nq = (n_heads + 2 * n_groups) * head_size, Ko = n_heads * head_size;
-  if (!gemv_block_plan(4, Nq, hidden, group_size, NG, &gq, &mu, &lds) || gq.ktpg != 1) return 0;
-  if (!gemv_block_plan(4, hidden, Ko, group_size, NG, &go, &mu, &lds) || go.ktpg != 1 || Ko > 8192) return 0;
+  // int4: a quantisation group per k-tile (ktpg == 1); int8: per channel (one group per column: ktpg >= KT) -- the two forms of AbFmt
+  auto fmt_ok = [&](const GemvArgs& g) { return wbits == 4 ? g.ktpg == 1 : g.ktpg >= g.KT; };
+  size_t lds_o = 0;
+  if (!gemv_block_plan(wbits, Nq, hidden, group_size, NG, &gq, &mu, &lds) || !fmt_ok(gq)) return 0;
+  if (!gemv_block_plan(wbits, hidden, Ko, group_size, NG, &go, &mu, &lds_o) || !fmt_ok(go) || Ko > 8192) return 0;
+  lds = std::max(lds, lds_o);
   // every wave's share must fit its ring: ceil(units / WN) * longest k-slice
-  auto fits = [](const GemvArgs& g) {
+  const int ring = wbits == 4 ? AbFmt<4>::RING : AbFmt<8>::RING;
+  auto fits = [ring](const GemvArgs& g) {
     int longest = 0;
-    for (int i = 0; i < g.WK; ++i) longest = std::max(longest, g.kcut[i + 1] - g.kcut[i]);
-    return ((g.upb + g.WN - 1) / g.WN) * longest <= AB_RING;
+    const int gsz = g.ktpg < g.KT ? g.ktpg : 1;
+    for (int i = 0; i < g.WK; ++i) longest = std::max(longest, std::min(g.KT, g.kcut[i + 1] * gsz) - std::min(g.KT, g.kcut[i] * gsz));
+    return ((g.upb + g.WN - 1) / g.WN) * longest <= ring;
   };
   if (!fits(gq) || !fits(go)) return 0;
   // every workgroup of the launch must be RESIDENT at once (they wait for one another): the grid is <= one workgroup per CU by
   // construction; the kernel itself must fit a CU with its LDS at this block size (ask the occupancy calculator, once)
   const size_t lds_need = std::max<size_t>(lds, ab_attn_lds(aw));
-  static std::atomic<int> occ[2] = {{-1}, {-1}};
-  std::atomic<int>& oc = occ[aw == 8];
+  static std::atomic<int> occ[4] = {{-1}, {-1}, {-1}, {-1}};
+  std::atomic<int>& oc = occ[(aw == 8) + 2 * (wbits == 8)];
   int o = oc.load(std::memory_order_relaxed);
   if (o < 0) {
     int nb = 0;
     const size_t lds_q = std::max<size_t>(lds_need, 96 * 1024);  // (asked with a generous LDS figure: the answer is cached for all shapes)
-    const void* kern = aw == 8 ? reinterpret_cast<const void*>(decode_attn_block_kernel<8>) : reinterpret_cast<const void*>(decode_attn_block_kernel<4>);
-    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q) != hipSuccess)
+    const auto kern = ab_kernel(aw, wbits);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q) != hipSuccess)
       nb = 0;
-    else if ((aw == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decode_attn_block_kernel<8>, AB_THREADS, lds_q)
-                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decode_attn_block_kernel<4>, AB_THREADS, lds_q)) != hipSuccess)
+    else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, AB_THREADS, lds_q) != hipSuccess)
       nb = 0;
     (void)hipGetLastError();
     o = nb;
@@ -560,7 +635,7 @@ int dihip_decode_attn_block(void* stream, int wbits, const float* h_in, const fl
   DIHIP_REQUIRE(n_spans_per_request > 0, DIHIP_PARAM_ERROR, "decode_attn_block: invalid parameter");
   DIHIP_REQUIRE(dihip_decode_attn_block_supported(wbits, group_size, hidden, n_heads, n_groups, head_size, max_seq_len, kv_mode, dtype, 1),
                 DIHIP_PARAM_ERROR,
-                "decode_attn_block: configuration not covered (batch 1, bf16, int4 g128, 16-bit cache, head size 128); see _supported");
+                "decode_attn_block: configuration not covered (batch 1, bf16, int4 g128 or int8 per channel, 16-bit cache, head size 128); see _supported");
   DIHIP_REQUIRE(reinterpret_cast<uintptr_t>(h_in) % 16 == 0 && reinterpret_cast<uintptr_t>(gamma) % 16 == 0, DIHIP_PARAM_ERROR,
                 "decode_attn_block: the hidden row and gamma must be 16-byte aligned");
   const AbLayout lay = ab_layout(n_heads, n_groups, head_size);
@@ -575,8 +650,8 @@ int dihip_decode_attn_block(void* stream, int wbits, const float* h_in, const fl
   int mu;
   size_t lds_q, lds_o;
   const int Nq = (n_heads + 2 * n_groups) * head_size, Ko = n_heads * head_size;
-  gemv_block_plan(4, Nq, hidden, group_size, p.NG, &p.q, &mu, &lds_q);
-  gemv_block_plan(4, hidden, Ko, group_size, p.NG, &p.o, &mu, &lds_o);
+  gemv_block_plan(wbits, Nq, hidden, group_size, p.NG, &p.q, &mu, &lds_q);
+  gemv_block_plan(wbits, hidden, Ko, group_size, p.NG, &p.o, &mu, &lds_o);
   p.q.w0 = reinterpret_cast<const u32x4_t*>(qkv_w);
   p.q.sz0 = reinterpret_cast<const uint32_t*>(qkv_sz);
   p.q.x = h_in;
@@ -641,10 +716,10 @@ int dihip_decode_attn_block(void* stream, int wbits, const float* h_in, const fl
   p.trace = debug_trace_buffer((size_t)(p.NA + p.NG) * 32 * sizeof(unsigned long long));
   a.trace = p.trace;  // (the attention body's own stamps: [workgroup][wave][8])
   const size_t lds = std::max<size_t>(std::max(lds_q, lds_o), ab_attn_lds(aw));
-  auto kern = aw == 8 ? decode_attn_block_kernel<8> : decode_attn_block_kernel<4>;
+  const auto kern = ab_kernel(aw, wbits);
   if (lds > 64 * 1024) {
-    static std::atomic<size_t> granted[2] = {{0}, {0}};
-    std::atomic<size_t>& gr = granted[aw == 8];
+    static std::atomic<size_t> granted[4] = {{0}, {0}, {0}, {0}};
+    std::atomic<size_t>& gr = granted[(aw == 8) + 2 * (wbits == 8)];
     if (lds > gr.load(std::memory_order_relaxed)) {
       DIHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                       DIHIP_RUNTIME_ERROR);

@@ -15,9 +15,10 @@ pytestmark = pytest.mark.gpu
 W7B = dict(hidden=3584, layers=2, n_heads=28, n_kv=4, head_dim=128, inter=1024, vocab=2048)
 
 
-def _model(decoder, seed=11, keep_fp=False, **over):
+def _model(decoder, seed=11, keep_fp=False, w8=False, **over):
     cfg = decoder.ModelConfig("attn-block", **{**W7B, **over})
-    return decoder.build_random_model(cfg, decoder.QuantSpec(4, 128, gptq_like_zeros=True), seed=seed, keep_fp=keep_fp)
+    quant = decoder.QuantSpec(8, -1) if w8 else decoder.QuantSpec(4, 128, gptq_like_zeros=True)   # int8 per channel (InstantQuant, BASELINE configs[1]) / int4 g128
+    return decoder.build_random_model(cfg, quant, seed=seed, keep_fp=keep_fp)
 
 
 def _session(decoder, model, max_len, block):
@@ -36,10 +37,11 @@ def _err_word(sess):
     return int(sess.block_sync.view(torch.int32)[1].item())
 
 
+@pytest.mark.parametrize("w8", [False, True], ids=["int4g128", "int8perchannel"])
 @pytest.mark.parametrize("history", [0, 1, 127, 128, 700, 2047])
-def test_one_launch_equals_the_three_it_replaces(pkg, history):
+def test_one_launch_equals_the_three_it_replaces(pkg, history, w8):
     from dash_infer_amd import decoder, ops
-    model = _model(decoder)
+    model = _model(decoder, w8=w8)
     max_len = 2048 + 64
     a, b = _session(decoder, model, max_len, False), _session(decoder, model, max_len, True)
     assert not a.attn_block and b.attn_block, "the fused launch must serve the Qwen2-7B attention widths on this GPU"
@@ -91,10 +93,11 @@ def test_other_split_counts_are_bit_identical_too(pkg, max_len, history):
     assert torch.equal(a.pool.pool, b.pool.pool)
 
 
-def test_decode_steps_through_a_replayed_graph_are_bit_identical(pkg):
+@pytest.mark.parametrize("w8", [False, True], ids=["int4g128", "int8perchannel"])
+def test_decode_steps_through_a_replayed_graph_are_bit_identical(pkg, w8):
     """whole decode steps (2 layers, final norm, lm_head, greedy) through a captured hipGraph, replayed: logits of every step equal"""
     from dash_infer_amd import decoder
-    model = _model(decoder, seed=23)
+    model = _model(decoder, seed=23, w8=w8)
     max_len = 512
     outs = []
     for block in (False, True):
@@ -121,8 +124,8 @@ def test_unsupported_configurations_keep_the_chain(pkg):
     small = decoder.ModelConfig("small", hidden=512, layers=1, n_heads=4, n_kv=2, head_dim=128, inter=1024, vocab=1024)
     m = decoder.build_random_model(small, decoder.QuantSpec(4, 128), seed=3)
     assert not _session(decoder, m, 64, True).attn_block           # fewer column tiles than GEMV workgroups
-    m8 = decoder.build_random_model(decoder.ModelConfig("w8", **W7B), decoder.QuantSpec(8, -1), seed=3)
-    assert not _session(decoder, m8, 256, True).attn_block          # int8 weights: twice the chunks per wave
+    m8 = decoder.build_random_model(decoder.ModelConfig("w8", **W7B), decoder.QuantSpec(8, 128), seed=3)
+    assert not _session(decoder, m8, 256, True).attn_block          # int8 sub-channel: the int8 form of the launch is the per-channel one
     m4 = _model(decoder)
     assert not decoder.DecodeSession(m4, 2, max_len=256, span_len=128).attn_block                     # batch 2
     assert not decoder.DecodeSession(m4, 1, max_len=256, span_len=128, kv_mode="u4").attn_block       # quantised cache
