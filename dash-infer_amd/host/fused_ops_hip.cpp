@@ -130,7 +130,7 @@ int read_group(const OperatorProto& p) {
 
 // ---- the attention half of a batch-1 decode layer as ONE launch (dihip_decode_attn_block, round 5) ---------------------------------
 // DihipNormGemm(qkv) -> DihipRopeSpanAttn -> DihipGemmAddTo(o) stay three operators of the list (context phase, batches, quantised
-// caches run them as before); for ONE request on the 16-bit cache with int4 g128 weights the o-projection operator, which finds
+// caches run them as before); for ONE request on the 16-bit cache with int4 g128 (or int8 per-channel) weights the o-projection operator, which finds
 // the two in front of it through HIPContext::Producer at Init, tells them at Reshape to skip their launches and issues the
 // single launch in its own Forward with what they hand over here.
 struct AttnBlockQkv {

@@ -499,7 +499,7 @@ def span_attn_decode_step(qkv, kv, old_lens_dev, rope_tab, n, g, H, max_len, sca
 
 
 def decode_attn_block_supported(qkv_w, hidden, n, g, H, max_len, kv_mode, dtype, batch):
-    """True when dihip_decode_attn_block serves this configuration (batch 1, bf16, int4 g128, 16-bit cache, ...)."""
+    """True when dihip_decode_attn_block serves this configuration (batch 1, bf16, int4 g128 or int8 per channel, 16-bit cache, ...)."""
     return bool(lib().dihip_decode_attn_block_supported(qkv_w.wbits, qkv_w.group, hidden, n, g, H, max_len, capi.KV[kv_mode],
                                                          capi.BF16 if dtype == torch.bfloat16 else capi.F16, batch))
 

@@ -398,14 +398,15 @@ int dihip_span_attn_decode_step(void* stream, void* output, const void* qkv, voi
  * decode attention launch into the FT [batch, n_heads * 128] output (the second launch of 3b) */
 int dihip_span_attn_merge_partials(void* stream, void* output, const float* partials, int batch, int n_heads,
                                    int nsplits, int dtype);
-/* 3e. The attention half of a batch-1 decode layer as ONE launch (round 5): LayerNormNoBeta -> Gemm[A16W4](qkv, +bias) -> Rotary ->
- * DecOptMQA (DecoderCacheAppend + SpanAttention + reduce) -> Gemm[A16W4](o) -> Binary ADD of the reference graph
+/* 3e. The attention half of a batch-1 decode layer as ONE launch (round 5): LayerNormNoBeta -> Gemm[A16W4 | A16W8](qkv, +bias) -> Rotary ->
+ * DecOptMQA (DecoderCacheAppend + SpanAttention + reduce) -> Gemm[A16W4 | A16W8](o) -> Binary ADD of the reference graph
  * (qwen_v15.py:210-300; the operator loop it shortens: csrc/core/model/model.cpp:1248-1325).  Equivalent, BIT FOR BIT, to
  *     dihip_fused_norm_gemm(h_in ...) ; dihip_span_attn_decode_fused_sync(...) ; dihip_fused_gemm_addto(attn, o ..., h_res, h_out)
  * at M = 1: the qkv and o weights and the K / V tiles are requested in the first microsecond of the launch, the three operators
  * hand their rows over INSIDE it (8-byte {value, tag} granules, agent-scope stores / loads, bounded waits; csrc/decode_attn_block.hip).
  *   h_in   : f32 [hidden] input of the norm (16-byte aligned);  h_res : f32 [hidden] residual or NULL (row-parallel TP ranks > 0);
- *   h_out  : f32 [hidden] (may alias h_in / h_res);  gamma: bf16 [hidden];  qkv_* / o_*: packed int4 weights (section 1), bf16 bias or NULL
+ *   h_out  : f32 [hidden] (may alias h_in / h_res);  gamma: bf16 [hidden];  qkv_* / o_*: packed weights (section 1) -- int4 with a group per 128 k
+ *            (wbits 4, group_size 128) or, since round 6, int8 per channel (wbits 8, group_size -1: InstantQuant, BASELINE configs[1]) --, bf16 bias or NULL
  *   ws     : >= dihip_decode_attn_block_workspace_bytes(...) (no initialisation)
  *   sync   : >= dihip_decode_attn_block_sync_bytes(...), 16-byte aligned, zeroed ONCE by the caller; calls sharing it must be ordered
  *            on one stream (hipGraph replay included: the launch keeps its own epoch in it).  Word 1 of `sync` is an error flag: non-zero
@@ -419,7 +420,8 @@ int dihip_span_attn_merge_partials(void* stream, void* output, const float* part
  *            Since round 6 the split records of the attention live in `sync` too (two buffers alternating by launch: polled by their
  *            consumers, zeroed by them for the launch after next); DIHIP_ATTN_BLOCK_FAULT=1 (tests) makes one workgroup withhold its
  *            rows so that the waits time out.
- * _supported() == 0 (other batch sizes, dtypes, caches, weight formats, too few CUs, DIHIP_ATTN_BLOCK=0): keep the three calls. */
+ * _supported() == 0 (other batch sizes, dtypes, caches, weight formats -- int8 sub-channel, f16 --, too few CUs, DIHIP_ATTN_BLOCK=0,
+ * DIHIP_ATTN_BLOCK_W8=0 for int8): keep the three calls. */
 int dihip_decode_attn_block_supported(int wbits, int group_size, int hidden, int n_heads, int n_groups, int head_size,
                                       int max_seq_len, int kv_mode, int dtype, int batch);
 size_t dihip_decode_attn_block_sync_bytes(int n_heads, int n_groups, int head_size);
