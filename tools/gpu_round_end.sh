@@ -40,7 +40,7 @@ PY
 done
 export TMPDIR=/tmp
 cd /tmp
-for w in int4_b1 int4_b32_u4kv cfg3_rank tp8_rank_7b prefill_2048; do
+for w in int4_b1 int8_b1 int4_b32_u4kv cfg3_rank tp8_rank_7b prefill_2048; do
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -o $w -- python $ROOT/bench.py --workload $w --no-cpu-baseline --no-extra > $OUT/prof_bench_$w.json 2> $OUT/prof_bench_$w.err
   f=$(find $OUT/prof_$w -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" $OUT/bench_${w}_kernel_stats.csv && echo "== $w" && grep dihip $OUT/bench_${w}_kernel_stats.csv | head -8 | cut -d, -f1-4 | cut -c1-170
