@@ -86,6 +86,7 @@ _SIGS = {
     "dihip_decode_attn_block_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "dihip_decode_attn_block_status_async": (i32, [vp, vp, vp]),
     "dihip_decode_attn_block_reset": (i32, [vp, vp, sz]),
+    "dihip_decode_attn_block_prepare": (i32, [vp, vp, sz, i32, i32, i32, i32]),
     "dihip_decode_mlp_block_supported": (i32, [i32] * 6),
     "dihip_decode_mlp_block_sync_bytes": (sz, [i32]),
     "dihip_decode_mlp_block": (i32, [vp, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz]),

@@ -47,20 +47,19 @@ void span_attn_block_plan(int batch, int n_heads, int n_groups, int max_seq_len,
 
 constexpr int AB_THREADS = GEMV_THREADS;  // 8 waves
 // The weight format of the launch's two GEMVs (both the same): what the stand-alone decode GEMV instantiates for it
-//   WB = 4: int4 with a quantisation group per k-tile of 128 (GPT form: scale and zero applied per chunk)        -- ring of 8 chunks per wave
-//   WB = 8: int8 per channel (InstantQuant, BASELINE configs[1]): k-tiles of 64, ONE (scale, zero) per column, applied at the end of the
-//           wave's k-slice (the MFMA accumulators run through it)                                                  -- ring of 16 chunks per wave
+//   WB = 4: int4, k-tiles of 128, ring of 8 chunks per wave;   WB = 8: int8, k-tiles of 64, ring of 16 chunks per wave
+//   GPT   : a quantisation group per k-tile (int4 g128 -- the headline --, int8 g64): scale and zero applied per 1 KiB chunk
+//   !GPT  : groups of several k-tiles (int8 g128, int4 g256 ...) or ONE group per column (per channel: InstantQuant int8, BASELINE
+//           configs[1]; int4 per channel): the MFMA accumulators and the sum of x run through the group, one fma pair at its end
 template <int WB>
 struct AbFmt;
 template <>
 struct AbFmt<4> {
   static constexpr int KTILE = 128, KSTEPS = 4, RING = 8, EARLY_DEFAULT = 4;
-  static constexpr bool GPT = true;
 };
 template <>
 struct AbFmt<8> {
   static constexpr int KTILE = 64, KSTEPS = 2, RING = 16, EARLY_DEFAULT = 8;
-  static constexpr bool GPT = false;
 };
 constexpr int AB_RING = AbFmt<4>::RING;   // 1 KiB weight chunks a wave holds per GEMV (int4): the whole share is resident
 #ifndef DIHIP_AB_EARLY
@@ -125,8 +124,12 @@ struct AbCursor {
   const char* iwp;
   const char* isp;
   int ikt;
+  int igl, gcount;  // !GPT: k-tiles left in the quantisation group / per group (per channel: never expires)
 };
-__device__ __forceinline__ AbCursor ab_cursor(const AbShare& s) { return AbCursor{s.wtile, s.stile, s.wtile, s.stile, s.k_lo}; }
+__device__ __forceinline__ AbCursor ab_cursor(const GemvArgs& g, const AbShare& s) {
+  const int gcount = g.ktpg < g.KT ? g.ktpg : (1 << 30);
+  return AbCursor{s.wtile, s.stile, s.wtile, s.stile, s.k_lo, gcount, gcount};
+}
 template <int J0, int J1, int RING, bool GPT>
 __device__ __forceinline__ void ab_issue(const GemvArgs& g, const AbShare& s, AbCursor& c, u32x4_t (&wb)[RING], uint32_t (&sb)[RING],
                                          int lane) {
@@ -138,9 +141,15 @@ __device__ __forceinline__ void ab_issue(const GemvArgs& g, const AbShare& s, Ab
     stream_load_b128(wb[j], uniform_ptr(real ? c.iwp : dummy), voff_w);
     stream_load_b32(sb[j], uniform_ptr(real ? c.isp : dummy), voff_s);
     c.iwp += 1024;
-    if constexpr (GPT) c.isp += 64;  // (per-channel: every chunk of the tile reads the tile's one scale word)
+    if constexpr (GPT) {
+      c.isp += 64;
+    } else if (--c.igl == 0) {  // (every chunk of a group reads the group's one scale word; per channel: the tile's)
+      c.igl = c.gcount;
+      c.isp += 64;
+    }
     if (++c.ikt == s.k_hi) {
       c.ikt = s.k_lo;
+      c.igl = c.gcount;
       c.wtile += s.wstep;
       c.stile += s.sstep;
       c.iwp = c.wtile;
@@ -171,12 +180,11 @@ __device__ __forceinline__ void ab_stage_vector(uint16_t* xs, float* xsum_tab, i
 // the resident share against the staged row: DIHIP_GEMV_CONSUME of gemv_stream_body for bf16, M = 1 -- int4 with a group per k-tile (GPT:
 // scale and zero per chunk) or int8 per channel (one scale / zero per column: the MFMA accumulators and the sum of x run through the
 // wave's whole k-slice of a tile, one fma pair at its end)
-template <int WB>
+template <int WB, bool GPT>
 __device__ __forceinline__ void ab_consume(const GemvArgs& g, const AbShare& s, const u32x4_t (&wb)[AbFmt<WB>::RING],
                                            const uint32_t (&sb)[AbFmt<WB>::RING], unsigned char* smem, const float* xsum_tab, float* red, int lane) {
   using EX = ExpandV<WB, DIHIP_BF16>;
   constexpr int KTILE = AbFmt<WB>::KTILE, KSTEPS = AbFmt<WB>::KSTEPS, RING = AbFmt<WB>::RING;
-  constexpr bool GPT = AbFmt<WB>::GPT;
   const int ni = lane & 15, kb = lane >> 4;
   const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
   uint32_t ex_mask = 0x000F000Fu, ex_magic = 0x43004300u;
@@ -195,21 +203,19 @@ __device__ __forceinline__ void ab_consume(const GemvArgs& g, const AbShare& s, 
   const float* xt = xsum_tab + s.k_lo * 16;
   float tot = 0.f;
   if constexpr (GPT) {
-#pragma unroll
-    for (int j = 0; j < RING; ++j) {
-      if (j >= s.total) break;
+    auto chunk = [&](const u32x4_t& w, uint32_t sw) {
       f32x4_t g0 = zero4, g1 = zero4;
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
         const u32x4_t af = *reinterpret_cast<const u32x4_t*>(smem + xk + ks * 64);
-        const u32x4_t bf = EX::frag(wb[j], ks, ex_mask, ex_magic);
+        const u32x4_t bf = EX::frag(w, ks, ex_mask, ex_magic);
         if (ks & 1) g1 = mfma16<DIHIP_BF16>(af, bf, ks == 1 ? zero4 : g1);
         else g0 = mfma16<DIHIP_BF16>(af, bf, ks == 0 ? zero4 : g0);
       }
       xk += xk_step;
       const bool tile_end = ++ckt == s.k_hi;
-      const float s_ = bf16_bits_to_f32(sb[j] & 0xFFFFu);
-      const float nzp_ = -(bf16_bits_to_f32(sb[j] >> 16) + EX::OFFSET);
+      const float s_ = bf16_bits_to_f32(sw & 0xFFFFu);
+      const float nzp_ = -(bf16_bits_to_f32(sw >> 16) + EX::OFFSET);
       tot = fmaf(s_, fmaf(nzp_, xt[0], g0[0] + g1[0]), tot);
       xt += 16;
       if (tile_end) {
@@ -221,10 +227,22 @@ __device__ __forceinline__ void ab_consume(const GemvArgs& g, const AbShare& s, 
         xk = xk_reset;
         xt = xsum_tab + s.k_lo * 16;
       }
+    };
+#pragma unroll
+    for (int j = 0; j < RING; ++j) {
+      if constexpr (RING <= 8) {
+        if (j >= s.total) break;
+        chunk(wb[j], sb[j]);
+      } else {  // (sixteen slots with a break do not unroll, and a ring indexed at run time lives in scratch)
+        if (j < s.total) chunk(wb[j], sb[j]);
+      }
     }
   } else {
-    // per channel: the accumulators and the sum of x run through the wave's k-slice of a tile (no early exit from the loop: sixteen
-    // slots with a break do not unroll, and a ring indexed at run time lives in scratch)
+    // groups of several k-tiles / per channel: the accumulators and the sum of x run through the group -- for a column's one group, through
+    // the wave's k-slice of the tile (no early exit from the loop: sixteen slots with a break do not unroll, and a ring indexed at run
+    // time lives in scratch)
+    const int gcount = g.ktpg < g.KT ? g.ktpg : (1 << 30);
+    int cgl = gcount;
     float xacc = 0.f;
     f32x4_t g0 = zero4, g1 = zero4;
 #pragma unroll
@@ -240,13 +258,17 @@ __device__ __forceinline__ void ab_consume(const GemvArgs& g, const AbShare& s, 
         xk += xk_step;
         xacc += xt[0];
         xt += 16;
-        if (++ckt == s.k_hi) {  // the group ends with the k-slice
+        const bool tile_end = ++ckt == s.k_hi;
+        if (--cgl == 0 || tile_end) {  // group end (wave-uniform); a column's one group ends with the k-slice
+          cgl = gcount;
           const float s_ = bf16_bits_to_f32(sb[j] & 0xFFFFu);
           const float nzp_ = -(bf16_bits_to_f32(sb[j] >> 16) + EX::OFFSET);
           tot = fmaf(s_, fmaf(nzp_, xacc, g0[0] + g1[0]), tot);
           xacc = 0.f;
           g0 = zero4;
           g1 = zero4;
+        }
+        if (tile_end) {
           float* dst = red + ((size_t)(cv * g.WK + s.wk)) * 16 + ni;
           if (kb == 0) dst[0] = tot;
           tot = 0.f;
@@ -261,11 +283,10 @@ __device__ __forceinline__ void ab_consume(const GemvArgs& g, const AbShare& s, 
 }
 
 // AW = live waves of an attention workgroup (the plan's: 4; 8 with DIHIP_ATTN_WIDE=1 -- the stand-alone kernel's forms, same records)
-// WB = weight bits of the two GEMVs (AbFmt)
-template <int AW, int WB = 4>
+// WB = weight bits of the two GEMVs, GPT = a quantisation group per k-tile (AbFmt)
+template <int AW, int WB = 4, bool GPT = true>
 __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const AttnBlockArgs p) {
   constexpr int RING = AbFmt<WB>::RING, KTILE = AbFmt<WB>::KTILE;
-  constexpr bool GPT = AbFmt<WB>::GPT;
   constexpr int EARLY = WB == 4 ? AB_EARLY : AbFmt<WB>::EARLY_DEFAULT;  // slots of the qkv share requested before the RMSNorm prologue
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int bid = (int)blockIdx.x;
@@ -350,7 +371,7 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
   // the qkv share in two halves, AB_EARLY slots here and the rest at the RMSNorm's barrier: a CU holds ~32 KiB of outstanding misses,
   // and eight waves asking for 8 KiB each queue the second half of the workgroup behind the first (the stand-alone kernel's 4 + 4
   // ring fill, profiles/r03_gemv_wave_timeline.txt); -DDIHIP_AB_EARLY=8: everything at once (round 5)
-  AbCursor cq = ab_cursor(sq);
+  AbCursor cq = ab_cursor(q, sq);
   ab_issue<0, EARLY, RING, GPT>(q, sq, cq, wq, sq_, lane);
 
   uint16_t* xs = reinterpret_cast<uint16_t*>(smem + 256);
@@ -409,7 +430,7 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
   DIHIP_AB_STAMP(2);  // qkv share landed
 
   // ---- qkv tiles of this workgroup ----
-  ab_consume<WB>(q, sq, wq, sq_, smem, xsum_q, red_q, lane);
+  ab_consume<WB, GPT>(q, sq, wq, sq_, smem, xsum_q, red_q, lane);
   __syncthreads();
   if (tid < nq_e && n_q < q.N && !(p.fault && lb == 0)) {  // element e = tid: column tile e / 16 of this workgroup, column e % 16
     float v = 0.f;
@@ -424,7 +445,7 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
   // the o-projection's share: requested only now -- nothing on this workgroup's path needs it for several microseconds -- so
   // that it does not queue in front of the qkv shares every workgroup of the launch waits for
   const AbShare so = ab_share(o, ob, NB, wave);
-  AbCursor co = ab_cursor(so);
+  AbCursor co = ab_cursor(o, so);
   ab_issue<0, RING, RING, GPT>(o, so, co, wo, so_, lane);
   stream_wait<0>();
 #pragma unroll
@@ -479,7 +500,7 @@ __global__ __launch_bounds__(AB_THREADS) void decode_attn_block_kernel(const Att
   DIHIP_AB_STAMP(5);  // this wave's slice of the attention output swept into LDS
 
   // ---- o-projection tiles: h_out = h_res + attn . Wo ----
-  ab_consume<WB>(o, so, wo, so_, smem, xsum_o, red_o, lane);
+  ab_consume<WB, GPT>(o, so, wo, so_, smem, xsum_o, red_o, lane);
   __syncthreads();
   DIHIP_AB_STAMP(6);  // o tiles multiplied
   if (tid < no_e && n_o < o.N) {
@@ -516,9 +537,13 @@ static bool ab_grid(int n_heads, int n_groups, int head_size, int hidden, int ns
   return *NG >= 32;
 }
 using AbKernel = void (*)(const AttnBlockArgs);
-static AbKernel ab_kernel(int aw, int wbits) {
-  if (wbits == 8) return aw == 8 ? decode_attn_block_kernel<8, 8> : decode_attn_block_kernel<4, 8>;
-  return aw == 8 ? decode_attn_block_kernel<8, 4> : decode_attn_block_kernel<4, 4>;
+static AbKernel ab_kernel(int aw, int wbits, bool gpt) {
+  if (wbits == 8) {
+    if (gpt) return aw == 8 ? decode_attn_block_kernel<8, 8, true> : decode_attn_block_kernel<4, 8, true>;
+    return aw == 8 ? decode_attn_block_kernel<8, 8, false> : decode_attn_block_kernel<4, 8, false>;
+  }
+  if (gpt) return aw == 8 ? decode_attn_block_kernel<8, 4, true> : decode_attn_block_kernel<4, 4, true>;
+  return aw == 8 ? decode_attn_block_kernel<8, 4, false> : decode_attn_block_kernel<4, 4, false>;
 }
 static size_t ab_attn_lds(int aw) { return (size_t)((ft_mfma_smem_bytes(aw) + 15) & ~15) + FT_MFMA_GATHER_IMG_BYTES; }
 static AbLayout ab_layout(int n_heads, int n_groups, int head_size) {
@@ -533,11 +558,51 @@ static AbLayout ab_layout(int n_heads, int n_groups, int head_size) {
   return l;
 }
 
+// The record layout (heads x splits) the polled records of `sync` were last used with.  A change clears the record region on `stream`
+// -- eagerly: a memset captured into a hipGraph would run at every replay, and was observed to corrupt replayed steps (round 6: the
+// C++ runner's first captured step after a layout change, tests/test_gpu_attn_block.py::test_launch_plans_...); under capture a change
+// is an error that names the call to make first.
+static int ab_sync_layout(hipStream_t stream, const void* sync, const AbLayout& lay, int n_heads, int ns) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, unsigned> last_layout;
+  const unsigned key = ((unsigned)n_heads << 16) | (unsigned)ns;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = last_layout.find(sync);
+    if (it == last_layout.end()) {  // first use: the caller zeroed the buffer (contract)
+      last_layout[sync] = key;
+      return DIHIP_SUCCESS;
+    }
+    if (it->second == key) return DIHIP_SUCCESS;
+  }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) cs = hipStreamCaptureStatusNone;
+  (void)hipGetLastError();
+  DIHIP_REQUIRE(cs == hipStreamCaptureStatusNone, DIHIP_RUNTIME_ERROR,
+                "decode_attn_block: the split plan of this sync buffer changed inside a stream capture -- call dihip_decode_attn_block_prepare() "
+                "(or run one launch) outside the capture first");
+  char* sb = const_cast<char*>(reinterpret_cast<const char*>(sync));
+  DIHIP_CHECK_HIP(hipMemsetAsync(sb + lay.rec, 0, 2 * lay.rec_bytes, stream), DIHIP_RUNTIME_ERROR);
+  std::lock_guard<std::mutex> lk(mu);
+  last_layout[sync] = key;
+  return DIHIP_SUCCESS;
+}
+
 }  // namespace dihip
 
 using namespace dihip;
 
 extern "C" {
+
+int dihip_decode_attn_block_prepare(void* stream, void* sync, size_t sync_bytes, int n_heads, int n_groups, int head_size, int max_seq_len) {
+  DIHIP_REQUIRE(sync && n_heads > 0 && n_groups > 0 && n_heads % n_groups == 0 && max_seq_len > 0, DIHIP_PARAM_ERROR, "decode_attn_block_prepare: bad argument");
+  const AbLayout lay = ab_layout(n_heads, n_groups, head_size);
+  DIHIP_REQUIRE(sync_bytes >= lay.total, DIHIP_MEMORY_ERROR, "decode_attn_block_prepare: sync buffer too small (%zu < %zu)", sync_bytes, lay.total);
+  int ns, nc, tps, aw;
+  size_t pb;
+  span_attn_block_plan(1, n_heads, n_groups, max_seq_len, &ns, &nc, &tps, &pb, &aw);
+  return ab_sync_layout(reinterpret_cast<hipStream_t>(stream), sync, lay, n_heads, ns);
+}
 
 int dihip_decode_attn_block_supported(int wbits, int group_size, int hidden, int n_heads, int n_groups, int head_size, int max_seq_len,
                                       int kv_mode, int dtype, int batch) {
@@ -557,11 +622,11 @@ int dihip_decode_attn_block_supported(int wbits, int group_size, int hidden, int
   int mu;
   size_t lds;
   const int Nq = (n_heads + 2 * n_groups) * head_size, Ko = n_heads * head_size;
-  // int4: a quantisation group per k-tile (ktpg == 1); int8: per channel (one group per column: ktpg >= KT) -- the two forms of AbFmt
-  auto fmt_ok = [&](const GemvArgs& g) { return wbits == 4 ? g.ktpg == 1 : g.ktpg >= g.KT; };
+  // a group per k-tile (GPT form), groups of whole k-tiles, or one group per column -- both matrices the same form
+  auto fmt_ok = [&](const GemvArgs& g) { return g.ktpg >= 1; };
   size_t lds_o = 0;
   if (!gemv_block_plan(wbits, Nq, hidden, group_size, NG, &gq, &mu, &lds) || !fmt_ok(gq)) return 0;
-  if (!gemv_block_plan(wbits, hidden, Ko, group_size, NG, &go, &mu, &lds_o) || !fmt_ok(go) || Ko > 8192) return 0;
+  if (!gemv_block_plan(wbits, hidden, Ko, group_size, NG, &go, &mu, &lds_o) || !fmt_ok(go) || Ko > 8192 || (gq.ktpg == 1) != (go.ktpg == 1)) return 0;
   lds = std::max(lds, lds_o);
   // every wave's share must fit its ring: ceil(units / WN) * longest k-slice
   const int ring = wbits == 4 ? AbFmt<4>::RING : AbFmt<8>::RING;
@@ -576,12 +641,12 @@ int dihip_decode_attn_block_supported(int wbits, int group_size, int hidden, int
   // construction; the kernel itself must fit a CU with its LDS at this block size (ask the occupancy calculator, once)
   const size_t lds_need = std::max<size_t>(lds, ab_attn_lds(aw));
   static std::atomic<int> occ[4] = {{-1}, {-1}, {-1}, {-1}};
-  std::atomic<int>& oc = occ[(aw == 8) + 2 * (wbits == 8)];
+  std::atomic<int>& oc = occ[(aw == 8) + 2 * (wbits == 8)];  // (the GPT and the group forms of a width differ in a few VALU instructions: one answer)
   int o = oc.load(std::memory_order_relaxed);
   if (o < 0) {
     int nb = 0;
     const size_t lds_q = std::max<size_t>(lds_need, 96 * 1024);  // (asked with a generous LDS figure: the answer is cached for all shapes)
-    const auto kern = ab_kernel(aw, wbits);
+    const auto kern = ab_kernel(aw, wbits, gq.ktpg == 1);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q) != hipSuccess)
       nb = 0;
     else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, AB_THREADS, lds_q) != hipSuccess)
@@ -635,7 +700,7 @@ int dihip_decode_attn_block(void* stream, int wbits, const float* h_in, const fl
   DIHIP_REQUIRE(n_spans_per_request > 0, DIHIP_PARAM_ERROR, "decode_attn_block: invalid parameter");
   DIHIP_REQUIRE(dihip_decode_attn_block_supported(wbits, group_size, hidden, n_heads, n_groups, head_size, max_seq_len, kv_mode, dtype, 1),
                 DIHIP_PARAM_ERROR,
-                "decode_attn_block: configuration not covered (batch 1, bf16, int4 g128 or int8 per channel, 16-bit cache, head size 128); see _supported");
+                "decode_attn_block: configuration not covered (batch 1, bf16, int4 / int8 weights, 16-bit cache, head size 128); see _supported");
   DIHIP_REQUIRE(reinterpret_cast<uintptr_t>(h_in) % 16 == 0 && reinterpret_cast<uintptr_t>(gamma) % 16 == 0, DIHIP_PARAM_ERROR,
                 "decode_attn_block: the hidden row and gamma must be 16-byte aligned");
   const AbLayout lay = ab_layout(n_heads, n_groups, head_size);
@@ -673,19 +738,10 @@ int dihip_decode_attn_block(void* stream, int wbits, const float* h_in, const fl
     p.rec = reinterpret_cast<unsigned*>(sb + lay.rec);
     p.rec_bytes = (unsigned)((size_t)n_heads * ns * ATTN_PSTRIDE * sizeof(float));
     // the record buffers are zero between launches only where the LAST launch's owners zeroed them: a launch with another record
-    // layout on the same sync buffer (another split count) starts from a cleared region (a memset node when captured; rare)
-    static std::mutex mu;
-    static std::unordered_map<const void*, unsigned> last_layout;
-    const unsigned key = ((unsigned)n_heads << 16) | (unsigned)ns;
-    bool clear = false;
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      auto it = last_layout.find(sync);
-      clear = it != last_layout.end() && it->second != key;
-      last_layout[sync] = key;
-    }
-    if (clear)
-      DIHIP_CHECK_HIP(hipMemsetAsync(sb + lay.rec, 0, 2 * lay.rec_bytes, reinterpret_cast<hipStream_t>(stream)), DIHIP_RUNTIME_ERROR);
+    // layout on the same sync buffer (another split count) starts from a cleared region -- ab_sync_layout, NEVER inside a stream
+    // capture (see dihip_decode_attn_block_prepare)
+    const int st = ab_sync_layout(reinterpret_cast<hipStream_t>(stream), sync, lay, n_heads, ns);
+    if (st != DIHIP_SUCCESS) return st;
   }
   static const unsigned spin_limit = (unsigned)std::max(1024, env_int("DIHIP_ATTN_BLOCK_SPINS", 1 << 18));
   p.spin_limit = spin_limit;
@@ -716,10 +772,11 @@ int dihip_decode_attn_block(void* stream, int wbits, const float* h_in, const fl
   p.trace = debug_trace_buffer((size_t)(p.NA + p.NG) * 32 * sizeof(unsigned long long));
   a.trace = p.trace;  // (the attention body's own stamps: [workgroup][wave][8])
   const size_t lds = std::max<size_t>(std::max(lds_q, lds_o), ab_attn_lds(aw));
-  const auto kern = ab_kernel(aw, wbits);
+  const bool gpt = p.q.ktpg == 1;
+  const auto kern = ab_kernel(aw, wbits, gpt);
   if (lds > 64 * 1024) {
-    static std::atomic<size_t> granted[4] = {{0}, {0}, {0}, {0}};
-    std::atomic<size_t>& gr = granted[(aw == 8) + 2 * (wbits == 8)];
+    static std::atomic<size_t> granted[8] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
+    std::atomic<size_t>& gr = granted[(aw == 8) + 2 * (wbits == 8) + 4 * gpt];
     if (lds > gr.load(std::memory_order_relaxed)) {
       DIHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                       DIHIP_RUNTIME_ERROR);

@@ -438,6 +438,10 @@ class DihipGemmAddToOp : public AsOperator {
       }
       const size_t wb = dihip_decode_attn_block_workspace_bytes(a.n, a.g, a.h, ctx_->GetModelMaxLength());
       if (a.ws->GetSizeInByte() < wb) AS_CHECK_STATUS(a.ws->SetShape(Shape{(int64_t)wb}));
+      // the split plan of this step's launches (HIPContext::PlanLength) may differ from the one the records of the sync buffer were last
+      // used with: the record region is cleared HERE, outside the captured step (dihip_decode_attn_block_prepare)
+      AsTensor* sy = tensor_map_->at("dihip.attn_block_sync").get();
+      AS_CHECK_STATUS(FromDihip(dihip_decode_attn_block_prepare(s, sy->GetDataPtr(), sy->GetSizeInByte(), a.n, a.g, a.h, hip_ctx(ctx_).PlanLength())));
     }
     return grow_workspace(tensor_map_, dihip_gemm_lowp_workspace_bytes(w_.wbits, std::max(m_, 1), w_.n, w_.k, w_.group));
   }

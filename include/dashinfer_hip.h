@@ -406,7 +406,8 @@ int dihip_span_attn_merge_partials(void* stream, void* output, const float* part
  * hand their rows over INSIDE it (8-byte {value, tag} granules, agent-scope stores / loads, bounded waits; csrc/decode_attn_block.hip).
  *   h_in   : f32 [hidden] input of the norm (16-byte aligned);  h_res : f32 [hidden] residual or NULL (row-parallel TP ranks > 0);
  *   h_out  : f32 [hidden] (may alias h_in / h_res);  gamma: bf16 [hidden];  qkv_* / o_*: packed weights (section 1) -- int4 with a group per 128 k
- *            (wbits 4, group_size 128) or, since round 6, int8 per channel (wbits 8, group_size -1: InstantQuant, BASELINE configs[1]) --, bf16 bias or NULL
+ *            (wbits 4, group_size 128: the headline) and, since round 6, int8 per channel (wbits 8, group_size -1: InstantQuant, BASELINE
+ *            configs[1]) and the other forms the decode GEMV streams (int8 g64 / g128, int4 per channel / g256) --, bf16 bias or NULL
  *   ws     : >= dihip_decode_attn_block_workspace_bytes(...) (no initialisation)
  *   sync   : >= dihip_decode_attn_block_sync_bytes(...), 16-byte aligned, zeroed ONCE by the caller; calls sharing it must be ordered
  *            on one stream (hipGraph replay included: the launch keeps its own epoch in it).  Word 1 of `sync` is an error flag: non-zero
@@ -420,7 +421,7 @@ int dihip_span_attn_merge_partials(void* stream, void* output, const float* part
  *            Since round 6 the split records of the attention live in `sync` too (two buffers alternating by launch: polled by their
  *            consumers, zeroed by them for the launch after next); DIHIP_ATTN_BLOCK_FAULT=1 (tests) makes one workgroup withhold its
  *            rows so that the waits time out.
- * _supported() == 0 (other batch sizes, dtypes, caches, weight formats -- int8 sub-channel, f16 --, too few CUs, DIHIP_ATTN_BLOCK=0,
+ * _supported() == 0 (other batch sizes, dtypes -- f16 --, caches, too few CUs, DIHIP_ATTN_BLOCK=0,
  * DIHIP_ATTN_BLOCK_W8=0 for int8): keep the three calls. */
 int dihip_decode_attn_block_supported(int wbits, int group_size, int hidden, int n_heads, int n_groups, int head_size,
                                       int max_seq_len, int kv_mode, int dtype, int batch);
@@ -428,6 +429,12 @@ size_t dihip_decode_attn_block_sync_bytes(int n_heads, int n_groups, int head_si
 size_t dihip_decode_attn_block_workspace_bytes(int n_heads, int n_groups, int head_size, int max_seq_len);
 int dihip_decode_attn_block_status_async(void* stream, const void* sync, unsigned* host_word);
 int dihip_decode_attn_block_reset(void* stream, void* sync, size_t sync_bytes);
+/* A sync buffer remembers the split plan its polled records were last used with; a launch with ANOTHER plan (max_seq_len moved to another
+ * split count) first clears the record region -- on the stream, eagerly.  Inside a stream capture that clear must not happen (a captured
+ * memset would run at every replay): a caller that captures its step calls _prepare() with the plan's max_seq_len OUTSIDE the capture
+ * whenever the plan may have changed (host/fused_ops_hip.cpp does at Reshape); a launch that finds the plan changed under capture fails with
+ * DIHIP_RUNTIME_ERROR.  No-op when nothing changed. */
+int dihip_decode_attn_block_prepare(void* stream, void* sync, size_t sync_bytes, int n_heads, int n_groups, int head_size, int max_seq_len);
 int dihip_decode_attn_block(void* stream, int wbits, const float* h_in, const float* h_res, float* h_out, const void* gamma,
                             float eps, const void* qkv_w, const void* qkv_sz, const void* qkv_bias, const void* o_w,
                             const void* o_sz, void* const* k_span_array, void* const* v_span_array,

@@ -15,9 +15,18 @@ pytestmark = pytest.mark.gpu
 W7B = dict(hidden=3584, layers=2, n_heads=28, n_kv=4, head_dim=128, inter=1024, vocab=2048)
 
 
-def _model(decoder, seed=11, keep_fp=False, w8=False, **over):
+# the weight forms of the launch: (wbits, group) -- int4 g128 (the headline: a group per k-tile), int8 per channel (InstantQuant, BASELINE
+# configs[1]), and the other forms of the stand-alone decode GEMV: int8 g64 (a group per k-tile of 64), int8 g128 (two k-tiles per group),
+# int4 per channel, int4 g256
+FORMS = {"int4g128": (4, 128), "int8perchannel": (8, -1), "int8g64": (8, 64), "int8g128": (8, 128), "int4perchannel": (4, -1), "int4g256": (4, 256)}
+
+
+def _model(decoder, seed=11, keep_fp=False, w8=False, form=None, **over):
     cfg = decoder.ModelConfig("attn-block", **{**W7B, **over})
-    quant = decoder.QuantSpec(8, -1) if w8 else decoder.QuantSpec(4, 128, gptq_like_zeros=True)   # int8 per channel (InstantQuant, BASELINE configs[1]) / int4 g128
+    if form is None:
+        form = "int8perchannel" if w8 else "int4g128"
+    wbits, group = FORMS[form]
+    quant = decoder.QuantSpec(wbits, group, gptq_like_zeros=True) if form == "int4g128" else decoder.QuantSpec(wbits, group)
     return decoder.build_random_model(cfg, quant, seed=seed, keep_fp=keep_fp)
 
 
@@ -37,11 +46,11 @@ def _err_word(sess):
     return int(sess.block_sync.view(torch.int32)[1].item())
 
 
-@pytest.mark.parametrize("w8", [False, True], ids=["int4g128", "int8perchannel"])
-@pytest.mark.parametrize("history", [0, 1, 127, 128, 700, 2047])
-def test_one_launch_equals_the_three_it_replaces(pkg, history, w8):
+@pytest.mark.parametrize("form,history", [(f, h) for f in ("int4g128", "int8perchannel") for h in (0, 1, 127, 128, 700, 2047)] +
+                         [(f, h) for f in ("int8g64", "int8g128", "int4perchannel", "int4g256") for h in (1, 700, 2047)])
+def test_one_launch_equals_the_three_it_replaces(pkg, history, form):
     from dash_infer_amd import decoder, ops
-    model = _model(decoder, w8=w8)
+    model = _model(decoder, form=form)
     max_len = 2048 + 64
     a, b = _session(decoder, model, max_len, False), _session(decoder, model, max_len, True)
     assert not a.attn_block and b.attn_block, "the fused launch must serve the Qwen2-7B attention widths on this GPU"
@@ -124,8 +133,6 @@ def test_unsupported_configurations_keep_the_chain(pkg):
     small = decoder.ModelConfig("small", hidden=512, layers=1, n_heads=4, n_kv=2, head_dim=128, inter=1024, vocab=1024)
     m = decoder.build_random_model(small, decoder.QuantSpec(4, 128), seed=3)
     assert not _session(decoder, m, 64, True).attn_block           # fewer column tiles than GEMV workgroups
-    m8 = decoder.build_random_model(decoder.ModelConfig("w8", **W7B), decoder.QuantSpec(8, 128), seed=3)
-    assert not _session(decoder, m8, 256, True).attn_block          # int8 sub-channel: the int8 form of the launch is the per-channel one
     m4 = _model(decoder)
     assert not decoder.DecodeSession(m4, 2, max_len=256, span_len=128).attn_block                     # batch 2
     assert not decoder.DecodeSession(m4, 1, max_len=256, span_len=128, kv_mode="u4").attn_block       # quantised cache
@@ -365,7 +372,7 @@ def test_launch_plans_follow_the_requests_length_not_the_engines_maximum(pkg):
     assert sup(3584) and not sup(4096)
     prompt = [int(t) for t in torch.randint(0, cfg.vocab, (3580,), generator=torch.Generator().manual_seed(3)).tolist()]
     runs = {}
-    for graph in (True, False):
+    for graph in (True, False):   # (graph first: its first captured step meets a sync buffer whose address an earlier runner used with another plan)
         h = Host(model, 1, 4096, span, "none")
         k, v = h.spans()
         first = h.start(prompt, k, v)
@@ -378,3 +385,51 @@ def test_launch_plans_follow_the_requests_length_not_the_engines_maximum(pkg):
     assert runs[True][0] == runs[False][0]
     for t, ((la, ia), (lb, ib)) in enumerate(zip(runs[True][1], runs[False][1])):
         assert ia == ib and torch.equal(la, lb), f"across 3584, step {t}"
+
+
+def test_a_changed_split_plan_is_cleared_outside_a_capture_or_refused_inside(pkg):
+    """The polled records of a sync buffer are laid out per split plan; a launch with another plan clears the record region first -- eagerly.
+    Inside a stream capture it must not (a memset captured into the graph ran at every replay and corrupted replayed steps: round 6): the
+    launch fails and names dihip_decode_attn_block_prepare(), which the capturing caller runs outside the capture (the C++ operator layer
+    does at Reshape); after it the captured launch is the eager one, bit for bit."""
+    from dash_infer_amd import decoder, ops
+    from dash_infer_amd.capi import lib
+    model = _model(decoder, seed=41)
+    a, b = _session(decoder, model, 1100, False), _session(decoder, model, 1100, True)
+    for s in (a, b):
+        s.fill_cache_random(200, seed=6)
+        s.set_state([5], [200])
+    b.pool.pool.copy_(a.pool.pool)
+    h0 = torch.randn(1, model.cfg.hidden, generator=torch.Generator(device="cuda").manual_seed(9), device="cuda", dtype=torch.float32)
+    b.max_len = 300          # a first launch with the 3-split plan of a 300-token engine on this sync buffer ...
+    b.h.copy_(h0)
+    b.run_single_layer(0)
+    torch.cuda.synchronize()
+    b.max_len = 1100         # ... then the 9-split plan, under capture: refused
+    b.set_state([5], [200])
+    b.pool.pool.copy_(a.pool.pool)
+    st = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(Exception) as e:
+        with torch.cuda.stream(st):
+            b.h.copy_(h0)
+            with torch.cuda.graph(g, stream=st):
+                b.run_single_layer(0)
+    assert "prepare" in str(e.value)
+    torch.cuda.synchronize()
+    cfg = model.cfg
+    ops.check(lib().dihip_decode_attn_block_prepare(ops.cur_stream(), ops.ptr(b.block_sync), b.block_sync.numel(), cfg.n_heads, cfg.n_kv, cfg.head_dim, 1100),
+              "prepare")
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        b.h.copy_(h0)
+        with torch.cuda.graph(g, stream=st):
+            b.run_single_layer(0)
+        b.h.copy_(h0)
+        g.replay()
+    torch.cuda.synchronize()
+    a.h.copy_(h0)
+    a.run_single_layer(0)
+    torch.cuda.synchronize()
+    assert _err_word(b) == 0
+    assert torch.equal(a.h, b.h), f"max diff {(a.h - b.h).abs().max().item():.3e}"
