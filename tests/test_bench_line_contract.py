@@ -1,4 +1,4 @@
-"""The committed driver-style bench line (profiles/r06ze_bench_default.json: the stdout of `python bench.py --gpus 1 --steps 20 --warmup 5`, the
+"""The committed driver-style bench line (profiles/r06zf_bench_default.json: the stdout of `python bench.py --gpus 1 --steps 20 --warmup 5`, the
 driver's own command, on an MI355X) against the contract the driver reads: ONE JSON line under 4 KB with metric / value / unit / n_gpus / steps /
 warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, a `roofline` object for the TIME-dominant
 kernel (+ `roofline_gemv`), a `cpu_baseline` object -- and internally consistent numbers (value = batch / ms_per_step, roofline.frac = achieved /
@@ -17,7 +17,7 @@ def _line():
 
 
 def _stdout():
-    return open(os.path.join(ROOT, "profiles", "r06ze_bench_default.json")).read()
+    return open(os.path.join(ROOT, "profiles", "r06zf_bench_default.json")).read()
 
 
 def _headline():
@@ -76,9 +76,9 @@ def test_numbers_are_consistent():
     assert b["count"] == 5 and b["ms_per_step_min"] <= d["ms_per_step"] <= b["ms_per_step_max"]
     # `value` is the C++ operator layer's figure; the Python runner's is beside it
     assert d["runner"].startswith("host") and d["python_runner_tokens_per_s"] > 0
-    # the committed rocprofv3 summary of the same command agrees with the line's kernel durations (profiles/r06ze_bench_int4_b1_kernel_stats.csv)
+    # the committed rocprofv3 summary of the same command agrees with the line's kernel durations (profiles/r06zf_bench_int4_b1_kernel_stats.csv)
     import csv
-    rows = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r06ze_bench_int4_b1_kernel_stats.csv")))}
+    rows = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r06zf_bench_int4_b1_kernel_stats.csv")))}
     blk = [v for k, v in rows.items() if "decode_attn_block_kernel" in k][0]
     in_line = [r for r in (d["roofline"], _second(d)) if "decode_attn_block_kernel" in r["kernel"]][0]
     assert abs(blk - in_line["avg_kernel_us_rocprof"]) <= 0.05 * blk
