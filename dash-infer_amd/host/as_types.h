@@ -140,6 +140,7 @@ class DeviceContext {
   AsCacheMode GetCacheMode() const { return cache_mode_; }
   int GetModelMaxBatch() const { return max_batch_; }
   int GetModelMaxLength() const { return max_length_; }
+  int GetMaxTopLogprobs() const { return 10; }  // device_context.h:135,182 (engine_max_top_logprobs, const)
   int GetRank() const { return rank_; }
   int GetNranks() const { return nranks_; }
   void SetNumberHeads(int v) { num_heads_ = v; }
@@ -292,6 +293,19 @@ struct GenerateConfig {
   bool early_stopping = true;
   int eos_token_id = -1;
   std::vector<std::vector<int64_t>> stop_words_ids;
+  // the logits processors GenerateOp runs before sampling and its log-probability outputs (csrc/interface/allspark.h:122-146, defaults alike)
+  float repetition_penalty = 1.0f;
+  float presence_penalty = 0.f;
+  float frequency_penalty = 0.f;
+  bool suppress_repetition_in_generation = false;
+  int no_repeat_ngram_size = 0;
+  int min_length = 0;
+  bool logprobs = false;
+  int top_logprobs = 0;     // <= 10 (engine_max_top_logprobs, csrc/common/as_engine.h:232)
+  // anything but the neutral values: the request needs its token history on the device
+  bool has_logits_processors() const {
+    return repetition_penalty != 1.0f || presence_penalty != 0.f || frequency_penalty != 0.f || no_repeat_ngram_size != 0 || min_length > 0;
+  }
 };
 
 // csrc/common/request.h:25-40, the slice the id-processing operators touch: the request's input tensors, its intermediate
@@ -301,6 +315,9 @@ struct Request {
   std::string request_id;
   std::map<std::string, std::shared_ptr<class AsTensor>> inputs, interim;
   std::vector<int64_t> generated_ids_queue;
+  // request.h:37-39: per generated token, the top_logprobs (token, log-probability) pairs and the chosen token's log-probability
+  std::vector<std::vector<std::pair<int, float>>> log_probs_list;
+  std::vector<float> token_logprobs_list;
   std::mutex queue_mu;
   bool finish = false;
   void enqueue(int64_t t) {
@@ -317,6 +334,10 @@ struct GenerateContext {
   unsigned long long sample_calls = 0;   // draws taken so far (the per-request random stream's position)
   // generate_context.h:32-55: what UpdateIdOp / PreProcessIdOp read
   int in_length_bias = 0;
+  int input_len = 0;                     // generate_context.h:45: prompt length (the logits processors' "generated" tokens start here)
+  // model-runner path (device-resident step state): the request's token history [max_length] INT64 and its log-probability records
+  // [max_length][1 + 2 * 10] on the device, written by the step itself (csrc/logits_proc.hip: the rows / records forms)
+  std::shared_ptr<class AsTensor> history_dev, logprob_records_dev;
   bool finish = false;
   int generate_method = 0;               // sample = 0 (beam search = 1 is refused, generate_op.cpp:655-660)
   bool gen_over[1] = {false};

@@ -24,6 +24,7 @@
 // Activation layouts between two fused operators (row-major / DIHIP_ACT_FRAG32) are negotiated through HIPContext: the consumer
 // advertises its GEMM shape for the tensor at Init, the producer decides at Reshape when the row count is known
 // (decoder.DecodeSession: ops.prefers_frag).
+#include <cstdio>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -1011,7 +1012,16 @@ class DihipGreedyOp : public AsOperator {
     seq_ = 1;
     auto ids = tensor_map_->find(hip_ctx(ctx_).InputIdsName());  // (the runner names the graph's id tensor: a converter export need not call it "input_ids")
     if (rt && rt->is_context && ids != tensor_map_->end() && ids->second->GetShape().size() >= 2) seq_ = std::max(1, (int)ids->second->GetShape()[1]);
-    if (rt && rt->GetGenCtxListSize() > 0) AS_CHECK_STATUS(params_.Gather(rt, rows_, stream_of(ctx_)));
+    if (rt && rt->GetGenCtxListSize() > 0) {
+      AS_CHECK_STATUS(params_.Gather(rt, rows_, stream_of(ctx_)));
+      // logits processors / log-probabilities over the requests' DEVICE-resident histories and records (rows form: the step replays)
+      std::string why;
+      const AsStatus st = proc_.Gather(rt, rows_, vocab_, ctx_->GetModelMaxLength(), true, stream_of(ctx_), &why);
+      if (st != AsStatus::ALLSPARK_SUCCESS) {
+        std::fprintf(stderr, "[dashinfer_hip] DihipGreedy: %s\n", why.c_str());
+        return st;
+      }
+    }
     AsTensor* y = tensor_map_->at(out_names_[0]).get();
     y->SetDataType(INT64);
     AS_CHECK_STATUS(y->SetShape(Shape{rows_, 1}));
@@ -1039,28 +1049,44 @@ class DihipGreedyOp : public AsOperator {
       AS_CHECK_STATUS(FromDihip(dihip_cast_to_f32(s, (float*)f32_->GetDataPtr(), last, (size_t)rows * vocab_, DihipDtype(x->GetDataType()))));
       logits = (const float*)f32_->GetDataPtr();
     }
-    if (params_.any_sampling()) {
-      // position of the sampled token = tokens in the sequence after this step: new_seq_lens on the device, else staged
-      const uint32_t* pos = cb;
-      if (!on_dev) {
-        AS_CHECK_STATUS(params_.StagePositions(rt, rt->is_context ? seq_ : 1, s));
-        pos = params_.dev_pos();
+    const bool extras = proc_.any_processors() || proc_.any_logprobs();
+    if (extras && !on_dev && !rt->is_context) {
+      std::fprintf(stderr, "[dashinfer_hip] DihipGreedy: logits processors / logprobs in the decoder phase need the device-resident step state\n");
+      return AsStatus::ALLSPARK_INVALID_CALL_ERROR;
+    }
+    if (proc_.any_processors()) {
+      // decoder: the step's input id (this operator's own output tensor, which the runner binds as the graph's ids) joins the history at
+      // position new_len - 1 and cur_len is the device's new length; context: the history holds the prompt, cur_len = its length
+      if (on_dev) {
+        AS_CHECK_STATUS(proc_.RunRows(const_cast<float*>(logits), (const int64_t*)y->GetDataPtr(), cb, s));
+      } else {
+        AS_CHECK_STATUS(proc_.StageCurLen(seq_, s));
+        AS_CHECK_STATUS(proc_.RunRows(const_cast<float*>(logits), nullptr, nullptr, s));
       }
-      return FromDihip(dihip_sample_rows(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, params_.top_k(), params_.top_p(),
-                                         params_.temperature(), params_.seed(), pos, ca, cb, params_.wide_rows()));
     }
-    if (on_dev) {
-      auto o = tensor_map_->find("dihip.old_seq_lens"), n = tensor_map_->find("dihip.new_seq_lens");
-      return FromDihip(dihip_argmax_advance(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, ws_->GetDataPtr(),
-                                            ws_->GetSizeInByte(), (uint32_t*)o->second->GetDataPtr(), (uint32_t*)n->second->GetDataPtr()));
+    const uint32_t* pos = cb;  // position of the sampled token = tokens in the sequence after this step: new_seq_lens on the device, else staged
+    if (!on_dev && (params_.any_sampling() || proc_.any_logprobs())) {
+      AS_CHECK_STATUS(params_.StagePositions(rt, rt->is_context ? seq_ : 1, s));
+      pos = params_.dev_pos();
     }
-    return FromDihip(dihip_argmax(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, ws_->GetDataPtr(), ws_->GetSizeInByte()));
+    if (params_.any_sampling()) {
+      AS_CHECK_STATUS(FromDihip(dihip_sample_rows(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, params_.top_k(), params_.top_p(),
+                                                  params_.temperature(), params_.seed(), pos, ca, cb, params_.wide_rows())));
+    } else if (on_dev) {
+      AS_CHECK_STATUS(FromDihip(dihip_argmax_advance(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, ws_->GetDataPtr(), ws_->GetSizeInByte(), ca, cb)));
+    } else {
+      AS_CHECK_STATUS(FromDihip(dihip_argmax(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, ws_->GetDataPtr(), ws_->GetSizeInByte())));
+    }
+    // record index = the sampled token's index in the sequence: the advanced length - 1 on the device, the staged position otherwise
+    if (proc_.any_logprobs()) AS_CHECK_STATUS(proc_.LogprobsRows(logits, (const int64_t*)y->GetDataPtr(), pos, on_dev ? -1 : 0, s));
+    return AsStatus::ALLSPARK_SUCCESS;
   }
 
  private:
   int rows_ = 0, vocab_ = 0, seq_ = 1;
   std::unique_ptr<AsTensor> ws_, f32_;
   SamplingParams params_;
+  LogitsProcParams proc_;
 };
 REGISTER_OP(DihipGreedy, HIP, DihipGreedyOp)
 

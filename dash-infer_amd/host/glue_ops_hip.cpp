@@ -16,6 +16,7 @@
 // (include/dashinfer_hip.h section 5) on the context's stream.  The decode step of the product (decoder.py, bench.py)
 // never runs these as separate launches -- they ride in GEMV prologues / epilogues there; this file is the drop-in
 // surface for the reference's own graph.
+#include <cstdio>
 #include <algorithm>
 #include <cmath>
 
@@ -338,7 +339,16 @@ class GenerateOpHIP : public AsOperator {
     AsTensor* y = tensor_map_->at(out_names_[0]).get();
     y->SetDataType(INT64);
     AS_CHECK_STATUS(y->SetShape(Shape{rows_, 1}));
-    if (rt && rt->GetGenCtxListSize() > 0) AS_CHECK_STATUS(params_.Gather(rt, rows_, stream_of(ctx_)));
+    if (rt && rt->GetGenCtxListSize() > 0) {
+      AS_CHECK_STATUS(params_.Gather(rt, rows_, stream_of(ctx_)));
+      // the logits processors before sampling and the log-probabilities after it (generate_op.cpp:536-538, :600-606): staged form
+      std::string why;
+      const AsStatus st = proc_.Gather(rt, rows_, vocab_, ctx_->GetModelMaxLength(), false, stream_of(ctx_), &why);
+      if (st != AsStatus::ALLSPARK_SUCCESS) {
+        std::fprintf(stderr, "[dashinfer_hip] GenerateOp: %s\n", why.c_str());
+        return st;
+      }
+    }
     // scratch: f32 copy of FT logits + the arg-max partials (64 pairs per row)
     const int64_t need = (x->GetDataType() == FLOAT32 ? 0 : (int64_t)rows_ * vocab_ * 4) + (int64_t)rows_ * 64 * 8 + 256;
     AsTensor* wsp = tensor_map_->at("workspace").get();
@@ -362,17 +372,31 @@ class GenerateOpHIP : public AsOperator {
       logits = (const float*)ws;
       off = ((size_t)rows_ * vocab_ * 4 + 255) & ~(size_t)255;
     }
-    if (rt && rt->GetGenCtxListSize() > 0 && params_.any_sampling()) {
-      AS_CHECK_STATUS(params_.StagePositions(rt, rt->is_context ? seq_ : 1, s));
-      return FromDihip(dihip_sample_rows(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, params_.top_k(), params_.top_p(), params_.temperature(),
-                                         params_.seed(), params_.dev_pos(), nullptr, nullptr, params_.wide_rows()));
+    const bool have_rt = rt && rt->GetGenCtxListSize() > 0;
+    if (have_rt && proc_.any_processors()) {  // in place on the scores, as the reference does (generate_impl_gpu.hpp:105-109)
+      std::string why;
+      const AsStatus st = proc_.StageHistory(rt, s, &why);
+      if (st != AsStatus::ALLSPARK_SUCCESS) {
+        std::fprintf(stderr, "[dashinfer_hip] GenerateOp: %s\n", why.c_str());
+        return st;
+      }
+      AS_CHECK_STATUS(proc_.RunStaged(const_cast<float*>(logits), s));
     }
-    return FromDihip(dihip_argmax(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, ws + off, wsp->GetSizeInByte() - off));
+    if (have_rt && params_.any_sampling()) {
+      AS_CHECK_STATUS(params_.StagePositions(rt, rt->is_context ? seq_ : 1, s));
+      AS_CHECK_STATUS(FromDihip(dihip_sample_rows(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, params_.top_k(), params_.top_p(),
+                                                  params_.temperature(), params_.seed(), params_.dev_pos(), nullptr, nullptr, params_.wide_rows())));
+    } else {
+      AS_CHECK_STATUS(FromDihip(dihip_argmax(s, (int64_t*)y->GetDataPtr(), logits, rows_, vocab_, ws + off, wsp->GetSizeInByte() - off)));
+    }
+    if (have_rt && proc_.any_logprobs()) return proc_.LogprobsStaged(rt, logits, (const int64_t*)y->GetDataPtr(), ctx_->GetRank() == 0, s);
+    return AsStatus::ALLSPARK_SUCCESS;
   }
 
  private:
   int rows_ = 0, vocab_ = 0, seq_ = 1;
   SamplingParams params_;
+  LogitsProcParams proc_;
 };
 REGISTER_OP(GenerateOp, HIP, GenerateOpHIP)
 

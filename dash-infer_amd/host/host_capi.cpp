@@ -73,6 +73,8 @@ struct dihost_model {
   std::vector<OperatorProto> graph;          // dihost_graph_add_op
   std::unique_ptr<HipModelRunner> runner;    // dihost_graph_build
   std::string text;
+  GenerateConfig next_gen;                   // dihost_next_request_generation
+  bool has_next_gen = false;
 };
 static thread_local std::string g_err;
 
@@ -474,6 +476,19 @@ static std::shared_ptr<GenerateContext> make_request(dihost_model_t m, int step,
   gc->gen_cfg.top_p = top_p;
   gc->gen_cfg.temperature = temperature;
   gc->gen_cfg.seed = seed;
+  if (m->has_next_gen) {  // dihost_next_request_generation: the rest of the generation config, for this request only
+    const GenerateConfig& n = m->next_gen;
+    gc->gen_cfg.repetition_penalty = n.repetition_penalty;
+    gc->gen_cfg.frequency_penalty = n.frequency_penalty;
+    gc->gen_cfg.presence_penalty = n.presence_penalty;
+    gc->gen_cfg.no_repeat_ngram_size = n.no_repeat_ngram_size;
+    gc->gen_cfg.min_length = n.min_length;
+    gc->gen_cfg.eos_token_id = n.eos_token_id;
+    gc->gen_cfg.suppress_repetition_in_generation = n.suppress_repetition_in_generation;
+    gc->gen_cfg.logprobs = n.logprobs;
+    gc->gen_cfg.top_logprobs = n.top_logprobs;
+    m->has_next_gen = false;
+  }
   std::vector<std::vector<void*>> ks(n_layers), vs(n_layers);
   for (int l = 0; l < n_layers; ++l)
     for (int i = 0; i < spans_per_req; ++i) {
@@ -483,6 +498,84 @@ static std::shared_ptr<GenerateContext> make_request(dihost_model_t m, int step,
   gc->virtual_k_cache = std::make_shared<ListVirtualCache>(std::move(ks), m->ctx.GetCacheSpanSize(), (size_t)cached_len);
   gc->virtual_v_cache = std::make_shared<ListVirtualCache>(std::move(vs), m->ctx.GetCacheSpanSize(), (size_t)cached_len);
   return gc;
+}
+static void fill_generation(GenerateConfig& g, float repetition_penalty, float frequency_penalty, float presence_penalty, int no_repeat_ngram_size,
+                            int min_length, int eos_token_id, int suppress_repetition_in_generation, int logprobs, int top_logprobs) {
+  g.repetition_penalty = repetition_penalty;
+  g.frequency_penalty = frequency_penalty;
+  g.presence_penalty = presence_penalty;
+  g.no_repeat_ngram_size = no_repeat_ngram_size;
+  g.min_length = min_length;
+  g.eos_token_id = eos_token_id;
+  g.suppress_repetition_in_generation = suppress_repetition_in_generation != 0;
+  g.logprobs = logprobs != 0;
+  g.top_logprobs = top_logprobs;
+}
+// The part of GenerateConfig (csrc/interface/allspark.h:112-146) GenerateOp's logits processors and log-probability outputs read, for the
+// NEXT request started through dihost_request_start (then forgotten) ...
+int dihost_next_request_generation(dihost_model_t m, float repetition_penalty, float frequency_penalty, float presence_penalty,
+                                   int no_repeat_ngram_size, int min_length, int eos_token_id, int suppress_repetition_in_generation, int logprobs,
+                                   int top_logprobs) {
+  if (!m) return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  fill_generation(m->next_gen, repetition_penalty, frequency_penalty, presence_penalty, no_repeat_ngram_size, min_length, eos_token_id,
+                  suppress_repetition_in_generation, logprobs, top_logprobs);
+  m->has_next_gen = true;
+  return 0;
+}
+// ... and for request `index` of the runtime context set by dihost_set_runtime (operator-by-operator use); input_len: its prompt length
+int dihost_request_generation(dihost_model_t m, int index, float repetition_penalty, float frequency_penalty, float presence_penalty,
+                              int no_repeat_ngram_size, int min_length, int eos_token_id, int suppress_repetition_in_generation, int logprobs,
+                              int top_logprobs, int input_len) {
+  if (!m || index < 0 || index >= (int)m->rt.gen_ctx_list.size()) return (int)AsStatus::ALLSPARK_PARAM_ERROR;
+  fill_generation(m->rt.gen_ctx_list[index]->gen_cfg, repetition_penalty, frequency_penalty, presence_penalty, no_repeat_ngram_size, min_length,
+                  eos_token_id, suppress_repetition_in_generation, logprobs, top_logprobs);
+  m->rt.gen_ctx_list[index]->input_len = input_len;
+  return 0;
+}
+// Log-probabilities of a request: `count` records starting at record `first` -> token_logprob [count], top_value / top_index [count, top_n]
+// (top_n <= 10).  runner != 0: request `index` of the model runner's running batch, records indexed by the token's POSITION in the sequence
+// (the first generated token of an L-token prompt is record L), read from the request's device-resident log after a stream synchronise;
+// runner == 0: request `index` of the runtime context, records in generation order (Request::log_probs_list / token_logprobs_list).
+// -> records copied, or a negative AsStatus.
+int dihost_request_logprobs(dihost_model_t m, int index, int runner, int first, int count, int top_n, float* token_logprob, float* top_value,
+                            int* top_index) {
+  if (!m || first < 0 || count < 0 || top_n < 0 || top_n > 10) return -(int)AsStatus::ALLSPARK_PARAM_ERROR;
+  const int S = m->ctx.GetMaxTopLogprobs();
+  if (runner) {
+    if (!m->runner || index < 0 || index >= (int)m->runner->running().size()) return -(int)AsStatus::ALLSPARK_PARAM_ERROR;
+    auto& gc = m->runner->running()[index];
+    if (!gc->logprob_records_dev) return -(int)AsStatus::ALLSPARK_INVALID_CALL_ERROR;
+    const int words = 1 + 2 * S;
+    const int64_t have = gc->logprob_records_dev->Count() / words;
+    const int n = (int)std::max<int64_t>(0, std::min<int64_t>(count, have - first));
+    std::vector<float> rec((size_t)n * words);
+    if (hipStreamSynchronize(m->ctx.GetStream()) != hipSuccess ||
+        (n > 0 && hipMemcpy(rec.data(), (const float*)gc->logprob_records_dev->GetDataPtr() + (size_t)first * words, rec.size() * sizeof(float),
+                            hipMemcpyDeviceToHost) != hipSuccess))
+      return -(int)AsStatus::ALLSPARK_RUNTIME_ERROR;
+    for (int i = 0; i < n; ++i) {
+      const float* r = rec.data() + (size_t)i * words;
+      if (token_logprob) token_logprob[i] = r[0];
+      for (int k = 0; k < top_n; ++k) {
+        if (top_value) top_value[(size_t)i * top_n + k] = r[1 + k];
+        if (top_index) std::memcpy(&top_index[(size_t)i * top_n + k], &r[1 + S + k], sizeof(int));
+      }
+    }
+    return n;
+  }
+  if (index < 0 || index >= (int)m->rt.gen_ctx_list.size() || !m->rt.gen_ctx_list[index]->request) return -(int)AsStatus::ALLSPARK_PARAM_ERROR;
+  Request& rq = *m->rt.gen_ctx_list[index]->request;
+  std::lock_guard<std::mutex> g(rq.queue_mu);
+  const int n = std::max(0, std::min(count, (int)rq.token_logprobs_list.size() - first));
+  for (int i = 0; i < n; ++i) {
+    if (token_logprob) token_logprob[i] = rq.token_logprobs_list[first + i];
+    const auto& top = rq.log_probs_list[first + i];
+    for (int k = 0; k < top_n; ++k) {
+      if (top_value) top_value[(size_t)i * top_n + k] = k < (int)top.size() ? top[k].second : -std::numeric_limits<float>::infinity();
+      if (top_index) top_index[(size_t)i * top_n + k] = k < (int)top.size() ? top[k].first : -1;
+    }
+  }
+  return n;
 }
 int dihost_request_start(dihost_model_t m, const int64_t* prompt_host, int len, int prefix_len, int top_k, float top_p, float temperature,
                          unsigned long long seed, int n_layers, int spans_per_req, void* const* k_spans, void* const* v_spans,

@@ -122,6 +122,21 @@ AsStatus HipModelRunner::StartRequest(std::shared_ptr<GenerateContext> gc, const
       hipEventRecord(staged_, s) != hipSuccess)
     return Fail(AsStatus::ALLSPARK_RUNTIME_ERROR, "prompt upload");
   gc->step = gc->prefix_len;  // model.cpp:532
+  gc->input_len = len;
+  // requests with logits processors / logprobs carry their token history and log-probability records on the device (the step appends
+  // to both itself: csrc/logits_proc.hip, rows / records forms).  The history starts as the prompt.
+  if (gc->gen_cfg.has_logits_processors()) {
+    if (gc->prefix_len != 0) return Fail(AsStatus::ALLSPARK_PARAM_ERROR, "StartRequest: logits processors over a cached prefix (the prefix's ids are not part of this prompt)");
+    gc->history_dev = std::make_shared<AsTensor>("history", DeviceType::HIP, INT64, Shape{(int64_t)std::max(ctx_->GetModelMaxLength(), len + 1)});
+    if (!gc->history_dev->GetDataPtr() ||
+        hipMemcpyAsync(gc->history_dev->GetDataPtr(), prompt_dev_->GetDataPtr(), (size_t)len * sizeof(int64_t), hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return Fail(AsStatus::ALLSPARK_MEMORY_ERROR, "StartRequest: token history");
+  }
+  if (gc->gen_cfg.logprobs) {
+    const int64_t words = (int64_t)std::max(ctx_->GetModelMaxLength(), len + 1) * (1 + 2 * ctx_->GetMaxTopLogprobs());
+    gc->logprob_records_dev = std::make_shared<AsTensor>("logprob_records", DeviceType::HIP, FLOAT32, Shape{words});
+    if (!gc->logprob_records_dev->GetDataPtr()) return Fail(AsStatus::ALLSPARK_MEMORY_ERROR, "StartRequest: log-probability records");
+  }
   RuntimeContext rt;
   rt.is_context = true;
   rt.current_batch = 0;

@@ -45,6 +45,9 @@ _SIGS = {
     "dihost_request_set_step": (i32, [vp, i32, i32, i32]),
     "dihost_set_phase": (i32, [vp, i32]),
     "dihost_request_poll": (i32, [vp, i32, C.POINTER(C.c_int64), i32, C.POINTER(i32), C.POINTER(i32)]),
+    "dihost_next_request_generation": (i32, [vp, C.c_float, C.c_float, C.c_float, i32, i32, i32, i32, i32, i32]),
+    "dihost_request_generation": (i32, [vp, i32, C.c_float, C.c_float, C.c_float, i32, i32, i32, i32, i32, i32, i32]),
+    "dihost_request_logprobs": (i32, [vp, i32, i32, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i32)]),
     "dihost_running_batch": (i32, [vp]),
     "dihost_requests_rewind": (i32, [vp, i32]),
     "dihost_last_error": (C.c_char_p, []),
@@ -250,6 +253,32 @@ class Model:
         if n < 0:
             raise HostError(-n, "request_poll")
         return [int(buf[i]) for i in range(n)], bool(fin.value), ni.value
+
+    # ---- GenerateOp's logits processors and log-probability outputs ---------------------------------------------------------
+    @staticmethod
+    def _gen(g):
+        return (float(g.get("repetition_penalty", 1.0)), float(g.get("frequency_penalty", 0.0)), float(g.get("presence_penalty", 0.0)),
+                int(g.get("no_repeat_ngram_size", 0)), int(g.get("min_length", 0)), int(g.get("eos_token_id", -1)),
+                int(bool(g.get("suppress_repetition_in_generation", False))), int(bool(g.get("logprobs", False))), int(g.get("top_logprobs", 0)))
+
+    def next_request_generation(self, **g):
+        """GenerateConfig's processor / logprobs fields for the NEXT request_start (model-runner path)."""
+        _ck(lib().dihost_next_request_generation(self.h, *self._gen(g)), "next_request_generation")
+
+    def request_generation(self, index, input_len, **g):
+        """... for request `index` of the runtime context (operator-by-operator path)."""
+        _ck(lib().dihost_request_generation(self.h, index, *self._gen(g), int(input_len)), "request_generation")
+
+    def request_logprobs(self, index, first, count, top_n, runner=True):
+        """-> (token_logprob [n], top_value [n, top_n], top_index [n, top_n]) as lists."""
+        tok = (C.c_float * max(count, 1))()
+        val = (C.c_float * max(count * top_n, 1))()
+        idx = (i32 * max(count * top_n, 1))()
+        n = lib().dihost_request_logprobs(self.h, index, int(runner), first, count, top_n, tok, val, idx)
+        if n < 0:
+            raise HostError(-n, "request_logprobs")
+        return ([tok[i] for i in range(n)], [[val[i * top_n + k] for k in range(top_n)] for i in range(n)],
+                [[idx[i * top_n + k] for k in range(top_n)] for i in range(n)])
 
     def set_phase(self, is_context):
         _ck(lib().dihost_set_phase(self.h, int(is_context)), "set_phase")

@@ -630,3 +630,39 @@ def sample(logits, top_k, top_p, temperature, seed, position=None, advance=(), w
     check(lib().dihip_sample(cur_stream(), ptr(ids), ptr(logits), M, N, ptr(tk), ptr(tp), ptr(tt), ptr(sd), ptr(position), ptr(a), ptr(b),
                              ptr(probs), ptr(cand)), "dihip_sample")
     return (ids, probs, cand) if want_probs else ids
+
+
+def logits_processor_(logits, ids, cur_len, input_len, repetition_penalty=None, frequency_penalty=None, presence_penalty=None,
+                      no_repeat_ngram_size=None, min_length=None, eos_token_id=None, suppress_repetition_in_generation=None, ws=None):
+    """GenerateOp's logits processors, in place on f32 logits [M, N] (dihip_logits_processor; cuda::LogitsProcessor,
+    csrc/core/kernel/cuda/beam_search.cu:456-539).  ids: int64 [M, max_len] device tensor; the per-request lists are python lists or
+    tensors of length M (None: the processor's neutral value)."""
+    M, N = logits.shape
+    dev = logits.device
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and ids.dtype == torch.int64 and ids.is_contiguous() and ids.shape[0] == M
+
+    def lst(v, dt, default):
+        return torch.as_tensor([default] * M if v is None else v, dtype=dt).to(dev)
+    cl, il = lst(cur_len, torch.int32, 0), lst(input_len, torch.int32, 0)
+    rp, fq, pr = lst(repetition_penalty, torch.float32, 1.0), lst(frequency_penalty, torch.float32, 0.0), lst(presence_penalty, torch.float32, 0.0)
+    ng, ml, eos = lst(no_repeat_ngram_size, torch.int32, 0), lst(min_length, torch.int32, 0), lst(eos_token_id, torch.int32, -1)
+    sup = lst(suppress_repetition_in_generation, torch.int32, 0)
+    need = lib().dihip_logits_processor_workspace_bytes(M, N)
+    if ws is None:
+        ws = torch.empty(max(need, 4), dtype=torch.uint8, device=dev)
+    check(lib().dihip_logits_processor(cur_stream(), ptr(logits), M, N, ptr(ids), ids.shape[1], ptr(cl), ptr(il), ptr(rp), ptr(fq), ptr(pr), ptr(ng),
+                                       ptr(ml), ptr(eos), ptr(sup), ptr(ws), ws.numel()), "dihip_logits_processor")
+    return logits
+
+
+def logprobs(logits, chosen=None, top_n=0):
+    """GenerateOp's log-probability outputs (dihip_logprobs; generate_impl_gpu.hpp:33-80): -> (token_logprob [M] or None, top values
+    [M, top_n] f32, top indices [M, top_n] i32)."""
+    M, N = logits.shape
+    dev = logits.device
+    assert logits.dtype == torch.float32 and logits.is_contiguous()
+    tok = torch.empty(M, dtype=torch.float32, device=dev) if chosen is not None else None
+    tv = torch.empty(M, max(top_n, 1), dtype=torch.float32, device=dev)
+    ti = torch.empty(M, max(top_n, 1), dtype=torch.int32, device=dev)
+    check(lib().dihip_logprobs(cur_stream(), ptr(logits), M, N, ptr(chosen), top_n, max(top_n, 1), ptr(tok), ptr(tv), ptr(ti)), "dihip_logprobs")
+    return tok, tv[:, :top_n], ti[:, :top_n]

@@ -535,6 +535,40 @@ int dihip_sample(void* stream, int64_t* ids, const float* logits, int M, int N, 
 int dihip_sample_rows(void* stream, int64_t* ids, const float* logits, int M, int N, const int* top_k, const float* top_p,
                       const float* temperature, const unsigned long long* seed, const uint32_t* position, uint32_t* counters_a,
                       uint32_t* counters_b, int wide_rows);
+/* The logits processors GenerateOp runs BEFORE sampling (generate_op.cpp:536-538 -> generate_impl_gpu.hpp:94-111 -> cuda::LogitsProcessor,
+ * csrc/core/kernel/cuda/beam_search.cu:456-539), in place on f32 logits [M, N], per request m with the BatchGencfg lists of
+ * generate_op.cpp:239-312 as device arrays [M]: repetition penalty over the distinct tokens of ids[m, lo .. cur_len) (lo = input_len when
+ * suppress_repetition_in_generation, else 0; s < 0 ? s * p : s / p), frequency / presence penalty over the generated tokens
+ * ids[m, input_len .. cur_len) (s -= count * frequency + (count > 0 ? presence : 0)), no-repeat n-gram and minimum length (s = -1e9).
+ * ids: INT64 [M, max_len] (the reference's max_dec_ids).  ONE launch driven by the requests' tokens: O(cur_len) logits touched, no copy
+ * of the scores and no memset of the count array (ws: dihip_logits_processor_workspace_bytes(M, N), scratch without state between
+ * calls).  Bit-identical to LogitsProcessor<float> evaluated without contraction (oracle/logits_proc.py). */
+size_t dihip_logits_processor_workspace_bytes(int M, int N);
+int dihip_logits_processor(void* stream, float* logits, int M, int N, const int64_t* ids, int max_len, const int* cur_len,
+                           const int* input_len, const float* repetition_penalty, const float* frequency_penalty,
+                           const float* presence_penalty, const int* no_repeat_ngram_size, const int* min_length,
+                           const int* eos_token_id, const int* suppress_repetition_in_generation, void* ws, size_t ws_bytes);
+/* the same over DEVICE-RESIDENT histories, for a decode step that replays as a hipGraph: history_rows [M] device pointers to the requests'
+ * own id buffers of max_len entries (a null row: that request asked for nothing); append_ids (may be NULL): the step's input id of every
+ * request, written to history[cur_len - 1] before the processors read it -- the history grows on the device, the host sends nothing per step
+ * (the reference copies every request's generated_ids_gpu into max_dec_ids each step: fill_max_dec_ids_gpu, generate_impl_gpu.hpp:270-304). */
+int dihip_logits_processor_rows(void* stream, float* logits, int M, int N, int64_t* const* history_rows, const int64_t* append_ids,
+                                int max_len, const int* cur_len, const int* input_len, const float* repetition_penalty,
+                                const float* frequency_penalty, const float* presence_penalty, const int* no_repeat_ngram_size,
+                                const int* min_length, const int* eos_token_id, const int* suppress_repetition_in_generation, void* ws,
+                                size_t ws_bytes);
+/* Log-probabilities AFTER sampling (generate_op.cpp:600-606 -> generate_impl_gpu.hpp:33-80 logprobs_gpu: log-softmax of the processed logits,
+ * SelectBatchTokenLogprob csrc/core/kernel/cuda/logprob.cu:15-35, top-k of the log-probabilities): token_logprob[m] = log-softmax(logits[m])
+ * [chosen[m]] (either may be NULL), top_value / top_index [M, out_stride]: the top_n <= 32 largest log-probabilities and their tokens
+ * (value descending, lower index first on ties; -inf / -1 beyond the row's length).  One launch; the [M, N] log-probability tensor the
+ * reference materialises is never written. */
+int dihip_logprobs(void* stream, const float* logits, int M, int N, const int64_t* chosen, int top_n, int out_stride,
+                   float* token_logprob, float* top_value, int* top_index);
+/* the same into per-request device-resident logs (graph replay: nothing returns to the host per step): row m writes the record
+ * {token_logprob, top values [out_stride], top indices [out_stride] (int32)} = 1 + 2 * out_stride words at
+ * records[m] + (position[m] + position_bias) * (1 + 2 * out_stride); a null records[m] or a position outside [0, max_records): skipped. */
+int dihip_logprobs_records(void* stream, const float* logits, int M, int N, const int64_t* chosen, int top_n, int out_stride,
+                           float* const* records, const uint32_t* position, int position_bias, int max_records);
 /* vocabulary-parallel greedy sampling for TP: one {f32 value, i32 global index} pair per row
  * from this rank's logits slice [M, N] (global index = local + index_offset); after an
  * all-gather of the pairs ([nparts][M]) every rank merges them to the same ids.                */

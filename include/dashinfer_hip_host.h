@@ -110,6 +110,23 @@ int dihost_request_put_token(dihost_model_t m, int index, int position, int64_t 
 int dihost_request_set_step(dihost_model_t m, int index, int step, int in_length_bias);
 int dihost_set_phase(dihost_model_t m, int is_context);
 int dihost_request_poll(dihost_model_t m, int index, int64_t* tokens, int capacity, int* finish, int* n_interim);
+/* GenerateOp's logits processors and log-probability outputs (generate_op.cpp:239-312 build_batch_gencfg, :536-538, :600-650; the
+ * GenerateConfig fields of csrc/interface/allspark.h:122-146: neutral values 1 / 0 / 0 / 0 / 0 / - / 0 / 0 / 0).
+ *   next_request_generation: for the NEXT request started through dihost_request_start -- the model runner gives it a device-resident token
+ *     history (the prompt; every step appends its input id) and, with logprobs, a device-resident record log: the step still replays as a graph;
+ *   request_generation:      for request `index` of the runtime context (operator-by-operator use: GenerateOp stages the request's host
+ *     "generated_ids" every Forward, as the reference's fill_max_dec_ids copies generated_ids_gpu); input_len = its prompt length;
+ *   request_logprobs:        `count` records from `first` -> token_logprob [count], top_value / top_index [count, top_n] (top_n <= 10).  runner != 0:
+ *     the running batch's request `index`, records indexed by the token's POSITION in its sequence (first generated token of an L-token prompt:
+ *     record L); runner == 0: the runtime context's request, records in generation order.  -> records copied, or a negative AsStatus. */
+int dihost_next_request_generation(dihost_model_t m, float repetition_penalty, float frequency_penalty, float presence_penalty,
+                                   int no_repeat_ngram_size, int min_length, int eos_token_id, int suppress_repetition_in_generation,
+                                   int logprobs, int top_logprobs);
+int dihost_request_generation(dihost_model_t m, int index, float repetition_penalty, float frequency_penalty, float presence_penalty,
+                              int no_repeat_ngram_size, int min_length, int eos_token_id, int suppress_repetition_in_generation, int logprobs,
+                              int top_logprobs, int input_len);
+int dihost_request_logprobs(dihost_model_t m, int index, int runner, int first, int count, int top_n, float* token_logprob,
+                            float* top_value, int* top_index);
 int dihost_running_batch(dihost_model_t m);
 /* benchmarks: every running request (and its cache) back to cached_len tokens; spans, shapes and the captured step are kept */
 int dihost_requests_rewind(dihost_model_t m, int cached_len);
