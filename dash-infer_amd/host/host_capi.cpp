@@ -202,10 +202,9 @@ int dihost_weights_load_file(dihost_model_t m, const char* path, int* count) {
   std::vector<int64_t> shape;
   int n = 0;
   for (const WeightRecord& r : recs) {
-    stage.resize((size_t)r.nbytes);
-    if (std::fseek(fp, (long)r.offset, SEEK_SET) != 0 || std::fread(stage.data(), 1, stage.size(), fp) != stage.size()) {
+    if (!ReadRecordDense(fp, r, &stage, &err)) {  // (CSC / ELL records densified: weight_file.h)
       std::fclose(fp);
-      g_err = "weight file: cannot read " + r.name;
+      g_err = "weight file: " + err;
       return (int)AsStatus::ALLSPARK_IO_ERROR;
     }
     if (!SliceForRank(r, stage.data(), rank, nranks, &share, &shape, &err)) {
@@ -245,11 +244,14 @@ int dihost_weight_file_slice(const char* path, const char* name, int rank, int n
     if (r.name != name) continue;
     FILE* fp = std::fopen(path, "rb");
     if (!fp) return (int)AsStatus::ALLSPARK_IO_ERROR;
-    std::vector<char> stage((size_t)r.nbytes), share;
+    std::vector<char> stage, share;
     std::vector<int64_t> shape;
-    const bool ok = std::fseek(fp, (long)r.offset, SEEK_SET) == 0 && std::fread(stage.data(), 1, stage.size(), fp) == stage.size();
+    const bool ok = ReadRecordDense(fp, r, &stage, &err);
     std::fclose(fp);
-    if (!ok) return (int)AsStatus::ALLSPARK_IO_ERROR;
+    if (!ok) {
+      g_err = "weight file: " + err;
+      return (int)AsStatus::ALLSPARK_IO_ERROR;
+    }
     if (!SliceForRank(r, stage.data(), rank, std::max(1, nranks), &share, &shape, &err)) {
       g_err = "weight file: " + err;
       return (int)AsStatus::ALLSPARK_PARAM_ERROR;

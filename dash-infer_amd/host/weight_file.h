@@ -4,7 +4,12 @@
 //   record*   "AS" | u16 0x0001 | u16 name length | name | header | data
 //             header = one text line  {'descr': '<f4', 'fortran_order': False, 'shape': (K, N),'group_list': (),'sparse_type': 0,'nnz': 0,'split_type': 1,}\n
 //                      (create_allsparky_header, :107-146: byte order, type letter, word size; shape; SplitMode of the TP splitter)
-//             data   = prod(shape) * word size bytes, little endian, row-major           (dense records; the sparse encodings are refused)
+//             data   = prod(shape) * word size bytes, little endian, row-major           (dense records)
+//                      sparse_type 1 (CSC, allsparkz_util.cpp:162-203): col_offset int32 [cols + 1] | row_idx int32 [nnz] | values [nnz]
+//                      sparse_type 2 (ELL, :205-254):                   row_idx uint16 [nnz] | values [nnz], nnz = cols * max_c, laid out in
+//                                    blocks of VECT = 16 / word entries per column (sparse_util.cpp:91-131)
+//                      both for 2-D f32 / f16 matrices; DENSIFIED on the way in (ReadRecordDense): this backend has no sparse GEMM, the
+//                      operators see the dense matrix the converter started from
 //   end       "AS" | u16 0 | u16 0                                                        (set_global_header, :331-339)
 //
 // The reference's reader is WeightFileParser (csrc/runtime/weight/weight_loader.cpp:20-130: the same letter / word-size -> DataType
@@ -29,9 +34,11 @@ struct WeightRecord {
   std::vector<int64_t> shape;
   int split_mode = 0;    // allspark.proto SplitMode of the tensor-parallel splitter (NOSPLIT 0, VSPLIT 1, HSPLIT 2, ...)
   std::vector<int64_t> group_list;  // GROUP_VSPLIT: widths of the column groups (qkv: [n H, g H, g H]; halved by the converter for packed int4)
-  int sparse_type = 0;
+  int sparse_type = 0;   // 0 dense, 1 CSC, 2 ELL
+  long long nnz = 0;     // stored entries of a sparse record (padding included)
   long long offset = 0;  // of the data in the file
-  long long nbytes = 0;
+  long long nbytes = 0;  // of the DENSE tensor
+  long long stored_bytes = 0;  // of the record's data in the file (== nbytes for a dense record)
 };
 
 namespace weight_file_detail {
@@ -125,22 +132,87 @@ inline bool IndexWeightFile(const std::string& path, std::vector<WeightRecord>* 
     };
     ints(shape, &r.shape);
     if (r.shape.empty()) return fail(r.name + ": no shape");
+    if (field(h, "sparse_type", &sparse)) r.sparse_type = std::atoi(sparse.c_str());
     long long count = 1;
-    for (int64_t d : r.shape) {  // (a malformed shape must not wrap the byte count)
-      if (d < 0 || (d > 0 && count > (long long)(file_size / (d * (long long)word)) + 1)) return fail(r.name + ": shape larger than the file");
+    // (a malformed shape must not wrap the byte count.)  A dense record cannot be larger than the file; a sparse one is stored
+    // compressed, so its dense size is bounded by a fixed 64 GiB instead
+    const long long dense_limit = r.sparse_type == 0 ? file_size : (1ll << 36);
+    for (int64_t d : r.shape) {
+      if (d < 0 || (d > 0 && count > (long long)(dense_limit / (d * (long long)word)) + 1)) return fail(r.name + ": shape larger than the file");
       count *= d;
     }
-    if (field(h, "sparse_type", &sparse)) r.sparse_type = std::atoi(sparse.c_str());
     if (field(h, "split_type", &split)) r.split_mode = std::atoi(split.c_str());
     if (field(h, "group_list", &groups)) ints(groups, &r.group_list);
-    if (r.sparse_type != 0) return fail(r.name + ": sparse encodings (CSC / ELL) are not served by this backend");
     r.nbytes = count * word;
+    r.stored_bytes = r.nbytes;
+    if (r.sparse_type != 0) {
+      std::string nnz;
+      if (r.sparse_type != 1 && r.sparse_type != 2) return fail(r.name + ": unknown sparse_type " + std::to_string(r.sparse_type));
+      if (r.shape.size() != 2 || (r.dtype != FLOAT32 && r.dtype != FLOAT16)) return fail(r.name + ": a sparse record that is not a 2-D f32 / f16 matrix");
+      if (!field(h, "nnz", &nnz)) return fail(r.name + ": sparse record without nnz");
+      r.nnz = std::atoll(nnz.c_str());
+      if (r.nnz < 0 || r.nnz > file_size) return fail(r.name + ": nnz larger than the file");
+      if (r.sparse_type == 2 && (r.shape[1] == 0 || r.nnz % r.shape[1] != 0 || (r.nnz / r.shape[1]) % (16 / word) != 0 || r.shape[0] > 65536))
+        return fail(r.name + ": malformed ELL record (nnz must be cols x a multiple of 16 / word size, at most 65536 rows)");
+      r.stored_bytes = r.sparse_type == 1 ? (r.shape[1] + 1) * 4 + r.nnz * (4 + word) : r.nnz * (2 + word);
+    }
     r.offset = std::ftell(fp);
-    if (r.offset < 0 || r.offset + r.nbytes > file_size) return fail("truncated data of " + r.name);  // EVERY record against the file's size
-    if (std::fseek(fp, (long)(r.offset + r.nbytes), SEEK_SET) != 0) return fail("truncated data of " + r.name);
+    if (r.offset < 0 || r.offset + r.stored_bytes > file_size) return fail("truncated data of " + r.name);  // EVERY record against the file's size
+    if (std::fseek(fp, (long)(r.offset + r.stored_bytes), SEEK_SET) != 0) return fail("truncated data of " + r.name);
     out->push_back(std::move(r));
   }
   std::fclose(fp);
+  return true;
+}
+
+// reads record `r` of an open file as the DENSE row-major tensor (r.nbytes bytes): dense records as stored; CSC / ELL records scattered
+// back into the matrix the reference's writer compressed (dense_to_csc_padding / dense_to_ell_padding, sparse_util.cpp:23-131).  The
+// writers pad columns with ZERO-valued entries whose row index repeats the last real one (ELL: whatever was in the buffer), so entries
+// ADD into a zeroed matrix and an entry outside it is an error only when its value is not zero.
+inline bool ReadRecordDense(FILE* fp, const WeightRecord& r, std::vector<char>* dense, std::string* err) {
+  auto fail = [&](const std::string& what) {
+    *err = r.name + ": " + what;
+    return false;
+  };
+  std::vector<char> stored((size_t)r.stored_bytes);
+  if (std::fseek(fp, (long)r.offset, SEEK_SET) != 0 || (!stored.empty() && std::fread(stored.data(), 1, stored.size(), fp) != stored.size()))
+    return fail("cannot read the record");
+  if (r.sparse_type == 0) {
+    dense->swap(stored);
+    return true;
+  }
+  const int64_t rows = r.shape[0], cols = r.shape[1];
+  const size_t word = (size_t)SizeofType(r.dtype);
+  dense->assign((size_t)r.nbytes, 0);
+  auto put = [&](int64_t row, int64_t col, const char* v) {  // dense[row, col] = v unless v is +0 / -0 (padding)
+    bool zero = true;
+    for (size_t b = 0; b < word; ++b) zero = zero && (v[b] == 0 || (b == word - 1 && (unsigned char)v[b] == 0x80));
+    if (zero) return true;
+    if (row < 0 || row >= rows || col < 0 || col >= cols) return false;
+    std::memcpy(dense->data() + ((size_t)row * cols + col) * word, v, word);
+    return true;
+  };
+  if (r.sparse_type == 1) {  // CSC: col_offset [cols + 1] | row_idx [nnz] | values [nnz]
+    const int32_t* off = reinterpret_cast<const int32_t*>(stored.data());
+    const int32_t* ridx = off + cols + 1;
+    const char* val = reinterpret_cast<const char*>(ridx + r.nnz);
+    if (off[0] != 0 || off[cols] != r.nnz) return fail("CSC column offsets do not span nnz");
+    for (int64_t c = 0; c < cols; ++c) {
+      if (off[c + 1] < off[c]) return fail("CSC column offsets decrease");
+      for (int64_t e = off[c]; e < off[c + 1]; ++e)
+        if (!put(ridx[e], c, val + (size_t)e * word)) return fail("CSC entry outside the matrix");
+    }
+    return true;
+  }
+  // ELL: blocks of VECT entries per column: for b in [0, max_c / VECT): for col: VECT entries (sparse_util.cpp:119-130)
+  const int64_t vect = 16 / (int64_t)word, max_c = cols ? r.nnz / cols : 0;
+  const uint16_t* ridx = reinterpret_cast<const uint16_t*>(stored.data());
+  const char* val = reinterpret_cast<const char*>(ridx + r.nnz);
+  int64_t pos = 0;
+  for (int64_t b = 0; b < max_c / vect; ++b)
+    for (int64_t c = 0; c < cols; ++c)
+      for (int64_t k = 0; k < vect; ++k, ++pos)
+        if (!put(ridx[pos], c, val + (size_t)pos * word)) return fail("ELL entry outside the matrix");
   return true;
 }
 

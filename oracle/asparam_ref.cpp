@@ -47,6 +47,25 @@ int ref_asparam_append_groups(const char* path, const char* name, const void* da
   return 0;
 }
 
+// a 2-D f32 matrix through the writer's SPARSE encodings (sparse_type 1 = CSC, 2 = ELL: save_allsparky, allsparkz_util.cpp:162-254, over
+// dense_to_csc_padding / dense_to_ell_padding of sparse_util.cpp); -> the nnz the writer stored, or -1
+int ref_asparam_append_sparse(const char* path, const char* name, const void* data, int64_t nbytes, char dtype_char, int word_size, const int* shape,
+                              int ndim, int split_mode, int sparse_type) {
+  allspark::TensorAttribute info;
+  info.sparse_type = sparse_type;
+  info.split_mode = split_mode;
+  info.shape.assign(shape, shape + ndim);
+  info.dtype = dtype_char;
+  info.word_size = word_size;
+  info.nnz = 0;
+  try {
+    allspark::util::save_allsparky_tofile(path, name, const_cast<void*>(data), nbytes, info);
+  } catch (...) {
+    return -1;
+  }
+  return info.nnz;
+}
+
 int ref_asparam_finish(const char* path) {
   try {
     allspark::util::set_global_header(path);

@@ -25,6 +25,8 @@ def ref_writer():
     lib.ref_asparam_append.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_char, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
     lib.ref_asparam_append_groups.restype = C.c_int
     lib.ref_asparam_append_groups.argtypes = lib.ref_asparam_append.argtypes + [C.POINTER(C.c_int), C.c_int]
+    lib.ref_asparam_append_sparse.restype = C.c_int
+    lib.ref_asparam_append_sparse.argtypes = lib.ref_asparam_append.argtypes + [C.c_int]
     lib.ref_asparam_finish.restype = C.c_int
     lib.ref_asparam_finish.argtypes = [C.c_char_p]
     return lib
@@ -38,17 +40,20 @@ def descr(a, bf16=False):
 
 
 def write(path, records):
-    """records: [(name, array, split_mode, bf16?[, group_list])]"""
+    """records: [(name, array, split_mode, bf16?[, group_list])]; a group_list entry "csc" / "ell" instead: the writer's sparse encoding"""
     lib = ref_writer()
     if os.path.exists(path):
         os.remove(path)
     for rec in records:
         name, a, split, bf16 = rec[:4]
-        groups = list(rec[4]) if len(rec) > 4 else []
+        sparse = {"csc": 1, "ell": 2}.get(rec[4], 0) if len(rec) > 4 and isinstance(rec[4], str) else 0
+        groups = list(rec[4]) if len(rec) > 4 and not sparse else []
         a = np.ascontiguousarray(a)
         letter, word = descr(a, bf16)
         shape = (C.c_int * a.ndim)(*a.shape)
-        if groups:
+        if sparse:
+            assert lib.ref_asparam_append_sparse(path.encode(), name.encode(), a.ctypes.data, a.nbytes, letter, word, shape, a.ndim, split, sparse) >= 0
+        elif groups:
             gl = (C.c_int * len(groups))(*groups)
             assert lib.ref_asparam_append_groups(path.encode(), name.encode(), a.ctypes.data, a.nbytes, letter, word, shape, a.ndim, split, gl,
                                                  len(groups)) == 0
@@ -129,6 +134,27 @@ def tiny_model(seed=5):
     return recs
 
 
+def sparse_model(seed=3):
+    """Two 2-D f32 matrices for the writer's sparse encodings (CSC / ELL): ~85 % zeros, an empty column, a full column, every non-zero well above
+    the writers' 1e-9 threshold; and one dense record behind them (the index must step over the compressed data).  [(name, array, split, bf16, enc)]"""
+    rng = np.random.default_rng(seed)
+    def mat(rows, cols):
+        a = rng.normal(0, 1, (rows, cols)).astype(np.float32)
+        a[np.abs(a) < 1e-3] = 0.5
+        a[rng.random((rows, cols)) < 0.85] = 0.0
+        a[:, 3] = 0.0
+        a[:, 5] = rng.normal(0, 1, rows).astype(np.float32) + 3.0
+        return a
+    return [("sparse.csc", mat(48, 24), NOSPLIT, False, "csc"), ("sparse.ell", mat(40, 16), NOSPLIT, False, "ell"),
+            ("sparse.csc.vsplit", mat(16, 32), VSPLIT, False, "csc"), ("dense.after", np.arange(10, dtype=np.float32).reshape(2, 5), NOSPLIT, False)]
+
+
+def main_sparse():
+    path = os.path.join(OUT, "tiny_sparse.asparam")
+    write(path, sparse_model())
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def main_tp():
     path = os.path.join(OUT, "tiny_qwen2_a16w4_tp.asparam")
     write(path, tp_model())
@@ -145,3 +171,4 @@ def main():
 if __name__ == "__main__":
     main()
     main_tp()
+    main_sparse()
