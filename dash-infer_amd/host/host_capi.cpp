@@ -157,6 +157,10 @@ int dihost_get_weight(dihost_model_t m, const char* name, int* dtype, int* ndim,
   if (shape8)
     for (size_t i = 0; i < t.GetShape().size() && i < 8; ++i) shape8[i] = t.GetShape()[i];
   if (data) *data = t.GetDataPtr();
+  if (!t.GetDataPtr() && t.Count() > 0) {  // (a released weight must not look like an empty one)
+    g_err = std::string("weight ") + name + " was released after its operator re-laid it out (InitV2): type and shape are still valid, the data is gone";
+    return (int)AsStatus::ALLSPARK_INVALID_CALL_ERROR;
+  }
   return 0;
 }
 // the records of a serialized weight file (.asparam, host/weight_file.h) as text, one per line: name|dtype|d0,d1,...|split_mode|offset|nbytes

@@ -37,7 +37,8 @@ int dihost_set_weight(dihost_model_t m, const char* name, int dtype, int ndim, c
  *           EPSPLIT; host/weight_file.h SliceForRank): ONE export of the whole model feeds any tensor-parallel degree that divides it;
  *   _slice: the same share of ONE record on the host (no GPU, no model; data == NULL: *nbytes / shape only) -- what _load_file uploads for
  *           (rank, nranks);
- *   dihost_get_weight: a weight's type / shape / device pointer (tests). */
+ *   dihost_get_weight: a weight's type / shape / device pointer (tests); ALLSPARK_INVALID_CALL_ERROR (type and shape filled, *data NULL) for a weight
+ *           whose operator released the source after re-laying it out. */
 int dihost_weight_file_index(const char* path, char* out, size_t cap, size_t* need);
 int dihost_weights_load_file(dihost_model_t m, const char* path, int* count);
 int dihost_weight_file_slice(const char* path, const char* name, int rank, int nranks, void* data, size_t capacity, size_t* nbytes,

@@ -557,6 +557,15 @@ def test_weights_from_a_serialized_file(env):
             ref_graph.add_graph(m, ref_graph.qwen2_graph(1, 4, 128, 1e-6, n, g, 1e6))
             rep = m.graph_build(fuse=True)
             assert rep["fused"], rep["why"]
+            if from_file:   # the operators released the sources they re-laid out: get_weight says so instead of handing out a null pointer as data
+                released = 0
+                for name, *_ in recs:
+                    try:
+                        m.get_weight(name)
+                    except hostapi.HostError as e:
+                        assert e.code == 8 and "released" in str(e), str(e)
+                        released += 1
+                assert released >= 4
             ks = [[pool.alloc()[0] for _ in range(max_len // span)]]
             vs = [[pool.alloc()[0] for _ in range(max_len // span)]]
             prompt = [int(t) for t in np.random.default_rng(2).integers(0, vocab, 21)]
