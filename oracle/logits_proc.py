@@ -11,9 +11,12 @@ Restates, for T = float:
   * logprobs_gpu, csrc/core/operator/generate_opt/generate/generate_impl_gpu.hpp:33-80: log-softmax of the row, the chosen token's
     value (SelectBatchTokenLogprob, kernel/cuda/logprob.cu:15-35), the top_logprobs largest values with their indices.
 
-PARITY: pinned on the reference's kernels by reading (the CUDA sources do not compile here: no nvcc; their x86 counterpart
-cpu::LogitsProcessor, kernel/cpu/beam_search.cpp:343-392, takes ONE GenerateConfig for the batch and has no frequency penalty, so it is
-not the path the serving engine's GPU build runs).  The loops below are the kernels' bodies with `tid` iterated on the host.
+PARITY: the processors are PINNED on the reference's own device code -- cuda::LogitsProcessor<float> and its kernels sliced from beam_search.cu where
+it lies and compiled for gfx950 (oracle/logits_ref.hip, oracle/Makefile `reflogits`): tests/test_gpu_logits_ref.py holds this restatement and the
+product equal to them bit for bit.  (Their x86 counterpart cpu::LogitsProcessor, kernel/cpu/beam_search.cpp:343-392, takes ONE GenerateConfig for the
+batch and has no frequency penalty: not the path the serving engine's GPU build runs.)  The log-probability half is restated from the source and
+checked as mathematics (float64 log-softmax, 2e-5): "parity unpinned" for that half.  The loops below are the kernels' bodies with `tid` iterated
+on the host.
 """
 import numpy as np
 
