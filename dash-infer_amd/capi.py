@@ -113,9 +113,10 @@ _SIGS = {
     "dihip_sample_rows": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32]),
     "dihip_logits_processor_workspace_bytes": (sz, [i32, i32]),
     "dihip_logits_processor": (i32, [vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz]),
-    "dihip_logprobs": (i32, [vp, vp, i32, i32, vp, i32, i32, vp, vp, vp]),
+    "dihip_logprobs_workspace_bytes": (sz, [i32, i32, i32]),
+    "dihip_logprobs": (i32, [vp, vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, sz]),
     "dihip_logits_processor_rows": (i32, [vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz]),
-    "dihip_logprobs_records": (i32, [vp, vp, i32, i32, vp, i32, i32, vp, vp, i32, i32]),
+    "dihip_logprobs_records": (i32, [vp, vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, vp, sz]),
     "dihip_argmax_partial": (i32, [vp, vp, vp, i32, i32, i32, vp, sz]),
     "dihip_argmax_merge": (i32, [vp, vp, vp, i32, i32]),
     "dihip_embedding": (i32, [vp, vp, vp, vp, i32, i32, i32]),

@@ -182,6 +182,11 @@ class LogitsProcParams {
         }
       }
     }
+    if (any_lp_) {
+      const int64_t wb = (int64_t)std::max<size_t>(dihip_logprobs_workspace_bytes(rows, vocab, top_n_), 8);
+      if (!lp_ws_ || (int64_t)lp_ws_->GetSizeInByte() < wb) lp_ws_ = std::make_unique<AsTensor>("logits_proc.logprobs_ws", DeviceType::HIP, INT64, Shape{(wb + 7) / 8});
+      if (!lp_ws_->GetDataPtr()) return AsStatus::ALLSPARK_MEMORY_ERROR;
+    }
     if (any_lp_ && !rows_form) {
       const int64_t ob = (int64_t)rows * kRecordWords * 4;
       if (!out_ || (int64_t)out_->GetSizeInByte() < ob) {
@@ -234,12 +239,14 @@ class LogitsProcParams {
                                                  count_->GetSizeInByte()));
   }
   AsStatus LogprobsRows(const float* logits, const int64_t* chosen, const uint32_t* position, int bias, hipStream_t s) {
-    return FromDihip(dihip_logprobs_records(s, logits, rows_, vocab_, chosen, top_n_, kStride, (float* const*)D<void*>(H<void*>(1)), position, bias, max_len_));
+    return FromDihip(dihip_logprobs_records(s, logits, rows_, vocab_, chosen, top_n_, kStride, (float* const*)D<void*>(H<void*>(1)), position, bias, max_len_,
+                                            lp_ws_->GetDataPtr(), lp_ws_->GetSizeInByte()));
   }
   // staged form: compute, fetch, and append to the requests' lists as UpdateProbs does (generate_op.cpp:36-57; rank 0 only)
   AsStatus LogprobsStaged(const RuntimeContext* rt, const float* logits, const int64_t* chosen, bool publish, hipStream_t s) {
     float* o = (float*)out_->GetDataPtr();
-    AS_CHECK_STATUS(FromDihip(dihip_logprobs(s, logits, rows_, vocab_, chosen, top_n_, kStride, o, o + rows_, (int*)(o + rows_ + (size_t)rows_ * kStride))));
+    AS_CHECK_STATUS(FromDihip(dihip_logprobs(s, logits, rows_, vocab_, chosen, top_n_, kStride, o, o + rows_, (int*)(o + rows_ + (size_t)rows_ * kStride),
+                                             lp_ws_->GetDataPtr(), lp_ws_->GetSizeInByte())));
     if (hipMemcpyAsync(out_host_, o, (size_t)rows_ * kRecordWords * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
       return AsStatus::ALLSPARK_RUNTIME_ERROR;
     if (!publish) return AsStatus::ALLSPARK_SUCCESS;
@@ -279,7 +286,7 @@ class LogitsProcParams {
     return AsStatus::ALLSPARK_PARAM_ERROR;
   }
   char* host_ = nullptr;
-  std::unique_ptr<AsTensor> dev_, count_, hist_, out_;
+  std::unique_ptr<AsTensor> dev_, count_, hist_, out_, lp_ws_;
   int64_t* hist_host_ = nullptr;
   size_t hist_host_cap_ = 0;
   float* out_host_ = nullptr;

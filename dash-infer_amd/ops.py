@@ -664,5 +664,7 @@ def logprobs(logits, chosen=None, top_n=0):
     tok = torch.empty(M, dtype=torch.float32, device=dev) if chosen is not None else None
     tv = torch.empty(M, max(top_n, 1), dtype=torch.float32, device=dev)
     ti = torch.empty(M, max(top_n, 1), dtype=torch.int32, device=dev)
-    check(lib().dihip_logprobs(cur_stream(), ptr(logits), M, N, ptr(chosen), top_n, max(top_n, 1), ptr(tok), ptr(tv), ptr(ti)), "dihip_logprobs")
+    ws = torch.empty(max(int(lib().dihip_logprobs_workspace_bytes(M, N, top_n)), 8), dtype=torch.uint8, device=dev)
+    check(lib().dihip_logprobs(cur_stream(), ptr(logits), M, N, ptr(chosen), top_n, max(top_n, 1), ptr(tok), ptr(tv), ptr(ti), ptr(ws), ws.numel()),
+          "dihip_logprobs")
     return tok, tv[:, :top_n], ti[:, :top_n]

@@ -560,15 +560,18 @@ int dihip_logits_processor_rows(void* stream, float* logits, int M, int N, int64
 /* Log-probabilities AFTER sampling (generate_op.cpp:600-606 -> generate_impl_gpu.hpp:33-80 logprobs_gpu: log-softmax of the processed logits,
  * SelectBatchTokenLogprob csrc/core/kernel/cuda/logprob.cu:15-35, top-k of the log-probabilities): token_logprob[m] = log-softmax(logits[m])
  * [chosen[m]] (either may be NULL), top_value / top_index [M, out_stride]: the top_n <= 32 largest log-probabilities and their tokens
- * (value descending, lower index first on ties; -inf / -1 beyond the row's length).  One launch; the [M, N] log-probability tensor the
- * reference materialises is never written. */
+ * (value descending, lower index first on ties; -inf / -1 beyond the row's length).  Two launches that fill the chip at any batch (per-chunk
+ * maxima, sums and candidates in `ws`: dihip_logprobs_workspace_bytes(M, N, top_n), 8-byte aligned, no state between calls; then one merge per
+ * row); the [M, N] log-probability tensor the reference materialises is never written. */
+size_t dihip_logprobs_workspace_bytes(int M, int N, int top_n);
 int dihip_logprobs(void* stream, const float* logits, int M, int N, const int64_t* chosen, int top_n, int out_stride,
-                   float* token_logprob, float* top_value, int* top_index);
+                   float* token_logprob, float* top_value, int* top_index, void* ws, size_t ws_bytes);
 /* the same into per-request device-resident logs (graph replay: nothing returns to the host per step): row m writes the record
  * {token_logprob, top values [out_stride], top indices [out_stride] (int32)} = 1 + 2 * out_stride words at
  * records[m] + (position[m] + position_bias) * (1 + 2 * out_stride); a null records[m] or a position outside [0, max_records): skipped. */
 int dihip_logprobs_records(void* stream, const float* logits, int M, int N, const int64_t* chosen, int top_n, int out_stride,
-                           float* const* records, const uint32_t* position, int position_bias, int max_records);
+                           float* const* records, const uint32_t* position, int position_bias, int max_records, void* ws,
+                           size_t ws_bytes);
 /* vocabulary-parallel greedy sampling for TP: one {f32 value, i32 global index} pair per row
  * from this rank's logits slice [M, N] (global index = local + index_offset); after an
  * all-gather of the pairs ([nparts][M]) every rank merges them to the same ids.                */
