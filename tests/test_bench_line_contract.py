@@ -1,4 +1,4 @@
-"""The committed driver-style bench line (profiles/r06zg_bench_default.json: the stdout of `python bench.py --gpus 1 --steps 20 --warmup 5`, the
+"""The committed driver-style bench line (profiles/r06zi_bench_default.json: the stdout of `python bench.py --gpus 1 --steps 20 --warmup 5`, the
 driver's own command, on an MI355X) against the contract the driver reads: ONE JSON line under 4 KB with metric / value / unit / n_gpus / steps /
 warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, a `roofline` object for the TIME-dominant
 kernel (+ `roofline_gemv`), a `cpu_baseline` object -- and internally consistent numbers (value = batch / ms_per_step, roofline.frac = achieved /
@@ -17,7 +17,7 @@ def _line():
 
 
 def _stdout():
-    return open(os.path.join(ROOT, "profiles", "r06zg_bench_default.json")).read()
+    return open(os.path.join(ROOT, "profiles", "r06zi_bench_default.json")).read()
 
 
 def _headline():
