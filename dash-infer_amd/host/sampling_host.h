@@ -106,7 +106,10 @@ class LogitsProcParams {
   static constexpr int kStride = 10;                 // top_logprobs places per record (GetMaxTopLogprobs)
   static constexpr int kRecordWords = 1 + 2 * kStride;
   ~LogitsProcParams() {
+    if (staged_) (void)hipEventSynchronize(staged_);  // (a staging copy may still read the pinned blocks)
     if (host_) (void)hipHostFree(host_);
+    if (hist_host_) (void)hipHostFree(hist_host_);
+    if (out_host_) (void)hipHostFree(out_host_);
     if (staged_) (void)hipEventDestroy(staged_);
   }
   bool any_processors() const { return any_proc_; }
